@@ -1,0 +1,422 @@
+/* mrcal_amd: MI355X-native implementation of mrcal's optimize() /
+ * optimizer_callback() hot path. C ABI of libmrcal_amd.so.
+ *
+ * Two tiers of entry points:
+ *
+ * 1. DROP-IN TIER. Same names, argument order, argument meaning and error
+ *    behaviour as the functions the reference's Python wrapper (and any ctypes
+ *    harness) binds for this path. A process that dlopen()s libmrcal_amd.so
+ *    instead of libmrcal.so and calls these gets the GPU implementation. All
+ *    pointers are HOST pointers, the caller allocates every buffer, sizes are
+ *    in bytes where the reference says bytes. Each declaration cites the
+ *    reference interface it replaces (file:line in dkogan/mrcal).
+ *
+ * 2. RESIDENT TIER (mrcal_amd_*). The same computation with the problem held
+ *    in HBM across calls: create a problem once, then evaluate / step / solve
+ *    without any host<->device traffic beyond scalars. This is what the
+ *    benchmark and the multi-GPU driver use. No reference counterpart: the
+ *    reference has no device.
+ *
+ * No torch types, no C++ types: plain pointers and sizes only.
+ */
+#pragma once
+#include <stdint.h>
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Types. Binary-compatible with the reference's (types.h, basic-geometry.h) */
+/* ------------------------------------------------------------------------ */
+
+/* reference: types.h:105-127 (mrcal_lensmodel_type_t). Same numeric values */
+typedef enum
+{
+    MRCAL_LENSMODEL_INVALID               = -2,
+    MRCAL_LENSMODEL_INVALID_BADCONFIG     = -1,
+    MRCAL_LENSMODEL_INVALID_MISSINGCONFIG = -3,
+    MRCAL_LENSMODEL_INVALID_TYPE          = -4,
+    MRCAL_LENSMODEL_PINHOLE               = 0,
+    MRCAL_LENSMODEL_STEREOGRAPHIC         = 1,
+    MRCAL_LENSMODEL_LONLAT                = 2,
+    MRCAL_LENSMODEL_LATLON                = 3,
+    MRCAL_LENSMODEL_OPENCV4               = 4,
+    MRCAL_LENSMODEL_OPENCV5               = 5,
+    MRCAL_LENSMODEL_OPENCV8               = 6,
+    MRCAL_LENSMODEL_OPENCV12              = 7,
+    MRCAL_LENSMODEL_CAHVOR                = 8,
+    MRCAL_LENSMODEL_CAHVORE               = 9,
+    MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC = 10
+} mrcal_lensmodel_type_t;
+
+/* reference: types.h:131-145 (mrcal_lensmodel_t): 16 bytes, the
+   configuration union sits at offset 8 */
+typedef struct
+{
+    mrcal_lensmodel_type_t type;
+    union
+    {
+        struct { double   linearity;               } LENSMODEL_CAHVORE__config;
+        struct { uint16_t order, Nx, Ny, fov_x_deg; } LENSMODEL_SPLINED_STEREOGRAPHIC__config;
+    };
+} mrcal_lensmodel_t;
+
+/* reference: basic-geometry.h:60-91 */
+typedef union { struct { double x,y;   }; double xy[2];  } mrcal_point2_t;
+typedef union { struct { double x,y,z; }; double xyz[3]; } mrcal_point3_t;
+typedef struct { mrcal_point3_t r, t; }                    mrcal_pose_t;
+
+/* reference: types.h:139-148 */
+typedef union { struct { double x2, y2; }; double values[2]; } mrcal_calobject_warp_t;
+
+/* reference: types.h:195-263 */
+typedef struct { int intrinsics; int extrinsics; /* -1: at the reference */ } mrcal_camera_index_t;
+typedef struct { mrcal_camera_index_t icam; int iframe;  } mrcal_observation_board_t;
+typedef struct { mrcal_camera_index_t icam; int i_point; } mrcal_observation_point_t;
+typedef struct
+{
+    mrcal_camera_index_t icam;
+    bool                 last_in_set : 1;
+    bool                 outlier     : 1;
+    mrcal_point3_t       px; /* UNPROJECTED observation vector */
+} mrcal_observation_point_triangulated_t;
+
+/* reference: types.h:283-307. One byte, passed BY VALUE. Bit order matters */
+typedef struct
+{
+    bool do_optimize_intrinsics_core         : 1;
+    bool do_optimize_intrinsics_distortions  : 1;
+    bool do_optimize_extrinsics              : 1;
+    bool do_optimize_frames                  : 1;
+    bool do_optimize_calobject_warp          : 1;
+    bool do_apply_regularization             : 1;
+    bool do_apply_outlier_rejection          : 1;
+    bool do_apply_regularization_unity_cam01 : 1;
+} mrcal_problem_selections_t;
+
+/* reference: types.h:313-315 (empty in the reference, kept as a placeholder) */
+typedef struct { char _unused; } mrcal_problem_constants_t;
+
+/* reference: types.h:321-344 */
+typedef struct
+{
+    double rms_reproj_error__pixels; /* <0: failure */
+    int    Noutliers_board;
+    int    Noutliers_triangulated_point;
+} mrcal_stats_t;
+
+/* The slice of SuiteSparse's cholmod_sparse that the reference's callback
+   touches (mrcal.c:4461-4463: p, i, x only). Field order as in CHOLMOD so
+   that a caller holding a real cholmod_sparse can pass it as is. Jt is
+   (Nstate x Nmeasurements) compressed-column, i.e. J in CSR */
+struct cholmod_sparse_struct
+{
+    size_t nrow, ncol, nzmax;
+    void *p, *i, *nz, *x, *z;
+    int stype, itype, xtype, dtype, sorted, packed;
+};
+
+/* ------------------------------------------------------------------------ */
+/* DROP-IN TIER                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* reference: mrcal.c:165-253 / mrcal.h (lens model names) */
+bool        mrcal_lensmodel_from_name(mrcal_lensmodel_t* lensmodel, const char* name);
+bool        mrcal_lensmodel_name     (char* out, int size, const mrcal_lensmodel_t* lensmodel);
+/* reference: mrcal.c:303-335 */
+int         mrcal_lensmodel_num_params(const mrcal_lensmodel_t* lensmodel);
+
+/* reference: mrcal.h:374-375, mrcal.c:361-371 */
+int mrcal_num_intrinsics_optimization_params(mrcal_problem_selections_t problem_selections,
+                                             const mrcal_lensmodel_t* lensmodel);
+
+/* reference: mrcal.h:388-421, mrcal.c:3450-3735. In place on (Nstate,) */
+void mrcal_pack_solver_state_vector  (double* b,
+                                      int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                      int Nframes,
+                                      int Npoints, int Npoints_fixed, int Nobservations_board,
+                                      mrcal_problem_selections_t problem_selections,
+                                      const mrcal_lensmodel_t* lensmodel);
+void mrcal_unpack_solver_state_vector(double* b,
+                                      int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                      int Nframes,
+                                      int Npoints, int Npoints_fixed, int Nobservations_board,
+                                      mrcal_problem_selections_t problem_selections,
+                                      const mrcal_lensmodel_t* lensmodel);
+
+/* reference: mrcal.h:437-446, mrcal.c:3929-3969 */
+bool mrcal_corresponding_icam_extrinsics(int* icam_extrinsics,
+                                         int icam_intrinsics,
+                                         int Ncameras_intrinsics,
+                                         int Ncameras_extrinsics,
+                                         int Nobservations_board,
+                                         const mrcal_observation_board_t* observations_board,
+                                         int Nobservations_point,
+                                         const mrcal_observation_point_t* observations_point);
+
+/* reference: mrcal.h:453-521, mrcal.c:6179-6624. The whole solve: dog-leg
+   iterations + outlier rejection. In/out arrays are updated in place; new
+   outliers are marked by negating observations_board_pool[].z */
+mrcal_stats_t
+mrcal_optimize( double* b_packed, int buffer_size_b_packed,
+                double* x,        int buffer_size_x,
+                double*                 intrinsics,
+                mrcal_pose_t*           rt_cam_ref,
+                mrcal_pose_t*           rt_ref_frame,
+                mrcal_point3_t*         points,
+                mrcal_calobject_warp_t* calobject_warp,
+                int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                int Npoints, int Npoints_fixed,
+                const mrcal_observation_board_t* observations_board,
+                const mrcal_observation_point_t* observations_point,
+                int Nobservations_board,
+                int Nobservations_point,
+                const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                int Nobservations_point_triangulated,
+                mrcal_point3_t* observations_board_pool,
+                mrcal_point3_t* observations_point_pool,
+                const mrcal_lensmodel_t* lensmodel,
+                const int* imagersizes,
+                mrcal_problem_selections_t       problem_selections,
+                const mrcal_problem_constants_t* problem_constants,
+                double calibration_object_spacing,
+                int calibration_object_width_n,
+                int calibration_object_height_n,
+                bool verbose,
+                bool check_gradient);
+
+/* reference: mrcal.h:539-609, mrcal.c:5972-6177. One evaluation of the cost
+   function: b_packed, x and (if Jt != NULL) the CSR Jacobian: Jt->p
+   (int32[Nmeas+1]), Jt->i (int32[Nnz]), Jt->x (double[Nnz]) */
+bool mrcal_optimizer_callback(double* b_packed, int buffer_size_b_packed,
+                              double* x,        int buffer_size_x,
+                              struct cholmod_sparse_struct* Jt,
+                              const double*                 intrinsics,
+                              const mrcal_pose_t*           rt_cam_ref,
+                              const mrcal_pose_t*           rt_ref_frame,
+                              const mrcal_point3_t*         points,
+                              const mrcal_calobject_warp_t* calobject_warp,
+                              int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                              int Npoints, int Npoints_fixed,
+                              const mrcal_observation_board_t* observations_board,
+                              const mrcal_observation_point_t* observations_point,
+                              int Nobservations_board,
+                              int Nobservations_point,
+                              const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                              int Nobservations_point_triangulated,
+                              const mrcal_point3_t* observations_board_pool,
+                              const mrcal_point3_t* observations_point_pool,
+                              const mrcal_lensmodel_t* lensmodel,
+                              const int* imagersizes,
+                              mrcal_problem_selections_t       problem_selections,
+                              const mrcal_problem_constants_t* problem_constants,
+                              double calibration_object_spacing,
+                              int calibration_object_width_n,
+                              int calibration_object_height_n,
+                              bool verbose);
+
+/* reference: mrcal.h:713-853 (layout of the measurement and state vectors),
+   mrcal.c:337-735, 3737-3880 */
+int mrcal_measurement_index_boards(int i_observation_board,
+                                   int Nobservations_board, int Nobservations_point,
+                                   int calibration_object_width_n, int calibration_object_height_n);
+int mrcal_num_measurements_boards(int Nobservations_board,
+                                  int calibration_object_width_n, int calibration_object_height_n);
+int mrcal_measurement_index_points(int i_observation_point,
+                                   int Nobservations_board, int Nobservations_point,
+                                   int calibration_object_width_n, int calibration_object_height_n);
+int mrcal_num_measurements_points(int Nobservations_point);
+int mrcal_measurement_index_points_triangulated(int i_point_triangulated,
+                                                int Nobservations_board, int Nobservations_point,
+                                                const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                                                int Nobservations_point_triangulated,
+                                                int calibration_object_width_n, int calibration_object_height_n);
+int mrcal_num_measurements_points_triangulated(const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                                               int Nobservations_point_triangulated);
+int mrcal_num_measurements_points_triangulated_initial_Npoints(const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                                                               int Nobservations_point_triangulated,
+                                                               int Npoints);
+bool mrcal_decode_observation_indices_points_triangulated(int* iobservation0, int* iobservation1,
+                                                          int* iobservation_point0,
+                                                          int* Nobservations_this_point,
+                                                          int* Nmeasurements_this_point,
+                                                          int* ipoint,
+                                                          const int imeasurement,
+                                                          const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                                                          int Nobservations_point_triangulated);
+int mrcal_measurement_index_regularization(const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                                           int Nobservations_point_triangulated,
+                                           int calibration_object_width_n, int calibration_object_height_n,
+                                           int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                           int Nframes,
+                                           int Npoints, int Npoints_fixed, int Nobservations_board, int Nobservations_point,
+                                           mrcal_problem_selections_t problem_selections,
+                                           const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_measurements_regularization(int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                          int Nframes,
+                                          int Npoints, int Npoints_fixed, int Nobservations_board,
+                                          mrcal_problem_selections_t problem_selections,
+                                          const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_measurements(int Nobservations_board, int Nobservations_point,
+                           const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                           int Nobservations_point_triangulated,
+                           int calibration_object_width_n, int calibration_object_height_n,
+                           int Ncameras_intrinsics, int Ncameras_extrinsics,
+                           int Nframes,
+                           int Npoints, int Npoints_fixed,
+                           mrcal_problem_selections_t problem_selections,
+                           const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states(int Ncameras_intrinsics, int Ncameras_extrinsics,
+                     int Nframes,
+                     int Npoints, int Npoints_fixed, int Nobservations_board,
+                     mrcal_problem_selections_t problem_selections,
+                     const mrcal_lensmodel_t* lensmodel);
+int mrcal_state_index_intrinsics(int icam_intrinsics,
+                                 int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                 int Nframes,
+                                 int Npoints, int Npoints_fixed, int Nobservations_board,
+                                 mrcal_problem_selections_t problem_selections,
+                                 const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states_intrinsics(int Ncameras_intrinsics,
+                                mrcal_problem_selections_t problem_selections,
+                                const mrcal_lensmodel_t* lensmodel);
+int mrcal_state_index_extrinsics(int icam_extrinsics,
+                                 int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                 int Nframes,
+                                 int Npoints, int Npoints_fixed, int Nobservations_board,
+                                 mrcal_problem_selections_t problem_selections,
+                                 const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states_extrinsics(int Ncameras_extrinsics,
+                                mrcal_problem_selections_t problem_selections);
+int mrcal_state_index_frames(int iframe,
+                             int Ncameras_intrinsics, int Ncameras_extrinsics,
+                             int Nframes,
+                             int Npoints, int Npoints_fixed, int Nobservations_board,
+                             mrcal_problem_selections_t problem_selections,
+                             const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states_frames(int Nframes,
+                            mrcal_problem_selections_t problem_selections);
+int mrcal_state_index_points(int i_point,
+                             int Ncameras_intrinsics, int Ncameras_extrinsics,
+                             int Nframes,
+                             int Npoints, int Npoints_fixed, int Nobservations_board,
+                             mrcal_problem_selections_t problem_selections,
+                             const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states_points(int Npoints, int Npoints_fixed,
+                            mrcal_problem_selections_t problem_selections);
+int mrcal_state_index_calobject_warp(int Ncameras_intrinsics, int Ncameras_extrinsics,
+                                     int Nframes,
+                                     int Npoints, int Npoints_fixed, int Nobservations_board,
+                                     mrcal_problem_selections_t problem_selections,
+                                     const mrcal_lensmodel_t* lensmodel);
+int mrcal_num_states_calobject_warp(mrcal_problem_selections_t problem_selections,
+                                    int Nobservations_board);
+
+/* reference: internal.h:99-114, mrcal.c:743-882 */
+int _mrcal_num_j_nonzero(int Nobservations_board,
+                         int Nobservations_point,
+                         const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                         int Nobservations_point_triangulated,
+                         int calibration_object_width_n,
+                         int calibration_object_height_n,
+                         int Ncameras_intrinsics, int Ncameras_extrinsics,
+                         int Nframes,
+                         int Npoints, int Npoints_fixed,
+                         const mrcal_observation_board_t* observations_board,
+                         const mrcal_observation_point_t* observations_point,
+                         mrcal_problem_selections_t problem_selections,
+                         const mrcal_lensmodel_t* lensmodel);
+
+/* ------------------------------------------------------------------------ */
+/* RESIDENT TIER                                                             */
+/* ------------------------------------------------------------------------ */
+
+/* Returns NULL-terminated static string describing the last error on this
+   thread ("" if none) */
+const char* mrcal_amd_last_error(void);
+
+/* Number of visible HIP devices; <=0 if there is no usable GPU */
+int mrcal_amd_device_count(void);
+
+typedef struct mrcal_amd_problem mrcal_amd_problem_t;
+
+/* Uploads a whole optimization problem (same arguments as
+   mrcal_optimizer_callback(), host pointers) to the current HIP device and
+   builds the iteration-invariant structure (state/measurement layout, CSR
+   rowptr/colidx) there. Returns NULL on error.
+
+   shard_begin_frame/shard_end_frame select a contiguous range of FRAMES whose
+   board observations this problem instance owns (multi-GPU sharding by
+   frame, one process per GPU); pass 0,-1 for "everything". All ranks still
+   see the full state vector; only the measurements are partitioned.
+   is_shard_leader says whether this instance owns the rows that belong to no
+   frame (discrete points, triangulated points, regularization). */
+mrcal_amd_problem_t*
+mrcal_amd_problem_create(const double*                 intrinsics,
+                         const mrcal_pose_t*           rt_cam_ref,
+                         const mrcal_pose_t*           rt_ref_frame,
+                         const mrcal_point3_t*         points,
+                         const mrcal_calobject_warp_t* calobject_warp,
+                         int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                         int Npoints, int Npoints_fixed,
+                         const mrcal_observation_board_t* observations_board,
+                         const mrcal_observation_point_t* observations_point,
+                         int Nobservations_board,
+                         int Nobservations_point,
+                         const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                         int Nobservations_point_triangulated,
+                         const mrcal_point3_t* observations_board_pool,
+                         const mrcal_point3_t* observations_point_pool,
+                         const mrcal_lensmodel_t* lensmodel,
+                         const int* imagersizes,
+                         mrcal_problem_selections_t problem_selections,
+                         double calibration_object_spacing,
+                         int calibration_object_width_n,
+                         int calibration_object_height_n,
+                         int shard_begin_frame, int shard_end_frame,
+                         bool is_shard_leader);
+void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem);
+
+/* sizes of the LOCAL (this shard's) problem */
+int     mrcal_amd_problem_Nstate       (const mrcal_amd_problem_t* problem);
+int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* problem);
+int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* problem);
+
+/* Device pointers into the problem's resident buffers (valid until destroy):
+   the packed state the next evaluation uses, and the outputs of the last
+   evaluation. J is CSR: rowptr int32[Nmeas+1], colidx int32[Nnz], values
+   double[Nnz], exactly the arrays mrcal_optimizer_callback() fills */
+double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* problem);
+double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* problem);
+int32_t* mrcal_amd_problem_dev_J_rowptr(mrcal_amd_problem_t* problem);
+int32_t* mrcal_amd_problem_dev_J_colidx(mrcal_amd_problem_t* problem);
+double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* problem);
+
+/* host <-> device copies of the packed state */
+bool mrcal_amd_problem_set_b_packed(mrcal_amd_problem_t* problem, const double* b_packed_host);
+bool mrcal_amd_problem_get_b_packed(mrcal_amd_problem_t* problem, double* b_packed_host);
+bool mrcal_amd_problem_get_x       (mrcal_amd_problem_t* problem, double* x_host);
+/* any of the three may be NULL */
+bool mrcal_amd_problem_get_J       (mrcal_amd_problem_t* problem,
+                                    int32_t* rowptr_host, int32_t* colidx_host, double* values_host);
+
+/* One evaluation of x (and J if with_jacobian) at the resident packed state.
+   Asynchronous on the problem's stream unless sync. This is the Jacobian
+   build the roofline is quoted on */
+bool mrcal_amd_problem_evaluate(mrcal_amd_problem_t* problem, bool with_jacobian, bool sync);
+
+/* The HIP stream (hipStream_t, as void*) all of this problem's kernels are
+   launched on, so that callers can bracket them with their own events */
+void* mrcal_amd_problem_stream(mrcal_amd_problem_t* problem);
+
+/* Timing of the most recent evaluation's dominant kernel (the board
+   Jacobian build), measured with HIP events on the problem's stream.
+   Returns milliseconds, <0 if unavailable */
+double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* problem);
+
+#ifdef __cplusplus
+}
+#endif

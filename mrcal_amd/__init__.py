@@ -1,0 +1,66 @@
+"""mrcal_amd: MI355X-native implementation of mrcal's optimize() /
+optimizer_callback() hot path.
+
+    import mrcal_amd as mrcal
+    stats          = mrcal.optimize(**optimization_inputs)
+    b, x, J, fact  = mrcal.optimizer_callback(**optimization_inputs)
+    i              = mrcal.state_index_frames(3, **optimization_inputs)
+
+The names, keyword arguments and return values are those of the reference's
+mrcal._mrcal module for this path (mrcal-pywrap.c:4501-4546). All of the compute
+happens in mrcal_amd/libmrcal_amd.so (HIP, gfx950); there is NO CPU fallback:
+without the library the import fails, without a GPU the compute entry points
+raise.
+"""
+import os as _os
+
+from ._cabi import MrcalLib as _MrcalLib
+from ._api  import Api as _Api, optimization_inputs_known_keys as _optimization_inputs_known_keys
+
+_libpath = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmrcal_amd.so")
+if not _os.path.exists(_libpath):
+    raise ImportError(
+        f"{_libpath} is missing. Build it with mrcal_amd/csrc/build.sh (or "
+        "python -c 'import __graft_entry__ as g; g.build()' at the repo root). "
+        "mrcal_amd has no CPU fallback")
+
+_lib = _MrcalLib(_libpath)
+_api = _Api(_lib)
+
+optimize                              = _api.optimize
+optimizer_callback                    = _api.optimizer_callback
+state_index_intrinsics                = _api.state_index_intrinsics
+state_index_extrinsics                = _api.state_index_extrinsics
+state_index_frames                    = _api.state_index_frames
+state_index_points                    = _api.state_index_points
+state_index_calobject_warp            = _api.state_index_calobject_warp
+num_states                            = _api.num_states
+num_states_intrinsics                 = _api.num_states_intrinsics
+num_states_extrinsics                 = _api.num_states_extrinsics
+num_states_frames                     = _api.num_states_frames
+num_states_points                     = _api.num_states_points
+num_states_calobject_warp             = _api.num_states_calobject_warp
+num_intrinsics_optimization_params    = _api.num_intrinsics_optimization_params
+measurement_index_boards              = _api.measurement_index_boards
+measurement_index_points              = _api.measurement_index_points
+measurement_index_points_triangulated = _api.measurement_index_points_triangulated
+measurement_index_regularization      = _api.measurement_index_regularization
+num_measurements                      = _api.num_measurements
+num_measurements_boards               = _api.num_measurements_boards
+num_measurements_points               = _api.num_measurements_points
+num_measurements_points_triangulated  = _api.num_measurements_points_triangulated
+num_measurements_regularization       = _api.num_measurements_regularization
+corresponding_icam_extrinsics         = _api.corresponding_icam_extrinsics
+pack_state                            = _api.pack_state
+unpack_state                          = _api.unpack_state
+lensmodel_num_params                  = _api.lensmodel_num_params
+
+from ._factorization import CHOLMOD_factorization
+
+
+def gpu_available():
+    """True if a HIP device is visible to libmrcal_amd.so"""
+    import ctypes
+    f = _lib.lib.mrcal_amd_device_count
+    f.restype = ctypes.c_int
+    return f() > 0

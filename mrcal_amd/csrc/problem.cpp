@@ -1,0 +1,507 @@
+// The resident problem object and the compute half of the C ABI.
+//
+// mrcal_amd_problem_t owns every HBM buffer of one calibration problem (or of
+// one frame-shard of it) and the HIP stream its kernels run on. The drop-in
+// mrcal_optimizer_callback() is a thin shell over it: create, evaluate, copy
+// out, destroy.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "layout.hpp"
+#include "host_state.hpp"
+#include "problem.hpp"
+#include "kernels.hpp"
+#include "problem_object.hpp"
+
+using namespace mrcal_amd;
+
+#define HIP_TRY(expr, onfail)                                           \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if(_e != hipSuccess)                                            \
+        {                                                               \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            onfail;                                                     \
+        }                                                               \
+    } while(0)
+
+namespace mrcal_amd {
+
+template<class T>
+static bool dev_alloc(T** p, size_t n)
+{
+    *p = NULL;
+    if(n == 0) n = 1;
+    HIP_TRY(hipMalloc((void**)p, n*sizeof(T)), return false);
+    return true;
+}
+template<class T>
+static bool dev_upload(T** p, const T* host, size_t n)
+{
+    if(!dev_alloc(p, n)) return false;
+    if(n > 0 && host != NULL)
+        HIP_TRY(hipMemcpy(*p, host, n*sizeof(T), hipMemcpyHostToDevice), return false);
+    return true;
+}
+
+} // namespace
+
+mrcal_amd_problem::~mrcal_amd_problem()
+{
+    hipFree(d_seed_intrinsics); hipFree(d_seed_rt_cam_ref); hipFree(d_seed_rt_ref_frame);
+    hipFree(d_seed_points); hipFree(d_board_meta); hipFree(d_board_pool);
+    hipFree(d_point_meta); hipFree(d_point_pool); hipFree(d_imagersizes);
+    hipFree(B.b); hipFree(B.joint); hipFree(B.x); hipFree(B.Jv); hipFree(B.Jp); hipFree(B.Ji);
+    if(ev_j0)  hipEventDestroy(ev_j0);
+    if(ev_j1)  hipEventDestroy(ev_j1);
+    if(stream) hipStreamDestroy(stream);
+}
+
+extern "C" {
+
+const char* mrcal_amd_last_error(void)
+{
+    return last_error_string().c_str();
+}
+
+int mrcal_amd_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mrcal_amd_problem_t*
+mrcal_amd_problem_create(const double*                 intrinsics,
+                         const mrcal_pose_t*           rt_cam_ref,
+                         const mrcal_pose_t*           rt_ref_frame,
+                         const mrcal_point3_t*         points,
+                         const mrcal_calobject_warp_t* calobject_warp,
+                         int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                         int Npoints, int Npoints_fixed,
+                         const mrcal_observation_board_t* observations_board,
+                         const mrcal_observation_point_t* observations_point,
+                         int Nobservations_board,
+                         int Nobservations_point,
+                         const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                         int Nobservations_point_triangulated,
+                         const mrcal_point3_t* observations_board_pool,
+                         const mrcal_point3_t* observations_point_pool,
+                         const mrcal_lensmodel_t* lensmodel,
+                         const int* imagersizes,
+                         mrcal_problem_selections_t problem_selections,
+                         double calibration_object_spacing,
+                         int calibration_object_width_n,
+                         int calibration_object_height_n,
+                         int shard_begin_frame, int shard_end_frame,
+                         bool is_shard_leader)
+{
+    last_error_string().clear();
+
+    if(mrcal_amd_device_count() <= 0)
+    {
+        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
+        return NULL;
+    }
+    if(!lens_supported(lensmodel->type))
+    {
+        char name[128] = "?";
+        mrcal_lensmodel_name(name, sizeof(name), lensmodel);
+        set_error("lens model %s (%d) is not implemented on the GPU yet", name, (int)lensmodel->type);
+        return NULL;
+    }
+    if(observations_point_triangulated != NULL && Nobservations_point_triangulated > 0)
+    {
+        set_error("triangulated-point observations are not implemented on the GPU yet");
+        return NULL;
+    }
+    if(Nobservations_board > 0 &&
+       (calibration_object_width_n <= 0 || calibration_object_height_n <= 0))
+    {
+        set_error("board observations given, but the board has no corners");
+        return NULL;
+    }
+
+    if(Nobservations_board <= 0) { Nobservations_board = 0; calibration_object_width_n = calibration_object_height_n = 0; }
+    if(Nobservations_point <= 0)   Nobservations_point = 0;
+
+    const mrcal_problem_selections_t sel =
+        effective_selections(problem_selections, *lensmodel, Nobservations_board);
+
+    mrcal_amd_problem* P = new mrcal_amd_problem();
+
+    // The STATE layout is global: every shard sees the whole state vector
+    Dims dg;
+    dg.Ncameras_intrinsics = Ncameras_intrinsics;
+    dg.Ncameras_extrinsics = Ncameras_extrinsics;
+    dg.Nframes             = Nframes;
+    dg.Npoints             = Npoints;
+    dg.Npoints_fixed       = Npoints_fixed;
+    dg.Nobservations_board = Nobservations_board;
+    dg.Nobservations_point = Nobservations_point;
+    dg.object_width_n      = calibration_object_width_n;
+    dg.object_height_n     = calibration_object_height_n;
+    const Layout Lg = make_layout(dg, sel, *lensmodel, NULL, 0);
+
+    // The MEASUREMENT layout is local to the shard
+    const bool sharded = !(shard_begin_frame <= 0 && (shard_end_frame < 0 || shard_end_frame >= Nframes));
+    if(!sharded) is_shard_leader = true;
+    std::vector<int> board_sel;
+    board_sel.reserve(Nobservations_board);
+    for(int i=0; i<Nobservations_board; i++)
+    {
+        const int f = observations_board[i].iframe;
+        if(!sharded || (f >= shard_begin_frame && f < shard_end_frame))
+            board_sel.push_back(i);
+    }
+    const int Nboard_local = (int)board_sel.size();
+    const int Npoint_local = is_shard_leader ? Nobservations_point : 0;
+
+    Layout L = Lg;
+    L.dims.Nobservations_board = Nboard_local;   // NOTE: has_warp etc. stay global
+    L.dims.Nobservations_point = Npoint_local;
+    L.Nmeas_boards         = Nboard_local * calibration_object_width_n*calibration_object_height_n * 2;
+    L.Nmeas_points         = Npoint_local * 2;
+    L.Nmeas_triangulated   = 0;
+    if(!is_shard_leader) { L.Nmeas_regularization = 0; L.has_unity_cam01 = false; L.Nreg_percamera = 0; }
+    L.i_meas_boards         = 0;
+    L.i_meas_points         = L.Nmeas_boards;
+    L.i_meas_triangulated   = L.i_meas_points + L.Nmeas_points;
+    L.i_meas_regularization = L.i_meas_triangulated;
+    L.Nmeas                 = L.i_meas_regularization + L.Nmeas_regularization;
+    P->L = L;
+
+    const int NPTS = calibration_object_width_n*calibration_object_height_n;
+
+    // per-observation metadata + CSR offsets
+    std::vector<BoardObsMeta> bmeta(Nboard_local);
+    int64_t innz = 0;
+    int     imeas = 0;
+    int     kmax  = 0;
+    for(int j=0; j<Nboard_local; j++)
+    {
+        const mrcal_observation_board_t& o = observations_board[board_sel[j]];
+        BoardObsMeta& m = bmeta[j];
+        memset(&m, 0, sizeof(m));
+        m.icam_intrinsics    = o.icam.intrinsics;
+        m.icam_extrinsics    = o.icam.extrinsics;
+        m.iframe             = o.iframe;
+        m.nnz_per_row        = nnz_per_board_row(L, o.icam.extrinsics);
+        m.i_state_intrinsics = (L.Nintr_state > 0) ? L.i_state_intrinsics + o.icam.intrinsics*L.Nintr_state : -1;
+        m.i_state_extrinsics = (L.Nstate_extrinsics > 0 && o.icam.extrinsics >= 0) ? L.i_state_extrinsics + 6*o.icam.extrinsics : -1;
+        m.i_state_frame      = (L.Nstate_frames > 0) ? L.i_state_frames + 6*o.iframe : -1;
+        m.i_meas0            = imeas;
+        m.i_nnz0             = innz;
+        imeas += 2*NPTS;
+        innz  += (int64_t)2*NPTS*m.nnz_per_row;
+        if(m.nnz_per_row > kmax) kmax = m.nnz_per_row;
+    }
+    std::vector<PointObsMeta> pmeta(Npoint_local);
+    for(int j=0; j<Npoint_local; j++)
+    {
+        const mrcal_observation_point_t& o = observations_point[j];
+        PointObsMeta& m = pmeta[j];
+        memset(&m, 0, sizeof(m));
+        const bool variable = sel.do_optimize_frames && o.i_point < Npoints - Npoints_fixed;
+        m.icam_intrinsics    = o.icam.intrinsics;
+        m.icam_extrinsics    = o.icam.extrinsics;
+        m.i_point            = o.i_point;
+        m.nnz_per_row        = nnz_per_point_row(L, o.icam.extrinsics, o.i_point);
+        m.i_state_intrinsics = (L.Nintr_state > 0) ? L.i_state_intrinsics + o.icam.intrinsics*L.Nintr_state : -1;
+        m.i_state_extrinsics = (L.Nstate_extrinsics > 0 && o.icam.extrinsics >= 0) ? L.i_state_extrinsics + 6*o.icam.extrinsics : -1;
+        m.i_state_point      = variable ? L.i_state_points + 3*o.i_point : -1;
+        m.i_meas0            = imeas;
+        m.i_nnz0             = innz;
+        imeas += 2;
+        innz  += 2*m.nnz_per_row;
+    }
+    const int64_t innz_reg = innz;
+    if(L.Nmeas_regularization > 0)
+        innz += (int64_t)Ncameras_intrinsics*L.Nreg_percamera + (L.has_unity_cam01 ? 3 : 0);
+    P->Nnz = innz;
+    if(innz > 0x7fffffffLL)
+    {
+        // the reference's CSR uses int32 offsets (cholmod itype int); so do we
+        set_error("Jacobian has %lld nonzeros: more than int32 CSR offsets can address. Shard the problem", (long long)innz);
+        delete P;
+        return NULL;
+    }
+    P->lds_bytes = 128 * (kmax | 1) * (int)sizeof(double);
+    if(P->lds_bytes > 160*1024)
+    {
+        set_error("a board row has %d nonzeros: the LDS tile would not fit", kmax);
+        delete P;
+        return NULL;
+    }
+
+    // board pool of the local observations
+    std::vector<mrcal_point3_t> pool_local;
+    const mrcal_point3_t* pool_src = observations_board_pool;
+    if(sharded)
+    {
+        pool_local.resize((size_t)Nboard_local*NPTS);
+        for(int j=0; j<Nboard_local; j++)
+            memcpy(&pool_local[(size_t)j*NPTS], &observations_board_pool[(size_t)board_sel[j]*NPTS],
+                   NPTS*sizeof(mrcal_point3_t));
+        pool_src = pool_local.data();
+    }
+    P->board_sel = board_sel;
+
+    bool ok = true;
+    HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking), ok = false);
+    HIP_TRY(hipEventCreate(&P->ev_j0), ok = false);
+    HIP_TRY(hipEventCreate(&P->ev_j1), ok = false);
+
+    ok = ok && dev_upload(&P->d_seed_intrinsics,   intrinsics,                  (size_t)Ncameras_intrinsics*L.Nintrinsics);
+    ok = ok && dev_upload(&P->d_seed_rt_cam_ref,   (const double*)rt_cam_ref,   (size_t)Ncameras_extrinsics*6);
+    ok = ok && dev_upload(&P->d_seed_rt_ref_frame, (const double*)rt_ref_frame, (size_t)Nframes*6);
+    ok = ok && dev_upload(&P->d_seed_points,       (const double*)points,       (size_t)Npoints*3);
+    ok = ok && dev_upload(&P->d_board_meta,        bmeta.data(),                (size_t)Nboard_local);
+    ok = ok && dev_upload(&P->d_board_pool,        (const double*)pool_src,     (size_t)Nboard_local*NPTS*3);
+    ok = ok && dev_upload(&P->d_point_meta,        pmeta.data(),                (size_t)Npoint_local);
+    ok = ok && dev_upload(&P->d_point_pool,        (const double*)observations_point_pool, (size_t)Npoint_local*3);
+    ok = ok && dev_upload(&P->d_imagersizes,       imagersizes,                 (size_t)Ncameras_intrinsics*2);
+    ok = ok && dev_alloc (&P->B.b,     (size_t)L.Nstate);
+    ok = ok && dev_alloc (&P->B.joint, (size_t)Nboard_local*JOINT_STRIDE);
+    ok = ok && dev_alloc (&P->B.x,     (size_t)L.Nmeas);
+    ok = ok && dev_alloc (&P->B.Jv,    (size_t)innz);
+    ok = ok && dev_alloc (&P->B.Jp,    (size_t)L.Nmeas+1);
+    ok = ok && dev_alloc (&P->B.Ji,    (size_t)innz);
+    if(!ok) { delete P; return NULL; }
+
+    DeviceProblem& D = P->D;
+    memset(&D, 0, sizeof(D));
+    D.lens_type   = (int)lensmodel->type;
+    D.Nintrinsics = L.Nintrinsics;   D.Ncore = L.Ncore;        D.Ncore_state = L.Ncore_state;
+    D.Ndist       = L.Ndist;         D.Ndist_state = L.Ndist_state; D.Nintr_state = L.Nintr_state;
+    D.i_state_intrinsics = L.i_state_intrinsics < 0 ? 0 : L.i_state_intrinsics;
+    D.i_state_extrinsics = L.i_state_extrinsics;
+    D.i_state_frames     = L.i_state_frames;
+    D.i_state_points     = L.i_state_points;
+    D.i_state_warp       = L.i_state_warp;
+    D.Nstate = L.Nstate;  D.Nmeas = L.Nmeas;
+    D.do_optimize_extrinsics = L.Nstate_extrinsics > 0;
+    D.do_optimize_frames     = sel.do_optimize_frames;
+    D.has_warp_state         = L.has_warp;
+    D.has_warp_seed          = (calobject_warp != NULL);
+    D.Ncameras_intrinsics = Ncameras_intrinsics; D.Ncameras_extrinsics = Ncameras_extrinsics;
+    D.Nframes = Nframes; D.Npoints = Npoints; D.Npoints_fixed = Npoints_fixed;
+    D.Nobs_board = Nboard_local; D.Nobs_point = Npoint_local;
+    D.W = calibration_object_width_n; D.H = calibration_object_height_n;
+    D.spacing = calibration_object_spacing;
+    if(calobject_warp) { D.seed_warp[0] = calobject_warp->x2; D.seed_warp[1] = calobject_warp->y2; }
+    if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+    {
+        D.spline_order = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.order;
+        D.spline_Nx    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Nx;
+        D.spline_Ny    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Ny;
+    }
+    if(lensmodel->type == MRCAL_LENSMODEL_CAHVORE)
+        D.cahvore_linearity = lensmodel->LENSMODEL_CAHVORE__config.linearity;
+    D.do_apply_regularization = sel.do_apply_regularization && is_shard_leader;
+    D.has_unity_cam01         = L.has_unity_cam01;
+    D.i_meas_regularization   = L.i_meas_regularization;
+    D.i_nnz_regularization    = innz_reg;
+    D.imager_width_cam0       = (Ncameras_intrinsics > 0) ? (double)imagersizes[0] : 1.0;
+    D.seed_intrinsics   = P->d_seed_intrinsics;
+    D.seed_rt_cam_ref   = P->d_seed_rt_cam_ref;
+    D.seed_rt_ref_frame = P->d_seed_rt_ref_frame;
+    D.seed_points       = P->d_seed_points;
+    D.board_meta        = P->d_board_meta;
+    D.board_pool        = P->d_board_pool;
+    D.point_meta        = P->d_point_meta;
+    D.point_pool        = P->d_point_pool;
+    D.imagersizes       = P->d_imagersizes;
+
+    // the seed state
+    P->b_host.assign(L.Nstate > 0 ? L.Nstate : 1, 0.0);
+    pack_state_from_arrays(P->b_host.data(), L, intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp);
+    HIP_TRY(hipMemcpyAsync(P->B.b, P->b_host.data(), (size_t)L.Nstate*sizeof(double),
+                           hipMemcpyHostToDevice, P->stream), { delete P; return NULL; });
+
+    // iteration-invariant CSR structure
+    HIP_TRY(launch_structure(D, P->B, P->stream), { delete P; return NULL; });
+    if(L.Nmeas_regularization <= 0)
+    {
+        const int32_t last = (int32_t)innz;
+        HIP_TRY(hipMemcpyAsync(&P->B.Jp[L.Nmeas], &last, sizeof(last), hipMemcpyHostToDevice, P->stream),
+                { delete P; return NULL; });
+    }
+    HIP_TRY(hipStreamSynchronize(P->stream), { delete P; return NULL; });
+    return P;
+}
+
+void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem)
+{
+    delete problem;
+}
+
+int     mrcal_amd_problem_Nstate       (const mrcal_amd_problem_t* p) { return p->L.Nstate; }
+int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* p) { return p->L.Nmeas;  }
+int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* p) { return p->Nnz;      }
+
+double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* p) { return p->B.b;  }
+double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* p) { return p->B.x;  }
+int32_t* mrcal_amd_problem_dev_J_rowptr(mrcal_amd_problem_t* p) { return p->B.Jp; }
+int32_t* mrcal_amd_problem_dev_J_colidx(mrcal_amd_problem_t* p) { return p->B.Ji; }
+double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* p) { return p->B.Jv; }
+void*    mrcal_amd_problem_stream      (mrcal_amd_problem_t* p) { return (void*)p->stream; }
+
+bool mrcal_amd_problem_set_b_packed(mrcal_amd_problem_t* p, const double* b)
+{
+    HIP_TRY(hipMemcpyAsync(p->B.b, b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyHostToDevice, p->stream), return false);
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_get_b_packed(mrcal_amd_problem_t* p, double* b)
+{
+    HIP_TRY(hipMemcpyAsync(b, p->B.b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_get_x(mrcal_amd_problem_t* p, double* x)
+{
+    HIP_TRY(hipMemcpyAsync(x, p->B.x, (size_t)p->L.Nmeas*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_get_J(mrcal_amd_problem_t* p, int32_t* rowptr, int32_t* colidx, double* values)
+{
+    if(rowptr) HIP_TRY(hipMemcpyAsync(rowptr, p->B.Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), return false);
+    if(colidx) HIP_TRY(hipMemcpyAsync(colidx, p->B.Ji, (size_t)p->Nnz*sizeof(int32_t),         hipMemcpyDeviceToHost, p->stream), return false);
+    if(values) HIP_TRY(hipMemcpyAsync(values, p->B.Jv, (size_t)p->Nnz*sizeof(double),          hipMemcpyDeviceToHost, p->stream), return false);
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+
+bool mrcal_amd_problem_evaluate(mrcal_amd_problem_t* p, bool with_jacobian, bool sync)
+{
+    HIP_TRY(launch_evaluate(p->D, p->B, with_jacobian, p->lds_bytes, p->stream,
+                            with_jacobian ? p->ev_j0 : NULL,
+                            with_jacobian ? p->ev_j1 : NULL),
+            return false);
+    p->have_jacobian_timing = with_jacobian && p->D.Nobs_board > 0;
+    if(sync) HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+
+double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* p)
+{
+    if(!p->have_jacobian_timing) return -1.0;
+    if(hipEventSynchronize(p->ev_j1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if(hipEventElapsedTime(&ms, p->ev_j0, p->ev_j1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+////////////////////////////////////////////////////////////////////////////////
+// drop-in: one evaluation
+////////////////////////////////////////////////////////////////////////////////
+bool mrcal_optimizer_callback(double* b_packed, int buffer_size_b_packed,
+                              double* x,        int buffer_size_x,
+                              struct cholmod_sparse_struct* Jt,
+                              const double*                 intrinsics,
+                              const mrcal_pose_t*           rt_cam_ref,
+                              const mrcal_pose_t*           rt_ref_frame,
+                              const mrcal_point3_t*         points,
+                              const mrcal_calobject_warp_t* calobject_warp,
+                              int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                              int Npoints, int Npoints_fixed,
+                              const mrcal_observation_board_t* observations_board,
+                              const mrcal_observation_point_t* observations_point,
+                              int Nobservations_board,
+                              int Nobservations_point,
+                              const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                              int Nobservations_point_triangulated,
+                              const mrcal_point3_t* observations_board_pool,
+                              const mrcal_point3_t* observations_point_pool,
+                              const mrcal_lensmodel_t* lensmodel,
+                              const int* imagersizes,
+                              mrcal_problem_selections_t       problem_selections,
+                              const mrcal_problem_constants_t* problem_constants,
+                              double calibration_object_spacing,
+                              int calibration_object_width_n,
+                              int calibration_object_height_n,
+                              bool verbose)
+{
+    (void)problem_constants; (void)verbose;
+    last_error_string().clear();
+
+    if(observations_point_triangulated != NULL && Nobservations_point_triangulated &&
+       !(!problem_selections.do_optimize_intrinsics_core &&
+         !problem_selections.do_optimize_intrinsics_distortions &&
+         problem_selections.do_optimize_extrinsics))
+    {
+        set_error("ERROR: We have triangulated points. At this time this is only allowed if we're NOT optimizing intrinsics AND if we ARE optimizing extrinsics.");
+        return false;
+    }
+    if(Nobservations_board > 0 && problem_selections.do_optimize_calobject_warp && calobject_warp == NULL)
+    {
+        set_error("ERROR: We're optimizing the calibration object warp, so a buffer with a seed MUST be passed in.");
+        return false;
+    }
+    const mrcal_problem_selections_t sel =
+        effective_selections(problem_selections, *lensmodel, Nobservations_board);
+    if(!sel.do_optimize_intrinsics_core && !sel.do_optimize_intrinsics_distortions &&
+       !sel.do_optimize_extrinsics      && !sel.do_optimize_frames &&
+       !sel.do_optimize_calobject_warp)
+    {
+        set_error("Not optimizing any of our variables!");
+        return false;
+    }
+
+    const int Nstate =
+        mrcal_num_states(Ncameras_intrinsics, Ncameras_extrinsics, Nframes,
+                         Npoints, Npoints_fixed, Nobservations_board, sel, lensmodel);
+    if(buffer_size_b_packed != Nstate*(int)sizeof(double))
+    {
+        set_error("The buffer passed to fill-in b_packed has the wrong size. Needed exactly %d bytes, but got %d bytes",
+                  Nstate*(int)sizeof(double), buffer_size_b_packed);
+        return false;
+    }
+    const int Nmeas =
+        mrcal_num_measurements(Nobservations_board, Nobservations_point,
+                               observations_point_triangulated, Nobservations_point_triangulated,
+                               calibration_object_width_n, calibration_object_height_n,
+                               Ncameras_intrinsics, Ncameras_extrinsics, Nframes,
+                               Npoints, Npoints_fixed, sel, lensmodel);
+    if(buffer_size_x != Nmeas*(int)sizeof(double))
+    {
+        set_error("The buffer passed to fill-in x has the wrong size. Needed exactly %d bytes, but got %d bytes",
+                  Nmeas*(int)sizeof(double), buffer_size_x);
+        return false;
+    }
+
+    mrcal_amd_problem_t* P =
+        mrcal_amd_problem_create(intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp,
+                                 Ncameras_intrinsics, Ncameras_extrinsics, Nframes,
+                                 Npoints, Npoints_fixed,
+                                 observations_board, observations_point,
+                                 Nobservations_board, Nobservations_point,
+                                 observations_point_triangulated, Nobservations_point_triangulated,
+                                 observations_board_pool, observations_point_pool,
+                                 lensmodel, imagersizes, sel,
+                                 calibration_object_spacing,
+                                 calibration_object_width_n, calibration_object_height_n,
+                                 0, -1, true);
+    if(P == NULL) return false;
+
+    bool ok = false;
+    if(P->L.Nstate != Nstate || P->L.Nmeas != Nmeas)
+    {
+        set_error("internal error: layout mismatch (%d,%d) vs (%d,%d)", P->L.Nstate, P->L.Nmeas, Nstate, Nmeas);
+        goto done;
+    }
+    memcpy(b_packed, P->b_host.data(), (size_t)Nstate*sizeof(double));
+    if(!mrcal_amd_problem_evaluate(P, Jt != NULL, true)) goto done;
+    if(!mrcal_amd_problem_get_x(P, x)) goto done;
+    if(Jt != NULL)
+        if(!mrcal_amd_problem_get_J(P, (int32_t*)Jt->p, (int32_t*)Jt->i, (double*)Jt->x)) goto done;
+    ok = true;
+ done:
+    mrcal_amd_problem_destroy(P);
+    return ok;
+}
+
+} // extern "C"

@@ -1,0 +1,210 @@
+"""Synthetic chessboard-calibration problems: the workload generator for the
+parity tests and the benchmark.
+
+Restates, with numpy only, the behaviour of the reference's
+mrcal.synthesize_board_observations() (mrcal/synthetic_data.py:236-554) and the
+input preparation of test/test-basic-calibration.py:25-135 +
+test/test_calibration_helpers.py:13-35:
+
+  - stationary cameras (camera 0 at the reference), a board of WxH corners
+    thrown around a nominal pose with uniform noise, only the poses where every
+    camera sees the whole board are kept
+  - per-corner weights uniform in [0.6,1], pixel noise N(0, sigma/weight), 1%
+    of the corners pushed 20x further out (outliers to be found by the solver)
+  - the solver is seeded from a perturbed copy of the truth
+
+Perfect pixel observations need the lens model. Rather than carrying a second
+projection implementation, the generator asks the library it is given: an
+optimizer_callback() evaluation with all observed pixels at 0 and all weights at
+1 returns x = q_hypothesis (mrcal.c:4712), which is what
+make_perfect_observations() computes (mrcal/synthetic_data.py:594-757).
+"""
+import numpy as np
+
+# The two cameras of the reference's test fixtures
+# (test/data/cam0.opencv8.cameramodel, test/data/cam1.opencv8.cameramodel):
+# fx fy cx cy k0..k7, imager 4000x2200. test-basic-calibration.py alternates them
+CAM_OPENCV8 = (
+    np.array((1761.181055, 1761.250444, 1965.706996, 1087.518797,
+              -0.01266096516, 0.03590794372, -0.0002547045941, 0.0005275929652,
+              0.01968883397, 0.01482863541, -0.0562239888, 0.0500223357)),
+    np.array((1761.181055, 1761.250444, 1965.706996, 1087.518797,
+              -0.01266096516, 0.03590794372, -0.0002547045941, 0.0005275929652,
+              0.01968883397, 0.01482863541, -0.0562239888, 0.0500223357)) * \
+    np.array((1.004, 0.996, 1.003, 0.99, 1.1, 0.9, 1.2, 0.8, 1.05, 0.95, 1.02, 0.98)))
+IMAGERSIZE = (4000, 2200)
+
+
+def R_from_r(r):
+    """Rodrigues. r: (...,3) -> (...,3,3)"""
+    r  = np.asarray(r, dtype=float)
+    th = np.linalg.norm(r, axis=-1)[..., None, None]
+    K  = np.zeros(r.shape[:-1] + (3,3))
+    K[...,0,1] = -r[...,2]; K[...,0,2] =  r[...,1]
+    K[...,1,0] =  r[...,2]; K[...,1,2] = -r[...,0]
+    K[...,2,0] = -r[...,1]; K[...,2,1] =  r[...,0]
+    small = th < 1e-8
+    ths   = np.where(small, 1.0, th)
+    a = np.where(small, 1.0, np.sin(ths)/ths)
+    b = np.where(small, 0.5, (1.0 - np.cos(ths))/(ths*ths))
+    return np.eye(3) + a*K + b*(K @ K)
+
+
+def intrinsics_for(lensmodel, Ncameras):
+    """Truth intrinsics for a parametric lens model, cut down from the OPENCV8
+    fixture cameras as test-basic-calibration.py:38-41 does for OPENCV4"""
+    N = {"LENSMODEL_PINHOLE": 4, "LENSMODEL_STEREOGRAPHIC": 4,
+         "LENSMODEL_LONLAT": 4, "LENSMODEL_LATLON": 4,
+         "LENSMODEL_OPENCV4": 8, "LENSMODEL_OPENCV5": 9,
+         "LENSMODEL_OPENCV8": 12, "LENSMODEL_OPENCV12": 16}[lensmodel]
+    out = np.zeros((Ncameras, N))
+    for i in range(Ncameras):
+        src = CAM_OPENCV8[i % 2]
+        n = min(N, 12)
+        out[i,:n] = src[:n]
+        if lensmodel in ("LENSMODEL_LONLAT", "LENSMODEL_LATLON"):
+            # angular models: pixels per radian
+            out[i,:2] = 1200.
+    return out
+
+
+def make_calibration_problem(api, *,
+                             Ncameras, Nframes,
+                             lensmodel         = "LENSMODEL_OPENCV8",
+                             object_width_n    = 10,
+                             object_height_n   = 10,
+                             object_spacing    = 0.1,
+                             calobject_warp    = (0.002, -0.005),
+                             pixel_noise       = 1.5,
+                             make_outliers     = True,
+                             seed              = 0,
+                             seed_perturbation = 1.0,
+                             camera_spacing    = 0.3,
+                             board_distance    = 4.0):
+    """Returns (optimization_inputs, truth). optimization_inputs is a dict
+    ready for api.optimize(**optimization_inputs); all blocks optimized,
+    regularization and outlier rejection on. api: a mrcal_amd._api.Api (any
+    backing library)"""
+    rng = np.random.RandomState(seed)
+    W, H = object_width_n, object_height_n
+
+    intrinsics_true = intrinsics_for(lensmodel, Ncameras)
+    imagersizes     = np.array((IMAGERSIZE,)*Ncameras, dtype=np.int32)
+
+    # cameras in a row along x, slightly mis-pointed; camera 0 is the reference
+    rt_cam_ref_true = np.zeros((Ncameras-1, 6))
+    for i in range(1, Ncameras):
+        rt_cam_ref_true[i-1,:3] = rng.uniform(-0.05, 0.05, size=3)
+        # rt_cam_ref transforms FROM the reference: a camera sitting at +x has
+        # negative t_x
+        rt_cam_ref_true[i-1,3:] = (-camera_spacing*i, rng.uniform(-0.05,0.05), rng.uniform(-0.05,0.05))
+    x_center = camera_spacing*(Ncameras-1)/2.
+
+    rt_ref_boardcenter = np.array((0., 0., 0., x_center, 0., board_distance))
+    noiseradius = np.array((np.pi/180.*30., np.pi/180.*30., np.pi/180.*20., 2.5, 2.5, 2.0))
+    board_center = np.array(((W-1)*object_spacing/2., (H-1)*object_spacing/2., 0.))
+    warp_true = None if calobject_warp is None else np.array(calobject_warp, dtype=float)
+
+    idx_cam = np.zeros((Ncameras, 3), dtype=np.int32)
+    idx_cam[:,1] = np.arange(Ncameras)
+    idx_cam[:,2] = np.arange(Ncameras) - 1
+
+    def project_frames(rt_ref_frame):
+        """perfect q of every corner for every (frame,camera): (Nf,Ncam,H,W,2)"""
+        Nf = rt_ref_frame.shape[0]
+        idx = np.tile(idx_cam, (Nf,1))
+        idx[:,0] = np.repeat(np.arange(Nf, dtype=np.int32), Ncameras)
+        obs = np.zeros((Nf*Ncameras, H, W, 3))
+        obs[...,2] = 1.0
+        x = api.optimizer_callback(
+            intrinsics   = intrinsics_true,
+            rt_cam_ref   = rt_cam_ref_true,
+            rt_ref_frame = rt_ref_frame,
+            observations_board = obs,
+            indices_frame_camintrinsics_camextrinsics = idx,
+            lensmodel    = lensmodel,
+            imagersizes  = imagersizes,
+            calobject_warp = warp_true,
+            calibration_object_spacing = object_spacing,
+            do_optimize_calobject_warp = False,
+            do_apply_regularization    = False,
+            no_jacobian = True, no_factorization = True)[1]
+        return x[:Nf*Ncameras*H*W*2].reshape(Nf, Ncameras, H, W, 2)
+
+    q_all  = np.zeros((0, Ncameras, H, W, 2))
+    rt_all = np.zeros((0, 6))
+    while q_all.shape[0] < Nframes:
+        Nchunk = max(Nframes, 16)
+        randomblock = rng.uniform(-1.0, 1.0, size=(Nchunk, 6))
+        rt_center   = rt_ref_boardcenter + randomblock*noiseradius
+        # board-corner-referenced pose: same rotation, origin moved to the corner
+        rt_frame        = rt_center.copy()
+        rt_frame[:,3:] -= (R_from_r(rt_center[:,:3]) @ board_center[:,None])[...,0]
+        q = project_frames(rt_frame)
+        visible = (q[...,0] >= 0) & (q[...,1] >= 0) & \
+                  (q[...,0] <= IMAGERSIZE[0]-1) & (q[...,1] <= IMAGERSIZE[1]-1) & \
+                  np.isfinite(q[...,0]) & np.isfinite(q[...,1])
+        # all cameras must see the full board, and the board must face them
+        keep = np.all(visible, axis=(1,2,3))
+        q_all  = np.concatenate((q_all,  q[keep]))
+        rt_all = np.concatenate((rt_all, rt_frame[keep]))
+    q_all  = q_all [:Nframes]
+    rt_ref_frame_true = rt_all[:Nframes]
+
+    weight = 0.2 + 0.8*(rng.rand(Nframes, Ncameras, H, W) + 1.)/2.
+    q_noise = rng.randn(Nframes, Ncameras, H, W, 2) * pixel_noise / weight[...,None]
+    if make_outliers:
+        Npts = Nframes*Ncameras*H*W
+        i_outliers = rng.choice(Npts, (Npts//100,), replace=False)
+        q_noise.reshape(Npts,2)[i_outliers] *= 20.
+    observations = np.concatenate((q_all + q_noise, weight[...,None]), axis=-1) \
+                     .reshape(Nframes*Ncameras, H, W, 3)
+
+    indices = np.tile(idx_cam, (Nframes,1))
+    indices[:,0] = np.repeat(np.arange(Nframes, dtype=np.int32), Ncameras)
+
+    # seed: the truth, perturbed
+    s = seed_perturbation
+    intrinsics = intrinsics_true.copy()
+    intrinsics[:,:2] *= 1. + s*0.01*rng.uniform(-1,1,size=(Ncameras,2))
+    intrinsics[:,2:4] += s*5.*rng.uniform(-1,1,size=(Ncameras,2))
+    if intrinsics.shape[1] > 4:
+        intrinsics[:,4:] *= 1. + s*0.1*rng.uniform(-1,1,size=intrinsics[:,4:].shape)
+    rt_cam_ref = rt_cam_ref_true + s*rng.uniform(-1,1,size=rt_cam_ref_true.shape) * \
+        np.array((2e-3,2e-3,2e-3, 1e-2,1e-2,1e-2))
+    rt_ref_frame = rt_ref_frame_true + s*rng.uniform(-1,1,size=rt_ref_frame_true.shape) * \
+        np.array((5e-3,5e-3,5e-3, 2e-2,2e-2,2e-2))
+
+    optimization_inputs = dict(
+        intrinsics   = np.ascontiguousarray(intrinsics),
+        rt_cam_ref   = np.ascontiguousarray(rt_cam_ref),
+        rt_ref_frame = np.ascontiguousarray(rt_ref_frame),
+        points       = None,
+        observations_board = np.ascontiguousarray(observations),
+        indices_frame_camintrinsics_camextrinsics = np.ascontiguousarray(indices),
+        observations_point = None,
+        indices_point_camintrinsics_camextrinsics = None,
+        lensmodel    = lensmodel,
+        imagersizes  = imagersizes,
+        calobject_warp = None if warp_true is None else np.zeros((2,)),
+        calibration_object_spacing = object_spacing,
+        do_optimize_intrinsics_core        = True,
+        do_optimize_intrinsics_distortions = intrinsics.shape[1] > 4,
+        do_optimize_extrinsics             = Ncameras > 1,
+        do_optimize_frames                 = True,
+        do_optimize_calobject_warp         = warp_true is not None,
+        do_apply_regularization            = True,
+        do_apply_outlier_rejection         = True,
+        verbose                            = False)
+    truth = dict(intrinsics   = intrinsics_true,
+                 rt_cam_ref   = rt_cam_ref_true,
+                 rt_ref_frame = rt_ref_frame_true,
+                 calobject_warp = warp_true,
+                 q            = q_all)
+    return optimization_inputs, truth
+
+
+def copy_inputs(optimization_inputs):
+    """deep copy of the arrays: optimize() works in place"""
+    return { k: (v.copy() if isinstance(v, np.ndarray) else v)
+             for k,v in optimization_inputs.items() }

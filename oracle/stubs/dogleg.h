@@ -1,0 +1,142 @@
+// TEST INFRASTRUCTURE ONLY. Not part of the product; nothing under mrcal_amd/
+// includes or links this.
+//
+// Stand-in for <dogleg.h> of libdogleg (third-party, NOT vendored in
+// /root/reference and not installed in this image; the reference pins it only
+// as ">= 0.15.3", doc/install.org:63). The reference's mrcal.c includes it at
+// mrcal.c:16 and uses:
+//
+//   - cholmod_sparse (fields p,i,x only: mrcal.c:4461-4463)
+//   - dogleg_parameters2_t, dogleg_getDefaultParameters()   mrcal.c:6289-6299
+//   - dogleg_optimize2(), dogleg_solverContext_t::beforeStep->{p,x},
+//     dogleg_freeContext()                                   mrcal.c:6385-6621
+//   - dogleg_testGradient()                                  mrcal.c:6603
+//   - dogleg_optimize_dense2()                               mrcal.c:3244
+//
+// This header declares exactly that surface so that the reference's own
+// sources can be compiled, unmodified and in place, into oracle/_ref/. The
+// definitions live in oracle/dogleg_restated.c: a restatement of libdogleg's
+// published Powell dog-leg algorithm with a CSparse-style simplicial Cholesky
+// standing in for CHOLMOD. PARITY UNPINNED for the iteration trajectory: no
+// copy of libdogleg/CHOLMOD exists here to pin it against.
+#pragma once
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+// Field order mirrors SuiteSparse's cholmod_sparse. Only p,i,x,nrow,ncol are
+// ever dereferenced by mrcal.c or by the restated solver
+typedef struct cholmod_sparse_struct
+{
+    size_t nrow, ncol, nzmax;
+    void *p, *i, *nz, *x, *z;
+    int stype, itype, xtype, dtype, sorted, packed;
+} cholmod_sparse;
+typedef struct cholmod_factor_struct cholmod_factor;
+typedef struct cholmod_common_struct cholmod_common;
+
+typedef void (dogleg_callback_t)      (const double* p, double* x, cholmod_sparse* Jt, void* cookie);
+typedef void (dogleg_callback_dense_t)(const double* p, double* x, double* J,          void* cookie);
+
+typedef struct
+{
+    double* p;
+    double* x;
+    double  norm2_x;
+    union
+    {
+        cholmod_sparse* Jt;
+        double*         J_dense; // row-first: grad0, grad1, ...
+    };
+    double* Jt_x;
+
+    double* updateCauchy;
+    double* updateGN;
+    double  updateCauchy_lensq, updateGN_lensq;
+    int     updateCauchy_valid, updateGN_valid;
+    int     didStepToEdgeOfTrustRegion;
+} dogleg_operatingPoint_t;
+
+typedef struct
+{
+    int    max_iterations;
+    int    dogleg_debug;
+    double trustregion0;
+    double trustregion_decrease_factor;
+    double trustregion_decrease_threshold;
+    double trustregion_increase_factor;
+    double trustregion_increase_threshold;
+    double Jt_x_threshold;
+    double update_threshold;
+    double trustregion_threshold;
+} dogleg_parameters2_t;
+
+#define DOGLEG_DEBUG_VNLOG 1
+
+struct dogleg_restated_factor_t;
+
+typedef struct
+{
+    dogleg_callback_t*       f;
+    dogleg_callback_dense_t* f_dense;
+    void*                    cookie;
+
+    dogleg_operatingPoint_t* beforeStep;
+    dogleg_operatingPoint_t* afterStep;
+
+    int                      is_sparse;
+    int                      Nstate, Nmeasurements, NJnnz;
+
+    // the "CHOLMOD" part: a simplicial Cholesky of JtJ + lambda I
+    struct dogleg_restated_factor_t* factorization;
+    double*                  factorization_dense;
+    int                      factorization_valid;
+    double                   lambda;
+
+    const dogleg_parameters2_t* parameters;
+
+    // bookkeeping for the oracle's users
+    int                      Ncallbacks;
+    int                      Nfactorizations;
+    int                      Nsteps;
+} dogleg_solverContext_t;
+
+void   dogleg_getDefaultParameters(dogleg_parameters2_t* parameters);
+
+double dogleg_optimize2(double* p, unsigned int Nstate,
+                        unsigned int Nmeas, unsigned int NJnnz,
+                        dogleg_callback_t* f, void* cookie,
+                        const dogleg_parameters2_t* parameters,
+                        dogleg_solverContext_t** returnContext);
+
+double dogleg_optimize_dense2(double* p, unsigned int Nstate,
+                              unsigned int Nmeas,
+                              dogleg_callback_dense_t* f, void* cookie,
+                              const dogleg_parameters2_t* parameters,
+                              dogleg_solverContext_t** returnContext);
+
+void   dogleg_freeContext(dogleg_solverContext_t** ctx);
+
+void   dogleg_testGradient(unsigned int var, const double* p0,
+                           unsigned int Nstate, unsigned int Nmeas, unsigned int NJnnz,
+                           dogleg_callback_t* f, void* cookie);
+
+// Oracle-only helpers (not in libdogleg): the counters of the most recent
+// dogleg_optimize2() call, so that the harness can report iterations/sec
+void   dogleg_restated_last_counts(int* Nsteps, int* Ncallbacks, int* Nfactorizations);
+
+// Oracle-only: factor JtJ (given Jt as CSC, i.e. J as CSR) and solve
+// JtJ x = b for Nrhs right-hand sides stored row-first in b (Nrhs,Nstate);
+// the solve happens in place. Returns false if JtJ is not positive definite.
+// This is the stand-in for CHOLMOD_factorization.solve_xt_JtJ_bt(sys='A'),
+// mrcal-pywrap.c:528-569
+bool   dogleg_restated_solve_JtJ(double* b, int Nrhs,
+                                 int Nstate, int Nmeas,
+                                 const int* Jt_p, const int* Jt_i, const double* Jt_x);
+
+#ifdef __cplusplus
+}
+#endif
