@@ -417,6 +417,40 @@ void* mrcal_amd_problem_stream(mrcal_amd_problem_t* problem);
    Returns milliseconds, <0 if unavailable */
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* problem);
 
+/* The whole solve on a resident problem: dog-leg iterations + outlier
+   rejection (if the problem selections ask for it), exactly what
+   mrcal_optimize() does between packing and unpacking the state. Returns the
+   rms error sqrt(|x|^2/Nmeasurements), <0 on failure. max_iterations<=0: the
+   reference's 300. The solution stays resident: read it with
+   mrcal_amd_problem_get_b_packed()/get_x() */
+double mrcal_amd_problem_solve(mrcal_amd_problem_t* problem, int max_iterations,
+                               int* Noutliers_board);
+
+/* Exactly Nsteps dog-leg steps (accepted or rejected) from the current
+   operating point, without termination tests or outlier rejection: the unit
+   of work the benchmark times. trustregion_inout (may be NULL) carries the
+   trust-region radius across calls; <=0 on input means "the default".
+   Returns the number of steps taken, <0 on error */
+int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* problem, int Nsteps, double* trustregion_inout);
+
+/* Counters of the most recent solve / run_steps. Any pointer may be NULL */
+void mrcal_amd_problem_solver_stats(mrcal_amd_problem_t* problem,
+                                    int* Niterations, int* Nevaluations, int* Nfactorizations,
+                                    int* Noutlier_passes, double* norm2_x, double* lambda, double* seconds);
+
+/* Test/diagnostic access. Evaluates at the resident state and copies out the
+   normal equations N = JtJ in the solver's block form (see
+   csrc/solver_kernels.hip): A (Nc*Nc), Bt (NE*Nc), D (NEb*6*6), g = Jt x
+   (Nstate), |x|^2; dims = {Nc, NE, NEb, Nfb, Nie, Nwarp}. Any pointer may be
+   NULL */
+bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* problem,
+                                            double* A, double* Bt, double* D, double* g,
+                                            double* norm2_x, int* dims);
+/* d = -(JtJ + lambda I)^-1 Jt x at the resident state, d (Nstate) to the host */
+bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* problem, double* step);
+/* the board observation pool of this shard, with any newly marked outliers */
+bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* problem, mrcal_point3_t* pool_local);
+
 #ifdef __cplusplus
 }
 #endif

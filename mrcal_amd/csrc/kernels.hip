@@ -340,13 +340,42 @@ void project_lens(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDI
 ////////////////////////////////////////////////////////////////////////////////
 // 2. board kernel
 ////////////////////////////////////////////////////////////////////////////////
-template<int PROJ, int NDIST, bool WITH_J>
+//
+// LDS tile of one pass (64 corners = 128 rows). Row (xy,corner) lives at LDS
+// row xy*64+corner; its columns are in STATE order:
+//
+//   [fx fy cx cy]   if the core is optimized. An x row holds (dq/dfx, 0, w, 0),
+//                   a y row (0, dq/dfy, 0, w): each CSR row carries only its
+//                   own 2 core columns, the tile carries all 4 so that a tile
+//                   column means the same state variable in every row
+//   [distortions]   Ndist_state
+//   [r_cam t_cam]   6, if this camera has extrinsics in the state
+//   [r_frame t_frame] 6, if frames are optimized
+//   [warp]          2, if the warp is optimized
+//   [x]             the residual itself (only when the Gram is being formed)
+//
+// The row stride is odd, which makes the per-lane column writes
+// (ds_write_b64, lane stride = one row) and the MFMA operand reads hit
+// distinct banks.
+//
+// Gram (WITH_GRAM): G = Tt T over the tile columns, accumulated over the
+// passes of the observation with v_mfma_f64_16x16x4_f64. One k-step is 4 tile
+// rows; lane l supplies T[4s + l/16][16b + l%16] for column block b, which is
+// simultaneously the A operand (A[i=l%16][k=l/16]) of row block b and the B
+// operand (B[k=l/16][j=l%16]) of column block b. Accumulator register v of
+// lane l holds G[16bi + l/16 + 4v][16bj + l%16] (layout measured on gfx950,
+// tools/mfma_f64_layout_probe.hip). The last column of G is Tt x = the
+// observation's slice of Jt x, its corner is |x|^2.
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM>
 __global__ __launch_bounds__(64)
 void board_kernel(DeviceProblem P,
                   const double* __restrict__ b,
                   const double* __restrict__ joint,
                   double*       __restrict__ x,
-                  double*       __restrict__ Jv)
+                  double*       __restrict__ Jv,
+                  double*       __restrict__ gram)
 {
     extern __shared__ __attribute__((aligned(16))) double tile[];
 
@@ -356,7 +385,10 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ jp = joint + (size_t)iobs*JOINT_STRIDE;
 
     const int  k       = m.nnz_per_row;
-    const int  ks      = k | 1;           // odd LDS row stride: conflict-free column writes
+    const int  ncore   = P.Ncore_state;          // 0 or 4
+    const int  kt      = k + (ncore ? 2 : 0);    // tile columns holding J
+    const int  kx      = kt + (WITH_GRAM ? 1 : 0);
+    const int  ks      = kx | 1;                 // odd LDS row stride
     const int  NPTS    = P.W*P.H;
     const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
 
@@ -366,6 +398,17 @@ void board_kernel(DeviceProblem P,
 
     double warp[2] = {0.0, 0.0};
     if(P.has_warp_seed) get_warp(warp, P, b);
+
+    // upper-triangular 16x16 tiles of G: up to 3 column blocks
+    constexpr int NBMAX = 3;
+    constexpr int NTMAX = NBMAX*(NBMAX+1)/2;
+    double4_t acc[WITH_GRAM ? NTMAX : 1];
+    if(WITH_GRAM)
+    {
+#pragma unroll
+        for(int t=0;t<NTMAX;t++) acc[t] = (double4_t){0.0,0.0,0.0,0.0};
+    }
+    const int NB = (kx + 15) >> 4;
 
     for(int chunk0 = 0; chunk0 < NPTS; chunk0 += 64)
     {
@@ -414,16 +457,18 @@ void board_kernel(DeviceProblem P,
                 // outliers keep their columns and get all-zero values
                 const double ww = inlier ? w : 0.0;
                 int c = 0;
-                if(P.Ncore_state)
+                if(ncore)
                 {
 #pragma unroll
                     for(int xy=0;xy<2;xy++)
                     {
                         const double dq_df = (q[xy] - intr[2+xy])/intr[xy];
-                        row[xy][0] = inlier ? dq_df * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
-                        row[xy][1] = ww * SCALE_INTRINSICS_CENTER_PIXEL;
+                        row[xy][xy]       = inlier ? dq_df * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
+                        row[xy][1-xy]     = 0.0;
+                        row[xy][2+xy]     = ww * SCALE_INTRINSICS_CENTER_PIXEL;
+                        row[xy][2+(1-xy)] = 0.0;
                     }
-                    c = 2;
+                    c = 4;
                 }
                 if(NDIST > 0 && P.Ndist_state)
                 {
@@ -499,15 +544,20 @@ void board_kernel(DeviceProblem P,
                     }
                     c += 2;
                 }
+                if(WITH_GRAM)
+                {
+                    row[0][c] = err.x;
+                    row[1][c] = err.y;
+                }
             }
         }
 
         if(WITH_J)
         {
             __syncthreads();
-            // Stream the tile out. Output element e of this pass is row e/k,
-            // column e%k, with row = 2*point + xy. 16 bytes per lane per store,
-            // 1 KiB contiguous per wave instruction
+            // Stream the tile out. Output element e of this pass is CSR row
+            // e/k, column e%k, with row = 2*point + xy. 16 bytes per lane per
+            // store, 1 KiB contiguous per wave instruction
             const int nelem = 2*npts*k;
             double* __restrict__ out = Jv + m.i_nnz0 + (size_t)2*chunk0*k;
             for(int e = 2*lane; e < nelem; e += 128)
@@ -516,13 +566,65 @@ void board_kernel(DeviceProblem P,
                 int c0 = e - r0*k;
                 int r1 = r0, c1 = c0 + 1;
                 if(c1 == k) { c1 = 0; r1++; }
+                // CSR column -> tile column: the row's own 2 core columns
+                // (f then c) sit at tile columns xy and 2+xy
+                const int xy0 = r0 & 1, xy1 = r1 & 1;
+                const int t0 = ncore ? ((c0 < 2) ? (2*c0 + xy0) : (c0 + 2)) : c0;
+                const int t1 = ncore ? ((c1 < 2) ? (2*c1 + xy1) : (c1 + 2)) : c1;
                 double2 v;
-                v.x = tile[(size_t)(((r0&1) << 6) + (r0 >> 1))*ks + c0];
-                v.y = tile[(size_t)(((r1&1) << 6) + (r1 >> 1))*ks + c1];
+                v.x = tile[(size_t)((xy0 << 6) + (r0 >> 1))*ks + t0];
+                v.y = tile[(size_t)((xy1 << 6) + (r1 >> 1))*ks + t1];
                 *reinterpret_cast<double2*>(&out[e]) = v;
+            }
+
+            if(WITH_GRAM)
+            {
+                // G += Tt T over this pass. 4 tile rows per k-step; rows of
+                // corners beyond npts hold stale data and are masked out
+                const int nsteps = (npts + 3) >> 2;
+                const int col    = lane & 15;
+                for(int plane = 0; plane < 2; plane++)
+                    for(int s = 0; s < nsteps; s++)
+                    {
+                        const int  rr    = 4*s + (lane >> 4);
+                        const bool valid = rr < npts;
+                        const double* __restrict__ trow = tile + (size_t)((plane << 6) + rr)*ks;
+                        double a[NBMAX];
+#pragma unroll
+                        for(int bb=0;bb<NBMAX;bb++)
+                        {
+                            const int cc = 16*bb + col;
+                            a[bb] = (bb < NB && valid && cc < kx) ? trow[cc] : 0.0;
+                        }
+                        int t = 0;
+#pragma unroll
+                        for(int bi=0;bi<NBMAX;bi++)
+#pragma unroll
+                            for(int bj=bi;bj<NBMAX;bj++,t++)
+                                if(bj < NB)
+                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
+                    }
             }
             __syncthreads();
         }
+    }
+
+    if(WITH_J && WITH_GRAM)
+    {
+        // accumulator layout, tile-major: gram[iobs][t][v][lane]. Only the
+        // tiles in use are written
+        double* __restrict__ g = gram + (size_t)iobs*GRAM_STRIDE;
+        int t = 0;
+#pragma unroll
+        for(int bi=0;bi<NBMAX;bi++)
+#pragma unroll
+            for(int bj=bi;bj<NBMAX;bj++,t++)
+                if(bj < NB)
+                {
+#pragma unroll
+                    for(int v=0;v<4;v++)
+                        g[(size_t)t*256 + v*64 + lane] = acc[t][v];
+                }
     }
 }
 
@@ -811,12 +913,15 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
         hipLaunchKernelGGL(board_prologue_kernel, dim3((P.Nobs_board + 63)/64), dim3(64), 0, stream,
                            P, B.b, B.joint);
         if(ev_j0) hipEventRecord(ev_j0, stream);
-        if(with_jacobian)
-            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.b, B.joint, B.x, B.Jv);
+        if(with_jacobian && B.gram != NULL)
+            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                               P, B.b, B.joint, B.x, B.Jv, B.gram);
+        else if(with_jacobian)
+            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                               P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
         else
-            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false>), dim3(P.Nobs_board), dim3(64), 0, stream,
-                               P, B.b, B.joint, B.x, B.Jv);
+            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false,false>), dim3(P.Nobs_board), dim3(64), 0, stream,
+                               P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
         if(ev_j1) hipEventRecord(ev_j1, stream);
     }
     if(P.Nobs_point > 0)

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "layout.hpp"
 #include "host_state.hpp"
 #include "problem.hpp"
@@ -52,11 +53,123 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_seed_intrinsics); hipFree(d_seed_rt_cam_ref); hipFree(d_seed_rt_ref_frame);
     hipFree(d_seed_points); hipFree(d_board_meta); hipFree(d_board_pool);
     hipFree(d_point_meta); hipFree(d_point_pool); hipFree(d_imagersizes);
-    hipFree(B.b); hipFree(B.joint); hipFree(B.x); hipFree(B.Jv); hipFree(B.Jp); hipFree(B.Ji);
+    hipFree(d_joint); hipFree(d_gram); hipFree(d_Jp); hipFree(d_Ji);
+    for(int i=0;i<2;i++)
+    {
+        hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv);
+        hipFree(op[i].N.A); hipFree(op[i].N.Bt); hipFree(op[i].N.D); hipFree(op[i].N.g); hipFree(op[i].N.scalars);
+        hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
+    }
+    hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.r); hipFree(F.status);
+    hipFree(d_step); hipFree(d_counts);
+    if(h_scalars) hipHostFree(h_scalars);
     if(ev_j0)  hipEventDestroy(ev_j0);
     if(ev_j1)  hipEventDestroy(ev_j1);
     if(stream) hipStreamDestroy(stream);
 }
+
+namespace mrcal_amd {
+
+bool problem_prepare_solver(mrcal_amd_problem* P)
+{
+    if(P->solver_ready) return true;
+    const Layout& L = P->L;
+    NormalDims& nd = P->nd;
+
+    // second operating point
+    bool ok = true;
+    ok = ok && dev_alloc(&P->op[1].b,  (size_t)L.Nstate);
+    ok = ok && dev_alloc(&P->op[1].x,  (size_t)L.Nmeas);
+    ok = ok && dev_alloc(&P->op[1].Jv, (size_t)P->Nnz);
+    ok = ok && dev_alloc(&P->d_gram,   (size_t)P->D.Nobs_board*GRAM_STRIDE);
+    for(int i=0;i<2 && ok;i++)
+    {
+        ok = ok && dev_alloc(&P->op[i].N.A,       (size_t)nd.Nc*nd.Nc);
+        ok = ok && dev_alloc(&P->op[i].N.Bt,      (size_t)nd.NE*nd.Nc);
+        ok = ok && dev_alloc(&P->op[i].N.D,       (size_t)nd.NEb*36);
+        ok = ok && dev_alloc(&P->op[i].N.g,       (size_t)nd.Nstate);
+        ok = ok && dev_alloc(&P->op[i].N.scalars, (size_t)NSCALARS);
+        ok = ok && dev_alloc(&P->op[i].step_cauchy, (size_t)nd.Nstate);
+        ok = ok && dev_alloc(&P->op[i].step_gn,     (size_t)nd.Nstate);
+    }
+    ok = ok && dev_alloc(&P->F.Wt, (size_t)nd.NE*nd.Nc);
+    ok = ok && dev_alloc(&P->F.LD, (size_t)nd.NEb*36);
+    ok = ok && dev_alloc(&P->F.y,  (size_t)nd.NE);
+    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc);
+    ok = ok && dev_alloc(&P->F.r,  (size_t)nd.Nc);
+    ok = ok && dev_alloc(&P->F.status, 1);
+    ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
+    ok = ok && dev_alloc(&P->d_counts, 4);
+    if(!ok) return false;
+    HIP_TRY(hipHostMalloc((void**)&P->h_scalars, 64*sizeof(double)), return false);
+
+    // assembly work lists. Observations of one frame are contiguous; the
+    // observations of one (intrinsics,extrinsics) pair are gathered in chunks
+    const int Nobs = P->D.Nobs_board;
+    std::vector<BoardObsMeta> meta(Nobs);
+    if(Nobs > 0)
+        HIP_TRY(hipMemcpy(meta.data(), P->d_board_meta, (size_t)Nobs*sizeof(BoardObsMeta), hipMemcpyDeviceToHost), return false);
+    std::vector<int> frame_begin(L.dims.Nframes+1, 0);
+    for(int o=0;o<Nobs;o++) frame_begin[meta[o].iframe+1]++;
+    for(int f=0;f<L.dims.Nframes;f++) frame_begin[f+1] += frame_begin[f];
+    // sanity: contiguity
+    for(int o=1;o<Nobs;o++)
+        if(meta[o].iframe < meta[o-1].iframe)
+        {
+            set_error("board observations must be sorted by frame");
+            return false;
+        }
+
+    std::vector<int> order(Nobs);
+    for(int o=0;o<Nobs;o++) order[o] = o;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b)
+                     {
+                         if(meta[a].icam_intrinsics != meta[b].icam_intrinsics) return meta[a].icam_intrinsics < meta[b].icam_intrinsics;
+                         return meta[a].icam_extrinsics < meta[b].icam_extrinsics;
+                     });
+    const int CHUNK = 32;
+    std::vector<int> chunk_begin;
+    for(int i=0;i<Nobs;)
+    {
+        int j = i;
+        while(j < Nobs && j - i < CHUNK &&
+              meta[order[j]].icam_intrinsics == meta[order[i]].icam_intrinsics &&
+              meta[order[j]].icam_extrinsics == meta[order[i]].icam_extrinsics) j++;
+        chunk_begin.push_back(i);
+        i = j;
+    }
+    chunk_begin.push_back(Nobs);
+    P->plan.Nchunks = (int)chunk_begin.size() - 1;
+    ok = ok && dev_upload(&P->plan.frame_obs_begin, frame_begin.data(), frame_begin.size());
+    ok = ok && dev_upload(&P->plan.chunk_begin,     chunk_begin.data(), chunk_begin.size());
+    ok = ok && dev_upload(&P->plan.pair_obs,        order.data(),       order.size());
+    if(!ok) return false;
+
+    P->solver_ready = true;
+    return true;
+}
+
+bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal)
+{
+    if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
+    const EvalBuffers B = P->eval_buffers(i, with_normal);
+    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream,
+                            with_jacobian ? P->ev_j0 : NULL,
+                            with_jacobian ? P->ev_j1 : NULL),
+            return false);
+    P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0;
+    if(with_normal)
+    {
+        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, P->op[i].N, P->stream), return false);
+        P->op[i].have_normal = true;
+    }
+    P->op[i].cauchy_valid = P->op[i].gn_valid = false;
+    P->stats.Nevaluations++;
+    return true;
+}
+
+} // namespace mrcal_amd
 
 extern "C" {
 
@@ -227,7 +340,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         delete P;
         return NULL;
     }
-    P->lds_bytes = 128 * (kmax | 1) * (int)sizeof(double);
+    // tile columns: k, +2 for the full core, +1 for the residual column (see board_kernel)
+    P->lds_bytes = 128 * ((kmax + 3) | 1) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
         set_error("a board row has %d nonzeros: the LDS tile would not fit", kmax);
@@ -262,13 +376,26 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     ok = ok && dev_upload(&P->d_point_meta,        pmeta.data(),                (size_t)Npoint_local);
     ok = ok && dev_upload(&P->d_point_pool,        (const double*)observations_point_pool, (size_t)Npoint_local*3);
     ok = ok && dev_upload(&P->d_imagersizes,       imagersizes,                 (size_t)Ncameras_intrinsics*2);
-    ok = ok && dev_alloc (&P->B.b,     (size_t)L.Nstate);
-    ok = ok && dev_alloc (&P->B.joint, (size_t)Nboard_local*JOINT_STRIDE);
-    ok = ok && dev_alloc (&P->B.x,     (size_t)L.Nmeas);
-    ok = ok && dev_alloc (&P->B.Jv,    (size_t)innz);
-    ok = ok && dev_alloc (&P->B.Jp,    (size_t)L.Nmeas+1);
-    ok = ok && dev_alloc (&P->B.Ji,    (size_t)innz);
+    ok = ok && dev_alloc (&P->op[0].b,  (size_t)L.Nstate);
+    ok = ok && dev_alloc (&P->d_joint,  (size_t)Nboard_local*JOINT_STRIDE);
+    ok = ok && dev_alloc (&P->op[0].x,  (size_t)L.Nmeas);
+    ok = ok && dev_alloc (&P->op[0].Jv, (size_t)innz);
+    ok = ok && dev_alloc (&P->d_Jp,     (size_t)L.Nmeas+1);
+    ok = ok && dev_alloc (&P->d_Ji,     (size_t)innz);
     if(!ok) { delete P; return NULL; }
+
+    {
+        NormalDims& nd = P->nd;
+        nd.Nstate       = L.Nstate;
+        nd.Nie          = L.Nstate_intrinsics + L.Nstate_extrinsics;
+        nd.Nwarp        = L.Nstate_warp;
+        nd.i_state_warp = L.i_state_warp;
+        nd.Nc           = nd.Nie + nd.Nwarp;
+        nd.NE           = L.Nstate_frames + L.Nstate_points;
+        nd.Nfb          = L.Nstate_frames/6;
+        nd.Npb          = L.Nstate_points/3;
+        nd.NEb          = nd.Nfb + nd.Npb;
+    }
 
     DeviceProblem& D = P->D;
     memset(&D, 0, sizeof(D));
@@ -317,15 +444,15 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     // the seed state
     P->b_host.assign(L.Nstate > 0 ? L.Nstate : 1, 0.0);
     pack_state_from_arrays(P->b_host.data(), L, intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp);
-    HIP_TRY(hipMemcpyAsync(P->B.b, P->b_host.data(), (size_t)L.Nstate*sizeof(double),
+    HIP_TRY(hipMemcpyAsync(P->op[0].b, P->b_host.data(), (size_t)L.Nstate*sizeof(double),
                            hipMemcpyHostToDevice, P->stream), { delete P; return NULL; });
 
     // iteration-invariant CSR structure
-    HIP_TRY(launch_structure(D, P->B, P->stream), { delete P; return NULL; });
+    HIP_TRY(launch_structure(D, P->eval_buffers(0,false), P->stream), { delete P; return NULL; });
     if(L.Nmeas_regularization <= 0)
     {
         const int32_t last = (int32_t)innz;
-        HIP_TRY(hipMemcpyAsync(&P->B.Jp[L.Nmeas], &last, sizeof(last), hipMemcpyHostToDevice, P->stream),
+        HIP_TRY(hipMemcpyAsync(&P->d_Jp[L.Nmeas], &last, sizeof(last), hipMemcpyHostToDevice, P->stream),
                 { delete P; return NULL; });
     }
     HIP_TRY(hipStreamSynchronize(P->stream), { delete P; return NULL; });
@@ -341,47 +468,43 @@ int     mrcal_amd_problem_Nstate       (const mrcal_amd_problem_t* p) { return p
 int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* p) { return p->L.Nmeas;  }
 int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* p) { return p->Nnz;      }
 
-double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* p) { return p->B.b;  }
-double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* p) { return p->B.x;  }
-int32_t* mrcal_amd_problem_dev_J_rowptr(mrcal_amd_problem_t* p) { return p->B.Jp; }
-int32_t* mrcal_amd_problem_dev_J_colidx(mrcal_amd_problem_t* p) { return p->B.Ji; }
-double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* p) { return p->B.Jv; }
+double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* p) { return p->op[p->icur].b;  }
+double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* p) { return p->op[p->icur].x;  }
+int32_t* mrcal_amd_problem_dev_J_rowptr(mrcal_amd_problem_t* p) { return p->d_Jp; }
+int32_t* mrcal_amd_problem_dev_J_colidx(mrcal_amd_problem_t* p) { return p->d_Ji; }
+double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* p) { return p->op[p->icur].Jv; }
 void*    mrcal_amd_problem_stream      (mrcal_amd_problem_t* p) { return (void*)p->stream; }
 
 bool mrcal_amd_problem_set_b_packed(mrcal_amd_problem_t* p, const double* b)
 {
-    HIP_TRY(hipMemcpyAsync(p->B.b, b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyHostToDevice, p->stream), return false);
+    HIP_TRY(hipMemcpyAsync(p->op[p->icur].b, b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyHostToDevice, p->stream), return false);
     HIP_TRY(hipStreamSynchronize(p->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_get_b_packed(mrcal_amd_problem_t* p, double* b)
 {
-    HIP_TRY(hipMemcpyAsync(b, p->B.b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
+    HIP_TRY(hipMemcpyAsync(b, p->op[p->icur].b, (size_t)p->L.Nstate*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
     HIP_TRY(hipStreamSynchronize(p->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_get_x(mrcal_amd_problem_t* p, double* x)
 {
-    HIP_TRY(hipMemcpyAsync(x, p->B.x, (size_t)p->L.Nmeas*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
+    HIP_TRY(hipMemcpyAsync(x, p->op[p->icur].x, (size_t)p->L.Nmeas*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
     HIP_TRY(hipStreamSynchronize(p->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_get_J(mrcal_amd_problem_t* p, int32_t* rowptr, int32_t* colidx, double* values)
 {
-    if(rowptr) HIP_TRY(hipMemcpyAsync(rowptr, p->B.Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), return false);
-    if(colidx) HIP_TRY(hipMemcpyAsync(colidx, p->B.Ji, (size_t)p->Nnz*sizeof(int32_t),         hipMemcpyDeviceToHost, p->stream), return false);
-    if(values) HIP_TRY(hipMemcpyAsync(values, p->B.Jv, (size_t)p->Nnz*sizeof(double),          hipMemcpyDeviceToHost, p->stream), return false);
+    if(rowptr) HIP_TRY(hipMemcpyAsync(rowptr, p->d_Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), return false);
+    if(colidx) HIP_TRY(hipMemcpyAsync(colidx, p->d_Ji, (size_t)p->Nnz*sizeof(int32_t),         hipMemcpyDeviceToHost, p->stream), return false);
+    if(values) HIP_TRY(hipMemcpyAsync(values, p->op[p->icur].Jv, (size_t)p->Nnz*sizeof(double),          hipMemcpyDeviceToHost, p->stream), return false);
     HIP_TRY(hipStreamSynchronize(p->stream), return false);
     return true;
 }
 
 bool mrcal_amd_problem_evaluate(mrcal_amd_problem_t* p, bool with_jacobian, bool sync)
 {
-    HIP_TRY(launch_evaluate(p->D, p->B, with_jacobian, p->lds_bytes, p->stream,
-                            with_jacobian ? p->ev_j0 : NULL,
-                            with_jacobian ? p->ev_j1 : NULL),
-            return false);
-    p->have_jacobian_timing = with_jacobian && p->D.Nobs_board > 0;
+    if(!problem_evaluate_op(p, p->icur, with_jacobian, false)) return false;
     if(sync) HIP_TRY(hipStreamSynchronize(p->stream), return false);
     return true;
 }

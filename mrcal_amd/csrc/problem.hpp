@@ -22,6 +22,7 @@
 //     J_colidx          int32[Nnz]        } reference's callback writes into
 //     J_values          double[Nnz]       } Jt->p, Jt->i, Jt->x
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "layout.hpp"
 
@@ -78,6 +79,25 @@ enum
     JOINT_DTJ_DTF = 75,   // 9
     JOINT_STRIDE  = 84
 };
+
+// Per-board-observation Gram matrix G = Tt T of the observation's Jacobian
+// tile T (columns in state order, plus the residual as a last column), as the
+// MFMA accumulators leave it: up to 3 column blocks of 16 -> 6 upper-triangular
+// 16x16 tiles, tile-major, each tile [v][lane] with G[16bi + lane/16 + 4v][16bj + lane%16]
+enum { GRAM_NB_MAX = 3, GRAM_NT_MAX = 6, GRAM_STRIDE = GRAM_NT_MAX*256 };
+__host__ __device__ inline int gram_tile_index(int bi, int bj) // bi <= bj
+{
+    // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+    return bi*GRAM_NB_MAX - bi*(bi-1)/2 + (bj - bi);
+}
+// G[i][j], any i,j
+__host__ __device__ inline double gram_get(const double* g, int i, int j)
+{
+    if(i > j) { int t = i; i = j; j = t; }
+    int bi = i >> 4, bj = j >> 4, ii = i & 15, jj = j & 15;
+    if(bi == bj && ii > jj) { int t = ii; ii = jj; jj = t; } // diagonal tiles are symmetric
+    return g[gram_tile_index(bi,bj)*256 + (ii >> 2)*64 + ((ii & 3) << 4) + jj];
+}
 
 struct DeviceProblem
 {

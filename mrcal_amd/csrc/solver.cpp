@@ -1,7 +1,389 @@
-// placeholder until the dog-leg solver lands
+// The dog-leg solver and the drop-in mrcal_optimize().
+//
+// Reference behaviour: mrcal_optimize() (mrcal.c:6179-6624) = [pack state] ->
+// do { dogleg_optimize2() } while(outlier rejection found something) ->
+// [unpack state, stats]. dogleg_optimize2() is libdogleg's (third party, not in
+// the reference tree): Powell's dog leg with a trust region. Its algorithm is
+// restated in oracle/dogleg_restated.c (CPU checker); THIS file is the
+// product: the same algorithm with every vector/matrix operation running on
+// the GPU (solver_kernels.hip) and only the scalar trust-region decisions on
+// the host.
+//
+// mrcal's solver settings (mrcal.c:6296-6299): Jt_x_threshold 0,
+// update_threshold 1e-7, trustregion_threshold 0, max_iterations 300; the rest
+// are libdogleg's defaults: trustregion0 1e3, decrease 0.1 below rho 0.25,
+// increase 2 above rho 0.75 (only if the step reached the trust-region edge).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <chrono>
 #include "host_state.hpp"
+#include "problem_object.hpp"
+
 using namespace mrcal_amd;
-extern "C"
+
+#define HIP_TRY(expr, onfail)                                           \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if(_e != hipSuccess)                                            \
+        {                                                               \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            onfail;                                                     \
+        }                                                               \
+    } while(0)
+
+namespace {
+
+struct DoglegParameters
+{
+    int    max_iterations                 = 300;
+    double trustregion0                   = 1.0e3;
+    double trustregion_decrease_factor    = 0.1;
+    double trustregion_decrease_threshold = 0.25;
+    double trustregion_increase_factor    = 2.0;
+    double trustregion_increase_threshold = 0.75;
+    double Jt_x_threshold                 = 0.0;
+    double update_threshold               = 1e-7;
+    double trustregion_threshold          = 0.0;
+};
+
+// device scalars -> host, one sync
+bool read_scalars(mrcal_amd_problem* P, const double* dev, int n, double* out)
+{
+    HIP_TRY(hipMemcpyAsync(P->h_scalars, dev, n*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    for(int i=0;i<n;i++) out[i] = P->h_scalars[i];
+    return true;
+}
+
+// x, J, N = JtJ blocks, g = Jt x, |x|^2, |g|^2, g^T N g at op[i].b
+bool evaluate_operating_point(mrcal_amd_problem* P, int i)
+{
+    mrcal_amd_oppoint& op = P->op[i];
+    if(!problem_evaluate_op(P, i, true, true)) return false;
+    double* sc = op.N.scalars;
+    HIP_TRY(launch_dot(P->nd.Nstate, op.N.g, op.N.g, &sc[SC_NORM2_G], P->stream), return false);
+    HIP_TRY(launch_quadform(P->nd, op.N, op.N.g, &sc[SC_GNG], P->stream), return false);
+    double s[3];
+    if(!read_scalars(P, sc, 3, s)) return false;
+    op.norm2_x = s[SC_NORM2_X];
+    // Cauchy step: -(|g|^2 / |J g|^2) g
+    const double norm2_g = s[SC_NORM2_G], gNg = s[SC_GNG];
+    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
+    op.cauchy_lensq = k*k*norm2_g;
+    HIP_TRY(launch_axpby(P->nd.Nstate, k, op.N.g, 0.0, NULL, op.step_cauchy, P->stream), return false);
+    op.cauchy_valid = true;
+    op.gn_valid     = false;
+    op.did_step_to_edge = false;
+    return true;
+}
+
+// Gauss-Newton step of op[i], adding lambda I until the factorization succeeds
+bool compute_gauss_newton(mrcal_amd_problem* P, int i)
+{
+    mrcal_amd_oppoint& op = P->op[i];
+    if(op.gn_valid) return true;
+    for(;;)
+    {
+        P->stats.Nfactorizations++;
+        HIP_TRY(launch_factor_and_solve(P->nd, op.N, P->F, P->stats.lambda, op.step_gn, P->stream), return false);
+        HIP_TRY(hipMemsetAsync(&op.N.scalars[SC_TMP0], 0, sizeof(double), P->stream), return false);
+        HIP_TRY(launch_dot(P->nd.Nstate, op.step_gn, op.step_gn, &op.N.scalars[SC_TMP0], P->stream), return false);
+        int status = 0;
+        HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->F.status, sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
+        double lensq;
+        if(!read_scalars(P, &op.N.scalars[SC_TMP0], 1, &lensq)) return false;
+        memcpy(&status, P->h_scalars + 32, sizeof(int));
+        if(status == 0 && lensq == lensq)
+        {
+            op.gn_lensq = lensq;
+            op.gn_valid = true;
+            return true;
+        }
+        // singular JtJ: regularize, like libdogleg does
+        P->stats.lambda = (P->stats.lambda == 0.0) ? 1e-10 : P->stats.lambda*10.0;
+        if(!(P->stats.lambda < 1e30))
+        {
+            set_error("could not make JtJ positive definite");
+            return false;
+        }
+    }
+}
+
+// the dog-leg step from op[ib] with the given trust region. The new state goes
+// to op[ia].b. Returns the squared step length, <0 on error
+double take_step(mrcal_amd_problem* P, int ib, int ia, double trustregion, double* expected_improvement)
+{
+    mrcal_amd_oppoint& from = P->op[ib];
+    const int n = P->nd.Nstate;
+    double step_len_sq;
+
+    if(from.cauchy_lensq >= trustregion*trustregion)
+    {
+        const double k = trustregion/sqrt(from.cauchy_lensq);
+        HIP_TRY(launch_axpby(n, k, from.step_cauchy, 0.0, NULL, P->d_step, P->stream), return -1.0);
+        step_len_sq = trustregion*trustregion;
+        from.did_step_to_edge = true;
+    }
+    else
+    {
+        if(!compute_gauss_newton(P, ib)) return -1.0;
+        if(from.gn_lensq <= trustregion*trustregion)
+        {
+            HIP_TRY(launch_axpby(n, 1.0, from.step_gn, 0.0, NULL, P->d_step, P->stream), return -1.0);
+            step_len_sq = from.gn_lensq;
+            from.did_step_to_edge = false;
+        }
+        else
+        {
+            // point on the Cauchy->GN segment at the trust-region edge:
+            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
+            double* sc = from.N.scalars;
+            HIP_TRY(hipMemsetAsync(&sc[SC_TMP0], 0, 2*sizeof(double), P->stream), return -1.0);
+            HIP_TRY(launch_dot(n, from.step_cauchy, from.step_gn, &sc[SC_TMP0], P->stream), return -1.0);
+            double ab;
+            if(!read_scalars(P, &sc[SC_TMP0], 1, &ab)) return -1.0;
+            const double dsq    = trustregion*trustregion;
+            const double norm2a = from.cauchy_lensq, norm2b = from.gn_lensq;
+            const double l2     = norm2a - 2.0*ab + norm2b;   // |a-b|^2
+            const double neg_c  = norm2a - ab;                // a.(a-b)
+            double disc = neg_c*neg_c - l2*(norm2a - dsq);
+            if(disc < 0.0) disc = 0.0;
+            const double k = (neg_c + sqrt(disc))/l2;
+            HIP_TRY(launch_axpby(n, 1.0-k, from.step_cauchy, k, from.step_gn, P->d_step, P->stream), return -1.0);
+            step_len_sq = (1.0-k)*(1.0-k)*norm2a + 2.0*k*(1.0-k)*ab + k*k*norm2b;
+            from.did_step_to_edge = true;
+        }
+    }
+
+    HIP_TRY(launch_axpby(n, 1.0, from.b, 1.0, P->d_step, P->op[ia].b, P->stream), return -1.0);
+
+    // expected improvement: |x|^2 - |x + J s|^2 = -2 g.s - s^T N s
+    double* sc = from.N.scalars;
+    HIP_TRY(hipMemsetAsync(&sc[SC_TMP1], 0, 2*sizeof(double), P->stream), return -1.0);
+    HIP_TRY(launch_dot(n, from.N.g, P->d_step, &sc[SC_TMP1], P->stream), return -1.0);
+    HIP_TRY(launch_quadform(P->nd, from.N, P->d_step, &sc[SC_TMP2], P->stream), return -1.0);
+    double s[2];
+    if(!read_scalars(P, &sc[SC_TMP1], 2, s)) return -1.0;
+    *expected_improvement = -2.0*s[0] - s[1];
+    return step_len_sq;
+}
+
+// libdogleg's main loop. On return op[P->icur] is the final operating point
+bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
+{
+    int ib = P->icur, ia = 1 - ib;
+    double trustregion = prm.trustregion0;
+    if(!evaluate_operating_point(P, ib)) return false;
+
+    int stepCount = 0;
+    while(stepCount < prm.max_iterations)
+    {
+        bool done = false;
+        for(;;)
+        {
+            double expected;
+            const double step_len_sq = take_step(P, ib, ia, trustregion, &expected);
+            if(step_len_sq < 0.0) return false;
+            if(step_len_sq < prm.update_threshold*prm.update_threshold) { done = true; break; }
+
+            if(!evaluate_operating_point(P, ia)) return false;
+            const double observed = P->op[ib].norm2_x - P->op[ia].norm2_x;
+            const double rho      = observed/expected;
+
+            if(rho < prm.trustregion_decrease_threshold)
+                trustregion *= prm.trustregion_decrease_factor;
+            else if(rho > prm.trustregion_increase_threshold && P->op[ib].did_step_to_edge)
+                trustregion *= prm.trustregion_increase_factor;
+
+            if(rho > 0.0)
+            {
+                const int t = ib; ib = ia; ia = t;
+                break;
+            }
+            if(trustregion < prm.trustregion_threshold || trustregion == 0.0 || !(trustregion == trustregion))
+            { done = true; break; }
+        }
+        if(done) break;
+        stepCount++;
+    }
+    P->icur = ib;
+    P->stats.Niterations += stepCount;
+    P->stats.norm2_x = P->op[ib].norm2_x;
+    return true;
+}
+
+// mrcal.c:3978-4402 markOutliers(), boards only. Returns true if new outliers
+// were marked
+bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, bool* found)
+{
+    *found = false;
+    const int Npts = P->D.Nobs_board * P->D.W * P->D.H;
+    if(Npts <= 0) { *Noutliers_board = 0; return true; }
+    const double k0 = 4.0, k1 = 5.0;
+    const double* x = P->op[P->icur].x;
+    double* sums = P->op[P->icur].N.scalars + SC_TMP0;
+
+    auto stats = [&](double thresh_sq, int* counts, double* sum) -> bool
+    {
+        HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
+        HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double), P->stream), return false);
+        HIP_TRY(launch_outlier_stats(Npts, thresh_sq, x, P->d_board_pool, P->d_counts, sums, P->stream), return false);
+        HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
+        if(!read_scalars(P, sums, 1, sum)) return false;
+        memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
+        return true;
+    };
+    int counts[4]; double sum;
+    if(!stats(-1.0, counts, &sum)) return false;
+    const int Noutliers = counts[0];
+    const int Ninliers  = Npts - Noutliers;
+    *Noutliers_board = Noutliers;
+    if(Ninliers <= 0) return true;
+    const double var = sum / (double)(Ninliers*2);
+    if(!stats(k1*k1*var, counts, &sum)) return false;
+    if(counts[1] == 0) return true;
+
+    HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
+    HIP_TRY(launch_mark_outliers(Npts, k0*k0*var, x, P->d_board_pool, P->d_counts, P->stream), return false);
+    HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
+    *Noutliers_board = Noutliers + counts[0];
+    *found = true;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+// Resident tier: the full solve on a resident problem. Returns rms error, <0
+// on failure. do_outlier_rejection<0: use the problem's own selection
+double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
+                               int* Noutliers_board_out)
+{
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return -1.0;
+    DoglegParameters prm;
+    if(max_iterations > 0) prm.max_iterations = max_iterations;
+
+    const auto t0 = std::chrono::steady_clock::now();
+    P->stats = mrcal_amd_solver_stats();
+    int Noutliers = 0;
+    for(;;)
+    {
+        if(!run_dogleg(P, prm)) return -1.0;
+        if(!P->L.sel.do_apply_outlier_rejection) break;
+        bool found;
+        if(!mark_outliers(P, &Noutliers, &found)) return -1.0;
+        if(!found) break;
+        P->stats.Noutlier_passes++;
+        fprintf(stderr, "mrcal_amd: Threw out some outliers. New count = %d/%d (%.1f%%). Going again\n",
+                Noutliers, P->L.Nmeas_boards,
+                (double)(Noutliers*100)/(double)(P->L.Nmeas_boards > 0 ? P->L.Nmeas_boards : 1));
+    }
+    if(Noutliers_board_out) *Noutliers_board_out = Noutliers;
+    P->stats.seconds_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return sqrt(P->stats.norm2_x / (double)P->L.Nmeas);
+}
+
+// Exactly `Nsteps` accepted-or-rejected dog-leg steps from the current
+// operating point, no termination tests, no outlier rejection: the unit the
+// benchmark times. Each step = 1 evaluation of x,J + the normal equations + a
+// factorization (when the trust region asks for the Gauss-Newton step).
+// Returns the number of evaluations done, <0 on error
+int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trustregion_inout)
+{
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return -1;
+    DoglegParameters prm;
+    int ib = P->icur, ia = 1 - ib;
+    double trustregion = (trustregion_inout && *trustregion_inout > 0.0) ? *trustregion_inout : prm.trustregion0;
+    if(!P->op[ib].have_normal || !P->op[ib].cauchy_valid)
+        if(!evaluate_operating_point(P, ib)) return -1;
+    int n = 0;
+    for(; n < Nsteps; n++)
+    {
+        double expected;
+        const double step_len_sq = take_step(P, ib, ia, trustregion, &expected);
+        if(step_len_sq < 0.0) return -1;
+        if(!evaluate_operating_point(P, ia)) return -1;
+        const double rho = (P->op[ib].norm2_x - P->op[ia].norm2_x)/expected;
+        if(rho < prm.trustregion_decrease_threshold)
+            trustregion *= prm.trustregion_decrease_factor;
+        else if(rho > prm.trustregion_increase_threshold && P->op[ib].did_step_to_edge)
+            trustregion *= prm.trustregion_increase_factor;
+        if(rho > 0.0) { const int t = ib; ib = ia; ia = t; }
+    }
+    P->icur = ib;
+    P->stats.norm2_x = P->op[ib].norm2_x;
+    if(trustregion_inout) *trustregion_inout = trustregion;
+    return n;
+}
+
+void mrcal_amd_problem_solver_stats(mrcal_amd_problem_t* P,
+                                    int* Niterations, int* Nevaluations, int* Nfactorizations,
+                                    int* Noutlier_passes, double* norm2_x, double* lambda, double* seconds)
+{
+    if(Niterations)     *Niterations     = P->stats.Niterations;
+    if(Nevaluations)    *Nevaluations    = P->stats.Nevaluations;
+    if(Nfactorizations) *Nfactorizations = P->stats.Nfactorizations;
+    if(Noutlier_passes) *Noutlier_passes = P->stats.Noutlier_passes;
+    if(norm2_x)         *norm2_x         = P->stats.norm2_x;
+    if(lambda)          *lambda          = P->stats.lambda;
+    if(seconds)         *seconds         = P->stats.seconds_solve;
+}
+
+// Debug/test access to the normal equations of the current operating point:
+// evaluates x, J and the blocks, copies A (Nc*Nc), Bt (NE*Nc), D (NEb*36), g
+// (Nstate) to the host. Any pointer may be NULL
+bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* P,
+                                            double* A, double* Bt, double* D, double* g,
+                                            double* norm2_x,
+                                            int* dims /* Nc, NE, NEb, Nfb, Nie, Nwarp */)
+{
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return false;
+    if(!problem_evaluate_op(P, P->icur, true, true)) return false;
+    const NormalDims& nd = P->nd;
+    const NormalBuffers& N = P->op[P->icur].N;
+    if(A)  HIP_TRY(hipMemcpyAsync(A,  N.A,  (size_t)nd.Nc*nd.Nc*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+    if(Bt) HIP_TRY(hipMemcpyAsync(Bt, N.Bt, (size_t)nd.NE*nd.Nc*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+    if(D)  HIP_TRY(hipMemcpyAsync(D,  N.D,  (size_t)nd.NEb*36*sizeof(double),   hipMemcpyDeviceToHost, P->stream), return false);
+    if(g)  HIP_TRY(hipMemcpyAsync(g,  N.g,  (size_t)nd.Nstate*sizeof(double),   hipMemcpyDeviceToHost, P->stream), return false);
+    if(norm2_x) HIP_TRY(hipMemcpyAsync(norm2_x, &N.scalars[SC_NORM2_X], sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    if(dims) { dims[0]=nd.Nc; dims[1]=nd.NE; dims[2]=nd.NEb; dims[3]=nd.Nfb; dims[4]=nd.Nie; dims[5]=nd.Nwarp; }
+    return true;
+}
+
+// Solves (JtJ + lambda I) d = -Jt x at the current operating point; d (Nstate)
+// to the host. The Gauss-Newton step, for tests
+bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* P, double* step)
+{
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return false;
+    if(!evaluate_operating_point(P, P->icur)) return false;
+    if(!compute_gauss_newton(P, P->icur)) return false;
+    HIP_TRY(hipMemcpyAsync(step, P->op[P->icur].step_gn, (size_t)P->nd.Nstate*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    return true;
+}
+
+// copies the (possibly outlier-marked) board observation pool back
+bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* P, mrcal_point3_t* pool_local)
+{
+    const size_t n = (size_t)P->D.Nobs_board*P->D.W*P->D.H;
+    if(n == 0) return true;
+    HIP_TRY(hipMemcpyAsync(pool_local, P->d_board_pool, n*sizeof(mrcal_point3_t), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    return true;
+}
+
+////////////////////////////////////////////////////////////////////////////////
+// drop-in: the whole solve
+////////////////////////////////////////////////////////////////////////////////
 mrcal_stats_t
 mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 double* x,        int buffer_size_x,
@@ -30,7 +412,97 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 bool verbose,
                 bool check_gradient)
 {
-    set_error("mrcal_optimize(): the GPU solver is not implemented yet");
-    mrcal_stats_t s = { -1.0, 0, 0 };
-    return s;
+    (void)problem_constants; (void)verbose;
+    last_error_string().clear();
+    const mrcal_stats_t failed = { -1.0, 0, 0 };
+
+    if(check_gradient)
+    {
+        set_error("mrcal_optimize(check_gradient=true) is not available in the GPU build");
+        return failed;
+    }
+    if(Nobservations_board > 0 && problem_selections.do_optimize_calobject_warp && calobject_warp == NULL)
+    {
+        set_error("ERROR: We're optimizing the calibration object warp, so a buffer with a seed MUST be passed in.");
+        return failed;
+    }
+    if(observations_point_triangulated != NULL && Nobservations_point_triangulated &&
+       !(!problem_selections.do_optimize_intrinsics_core &&
+         !problem_selections.do_optimize_intrinsics_distortions &&
+         problem_selections.do_optimize_extrinsics))
+    {
+        set_error("ERROR: We have triangulated points. At this time this is only allowed if we're NOT optimizing intrinsics AND if we ARE optimizing extrinsics.");
+        return failed;
+    }
+    const mrcal_problem_selections_t sel =
+        effective_selections(problem_selections, *lensmodel, Nobservations_board);
+    if(!sel.do_optimize_intrinsics_core && !sel.do_optimize_intrinsics_distortions &&
+       !sel.do_optimize_extrinsics      && !sel.do_optimize_frames &&
+       !sel.do_optimize_calobject_warp)
+        fprintf(stderr, "mrcal_amd: Warning: Not optimizing any of our variables\n");
+
+    mrcal_amd_problem_t* P =
+        mrcal_amd_problem_create(intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp,
+                                 Ncameras_intrinsics, Ncameras_extrinsics, Nframes,
+                                 Npoints, Npoints_fixed,
+                                 observations_board, observations_point,
+                                 Nobservations_board, Nobservations_point,
+                                 observations_point_triangulated, Nobservations_point_triangulated,
+                                 observations_board_pool, observations_point_pool,
+                                 lensmodel, imagersizes, sel,
+                                 calibration_object_spacing,
+                                 calibration_object_width_n, calibration_object_height_n,
+                                 0, -1, true);
+    if(P == NULL) return failed;
+
+    mrcal_stats_t stats = failed;
+    const int Nstate = P->L.Nstate, Nmeas = P->L.Nmeas;
+    std::vector<double> b(Nstate > 0 ? Nstate : 1);
+    int Noutliers = 0;
+    double rms;
+
+    if(b_packed != NULL && buffer_size_b_packed != Nstate*(int)sizeof(double))
+    {
+        set_error("The buffer passed to fill-in b_packed_final has the wrong size. Needed exactly %d bytes, but got %d bytes",
+                  Nstate*(int)sizeof(double), buffer_size_b_packed);
+        goto done;
+    }
+    if(x != NULL && buffer_size_x != Nmeas*(int)sizeof(double))
+    {
+        set_error("The buffer passed to fill-in x_final has the wrong size. Needed exactly %d bytes, but got %d bytes",
+                  Nmeas*(int)sizeof(double), buffer_size_x);
+        goto done;
+    }
+    if(Nmeas <= Nstate)
+        fprintf(stderr, "mrcal_amd: WARNING: problem isn't overdetermined: Nmeasurements=%d, Nstate=%d. Solver may not converge, and if it does, the results aren't reliable\n",
+                Nmeas, Nstate);
+
+    // input outliers count even if nothing new is found (mrcal.c:6418-6421)
+    for(int i=0; i<P->L.Nmeas_boards/2; i++)
+        if(observations_board_pool[i].z < 0.0) Noutliers++;
+
+    {
+        int Nout_solve = 0;
+        rms = mrcal_amd_problem_solve(P, 0, &Nout_solve);
+        if(rms < 0.0) goto done;
+        if(sel.do_apply_outlier_rejection) Noutliers = Nout_solve;
+    }
+
+    if(!mrcal_amd_problem_get_b_packed(P, b.data())) goto done;
+    unpack_state_to_arrays(b.data(), P->L, intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp);
+    if(b_packed) memcpy(b_packed, b.data(), (size_t)Nstate*sizeof(double));
+    if(x && !mrcal_amd_problem_get_x(P, x)) goto done;
+    // new outliers are reported by negated weights in the caller's array
+    if(sel.do_apply_outlier_rejection && P->stats.Noutlier_passes > 0)
+        if(!mrcal_amd_problem_get_board_pool(P, observations_board_pool)) goto done;
+
+    stats.rms_reproj_error__pixels     = rms;
+    stats.Noutliers_board              = Noutliers;
+    stats.Noutliers_triangulated_point = 0;
+
+ done:
+    mrcal_amd_problem_destroy(P);
+    return stats;
 }
+
+} // extern "C"

@@ -1,0 +1,170 @@
+"""Resident tier: a calibration problem held in HBM across evaluations and
+solver steps (include/mrcal_amd.h, mrcal_amd_problem_*). This is what the
+benchmark and the multi-GPU driver use; optimize()/optimizer_callback() are the
+one-shot forms of the same thing.
+"""
+import ctypes as C
+import numpy as np
+
+from ._cabi import _ptr, Lensmodel, ProblemSelections
+
+
+class Problem:
+    """One optimization problem (or one frame-shard of it) resident on the
+    current HIP device.
+
+        p = Problem(**optimization_inputs)
+        p.evaluate()                 # x, J at the resident packed state
+        x = p.x()                    # host copies on demand
+    """
+
+    def __init__(self, _shard=(0,-1), _leader=True, **optimization_inputs):
+        from . import _api, _lib
+        self._api = _api
+        self._lib = _lib.lib
+        self._declare()
+        p = _api._ingest(optimization_inputs, callback=False)
+        self._inputs = p   # keeps the numpy arrays alive
+        a = _api._common_args(p)
+        # common args: ..., lensmodel, imagersizes, sel, problem_constants, spacing, W, H, verbose
+        self.handle = self._lib.mrcal_amd_problem_create(
+            *a[:18], a[18], a[19], a[20], a[22], a[23], a[24],
+            int(_shard[0]), int(_shard[1]), bool(_leader))
+        if not self.handle:
+            raise RuntimeError("mrcal_amd_problem_create() failed:" + _api._last_error())
+        self.Nstate = self._lib.mrcal_amd_problem_Nstate(self.handle)
+        self.Nmeas  = self._lib.mrcal_amd_problem_Nmeasurements(self.handle)
+        self.Nnz    = self._lib.mrcal_amd_problem_Nnz(self.handle)
+
+    def _declare(self):
+        L = self._lib
+        if getattr(L, "_mrcal_amd_resident_declared", False):
+            return
+        vp = C.c_void_p
+        L.mrcal_amd_problem_create.restype  = vp
+        L.mrcal_amd_problem_create.argtypes = [
+            vp, vp, vp, vp, vp,
+            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+            vp, vp, C.c_int, C.c_int,
+            vp, C.c_int,
+            vp, vp,
+            C.POINTER(Lensmodel), vp, ProblemSelections,
+            C.c_double, C.c_int, C.c_int,
+            C.c_int, C.c_int, C.c_bool]
+        L.mrcal_amd_problem_destroy.restype  = None
+        L.mrcal_amd_problem_destroy.argtypes = [vp]
+        for name in ("Nstate", "Nmeasurements"):
+            f = getattr(L, f"mrcal_amd_problem_{name}")
+            f.restype, f.argtypes = C.c_int, [vp]
+        L.mrcal_amd_problem_Nnz.restype, L.mrcal_amd_problem_Nnz.argtypes = C.c_int64, [vp]
+        for name in ("dev_b_packed", "dev_x", "dev_J_rowptr", "dev_J_colidx", "dev_J_values", "stream"):
+            f = getattr(L, f"mrcal_amd_problem_{name}")
+            f.restype, f.argtypes = vp, [vp]
+        L.mrcal_amd_problem_set_b_packed.restype, L.mrcal_amd_problem_set_b_packed.argtypes = C.c_bool, [vp, vp]
+        L.mrcal_amd_problem_get_b_packed.restype, L.mrcal_amd_problem_get_b_packed.argtypes = C.c_bool, [vp, vp]
+        L.mrcal_amd_problem_get_x.restype,        L.mrcal_amd_problem_get_x.argtypes        = C.c_bool, [vp, vp]
+        L.mrcal_amd_problem_get_J.restype,        L.mrcal_amd_problem_get_J.argtypes        = C.c_bool, [vp, vp, vp, vp]
+        L.mrcal_amd_problem_evaluate.restype,     L.mrcal_amd_problem_evaluate.argtypes     = C.c_bool, [vp, C.c_bool, C.c_bool]
+        L.mrcal_amd_problem_last_jacobian_kernel_ms.restype  = C.c_double
+        L.mrcal_amd_problem_last_jacobian_kernel_ms.argtypes = [vp]
+        ip = C.POINTER(C.c_int)
+        dpp = C.POINTER(C.c_double)
+        L.mrcal_amd_problem_solve.restype,     L.mrcal_amd_problem_solve.argtypes     = C.c_double, [vp, C.c_int, ip]
+        L.mrcal_amd_problem_run_steps.restype, L.mrcal_amd_problem_run_steps.argtypes = C.c_int,    [vp, C.c_int, dpp]
+        L.mrcal_amd_problem_solver_stats.restype  = None
+        L.mrcal_amd_problem_solver_stats.argtypes = [vp, ip, ip, ip, ip, dpp, dpp, dpp]
+        L.mrcal_amd_problem_get_normal_equations.restype  = C.c_bool
+        L.mrcal_amd_problem_get_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.mrcal_amd_problem_gauss_newton_step.restype, L.mrcal_amd_problem_gauss_newton_step.argtypes = C.c_bool, [vp, vp]
+        L.mrcal_amd_problem_get_board_pool.restype,    L.mrcal_amd_problem_get_board_pool.argtypes    = C.c_bool, [vp, vp]
+        L._mrcal_amd_resident_declared = True
+
+    def _check(self, ok, what):
+        if not ok:
+            raise RuntimeError(f"{what} failed:" + self._api._last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.mrcal_amd_problem_destroy(self.handle)
+            self.handle = None
+    def __del__(self):
+        try:    self.close()
+        except Exception: pass
+    def __enter__(self): return self
+    def __exit__(self, *a): self.close()
+
+    def evaluate(self, with_jacobian=True, sync=True):
+        self._check(self._lib.mrcal_amd_problem_evaluate(self.handle, with_jacobian, sync), "evaluate")
+
+    def jacobian_kernel_ms(self):
+        return self._lib.mrcal_amd_problem_last_jacobian_kernel_ms(self.handle)
+
+    def set_b_packed(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        assert b.shape == (self.Nstate,)
+        self._check(self._lib.mrcal_amd_problem_set_b_packed(self.handle, _ptr(b)), "set_b_packed")
+
+    def b_packed(self):
+        b = np.empty((self.Nstate,), dtype=np.float64)
+        self._check(self._lib.mrcal_amd_problem_get_b_packed(self.handle, _ptr(b)), "get_b_packed")
+        return b
+
+    def x(self):
+        x = np.empty((self.Nmeas,), dtype=np.float64)
+        self._check(self._lib.mrcal_amd_problem_get_x(self.handle, _ptr(x)), "get_x")
+        return x
+
+    def J(self):
+        import scipy.sparse
+        P = np.empty((self.Nmeas+1,), dtype=np.int32)
+        I = np.empty((self.Nnz,),     dtype=np.int32)
+        X = np.empty((self.Nnz,),     dtype=np.float64)
+        self._check(self._lib.mrcal_amd_problem_get_J(self.handle, _ptr(P), _ptr(I), _ptr(X)), "get_J")
+        return scipy.sparse.csr_matrix((X, I, P), shape=(self.Nmeas, self.Nstate))
+
+    def stream(self):
+        return self._lib.mrcal_amd_problem_stream(self.handle)
+
+    # ---------------------------------------------------------------- solver
+    def solve(self, max_iterations=0):
+        """the whole solve (dog leg + outlier rejection); returns a stats dict.
+        The solution stays resident: b_packed(), x()"""
+        nout = C.c_int(0)
+        rms = self._lib.mrcal_amd_problem_solve(self.handle, int(max_iterations), C.byref(nout))
+        if rms < 0:
+            raise RuntimeError("mrcal_amd_problem_solve() failed:" + self._api._last_error())
+        st = self.solver_stats()
+        st.update(rms_reproj_error__pixels=rms, Noutliers_board=nout.value)
+        return st
+
+    def run_steps(self, Nsteps, trustregion=None):
+        """exactly Nsteps dog-leg steps; returns (steps done, trust region)"""
+        tr = C.c_double(-1.0 if trustregion is None else float(trustregion))
+        n = self._lib.mrcal_amd_problem_run_steps(self.handle, int(Nsteps), C.byref(tr))
+        if n < 0:
+            raise RuntimeError("mrcal_amd_problem_run_steps() failed:" + self._api._last_error())
+        return n, tr.value
+
+    def solver_stats(self):
+        i = [C.c_int(0) for _ in range(4)]
+        d = [C.c_double(0) for _ in range(3)]
+        self._lib.mrcal_amd_problem_solver_stats(self.handle, *[C.byref(v) for v in i], *[C.byref(v) for v in d])
+        return dict(Niterations=i[0].value, Nevaluations=i[1].value, Nfactorizations=i[2].value,
+                    Noutlier_passes=i[3].value, norm2_x=d[0].value, lambda_=d[1].value, seconds=d[2].value)
+
+    def normal_equations(self):
+        """evaluates at the resident state; returns dict(A,Bt,D,g,norm2_x,+dims)"""
+        dims = (C.c_int*6)()
+        self._check(self._lib.mrcal_amd_problem_get_normal_equations(self.handle, None,None,None,None,None, dims),
+                    "get_normal_equations")
+        Nc, NE, NEb, Nfb, Nie, Nwarp = list(dims)
+        A  = np.zeros((Nc,Nc)); Bt = np.zeros((NE,Nc)); D = np.zeros((NEb,6,6)); g = np.zeros((self.Nstate,))
+        n2 = np.zeros((1,))
+        self._check(self._lib.mrcal_amd_problem_get_normal_equations(self.handle, _ptr(A), _ptr(Bt), _ptr(D), _ptr(g), _ptr(n2), dims),
+                    "get_normal_equations")
+        return dict(A=A, Bt=Bt, D=D, g=g, norm2_x=n2[0], Nc=Nc, NE=NE, NEb=NEb, Nfb=Nfb, Nie=Nie, Nwarp=Nwarp)
+
+    def gauss_newton_step(self):
+        d = np.zeros((self.Nstate,))
+        self._check(self._lib.mrcal_amd_problem_gauss_newton_step(self.handle, _ptr(d)), "gauss_newton_step")
+        return d
