@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the optimize() hot path on MI355X.
+
+Metric (BASELINE.json): dog-leg ("LM") iterations per second on the 8-camera x
+1000-frame OPENCV8 chessboard calibration, plus the wall-clock of one full solve.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+           --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one dog-leg step of the solver on the whole problem: evaluation of
+all residuals x and of the CSR Jacobian J at the trial state (written to HBM in
+the reference's layout), Jt x and the block normal equations, the
+Schur-complement Cholesky factorization when the trust region asks for the
+Gauss-Newton step, step selection and the accept/reject test. That is what one
+iteration of libdogleg costs the reference (one optimizer_callback() + one
+CHOLMOD factorize/solve). The timed region starts with everything resident in
+HBM; steps continue the solve from the seed (no artificial repetition of a
+converged state).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus",   type=int, default=1)
+    ap.add_argument("--steps",  type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cameras", type=int, default=8)
+    ap.add_argument("--frames",  type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-iterations", type=int, default=3)
+    ap.add_argument("--no-full-solve", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(oi, Niterations):
+    """The reference's own mrcal_optimize() (its C sources compiled as
+    oracle/_ref/libmrcal_ref.so, driving the restated libdogleg+Cholesky of
+    oracle/dogleg_restated.c), single-threaded like the reference, on the SAME
+    problem, capped at a few iterations so that it finishes in ~10-30 s"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libmrcal_ref.so")
+    if not os.path.exists(path):
+        return None
+    from mrcal_amd._cabi import MrcalLib
+    from mrcal_amd._api  import Api
+    from mrcal_amd.synthetic import copy_inputs
+    ref = Api(MrcalLib(path))
+    oi = copy_inputs(oi)
+    oi["do_apply_outlier_rejection"] = False
+    ref.clib.dogleg_restated_set_max_iterations(int(Niterations))
+    t0 = time.perf_counter()
+    ref.optimize(**oi)
+    dt = time.perf_counter() - t0
+    ref.clib.dogleg_restated_set_max_iterations(0)
+    n = [C.c_int(0) for _ in range(3)]
+    ref.clib.dogleg_restated_last_counts(*[C.byref(v) for v in n])
+    tc, tf = C.c_double(0), C.c_double(0)
+    ref.clib.dogleg_restated_last_timing(C.byref(tc), C.byref(tf))
+    Nsteps, Ncallbacks, Nfact = [v.value for v in n]
+    # a step = one evaluation at a trial point (accepted or not), like ours
+    Ntrials = max(Ncallbacks - 1, 1)
+    return dict(value  = Ntrials/dt,
+                unit   = "iterations/s",
+                cores  = 1,
+                kind   = "reference",
+                sample = f"same problem, first {Nsteps} accepted iterations ({Ntrials} trial steps) of the "
+                         f"reference's mrcal_optimize() + restated libdogleg/CHOLMOD, {dt:.1f} s",
+                seconds = dt,
+                callback_ms_per_evaluation = 1e3*tc.value/max(Ncallbacks,1),
+                factorization_ms_each      = 1e3*tf.value/max(Nfact,1))
+
+
+def main():
+    args = parse_args()
+    rank       = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world      = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")
+
+    import mrcal_amd
+    from mrcal_amd.synthetic import make_calibration_problem
+
+    oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=args.cameras, Nframes=args.frames,
+                                     lensmodel="LENSMODEL_OPENCV8",
+                                     object_width_n=10, object_height_n=10, seed=0)
+    workload = f"{args.cameras} cameras x {args.frames} frames x 10x10 corners, LENSMODEL_OPENCV8, " \
+               "all variables optimized, warp + regularization"
+
+    if world > 1:
+        from mrcal_amd.parallel import ShardedProblem
+        problem = ShardedProblem(**oi)
+        barrier = lambda: (dist.barrier(), torch.cuda.synchronize())
+    else:
+        from mrcal_amd.resident import Problem
+        problem = Problem(**oi)
+        barrier = lambda: torch.cuda.synchronize()
+
+    def sync_all():
+        barrier()
+        problem.synchronize()
+
+    # untimed warmup, then EXACTLY --steps timed steps
+    tr = None
+    if args.warmup > 0:
+        _, tr = problem.run_steps(args.warmup, tr)
+    sync_all()
+    problem.jacobian_timing_begin(2*args.steps + 4)
+    t0 = time.perf_counter()
+    n, tr = problem.run_steps(args.steps, tr)
+    sync_all()
+    dt = time.perf_counter() - t0
+    nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
+    assert n == args.steps
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = problem.solver_stats()
+
+    # the dominant kernel: the board Jacobian build. Algorithmic bytes per
+    # launch: per observation of P corners and k nonzeros per
+    # row, 24 P (read qx,qy,w) + 16 P (write x) + 16 P k (write J values)
+    alg_bytes  = problem.jacobian_algorithmic_bytes()
+    kernel_ms  = ktot_ms/max(nlaunch,1)
+    achieved   = alg_bytes/1e9/(kernel_ms*1e-3) if kernel_ms > 0 else 0.0
+    traffic    = None
+    tpath = os.path.join(ROOT, "profiles", "board_kernel_hbm_traffic.json")
+    if os.path.exists(tpath) and world == 1:
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload_cameras") == args.cameras and tj.get("workload_frames") == args.frames:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = dict(
+        metric  = "LM (dog-leg) iterations/sec, 8-cam x 1000-frame OPENCV8 calibration",
+        value   = args.steps/dt,
+        unit    = "iterations/s",
+        n_gpus  = world,
+        steps   = args.steps,
+        warmup  = args.warmup,
+        ms_per_step = 1e3*dt/args.steps,
+        higher_is_better = True,
+        scaling = "strong",
+        vs_baseline = None,
+        dtype   = "f64",
+        data    = "synthetic",
+        config  = dict(workload = workload,
+                       Nstate = problem.Nstate_global, Nmeasurements = problem.Nmeas_global,
+                       Nnz_J = problem.Nnz_global,
+                       parallelism = "single GPU" if world == 1 else f"frames sharded over {world} GPUs, all-reduce of the reduced normal equations"),
+        roofline = dict(bound = "hbm",
+                        kernel = "board_kernel (residuals + CSR Jacobian + per-observation Gram)",
+                        achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
+                        frac = achieved/HBM_PEAK_GBS,
+                        traffic = traffic,
+                        algorithmic_bytes_per_launch = alg_bytes,
+                        kernel_ms_avg = kernel_ms, kernel_ms_min = kmin_ms, kernel_ms_max = kmax_ms,
+                        launches_timed = nlaunch),
+        solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"]),
+    )
+
+    if rank == 0 and not args.no_full_solve and world == 1:
+        # the second half of the metric: one full solve, seed to return,
+        # outlier rejection included, on a fresh copy
+        from mrcal_amd.resident import Problem
+        p2 = Problem(**oi)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s2 = p2.solve()
+        p2.synchronize()
+        result["full_solve"] = dict(seconds = time.perf_counter() - t0,
+                                    iterations = s2["Niterations"], evaluations = s2["Nevaluations"],
+                                    outlier_passes = s2["Noutlier_passes"],
+                                    rms_reproj_error__pixels = s2["rms_reproj_error__pixels"],
+                                    Noutliers_board = s2["Noutliers_board"])
+        p2.close()
+
+    if rank == 0:
+        cb = None
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(oi, args.cpu_baseline_iterations)
+        result["cpu_baseline"] = cb
+        print(json.dumps(result))
+
+    problem.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

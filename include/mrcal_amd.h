@@ -384,6 +384,12 @@ void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem);
 int     mrcal_amd_problem_Nstate       (const mrcal_amd_problem_t* problem);
 int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* problem);
 int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* problem);
+/* Algorithmic HBM bytes of one launch of the board Jacobian kernel on this
+   problem: per observation of P corners with k nonzeros per row,
+   24 P (read qx,qy,weight) + 16 P (write x) + 16 P k (write J values) */
+int64_t mrcal_amd_problem_jacobian_algorithmic_bytes(const mrcal_amd_problem_t* problem);
+/* waits for everything queued on the problem's stream */
+bool    mrcal_amd_problem_synchronize  (mrcal_amd_problem_t* problem);
 
 /* Device pointers into the problem's resident buffers (valid until destroy):
    the packed state the next evaluation uses, and the outputs of the last
@@ -416,6 +422,14 @@ void* mrcal_amd_problem_stream(mrcal_amd_problem_t* problem);
    Jacobian build), measured with HIP events on the problem's stream.
    Returns milliseconds, <0 if unavailable */
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* problem);
+
+/* Records a HIP event pair around EVERY Jacobian-kernel launch from now on
+   (up to `capacity` launches), on the problem's stream; _end() stops, waits and
+   reports the number of launches and their total/min/max duration (ms). This
+   is how the benchmark measures the dominant kernel over its timed region */
+bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int capacity);
+bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
+                                           double* total_ms, double* min_ms, double* max_ms);
 
 /* The whole solve on a resident problem: dog-leg iterations + outlier
    rejection (if the problem selections ask for it), exactly what

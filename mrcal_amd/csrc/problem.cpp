@@ -64,6 +64,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.r); hipFree(F.status);
     hipFree(d_step); hipFree(d_counts);
     if(h_scalars) hipHostFree(h_scalars);
+    for(hipEvent_t e : ev_pool) hipEventDestroy(e);
     if(ev_j0)  hipEventDestroy(ev_j0);
     if(ev_j1)  hipEventDestroy(ev_j1);
     if(stream) hipStreamDestroy(stream);
@@ -154,9 +155,13 @@ bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool w
 {
     if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
     const EvalBuffers B = P->eval_buffers(i, with_normal);
-    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream,
-                            with_jacobian ? P->ev_j0 : NULL,
-                            with_jacobian ? P->ev_j1 : NULL),
+    hipEvent_t e0 = with_jacobian ? P->ev_j0 : NULL, e1 = with_jacobian ? P->ev_j1 : NULL;
+    if(with_jacobian && P->ev_pool_enabled && P->ev_pool_used + 2 <= (int)P->ev_pool.size())
+    {
+        e0 = P->ev_pool[P->ev_pool_used++];
+        e1 = P->ev_pool[P->ev_pool_used++];
+    }
+    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream, e0, e1),
             return false);
     P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0;
     if(with_normal)
@@ -310,6 +315,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         innz  += (int64_t)2*NPTS*m.nnz_per_row;
         if(m.nnz_per_row > kmax) kmax = m.nnz_per_row;
     }
+    // per board observation 24 P (read qx,qy,w) + 16 P (write x) + 16 P k (write J values)
+    P->board_alg_bytes = (int64_t)Nboard_local*NPTS*(24 + 16) + innz*8;
     std::vector<PointObsMeta> pmeta(Npoint_local);
     for(int j=0; j<Npoint_local; j++)
     {
@@ -467,6 +474,12 @@ void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem)
 int     mrcal_amd_problem_Nstate       (const mrcal_amd_problem_t* p) { return p->L.Nstate; }
 int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* p) { return p->L.Nmeas;  }
 int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* p) { return p->Nnz;      }
+int64_t mrcal_amd_problem_jacobian_algorithmic_bytes(const mrcal_amd_problem_t* p) { return p->board_alg_bytes; }
+bool    mrcal_amd_problem_synchronize  (mrcal_amd_problem_t* p)
+{
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
 
 double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* p) { return p->op[p->icur].b;  }
 double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* p) { return p->op[p->icur].x;  }
@@ -506,6 +519,42 @@ bool mrcal_amd_problem_evaluate(mrcal_amd_problem_t* p, bool with_jacobian, bool
 {
     if(!problem_evaluate_op(p, p->icur, with_jacobian, false)) return false;
     if(sync) HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    return true;
+}
+
+// Starts (capacity>0) or stops (capacity<=0) recording one HIP event pair
+// around every Jacobian-kernel launch on the problem's stream
+bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* p, int capacity)
+{
+    p->ev_pool_used = 0;
+    p->ev_pool_enabled = capacity > 0;
+    while((int)p->ev_pool.size() < 2*capacity)
+    {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e), return false);
+        p->ev_pool.push_back(e);
+    }
+    return true;
+}
+// Collects what was recorded since _begin(): number of launches and their
+// total / min / max duration in ms. Stops the recording
+bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunches,
+                                           double* total_ms, double* min_ms, double* max_ms)
+{
+    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    int n = 0; double tot = 0, mn = 1e300, mx = 0;
+    for(int i=0; i+1<p->ev_pool_used; i+=2)
+    {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i+1]), return false);
+        n++; tot += ms; if(ms < mn) mn = ms; if(ms > mx) mx = ms;
+    }
+    p->ev_pool_enabled = false;
+    p->ev_pool_used = 0;
+    if(Nlaunches) *Nlaunches = n;
+    if(total_ms)  *total_ms  = tot;
+    if(min_ms)    *min_ms    = n ? mn : 0;
+    if(max_ms)    *max_ms    = mx;
     return true;
 }
 

@@ -37,6 +37,7 @@ struct mrcal_amd_problem
     mrcal_amd::DeviceProblem D;
     mrcal_amd::NormalDims    nd;
     int64_t                  Nnz        = 0;
+    int64_t                  board_alg_bytes = 0; // algorithmic HBM bytes of one board-kernel launch
     int                      lds_bytes  = 0;
     std::vector<int>         board_sel;  // global index of each local board observation
     std::vector<double>      b_host;     // the seed, packed
@@ -44,6 +45,10 @@ struct mrcal_amd_problem
     hipStream_t stream = NULL;
     hipEvent_t  ev_j0  = NULL, ev_j1 = NULL;
     bool        have_jacobian_timing = false;
+    // optional: an event pair per Jacobian-kernel launch, to average over a timed region
+    std::vector<hipEvent_t> ev_pool;
+    int         ev_pool_used = 0;
+    bool        ev_pool_enabled = false;
 
     // inputs
     double* d_seed_intrinsics   = NULL;

@@ -35,6 +35,7 @@ class Problem:
         self.Nstate = self._lib.mrcal_amd_problem_Nstate(self.handle)
         self.Nmeas  = self._lib.mrcal_amd_problem_Nmeasurements(self.handle)
         self.Nnz    = self._lib.mrcal_amd_problem_Nnz(self.handle)
+        self.Nstate_global, self.Nmeas_global, self.Nnz_global = self.Nstate, self.Nmeas, self.Nnz
 
     def _declare(self):
         L = self._lib
@@ -57,6 +58,9 @@ class Problem:
             f = getattr(L, f"mrcal_amd_problem_{name}")
             f.restype, f.argtypes = C.c_int, [vp]
         L.mrcal_amd_problem_Nnz.restype, L.mrcal_amd_problem_Nnz.argtypes = C.c_int64, [vp]
+        L.mrcal_amd_problem_jacobian_algorithmic_bytes.restype  = C.c_int64
+        L.mrcal_amd_problem_jacobian_algorithmic_bytes.argtypes = [vp]
+        L.mrcal_amd_problem_synchronize.restype, L.mrcal_amd_problem_synchronize.argtypes = C.c_bool, [vp]
         for name in ("dev_b_packed", "dev_x", "dev_J_rowptr", "dev_J_colidx", "dev_J_values", "stream"):
             f = getattr(L, f"mrcal_amd_problem_{name}")
             f.restype, f.argtypes = vp, [vp]
@@ -77,6 +81,9 @@ class Problem:
         L.mrcal_amd_problem_get_normal_equations.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.mrcal_amd_problem_gauss_newton_step.restype, L.mrcal_amd_problem_gauss_newton_step.argtypes = C.c_bool, [vp, vp]
         L.mrcal_amd_problem_get_board_pool.restype,    L.mrcal_amd_problem_get_board_pool.argtypes    = C.c_bool, [vp, vp]
+        L.mrcal_amd_problem_jacobian_timing_begin.restype,  L.mrcal_amd_problem_jacobian_timing_begin.argtypes = C.c_bool, [vp, C.c_int]
+        L.mrcal_amd_problem_jacobian_timing_end.restype  = C.c_bool
+        L.mrcal_amd_problem_jacobian_timing_end.argtypes = [vp, ip, dpp, dpp, dpp]
         L._mrcal_amd_resident_declared = True
 
     def _check(self, ok, what):
@@ -98,6 +105,22 @@ class Problem:
 
     def jacobian_kernel_ms(self):
         return self._lib.mrcal_amd_problem_last_jacobian_kernel_ms(self.handle)
+
+    def synchronize(self):
+        self._check(self._lib.mrcal_amd_problem_synchronize(self.handle), "synchronize")
+
+    def jacobian_algorithmic_bytes(self):
+        return int(self._lib.mrcal_amd_problem_jacobian_algorithmic_bytes(self.handle))
+
+    def jacobian_timing_begin(self, capacity):
+        self._check(self._lib.mrcal_amd_problem_jacobian_timing_begin(self.handle, int(capacity)), "jacobian_timing_begin")
+
+    def jacobian_timing_end(self):
+        """(Nlaunches, total_ms, min_ms, max_ms) of the Jacobian kernel since _begin()"""
+        n = C.c_int(0); t = C.c_double(0); mn = C.c_double(0); mx = C.c_double(0)
+        self._check(self._lib.mrcal_amd_problem_jacobian_timing_end(self.handle, C.byref(n), C.byref(t), C.byref(mn), C.byref(mx)),
+                    "jacobian_timing_end")
+        return n.value, t.value, mn.value, mx.value
 
     def set_b_packed(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

@@ -50,6 +50,27 @@
 #define SAY(fmt, ...) fprintf(stderr, "dogleg_restated: " fmt "\n", ##__VA_ARGS__)
 
 static int last_Nsteps, last_Ncallbacks, last_Nfactorizations;
+
+// Oracle-only knob (not in libdogleg): caps the iterations of every
+// subsequent dogleg_optimize2() call regardless of what the caller asked for,
+// so that the benchmark's CPU baseline can time a BOUNDED number of the
+// reference's iterations at full problem size. <=0: no cap
+static int max_iterations_override = 0;
+void dogleg_restated_set_max_iterations(int n) { max_iterations_override = n; }
+// accumulated wall-clock seconds spent inside the callback / the factorization
+static double seconds_callback, seconds_factorization;
+void dogleg_restated_last_timing(double* callback, double* factorization)
+{
+    if(callback)      *callback      = seconds_callback;
+    if(factorization) *factorization = seconds_factorization;
+}
+#include <time.h>
+static double now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9*(double)ts.tv_nsec;
+}
 void dogleg_restated_last_counts(int* Nsteps, int* Ncallbacks, int* Nfactorizations)
 {
     if(Nsteps)          *Nsteps          = last_Nsteps;
@@ -499,7 +520,9 @@ static bool computeCallbackOperatingPoint(dogleg_operatingPoint_t* point, dogleg
     ctx->Ncallbacks++;
     if(ctx->is_sparse)
     {
+        const double t0 = now();
         (*ctx->f)(point->p, point->x, point->Jt, ctx->cookie);
+        seconds_callback += now() - t0;
         const int*    P = (const int*)   point->Jt->p;
         const int*    I = (const int*)   point->Jt->i;
         const double* X = (const double*)point->Jt->x;
@@ -558,6 +581,7 @@ static void computeGaussNewtonUpdate(dogleg_operatingPoint_t* point, dogleg_solv
         while(1)
         {
             bool ok;
+            const double t0 = now();
             ctx->Nfactorizations++;
             if(ctx->is_sparse)
             {
@@ -586,6 +610,7 @@ static void computeGaussNewtonUpdate(dogleg_operatingPoint_t* point, dogleg_solv
                     }
                 ok = dense_cholesky(A, n);
             }
+            seconds_factorization += now() - t0;
             if(ok) break;
 
             // singular JtJ. Raise lambda and go again
@@ -708,7 +733,10 @@ static int runOptimizer(dogleg_solverContext_t* ctx)
 
     ctx->factorization_valid = 0;
 
-    while(stepCount < P->max_iterations)
+    const int max_iterations =
+        (max_iterations_override > 0 && max_iterations_override < P->max_iterations) ?
+        max_iterations_override : P->max_iterations;
+    while(stepCount < max_iterations)
     {
         while(1)
         {
@@ -767,7 +795,7 @@ static int runOptimizer(dogleg_solverContext_t* ctx)
         }
         stepCount++;
     }
-    if(P->dogleg_debug && stepCount == P->max_iterations)
+    if(P->dogleg_debug && stepCount == max_iterations)
         SAY("Exceeded max number of iterations");
 
  done:
@@ -794,6 +822,7 @@ static double optimize_generic(double* p, int Nstate, int Nmeas, int NJnnz, int 
     ctx->afterStep     = allocOperatingPoint(Nstate, Nmeas, NJnnz, is_sparse);
 
     memcpy(ctx->beforeStep->p, p, Nstate*sizeof(double));
+    if(is_sparse) seconds_callback = seconds_factorization = 0.0;
     ctx->Nsteps = runOptimizer(ctx);
     memcpy(p, ctx->beforeStep->p, Nstate*sizeof(double));
 

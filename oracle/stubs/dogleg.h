@@ -128,6 +128,12 @@ void   dogleg_testGradient(unsigned int var, const double* p0,
 // dogleg_optimize2() call, so that the harness can report iterations/sec
 void   dogleg_restated_last_counts(int* Nsteps, int* Ncallbacks, int* Nfactorizations);
 
+// Oracle-only: cap on the iterations of every subsequent dogleg_optimize2()
+// (<=0: none), and the seconds the last sparse solve spent in the callback and
+// in the factorization. For the benchmark's bounded CPU baseline
+void   dogleg_restated_set_max_iterations(int n);
+void   dogleg_restated_last_timing(double* callback, double* factorization);
+
 // Oracle-only: factor JtJ (given Jt as CSC, i.e. J as CSR) and solve
 // JtJ x = b for Nrhs right-hand sides stored row-first in b (Nrhs,Nstate);
 // the solve happens in place. Returns false if JtJ is not positive definite.
