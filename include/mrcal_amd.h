@@ -431,6 +431,44 @@ bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int c
 bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
                                            double* total_ms, double* min_ms, double* max_ms);
 
+/* ---- Phase API: the pieces of one dog-leg step ---------------------------
+   For the multi-GPU driver (one process per GPU, observations sharded by
+   frame): it runs these phases on every rank and all-reduces (RCCL) the
+   buffers in between. All phases are queued on the problem's stream and do not
+   synchronize with the host. iop in {0,1} selects one of the two operating
+   points (libdogleg's beforeStep/afterStep).
+
+     phase_evaluate(iop)        x, J, this shard's blocks of JtJ, its part of
+                                g = Jt x (BUF_G) and of |x|^2 (BUF_SCALARS[0])
+     phase_quadform(iop,v,out)  *out += v^T (local JtJ) v
+     phase_factor_local(iop,l)  factor the local frame/point blocks; this shard's
+                                summand of the Schur complement and of the reduced
+                                rhs in BUF_SCHUR = [S (Nc*Nc) | r (Nc)]
+     phase_solve_backsub(iop)   Cholesky of BUF_SCHUR (after its all-reduce),
+                                d_S, and the local frame/point steps, into
+                                BUF_STEP_GN (other shards' frame entries stay 0)
+*/
+enum
+{
+    MRCAL_AMD_BUF_B = 0, MRCAL_AMD_BUF_X, MRCAL_AMD_BUF_G,
+    MRCAL_AMD_BUF_STEP_CAUCHY, MRCAL_AMD_BUF_STEP_GN, MRCAL_AMD_BUF_SCALARS,
+    MRCAL_AMD_BUF_STEP, MRCAL_AMD_BUF_SCHUR, MRCAL_AMD_BUF_STATUS
+};
+/* device pointer + element count of a solver buffer (doubles; BUF_STATUS: int) */
+void* mrcal_amd_problem_buffer(mrcal_amd_problem_t* problem, int which, int iop, int64_t* Nelements);
+/* info[8] = { Nstate, Nie, NE, Nc, frame_lo, frame_hi, is_leader, Ncorners_local }.
+   State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames+points, then the warp */
+void  mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info);
+bool  mrcal_amd_problem_phase_evaluate     (mrcal_amd_problem_t* problem, int iop);
+bool  mrcal_amd_problem_phase_quadform     (mrcal_amd_problem_t* problem, int iop, const double* v_dev, double* out_dev);
+bool  mrcal_amd_problem_phase_factor_local (mrcal_amd_problem_t* problem, int iop, double lambda);
+bool  mrcal_amd_problem_phase_solve_backsub(mrcal_amd_problem_t* problem, int iop);
+bool  mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* problem, int iop, double thresh_sq,
+                                            int* counts_dev, double* sums_dev);
+bool  mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* problem, int iop, double thresh_sq, int* counts_dev);
+/* which operating point get_b_packed()/get_x()/get_J() read */
+void  mrcal_amd_problem_set_current(mrcal_amd_problem_t* problem, int iop);
+
 /* The whole solve on a resident problem: dog-leg iterations + outlier
    rejection (if the problem selections ask for it), exactly what
    mrcal_optimize() does between packing and unpacking the state. Returns the

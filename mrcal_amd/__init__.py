@@ -14,6 +14,16 @@ raise.
 """
 import os as _os
 
+# ONE HIP runtime per process. torch ships its own libamdhip64 (soname
+# libamdhip64.so.7, like /opt/rocm's); whichever is loaded first serves
+# libmrcal_amd.so too, but only if torch comes first: loaded after us, torch
+# brings up a second runtime that finds no GPU. The multi-GPU path needs torch
+# (RCCL via torch.distributed), so load it before the library
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:         # the C ABI and the single-GPU path do not need it
+    _torch = None
+
 from ._cabi import MrcalLib as _MrcalLib
 from ._api  import Api as _Api, optimization_inputs_known_keys as _optimization_inputs_known_keys
 

@@ -61,7 +61,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
     }
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.r); hipFree(F.status);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.status);
     hipFree(d_step); hipFree(d_counts);
     if(h_scalars) hipHostFree(h_scalars);
     for(hipEvent_t e : ev_pool) hipEventDestroy(e);
@@ -97,12 +97,21 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->F.Wt, (size_t)nd.NE*nd.Nc);
     ok = ok && dev_alloc(&P->F.LD, (size_t)nd.NEb*36);
     ok = ok && dev_alloc(&P->F.y,  (size_t)nd.NE);
-    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc);
-    ok = ok && dev_alloc(&P->F.r,  (size_t)nd.Nc);
+    // S and r contiguous: one all-reduce moves both
+    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc);
+    P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
     ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
     ok = ok && dev_alloc(&P->d_counts, 4);
     if(!ok) return false;
+    // rows of blocks this shard does not own are never written: they must read as 0
+    HIP_TRY(hipMemset(P->F.Wt, 0, (size_t)(nd.NE*nd.Nc > 0 ? nd.NE*nd.Nc : 1)*sizeof(double)), return false);
+    HIP_TRY(hipMemset(P->F.y,  0, (size_t)(nd.NE > 0 ? nd.NE : 1)*sizeof(double)), return false);
+    for(int i=0;i<2;i++)
+    {
+        HIP_TRY(hipMemset(P->op[i].step_gn,     0, (size_t)nd.Nstate*sizeof(double)), return false);
+        HIP_TRY(hipMemset(P->op[i].step_cauchy, 0, (size_t)nd.Nstate*sizeof(double)), return false);
+    }
     HIP_TRY(hipHostMalloc((void**)&P->h_scalars, 64*sizeof(double)), return false);
 
     // assembly work lists. Observations of one frame are contiguous; the
@@ -402,6 +411,15 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         nd.Nfb          = L.Nstate_frames/6;
         nd.Npb          = L.Nstate_points/3;
         nd.NEb          = nd.Nfb + nd.Npb;
+        P->is_leader    = is_shard_leader;
+        P->br.frame_lo  = 0;  P->br.frame_hi = nd.Nfb;
+        if(sharded && nd.Nfb > 0)
+        {
+            P->br.frame_lo = shard_begin_frame < 0 ? 0 : shard_begin_frame;
+            P->br.frame_hi = (shard_end_frame < 0 || shard_end_frame > Nframes) ? Nframes : shard_end_frame;
+        }
+        P->br.point_lo  = nd.Nfb;
+        P->br.point_hi  = is_shard_leader ? nd.NEb : nd.Nfb;
     }
 
     DeviceProblem& D = P->D;

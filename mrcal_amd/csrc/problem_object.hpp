@@ -36,6 +36,8 @@ struct mrcal_amd_problem
     mrcal_amd::Layout        L;          // state layout global, measurement layout local to the shard
     mrcal_amd::DeviceProblem D;
     mrcal_amd::NormalDims    nd;
+    mrcal_amd::BlockRanges   br = {0,0,0,0};   // the E blocks this shard owns
+    bool                     is_leader = true;
     int64_t                  Nnz        = 0;
     int64_t                  board_alg_bytes = 0; // algorithmic HBM bytes of one board-kernel launch
     int                      lds_bytes  = 0;

@@ -19,6 +19,7 @@
 #include <chrono>
 #include "host_state.hpp"
 #include "problem_object.hpp"
+#include "../../include/mrcal_amd.h"
 
 using namespace mrcal_amd;
 
@@ -86,7 +87,7 @@ bool compute_gauss_newton(mrcal_amd_problem* P, int i)
     for(;;)
     {
         P->stats.Nfactorizations++;
-        HIP_TRY(launch_factor_and_solve(P->nd, op.N, P->F, P->stats.lambda, op.step_gn, P->stream), return false);
+        HIP_TRY(launch_factor_and_solve(P->nd, P->br, op.N, P->F, P->stats.lambda, op.step_gn, P->stream), return false);
         HIP_TRY(hipMemsetAsync(&op.N.scalars[SC_TMP0], 0, sizeof(double), P->stream), return false);
         HIP_TRY(launch_dot(P->nd.Nstate, op.step_gn, op.step_gn, &op.N.scalars[SC_TMP0], P->stream), return false);
         int status = 0;
@@ -370,6 +371,79 @@ bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* P, double* step)
     HIP_TRY(hipStreamSynchronize(P->stream), return false);
     return true;
 }
+
+////////////////////////////////////////////////////////////////////////////////
+// Phase API: the pieces of one dog-leg step, for the multi-GPU driver
+// (mrcal_amd/parallel.py), which interleaves them with RCCL all-reduces of the
+// buffers exposed by mrcal_amd_problem_buffer(). Everything is queued on the
+// problem's stream; nothing here synchronizes with the host
+////////////////////////////////////////////////////////////////////////////////
+void* mrcal_amd_problem_buffer(mrcal_amd_problem_t* P, int which, int iop, int64_t* Nelements)
+{
+    if(!problem_prepare_solver(P)) return NULL;
+    const NormalDims& nd = P->nd;
+    mrcal_amd_oppoint& op = P->op[iop & 1];
+    void* p = NULL; int64_t n = 0;
+    switch(which)
+    {
+    case MRCAL_AMD_BUF_B:           p = op.b;           n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_X:           p = op.x;           n = P->L.Nmeas; break;
+    case MRCAL_AMD_BUF_G:           p = op.N.g;         n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_STEP_CAUCHY: p = op.step_cauchy; n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_STEP_GN:     p = op.step_gn;     n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_SCALARS:     p = op.N.scalars;   n = NSCALARS;  break;
+    case MRCAL_AMD_BUF_STEP:        p = P->d_step;      n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_SCHUR:       p = P->F.S;         n = (int64_t)nd.Nc*nd.Nc + nd.Nc; break;
+    case MRCAL_AMD_BUF_STATUS:      p = P->F.status;    n = 1; break;
+    default: set_error("unknown buffer %d", which);
+    }
+    if(Nelements) *Nelements = n;
+    return p;
+}
+void mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info)
+{
+    info[0] = P->nd.Nstate; info[1] = P->nd.Nie; info[2] = P->nd.NE; info[3] = P->nd.Nc;
+    info[4] = P->br.frame_lo; info[5] = P->br.frame_hi; info[6] = P->is_leader ? 1 : 0;
+    info[7] = P->D.Nobs_board * P->D.W * P->D.H;
+}
+bool mrcal_amd_problem_phase_evaluate(mrcal_amd_problem_t* P, int iop)
+{
+    if(!problem_prepare_solver(P)) return false;
+    return problem_evaluate_op(P, iop & 1, true, true);
+}
+bool mrcal_amd_problem_phase_quadform(mrcal_amd_problem_t* P, int iop, const double* v_dev, double* out_dev)
+{
+    HIP_TRY(launch_quadform(P->nd, P->op[iop & 1].N, v_dev, out_dev, P->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_phase_factor_local(mrcal_amd_problem_t* P, int iop, double lambda)
+{
+    P->stats.Nfactorizations++;
+    HIP_TRY(launch_factor_local(P->nd, P->br, P->op[iop & 1].N, P->F, lambda, P->is_leader, P->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_phase_solve_backsub(mrcal_amd_problem_t* P, int iop)
+{
+    HIP_TRY(launch_solve_backsub(P->nd, P->br, P->F, P->op[iop & 1].step_gn, P->stream), return false);
+    return true;
+}
+// outlier statistics / marking on the local board observations
+// (mrcal.c:3978-4402). counts (device int[4]) and sums (device double[1]) are
+// accumulated into, not cleared
+bool mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* P, int iop, double thresh_sq,
+                                           int* counts_dev, double* sums_dev)
+{
+    const int Npts = P->D.Nobs_board * P->D.W * P->D.H;
+    HIP_TRY(launch_outlier_stats(Npts, thresh_sq, P->op[iop & 1].x, P->d_board_pool, counts_dev, sums_dev, P->stream), return false);
+    return true;
+}
+bool mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* P, int iop, double thresh_sq, int* counts_dev)
+{
+    const int Npts = P->D.Nobs_board * P->D.W * P->D.H;
+    HIP_TRY(launch_mark_outliers(Npts, thresh_sq, P->op[iop & 1].x, P->d_board_pool, counts_dev, P->stream), return false);
+    return true;
+}
+void mrcal_amd_problem_set_current(mrcal_amd_problem_t* P, int iop) { P->icur = iop & 1; }
 
 // copies the (possibly outlier-marked) board observation pool back
 bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* P, mrcal_point3_t* pool_local)

@@ -228,14 +228,14 @@ void rows_generic_kernel(NormalDims nd, int row0, int row1,
 // One workgroup per E block: L L^T = D_e + lambda I;  Wt_e = L^-1 Bt_e;  y_e = L^-1 g_e.
 // status[0] is set to 1 if any block is not positive definite
 __global__ __launch_bounds__(64)
-void eblock_factor_kernel(NormalDims nd, double lambda,
+void eblock_factor_kernel(NormalDims nd, BlockRanges br, double lambda,
                           const double* __restrict__ Bt, const double* __restrict__ D,
                           const double* __restrict__ g,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
                           int* __restrict__ status)
 {
     __shared__ double L[36];
-    const int blk = blockIdx.x;
+    const int blk = br.block(blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
     const int t   = threadIdx.x;
@@ -281,7 +281,7 @@ void eblock_factor_kernel(NormalDims nd, double lambda,
 
 // S = A + lambda I ;  r = g_S.  The SYRK then subtracts Wt^T Wt and Wt^T y
 __global__ __launch_bounds__(256)
-void schur_init_kernel(NormalDims nd, double lambda,
+void schur_init_kernel(NormalDims nd, double lambda, int with_rhs,
                        const double* __restrict__ A, const double* __restrict__ g,
                        double* __restrict__ S, double* __restrict__ r)
 {
@@ -295,7 +295,7 @@ void schur_init_kernel(NormalDims nd, double lambda,
     if(idx < (size_t)nd.Nc)
     {
         const int i = (int)idx;
-        r[i] = g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)];
+        r[i] = with_rhs ? g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0;
     }
 }
 
@@ -304,14 +304,14 @@ void schur_init_kernel(NormalDims nd, double lambda,
 // skipped; the lower triangle is mirrored by the last step of the Cholesky
 #define SYRK_TILE 32
 __global__ __launch_bounds__(256)
-void schur_syrk_kernel(NormalDims nd, int e_per_slice,
+void schur_syrk_kernel(NormalDims nd, int e_lo, int e_hi, int e_per_slice,
                        const double* __restrict__ Wt, const double* __restrict__ y,
                        double* __restrict__ S, double* __restrict__ r)
 {
     const int bi = blockIdx.x, bj = blockIdx.y;
     if(bj < bi) return;
-    const int e_begin = blockIdx.z*e_per_slice;
-    const int e_end   = min(nd.NE, e_begin + e_per_slice);
+    const int e_begin = e_lo + blockIdx.z*e_per_slice;
+    const int e_end   = min(e_hi, e_begin + e_per_slice);
     if(e_begin >= e_end) return;
 
     __shared__ double Wi[16][SYRK_TILE+1];
@@ -476,20 +476,20 @@ void schur_cholesky_solve_kernel(int n, double* __restrict__ S, double* __restri
 
 // d_e = -L^-T (y_e + Wt_e d_s);  also scatters d_s into the state-ordered step
 __global__ __launch_bounds__(64)
-void backsub_kernel(NormalDims nd,
+void backsub_kernel(NormalDims nd, BlockRanges br,
                     const double* __restrict__ Wt, const double* __restrict__ LD,
                     const double* __restrict__ y, const double* __restrict__ ds,
                     double* __restrict__ step)
 {
-    const int blk = blockIdx.x;
     const int t   = threadIdx.x;
-    if(blk == nd.NEb)
+    if((int)blockIdx.x == br.count())
     {
         // the extra block copies d_s
         for(int i=t;i<nd.Nc;i+=blockDim.x)
             step[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = ds[i];
         return;
     }
+    const int blk = br.block(blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
     __shared__ double red[6][64];
@@ -665,31 +665,48 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
     return hipGetLastError();
 }
 
-hipError_t launch_factor_and_solve(const NormalDims& nd, const NormalBuffers& N, const FactorBuffers& F,
-                                   double lambda, double* step_gn, hipStream_t stream)
+// Phase 1 of the Gauss-Newton solve, local to a shard: factor the local E
+// blocks and form this shard's contribution to the Schur complement and to
+// the reduced right-hand side: S_loc = A_loc (+ lambda I) - sum_local Wt^T Wt,
+// r_loc = (g_S) - sum_local Wt^T y. The "(...)" terms are added by the shard
+// leader only, so that the sum over shards has them once
+hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
+                               const NormalBuffers& N, const FactorBuffers& F,
+                               double lambda, bool is_leader, hipStream_t stream)
 {
     hipError_t e;
     if((e = hipMemsetAsync(F.status, 0, sizeof(int), stream)) != hipSuccess) return e;
-    if(nd.NEb > 0)
-        hipLaunchKernelGGL(eblock_factor_kernel, dim3(nd.NEb), dim3(64), 0, stream,
-                           nd, lambda, N.Bt, N.D, N.g, F.Wt, F.LD, F.y, F.status);
+    if(br.count() > 0)
+        hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
+                           nd, br, lambda, N.Bt, N.D, N.g, F.Wt, F.LD, F.y, F.status);
     {
         const size_t n2 = (size_t)nd.Nc*nd.Nc;
         hipLaunchKernelGGL(schur_init_kernel, dim3((unsigned)((n2 + 255)/256)), dim3(256), 0, stream,
-                           nd, lambda, N.A, N.g, F.S, F.r);
+                           nd, is_leader ? lambda : 0.0, is_leader ? 1 : 0, N.A, N.g, F.S, F.r);
     }
-    if(nd.NE > 0)
+    // the E rows of the local blocks: two contiguous ranges (frames, points)
+    for(int part = 0; part < 2; part++)
     {
+        int e_lo, e_hi;
+        br.e_range(nd, part, &e_lo, &e_hi);
+        if(e_hi <= e_lo) continue;
         const int ntile  = (nd.Nc + SYRK_TILE - 1)/SYRK_TILE;
-        // enough slices to fill the machine: ~2k workgroups
         int nslices = 2048 / (ntile*(ntile+1)/2);
         if(nslices < 1) nslices = 1;
-        int e_per_slice = (nd.NE + nslices - 1)/nslices;
+        int e_per_slice = (e_hi - e_lo + nslices - 1)/nslices;
         e_per_slice = ((e_per_slice + 15)/16)*16;
-        nslices = (nd.NE + e_per_slice - 1)/e_per_slice;
+        nslices = (e_hi - e_lo + e_per_slice - 1)/e_per_slice;
         hipLaunchKernelGGL(schur_syrk_kernel, dim3(ntile, ntile, nslices), dim3(256), 0, stream,
-                           nd, e_per_slice, F.Wt, F.y, F.S, F.r);
+                           nd, e_lo, e_hi, e_per_slice, F.Wt, F.y, F.S, F.r);
     }
+    return hipGetLastError();
+}
+
+// Phase 2: dense Cholesky of the (summed) Schur complement, d_S, and the
+// back-substitution of the local E blocks into step_gn
+hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
+                                const FactorBuffers& F, double* step_gn, hipStream_t stream)
+{
     {
         const int n = nd.Nc;
         const size_t lds = ((size_t)n*(n|1) + n)*sizeof(double);
@@ -700,9 +717,25 @@ hipError_t launch_factor_and_solve(const NormalDims& nd, const NormalBuffers& N,
             hipLaunchKernelGGL((schur_cholesky_solve_kernel<false>), dim3(1), dim3(1024), 0, stream,
                                n, F.S, F.r, F.status);
     }
-    hipLaunchKernelGGL(backsub_kernel, dim3(nd.NEb+1), dim3(64), 0, stream,
-                       nd, F.Wt, F.LD, F.y, F.r, step_gn);
+    if(br.count() < nd.NEb && nd.NE > 0)
+    {
+        // a shard writes only its own blocks; the others' entries must be 0 for
+        // the all-reduce that follows (they may hold the previous sum)
+        hipError_t e = hipMemsetAsync(step_gn + nd.Nie, 0, (size_t)nd.NE*sizeof(double), stream);
+        if(e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(backsub_kernel, dim3(br.count()+1), dim3(64), 0, stream,
+                       nd, br, F.Wt, F.LD, F.y, F.r, step_gn);
     return hipGetLastError();
+}
+
+hipError_t launch_factor_and_solve(const NormalDims& nd, const BlockRanges& br,
+                                   const NormalBuffers& N, const FactorBuffers& F,
+                                   double lambda, double* step_gn, hipStream_t stream)
+{
+    hipError_t e = launch_factor_local(nd, br, N, F, lambda, true, stream);
+    if(e != hipSuccess) return e;
+    return launch_solve_backsub(nd, br, F, step_gn, stream);
 }
 
 hipError_t launch_quadform(const NormalDims& nd, const NormalBuffers& N, const double* v, double* out,

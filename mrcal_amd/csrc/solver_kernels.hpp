@@ -22,6 +22,26 @@ struct NormalDims
     int NEb;          // Nfb + Npb
 };
 
+// The E blocks a shard owns: a contiguous range of frame blocks plus (on the
+// shard leader) all the point blocks
+struct BlockRanges
+{
+    int frame_lo, frame_hi;   // frame blocks [lo,hi)
+    int point_lo, point_hi;   // point blocks, as block indices (>= Nfb)
+    __host__ __device__ int count() const { return (frame_hi - frame_lo) + (point_hi - point_lo); }
+    __host__ __device__ int block(int i) const
+    {
+        const int nf = frame_hi - frame_lo;
+        return (i < nf) ? frame_lo + i : point_lo + (i - nf);
+    }
+    // E-row range of part 0 (frames) / 1 (points)
+    __host__ __device__ void e_range(const NormalDims& nd, int part, int* lo, int* hi) const
+    {
+        if(part == 0) { *lo = 6*frame_lo; *hi = 6*frame_hi; }
+        else          { *lo = 6*nd.Nfb + 3*(point_lo - nd.Nfb); *hi = 6*nd.Nfb + 3*(point_hi - nd.Nfb); }
+    }
+};
+
 enum { SC_NORM2_X = 0, SC_NORM2_G, SC_GNG, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, NSCALARS = 8 };
 
 // the normal equations of one operating point, unfactored
@@ -56,7 +76,13 @@ struct AssemblyPlan
 
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
                            const EvalBuffers& B, const NormalBuffers& N, hipStream_t stream);
-hipError_t launch_factor_and_solve(const NormalDims& nd, const NormalBuffers& N, const FactorBuffers& F,
+hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
+                               const NormalBuffers& N, const FactorBuffers& F,
+                               double lambda, bool is_leader, hipStream_t stream);
+hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
+                                const FactorBuffers& F, double* step_gn, hipStream_t stream);
+hipError_t launch_factor_and_solve(const NormalDims& nd, const BlockRanges& br,
+                                   const NormalBuffers& N, const FactorBuffers& F,
                                    double lambda, double* step_gn, hipStream_t stream);
 hipError_t launch_quadform(const NormalDims& nd, const NormalBuffers& N, const double* v, double* out,
                            hipStream_t stream);
