@@ -90,6 +90,24 @@ template<int N> MRCAL_AMD_HD Dual<N> dtan(const Dual<N>& a)
     for(int i=0;i<N;i++) r.d[i] = a.d[i]*k;
     return r;
 }
+// atan2(y,x): d = (dy x - y dx)/(x^2+y^2)   (_autodiff.hh:208-224)
+template<int N> MRCAL_AMD_HD Dual<N> datan2(const Dual<N>& y, const Dual<N>& x)
+{
+    Dual<N> r;
+    r.x = atan2(y.x, x.x);
+    const double inv = 1.0/(y.x*y.x + x.x*x.x);
+    for(int i=0;i<N;i++) r.d[i] = (y.d[i]*x.x - y.x*x.d[i]) * inv;
+    return r;
+}
+template<int N> MRCAL_AMD_HD Dual<N> dsin(const Dual<N>& a)
+{
+    double sv, cv;
+    sincos(a.x, &sv, &cv);
+    Dual<N> r;
+    r.x = sv;
+    for(int i=0;i<N;i++) r.d[i] = cv*a.d[i];
+    return r;
+}
 template<int N> MRCAL_AMD_HD Dual<N> dacos(const Dual<N>& a)
 {
     Dual<N> r;

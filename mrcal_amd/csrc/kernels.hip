@@ -14,12 +14,12 @@
 //      step 2; computing it redundantly in all 64 lanes of every wave would
 //      cost more than the whole HBM budget of the evaluation.
 //   2. board_kernel            one WAVEFRONT (64 lanes) per board observation,
-//      one lane per chessboard corner, 64 corners per pass. Each lane projects
-//      its corner and forms its two Jacobian rows in registers; rows go to an
+//      one lane per Jacobian row, 64 rows (32 corners) per pass. Each lane
+//      projects its corner and forms its CSR row in registers; rows go to an
 //      LDS tile (odd row stride => conflict-free ds_write_b64) and the tile is
 //      then streamed to HBM as one contiguous, 16-byte-per-lane coalesced run:
 //      consecutive CSR rows of one observation are adjacent in J's value
-//      array, so the whole 2*W*H x k tile is ONE contiguous HBM extent.
+//      array, so the whole 2*W*H x k block is ONE contiguous HBM extent.
 //   3. point_kernel / regularization_kernel: one lane per row pair / row.
 //      These are a few hundred rows; they are launch-latency, not bandwidth.
 //
@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include "problem.hpp"
 #include "device_math.hpp"
+#include "lens_models.hpp"
 #include "kernels.hpp"
 
 namespace mrcal_amd {
@@ -181,168 +182,18 @@ void board_prologue_kernel(DeviceProblem P, const double* __restrict__ b, double
 }
 
 ////////////////////////////////////////////////////////////////////////////////
-// lens models: q, dq/dp (2x3), dq/d(distortion) (2 x NDIST)
-////////////////////////////////////////////////////////////////////////////////
-
-// OpenCV rational + tangential + thin-prism family; NDIST = 0 is a pinhole.
-// The k[] slots beyond NDIST are compile-time zeros and fold away
-template<int NDIST, bool WITH_GRAD>
-__device__ __forceinline__
-void project_opencv(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDIST : 1],
-                    const double* p, const double* intr)
-{
-    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-    double k[12];
-#pragma unroll
-    for(int i=0;i<12;i++) k[i] = (i < NDIST) ? intr[4+i] : 0.0;
-
-    const double iz = 1.0/p[2];
-    const double X  = p[0]*iz;
-    const double Y  = p[1]*iz;
-    const double r2 = X*X + Y*Y;
-    const double r4 = r2*r2;
-    const double r6 = r4*r2;
-    const double a1 = 2.0*X*Y;
-    const double a2 = r2 + 2.0*X*X;
-    const double a3 = r2 + 2.0*Y*Y;
-    const double num  = 1.0 + k[0]*r2 + k[1]*r4 + k[4]*r6;
-    const double iden = 1.0/(1.0 + k[5]*r2 + k[6]*r4 + k[7]*r6);
-    const double xd = X*num*iden + k[2]*a1 + k[3]*a2 + k[8] *r2 + k[9] *r4;
-    const double yd = Y*num*iden + k[2]*a3 + k[3]*a1 + k[10]*r2 + k[11]*r4;
-    q[0] = xd*fx + cx;
-    q[1] = yd*fy + cy;
-
-    if(!WITH_GRAD) return;
-
-    const double dX[3] = { iz,  0.0, -X*iz };
-    const double dY[3] = { 0.0, iz,  -Y*iz };
-#pragma unroll
-    for(int j=0;j<3;j++)
-    {
-        const double dr2   = 2.0*X*dX[j] + 2.0*Y*dY[j];
-        const double dnum  = k[0]*dr2 + 2.0*k[1]*r2*dr2 + 3.0*k[4]*r4*dr2;
-        const double diden = -iden*iden*(k[5]*dr2 + 2.0*k[6]*r2*dr2 + 3.0*k[7]*r4*dr2);
-        const double da1   = 2.0*(X*dY[j] + Y*dX[j]);
-        const double dxd   = dX[j]*num*iden + X*dnum*iden + X*num*diden +
-            k[2]*da1 + k[3]*(dr2 + 4.0*X*dX[j]) + k[8]*dr2  + 2.0*r2*k[9]*dr2;
-        const double dyd   = dY[j]*num*iden + Y*dnum*iden + Y*num*diden +
-            k[2]*(dr2 + 4.0*Y*dY[j]) + k[3]*da1 + k[10]*dr2 + 2.0*r2*k[11]*dr2;
-        dq_dp[0][j] = fx*dxd;
-        dq_dp[1][j] = fy*dyd;
-    }
-    if(NDIST >= 4)
-    {
-        dq_dk[0][0] = fx*X*iden*r2;   dq_dk[1][0] = fy*(Y*iden*r2);
-        dq_dk[0][1] = fx*X*iden*r4;   dq_dk[1][1] = fy*Y*iden*r4;
-        dq_dk[0][2] = fx*a1;          dq_dk[1][2] = fy*a3;
-        dq_dk[0][3] = fx*a2;          dq_dk[1][3] = fy*a1;
-    }
-    if(NDIST >= 5)
-    {
-        dq_dk[0][4] = fx*X*iden*r6;   dq_dk[1][4] = fy*Y*iden*r6;
-    }
-    if(NDIST >= 8)
-    {
-        const double t = num*(-iden)*iden;
-        dq_dk[0][5] = fx*X*t*r2;      dq_dk[1][5] = fy*Y*t*r2;
-        dq_dk[0][6] = fx*X*t*r4;      dq_dk[1][6] = fy*Y*t*r4;
-        dq_dk[0][7] = fx*X*t*r6;      dq_dk[1][7] = fy*Y*t*r6;
-    }
-    if(NDIST >= 12)
-    {
-        dq_dk[0][8]  = fx*r2;         dq_dk[1][8]  = 0.0;
-        dq_dk[0][9]  = fx*r4;         dq_dk[1][9]  = 0.0;
-        dq_dk[0][10] = 0.0;           dq_dk[1][10] = fy*r2;
-        dq_dk[0][11] = 0.0;           dq_dk[1][11] = fy*r4;
-    }
-}
-
-// q = 2 p_xy/(|p| + p_z) f + c
-template<bool WITH_GRAD>
-__device__ __forceinline__
-void project_stereographic(double* q, double (*dq_dp)[3], const double* p, const double* intr)
-{
-    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-    const double mag   = sqrt(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
-    const double scale = 2.0/(mag + p[2]);
-    if(WITH_GRAD)
-    {
-        const double A = -scale*scale/2.0;
-        const double B = A/mag;
-        dq_dp[0][0] = fx*(p[0]*(B*p[0]) + scale);
-        dq_dp[0][1] = fx*(p[0]*(B*p[1]));
-        dq_dp[0][2] = fx*(p[0]*(B*p[2] + A));
-        dq_dp[1][0] = fy*(p[1]*(B*p[0]));
-        dq_dp[1][1] = fy*(p[1]*(B*p[1]) + scale);
-        dq_dp[1][2] = fy*(p[1]*(B*p[2] + A));
-    }
-    q[0] = p[0]*scale*fx + cx;
-    q[1] = p[1]*scale*fy + cy;
-}
-
-// equirectangular: q = (atan2(px,pz), asin(py/|p|)) f + c
-template<bool WITH_GRAD>
-__device__ __forceinline__
-void project_lonlat(double* q, double (*dq_dp)[3], const double* p, const double* intr)
-{
-    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-    const double in2   = 1.0/(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
-    const double im    = sqrt(in2);
-    const double in2xz = 1.0/(p[0]*p[0] + p[2]*p[2]);
-    const double imxz  = sqrt(in2xz);
-    if(WITH_GRAD)
-    {
-        dq_dp[0][0] =  fx*in2xz*p[2];
-        dq_dp[0][1] =  0.0;
-        dq_dp[0][2] = -fx*in2xz*p[0];
-        dq_dp[1][0] = -fy*imxz*(p[1]*p[0]*in2);
-        dq_dp[1][1] = -fy*imxz*(p[1]*p[1]*in2 - 1.0);
-        dq_dp[1][2] = -fy*imxz*(p[1]*p[2]*in2);
-    }
-    q[0] = atan2(p[0], p[2])*fx + cx;
-    q[1] = asin(p[1]*im)    *fy + cy;
-}
-// transverse equirectangular: lonlat with x and y swapped
-template<bool WITH_GRAD>
-__device__ __forceinline__
-void project_latlon(double* q, double (*dq_dp)[3], const double* p, const double* intr)
-{
-    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-    const double in2   = 1.0/(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
-    const double im    = sqrt(in2);
-    const double in2yz = 1.0/(p[1]*p[1] + p[2]*p[2]);
-    const double imyz  = sqrt(in2yz);
-    if(WITH_GRAD)
-    {
-        dq_dp[0][0] = -fx*imyz*(p[0]*p[0]*in2 - 1.0);
-        dq_dp[0][1] = -fx*imyz*(p[0]*p[1]*in2);
-        dq_dp[0][2] = -fx*imyz*(p[0]*p[2]*in2);
-        dq_dp[1][0] =  0.0;
-        dq_dp[1][1] =  fy*in2yz*p[2];
-        dq_dp[1][2] = -fy*in2yz*p[1];
-    }
-    q[0] = asin(p[0]*im)    *fx + cx;
-    q[1] = atan2(p[1], p[2])*fy + cy;
-}
-
-// dispatch over the "simple" (closed-form, central) models
-template<int PROJ, int NDIST, bool WITH_GRAD>
-__device__ __forceinline__
-void project_lens(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDIST : 1],
-                  const double* p, const double* intr)
-{
-    if     (PROJ == PROJ_OPENCV)        project_opencv<NDIST,WITH_GRAD>(q, dq_dp, dq_dk, p, intr);
-    else if(PROJ == PROJ_STEREOGRAPHIC) project_stereographic<WITH_GRAD>(q, dq_dp, p, intr);
-    else if(PROJ == PROJ_LONLAT)        project_lonlat<WITH_GRAD>(q, dq_dp, p, intr);
-    else                                project_latlon<WITH_GRAD>(q, dq_dp, p, intr);
-}
-
-////////////////////////////////////////////////////////////////////////////////
 // 2. board kernel
 ////////////////////////////////////////////////////////////////////////////////
 //
-// LDS tile of one pass (64 corners = 128 rows). Row (xy,corner) lives at LDS
-// row xy*64+corner; its columns are in STATE order:
+// One wavefront per board observation, ONE LANE PER JACOBIAN ROW, 64 rows (32
+// corners x {qx,qy}) per pass. A lane projects its corner, evaluates its own
+// image row of the projection gradient, and forms the k values of its CSR row
+// in registers.
+//
+// LDS tile of one pass: 64 rows x ks doubles (13.8 KB at 24 nonzeros per row:
+// 11 waves per CU fit in the 160 KB LDS, which is what lets the stores of one
+// wave overlap the arithmetic and the MFMAs of the others). A row's columns are
+// in STATE order:
 //
 //   [fx fy cx cy]   if the core is optimized. An x row holds (dq/dfx, 0, w, 0),
 //                   a y row (0, dq/dfy, 0, w): each CSR row carries only its
@@ -354,9 +205,14 @@ void project_lens(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDI
 //   [warp]          2, if the warp is optimized
 //   [x]             the residual itself (only when the Gram is being formed)
 //
-// The row stride is odd, which makes the per-lane column writes
-// (ds_write_b64, lane stride = one row) and the MFMA operand reads hit
-// distinct banks.
+// The row stride ks is odd, which makes the per-lane column writes
+// (ds_write_b64, lane stride = one row) hit distinct banks.
+//
+// Copy-out: consecutive CSR rows of one observation are adjacent in J's value
+// array, so the 64 x k tile is ONE contiguous HBM extent; it is streamed out 16
+// bytes per lane, 1 KiB contiguous per wave instruction (measured: this store
+// pattern reaches 5.9 TB/s, a row-per-lane direct store 3.4 TB/s;
+// tools/exp/store_patterns.hip).
 //
 // Gram (WITH_GRAM): G = Tt T over the tile columns, accumulated over the
 // passes of the observation with v_mfma_f64_16x16x4_f64. One k-step is 4 tile
@@ -389,19 +245,28 @@ void board_kernel(DeviceProblem P,
     const int  kt      = k + (ncore ? 2 : 0);    // tile columns holding J
     const int  kx      = kt + (WITH_GRAM ? 1 : 0);
     const int  ks      = kx | 1;                 // odd LDS row stride
+    const int  ks_alloc = P.board_tile_stride;   // the stride the LDS allocation was sized for (>= ks)
     const int  NPTS    = P.W*P.H;
+    const int  NROWS   = 2*NPTS;
     const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
 
+    // filled without a loop: see the note in lens_models.hpp
     double intr[4 + NDIST];
-#pragma unroll
-    for(int i=0;i<4+NDIST;i++) intr[i] = get_intrinsic(P, b, m.icam_intrinsics, i);
+#define MRCAL_AMD_LOAD_INTR(i) if((i) < 4+NDIST) intr[(i) < 4+NDIST ? (i) : 0] = get_intrinsic(P, b, m.icam_intrinsics, (i))
+    MRCAL_AMD_LOAD_INTR(0);  MRCAL_AMD_LOAD_INTR(1);  MRCAL_AMD_LOAD_INTR(2);  MRCAL_AMD_LOAD_INTR(3);
+    MRCAL_AMD_LOAD_INTR(4);  MRCAL_AMD_LOAD_INTR(5);  MRCAL_AMD_LOAD_INTR(6);  MRCAL_AMD_LOAD_INTR(7);
+    MRCAL_AMD_LOAD_INTR(8);  MRCAL_AMD_LOAD_INTR(9);  MRCAL_AMD_LOAD_INTR(10); MRCAL_AMD_LOAD_INTR(11);
+    MRCAL_AMD_LOAD_INTR(12); MRCAL_AMD_LOAD_INTR(13); MRCAL_AMD_LOAD_INTR(14); MRCAL_AMD_LOAD_INTR(15);
+#undef MRCAL_AMD_LOAD_INTR
+    static_assert(4 + NDIST <= 16, "extend the list above");
+    const double intr_fx = intr[0], intr_fy = intr[1], intr_cx = intr[2], intr_cy = intr[3];
 
     double warp[2] = {0.0, 0.0};
     if(P.has_warp_seed) get_warp(warp, P, b);
 
     // upper-triangular 16x16 tiles of G: up to 3 column blocks
-    constexpr int NBMAX = 3;
-    constexpr int NTMAX = NBMAX*(NBMAX+1)/2;
+    constexpr int NBMAX = GRAM_NB_MAX;
+    constexpr int NTMAX = GRAM_NT_MAX;
     double4_t acc[WITH_GRAM ? NTMAX : 1];
     if(WITH_GRAM)
     {
@@ -410,13 +275,37 @@ void board_kernel(DeviceProblem P,
     }
     const int NB = (kx + 15) >> 4;
 
-    for(int chunk0 = 0; chunk0 < NPTS; chunk0 += 64)
-    {
-        const int pt   = chunk0 + lane;
-        const int npts = (NPTS - chunk0 < 64) ? (NPTS - chunk0) : 64;
+    // copy-out stepping: element index e advances by 128 per iteration
+    const int step_rows = 128 / k;
+    const int step_cols = 128 - step_rows*k;
 
-        if(pt < NPTS)
+    const bool isy = (lane & 1) != 0;            // passes start at even rows
+
+    // HW_REG_HW_ID[3:0]: this wave's slot in its SIMD
+    const int order = (P.debug_ablate & 8) ? 0 : (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1);
+
+    // The observation's pixels and weights (NPTS x 3 doubles) are staged in
+    // LDS up front, behind the tile. After that this wave issues NO vector
+    // loads: its stores are fire-and-forget, and nothing in the pass loop
+    // waits on vmcnt. (A global load inside the loop would have to wait for
+    // every store issued before it: vmcnt retires in order, and with a
+    // data-dependent number of stores per pass the compiler can only wait for
+    // vmcnt(0), which serializes the HBM write stream with the arithmetic.)
+    double* __restrict__ obs_lds = tile + 64*ks_alloc;
+    {
+        const double* __restrict__ pool = P.board_pool + (size_t)iobs*NPTS*3;
+        for(int i = lane; i < 3*NPTS; i += 64) obs_lds[i] = pool[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for(int row0 = 0; row0 < NROWS; row0 += 64)
+    {
+        const int r     = row0 + lane;
+        const int nrows = (NROWS - row0 < 64) ? (NROWS - row0) : 64;
+
+        if(r < NROWS)
         {
+            const int pt = r >> 1;
             const int iy = pt / P.W;
             const int ix = pt - iy*P.W;
             const double bx = (double)ix * P.spacing;
@@ -438,45 +327,46 @@ void board_kernel(DeviceProblem P,
             for(int i=0;i<3;i++)
                 p[i] = jp[JOINT_R+3*i+0]*bx + jp[JOINT_R+3*i+1]*by + jp[JOINT_R+3*i+2]*bz + jp[JOINT_T+i];
 
-            double q[2], dq_dp[2][3], dq_dk[2][NDIST > 0 ? NDIST : 1];
-            project_lens<PROJ,NDIST,WITH_J>(q, dq_dp, dq_dk, p, intr);
+            double q, dq_dp[3], dq_dk[NDIST > 0 ? NDIST : 1];
+            if(P.debug_ablate & 4)
+            {
+                q = p[0]; dq_dp[0] = p[0]; dq_dp[1] = p[1]; dq_dp[2] = p[2];
+#pragma unroll
+                for(int i=0;i<NDIST;i++) dq_dk[i] = p[0] + (double)i;
+            }
+            else
+            project_lens_row<PROJ,NDIST,WITH_J>(lane & 1, &q, dq_dp, dq_dk, p, intr, P.cfg);
 
-            const double* __restrict__ obs = P.board_pool + ((size_t)iobs*NPTS + pt)*3;
-            const double qx_obs = obs[0], qy_obs = obs[1], w = obs[2];
+            const double q_obs  = obs_lds[3*pt + (lane & 1)];
+            const double w      = obs_lds[3*pt + 2];
             const bool   inlier = (w >= 0.0);
 
-            double2 err;
-            err.x = inlier ? (q[0] - qx_obs)*w : 0.0;
-            err.y = inlier ? (q[1] - qy_obs)*w : 0.0;
-            *reinterpret_cast<double2*>(&x[m.i_meas0 + 2*pt]) = err;
+            const double err = inlier ? (q - q_obs)*w : 0.0;
+            x[m.i_meas0 + r] = err;
 
             if(WITH_J)
             {
-                double* __restrict__ row[2] = { tile + (size_t)lane*ks,
-                                                tile + (size_t)(64 + lane)*ks };
+                double* __restrict__ row = tile + (size_t)lane*ks;
                 // outliers keep their columns and get all-zero values
                 const double ww = inlier ? w : 0.0;
                 int c = 0;
                 if(ncore)
                 {
-#pragma unroll
-                    for(int xy=0;xy<2;xy++)
-                    {
-                        const double dq_df = (q[xy] - intr[2+xy])/intr[xy];
-                        row[xy][xy]       = inlier ? dq_df * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
-                        row[xy][1-xy]     = 0.0;
-                        row[xy][2+xy]     = ww * SCALE_INTRINSICS_CENTER_PIXEL;
-                        row[xy][2+(1-xy)] = 0.0;
-                    }
+                    const double f  = isy ? intr_fy : intr_fx;
+                    const double cc = isy ? intr_cy : intr_cx;
+                    const double vf = inlier ? ((q - cc)/f) * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
+                    const double vc = ww * SCALE_INTRINSICS_CENTER_PIXEL;
+                    row[0] = isy ? 0.0 : vf;
+                    row[1] = isy ? vf  : 0.0;
+                    row[2] = isy ? 0.0 : vc;
+                    row[3] = isy ? vc  : 0.0;
                     c = 4;
                 }
                 if(NDIST > 0 && P.Ndist_state)
                 {
 #pragma unroll
-                    for(int xy=0;xy<2;xy++)
-#pragma unroll
-                        for(int i=0;i<NDIST;i++)
-                            row[xy][c+i] = inlier ? dq_dk[xy][i] * w * SCALE_DISTORTION : 0.0;
+                    for(int i=0;i<NDIST;i++)
+                        row[c+i] = inlier ? dq_dk[i] * w * SCALE_DISTORTION : 0.0;
                     c += NDIST;
                 }
                 if(has_ext)
@@ -493,13 +383,9 @@ void board_kernel(DeviceProblem P,
                                 by*jp[JOINT_MC + 9  + 3*i + l] +
                                 bz*jp[JOINT_MC + 18 + 3*i + l] +
                                 jp[JOINT_DTJ_DRC + 3*i + l];
-#pragma unroll
-                        for(int xy=0;xy<2;xy++)
-                        {
-                            const double g = dq_dp[xy][0]*dp[0] + dq_dp[xy][1]*dp[1] + dq_dp[xy][2]*dp[2];
-                            row[xy][c+l]   = inlier ? g * w * SCALE_ROTATION_CAMERA : 0.0;
-                            row[xy][c+3+l] = inlier ? dq_dp[xy][l] * w * SCALE_TRANSLATION_CAMERA : 0.0;
-                        }
+                        const double g = dq_dp[0]*dp[0] + dq_dp[1]*dp[1] + dq_dp[2]*dp[2];
+                        row[c+l]   = inlier ? g * w * SCALE_ROTATION_CAMERA : 0.0;
+                        row[c+3+l] = inlier ? dq_dp[l] * w * SCALE_TRANSLATION_CAMERA : 0.0;
                     }
                     c += 6;
                 }
@@ -518,94 +404,104 @@ void board_kernel(DeviceProblem P,
                                 bz*jp[JOINT_MF + 18 + 3*i + l];
                             dpt[i] = jp[JOINT_DTJ_DTF + 3*i + l];
                         }
-#pragma unroll
-                        for(int xy=0;xy<2;xy++)
-                        {
-                            const double gr = dq_dp[xy][0]*dpr[0] + dq_dp[xy][1]*dpr[1] + dq_dp[xy][2]*dpr[2];
-                            const double gt = dq_dp[xy][0]*dpt[0] + dq_dp[xy][1]*dpt[1] + dq_dp[xy][2]*dpt[2];
-                            row[xy][c+l]   = inlier ? gr * w * SCALE_ROTATION_FRAME    : 0.0;
-                            row[xy][c+3+l] = inlier ? gt * w * SCALE_TRANSLATION_FRAME : 0.0;
-                        }
+                        const double gr = dq_dp[0]*dpr[0] + dq_dp[1]*dpr[1] + dq_dp[2]*dpr[2];
+                        const double gt = dq_dp[0]*dpt[0] + dq_dp[1]*dpt[1] + dq_dp[2]*dpt[2];
+                        row[c+l]   = inlier ? gr * w * SCALE_ROTATION_FRAME    : 0.0;
+                        row[c+3+l] = inlier ? gt * w * SCALE_TRANSLATION_FRAME : 0.0;
                     }
                     c += 6;
                 }
                 if(P.has_warp_state)
                 {
                     // dq/dwarp_i = (dq/dt . Rj[:,2]) dz/dwarp_i
-#pragma unroll
-                    for(int xy=0;xy<2;xy++)
-                    {
-                        const double d =
-                            dq_dp[xy][0]*jp[JOINT_R + 2] +
-                            dq_dp[xy][1]*jp[JOINT_R + 5] +
-                            dq_dp[xy][2]*jp[JOINT_R + 8];
-                        row[xy][c+0] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[0]) : 0.0;
-                        row[xy][c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
-                    }
+                    const double d =
+                        dq_dp[0]*jp[JOINT_R + 2] +
+                        dq_dp[1]*jp[JOINT_R + 5] +
+                        dq_dp[2]*jp[JOINT_R + 8];
+                    row[c+0] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[0]) : 0.0;
+                    row[c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
                     c += 2;
                 }
                 if(WITH_GRAM)
-                {
-                    row[0][c] = err.x;
-                    row[1][c] = err.y;
-                }
+                    row[c] = err;
             }
         }
 
         if(WITH_J)
         {
-            __syncthreads();
-            // Stream the tile out. Output element e of this pass is CSR row
-            // e/k, column e%k, with row = 2*point + xy. 16 bytes per lane per
-            // store, 1 KiB contiguous per wave instruction
-            const int nelem = 2*npts*k;
-            double* __restrict__ out = Jv + m.i_nnz0 + (size_t)2*chunk0*k;
-            for(int e = 2*lane; e < nelem; e += 128)
+            // The workgroup IS one wavefront, and the LDS executes a wave's DS
+            // instructions in order: the tile reads below see the writes above
+            // without an s_barrier. __syncthreads() would also wait for this
+            // wave's outstanding global stores (vmcnt(0)), i.e. serialize the
+            // HBM write stream of a pass with the arithmetic of the next one
+            __builtin_amdgcn_wave_barrier();
+            // Two phases read the tile: the copy-out (vector-memory bound)
+            // and the Gram (MFMA bound). Waves alternate the order by the
+            // parity of their hardware wave slot, so that co-resident waves
+            // of a SIMD lean on different pipes at the same time
+            for(int phase = 0; phase < 2; phase++)
             {
-                int r0 = e / k;
-                int c0 = e - r0*k;
-                int r1 = r0, c1 = c0 + 1;
-                if(c1 == k) { c1 = 0; r1++; }
-                // CSR column -> tile column: the row's own 2 core columns
-                // (f then c) sit at tile columns xy and 2+xy
-                const int xy0 = r0 & 1, xy1 = r1 & 1;
-                const int t0 = ncore ? ((c0 < 2) ? (2*c0 + xy0) : (c0 + 2)) : c0;
-                const int t1 = ncore ? ((c1 < 2) ? (2*c1 + xy1) : (c1 + 2)) : c1;
-                double2 v;
-                v.x = tile[(size_t)((xy0 << 6) + (r0 >> 1))*ks + t0];
-                v.y = tile[(size_t)((xy1 << 6) + (r1 >> 1))*ks + t1];
-                *reinterpret_cast<double2*>(&out[e]) = v;
-            }
-
-            if(WITH_GRAM)
-            {
-                // G += Tt T over this pass. 4 tile rows per k-step; rows of
-                // corners beyond npts hold stale data and are masked out
-                const int nsteps = (npts + 3) >> 2;
-                const int col    = lane & 15;
-                for(int plane = 0; plane < 2; plane++)
-                    for(int s = 0; s < nsteps; s++)
+                if((phase ^ order) == 0)
+                {
+                    // Stream the tile out. Output element e of this pass is CSR row
+                    // e/k, column e%k. 16 bytes per lane per store, 1 KiB contiguous
+                    // per wave instruction. nrows is even, so is the element count
+                    const int nelem = nrows*k;
+                    double* __restrict__ out = Jv + m.i_nnz0 + (size_t)row0*k;
+                    int e  = 2*lane;
+                    int r0 = e / k;
+                    int c0 = e - r0*k;
+                    if(!(P.debug_ablate & 1))
+                    for(; e < nelem; e += 128)
                     {
-                        const int  rr    = 4*s + (lane >> 4);
-                        const bool valid = rr < npts;
-                        const double* __restrict__ trow = tile + (size_t)((plane << 6) + rr)*ks;
-                        double a[NBMAX];
-#pragma unroll
-                        for(int bb=0;bb<NBMAX;bb++)
-                        {
-                            const int cc = 16*bb + col;
-                            a[bb] = (bb < NB && valid && cc < kx) ? trow[cc] : 0.0;
-                        }
-                        int t = 0;
-#pragma unroll
-                        for(int bi=0;bi<NBMAX;bi++)
-#pragma unroll
-                            for(int bj=bi;bj<NBMAX;bj++,t++)
-                                if(bj < NB)
-                                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
+                        int r1 = r0, c1 = c0 + 1;
+                        if(c1 == k) { c1 = 0; r1++; }
+                        // CSR column -> tile column: the row's own 2 core columns
+                        // (f then c) sit at tile columns xy and 2+xy
+                        const int xy0 = r0 & 1, xy1 = r1 & 1;
+                        const int t0 = ncore ? ((c0 < 2) ? (2*c0 + xy0) : (c0 + 2)) : c0;
+                        const int t1 = ncore ? ((c1 < 2) ? (2*c1 + xy1) : (c1 + 2)) : c1;
+                        double2 v;
+                        v.x = tile[r0*ks + t0];
+                        v.y = tile[r1*ks + t1];
+                        *reinterpret_cast<double2*>(&out[e]) = v;
+                        c0 += step_cols; r0 += step_rows;
+                        if(c0 >= k) { c0 -= k; r0++; }
                     }
+
+                }
+                else
+                {
+                    if(WITH_GRAM && !(P.debug_ablate & 2))
+                    {
+                        // G += Tt T over this pass. 4 tile rows per k-step; rows
+                        // beyond nrows hold stale data and are masked out
+                        const int nsteps = (nrows + 3) >> 2;
+                        const int col    = lane & 15;
+                        for(int s = 0; s < nsteps; s++)
+                        {
+                            const int  rr    = 4*s + (lane >> 4);
+                            const bool valid = rr < nrows;
+                            const double* __restrict__ trow = tile + rr*ks;
+                            double a[NBMAX];
+#pragma unroll
+                            for(int bb=0;bb<NBMAX;bb++)
+                            {
+                                const int cc = 16*bb + col;
+                                a[bb] = (bb < NB && valid && cc < kx) ? trow[cc] : 0.0;
+                            }
+                            int t = 0;
+#pragma unroll
+                            for(int bi=0;bi<NBMAX;bi++)
+#pragma unroll
+                                for(int bj=bi;bj<NBMAX;bj++,t++)
+                                    if(bj < NB)
+                                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
+                        }
+                    }
+                }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -754,7 +650,7 @@ void point_kernel(DeviceProblem P,
     }
 
     double q[2], dq_dp[2][3], dq_dk[2][NDIST > 0 ? NDIST : 1];
-    project_lens<PROJ,NDIST,WITH_J>(q, dq_dp, dq_dk, p, intr);
+    project_lens<PROJ,NDIST,WITH_J>(q, dq_dp, dq_dk, p, intr, P.cfg);
 
     x[m.i_meas0+0] = (q[0] - obs[0])*w;
     x[m.i_meas0+1] = (q[1] - obs[1])*w;
@@ -920,7 +816,7 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
                                P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
         else
-            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false,false>), dim3(P.Nobs_board), dim3(64), 0, stream,
+            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
                                P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
         if(ev_j1) hipEventRecord(ev_j1, stream);
     }
@@ -957,6 +853,8 @@ bool lens_supported(int lens_type)
     case MRCAL_LENSMODEL_OPENCV5:
     case MRCAL_LENSMODEL_OPENCV8:
     case MRCAL_LENSMODEL_OPENCV12:
+    case MRCAL_LENSMODEL_CAHVOR:
+    case MRCAL_LENSMODEL_CAHVORE:
         return true;
     default:
         return false;
@@ -977,6 +875,8 @@ hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool wi
     case MRCAL_LENSMODEL_OPENCV5:       launch_eval_t<PROJ_OPENCV,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
     case MRCAL_LENSMODEL_OPENCV8:       launch_eval_t<PROJ_OPENCV,        8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
     case MRCAL_LENSMODEL_OPENCV12:      launch_eval_t<PROJ_OPENCV,        12>(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
+    case MRCAL_LENSMODEL_CAHVOR:        launch_eval_t<PROJ_CAHVOR,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
+    case MRCAL_LENSMODEL_CAHVORE:       launch_eval_t<PROJ_CAHVORE,       8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
     default:
         return hipErrorInvalidValue;
     }

@@ -6,7 +6,6 @@
 
 namespace mrcal_amd {
 
-enum { PROJ_OPENCV = 0, PROJ_STEREOGRAPHIC = 1, PROJ_LONLAT = 2, PROJ_LATLON = 3 };
 
 // device pointers of one operating point
 struct EvalBuffers

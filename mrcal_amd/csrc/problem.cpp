@@ -357,10 +357,12 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         return NULL;
     }
     // tile columns: k, +2 for the full core, +1 for the residual column (see board_kernel)
-    P->lds_bytes = 128 * ((kmax + 3) | 1) * (int)sizeof(double);
+    // + the observation's pixels and weights, staged behind the tile
+    const int board_tile_stride = (kmax + 3) | 1;
+    P->lds_bytes = (64*board_tile_stride + 3*NPTS) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
-        set_error("a board row has %d nonzeros: the LDS tile would not fit", kmax);
+        set_error("a board row has %d nonzeros and the board %d corners: the LDS tile would not fit", kmax, NPTS);
         delete P;
         return NULL;
     }
@@ -442,15 +444,19 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.Nobs_board = Nboard_local; D.Nobs_point = Npoint_local;
     D.W = calibration_object_width_n; D.H = calibration_object_height_n;
     D.spacing = calibration_object_spacing;
+    D.board_tile_stride = board_tile_stride;
     if(calobject_warp) { D.seed_warp[0] = calobject_warp->x2; D.seed_warp[1] = calobject_warp->y2; }
     if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
     {
-        D.spline_order = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.order;
-        D.spline_Nx    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Nx;
-        D.spline_Ny    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Ny;
+        D.cfg.spline_order = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.order;
+        D.cfg.spline_Nx    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Nx;
+        D.cfg.spline_Ny    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Ny;
+        D.cfg.spline_segments_per_u =
+            spline_segments_per_u(D.cfg.spline_order, D.cfg.spline_Nx,
+                                  (double)lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.fov_x_deg);
     }
     if(lensmodel->type == MRCAL_LENSMODEL_CAHVORE)
-        D.cahvore_linearity = lensmodel->LENSMODEL_CAHVORE__config.linearity;
+        D.cfg.cahvore_linearity = lensmodel->LENSMODEL_CAHVORE__config.linearity;
     D.do_apply_regularization = sel.do_apply_regularization && is_shard_leader;
     D.has_unity_cam01         = L.has_unity_cam01;
     D.i_meas_regularization   = L.i_meas_regularization;
@@ -574,6 +580,27 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
     if(min_ms)    *min_ms    = n ? mn : 0;
     if(max_ms)    *max_ms    = mx;
     return true;
+}
+
+// dev tool: average duration (ms) of nrep back-to-back launches of the
+// evaluation kernels alone, with the given debug_ablate bits
+double mrcal_amd_problem_debug_time_evaluate(mrcal_amd_problem_t* p, bool with_gram, int ablate, int nrep)
+{
+    if(with_gram && !problem_prepare_solver(p)) return -1.0;
+    const int saved = p->D.debug_ablate;
+    p->D.debug_ablate = ablate;
+    const EvalBuffers B = p->eval_buffers(p->icur, with_gram);
+    double total = 0.0;
+    for(int i=0; i<nrep+1; i++)
+    {
+        if(launch_evaluate(p->D, B, true, p->lds_bytes, p->stream, p->ev_j0, p->ev_j1) != hipSuccess) return -1.0;
+        if(hipStreamSynchronize(p->stream) != hipSuccess) return -1.0;
+        float ms = 0;
+        hipEventElapsedTime(&ms, p->ev_j0, p->ev_j1);
+        if(i > 0) total += ms;
+    }
+    p->D.debug_ablate = saved;
+    return total/nrep;
 }
 
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* p)

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "layout.hpp"
+#include "lens_models.hpp"
 
 namespace mrcal_amd {
 
@@ -112,13 +113,16 @@ struct DeviceProblem
     int Ncameras_intrinsics, Ncameras_extrinsics, Nframes, Npoints, Npoints_fixed;
     int Nobs_board, Nobs_point;
     int W, H;
+    int board_tile_stride;   // doubles per LDS tile row of the board kernel, sized for the widest row
     double spacing;
     double seed_warp[2];
 
-    // splined-model configuration
-    int spline_order, spline_Nx, spline_Ny;
-    double spline_segments_per_u;
-    double cahvore_linearity;
+    // model configuration that is not in the intrinsics vector
+    LensConfig cfg;
+
+    // performance-debugging knob (tools/probe_board.py): bit0 skip the J copy-out,
+    // bit1 skip the MFMAs, bit2 skip the projection arithmetic. 0 in production
+    int debug_ablate;
 
     // regularization
     int do_apply_regularization;
