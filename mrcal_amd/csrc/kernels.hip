@@ -14,12 +14,12 @@
 //      step 2; computing it redundantly in all 64 lanes of every wave would
 //      cost more than the whole HBM budget of the evaluation.
 //   2. board_kernel            one WAVEFRONT (64 lanes) per board observation,
-//      one lane per Jacobian row, 64 rows (32 corners) per pass. Each lane
-//      projects its corner and forms its CSR row in registers; rows go to an
-//      LDS tile (odd row stride => conflict-free ds_write_b64) and the tile is
-//      then streamed to HBM as one contiguous, 16-byte-per-lane coalesced run:
-//      consecutive CSR rows of one observation are adjacent in J's value
-//      array, so the whole 2*W*H x k block is ONE contiguous HBM extent.
+//      one lane per chessboard corner. Each lane projects its corner and forms
+//      its two CSR rows in registers; rows go through a 64-row LDS tile (odd
+//      row stride => conflict-free ds_write_b64), half a pass at a time, and
+//      the tile is streamed to HBM as one contiguous, 16-byte-per-lane
+//      coalesced run: consecutive CSR rows of one observation are adjacent in
+//      J's value array, so the whole 2*W*H x k block is ONE contiguous extent.
 //   3. point_kernel / regularization_kernel: one lane per row pair / row.
 //      These are a few hundred rows; they are launch-latency, not bandwidth.
 //
@@ -163,6 +163,28 @@ void joint_pose_record(double* __restrict__ out,
 __global__ __launch_bounds__(64)
 void board_prologue_kernel(DeviceProblem P, const double* __restrict__ b, double* __restrict__ joint)
 {
+    // the blocks past the observations unpack the intrinsics of every camera
+    // and the board warp from the packed state (or copy the seeds)
+    const int nblocks_obs = (P.Nobs_board + 63)/64;
+    if((int)blockIdx.x >= nblocks_obs)
+    {
+        double* __restrict__ u = joint + (size_t)P.Nobs_board*JOINT_STRIDE;
+        const int n = P.Ncameras_intrinsics*P.Nintrinsics;
+        const int i = (blockIdx.x - nblocks_obs)*blockDim.x + threadIdx.x;
+        if(i < n)
+        {
+            const int icam = i / P.Nintrinsics;
+            u[i] = get_intrinsic(P, b, icam, i - icam*P.Nintrinsics);
+        }
+        else if(i < n + 2)
+        {
+            double w[2] = {0.0, 0.0};
+            if(P.has_warp_seed) get_warp(w, P, b);
+            u[i] = w[i - n];
+        }
+        return;
+    }
+
     const int iobs = blockIdx.x*blockDim.x + threadIdx.x;
     if(iobs >= P.Nobs_board) return;
     const BoardObsMeta m = P.board_meta[iobs];
@@ -185,55 +207,83 @@ void board_prologue_kernel(DeviceProblem P, const double* __restrict__ b, double
 // 2. board kernel
 ////////////////////////////////////////////////////////////////////////////////
 //
-// One wavefront per board observation, ONE LANE PER JACOBIAN ROW, 64 rows (32
-// corners x {qx,qy}) per pass. A lane projects its corner, evaluates its own
-// image row of the projection gradient, and forms the k values of its CSR row
-// in registers.
+// One wavefront per board observation, one lane per chessboard corner, 64
+// corners per pass. A lane projects its corner and forms BOTH its Jacobian
+// rows in registers (the x and y rows share most of the projection and all of
+// the pose chain rule), at the fixed tile columns of problem.hpp.
 //
-// LDS tile of one pass: 64 rows x ks doubles (13.8 KB at 24 nonzeros per row:
-// 11 waves per CU fit in the 160 KB LDS, which is what lets the stores of one
-// wave overlap the arithmetic and the MFMAs of the others). A row's columns are
-// in STATE order:
-//
-//   [fx fy cx cy]   if the core is optimized. An x row holds (dq/dfx, 0, w, 0),
-//                   a y row (0, dq/dfy, 0, w): each CSR row carries only its
-//                   own 2 core columns, the tile carries all 4 so that a tile
-//                   column means the same state variable in every row
-//   [distortions]   Ndist_state
-//   [r_cam t_cam]   6, if this camera has extrinsics in the state
-//   [r_frame t_frame] 6, if frames are optimized
-//   [warp]          2, if the warp is optimized
-//   [x]             the residual itself (only when the Gram is being formed)
-//
-// The row stride ks is odd, which makes the per-lane column writes
-// (ds_write_b64, lane stride = one row) hit distinct banks.
+// The rows then go through a 64-row LDS tile in two halves: lanes 0..31 store
+// their 64 rows, the wave streams them out and accumulates their Gram; then
+// lanes 32..63. A 64-row tile (14.8 KB at OPENCV8) instead of a 128-row one is
+// what lets ~9 waves share a CU's 160 KB of LDS: the kernel is a mix of FP64
+// arithmetic, HBM stores and exposed latencies, and only other resident waves
+// can fill one wave's gaps.
 //
 // Copy-out: consecutive CSR rows of one observation are adjacent in J's value
-// array, so the 64 x k tile is ONE contiguous HBM extent; it is streamed out 16
-// bytes per lane, 1 KiB contiguous per wave instruction (measured: this store
+// array, so the 64 x k half-tile is ONE contiguous HBM extent; it is streamed
+// out 16 bytes per lane, whole rows per wave instruction (measured: this store
 // pattern reaches 5.9 TB/s, a row-per-lane direct store 3.4 TB/s;
-// tools/exp/store_patterns.hip).
+// tools/exp/store_patterns.hip). Each lane owns a fixed pair of CSR columns
+// and walks down the rows, so the loop body is two LDS reads, one store and a
+// few integer adds.
 //
-// Gram (WITH_GRAM): G = Tt T over the tile columns, accumulated over the
-// passes of the observation with v_mfma_f64_16x16x4_f64. One k-step is 4 tile
-// rows; lane l supplies T[4s + l/16][16b + l%16] for column block b, which is
-// simultaneously the A operand (A[i=l%16][k=l/16]) of row block b and the B
-// operand (B[k=l/16][j=l%16]) of column block b. Accumulator register v of
-// lane l holds G[16bi + l/16 + 4v][16bj + l%16] (layout measured on gfx950,
-// tools/mfma_f64_layout_probe.hip). The last column of G is Tt x = the
-// observation's slice of Jt x, its corner is |x|^2.
-typedef double double4_t __attribute__((ext_vector_type(4)));
+// Gram (WITH_GRAM): G = Tt T over the tile columns with v_mfma_f64_4x4x4f64
+// (problem.hpp). On gfx950 the FP64 MFMAs run on the same FP64 lanes as the
+// vector FMAs (measured: they do not overlap, tools/exp/launch_floor.hip), and
+// the 4x4x4 form is 1.46x faster per flop than 16x16x4 and wastes no flops on
+// padding a 27-column tile to 32: 350 instead of 150 MFMAs per observation,
+// at 19 instead of 113 cycles each. The last tile column is the residual, so
+// the last column of G is Tt x = the observation's slice of Jt x and its
+// corner |x|^2.
+//
+// Nothing in the pass loop loads from global memory: the observed pixels are
+// staged in LDS up front, the intrinsics were unpacked by the prologue kernel.
+// The stores are fire-and-forget.
+
+// CSR column c of a board row with image coordinate xy -> tile column
+__device__ __forceinline__
+int board_csr_to_tile_col(const DeviceProblem& P, bool has_ext, int c, int xy)
+{
+    if(P.Ncore_state)
+    {
+        if(c < 2) return 2*c + xy;      // f, then c, of this row's own coordinate
+        c -= 2;
+    }
+    if(c < P.Ndist_state) return 4 + c;
+    c -= P.Ndist_state;
+    if(has_ext)
+    {
+        if(c < 6) return tile_ext0(P.Ndist) + c;
+        c -= 6;
+    }
+    if(P.do_optimize_frames)
+    {
+        if(c < 6) return tile_frame0(P.Ndist) + c;
+        c -= 6;
+    }
+    return tile_warp0(P.Ndist) + c;
+}
 
 template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM>
 __global__ __launch_bounds__(64)
 void board_kernel(DeviceProblem P,
-                  const double* __restrict__ b,
                   const double* __restrict__ joint,
                   double*       __restrict__ x,
                   double*       __restrict__ Jv,
                   double*       __restrict__ gram)
 {
-    extern __shared__ __attribute__((aligned(16))) double tile[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+
+    constexpr int EXT0   = 4 + NDIST;
+    constexpr int FRAME0 = EXT0 + 6;
+    constexpr int WARP0  = FRAME0 + 6;
+    constexpr int XCOL   = WARP0 + 2;
+    constexpr int NCOLS  = XCOL + 1;
+    constexpr int NBLK   = (NCOLS + 3)/4;
+    constexpr int NCOLS4 = 4*NBLK;              // columns written per row, incl. the zero padding
+    constexpr int KS     = NCOLS4 | 1;          // odd LDS row stride
+    constexpr int NPAIRS = NBLK*(NBLK+1)/2;
+    constexpr int NM     = (NPAIRS + 3)/4;      // MFMAs per k-step
 
     const int iobs = blockIdx.x;
     const int lane = threadIdx.x;
@@ -241,85 +291,118 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ jp = joint + (size_t)iobs*JOINT_STRIDE;
 
     const int  k       = m.nnz_per_row;
-    const int  ncore   = P.Ncore_state;          // 0 or 4
-    const int  kt      = k + (ncore ? 2 : 0);    // tile columns holding J
-    const int  kx      = kt + (WITH_GRAM ? 1 : 0);
-    const int  ks      = kx | 1;                 // odd LDS row stride
-    const int  ks_alloc = P.board_tile_stride;   // the stride the LDS allocation was sized for (>= ks)
     const int  NPTS    = P.W*P.H;
-    const int  NROWS   = 2*NPTS;
     const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
 
-    // filled without a loop: see the note in lens_models.hpp
-    double intr[4 + NDIST];
-#define MRCAL_AMD_LOAD_INTR(i) if((i) < 4+NDIST) intr[(i) < 4+NDIST ? (i) : 0] = get_intrinsic(P, b, m.icam_intrinsics, (i))
-    MRCAL_AMD_LOAD_INTR(0);  MRCAL_AMD_LOAD_INTR(1);  MRCAL_AMD_LOAD_INTR(2);  MRCAL_AMD_LOAD_INTR(3);
-    MRCAL_AMD_LOAD_INTR(4);  MRCAL_AMD_LOAD_INTR(5);  MRCAL_AMD_LOAD_INTR(6);  MRCAL_AMD_LOAD_INTR(7);
-    MRCAL_AMD_LOAD_INTR(8);  MRCAL_AMD_LOAD_INTR(9);  MRCAL_AMD_LOAD_INTR(10); MRCAL_AMD_LOAD_INTR(11);
-    MRCAL_AMD_LOAD_INTR(12); MRCAL_AMD_LOAD_INTR(13); MRCAL_AMD_LOAD_INTR(14); MRCAL_AMD_LOAD_INTR(15);
-#undef MRCAL_AMD_LOAD_INTR
-    static_assert(4 + NDIST <= 16, "extend the list above");
-    const double intr_fx = intr[0], intr_fy = intr[1], intr_cx = intr[2], intr_cy = intr[3];
+    double* __restrict__ tile    = lds;
+    double* __restrict__ obs_lds = lds + 64*KS;
 
-    double warp[2] = {0.0, 0.0};
-    if(P.has_warp_seed) get_warp(warp, P, b);
-
-    // upper-triangular 16x16 tiles of G: up to 3 column blocks
-    constexpr int NBMAX = GRAM_NB_MAX;
-    constexpr int NTMAX = GRAM_NT_MAX;
-    double4_t acc[WITH_GRAM ? NTMAX : 1];
-    if(WITH_GRAM)
-    {
-#pragma unroll
-        for(int t=0;t<NTMAX;t++) acc[t] = (double4_t){0.0,0.0,0.0,0.0};
-    }
-    const int NB = (kx + 15) >> 4;
-
-    // copy-out stepping: element index e advances by 128 per iteration
-    const int step_rows = 128 / k;
-    const int step_cols = 128 - step_rows*k;
-
-    const bool isy = (lane & 1) != 0;            // passes start at even rows
-
-    // HW_REG_HW_ID[3:0]: this wave's slot in its SIMD
-    const int order = (P.debug_ablate & 8) ? 0 : (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1);
-
-    // The observation's pixels and weights (NPTS x 3 doubles) are staged in
-    // LDS up front, behind the tile. After that this wave issues NO vector
-    // loads: its stores are fire-and-forget, and nothing in the pass loop
-    // waits on vmcnt. (A global load inside the loop would have to wait for
-    // every store issued before it: vmcnt retires in order, and with a
-    // data-dependent number of stores per pass the compiler can only wait for
-    // vmcnt(0), which serializes the HBM write stream with the arithmetic.)
-    double* __restrict__ obs_lds = tile + 64*ks_alloc;
+    // stage the observation: qx,qy,weight of every corner. All the loads are
+    // issued before the first wait
     {
         const double* __restrict__ pool = P.board_pool + (size_t)iobs*NPTS*3;
-        for(int i = lane; i < 3*NPTS; i += 64) obs_lds[i] = pool[i];
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    for(int row0 = 0; row0 < NROWS; row0 += 64)
-    {
-        const int r     = row0 + lane;
-        const int nrows = (NROWS - row0 < 64) ? (NROWS - row0) : 64;
-
-        if(r < NROWS)
+        for(int base = 0; base < 3*NPTS; base += 64*8)
         {
-            const int pt = r >> 1;
+            double v[8];
+#pragma unroll
+            for(int j=0;j<8;j++)
+            {
+                const int idx = base + 64*j + lane;
+                v[j] = (idx < 3*NPTS) ? pool[idx] : 0.0;
+            }
+#pragma unroll
+            for(int j=0;j<8;j++)
+            {
+                const int idx = base + 64*j + lane;
+                if(idx < 3*NPTS) obs_lds[idx] = v[j];
+            }
+        }
+    }
+
+    // intrinsics of this camera and the board warp, unpacked by the prologue kernel
+    const double* __restrict__ ip = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
+    double intr[4 + NDIST];
+#pragma unroll
+    for(int i=0;i<4+NDIST;i++) intr[i] = ip[i];
+    const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
+    const double warp0 = wp[0], warp1 = wp[1];
+
+    // Gram operand addressing: for MFMA mm this lane reads, at tile row
+    // 4 s + lane/16, column 4 bi + lane%4 (A) and 4 bj + lane%4 (B) of the
+    // block pair in its slot
+    int goffA[WITH_GRAM ? NM : 1], goffB[WITH_GRAM ? NM : 1];
+    double acc[WITH_GRAM ? NM : 1];
+    if(WITH_GRAM)
+    {
+        const int slot = (lane >> 2) & 3;
+#pragma unroll
+        for(int mm=0;mm<NM;mm++)
+        {
+            int p = 4*mm + slot;
+            if(p >= NPAIRS) p = 0;
+            // unrank p -> (bi <= bj) without a data-dependent loop: block row
+            // i starts at pair index i NBLK - i(i-1)/2
+            int bi = 0, first = 0;
+#pragma unroll
+            for(int i=1;i<NBLK;i++)
+            {
+                const int first_i = i*NBLK - i*(i-1)/2;
+                if(p >= first_i) { bi = i; first = first_i; }
+            }
+            const int bj = bi + (p - first);
+            goffA[mm] = (lane >> 4)*KS + 4*bi + (lane & 3);
+            goffB[mm] = (lane >> 4)*KS + 4*bj + (lane & 3);
+            acc[mm] = 0.0;
+        }
+    }
+
+    // copy-out: this lane's fixed pair of CSR columns (k even), as tile
+    // columns for an x row and for a y row
+    const int  pairs_per_row = k >> 1;
+    const int  rows_per_iter = (k > 0 && !(k & 1)) ? 64 / pairs_per_row : 0;
+    const bool co_active     = lane < rows_per_iter*pairs_per_row;
+    const int  co_rsub       = co_active ? lane / pairs_per_row : 0;
+    const int  co_c0         = 2*(lane - co_rsub*pairs_per_row);
+    int co_tx0 = 0, co_tx1 = 0, co_ty0 = 0, co_ty1 = 0;
+    if(WITH_J && co_active)
+    {
+        co_tx0 = board_csr_to_tile_col(P, has_ext, co_c0,   0);
+        co_tx1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 0);
+        co_ty0 = board_csr_to_tile_col(P, has_ext, co_c0,   1);
+        co_ty1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 1);
+    }
+
+    __builtin_amdgcn_wave_barrier();   // obs_lds is complete (one wave: the LDS is in order)
+    if(P.debug_ablate & 16) { if(obs_lds[lane] + intr[0] + warp0 + jp[0] == 12345.678) x[0] = 1.0; return; }
+
+    for(int pt0 = 0; pt0 < NPTS; pt0 += 64)
+    {
+        const int  pt    = pt0 + lane;
+        const bool valid = pt < NPTS;
+
+        // both rows of this corner, at the fixed tile columns
+        double row[2][NCOLS4];
+#pragma unroll
+        for(int xy=0;xy<2;xy++)
+#pragma unroll
+            for(int c=0;c<NCOLS4;c++) row[xy][c] = 0.0;
+
+        if(valid)
+        {
             const int iy = pt / P.W;
             const int ix = pt - iy*P.W;
             const double bx = (double)ix * P.spacing;
             const double by = (double)iy * P.spacing;
-            double bz = 0.0, dz_dw[2] = {0.0, 0.0};
+            double bz = 0.0, dz_dw0 = 0.0, dz_dw1 = 0.0;
             if(P.has_warp_seed)
             {
                 // parabolic flex along each board axis, max deflection at the centre
                 const double xr = (double)ix / (double)(P.W - 1);
                 const double yr = (double)iy / (double)(P.H - 1);
-                dz_dw[0] = 4.0*xr*(1.0 - xr);
-                dz_dw[1] = 4.0*yr*(1.0 - yr);
-                bz += warp[0]*dz_dw[0];
-                bz += warp[1]*dz_dw[1];
+                dz_dw0 = 4.0*xr*(1.0 - xr);
+                dz_dw1 = 4.0*yr*(1.0 - yr);
+                bz += warp0*dz_dw0;
+                bz += warp1*dz_dw1;
             }
 
             double p[3];
@@ -327,47 +410,46 @@ void board_kernel(DeviceProblem P,
             for(int i=0;i<3;i++)
                 p[i] = jp[JOINT_R+3*i+0]*bx + jp[JOINT_R+3*i+1]*by + jp[JOINT_R+3*i+2]*bz + jp[JOINT_T+i];
 
-            double q, dq_dp[3], dq_dk[NDIST > 0 ? NDIST : 1];
+            double q[2], dq_dp[2][3], dq_dk[2][NDIST > 0 ? NDIST : 1];
             if(P.debug_ablate & 4)
             {
-                q = p[0]; dq_dp[0] = p[0]; dq_dp[1] = p[1]; dq_dp[2] = p[2];
+                q[0] = p[0]; q[1] = p[1];
 #pragma unroll
-                for(int i=0;i<NDIST;i++) dq_dk[i] = p[0] + (double)i;
+                for(int i=0;i<3;i++) { dq_dp[0][i] = p[i]; dq_dp[1][i] = p[i] + 1.0; }
+#pragma unroll
+                for(int i=0;i<NDIST;i++) { dq_dk[0][i] = p[0] + (double)i; dq_dk[1][i] = p[1] + (double)i; }
             }
             else
-            project_lens_row<PROJ,NDIST,WITH_J>(lane & 1, &q, dq_dp, dq_dk, p, intr, P.cfg);
+            project_lens<PROJ,NDIST,WITH_J>(q, dq_dp, dq_dk, p, intr, P.cfg);
 
-            const double q_obs  = obs_lds[3*pt + (lane & 1)];
+            const double qx_obs = obs_lds[3*pt + 0];
+            const double qy_obs = obs_lds[3*pt + 1];
             const double w      = obs_lds[3*pt + 2];
             const bool   inlier = (w >= 0.0);
 
-            const double err = inlier ? (q - q_obs)*w : 0.0;
-            x[m.i_meas0 + r] = err;
+            double2 err;
+            err.x = inlier ? (q[0] - qx_obs)*w : 0.0;
+            err.y = inlier ? (q[1] - qy_obs)*w : 0.0;
+            *reinterpret_cast<double2*>(&x[m.i_meas0 + 2*pt]) = err;
 
-            if(WITH_J)
+            // outliers keep their columns and get all-zero values: everything
+            // below is skipped for them and the rows stay 0
+            if(WITH_J && inlier)
             {
-                double* __restrict__ row = tile + (size_t)lane*ks;
-                // outliers keep their columns and get all-zero values
-                const double ww = inlier ? w : 0.0;
-                int c = 0;
-                if(ncore)
+                if(P.Ncore_state)
                 {
-                    const double f  = isy ? intr_fy : intr_fx;
-                    const double cc = isy ? intr_cy : intr_cx;
-                    const double vf = inlier ? ((q - cc)/f) * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
-                    const double vc = ww * SCALE_INTRINSICS_CENTER_PIXEL;
-                    row[0] = isy ? 0.0 : vf;
-                    row[1] = isy ? vf  : 0.0;
-                    row[2] = isy ? 0.0 : vc;
-                    row[3] = isy ? vc  : 0.0;
-                    c = 4;
+                    row[0][0] = (q[0] - intr[2])/intr[0] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
+                    row[0][2] = w * SCALE_INTRINSICS_CENTER_PIXEL;
+                    row[1][1] = (q[1] - intr[3])/intr[1] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
+                    row[1][3] = w * SCALE_INTRINSICS_CENTER_PIXEL;
                 }
                 if(NDIST > 0 && P.Ndist_state)
                 {
 #pragma unroll
-                    for(int i=0;i<NDIST;i++)
-                        row[c+i] = inlier ? dq_dk[i] * w * SCALE_DISTORTION : 0.0;
-                    c += NDIST;
+                    for(int xy=0;xy<2;xy++)
+#pragma unroll
+                        for(int i=0;i<NDIST;i++)
+                            row[xy][4+i] = dq_dk[xy][i] * w * SCALE_DISTORTION;
                 }
                 if(has_ext)
                 {
@@ -383,11 +465,14 @@ void board_kernel(DeviceProblem P,
                                 by*jp[JOINT_MC + 9  + 3*i + l] +
                                 bz*jp[JOINT_MC + 18 + 3*i + l] +
                                 jp[JOINT_DTJ_DRC + 3*i + l];
-                        const double g = dq_dp[0]*dp[0] + dq_dp[1]*dp[1] + dq_dp[2]*dp[2];
-                        row[c+l]   = inlier ? g * w * SCALE_ROTATION_CAMERA : 0.0;
-                        row[c+3+l] = inlier ? dq_dp[l] * w * SCALE_TRANSLATION_CAMERA : 0.0;
+#pragma unroll
+                        for(int xy=0;xy<2;xy++)
+                        {
+                            const double g = dq_dp[xy][0]*dp[0] + dq_dp[xy][1]*dp[1] + dq_dp[xy][2]*dp[2];
+                            row[xy][EXT0+l]   = g * w * SCALE_ROTATION_CAMERA;
+                            row[xy][EXT0+3+l] = dq_dp[xy][l] * w * SCALE_TRANSLATION_CAMERA;
+                        }
                     }
-                    c += 6;
                 }
                 if(P.do_optimize_frames)
                 {
@@ -404,123 +489,131 @@ void board_kernel(DeviceProblem P,
                                 bz*jp[JOINT_MF + 18 + 3*i + l];
                             dpt[i] = jp[JOINT_DTJ_DTF + 3*i + l];
                         }
-                        const double gr = dq_dp[0]*dpr[0] + dq_dp[1]*dpr[1] + dq_dp[2]*dpr[2];
-                        const double gt = dq_dp[0]*dpt[0] + dq_dp[1]*dpt[1] + dq_dp[2]*dpt[2];
-                        row[c+l]   = inlier ? gr * w * SCALE_ROTATION_FRAME    : 0.0;
-                        row[c+3+l] = inlier ? gt * w * SCALE_TRANSLATION_FRAME : 0.0;
+#pragma unroll
+                        for(int xy=0;xy<2;xy++)
+                        {
+                            const double gr = dq_dp[xy][0]*dpr[0] + dq_dp[xy][1]*dpr[1] + dq_dp[xy][2]*dpr[2];
+                            const double gt = dq_dp[xy][0]*dpt[0] + dq_dp[xy][1]*dpt[1] + dq_dp[xy][2]*dpt[2];
+                            row[xy][FRAME0+l]   = gr * w * SCALE_ROTATION_FRAME;
+                            row[xy][FRAME0+3+l] = gt * w * SCALE_TRANSLATION_FRAME;
+                        }
                     }
-                    c += 6;
                 }
                 if(P.has_warp_state)
                 {
                     // dq/dwarp_i = (dq/dt . Rj[:,2]) dz/dwarp_i
-                    const double d =
-                        dq_dp[0]*jp[JOINT_R + 2] +
-                        dq_dp[1]*jp[JOINT_R + 5] +
-                        dq_dp[2]*jp[JOINT_R + 8];
-                    row[c+0] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[0]) : 0.0;
-                    row[c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
-                    c += 2;
+#pragma unroll
+                    for(int xy=0;xy<2;xy++)
+                    {
+                        const double d =
+                            dq_dp[xy][0]*jp[JOINT_R + 2] +
+                            dq_dp[xy][1]*jp[JOINT_R + 5] +
+                            dq_dp[xy][2]*jp[JOINT_R + 8];
+                        row[xy][WARP0+0] = (w*SCALE_CALOBJECT_WARP)*(d*dz_dw0);
+                        row[xy][WARP0+1] = (w*SCALE_CALOBJECT_WARP)*(d*dz_dw1);
+                    }
                 }
-                if(WITH_GRAM)
-                    row[c] = err;
+            }
+            if(WITH_GRAM)
+            {
+                row[0][XCOL] = err.x;
+                row[1][XCOL] = err.y;
             }
         }
 
-        if(WITH_J)
-        {
-            // The workgroup IS one wavefront, and the LDS executes a wave's DS
-            // instructions in order: the tile reads below see the writes above
-            // without an s_barrier. __syncthreads() would also wait for this
-            // wave's outstanding global stores (vmcnt(0)), i.e. serialize the
-            // HBM write stream of a pass with the arithmetic of the next one
-            __builtin_amdgcn_wave_barrier();
-            // Two phases read the tile: the copy-out (vector-memory bound)
-            // and the Gram (MFMA bound). Waves alternate the order by the
-            // parity of their hardware wave slot, so that co-resident waves
-            // of a SIMD lean on different pipes at the same time
-            for(int phase = 0; phase < 2; phase++)
-            {
-                if((phase ^ order) == 0)
-                {
-                    // Stream the tile out. Output element e of this pass is CSR row
-                    // e/k, column e%k. 16 bytes per lane per store, 1 KiB contiguous
-                    // per wave instruction. nrows is even, so is the element count
-                    const int nelem = nrows*k;
-                    double* __restrict__ out = Jv + m.i_nnz0 + (size_t)row0*k;
-                    int e  = 2*lane;
-                    int r0 = e / k;
-                    int c0 = e - r0*k;
-                    if(!(P.debug_ablate & 1))
-                    for(; e < nelem; e += 128)
-                    {
-                        int r1 = r0, c1 = c0 + 1;
-                        if(c1 == k) { c1 = 0; r1++; }
-                        // CSR column -> tile column: the row's own 2 core columns
-                        // (f then c) sit at tile columns xy and 2+xy
-                        const int xy0 = r0 & 1, xy1 = r1 & 1;
-                        const int t0 = ncore ? ((c0 < 2) ? (2*c0 + xy0) : (c0 + 2)) : c0;
-                        const int t1 = ncore ? ((c1 < 2) ? (2*c1 + xy1) : (c1 + 2)) : c1;
-                        double2 v;
-                        v.x = tile[r0*ks + t0];
-                        v.y = tile[r1*ks + t1];
-                        *reinterpret_cast<double2*>(&out[e]) = v;
-                        c0 += step_cols; r0 += step_rows;
-                        if(c0 >= k) { c0 -= k; r0++; }
-                    }
+        if(!WITH_J) continue;
 
-                }
-                else
+        // the two halves of the pass go through the tile one after the other
+        for(int h = 0; h < 2; h++)
+        {
+            const int nc    = NPTS - pt0 - 32*h;          // corners in this half
+            if(nc <= 0) break;
+            const int nrows = 2*((nc < 32) ? nc : 32);
+
+            // WAR: the previous half's tile reads are complete (in-order LDS)
+            __builtin_amdgcn_wave_barrier();
+            if((lane >> 5) == h)
+            {
+                double* __restrict__ t0 = tile + (size_t)(2*(lane & 31))*KS;
+#pragma unroll
+                for(int c=0;c<NCOLS4;c++)
                 {
-                    if(WITH_GRAM && !(P.debug_ablate & 2))
-                    {
-                        // G += Tt T over this pass. 4 tile rows per k-step; rows
-                        // beyond nrows hold stale data and are masked out
-                        const int nsteps = (nrows + 3) >> 2;
-                        const int col    = lane & 15;
-                        for(int s = 0; s < nsteps; s++)
-                        {
-                            const int  rr    = 4*s + (lane >> 4);
-                            const bool valid = rr < nrows;
-                            const double* __restrict__ trow = tile + rr*ks;
-                            double a[NBMAX];
-#pragma unroll
-                            for(int bb=0;bb<NBMAX;bb++)
-                            {
-                                const int cc = 16*bb + col;
-                                a[bb] = (bb < NB && valid && cc < kx) ? trow[cc] : 0.0;
-                            }
-                            int t = 0;
-#pragma unroll
-                            for(int bi=0;bi<NBMAX;bi++)
-#pragma unroll
-                                for(int bj=bi;bj<NBMAX;bj++,t++)
-                                    if(bj < NB)
-                                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
-                        }
-                    }
+                    t0[c]      = row[0][c];
+                    t0[KS + c] = row[1][c];
                 }
             }
             __builtin_amdgcn_wave_barrier();
+
+            // stream the half-tile out: rows row0 .. row0+nrows of the observation
+            double* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
+            if(!(P.debug_ablate & 1))
+            {
+                if(rows_per_iter > 0)
+                {
+                    if(co_active)
+                        for(int r = co_rsub; r < nrows; r += rows_per_iter)
+                        {
+                            const bool isy = (r & 1) != 0;
+                            double2 v;
+                            v.x = tile[r*KS + (isy ? co_ty0 : co_tx0)];
+                            v.y = tile[r*KS + (isy ? co_ty1 : co_tx1)];
+                            *reinterpret_cast<double2*>(&out[r*k + co_c0]) = v;
+                        }
+                }
+                else
+                {
+                    // odd k: a 16-byte pair can straddle two rows
+                    const int nelem = nrows*k;
+                    for(int e = 2*lane; e < nelem; e += 128)
+                    {
+                        const int r0 = e / k,       c0 = e - r0*k;
+                        const int r1 = (e+1) / k,   c1 = (e+1) - r1*k;
+                        double2 v;
+                        v.x = tile[r0*KS + board_csr_to_tile_col(P, has_ext, c0, r0 & 1)];
+                        v.y = tile[r1*KS + board_csr_to_tile_col(P, has_ext, c1, r1 & 1)];
+                        *reinterpret_cast<double2*>(&out[e]) = v;
+                    }
+                }
+            }
+
+            if(WITH_GRAM && !(P.debug_ablate & 2))
+            {
+                // G += Tt T over this half. 4 tile rows per k-step; the rows
+                // between nrows and the end of the last step belong to lanes
+                // without a corner, which stored zeros
+                // A full half (64 rows, 16 steps) runs fully unrolled: the
+                // step's row offset folds into the DS instructions' immediate
+                // offsets, and with no branches in between the loads of the
+                // next steps are issued under the MFMAs of this one
+                const int nsteps = (nrows + 3) >> 2;
+                if(nsteps == 16)
+                {
+#pragma unroll
+                    for(int s = 0; s < 16; s++)
+#pragma unroll
+                        for(int mm=0;mm<NM;mm++)
+                            acc[mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tile[goffA[mm] + s*4*KS],
+                                                                         tile[goffB[mm] + s*4*KS],
+                                                                         acc[mm], 0, 0, 0);
+                }
+                else
+                    for(int s = 0; s < nsteps; s++)
+                    {
+                        const double* __restrict__ ts = tile + s*4*KS;
+#pragma unroll
+                        for(int mm=0;mm<NM;mm++)
+                            acc[mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(ts[goffA[mm]], ts[goffB[mm]], acc[mm], 0, 0, 0);
+                    }
+            }
         }
     }
 
     if(WITH_J && WITH_GRAM)
     {
-        // accumulator layout, tile-major: gram[iobs][t][v][lane]. Only the
-        // tiles in use are written
-        double* __restrict__ g = gram + (size_t)iobs*GRAM_STRIDE;
-        int t = 0;
+        double* __restrict__ g = gram + (size_t)iobs*(NM*64);
 #pragma unroll
-        for(int bi=0;bi<NBMAX;bi++)
-#pragma unroll
-            for(int bj=bi;bj<NBMAX;bj++,t++)
-                if(bj < NB)
-                {
-#pragma unroll
-                    for(int v=0;v<4;v++)
-                        g[(size_t)t*256 + v*64 + lane] = acc[t][v];
-                }
+        for(int mm=0;mm<NM;mm++)
+            g[mm*64 + lane] = acc[mm];
     }
 }
 
@@ -806,18 +899,20 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
 {
     if(P.Nobs_board > 0)
     {
-        hipLaunchKernelGGL(board_prologue_kernel, dim3((P.Nobs_board + 63)/64), dim3(64), 0, stream,
+        const int nblocks_obs    = (P.Nobs_board + 63)/64;
+        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack), dim3(64), 0, stream,
                            P, B.b, B.joint);
         if(ev_j0) hipEventRecord(ev_j0, stream);
         if(with_jacobian && B.gram != NULL)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.b, B.joint, B.x, B.Jv, B.gram);
+                               P, B.joint, B.x, B.Jv, B.gram);
         else if(with_jacobian)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
+                               P, B.joint, B.x, B.Jv, (double*)NULL);
         else
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.b, B.joint, B.x, B.Jv, (double*)NULL);
+                               P, B.joint, B.x, B.Jv, (double*)NULL);
         if(ev_j1) hipEventRecord(ev_j1, stream);
     }
     if(P.Nobs_point > 0)

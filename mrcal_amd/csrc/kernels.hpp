@@ -16,7 +16,7 @@ struct EvalBuffers
     double*  Jv;     // CSR values               [Nnz]
     int32_t* Jp;     // CSR rowptr               [Nmeas+1]
     int32_t* Ji;     // CSR colidx               [Nnz]
-    double*  gram;   // per-observation Gram     [Nobs_board][GRAM_STRIDE]; NULL: don't form it
+    double*  gram;   // per-observation Gram     [Nobs_board][gram_stride(Ndist)]; NULL: don't form it
 };
 
 bool lens_supported(int lens_type);

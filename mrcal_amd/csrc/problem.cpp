@@ -83,7 +83,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->op[1].b,  (size_t)L.Nstate);
     ok = ok && dev_alloc(&P->op[1].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc(&P->op[1].Jv, (size_t)P->Nnz);
-    ok = ok && dev_alloc(&P->d_gram,   (size_t)P->D.Nobs_board*GRAM_STRIDE);
+    ok = ok && dev_alloc(&P->d_gram,   (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
     for(int i=0;i<2 && ok;i++)
     {
         ok = ok && dev_alloc(&P->op[i].N.A,       (size_t)nd.Nc*nd.Nc);
@@ -357,15 +357,15 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         return NULL;
     }
     // tile columns: k, +2 for the full core, +1 for the residual column (see board_kernel)
-    // + the observation's pixels and weights, staged behind the tile
-    const int board_tile_stride = (kmax + 3) | 1;
-    P->lds_bytes = (64*board_tile_stride + 3*NPTS) * (int)sizeof(double);
+    // LDS of the board kernel: the 64-row tile + the observation's pixels and weights
+    P->lds_bytes = (64*tile_stride(L.Ndist) + 3*NPTS) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
-        set_error("a board row has %d nonzeros and the board %d corners: the LDS tile would not fit", kmax, NPTS);
+        set_error("the board has %d corners and the lens model %d distortion parameters: the LDS tile would not fit", NPTS, L.Ndist);
         delete P;
         return NULL;
     }
+    (void)kmax;
 
     // board pool of the local observations
     std::vector<mrcal_point3_t> pool_local;
@@ -395,7 +395,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     ok = ok && dev_upload(&P->d_point_pool,        (const double*)observations_point_pool, (size_t)Npoint_local*3);
     ok = ok && dev_upload(&P->d_imagersizes,       imagersizes,                 (size_t)Ncameras_intrinsics*2);
     ok = ok && dev_alloc (&P->op[0].b,  (size_t)L.Nstate);
-    ok = ok && dev_alloc (&P->d_joint,  (size_t)Nboard_local*JOINT_STRIDE);
+    // + the unpacked intrinsics and warp (DeviceProblem::unpacked)
+    ok = ok && dev_alloc (&P->d_joint,  (size_t)Nboard_local*JOINT_STRIDE + (size_t)Ncameras_intrinsics*L.Nintrinsics + 2);
     ok = ok && dev_alloc (&P->op[0].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc (&P->op[0].Jv, (size_t)innz);
     ok = ok && dev_alloc (&P->d_Jp,     (size_t)L.Nmeas+1);
@@ -444,7 +445,6 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.Nobs_board = Nboard_local; D.Nobs_point = Npoint_local;
     D.W = calibration_object_width_n; D.H = calibration_object_height_n;
     D.spacing = calibration_object_spacing;
-    D.board_tile_stride = board_tile_stride;
     if(calobject_warp) { D.seed_warp[0] = calobject_warp->x2; D.seed_warp[1] = calobject_warp->y2; }
     if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
     {
@@ -471,6 +471,7 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.point_meta        = P->d_point_meta;
     D.point_pool        = P->d_point_pool;
     D.imagersizes       = P->d_imagersizes;
+    D.unpacked          = P->d_joint + (size_t)Nboard_local*JOINT_STRIDE;
 
     // the seed state
     P->b_host.assign(L.Nstate > 0 ? L.Nstate : 1, 0.0);

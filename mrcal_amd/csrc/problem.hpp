@@ -81,23 +81,59 @@ enum
     JOINT_STRIDE  = 84
 };
 
-// Per-board-observation Gram matrix G = Tt T of the observation's Jacobian
-// tile T (columns in state order, plus the residual as a last column), as the
-// MFMA accumulators leave it: up to 3 column blocks of 16 -> 6 upper-triangular
-// 16x16 tiles, tile-major, each tile [v][lane] with G[16bi + lane/16 + 4v][16bj + lane%16]
-enum { GRAM_NB_MAX = 3, GRAM_NT_MAX = 6, GRAM_STRIDE = GRAM_NT_MAX*256 };
-__host__ __device__ inline int gram_tile_index(int bi, int bj) // bi <= bj
+// The Jacobian tile of a board observation, as the board kernel lays it out in
+// LDS: one row per measurement, columns at FIXED positions that depend on the
+// lens model only (NDIST = its number of distortion parameters), whether or
+// not the corresponding block is being optimized:
+//
+//   [0..3]   fx fy cx cy      an x row holds (dq/dfx, 0, w, 0), a y row (0, dq/dfy, 0, w)
+//   [4..)    distortions      NDIST
+//   [EXT0..) r_cam t_cam      6
+//   [FRAME0..) r_frame t_frame 6
+//   [WARP0..) warp            2
+//   [XCOL]   the residual x
+//   padding to a multiple of 4, zero
+//
+// Blocks that are not in the state (or a camera that sits at the reference)
+// hold zeros. The fixed layout costs a few zero columns in the Gram; it buys
+// compile-time register indexing in the kernel.
+__host__ __device__ inline int tile_ext0  (int ndist) { return 4 + ndist; }
+__host__ __device__ inline int tile_frame0(int ndist) { return 4 + ndist + 6; }
+__host__ __device__ inline int tile_warp0 (int ndist) { return 4 + ndist + 12; }
+__host__ __device__ inline int tile_xcol  (int ndist) { return 4 + ndist + 14; }
+__host__ __device__ inline int tile_ncols (int ndist) { return 4 + ndist + 15; }
+__host__ __device__ inline int tile_nblk  (int ndist) { return (tile_ncols(ndist) + 3) >> 2; }
+// LDS row stride in doubles: odd (conflict-free per-lane column writes), >= 4 nblk
+__host__ __device__ inline int tile_stride(int ndist) { return (4*tile_nblk(ndist)) | 1; }
+
+// Per-board-observation Gram matrix G = Tt T of the tile, formed with
+// v_mfma_f64_4x4x4f64 (4 independent 4x4 blocks per instruction, k = 4 tile
+// rows per step). G is cut into 4x4 blocks; the NBLK(NBLK+1)/2 blocks (bi<=bj)
+// are numbered row-major over the upper triangle, block pair p goes to MFMA
+// p/4, block slot p%4. Measured operand layout on gfx950
+// (tools/mfma_f64_4x4x4_layout_probe.hip):
+//   A lane = 16 k + 4 slot + i     B lane = 16 k + 4 slot + j     D lane = 16 i + 4 slot + j
+// so accumulator m, lane l holds G[4 bi + l/16][4 bj + l%4] of the pair in slot (l%16)/4.
+// Storage: gram[iobs][m][lane], gram_nmfma(ndist)*64 doubles per observation
+__host__ __device__ inline int gram_npairs(int ndist) { const int n = tile_nblk(ndist); return n*(n+1)/2; }
+__host__ __device__ inline int gram_nmfma (int ndist) { return (gram_npairs(ndist) + 3) >> 2; }
+__host__ __device__ inline int gram_stride(int ndist) { return gram_nmfma(ndist)*64; }
+__host__ __device__ inline int gram_pair_index(int nblk, int bi, int bj) // bi <= bj
 {
-    // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-    return bi*GRAM_NB_MAX - bi*(bi-1)/2 + (bj - bi);
+    return bi*nblk - bi*(bi-1)/2 + (bj - bi);
+}
+__host__ __device__ inline void gram_pair_unrank(int nblk, int p, int* bi, int* bj)
+{
+    int i = 0;
+    while(i < nblk-1 && p >= nblk - i) { p -= nblk - i; i++; }
+    *bi = i; *bj = i + p;
 }
 // G[i][j], any i,j
-__host__ __device__ inline double gram_get(const double* g, int i, int j)
+__host__ __device__ inline double gram_get(const double* g, int nblk, int i, int j)
 {
-    if(i > j) { int t = i; i = j; j = t; }
-    int bi = i >> 4, bj = j >> 4, ii = i & 15, jj = j & 15;
-    if(bi == bj && ii > jj) { int t = ii; ii = jj; jj = t; } // diagonal tiles are symmetric
-    return g[gram_tile_index(bi,bj)*256 + (ii >> 2)*64 + ((ii & 3) << 4) + jj];
+    if((i >> 2) > (j >> 2)) { int t = i; i = j; j = t; }
+    const int p = gram_pair_index(nblk, i >> 2, j >> 2);
+    return g[(p >> 2)*64 + 16*(i & 3) + 4*(p & 3) + (j & 3)];
 }
 
 struct DeviceProblem
@@ -113,7 +149,6 @@ struct DeviceProblem
     int Ncameras_intrinsics, Ncameras_extrinsics, Nframes, Npoints, Npoints_fixed;
     int Nobs_board, Nobs_point;
     int W, H;
-    int board_tile_stride;   // doubles per LDS tile row of the board kernel, sized for the widest row
     double spacing;
     double seed_warp[2];
 
@@ -141,6 +176,10 @@ struct DeviceProblem
     const PointObsMeta* point_meta;
     const double*       point_pool;
     const int*          imagersizes;
+
+    // state unpacked by the prologue kernel, every evaluation:
+    //   [Ncameras_intrinsics][Nintrinsics] intrinsics, then the 2 warp values
+    const double*       unpacked;
 };
 
 } // namespace mrcal_amd

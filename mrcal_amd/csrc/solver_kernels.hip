@@ -52,7 +52,9 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
     }
 }
 
-// tile column j of a board observation -> state index; -1 for the residual column
+// The assembly kernels walk the "compact" columns of a board observation: the
+// columns that exist in the state, in state order, then the residual. Compact
+// column j -> state index (-1 for the residual column)
 __device__ __forceinline__ int board_tile_col_to_state(const DeviceProblem& P, const BoardObsMeta& m, int j)
 {
     if(j < P.Nintr_state) return m.i_state_intrinsics + j;
@@ -74,12 +76,43 @@ __device__ __forceinline__ int board_tile_col_to_state(const DeviceProblem& P, c
     }
     return -1;
 }
+// compact column j -> column of the board kernel's fixed tile layout (problem.hpp)
+__device__ __forceinline__ int board_compact_to_tile_col(const DeviceProblem& P, const BoardObsMeta& m, int j)
+{
+    if(j < P.Ncore_state) return j;
+    j -= P.Ncore_state;
+    if(j < P.Ndist_state) return 4 + j;
+    j -= P.Ndist_state;
+    if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0)
+    {
+        if(j < 6) return tile_ext0(P.Ndist) + j;
+        j -= 6;
+    }
+    if(P.do_optimize_frames)
+    {
+        if(j < 6) return tile_frame0(P.Ndist) + j;
+        j -= 6;
+    }
+    if(P.has_warp_state)
+    {
+        if(j < 2) return tile_warp0(P.Ndist) + j;
+        j -= 2;
+    }
+    return tile_xcol(P.Ndist);
+}
 __device__ __forceinline__ int board_tile_ncols(const DeviceProblem& P, const BoardObsMeta& m)
 {
     return P.Nintr_state +
         ((P.do_optimize_extrinsics && m.icam_extrinsics >= 0) ? 6 : 0) +
         (P.do_optimize_frames ? 6 : 0) +
         (P.has_warp_state ? 2 : 0) + 1;
+}
+// G[i][j] by compact columns
+__device__ __forceinline__ double board_gram(const DeviceProblem& P, const BoardObsMeta& m,
+                                             const double* __restrict__ G, int i, int j)
+{
+    return gram_get(G, tile_nblk(P.Ndist),
+                    board_compact_to_tile_col(P, m, i), board_compact_to_tile_col(P, m, j));
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -105,7 +138,7 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd,
     for(int o = o0; o < o1; o++)
     {
         const BoardObsMeta m = P.board_meta[o];
-        const double* __restrict__ G = gram + (size_t)o*GRAM_STRIDE;
+        const double* __restrict__ G = gram + (size_t)o*gram_stride(P.Ndist);
         const int ncols = board_tile_ncols(P, m);
         // tile column of the frame block
         const int jf = P.Nintr_state + ((P.do_optimize_extrinsics && m.icam_extrinsics >= 0) ? 6 : 0);
@@ -113,12 +146,12 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd,
         if(t < 36)
         {
             const int a = t/6, c = t - 6*a;
-            D[(size_t)f*36 + t] += gram_get(G, jf+a, jf+c);
+            D[(size_t)f*36 + t] += board_gram(P, m, G, jf+a, jf+c);
         }
         else if(t < 42)
         {
             const int a = t - 36;
-            g[nd.Nie + e0 + a] += gram_get(G, jf+a, ncols-1);
+            g[nd.Nie + e0 + a] += board_gram(P, m, G, jf+a, ncols-1);
         }
         // Bt: (ncols-1-6) S columns x 6
         const int nS = ncols - 1 - 6;
@@ -127,7 +160,7 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd,
             const int js = idx/6, a = idx - 6*js;
             const int j  = (js < jf) ? js : js + 6;   // skip the frame columns
             const int s  = state_to_SE(nd, board_tile_col_to_state(P, m, j));
-            Bt[(size_t)(e0 + a)*nd.Nc + s] += gram_get(G, j, jf+a);
+            Bt[(size_t)(e0 + a)*nd.Nc + s] += board_gram(P, m, G, j, jf+a);
         }
         __syncthreads(); // two observations of a frame may share S columns (the warp always)
     }
@@ -162,7 +195,7 @@ void reduce_pairs_kernel(DeviceProblem P, NormalDims nd,
         const int tj = (j < jf) ? j : j + nfr;
         double acc = 0.0;
         for(int c = c0; c < c1; c++)
-            acc += gram_get(gram + (size_t)pair_obs[c]*GRAM_STRIDE, ti, tj);
+            acc += board_gram(P, m0, gram + (size_t)pair_obs[c]*gram_stride(P.Ndist), ti, tj);
 
         const int si = board_tile_col_to_state(P, m0, ti);
         const int sj = board_tile_col_to_state(P, m0, tj);
