@@ -161,8 +161,10 @@ void joint_pose_record(double* __restrict__ out,
 }
 
 __global__ __launch_bounds__(64)
-void board_prologue_kernel(DeviceProblem P, const double* __restrict__ b, double* __restrict__ joint)
+void board_prologue_kernel(DeviceProblem P, OpRef R, double* __restrict__ joint)
 {
+    if(opref_skip(R)) return;
+    const double* __restrict__ b = opref_get(R).b;
     // the blocks past the observations unpack the intrinsics of every camera
     // and the board warp from the packed state (or copy the seeds)
     const int nblocks_obs = (P.Nobs_board + 63)/64;
@@ -267,12 +269,14 @@ int board_csr_to_tile_col(const DeviceProblem& P, bool has_ext, int c, int xy)
 template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM>
 __global__ __launch_bounds__(64)
 void board_kernel(DeviceProblem P,
+                  OpRef R,
                   const double* __restrict__ joint,
-                  double*       __restrict__ x,
-                  double*       __restrict__ Jv,
                   double*       __restrict__ gram)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if(opref_skip(R)) return;
+    double* __restrict__ x  = opref_get(R).x;
+    double* __restrict__ Jv = opref_get(R).Jv;
 
     constexpr int EXT0   = 4 + NDIST;
     constexpr int FRAME0 = EXT0 + 6;
@@ -673,11 +677,12 @@ void board_structure_kernel(DeviceProblem P, int32_t* __restrict__ rowptr, int32
 ////////////////////////////////////////////////////////////////////////////////
 template<int PROJ, int NDIST, bool WITH_J>
 __global__ __launch_bounds__(64)
-void point_kernel(DeviceProblem P,
-                  const double* __restrict__ b,
-                  double*       __restrict__ x,
-                  double*       __restrict__ Jv)
+void point_kernel(DeviceProblem P, OpRef R)
 {
+    if(opref_skip(R)) return;
+    const double* __restrict__ b  = opref_get(R).b;
+    double*       __restrict__ x  = opref_get(R).x;
+    double*       __restrict__ Jv = opref_get(R).Jv;
     const int iobs = blockIdx.x*blockDim.x + threadIdx.x;
     if(iobs >= P.Nobs_point) return;
     const PointObsMeta m = P.point_meta[iobs];
@@ -826,12 +831,14 @@ void point_structure_kernel(DeviceProblem P, int32_t* __restrict__ rowptr, int32
 template<bool WITH_J, bool WITH_STRUCTURE>
 __global__ __launch_bounds__(64)
 void regularization_kernel(DeviceProblem P,
-                           const double* __restrict__ b,
-                           double*       __restrict__ x,
-                           double*       __restrict__ Jv,
+                           OpRef R,
                            int32_t*      __restrict__ rowptr,
                            int32_t*      __restrict__ colidx)
 {
+    if(opref_skip(R)) return;
+    const double* __restrict__ b  = opref_get(R).b;
+    double*       __restrict__ x  = opref_get(R).x;
+    double*       __restrict__ Jv = opref_get(R).Jv;
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     const int Ndist_rows   = P.do_apply_regularization ? P.Ncameras_intrinsics*P.Ndist_state : 0;
     const int Ncenter_rows = (P.do_apply_regularization && P.Ncore_state) ? P.Ncameras_intrinsics*2 : 0;
@@ -895,44 +902,48 @@ void regularization_kernel(DeviceProblem P,
 template<int PROJ, int NDIST>
 static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                           int lds_bytes, hipStream_t stream,
-                          hipEvent_t ev_j0, hipEvent_t ev_j1)
+                          hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
-    if(P.Nobs_board > 0)
+    if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
         const int nblocks_obs    = (P.Nobs_board + 63)/64;
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
         hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack), dim3(64), 0, stream,
-                           P, B.b, B.joint);
+                           P, B.R, B.joint);
+    }
+    if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
+    {
         if(ev_j0) hipEventRecord(ev_j0, stream);
         if(with_jacobian && B.gram != NULL)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.joint, B.x, B.Jv, B.gram);
+                               P, B.R, B.joint, B.gram);
         else if(with_jacobian)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.joint, B.x, B.Jv, (double*)NULL);
+                               P, B.R, B.joint, (double*)NULL);
         else
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,false,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B.joint, B.x, B.Jv, (double*)NULL);
+                               P, B.R, B.joint, (double*)NULL);
         if(ev_j1) hipEventRecord(ev_j1, stream);
     }
+    if(!(parts & EVAL_PART_REST)) return;
     if(P.Nobs_point > 0)
     {
         if(with_jacobian)
             hipLaunchKernelGGL((point_kernel<PROJ,NDIST,true>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream,
-                               P, B.b, B.x, B.Jv);
+                               P, B.R);
         else
             hipLaunchKernelGGL((point_kernel<PROJ,NDIST,false>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream,
-                               P, B.b, B.x, B.Jv);
+                               P, B.R);
     }
     const int Nreg = P.Nmeas - P.i_meas_regularization;
     if(Nreg > 0)
     {
         if(with_jacobian)
             hipLaunchKernelGGL((regularization_kernel<true,false>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
-                               P, B.b, B.x, B.Jv, (int32_t*)NULL, (int32_t*)NULL);
+                               P, B.R, (int32_t*)NULL, (int32_t*)NULL);
         else
             hipLaunchKernelGGL((regularization_kernel<false,false>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
-                               P, B.b, B.x, B.Jv, (int32_t*)NULL, (int32_t*)NULL);
+                               P, B.R, (int32_t*)NULL, (int32_t*)NULL);
     }
 }
 
@@ -958,20 +969,20 @@ bool lens_supported(int lens_type)
 
 hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                            int lds_bytes, hipStream_t stream,
-                           hipEvent_t ev_j0, hipEvent_t ev_j1)
+                           hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
     switch(P.lens_type)
     {
-    case MRCAL_LENSMODEL_PINHOLE:       launch_eval_t<PROJ_OPENCV,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_STEREOGRAPHIC: launch_eval_t<PROJ_STEREOGRAPHIC, 0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_LONLAT:        launch_eval_t<PROJ_LONLAT,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_LATLON:        launch_eval_t<PROJ_LATLON,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_OPENCV4:       launch_eval_t<PROJ_OPENCV,        4 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_OPENCV5:       launch_eval_t<PROJ_OPENCV,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_OPENCV8:       launch_eval_t<PROJ_OPENCV,        8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_OPENCV12:      launch_eval_t<PROJ_OPENCV,        12>(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_CAHVOR:        launch_eval_t<PROJ_CAHVOR,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
-    case MRCAL_LENSMODEL_CAHVORE:       launch_eval_t<PROJ_CAHVORE,       8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1); break;
+    case MRCAL_LENSMODEL_PINHOLE:       launch_eval_t<PROJ_OPENCV,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_STEREOGRAPHIC: launch_eval_t<PROJ_STEREOGRAPHIC, 0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_LONLAT:        launch_eval_t<PROJ_LONLAT,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_LATLON:        launch_eval_t<PROJ_LATLON,        0 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_OPENCV4:       launch_eval_t<PROJ_OPENCV,        4 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_OPENCV5:       launch_eval_t<PROJ_OPENCV,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_OPENCV8:       launch_eval_t<PROJ_OPENCV,        8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_OPENCV12:      launch_eval_t<PROJ_OPENCV,        12>(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_CAHVOR:        launch_eval_t<PROJ_CAHVOR,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_CAHVORE:       launch_eval_t<PROJ_CAHVORE,       8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
     default:
         return hipErrorInvalidValue;
     }
@@ -991,7 +1002,7 @@ hipError_t launch_structure(const DeviceProblem& P, const EvalBuffers& B, hipStr
     // rows; the host writes it otherwise
     if(Nreg > 0)
         hipLaunchKernelGGL((regularization_kernel<false,true>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
-                           P, B.b, B.x, B.Jv, B.Jp, B.Ji);
+                           P, B.R, B.Jp, B.Ji);
     return hipGetLastError();
 }
 

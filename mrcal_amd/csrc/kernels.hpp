@@ -7,13 +7,44 @@
 namespace mrcal_amd {
 
 
-// device pointers of one operating point
+// Device pointers of one operating point of the solver: a state, the cost
+// function there and its normal equations. Two of these live in device memory
+// (mrcal_amd_problem::d_ops); kernels reach them through an OpRef
+struct OpDev
+{
+    double* b;            // packed state             [Nstate]
+    double* x;            // residuals                [Nmeas]
+    double* Jv;           // CSR values               [Nnz]
+    // normal equations (solver_kernels.hpp); NULL until the solver is prepared
+    double* A;            // [Nc][Nc]
+    double* Bt;           // [NE][Nc]
+    double* D;            // [NEb][6][6]
+    double* g;            // [Nstate]   Jt x
+    double* scalars;      // [NSCALARS]
+    double* step_cauchy;  // [Nstate]
+    double* step_gn;      // [Nstate]
+};
+
+// Which operating point a kernel works on. The index is either known to the
+// host (sel == NULL: ops already points at the right one) or lives in device
+// memory (the dog-leg control block decides it on the device, so that a whole
+// solver step can be queued without the host knowing which of the two points
+// is current). skip, if given, points at a device flag that turns the kernel
+// into a no-op (solver finished / step aborted)
+struct OpRef
+{
+    const OpDev* ops;
+    const int*   sel;
+    const int*   skip;
+};
+__device__ __forceinline__ bool opref_skip(const OpRef& r) { return r.skip != NULL && *r.skip != 0; }
+__device__ __forceinline__ const OpDev& opref_get(const OpRef& r) { return r.ops[r.sel ? *r.sel : 0]; }
+
+// what one evaluation reads and writes
 struct EvalBuffers
 {
-    double*  b;      // packed state             [Nstate]
-    double*  joint;  // prologue scratch         [Nobs_board][JOINT_STRIDE]
-    double*  x;      // residuals                [Nmeas]
-    double*  Jv;     // CSR values               [Nnz]
+    OpRef    R;      // b in; x, Jv out
+    double*  joint;  // prologue scratch         [Nobs_board][JOINT_STRIDE] + unpacked intrinsics
     int32_t* Jp;     // CSR rowptr               [Nmeas+1]
     int32_t* Ji;     // CSR colidx               [Nnz]
     double*  gram;   // per-observation Gram     [Nobs_board][gram_stride(Ndist)]; NULL: don't form it
@@ -23,9 +54,12 @@ bool lens_supported(int lens_type);
 
 // x (and J values if with_jacobian) at B.b. ev_j0/ev_j1, if given, bracket the
 // board Jacobian kernel on the stream
+// parts: which of the evaluation's kernels to queue (the solver splits an
+// evaluation around the board kernel when that kernel is being timed)
+enum { EVAL_PART_PROLOGUE = 1, EVAL_PART_BOARD = 2, EVAL_PART_REST = 4, EVAL_PART_ALL = 7 };
 hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                            int lds_bytes, hipStream_t stream,
-                           hipEvent_t ev_j0, hipEvent_t ev_j1);
+                           hipEvent_t ev_j0, hipEvent_t ev_j1, int parts = EVAL_PART_ALL);
 
 // rowptr/colidx; iteration-invariant
 hipError_t launch_structure(const DeviceProblem& P, const EvalBuffers& B, hipStream_t stream);

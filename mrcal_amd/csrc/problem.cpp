@@ -57,13 +57,17 @@ mrcal_amd_problem::~mrcal_amd_problem()
     for(int i=0;i<2;i++)
     {
         hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv);
-        hipFree(op[i].N.A); hipFree(op[i].N.Bt); hipFree(op[i].N.D); hipFree(op[i].N.g); hipFree(op[i].N.scalars);
+        hipFree(op[i].A); hipFree(op[i].Bt); hipFree(op[i].D); hipFree(op[i].g); hipFree(op[i].scalars);
         hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
     }
+    hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.status);
-    hipFree(d_step); hipFree(d_counts);
-    if(h_scalars) hipHostFree(h_scalars);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Linv); hipFree(F.status);
+    hipFree(d_step); hipFree(d_counts); hipFree(d_ctl);
+    if(h_scalars)  hipHostFree(h_scalars);
+    if(h_ctl_ring) hipHostFree(h_ctl_ring);
+    for(hipEvent_t e : ctl_events) hipEventDestroy(e);
+    for(int i=0;i<3;i++) if(step_graph[i]) hipGraphExecDestroy(step_graph[i]);
     for(hipEvent_t e : ev_pool) hipEventDestroy(e);
     if(ev_j0)  hipEventDestroy(ev_j0);
     if(ev_j1)  hipEventDestroy(ev_j1);
@@ -86,13 +90,19 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->d_gram,   (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
     for(int i=0;i<2 && ok;i++)
     {
-        ok = ok && dev_alloc(&P->op[i].N.A,       (size_t)nd.Nc*nd.Nc);
-        ok = ok && dev_alloc(&P->op[i].N.Bt,      (size_t)nd.NE*nd.Nc);
-        ok = ok && dev_alloc(&P->op[i].N.D,       (size_t)nd.NEb*36);
-        ok = ok && dev_alloc(&P->op[i].N.g,       (size_t)nd.Nstate);
-        ok = ok && dev_alloc(&P->op[i].N.scalars, (size_t)NSCALARS);
+        ok = ok && dev_alloc(&P->op[i].A,       (size_t)nd.Nc*nd.Nc);
+        ok = ok && dev_alloc(&P->op[i].Bt,      (size_t)nd.NE*nd.Nc);
+        ok = ok && dev_alloc(&P->op[i].D,       (size_t)nd.NEb*36);
+        ok = ok && dev_alloc(&P->op[i].g,       (size_t)nd.Nstate);
+        ok = ok && dev_alloc(&P->op[i].scalars, (size_t)NSCALARS);
         ok = ok && dev_alloc(&P->op[i].step_cauchy, (size_t)nd.Nstate);
         ok = ok && dev_alloc(&P->op[i].step_gn,     (size_t)nd.Nstate);
+    }
+    ok = ok && dev_alloc(&P->F.Linv, (size_t)((nd.Nc + 15)/16)*256);
+    {
+        char* ctl = NULL;
+        ok = ok && dev_alloc(&ctl, solver_ctl_bytes());
+        P->d_ctl = (SolverCtl*)ctl;
     }
     ok = ok && dev_alloc(&P->F.Wt, (size_t)nd.NE*nd.Nc);
     ok = ok && dev_alloc(&P->F.LD, (size_t)nd.NEb*36);
@@ -113,6 +123,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         HIP_TRY(hipMemset(P->op[i].step_cauchy, 0, (size_t)nd.Nstate*sizeof(double)), return false);
     }
     HIP_TRY(hipHostMalloc((void**)&P->h_scalars, 64*sizeof(double)), return false);
+    if(!problem_sync_ops(P)) return false;
 
     // assembly work lists. Observations of one frame are contiguous; the
     // observations of one (intrinsics,extrinsics) pair are gathered in chunks
@@ -160,26 +171,42 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     return true;
 }
 
-bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal)
+bool problem_sync_ops(mrcal_amd_problem* P)
+{
+    if(P->d_ops == NULL && !dev_alloc(&P->d_ops, 2)) return false;
+    OpDev h[2] = { P->op[0], P->op[1] };
+    HIP_TRY(hipMemcpy(P->d_ops, h, sizeof(h), hipMemcpyHostToDevice), return false);
+    return true;
+}
+
+bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobian, bool with_normal, int parts)
 {
     if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
-    const EvalBuffers B = P->eval_buffers(i, with_normal);
-    hipEvent_t e0 = with_jacobian ? P->ev_j0 : NULL, e1 = with_jacobian ? P->ev_j1 : NULL;
-    if(with_jacobian && P->ev_pool_enabled && P->ev_pool_used + 2 <= (int)P->ev_pool.size())
+    const EvalBuffers B = P->eval_buffers(R, with_normal);
+    hipEvent_t e0 = NULL, e1 = NULL;
+    if(with_jacobian && (parts & EVAL_PART_BOARD) && !P->capturing)
     {
-        e0 = P->ev_pool[P->ev_pool_used++];
-        e1 = P->ev_pool[P->ev_pool_used++];
+        e0 = P->ev_j0; e1 = P->ev_j1;
+        if(P->ev_pool_enabled && P->ev_pool_used + 2 <= (int)P->ev_pool.size())
+        {
+            e0 = P->ev_pool[P->ev_pool_used++];
+            e1 = P->ev_pool[P->ev_pool_used++];
+        }
     }
-    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream, e0, e1),
+    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream, e0, e1, parts),
             return false);
-    P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0;
-    if(with_normal)
-    {
-        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, P->op[i].N, P->stream), return false);
-        P->op[i].have_normal = true;
-    }
-    P->op[i].cauchy_valid = P->op[i].gn_valid = false;
+    if(parts & EVAL_PART_BOARD)
+        P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0 && e0 != NULL;
+    if(with_normal && (parts & EVAL_PART_REST))
+        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, P->stream), return false);
+    return true;
+}
+
+bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal)
+{
+    if(!problem_evaluate_ref(P, P->opref(i), with_jacobian, with_normal, EVAL_PART_ALL)) return false;
     P->stats.Nevaluations++;
+    if(with_normal) P->op[i].have_normal = true;
     return true;
 }
 
@@ -402,6 +429,7 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     ok = ok && dev_alloc (&P->d_Jp,     (size_t)L.Nmeas+1);
     ok = ok && dev_alloc (&P->d_Ji,     (size_t)innz);
     if(!ok) { delete P; return NULL; }
+    if(!problem_sync_ops(P)) { delete P; return NULL; }
 
     {
         NormalDims& nd = P->nd;

@@ -9,19 +9,12 @@
 
 // One operating point of the dog-leg iteration: the state, the cost function
 // there (x, J) and its normal equations. The solver flips between two of these
-// (libdogleg's beforeStep / afterStep)
-struct mrcal_amd_oppoint
+// (libdogleg's beforeStep / afterStep). Host copy of the device pointers; the
+// device has the same in mrcal_amd_problem::d_ops
+struct mrcal_amd_oppoint : public mrcal_amd::OpDev
 {
-    double* b  = NULL;          // packed state [Nstate]
-    double* x  = NULL;          // residuals    [Nmeas]
-    double* Jv = NULL;          // CSR values   [Nnz]
-    mrcal_amd::NormalBuffers N = {};
-    double* step_cauchy = NULL; // [Nstate]
-    double* step_gn     = NULL; // [Nstate]
-
-    // host mirrors
-    double norm2_x = 0, cauchy_lensq = 0, gn_lensq = 0;
-    bool   have_normal = false, cauchy_valid = false, gn_valid = false, did_step_to_edge = false;
+    mrcal_amd_oppoint() { memset(static_cast<mrcal_amd::OpDev*>(this), 0, sizeof(mrcal_amd::OpDev)); }
+    bool have_normal = false;
 };
 
 struct mrcal_amd_solver_stats
@@ -47,6 +40,7 @@ struct mrcal_amd_problem
     hipStream_t stream = NULL;
     hipEvent_t  ev_j0  = NULL, ev_j1 = NULL;
     bool        have_jacobian_timing = false;
+    bool        capturing = false;      // a hipGraph capture is in progress on the stream
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region
     std::vector<hipEvent_t> ev_pool;
     int         ev_pool_used = 0;
@@ -70,6 +64,7 @@ struct mrcal_amd_problem
     int32_t* d_Ji    = NULL;
 
     mrcal_amd_oppoint op[2];
+    mrcal_amd::OpDev* d_ops = NULL;      // device copy of op[0..1]
     int icur = 0;                        // which operating point the accessors/evaluate() address
 
     // solver
@@ -79,15 +74,30 @@ struct mrcal_amd_problem
     double*                    d_step   = NULL;   // [Nstate]
     int*                       d_counts = NULL;   // [4]
     double*                    h_scalars = NULL;  // pinned [64]
+    // device-side dog-leg control (solver_kernels.hpp): the block, and a ring
+    // of pinned host copies the host polls without stalling the queue
+    mrcal_amd::SolverCtl*      d_ctl = NULL;
+    mrcal_amd::SolverCtl*      h_ctl_ring = NULL;
+    std::vector<hipEvent_t>    ctl_events;
+    bool                       ctl_initialized = false;
+    // one trial step captured as a graph: whole [0], or split around the board
+    // kernel ([1] before, [2] after) when that kernel is being timed with events
+    hipGraphExec_t             step_graph[3] = {NULL, NULL, NULL};
     mrcal_amd_solver_stats     stats;
 
-    mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const
+    // op i, resolved by the host
+    mrcal_amd::OpRef opref(int i) const
+    {
+        mrcal_amd::OpRef R = { d_ops + i, NULL, NULL };
+        return R;
+    }
+    mrcal_amd::EvalBuffers eval_buffers(const mrcal_amd::OpRef& R, bool with_gram) const
     {
         mrcal_amd::EvalBuffers B;
-        B.b = op[i].b; B.joint = d_joint; B.x = op[i].x; B.Jv = op[i].Jv;
-        B.Jp = d_Jp; B.Ji = d_Ji; B.gram = with_gram ? d_gram : NULL;
+        B.R = R; B.joint = d_joint; B.Jp = d_Jp; B.Ji = d_Ji; B.gram = with_gram ? d_gram : NULL;
         return B;
     }
+    mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const { return eval_buffers(opref(i), with_gram); }
 
     mrcal_amd_problem() { memset(&D, 0, sizeof(D)); memset(&L, 0, sizeof(L)); memset(&nd, 0, sizeof(nd)); }
     ~mrcal_amd_problem();
@@ -98,4 +108,9 @@ namespace mrcal_amd {
 bool problem_prepare_solver(mrcal_amd_problem* P);
 // x, J (and the normal equations if with_normal) at op[i].b
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal);
+// the same, with the operating point possibly resolved on the device
+bool problem_evaluate_ref(mrcal_amd_problem* P, const mrcal_amd::OpRef& R, bool with_jacobian, bool with_normal,
+                          int parts = mrcal_amd::EVAL_PART_ALL);
+// uploads op[0..1] to d_ops
+bool problem_sync_ops(mrcal_amd_problem* P);
 }

@@ -17,6 +17,8 @@
 #include <math.h>
 #include <string.h>
 #include <chrono>
+#include <vector>
+#include <stdlib.h>
 #include "host_state.hpp"
 #include "problem_object.hpp"
 #include "../../include/mrcal_amd.h"
@@ -57,50 +59,223 @@ bool read_scalars(mrcal_amd_problem* P, const double* dev, int n, double* out)
     return true;
 }
 
-// x, J, N = JtJ blocks, g = Jt x, |x|^2, |g|^2, g^T N g at op[i].b
-bool evaluate_operating_point(mrcal_amd_problem* P, int i)
+enum { CTL_RING = 8 };
+
+bool ctl_prepare(mrcal_amd_problem* P)
 {
-    mrcal_amd_oppoint& op = P->op[i];
-    if(!problem_evaluate_op(P, i, true, true)) return false;
-    double* sc = op.N.scalars;
-    HIP_TRY(launch_dot(P->nd.Nstate, op.N.g, op.N.g, &sc[SC_NORM2_G], P->stream), return false);
-    HIP_TRY(launch_quadform(P->nd, op.N, op.N.g, &sc[SC_GNG], P->stream), return false);
-    double s[3];
-    if(!read_scalars(P, sc, 3, s)) return false;
-    op.norm2_x = s[SC_NORM2_X];
-    // Cauchy step: -(|g|^2 / |J g|^2) g
-    const double norm2_g = s[SC_NORM2_G], gNg = s[SC_GNG];
-    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
-    op.cauchy_lensq = k*k*norm2_g;
-    HIP_TRY(launch_axpby(P->nd.Nstate, k, op.N.g, 0.0, NULL, op.step_cauchy, P->stream), return false);
-    op.cauchy_valid = true;
-    op.gn_valid     = false;
-    op.did_step_to_edge = false;
+    if(P->h_ctl_ring != NULL) return true;
+    HIP_TRY(hipHostMalloc((void**)&P->h_ctl_ring, CTL_RING*sizeof(SolverCtl)), return false);
+    for(int i=0;i<CTL_RING;i++)
+    {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming), return false);
+        P->ctl_events.push_back(e);
+    }
     return true;
 }
 
-// Gauss-Newton step of op[i], adding lambda I until the factorization succeeds
+// (re)starts the device-side dog-leg at the point op[P->icur]
+bool ctl_reset(mrcal_amd_problem* P, const DoglegParameters& prm, bool check_termination)
+{
+    if(!ctl_prepare(P)) return false;
+    std::vector<char> buf(solver_ctl_bytes(), 0);
+    SolverCtl& c = *(SolverCtl*)buf.data();
+    c.trustregion_decrease_factor    = prm.trustregion_decrease_factor;
+    c.trustregion_decrease_threshold = prm.trustregion_decrease_threshold;
+    c.trustregion_increase_factor    = prm.trustregion_increase_factor;
+    c.trustregion_increase_threshold = prm.trustregion_increase_threshold;
+    c.update_threshold               = prm.update_threshold;
+    c.trustregion_threshold          = prm.trustregion_threshold;
+    c.max_iterations                 = prm.max_iterations;
+    c.check_termination              = check_termination ? 1 : 0;
+    c.trustregion                    = prm.trustregion0;
+    c.lambda                         = P->stats.lambda;
+    c.ib = P->icur; c.ia = 1 - P->icur;
+    HIP_TRY(hipMemcpyAsync(P->d_ctl, buf.data(), buf.size(), hipMemcpyHostToDevice, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);   // buf goes out of scope
+    P->ctl_initialized = true;
+    return true;
+}
+
+// x, J, the normal equations, g, |x|^2 and the Cauchy step at the starting point
+bool enqueue_initial_point(mrcal_amd_problem* P)
+{
+    const OpRef R = { P->d_ops, &P->d_ctl->ib, NULL };
+    if(!problem_evaluate_ref(P, R, true, true)) return false;
+    HIP_TRY(launch_finish_point(P->nd, P->d_ops, P->d_ctl, true, P->stream), return false);
+    return true;
+}
+
+// One trial step of the dog-leg, entirely queued: every decision is taken on
+// the device (solver_kernels.hip, "dog-leg control"). segment: 0 = all of it;
+// 1 = up to the board kernel, 2 = the board kernel alone, 3 = after it
+bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
+{
+    SolverCtl* ctl = P->d_ctl;
+    const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval(ctl) };
+    if(segment == 0 || segment == 1)
+    {
+        HIP_TRY(launch_step_begin(P->d_ops, ctl, P->F.status, P->stream), return false);
+        {
+            // the Gauss-Newton step from the current point, if this trial needs it
+            const OpRef R = { P->d_ops, &ctl->ib, solver_ctl_skip_factor(ctl) };
+            HIP_TRY(launch_factor_local(P->nd, P->br, R, P->F, 0.0, ctl, true, P->stream), return false);
+            HIP_TRY(launch_solve_backsub(P->nd, P->br, R, P->F, NULL, false, P->stream), return false);
+        }
+        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream), return false);
+        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE)) return false;
+    }
+    if(segment == 0 || segment == 2)
+        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_BOARD)) return false;
+    if(segment == 0 || segment == 3)
+    {
+        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_REST)) return false;
+        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, false, P->stream), return false);
+        HIP_TRY(launch_step_accept(P->d_ops, ctl, P->stream), return false);
+    }
+    return true;
+}
+
+bool capture_segment(mrcal_amd_problem* P, int segment, hipGraphExec_t* exec)
+{
+    hipGraph_t graph = NULL;
+    HIP_TRY(hipStreamBeginCapture(P->stream, hipStreamCaptureModeThreadLocal), return false);
+    P->capturing = true;
+    const bool ok = enqueue_trial_step(P, segment);
+    P->capturing = false;
+    hipError_t e = hipStreamEndCapture(P->stream, &graph);
+    if(!ok || e != hipSuccess || graph == NULL)
+    {
+        if(graph) hipGraphDestroy(graph);
+        set_error("could not capture the solver step into a HIP graph: %s", hipGetErrorString(e));
+        return false;
+    }
+    HIP_TRY(hipGraphInstantiate(exec, graph, NULL, NULL, 0), { hipGraphDestroy(graph); return false; });
+    hipGraphDestroy(graph);
+    return true;
+}
+
+// Queues one trial step: as ONE captured graph normally; when the board kernel
+// is being timed with per-launch events, as graph | event | kernel | event |
+// graph. Graphs are captured on first use (MRCAL_AMD_NO_GRAPH=1: eager launches)
+bool queue_trial_step(mrcal_amd_problem* P)
+{
+    static const bool use_graph = (getenv("MRCAL_AMD_NO_GRAPH") == NULL);
+    if(!use_graph) return enqueue_trial_step(P, 0);
+    if(!P->ev_pool_enabled)
+    {
+        if(P->step_graph[0] == NULL && !capture_segment(P, 0, &P->step_graph[0])) return false;
+        HIP_TRY(hipGraphLaunch(P->step_graph[0], P->stream), return false);
+        return true;
+    }
+    if(P->step_graph[1] == NULL && !capture_segment(P, 1, &P->step_graph[1])) return false;
+    if(P->step_graph[2] == NULL && !capture_segment(P, 3, &P->step_graph[2])) return false;
+    HIP_TRY(hipGraphLaunch(P->step_graph[1], P->stream), return false);
+    if(!enqueue_trial_step(P, 2)) return false;
+    HIP_TRY(hipGraphLaunch(P->step_graph[2], P->stream), return false);
+    return true;
+}
+
+bool read_ctl(mrcal_amd_problem* P, SolverCtl* c)
+{
+    HIP_TRY(hipMemcpyAsync(&P->h_ctl_ring[0], P->d_ctl, sizeof(SolverCtl), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    *c = P->h_ctl_ring[0];
+    return true;
+}
+
+void absorb_ctl(mrcal_amd_problem* P, const SolverCtl& c)
+{
+    P->icur = c.ib;
+    P->stats.lambda  = c.lambda;
+    P->stats.norm2_x = c.norm2_x[c.ib];
+    P->op[0].have_normal = P->op[1].have_normal = true;
+}
+
+// libdogleg's main loop. The host only keeps the queue fed and looks, a few
+// steps behind, at whether the device has declared the solve finished. On
+// return op[P->icur] is the final operating point
+bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
+{
+    if(!ctl_reset(P, prm, true)) return false;
+    if(!enqueue_initial_point(P)) return false;
+
+    const int LAG = 3;      // how many steps the host may run ahead of what it has seen
+    static const bool debug = (getenv("MRCAL_AMD_DEBUG_SOLVER") != NULL);
+    int  nqueued = 0;
+    bool done = false;
+    const int max_trials = 100*prm.max_iterations + 1000;   // runaway guard
+    while(!done && nqueued < max_trials)
+    {
+        if(!queue_trial_step(P)) return false;
+        const int slot = nqueued % CTL_RING;
+        HIP_TRY(hipMemcpyAsync(&P->h_ctl_ring[slot], P->d_ctl, sizeof(SolverCtl), hipMemcpyDeviceToHost, P->stream), return false);
+        HIP_TRY(hipEventRecord(P->ctl_events[slot], P->stream), return false);
+        nqueued++;
+        if(debug)
+        {
+            HIP_TRY(hipStreamSynchronize(P->stream), return false);
+            const SolverCtl& s = P->h_ctl_ring[slot];
+            int st = 0;
+            hipMemcpy(&st, P->F.status, sizeof(int), hipMemcpyDeviceToHost);
+            fprintf(stderr, "trial %3d: accepted %3d tr %-10.4g |x|^2 %.10g lambda %-8.3g need_gn %d abort %d chol_status %d step_len %.3g expected %.6g kc %.3g kg %.3g done %d\n",
+                    nqueued, s.Nsteps_accepted, s.trustregion, s.norm2_x[s.ib], s.lambda, s.need_gn, s.abort_step, st,
+                    sqrt(s.step_len_sq), s.expected_improvement, s.k_cauchy, s.k_gn, s.done);
+        }
+        // look at the newest snapshot that is at least LAG steps old, or any
+        // newer one that happens to be complete
+        for(int back = 1; back <= CTL_RING-1 && back <= nqueued; back++)
+        {
+            const int j = nqueued - back, sj = j % CTL_RING;
+            hipError_t q = hipEventQuery(P->ctl_events[sj]);
+            if(q == hipErrorNotReady)
+            {
+                if(back < LAG) continue;
+                HIP_TRY(hipEventSynchronize(P->ctl_events[sj]), return false);
+            }
+            else if(q != hipSuccess)
+            {
+                set_error("hipEventQuery: %s", hipGetErrorString(q));
+                return false;
+            }
+            if(P->h_ctl_ring[sj].done) done = true;
+            break;
+        }
+    }
+    SolverCtl c;
+    if(!read_ctl(P, &c)) return false;
+    if(c.error)
+    {
+        set_error("could not make JtJ positive definite");
+        return false;
+    }
+    absorb_ctl(P, c);
+    P->stats.Niterations     += c.Nsteps_accepted;
+    P->stats.Nevaluations    += c.Nevaluations;
+    P->stats.Nfactorizations += c.Nfactorizations;
+    return true;
+}
+
+// Host-driven Gauss-Newton step of op[i] (tests, and the reference for the
+// device-controlled path): (JtJ + lambda I) d = -Jt x, adding lambda until the
+// factorization succeeds. The normal equations of op[i] must be current
 bool compute_gauss_newton(mrcal_amd_problem* P, int i)
 {
-    mrcal_amd_oppoint& op = P->op[i];
-    if(op.gn_valid) return true;
     for(;;)
     {
         P->stats.Nfactorizations++;
-        HIP_TRY(launch_factor_and_solve(P->nd, P->br, op.N, P->F, P->stats.lambda, op.step_gn, P->stream), return false);
-        HIP_TRY(hipMemsetAsync(&op.N.scalars[SC_TMP0], 0, sizeof(double), P->stream), return false);
-        HIP_TRY(launch_dot(P->nd.Nstate, op.step_gn, op.step_gn, &op.N.scalars[SC_TMP0], P->stream), return false);
+        HIP_TRY(hipMemsetAsync(P->F.status, 0, sizeof(int), P->stream), return false);
+        HIP_TRY(launch_factor_local(P->nd, P->br, P->opref(i), P->F, P->stats.lambda, NULL, true, P->stream), return false);
+        HIP_TRY(launch_solve_backsub(P->nd, P->br, P->opref(i), P->F, NULL, true, P->stream), return false);
+        double* sc = P->op[i].scalars;
+        HIP_TRY(hipMemsetAsync(&sc[SC_TMP0], 0, sizeof(double), P->stream), return false);
+        HIP_TRY(launch_dot(P->nd.Nstate, P->op[i].step_gn, P->op[i].step_gn, &sc[SC_TMP0], P->stream), return false);
         int status = 0;
         HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->F.status, sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
         double lensq;
-        if(!read_scalars(P, &op.N.scalars[SC_TMP0], 1, &lensq)) return false;
+        if(!read_scalars(P, &sc[SC_TMP0], 1, &lensq)) return false;
         memcpy(&status, P->h_scalars + 32, sizeof(int));
-        if(status == 0 && lensq == lensq)
-        {
-            op.gn_lensq = lensq;
-            op.gn_valid = true;
-            return true;
-        }
+        if(status == 0 && lensq == lensq) return true;
         // singular JtJ: regularize, like libdogleg does
         P->stats.lambda = (P->stats.lambda == 0.0) ? 1e-10 : P->stats.lambda*10.0;
         if(!(P->stats.lambda < 1e30))
@@ -109,109 +284,6 @@ bool compute_gauss_newton(mrcal_amd_problem* P, int i)
             return false;
         }
     }
-}
-
-// the dog-leg step from op[ib] with the given trust region. The new state goes
-// to op[ia].b. Returns the squared step length, <0 on error
-double take_step(mrcal_amd_problem* P, int ib, int ia, double trustregion, double* expected_improvement)
-{
-    mrcal_amd_oppoint& from = P->op[ib];
-    const int n = P->nd.Nstate;
-    double step_len_sq;
-
-    if(from.cauchy_lensq >= trustregion*trustregion)
-    {
-        const double k = trustregion/sqrt(from.cauchy_lensq);
-        HIP_TRY(launch_axpby(n, k, from.step_cauchy, 0.0, NULL, P->d_step, P->stream), return -1.0);
-        step_len_sq = trustregion*trustregion;
-        from.did_step_to_edge = true;
-    }
-    else
-    {
-        if(!compute_gauss_newton(P, ib)) return -1.0;
-        if(from.gn_lensq <= trustregion*trustregion)
-        {
-            HIP_TRY(launch_axpby(n, 1.0, from.step_gn, 0.0, NULL, P->d_step, P->stream), return -1.0);
-            step_len_sq = from.gn_lensq;
-            from.did_step_to_edge = false;
-        }
-        else
-        {
-            // point on the Cauchy->GN segment at the trust-region edge:
-            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
-            double* sc = from.N.scalars;
-            HIP_TRY(hipMemsetAsync(&sc[SC_TMP0], 0, 2*sizeof(double), P->stream), return -1.0);
-            HIP_TRY(launch_dot(n, from.step_cauchy, from.step_gn, &sc[SC_TMP0], P->stream), return -1.0);
-            double ab;
-            if(!read_scalars(P, &sc[SC_TMP0], 1, &ab)) return -1.0;
-            const double dsq    = trustregion*trustregion;
-            const double norm2a = from.cauchy_lensq, norm2b = from.gn_lensq;
-            const double l2     = norm2a - 2.0*ab + norm2b;   // |a-b|^2
-            const double neg_c  = norm2a - ab;                // a.(a-b)
-            double disc = neg_c*neg_c - l2*(norm2a - dsq);
-            if(disc < 0.0) disc = 0.0;
-            const double k = (neg_c + sqrt(disc))/l2;
-            HIP_TRY(launch_axpby(n, 1.0-k, from.step_cauchy, k, from.step_gn, P->d_step, P->stream), return -1.0);
-            step_len_sq = (1.0-k)*(1.0-k)*norm2a + 2.0*k*(1.0-k)*ab + k*k*norm2b;
-            from.did_step_to_edge = true;
-        }
-    }
-
-    HIP_TRY(launch_axpby(n, 1.0, from.b, 1.0, P->d_step, P->op[ia].b, P->stream), return -1.0);
-
-    // expected improvement: |x|^2 - |x + J s|^2 = -2 g.s - s^T N s
-    double* sc = from.N.scalars;
-    HIP_TRY(hipMemsetAsync(&sc[SC_TMP1], 0, 2*sizeof(double), P->stream), return -1.0);
-    HIP_TRY(launch_dot(n, from.N.g, P->d_step, &sc[SC_TMP1], P->stream), return -1.0);
-    HIP_TRY(launch_quadform(P->nd, from.N, P->d_step, &sc[SC_TMP2], P->stream), return -1.0);
-    double s[2];
-    if(!read_scalars(P, &sc[SC_TMP1], 2, s)) return -1.0;
-    *expected_improvement = -2.0*s[0] - s[1];
-    return step_len_sq;
-}
-
-// libdogleg's main loop. On return op[P->icur] is the final operating point
-bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
-{
-    int ib = P->icur, ia = 1 - ib;
-    double trustregion = prm.trustregion0;
-    if(!evaluate_operating_point(P, ib)) return false;
-
-    int stepCount = 0;
-    while(stepCount < prm.max_iterations)
-    {
-        bool done = false;
-        for(;;)
-        {
-            double expected;
-            const double step_len_sq = take_step(P, ib, ia, trustregion, &expected);
-            if(step_len_sq < 0.0) return false;
-            if(step_len_sq < prm.update_threshold*prm.update_threshold) { done = true; break; }
-
-            if(!evaluate_operating_point(P, ia)) return false;
-            const double observed = P->op[ib].norm2_x - P->op[ia].norm2_x;
-            const double rho      = observed/expected;
-
-            if(rho < prm.trustregion_decrease_threshold)
-                trustregion *= prm.trustregion_decrease_factor;
-            else if(rho > prm.trustregion_increase_threshold && P->op[ib].did_step_to_edge)
-                trustregion *= prm.trustregion_increase_factor;
-
-            if(rho > 0.0)
-            {
-                const int t = ib; ib = ia; ia = t;
-                break;
-            }
-            if(trustregion < prm.trustregion_threshold || trustregion == 0.0 || !(trustregion == trustregion))
-            { done = true; break; }
-        }
-        if(done) break;
-        stepCount++;
-    }
-    P->icur = ib;
-    P->stats.Niterations += stepCount;
-    P->stats.norm2_x = P->op[ib].norm2_x;
-    return true;
 }
 
 // mrcal.c:3978-4402 markOutliers(), boards only. Returns true if new outliers
@@ -223,7 +295,7 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, bool* found)
     if(Npts <= 0) { *Noutliers_board = 0; return true; }
     const double k0 = 4.0, k1 = 5.0;
     const double* x = P->op[P->icur].x;
-    double* sums = P->op[P->icur].N.scalars + SC_TMP0;
+    double* sums = P->op[P->icur].scalars + SC_TMP0;
 
     auto stats = [&](double thresh_sq, int* counts, double* sum) -> bool
     {
@@ -260,7 +332,7 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, bool* found)
 extern "C" {
 
 // Resident tier: the full solve on a resident problem. Returns rms error, <0
-// on failure. do_outlier_rejection<0: use the problem's own selection
+// on failure
 double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
                                int* Noutliers_board_out)
 {
@@ -293,34 +365,29 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
 // operating point, no termination tests, no outlier rejection: the unit the
 // benchmark times. Each step = 1 evaluation of x,J + the normal equations + a
 // factorization (when the trust region asks for the Gauss-Newton step).
-// Returns the number of evaluations done, <0 on error
+// Returns the number of steps queued, <0 on error. Returns when they are done
 int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trustregion_inout)
 {
     last_error_string().clear();
     if(!problem_prepare_solver(P)) return -1;
     DoglegParameters prm;
-    int ib = P->icur, ia = 1 - ib;
-    double trustregion = (trustregion_inout && *trustregion_inout > 0.0) ? *trustregion_inout : prm.trustregion0;
-    if(!P->op[ib].have_normal || !P->op[ib].cauchy_valid)
-        if(!evaluate_operating_point(P, ib)) return -1;
-    int n = 0;
-    for(; n < Nsteps; n++)
+    if(trustregion_inout && *trustregion_inout > 0.0) prm.trustregion0 = *trustregion_inout;
+    if(!P->ctl_initialized || !(trustregion_inout && *trustregion_inout > 0.0))
     {
-        double expected;
-        const double step_len_sq = take_step(P, ib, ia, trustregion, &expected);
-        if(step_len_sq < 0.0) return -1;
-        if(!evaluate_operating_point(P, ia)) return -1;
-        const double rho = (P->op[ib].norm2_x - P->op[ia].norm2_x)/expected;
-        if(rho < prm.trustregion_decrease_threshold)
-            trustregion *= prm.trustregion_decrease_factor;
-        else if(rho > prm.trustregion_increase_threshold && P->op[ib].did_step_to_edge)
-            trustregion *= prm.trustregion_increase_factor;
-        if(rho > 0.0) { const int t = ib; ib = ia; ia = t; }
+        if(!ctl_reset(P, prm, false)) return -1;
+        if(!enqueue_initial_point(P)) return -1;
     }
-    P->icur = ib;
-    P->stats.norm2_x = P->op[ib].norm2_x;
-    if(trustregion_inout) *trustregion_inout = trustregion;
-    return n;
+    for(int n = 0; n < Nsteps; n++)
+        if(!queue_trial_step(P)) return -1;
+    SolverCtl c;
+    if(!read_ctl(P, &c)) return -1;
+    if(c.error) { set_error("could not make JtJ positive definite"); return -1; }
+    absorb_ctl(P, c);
+    P->stats.Nevaluations    = c.Nevaluations;
+    P->stats.Nfactorizations = c.Nfactorizations;
+    P->stats.Niterations     = c.Nsteps_accepted;
+    if(trustregion_inout) *trustregion_inout = c.trustregion;
+    return Nsteps;
 }
 
 void mrcal_amd_problem_solver_stats(mrcal_amd_problem_t* P,
@@ -348,7 +415,7 @@ bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* P,
     if(!problem_prepare_solver(P)) return false;
     if(!problem_evaluate_op(P, P->icur, true, true)) return false;
     const NormalDims& nd = P->nd;
-    const NormalBuffers& N = P->op[P->icur].N;
+    const mrcal_amd_oppoint& N = P->op[P->icur];
     if(A)  HIP_TRY(hipMemcpyAsync(A,  N.A,  (size_t)nd.Nc*nd.Nc*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
     if(Bt) HIP_TRY(hipMemcpyAsync(Bt, N.Bt, (size_t)nd.NE*nd.Nc*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
     if(D)  HIP_TRY(hipMemcpyAsync(D,  N.D,  (size_t)nd.NEb*36*sizeof(double),   hipMemcpyDeviceToHost, P->stream), return false);
@@ -365,7 +432,7 @@ bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* P, double* step)
 {
     last_error_string().clear();
     if(!problem_prepare_solver(P)) return false;
-    if(!evaluate_operating_point(P, P->icur)) return false;
+    if(!problem_evaluate_op(P, P->icur, true, true)) return false;
     if(!compute_gauss_newton(P, P->icur)) return false;
     HIP_TRY(hipMemcpyAsync(step, P->op[P->icur].step_gn, (size_t)P->nd.Nstate*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
     HIP_TRY(hipStreamSynchronize(P->stream), return false);
@@ -388,10 +455,10 @@ void* mrcal_amd_problem_buffer(mrcal_amd_problem_t* P, int which, int iop, int64
     {
     case MRCAL_AMD_BUF_B:           p = op.b;           n = nd.Nstate; break;
     case MRCAL_AMD_BUF_X:           p = op.x;           n = P->L.Nmeas; break;
-    case MRCAL_AMD_BUF_G:           p = op.N.g;         n = nd.Nstate; break;
+    case MRCAL_AMD_BUF_G:           p = op.g;           n = nd.Nstate; break;
     case MRCAL_AMD_BUF_STEP_CAUCHY: p = op.step_cauchy; n = nd.Nstate; break;
     case MRCAL_AMD_BUF_STEP_GN:     p = op.step_gn;     n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_SCALARS:     p = op.N.scalars;   n = NSCALARS;  break;
+    case MRCAL_AMD_BUF_SCALARS:     p = op.scalars;     n = NSCALARS;  break;
     case MRCAL_AMD_BUF_STEP:        p = P->d_step;      n = nd.Nstate; break;
     case MRCAL_AMD_BUF_SCHUR:       p = P->F.S;         n = (int64_t)nd.Nc*nd.Nc + nd.Nc; break;
     case MRCAL_AMD_BUF_STATUS:      p = P->F.status;    n = 1; break;
@@ -413,18 +480,23 @@ bool mrcal_amd_problem_phase_evaluate(mrcal_amd_problem_t* P, int iop)
 }
 bool mrcal_amd_problem_phase_quadform(mrcal_amd_problem_t* P, int iop, const double* v_dev, double* out_dev)
 {
-    HIP_TRY(launch_quadform(P->nd, P->op[iop & 1].N, v_dev, out_dev, P->stream), return false);
+    HIP_TRY(launch_quadform(P->nd, P->opref(iop & 1), v_dev, out_dev, P->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_phase_factor_local(mrcal_amd_problem_t* P, int iop, double lambda)
 {
     P->stats.Nfactorizations++;
-    HIP_TRY(launch_factor_local(P->nd, P->br, P->op[iop & 1].N, P->F, lambda, P->is_leader, P->stream), return false);
+    HIP_TRY(hipMemsetAsync(P->F.status, 0, sizeof(int), P->stream), return false);
+    HIP_TRY(launch_factor_local(P->nd, P->br, P->opref(iop & 1), P->F, lambda, NULL, P->is_leader, P->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_phase_solve_backsub(mrcal_amd_problem_t* P, int iop)
 {
-    HIP_TRY(launch_solve_backsub(P->nd, P->br, P->F, P->op[iop & 1].step_gn, P->stream), return false);
+    if(P->br.count() < P->nd.NEb && P->nd.NE > 0)
+        // a shard writes only its own blocks; the others' entries must be 0 for
+        // the all-reduce that follows (they may hold the previous sum)
+        HIP_TRY(hipMemsetAsync(P->op[iop & 1].step_gn + P->nd.Nie, 0, (size_t)P->nd.NE*sizeof(double), P->stream), return false);
+    HIP_TRY(launch_solve_backsub(P->nd, P->br, P->opref(iop & 1), P->F, NULL, true, P->stream), return false);
     return true;
 }
 // outlier statistics / marking on the local board observations

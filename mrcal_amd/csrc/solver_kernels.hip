@@ -124,11 +124,14 @@ __device__ __forceinline__ double board_gram(const DeviceProblem& P, const Board
 // observation order and without atomics:
 //   D_f  += G[frame,frame]      g_f += G[frame,x]     Bt[frame rows][S cols] += G[S,frame]
 __global__ __launch_bounds__(256)
-void assemble_frames_kernel(DeviceProblem P, NormalDims nd,
+void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
                             const int* __restrict__ frame_obs_begin, // [Nframes+1], local obs indices
-                            const double* __restrict__ gram,
-                            double* __restrict__ Bt, double* __restrict__ D, double* __restrict__ g)
+                            const double* __restrict__ gram)
 {
+    if(opref_skip(R)) return;
+    double* __restrict__ Bt = opref_get(R).Bt;
+    double* __restrict__ D  = opref_get(R).D;
+    double* __restrict__ g  = opref_get(R).g;
     const int f = blockIdx.x;
     const int t = threadIdx.x;
     const int o0 = frame_obs_begin[f], o1 = frame_obs_begin[f+1];
@@ -170,12 +173,15 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd,
 // scatter to the same entries of A, so they are summed per pair first. One
 // workgroup per chunk of one pair's observation list
 __global__ __launch_bounds__(256)
-void reduce_pairs_kernel(DeviceProblem P, NormalDims nd,
+void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R,
                          const int* __restrict__ chunk_begin,  // [Nchunks+1] into pair_obs
                          const int* __restrict__ pair_obs,     // observation indices grouped by pair
-                         const double* __restrict__ gram,
-                         double* __restrict__ A, double* __restrict__ g, double* __restrict__ norm2_x)
+                         const double* __restrict__ gram)
 {
+    if(opref_skip(R)) return;
+    double* __restrict__ A = opref_get(R).A;
+    double* __restrict__ g = opref_get(R).g;
+    double* __restrict__ norm2_x = &opref_get(R).scalars[SC_NORM2_X];
     const int c0 = chunk_begin[blockIdx.x], c1 = chunk_begin[blockIdx.x+1];
     if(c0 >= c1) return;
     const BoardObsMeta m0 = P.board_meta[pair_obs[c0]];
@@ -216,12 +222,18 @@ void reduce_pairs_kernel(DeviceProblem P, NormalDims nd,
 // Rows that do not come from board observations (discrete points,
 // regularization): one lane per CSR row, scattered with atomics. These are few
 __global__ __launch_bounds__(64)
-void rows_generic_kernel(NormalDims nd, int row0, int row1,
-                         const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
-                         const double* __restrict__ Jv, const double* __restrict__ x,
-                         double* __restrict__ A, double* __restrict__ Bt, double* __restrict__ D,
-                         double* __restrict__ g, double* __restrict__ norm2_x)
+void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
+                         const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Jv = O.Jv;
+    const double* __restrict__ x  = O.x;
+    double* __restrict__ A  = O.A;
+    double* __restrict__ Bt = O.Bt;
+    double* __restrict__ D  = O.D;
+    double* __restrict__ g  = O.g;
+    double* __restrict__ norm2_x = &O.scalars[SC_NORM2_X];
     const int r = row0 + blockIdx.x*blockDim.x + threadIdx.x;
     if(r >= row1) return;
     const int p0 = Jp[r], p1 = Jp[r+1];
@@ -254,6 +266,25 @@ void rows_generic_kernel(NormalDims nd, int row0, int row1,
     }
 }
 
+// A, Bt, D, g and the scalars of an operating point, zeroed in one launch
+__global__ __launch_bounds__(256)
+void zero_normal_kernel(NormalDims nd, OpRef R)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const size_t nA = (size_t)nd.Nc*nd.Nc, nB = (size_t)nd.NE*nd.Nc, nD = (size_t)nd.NEb*36;
+    const size_t total = nA + nB + nD + nd.Nstate + NSCALARS;
+    for(size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x*blockDim.x)
+    {
+        size_t j = i;
+        if(j < nA) { O.A[j] = 0.0; continue; }   j -= nA;
+        if(j < nB) { O.Bt[j] = 0.0; continue; }  j -= nB;
+        if(j < nD) { O.D[j] = 0.0; continue; }   j -= nD;
+        if(j < (size_t)nd.Nstate) { O.g[j] = 0.0; continue; }  j -= nd.Nstate;
+        O.scalars[j] = 0.0;
+    }
+}
+
 ////////////////////////////////////////////////////////////////////////////////
 // Schur complement
 ////////////////////////////////////////////////////////////////////////////////
@@ -261,12 +292,17 @@ void rows_generic_kernel(NormalDims nd, int row0, int row1,
 // One workgroup per E block: L L^T = D_e + lambda I;  Wt_e = L^-1 Bt_e;  y_e = L^-1 g_e.
 // status[0] is set to 1 if any block is not positive definite
 __global__ __launch_bounds__(64)
-void eblock_factor_kernel(NormalDims nd, BlockRanges br, double lambda,
-                          const double* __restrict__ Bt, const double* __restrict__ D,
-                          const double* __restrict__ g,
+void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
                           int* __restrict__ status)
 {
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Bt = O.Bt;
+    const double* __restrict__ D  = O.D;
+    const double* __restrict__ g  = O.g;
+    const double lambda = ctl ? ctl->lambda : lambda_host;
+
     __shared__ double L[36];
     const int blk = br.block(blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
@@ -314,33 +350,37 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, double lambda,
 
 // S = A + lambda I ;  r = g_S.  The SYRK then subtracts Wt^T Wt and Wt^T y
 __global__ __launch_bounds__(256)
-void schur_init_kernel(NormalDims nd, double lambda, int with_rhs,
-                       const double* __restrict__ A, const double* __restrict__ g,
+void schur_init_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
                        double* __restrict__ S, double* __restrict__ r)
 {
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double lambda = is_leader ? (ctl ? ctl->lambda : lambda_host) : 0.0;
     const size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
     const size_t n2  = (size_t)nd.Nc*nd.Nc;
     if(idx < n2)
     {
         const int i = (int)(idx / nd.Nc), j = (int)(idx - (size_t)i*nd.Nc);
-        S[idx] = A[idx] + ((i==j) ? lambda : 0.0);
+        S[idx] = O.A[idx] + ((i==j) ? lambda : 0.0);
     }
     if(idx < (size_t)nd.Nc)
     {
         const int i = (int)idx;
-        r[i] = with_rhs ? g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0;
+        r[i] = is_leader ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0;
     }
 }
 
 // S -= Wt^T Wt ,  r -= Wt^T y.   Tile (32 x 32 of S) x (slice of E rows) per
 // workgroup; partial products are added atomically. Tiles with bj < bi are
-// skipped; the lower triangle is mirrored by the last step of the Cholesky
+// skipped and the result goes to the LOWER triangle (S[j][i], j >= i), which is
+// what the Cholesky reads
 #define SYRK_TILE 32
 __global__ __launch_bounds__(256)
-void schur_syrk_kernel(NormalDims nd, int e_lo, int e_hi, int e_per_slice,
+void schur_syrk_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
                        const double* __restrict__ Wt, const double* __restrict__ y,
                        double* __restrict__ S, double* __restrict__ r)
 {
+    if(skip != NULL && *skip) return;
     const int bi = blockIdx.x, bj = blockIdx.y;
     if(bj < bi) return;
     const int e_begin = e_lo + blockIdx.z*e_per_slice;
@@ -385,7 +425,7 @@ void schur_syrk_kernel(NormalDims nd, int e_lo, int e_hi, int e_per_slice,
         {
             const int i = i0 + ty + 16*a, j = j0 + tx + 16*bb;
             if(i < nd.Nc && j < nd.Nc && j >= i)
-                atomicAdd(&S[(size_t)i*nd.Nc + j], -acc[a][bb]);
+                atomicAdd(&S[(size_t)j*nd.Nc + i], -acc[a][bb]);
         }
     if(bj == bi && tx == 0)
         for(int a=0;a<2;a++)
@@ -395,125 +435,270 @@ void schur_syrk_kernel(NormalDims nd, int e_lo, int e_hi, int e_per_slice,
         }
 }
 
-// Dense Cholesky of S (upper triangle valid on input), one workgroup. On output
-// the LOWER triangle of S holds L. Then solves S d = -r in place: r <- d.
-// The matrix is staged in LDS when it fits (n <= CHOL_LDS_NMAX), else it is
-// factored in place in global memory (correct, slow; large camera blocks are
-// a later-round optimization).
-__device__ __forceinline__ double& chol_at(double* M, int ld, int i, int j) { return M[(size_t)i*ld + j]; }
+// Dense Cholesky of S (lower triangle valid on input) and the solve S d = -r,
+// one workgroup of 1024. On output the LOWER triangle of S holds L, and r holds d.
+//
+// Blocked, panels of 16 columns, 3 workgroup barriers per panel instead of 3
+// per column:
+//   (a) wave 0 factors the 16x16 diagonal block IN REGISTERS: lane i holds row
+//       i, pivots and multipliers travel by v_readlane. No LDS round trips
+//   (b) the rows below the panel: one forward substitution per row, one row
+//       per thread
+//   (c) rank-16 update of the trailing matrix, 32x32 threads, each owning up
+//       to 4x4 entries 32 apart, so that one pass over the panel's 16 columns
+//       feeds 16 FMAs from 8 LDS reads
+// The right-hand side rides along as an extra matrix row n, so L z = r is
+// solved by the factorization itself; L^T d = z then goes panel by panel,
+// backwards: the 16x16 triangle again in registers of wave 0.
+//
+// Storage: packed lower triangle in LDS ((n+1)(n+2)/2 doubles: n <= 200 fits)
+// when IN_LDS, else in place in global memory, row-major (correct, slow: large
+// camera blocks get their own multi-workgroup kernel)
+#define CHOL_PB 16
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    return u.d;
+}
 
 template<bool IN_LDS>
 __global__ __launch_bounds__(1024)
-void schur_cholesky_solve_kernel(int n, double* __restrict__ S, double* __restrict__ r,
+void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_factor,
+                                 double* __restrict__ S, double* __restrict__ r,
                                  int* __restrict__ status)
 {
+    if(skip != NULL && *skip) return;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t  = threadIdx.x;
     const int nt = blockDim.x;
-    const int ld = IN_LDS ? (n | 1) : n;
-    double* M = IN_LDS ? lds : S;
+    const int npanels = (n + CHOL_PB - 1)/CHOL_PB;
 
-    // symmetrize into the lower triangle (and into LDS)
-    for(int idx = t; idx < n*n; idx += nt)
+    // element (i,j), j <= i <= n. Row n is the right-hand side
+    double* const Mp = lds;
+    auto rowbase = [&](int i) -> size_t { return IN_LDS ? (size_t)i*(i+1)/2 : (size_t)i*n; };
+    auto rowptr  = [&](int i) -> double* { return IN_LDS ? (Mp + (size_t)i*(i+1)/2) : ((i == n) ? r : (S + (size_t)i*n)); };
+    (void)rowbase;
+
+    // the lower triangle into LDS: 4 loads in flight per thread
+    if(IN_LDS)
     {
-        const int i = idx / n, j = idx - i*n;
-        if(j <= i) chol_at(M, ld, i, j) = S[(size_t)j*n + i];
+        for(int idx0 = 0; idx0 < n*n; idx0 += 4*nt)
+        {
+            double v[4];
+#pragma unroll
+            for(int u = 0; u < 4; u++)
+            {
+                const int idx = idx0 + u*nt + t;
+                v[u] = (idx < n*n) ? S[idx] : 0.0;
+            }
+#pragma unroll
+            for(int u = 0; u < 4; u++)
+            {
+                const int idx = idx0 + u*nt + t;
+                const int i = idx / n, j = idx - i*n;
+                if(idx < n*n && j <= i) rowptr(i)[j] = v[u];
+            }
+        }
+        for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     }
-    __syncthreads();
-
-    __shared__ int notpd;
+    __shared__ int    notpd;
+    __shared__ double rdiag[CHOL_PB];
     if(t == 0) notpd = 0;
     __syncthreads();
 
-    // right-looking, panels of PB columns
-    constexpr int PB = 8;
-    for(int j0 = 0; j0 < n; j0 += PB)
+    for(int p = 0; p < npanels; p++)
     {
-        const int jb = min(PB, n - j0);
-        // factor the panel's diagonal block and the panel below it, column by column.
-        // rows are spread over the threads; within a column only the pivot is serial
-        for(int jj = 0; jj < jb; jj++)
-        {
-            const int j = j0 + jj;
-            if(t == 0)
-            {
-                double d = chol_at(M, ld, j, j);
-                if(!(d > 0.0)) { notpd = 1; d = 1.0; }
-                chol_at(M, ld, j, j) = sqrt(d);
-            }
-            __syncthreads();
-            const double djj = chol_at(M, ld, j, j);
-            for(int i = j + 1 + t; i < n; i += nt)
-                chol_at(M, ld, i, j) /= djj;
-            __syncthreads();
-            // update the remaining columns of the panel only
-            const int ncols = jb - jj - 1;
-            for(int idx = t; idx < ncols*(n - j - 1); idx += nt)
-            {
-                const int cc = idx % ncols, ii = idx / ncols;
-                const int c = j + 1 + cc, i = j + 1 + ii;
-                if(i >= c)
-                    chol_at(M, ld, i, c) -= chol_at(M, ld, i, j)*chol_at(M, ld, c, j);
-            }
-            __syncthreads();
-        }
-        // trailing update: M[i][c] -= sum_k L[i][k] L[c][k], k in the panel; i >= c >= j0+jb
+        const int j0 = p*CHOL_PB;
+        const int jb = min(CHOL_PB, n - j0);
         const int m0 = j0 + jb;
-        const int nm = n - m0;
-        for(int idx = t; idx < nm*nm; idx += nt)
+
+        // (a) diagonal block, wave 0, in registers: lane i (< jb) holds row i
+        if(t < 64)
         {
-            const int ii = idx / nm, cc = idx - ii*nm;
-            if(cc > ii) continue;
-            const int i = m0 + ii, c = m0 + cc;
-            double acc = 0.0;
+            double row[CHOL_PB];
+            {
+                const double* __restrict__ src = rowptr(j0 + ((t < jb) ? t : 0)) + j0;
 #pragma unroll
-            for(int kk = 0; kk < PB; kk++)
-                if(kk < jb)
-                    acc += chol_at(M, ld, i, j0+kk)*chol_at(M, ld, c, j0+kk);
-            chol_at(M, ld, i, c) -= acc;
+                for(int c = 0; c < CHOL_PB; c++) row[c] = (t < jb && c <= t) ? src[c] : 0.0;
+            }
+            double myrd = 1.0;
+#pragma unroll
+            for(int j = 0; j < CHOL_PB; j++)
+            {
+                if(j < jb)
+                {
+                    double d = readlane_f64(row[j], j);
+                    if(!(d > 0.0)) { if(t == 0) notpd = 1; d = 1.0; }
+                    d = sqrt(d);
+                    const double rd = 1.0/d;
+                    if(t == j) myrd = rd;
+                    row[j] = (t == j) ? d : row[j]*rd;
+#pragma unroll
+                    for(int c = j+1; c < CHOL_PB; c++)
+                    {
+                        const double lcj = readlane_f64(row[j], c);   // L[c][j]
+                        if(t >= c) row[c] -= row[j]*lcj;
+                    }
+                }
+            }
+            if(t < jb)
+            {
+                double* __restrict__ dst = rowptr(j0 + t) + j0;
+#pragma unroll
+                for(int c = 0; c < CHOL_PB; c++) if(c <= t) dst[c] = row[c];
+                rdiag[t] = myrd;
+            }
+        }
+        __syncthreads();
+
+        // (b) rows below (and the rhs row): forward substitution against the block
+        for(int i = m0 + t; i <= n; i += nt)
+        {
+            double* __restrict__ ri = rowptr(i) + j0;
+            double o[CHOL_PB];
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c++)
+            {
+                if(c < jb)
+                {
+                    const double* __restrict__ lc = rowptr(j0 + c) + j0;
+                    double v = ri[c];
+#pragma unroll
+                    for(int k = 0; k < CHOL_PB; k++)
+                        if(k < c) v -= o[k]*lc[k];
+                    o[c] = v*rdiag[c];
+                }
+                else o[c] = 0.0;
+            }
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c++) if(c < jb) ri[c] = o[c];
+        }
+        __syncthreads();
+
+        // (c) trailing update: M[i][c] -= sum_k L[i][k] L[c][k], k in the panel;
+        //     n >= i >= c >= m0, c < n. Thread (ty,tx) owns i = m0+ty+32a, c = m0+tx+32b
+        {
+            const int ty = t >> 5, tx = t & 31;
+            const int nrows = n + 1 - m0;       // rows m0..n
+            const int ncols = n - m0;           // cols m0..n-1
+            if(ncols > 0)
+            {
+                constexpr int NT = 4;
+                static_assert(NT*32 >= 128, "");
+                // (n - m0 can exceed 128 only for n > 144: then loop over super-tiles)
+                for(int a0 = 0; a0 < nrows; a0 += 32*NT)
+                    for(int b0 = 0; b0 <= a0 && b0 < ncols; b0 += 32*NT)
+                    {
+                        const double* __restrict__ pi[NT];
+                        const double* __restrict__ pc[NT];
+                        bool vi[NT], vc[NT];
+#pragma unroll
+                        for(int a = 0; a < NT; a++)
+                        {
+                            const int ii = a0 + ty + 32*a;
+                            vi[a] = ii < nrows;
+                            pi[a] = rowptr(m0 + (vi[a] ? ii : 0)) + j0;
+                            const int cc = b0 + tx + 32*a;
+                            vc[a] = cc < ncols;
+                            pc[a] = rowptr(m0 + (vc[a] ? cc : 0)) + j0;
+                        }
+                        double acc[NT][NT];
+#pragma unroll
+                        for(int a = 0; a < NT; a++)
+#pragma unroll
+                            for(int b = 0; b < NT; b++) acc[a][b] = 0.0;
+#pragma unroll
+                        for(int kk = 0; kk < CHOL_PB; kk++)
+                        {
+                            if(kk < jb)
+                            {
+                                double li[NT], lc[NT];
+#pragma unroll
+                                for(int a = 0; a < NT; a++) { li[a] = pi[a][kk]; lc[a] = pc[a][kk]; }
+#pragma unroll
+                                for(int a = 0; a < NT; a++)
+#pragma unroll
+                                    for(int b = 0; b < NT; b++) acc[a][b] += li[a]*lc[b];
+                            }
+                        }
+#pragma unroll
+                        for(int a = 0; a < NT; a++)
+#pragma unroll
+                            for(int b = 0; b < NT; b++)
+                            {
+                                const int ii = a0 + ty + 32*a, cc = b0 + tx + 32*b;
+                                if(vi[a] && vc[b] && cc <= ii)
+                                    rowptr(m0 + ii)[m0 + cc] -= acc[a][b];
+                            }
+                    }
+            }
         }
         __syncthreads();
     }
     if(t == 0 && notpd) atomicExch(status, 1);
 
-    // L z = r ; L^T d = z ; r <- -d.  Column-oriented, the vector lives in LDS
-    __shared__ double piv;
-    double* v = IN_LDS ? (lds + (size_t)n*ld) : r;
-    if(IN_LDS) { for(int i=t;i<n;i+=nt) v[i] = r[i]; __syncthreads(); }
-    for(int j=0;j<n;j++)
+    // row n now holds z = L^-1 r. Solve L^T d = z backwards, panel by panel
+    double* __restrict__ z = rowptr(n);
+    for(int p = npanels-1; p >= 0; p--)
     {
-        if(t == 0) { piv = v[j]/chol_at(M, ld, j, j); v[j] = piv; }
+        const int j0 = p*CHOL_PB;
+        const int jb = min(CHOL_PB, n - j0);
+        if(t < 64)
+        {
+            // lane c holds z[c] and column c of the diagonal block
+            double col[CHOL_PB];
+#pragma unroll
+            for(int k = 0; k < CHOL_PB; k++)
+                col[k] = (t < jb && k < jb && k >= t) ? rowptr(j0 + k)[j0 + t] : 0.0;
+            double zc = (t < jb) ? z[j0 + t] : 0.0;
+#pragma unroll
+            for(int k = CHOL_PB-1; k >= 0; k--)
+            {
+                if(k < jb)
+                {
+                    if(t == k) zc = zc/col[k];
+                    const double dk = readlane_f64(zc, k);
+                    if(t < k) zc -= col[k]*dk;
+                }
+            }
+            if(t < jb) z[j0 + t] = zc;
+        }
         __syncthreads();
-        const double pj = piv;
-        for(int i=j+1+t;i<n;i+=nt) v[i] -= chol_at(M, ld, i, j)*pj;
+        // z[i] -= sum_c L[j0+c][i] d[c],  i < j0
+        for(int i = t; i < j0; i += nt)
+        {
+            double acc = 0.0;
+            for(int c = 0; c < jb; c++) acc += rowptr(j0+c)[i]*z[j0+c];
+            z[i] -= acc;
+        }
         __syncthreads();
     }
-    for(int j=n-1;j>=0;j--)
-    {
-        if(t == 0) { piv = v[j]/chol_at(M, ld, j, j); v[j] = piv; }
-        __syncthreads();
-        const double pj = piv;
-        for(int i=t;i<j;i+=nt) v[i] -= chol_at(M, ld, j, i)*pj;
-        __syncthreads();
-    }
-    for(int i=t;i<n;i+=nt) r[i] = -v[i];
-
-    // keep the factor for later solves (uncertainty, solve_xt_JtJ_bt)
+    // r <- -d ; keep the factor for later solves (uncertainty, solve_xt_JtJ_bt)
     if(IN_LDS)
+    {
+        for(int i = t; i < n; i += nt) r[i] = -z[i];
+        if(keep_factor)
         for(int idx = t; idx < n*n; idx += nt)
         {
             const int i = idx / n, j = idx - i*n;
-            if(j <= i) S[(size_t)i*n + j] = chol_at(M, ld, i, j);
+            if(j <= i) S[(size_t)i*n + j] = rowptr(i)[j];
         }
+    }
+    else
+        for(int i = t; i < n; i += nt) r[i] = -r[i];
 }
 
 // d_e = -L^-T (y_e + Wt_e d_s);  also scatters d_s into the state-ordered step
 __global__ __launch_bounds__(64)
-void backsub_kernel(NormalDims nd, BlockRanges br,
+void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restrict__ skip_also,
                     const double* __restrict__ Wt, const double* __restrict__ LD,
-                    const double* __restrict__ y, const double* __restrict__ ds,
-                    double* __restrict__ step)
+                    const double* __restrict__ y, const double* __restrict__ ds)
 {
+    if(opref_skip(R)) return;
+    if(skip_also != NULL && *skip_also) return;
+    double* __restrict__ step = opref_get(R).step_gn;
     const int t   = threadIdx.x;
     if((int)blockIdx.x == br.count())
     {
@@ -557,37 +742,84 @@ void backsub_kernel(NormalDims nd, BlockRanges br,
 ////////////////////////////////////////////////////////////////////////////////
 // v^T N v = |J v|^2 from the blocks;  dot products
 ////////////////////////////////////////////////////////////////////////////////
-// one wave per row of [A ; Bt]: out += v_row * (row . v_S) * (1 for A rows, 2 for Bt rows);
-// D blocks by the first NEb lanes of the grid
-__global__ __launch_bounds__(64)
-void quadform_kernel(NormalDims nd,
-                     const double* __restrict__ A, const double* __restrict__ Bt, const double* __restrict__ D,
-                     const double* __restrict__ v, double* __restrict__ out)
+// out[0] += v^T N v, and if nout == 3: out[1] += g . v,  out[2] += v . v   with N = [A B; Bt D]
+// of the operating point: v^T N v = v_S^T A v_S + 2 v_E^T (Bt v_S) + v_E^T D v_E.
+// One wave per group of rows of [A ; Bt]; one atomic triple per workgroup
+#define QF_ROWS_PER_WAVE 8
+__global__ __launch_bounds__(256)
+void quadform_kernel(NormalDims nd, OpRef R, const double* __restrict__ v_in, int v_is_g,
+                     double* __restrict__ out_in, int out_in_scalars_at, int nout)
 {
-    const int row  = blockIdx.x;
-    const int lane = threadIdx.x;
-    const double* __restrict__ M = (row < nd.Nc) ? A + (size_t)row*nd.Nc : Bt + (size_t)(row - nd.Nc)*nd.Nc;
-    double acc = 0.0;
-    for(int c=lane;c<nd.Nc;c+=64)
-        acc += M[c]*v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
-    for(int off=32; off>0; off>>=1) acc += __shfl_down(acc, off);
-    if(lane == 0)
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ v   = v_is_g ? O.g : v_in;
+    double*       __restrict__ out = (out_in != NULL) ? out_in : (O.scalars + out_in_scalars_at);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Nrows = nd.Nc + nd.NE;
+    const int row0  = (blockIdx.x*4 + wave)*QF_ROWS_PER_WAVE;
+
+    // the 8 rows of this wave against v_S, all loads in flight together
+    const double* __restrict__ M[QF_ROWS_PER_WAVE];
+#pragma unroll
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
     {
-        double vr, w;
-        if(row < nd.Nc) { vr = v[(row < nd.Nie) ? row : nd.i_state_warp + (row - nd.Nie)]; w = 1.0; }
-        else            { vr = v[nd.Nie + (row - nd.Nc)];                                   w = 2.0; }
-        double total = w*vr*acc;
-        // the D block of this E row
+        int row = row0 + rr;
+        if(row >= Nrows) row = Nrows - 1;   // duplicate work, discarded below
+        M[rr] = (row < nd.Nc) ? O.A + (size_t)row*nd.Nc : O.Bt + (size_t)(row - nd.Nc)*nd.Nc;
+    }
+    double acc[QF_ROWS_PER_WAVE];
+#pragma unroll
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] = 0.0;
+    for(int c = lane; c < nd.Nc; c += 64)
+    {
+        const double vs = v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
+#pragma unroll
+        for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] += M[rr][c]*vs;
+    }
+#pragma unroll
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
+        for(int off=32; off>0; off>>=1) acc[rr] += __shfl_down(acc[rr], off);
+    // lane rr finishes row rr
+    double mine = 0.0;
+#pragma unroll
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
+    {
+        const double a0 = __shfl(acc[rr], 0);
+        if(lane == rr) mine = a0;
+    }
+    double t_vNv = 0.0, t_gv = 0.0, t_vv = 0.0;
+    const int row = row0 + lane;
+    if(lane < QF_ROWS_PER_WAVE && row < Nrows)
+    {
+        int    is;      // state index of this row's variable
+        double wgt;
+        if(row < nd.Nc) { is = (row < nd.Nie) ? row : nd.i_state_warp + (row - nd.Nie); wgt = 1.0; }
+        else            { is = nd.Nie + (row - nd.Nc);                                  wgt = 2.0; }
+        const double vr = v[is];
+        double total = wgt*vr*mine;
         if(row >= nd.Nc)
         {
             int blk, a, de, e0;
             E_to_block(nd, row - nd.Nc, &blk, &a, &de, &e0);
             double s = 0.0;
-            for(int c=0;c<de;c++) s += D[(size_t)blk*36 + a*6 + c]*v[nd.Nie + e0 + c];
+            for(int c=0;c<de;c++) s += O.D[(size_t)blk*36 + a*6 + c]*v[nd.Nie + e0 + c];
             total += vr*s;
         }
-        atomicAdd(out, total);
+        t_vNv = total;
+        t_gv  = O.g[is]*vr;
+        t_vv  = vr*vr;
     }
+    for(int off=4; off>0; off>>=1)
+    {
+        t_vNv += __shfl_down(t_vNv, off);
+        t_gv  += __shfl_down(t_gv,  off);
+        t_vv  += __shfl_down(t_vv,  off);
+    }
+    __shared__ double part[4][3];
+    if(lane == 0) { part[wave][0] = t_vNv; part[wave][1] = t_gv; part[wave][2] = t_vv; }
+    __syncthreads();
+    if(threadIdx.x < nout)
+        atomicAdd(&out[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256)
@@ -612,6 +844,9 @@ void axpby_kernel(int n, double alpha, const double* __restrict__ a, double beta
     if(i < n) y[i] = alpha*a[i] + ((b != NULL) ? beta*b[i] : 0.0);
 }
 
+////////////////////////////////////////////////////////////////////////////////
+// outlier rejection
+////////////////////////////////////////////////////////////////////////////////
 // marks board-corner outliers: weight *= -1 for inliers with |x| > k sigma in
 // either coordinate (mrcal.c:4320-4345). counts[0] += number newly marked
 __global__ __launch_bounds__(256)
@@ -668,33 +903,226 @@ void outlier_stats_kernel(int Npoints_board, double thresh_sq,
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// dog-leg control (libdogleg's trust-region logic, on the device)
+////////////////////////////////////////////////////////////////////////////////
+// flags derived from the control state, for the kernels' skip pointers
+//   skip_factor: this trial does not need a factorization
+//   skip_eval:   this trial does not evaluate a new point
+struct SolverCtlFlags { int skip_factor, skip_eval; };
+static_assert(sizeof(SolverCtlFlags) == 8, "");
+
+__global__ void step_begin_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctl->abort_step = 0;
+    *chol_status = 0;
+    {
+        double* sc = ops[ctl->ib].scalars;
+        sc[SC_STEP_SNS] = sc[SC_STEP_GS] = sc[SC_STEP_SS] = 0.0;
+        if(!ctl->gn_valid[ctl->ib]) sc[SC_GN_LENSQ] = sc[SC_GN_DOT_CAUCHY] = 0.0;
+    }
+    if(!ctl->done && ctl->check_termination && ctl->Nsteps_accepted >= ctl->max_iterations)
+        ctl->done = 1;
+    if(ctl->done) { fl->skip_factor = 1; fl->skip_eval = 1; ctl->need_gn = 0; return; }
+    const int ib = ctl->ib;
+    const double tr = ctl->trustregion;
+    // the Cauchy step reaches the edge of the trust region: no need for Gauss-Newton
+    const bool cauchy_only = ctl->cauchy_lensq[ib] >= tr*tr;
+    ctl->need_gn = (!cauchy_only && !ctl->gn_valid[ib]) ? 1 : 0;
+    if(ctl->need_gn) ctl->Nfactorizations++;
+    fl->skip_factor = ctl->need_gn ? 0 : 1;
+    fl->skip_eval   = 0;
+}
+
+// |step_gn|^2 -> scalars[SC_GN_LENSQ], step_cauchy . step_gn -> scalars[SC_GN_DOT_CAUCHY] of the point ctl->ib
+__global__ __launch_bounds__(256)
+void gn_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                    const SolverCtlFlags* __restrict__ fl)
+{
+    if(fl->skip_factor) return;
+    const OpDev& O = ops[ctl->ib];
+    double a = 0.0, b = 0.0;
+    for(int i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += gridDim.x*blockDim.x)
+    {
+        const double gn = O.step_gn[i];
+        a += gn*gn;
+        b += gn*O.step_cauchy[i];
+    }
+    for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    __shared__ double part[4][2];
+    if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if(threadIdx.x == 0) atomicAdd(&O.scalars[SC_GN_LENSQ], part[0][0]+part[1][0]+part[2][0]+part[3][0]);
+    if(threadIdx.x == 1) atomicAdd(&O.scalars[SC_GN_DOT_CAUCHY], part[0][1]+part[1][1]+part[2][1]+part[3][1]);
+}
+
+// Chooses the dog-leg step from the point ctl->ib for the current trust
+// region, writes step and the trial state b[ia] = b[ib] + step. Every
+// workgroup derives the same coefficients from the control block; workgroup 0
+// records them. Fields written here are not read by the other workgroups of
+// this launch
+__global__ __launch_bounds__(256)
+void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
+                        const int* __restrict__ chol_status, double* __restrict__ step)
+{
+    if(ctl->done) return;
+    const int  ib = ctl->ib, ia = ctl->ia;
+    const OpDev& from = ops[ib];
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    const bool fresh_gn = ctl->need_gn != 0;
+
+    if(fresh_gn)
+    {
+        const double lensq = from.scalars[SC_GN_LENSQ];
+        if(*chol_status != 0 || !(lensq == lensq))
+        {
+            // JtJ is singular: regularize, like libdogleg does, and void this trial
+            if(leader)
+            {
+                double lam = ctl->lambda;
+                lam = (lam == 0.0) ? 1e-10 : lam*10.0;
+                ctl->lambda = lam;
+                if(!(lam < 1e30)) { ctl->error = 1; ctl->done = 1; }
+                ctl->abort_step = 1;
+                fl->skip_eval   = 1;
+            }
+            return;
+        }
+    }
+
+    const double tr = ctl->trustregion, dsq = tr*tr;
+    const double norm2a = ctl->cauchy_lensq[ib];
+    double kc, kg, len_sq;
+    int edge;
+    double norm2b = 0.0, ab = 0.0;
+    if(norm2a >= dsq)
+    {
+        kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
+    }
+    else
+    {
+        // Gauss-Newton step: fresh from this trial's factorization, or kept
+        // from an earlier, rejected trial from the same point
+        norm2b = fresh_gn ? from.scalars[SC_GN_LENSQ] : ctl->gn_lensq[ib];
+        ab     = from.scalars[SC_GN_DOT_CAUCHY];
+        if(norm2b <= dsq)
+        {
+            kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
+        }
+        else
+        {
+            // point on the Cauchy->GN segment at the trust-region edge:
+            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
+            const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
+            const double neg_c = norm2a - ab;                // a.(a-b)
+            double disc = neg_c*neg_c - l2*(norm2a - dsq);
+            if(disc < 0.0) disc = 0.0;
+            const double k = (neg_c + sqrt(disc))/l2;
+            kc = 1.0 - k; kg = k;
+            len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
+            edge = 1;
+        }
+    }
+
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i < nd.Nstate)
+    {
+        double s = kc*from.step_cauchy[i];
+        if(kg != 0.0) s += kg*from.step_gn[i];
+        step[i] = s;
+        ops[ia].b[i] = from.b[i] + s;
+    }
+
+    if(leader)
+    {
+        if(fresh_gn) { ctl->gn_lensq[ib] = norm2b; ctl->gn_valid[ib] = 1; }
+        ctl->k_cauchy = kc; ctl->k_gn = kg;
+        ctl->step_len_sq = len_sq;
+        ctl->did_step_to_edge[ib] = edge;
+        ctl->Ntrials++;
+        if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
+        {
+            ctl->done = 1;
+            fl->skip_eval = 1;
+        }
+    }
+}
+
+// After the evaluation of a point and the reduction g N g, g.g: its Cauchy
+// step -(|g|^2/|Jg|^2) g and the bookkeeping. which: 0 = the point ctl->ia
+// (a trial), 1 = the point ctl->ib (the initial evaluation)
+__global__ __launch_bounds__(256)
+void finish_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl,
+                         const SolverCtlFlags* __restrict__ fl, int initial)
+{
+    if(!initial && fl->skip_eval) return;
+    const int ip = initial ? ctl->ib : ctl->ia;
+    const OpDev& O = ops[ip];
+    const double gNg = O.scalars[SC_G_GNG], norm2_g = O.scalars[SC_G_GG];
+    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i < nd.Nstate) O.step_cauchy[i] = k*O.g[i];
+    if(blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        ctl->norm2_x[ip]      = O.scalars[SC_NORM2_X];
+        ctl->cauchy_lensq[ip] = k*k*norm2_g;
+        ctl->gn_valid[ip]     = 0;
+        ctl->did_step_to_edge[ip] = 0;
+        ctl->Nevaluations++;
+    }
+}
+
+// rho test, trust-region update, accept/reject
+__global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, const SolverCtlFlags* __restrict__ fl)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    if(fl->skip_eval) return;     // finished, or the trial was voided
+    const int ib = ctl->ib, ia = ctl->ia;
+    const OpDev& from = ops[ib];
+    // expected improvement: |x|^2 - |x + J s|^2 = -2 g.s - s^T N s
+    const double expected = -2.0*from.scalars[SC_STEP_GS] - from.scalars[SC_STEP_SNS];
+    ctl->expected_improvement = expected;
+    const double observed = ctl->norm2_x[ib] - ctl->norm2_x[ia];
+    const double rho = observed/expected;
+    double tr = ctl->trustregion;
+    if(rho < ctl->trustregion_decrease_threshold)
+        tr *= ctl->trustregion_decrease_factor;
+    else if(rho > ctl->trustregion_increase_threshold && ctl->did_step_to_edge[ib])
+        tr *= ctl->trustregion_increase_factor;
+    ctl->trustregion = tr;
+    if(rho > 0.0)
+    {
+        ctl->ib = ia; ctl->ia = ib;
+        ctl->Nsteps_accepted++;
+    }
+    else if(ctl->check_termination &&
+            (tr < ctl->trustregion_threshold || tr == 0.0 || !(tr == tr)))
+        ctl->done = 1;
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
-                           const EvalBuffers& B, const NormalBuffers& N, hipStream_t stream)
+                           const EvalBuffers& B, hipStream_t stream)
 {
-    hipError_t e;
-    if((e = hipMemsetAsync(N.A,  0, (size_t)nd.Nc*nd.Nc*sizeof(double), stream)) != hipSuccess) return e;
-    if(nd.NE > 0)
     {
-        if((e = hipMemsetAsync(N.Bt, 0, (size_t)nd.NE*nd.Nc*sizeof(double), stream)) != hipSuccess) return e;
-        if((e = hipMemsetAsync(N.D,  0, (size_t)nd.NEb*36*sizeof(double),   stream)) != hipSuccess) return e;
+        const size_t total = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + nd.Nstate + NSCALARS;
+        int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, B.R);
     }
-    if((e = hipMemsetAsync(N.g,  0, (size_t)nd.Nstate*sizeof(double), stream)) != hipSuccess) return e;
-    if((e = hipMemsetAsync(N.scalars, 0, NSCALARS*sizeof(double), stream)) != hipSuccess) return e;
-
     if(P.Nobs_board > 0)
     {
         if(P.do_optimize_frames)
             hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), 0, stream,
-                               P, nd, plan.frame_obs_begin, B.gram, N.Bt, N.D, N.g);
+                               P, nd, B.R, plan.frame_obs_begin, B.gram);
         hipLaunchKernelGGL(reduce_pairs_kernel, dim3(plan.Nchunks), dim3(256), 0, stream,
-                           P, nd, plan.chunk_begin, plan.pair_obs, B.gram, N.A, N.g, &N.scalars[SC_NORM2_X]);
+                           P, nd, B.R, plan.chunk_begin, plan.pair_obs, B.gram);
     }
     const int row0 = 2*P.W*P.H*P.Nobs_board;
     if(P.Nmeas > row0)
         hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - row0 + 63)/64), dim3(64), 0, stream,
-                           nd, row0, P.Nmeas, B.Jp, B.Ji, B.Jv, B.x, N.A, N.Bt, N.D, N.g, &N.scalars[SC_NORM2_X]);
+                           nd, B.R, row0, P.Nmeas, B.Jp, B.Ji);
     return hipGetLastError();
 }
 
@@ -702,20 +1130,19 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
 // blocks and form this shard's contribution to the Schur complement and to
 // the reduced right-hand side: S_loc = A_loc (+ lambda I) - sum_local Wt^T Wt,
 // r_loc = (g_S) - sum_local Wt^T y. The "(...)" terms are added by the shard
-// leader only, so that the sum over shards has them once
+// leader only, so that the sum over shards has them once. lambda comes from
+// the control block if one is given
 hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
-                               const NormalBuffers& N, const FactorBuffers& F,
-                               double lambda, bool is_leader, hipStream_t stream)
+                               const OpRef& R, const FactorBuffers& F,
+                               double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream)
 {
-    hipError_t e;
-    if((e = hipMemsetAsync(F.status, 0, sizeof(int), stream)) != hipSuccess) return e;
     if(br.count() > 0)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
-                           nd, br, lambda, N.Bt, N.D, N.g, F.Wt, F.LD, F.y, F.status);
+                           nd, br, R, lambda, ctl, F.Wt, F.LD, F.y, F.status);
     {
         const size_t n2 = (size_t)nd.Nc*nd.Nc;
         hipLaunchKernelGGL(schur_init_kernel, dim3((unsigned)((n2 + 255)/256)), dim3(256), 0, stream,
-                           nd, is_leader ? lambda : 0.0, is_leader ? 1 : 0, N.A, N.g, F.S, F.r);
+                           nd, R, lambda, ctl, is_leader ? 1 : 0, F.S, F.r);
     }
     // the E rows of the local blocks: two contiguous ranges (frames, points)
     for(int part = 0; part < 2; part++)
@@ -730,52 +1157,41 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
         e_per_slice = ((e_per_slice + 15)/16)*16;
         nslices = (e_hi - e_lo + e_per_slice - 1)/e_per_slice;
         hipLaunchKernelGGL(schur_syrk_kernel, dim3(ntile, ntile, nslices), dim3(256), 0, stream,
-                           nd, e_lo, e_hi, e_per_slice, F.Wt, F.y, F.S, F.r);
+                           nd, R.skip, e_lo, e_hi, e_per_slice, F.Wt, F.y, F.S, F.r);
     }
     return hipGetLastError();
 }
 
 // Phase 2: dense Cholesky of the (summed) Schur complement, d_S, and the
-// back-substitution of the local E blocks into step_gn
+// back-substitution of the local E blocks into step_gn of the point
 hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
-                                const FactorBuffers& F, double* step_gn, hipStream_t stream)
+                                const OpRef& R, const FactorBuffers& F, const int* skip_also, bool keep_factor,
+                                hipStream_t stream)
 {
     {
         const int n = nd.Nc;
-        const size_t lds = ((size_t)n*(n|1) + n)*sizeof(double);
-        if(lds <= 160*1024 - 64)
+        const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
+        if(lds <= 160*1024 - 512)
             hipLaunchKernelGGL((schur_cholesky_solve_kernel<true>), dim3(1), dim3(1024), lds, stream,
-                               n, F.S, F.r, F.status);
+                               n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
         else
             hipLaunchKernelGGL((schur_cholesky_solve_kernel<false>), dim3(1), dim3(1024), 0, stream,
-                               n, F.S, F.r, F.status);
-    }
-    if(br.count() < nd.NEb && nd.NE > 0)
-    {
-        // a shard writes only its own blocks; the others' entries must be 0 for
-        // the all-reduce that follows (they may hold the previous sum)
-        hipError_t e = hipMemsetAsync(step_gn + nd.Nie, 0, (size_t)nd.NE*sizeof(double), stream);
-        if(e != hipSuccess) return e;
+                               n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
     }
     hipLaunchKernelGGL(backsub_kernel, dim3(br.count()+1), dim3(64), 0, stream,
-                       nd, br, F.Wt, F.LD, F.y, F.r, step_gn);
+                       nd, br, R, skip_also, F.Wt, F.LD, F.y, F.r);
     return hipGetLastError();
 }
 
-hipError_t launch_factor_and_solve(const NormalDims& nd, const BlockRanges& br,
-                                   const NormalBuffers& N, const FactorBuffers& F,
-                                   double lambda, double* step_gn, hipStream_t stream)
+static int quadform_blocks(const NormalDims& nd)
 {
-    hipError_t e = launch_factor_local(nd, br, N, F, lambda, true, stream);
-    if(e != hipSuccess) return e;
-    return launch_solve_backsub(nd, br, F, step_gn, stream);
+    return (nd.Nc + nd.NE + 4*QF_ROWS_PER_WAVE - 1)/(4*QF_ROWS_PER_WAVE);
 }
-
-hipError_t launch_quadform(const NormalDims& nd, const NormalBuffers& N, const double* v, double* out,
+hipError_t launch_quadform(const NormalDims& nd, const OpRef& R, const double* v, double* out,
                            hipStream_t stream)
 {
-    hipLaunchKernelGGL(quadform_kernel, dim3(nd.Nc + nd.NE), dim3(64), 0, stream,
-                       nd, N.A, N.Bt, N.D, v, out);
+    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                       nd, R, v, 0, out, 0, 1);
     return hipGetLastError();
 }
 hipError_t launch_dot(int n, const double* a, const double* b, double* out, hipStream_t stream)
@@ -805,6 +1221,46 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
     if(Npoints_board <= 0) return hipSuccess;
     hipLaunchKernelGGL(mark_outliers_kernel, dim3((Npoints_board+255)/256), dim3(256), 0, stream,
                        Npoints_board, thresh_sq, x, pool, counts);
+    return hipGetLastError();
+}
+
+// ---- the device-controlled step. ctl is followed in memory by its SolverCtlFlags
+static SolverCtlFlags* ctl_flags(SolverCtl* ctl) { return (SolverCtlFlags*)(ctl + 1); }
+const int* solver_ctl_skip_factor(const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_factor; }
+const int* solver_ctl_skip_eval  (const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
+size_t     solver_ctl_bytes() { return sizeof(SolverCtl) + sizeof(SolverCtlFlags); }
+
+hipError_t launch_step_begin(const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream)
+{
+    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl), chol_status);
+    return hipGetLastError();
+}
+hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
+                              double* step, hipStream_t stream)
+{
+    int nb = (nd.Nstate + 255)/256; if(nb > 64) nb = 64;
+    hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
+    hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
+                       nd, ops, ctl, ctl_flags(ctl), F.status, step);
+    // for the expected improvement: (step^T N step, g.step, |step|^2) of ctl->ib
+    OpRef Rfrom = { ops, &ctl->ib, solver_ctl_skip_eval(ctl) };
+    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                       nd, Rfrom, step, 0, (double*)NULL, (int)SC_STEP_SNS, 3);
+    return hipGetLastError();
+}
+hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)
+{
+    // (g^T N g, g.g, g.g) -> SC_G_GNG..
+    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
+    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                       nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
+    hipLaunchKernelGGL(finish_point_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
+                       nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream)
+{
+    hipLaunchKernelGGL(step_accept_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl));
     return hipGetLastError();
 }
 

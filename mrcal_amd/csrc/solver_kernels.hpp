@@ -42,16 +42,22 @@ struct BlockRanges
     }
 };
 
-enum { SC_NORM2_X = 0, SC_NORM2_G, SC_GNG, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, NSCALARS = 8 };
-
-// the normal equations of one operating point, unfactored
-struct NormalBuffers
+// per-operating-point scalars (OpDev::scalars). All are zeroed when the
+// point's normal equations are assembled; [SC_GN_LENSQ..SC_STEP_SS] again at
+// the start of every trial step taken from the point
+enum
 {
-    double* A;        // [Nc][Nc]
-    double* Bt;       // [NE][Nc]
-    double* D;        // [NEb][6][6]
-    double* g;        // [Nstate]   Jt x, state order
-    double* scalars;  // [NSCALARS]
+    SC_NORM2_X = 0,        // |x|^2                                   (assembly)
+    SC_G_GNG,              // g^T N g  } the quadratic-form kernel     (after the assembly)
+    SC_G_GG,               // g . g    } writes (vNv, g.v, v.v)
+    SC_G_GG2,              // g . g    } to 3 consecutive slots
+    SC_GN_LENSQ,           // |step_gn|^2
+    SC_GN_DOT_CAUCHY,      // step_gn . step_cauchy
+    SC_STEP_SNS,           // step^T N step
+    SC_STEP_GS,            // g . step
+    SC_STEP_SS,            // |step|^2
+    SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3,   // host-driven paths
+    NSCALARS = 16
 };
 
 // factorization scratch, one set
@@ -62,6 +68,7 @@ struct FactorBuffers
     double* y;        // [NE]       L_e^-1 g_e
     double* S;        // [Nc][Nc]   Schur complement -> its Cholesky factor (lower)
     double* r;        // [Nc]       reduced rhs -> d_s
+    double* Linv;     // [ceil(Nc/16)][16][16] inverses of the diagonal blocks (large Nc only)
     int*    status;   // [1] nonzero: not positive definite
 };
 
@@ -74,17 +81,47 @@ struct AssemblyPlan
     int  Nchunks;
 };
 
+// The dog-leg control block: everything the trust-region logic needs, in
+// device memory. libdogleg keeps this on the host between callbacks; here the
+// decisions are taken by one-thread kernels between the vector kernels, so a
+// whole step is queued without a host round trip.
+struct SolverCtl
+{
+    // configuration (written by the host before a run)
+    double trustregion_decrease_factor, trustregion_decrease_threshold;
+    double trustregion_increase_factor, trustregion_increase_threshold;
+    double update_threshold, trustregion_threshold;
+    int    max_iterations;      // accepted steps
+    int    check_termination;   // 0: run exactly the queued steps (benchmark)
+
+    // state
+    double trustregion;
+    double lambda;              // diagonal regularization, raised when JtJ is not positive definite
+    double norm2_x[2], cauchy_lensq[2], gn_lensq[2];
+    int    gn_valid[2], did_step_to_edge[2];
+    int    ib, ia;              // operating point before / after the step being tried
+    int    done;                // the solve has terminated: every later kernel is a no-op
+    int    abort_step;          // this trial step is void (factorization failed, lambda was raised)
+    int    need_gn;             // this step needs the Gauss-Newton direction, and it is not computed yet
+    int    error;               // lambda ran away
+
+    // the step being tried
+    double step_len_sq, expected_improvement;
+    double k_cauchy, k_gn;      // step = k_cauchy step_cauchy + k_gn step_gn
+
+    // counters
+    int    Nsteps_accepted, Ntrials, Nfactorizations, Nevaluations;
+};
+
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
-                           const EvalBuffers& B, const NormalBuffers& N, hipStream_t stream);
+                           const EvalBuffers& B, hipStream_t stream);
 hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
-                               const NormalBuffers& N, const FactorBuffers& F,
-                               double lambda, bool is_leader, hipStream_t stream);
+                               const OpRef& R, const FactorBuffers& F,
+                               double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream);
 hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
-                                const FactorBuffers& F, double* step_gn, hipStream_t stream);
-hipError_t launch_factor_and_solve(const NormalDims& nd, const BlockRanges& br,
-                                   const NormalBuffers& N, const FactorBuffers& F,
-                                   double lambda, double* step_gn, hipStream_t stream);
-hipError_t launch_quadform(const NormalDims& nd, const NormalBuffers& N, const double* v, double* out,
+                                const OpRef& R, const FactorBuffers& F, const int* skip_also, bool keep_factor,
+                                hipStream_t stream);
+hipError_t launch_quadform(const NormalDims& nd, const OpRef& R, const double* v, double* out,
                            hipStream_t stream);
 hipError_t launch_dot(int n, const double* a, const double* b, double* out, hipStream_t stream);
 hipError_t launch_axpby(int n, double alpha, const double* a, double beta, const double* b, double* y,
@@ -93,5 +130,19 @@ hipError_t launch_outlier_stats(int Npoints_board, double thresh_sq, const doubl
                                 int* counts, double* sums, hipStream_t stream);
 hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const double* x, double* pool,
                                 int* counts, hipStream_t stream);
+
+// The device-controlled dog-leg step (single GPU), in the order they are queued:
+//   begin -> [factor_local, solve_backsub] -> choose -> [evaluate, assemble] -> finish_point -> accept
+hipError_t launch_step_begin (const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream);
+hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
+                              double* step, hipStream_t stream);
+// |g|^2, g N g, the Cauchy step of the point just evaluated (ctl->ia, or ctl->ib if initial)
+hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
+hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
+
+// the control block is followed in memory by its derived flags
+size_t     solver_ctl_bytes();
+const int* solver_ctl_skip_factor(const SolverCtl* ctl);   // device pointers, given the device pointer of ctl
+const int* solver_ctl_skip_eval  (const SolverCtl* ctl);
 
 } // namespace mrcal_amd
