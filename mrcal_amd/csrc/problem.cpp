@@ -108,7 +108,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->F.LD, (size_t)nd.NEb*36);
     ok = ok && dev_alloc(&P->F.y,  (size_t)nd.NE);
     // S and r contiguous: one all-reduce moves both
-    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc);
+    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc + 64 + 256);
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
     ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);

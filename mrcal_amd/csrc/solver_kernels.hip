@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include "problem.hpp"
 #include "solver_kernels.hpp"
+#include <type_traits>
 
 namespace mrcal_amd {
 
@@ -436,76 +437,88 @@ void schur_syrk_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, in
 }
 
 // Dense Cholesky of S (lower triangle valid on input) and the solve S d = -r,
-// one workgroup of 1024. On output the LOWER triangle of S holds L, and r holds d.
+// one workgroup of 1024 (16 waves). On output r holds d and, if keep_factor,
+// the lower triangle of S holds L.
 //
 // Blocked, panels of 16 columns, 3 workgroup barriers per panel instead of 3
 // per column:
-//   (a) wave 0 factors the 16x16 diagonal block IN REGISTERS: lane i holds row
-//       i, pivots and multipliers travel by v_readlane. No LDS round trips
-//   (b) the rows below the panel: one forward substitution per row, one row
-//       per thread
-//   (c) rank-16 update of the trailing matrix, 32x32 threads, each owning up
-//       to 4x4 entries 32 apart, so that one pass over the panel's 16 columns
-//       feeds 16 FMAs from 8 LDS reads
+//   (a) wave 0 factors the 16x16 diagonal block IN REGISTERS: lane i of a
+//       16-lane DPP row holds matrix row i; pivots and multipliers travel by
+//       DPP row_share (one VALU move per 32 bits, no LDS or SGPR round trip)
+//   (b) the rows below the panel: forward substitution with 16 lanes per
+//       matrix row (lane c holds column c; the 16 steps again by row_share):
+//       64 rows per pass instead of one row per thread with a 136-long
+//       dependent chain
+//   (c) rank-16 update of the trailing matrix with v_mfma_f64_16x16x4_f64, one
+//       16x16 tile at a time per wave: 16 LDS accesses feed 4096 FMAs, where a
+//       VALU register tile gets 16 FMAs out of 8 LDS reads (the LDS pipe was the
+//       limit of that variant: 5 us for the first panel)
 // The right-hand side rides along as an extra matrix row n, so L z = r is
 // solved by the factorization itself; L^T d = z then goes panel by panel,
-// backwards: the 16x16 triangle again in registers of wave 0.
+// backwards, the 16x16 triangle again by row_share in wave 0.
 //
-// Storage: packed lower triangle in LDS ((n+1)(n+2)/2 doubles: n <= 200 fits)
-// when IN_LDS, else in place in global memory, row-major (correct, slow: large
-// camera blocks get their own multi-workgroup kernel)
+// Storage: packed lower triangle in LDS, (n+1)(n+2)/2 doubles: n <= 200.
+// Larger camera blocks use schur_cholesky_solve_global_kernel below
 #define CHOL_PB 16
-__device__ __forceinline__ double readlane_f64(double v, int srclane)
+template<int N>
+__device__ __forceinline__ double row_share_f64(double v)   // lane N of each 16-lane row, to the row
 {
     union { double d; int i[2]; } u; u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + N, 0xf, 0xf, false);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + N, 0xf, 0xf, false);
     return u.d;
 }
+typedef double chol_double4_t __attribute__((ext_vector_type(4)));
 
-template<bool IN_LDS>
 __global__ __launch_bounds__(1024)
 void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_factor,
                                  double* __restrict__ S, double* __restrict__ r,
                                  int* __restrict__ status)
 {
     if(skip != NULL && *skip) return;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int t  = threadIdx.x;
-    const int nt = blockDim.x;
+    extern __shared__ __attribute__((aligned(16))) double Mp[];
+    const int t    = threadIdx.x;
+    const int nt   = blockDim.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l16  = t & 15;                  // lane within its DPP row
     const int npanels = (n + CHOL_PB - 1)/CHOL_PB;
 
-    // element (i,j), j <= i <= n. Row n is the right-hand side
-    double* const Mp = lds;
-    auto rowbase = [&](int i) -> size_t { return IN_LDS ? (size_t)i*(i+1)/2 : (size_t)i*n; };
-    auto rowptr  = [&](int i) -> double* { return IN_LDS ? (Mp + (size_t)i*(i+1)/2) : ((i == n) ? r : (S + (size_t)i*n)); };
-    (void)rowbase;
+    // element (i,j), j <= i <= n, packed. Row n is the right-hand side
+    auto rowptr = [&](int i) -> double* { return Mp + ((i*(i+1)) >> 1); };
 
-    // the lower triangle into LDS: 4 loads in flight per thread
-    if(IN_LDS)
-    {
-        for(int idx0 = 0; idx0 < n*n; idx0 += 4*nt)
-        {
-            double v[4];
-#pragma unroll
-            for(int u = 0; u < 4; u++)
-            {
-                const int idx = idx0 + u*nt + t;
-                v[u] = (idx < n*n) ? S[idx] : 0.0;
-            }
-#pragma unroll
-            for(int u = 0; u < 4; u++)
-            {
-                const int idx = idx0 + u*nt + t;
-                const int i = idx / n, j = idx - i*n;
-                if(idx < n*n && j <= i) rowptr(i)[j] = v[u];
-            }
-        }
-        for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
-    }
     __shared__ int    notpd;
-    __shared__ double rdiag[CHOL_PB];
+    __shared__ double rdiag_all[16*CHOL_PB];     // 1/L[j][j], every panel's (n <= 256)
     if(t == 0) notpd = 0;
+
+    // the lower triangle into LDS. Wave w takes rows w, w+16, ..., 64 columns
+    // per lane pass; 12 loads in flight per thread, no divisions
+    for(int i0 = wave; i0 < n; i0 += 16*4)
+    {
+        double v[4][3];
+#pragma unroll
+        for(int a = 0; a < 4; a++)
+#pragma unroll
+            for(int b = 0; b < 3; b++)
+            {
+                const int i = i0 + 16*a, j = lane + 64*b;
+                v[a][b] = (i < n && j <= i) ? S[(size_t)i*n + j] : 0.0;
+            }
+#pragma unroll
+        for(int a = 0; a < 4; a++)
+#pragma unroll
+            for(int b = 0; b < 3; b++)
+            {
+                const int i = i0 + 16*a, j = lane + 64*b;
+                if(i < n && j <= i) rowptr(i)[j] = v[a][b];
+            }
+        // rows longer than 192 (n > 192): the rest, plainly
+        for(int a = 0; a < 4; a++)
+        {
+            const int i = i0 + 16*a;
+            if(i < n) for(int j = lane + 192; j <= i; j += 64) rowptr(i)[j] = S[(size_t)i*n + j];
+        }
+    }
+    for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     __syncthreads();
 
     for(int p = 0; p < npanels; p++)
@@ -514,125 +527,139 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         const int jb = min(CHOL_PB, n - j0);
         const int m0 = j0 + jb;
 
-        // (a) diagonal block, wave 0, in registers: lane i (< jb) holds row i
-        if(t < 64)
+        // (a) diagonal block: wave 0, lanes 0..15 hold rows j0..j0+15
+        if(wave == 0)
         {
             double row[CHOL_PB];
             {
-                const double* __restrict__ src = rowptr(j0 + ((t < jb) ? t : 0)) + j0;
+                // unconditional loads (reading past the end of a packed row stays
+                // inside the buffer), then select: no branches
+                const bool mine = (lane < jb);
+                const double* __restrict__ src = rowptr(j0 + (mine ? lane : 0)) + j0;
+                double tmp[CHOL_PB];
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) row[c] = (t < jb && c <= t) ? src[c] : 0.0;
+                for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
+#pragma unroll
+                for(int c = 0; c < CHOL_PB; c++) row[c] = (mine && c <= lane) ? tmp[c] : 0.0;
             }
+            // No predication anywhere: the entries above the diagonal (row[c]
+            // of lane i < c) are simply never read for anything that matters
             double myrd = 1.0;
-#pragma unroll
-            for(int j = 0; j < CHOL_PB; j++)
+            bool   bad  = false;
+            auto column = [&](auto J)
             {
-                if(j < jb)
-                {
-                    double d = readlane_f64(row[j], j);
-                    if(!(d > 0.0)) { if(t == 0) notpd = 1; d = 1.0; }
-                    d = sqrt(d);
-                    const double rd = 1.0/d;
-                    if(t == j) myrd = rd;
-                    row[j] = (t == j) ? d : row[j]*rd;
+                constexpr int j = decltype(J)::value;
+                if(j >= jb) return;
+                double piv = row_share_f64<j>(row[j]);
+                bad = bad || !(piv > 0.0);
+                piv = (piv > 0.0) ? piv : 1.0;
+                // 1/sqrt(piv): hardware estimate + 2 Newton steps, sqrt = piv*rsqrt
+                double rd = __builtin_amdgcn_rsq(piv);
+                rd = rd*(1.5 - 0.5*piv*rd*rd);
+                rd = rd*(1.5 - 0.5*piv*rd*rd);
+                myrd = (lane == j) ? rd : myrd;
+                row[j] *= rd;      // lane j: piv*rd = sqrt(piv)
+                // L[i][c] -= L[i][j] L[c][j]; L[c][j] = lane c's row[j]
+#define CHOL_UPD(c) if((c) > j) row[(c) & 15] -= row[j]*row_share_f64<(c) & 15>(row[j]);
+                CHOL_UPD(1)  CHOL_UPD(2)  CHOL_UPD(3)  CHOL_UPD(4)  CHOL_UPD(5)
+                CHOL_UPD(6)  CHOL_UPD(7)  CHOL_UPD(8)  CHOL_UPD(9)  CHOL_UPD(10)
+                CHOL_UPD(11) CHOL_UPD(12) CHOL_UPD(13) CHOL_UPD(14) CHOL_UPD(15)
+#undef CHOL_UPD
+            };
+#define CHOL_COL(j) column(std::integral_constant<int,(j)>{});
+            CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
+            CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
+#undef CHOL_COL
+            if(lane < jb)
+            {
+                double* __restrict__ dst = rowptr(j0 + lane) + j0;
 #pragma unroll
-                    for(int c = j+1; c < CHOL_PB; c++)
-                    {
-                        const double lcj = readlane_f64(row[j], c);   // L[c][j]
-                        if(t >= c) row[c] -= row[j]*lcj;
-                    }
-                }
+                for(int c = 0; c < CHOL_PB; c++) if(c <= lane) dst[c] = row[c];
+                rdiag_all[p*CHOL_PB + lane] = myrd;
             }
-            if(t < jb)
+            if(bad && lane == 0) notpd = 1;
+        }
+        __syncthreads();
+
+        // (b) rows below (and the rhs row): L[i][j0..] <- A[i][j0..] L11^-T. 16 lanes per row
+        {
+            double lrow[CHOL_PB];      // row l16 of the diagonal block
             {
-                double* __restrict__ dst = rowptr(j0 + t) + j0;
+                const double* __restrict__ src = rowptr(j0 + ((l16 < jb) ? l16 : 0)) + j0;
+                double tmp[CHOL_PB];
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) if(c <= t) dst[c] = row[c];
-                rdiag[t] = myrd;
+                for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
+#pragma unroll
+                for(int c = 0; c < CHOL_PB; c++) lrow[c] = (l16 < jb && c < l16) ? tmp[c] : 0.0;
+            }
+            const double myrd = (l16 < jb) ? rdiag_all[p*CHOL_PB + l16] : 0.0;
+            // the 16 lanes of a DPP row work on the same matrix row: they leave the loop together
+            for(int i = m0 + (t >> 4); i <= n; i += (nt >> 4))
+            {
+                const bool ok = (l16 < jb);
+                double a = rowptr(i)[j0 + ((l16 < jb) ? l16 : 0)];
+                a = ok ? a : 0.0;
+                // lane c's value is final once the steps k < c are done (lrow[k] = 0
+                // for k >= c): its output is a*myrd, before and after step c
+                auto step = [&](auto C)
+                {
+                    constexpr int c = decltype(C)::value;
+                    a -= row_share_f64<c>(a*myrd)*lrow[c];
+                };
+#define CHOL_STEP(c) step(std::integral_constant<int,(c)>{});
+                CHOL_STEP(0)  CHOL_STEP(1)  CHOL_STEP(2)  CHOL_STEP(3)  CHOL_STEP(4)  CHOL_STEP(5)  CHOL_STEP(6)  CHOL_STEP(7)
+                CHOL_STEP(8)  CHOL_STEP(9)  CHOL_STEP(10) CHOL_STEP(11) CHOL_STEP(12) CHOL_STEP(13) CHOL_STEP(14) CHOL_STEP(15)
+#undef CHOL_STEP
+                if(ok) rowptr(i)[j0 + l16] = a*myrd;
             }
         }
         __syncthreads();
 
-        // (b) rows below (and the rhs row): forward substitution against the block
-        for(int i = m0 + t; i <= n; i += nt)
+        // (c) trailing update with MFMA: C[i][c] -= sum_k L[i][k] L[c][k], k in the
+        //     panel; rows m0..n (incl. the rhs row), columns m0..n-1, c <= i.
+        //     16x16 tiles (ta,tb), tb <= ta, dealt round-robin to the 16 waves.
+        //     Operand layout of v_mfma_f64_16x16x4_f64 (measured,
+        //     tools/mfma_f64_layout_probe.hip): A lane = A[i=l%16][k=l/16],
+        //     B lane = B[k=l/16][j=l%16], D register v of lane l = D[l/16 + 4v][l%16]
         {
-            double* __restrict__ ri = rowptr(i) + j0;
-            double o[CHOL_PB];
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++)
+            const int nrows = n + 1 - m0, ncols = n - m0;
+            const int ntr = (nrows + 15) >> 4, ntc = (ncols + 15) >> 4;
+            const int r16 = lane & 15, kq = lane >> 4;
+            int tidx = 0;
+            for(int ta = 0; ta < ntr; ta++)
             {
-                if(c < jb)
+                const int ntb = min(ta + 1, ntc);
+                for(int tb = 0; tb < ntb; tb++, tidx++)
                 {
-                    const double* __restrict__ lc = rowptr(j0 + c) + j0;
-                    double v = ri[c];
+                    if((tidx & 15) != wave) continue;
+                    const int  ia = 16*ta + r16, ib = 16*tb + r16;
+                    const bool va = ia < nrows, vb = ib < ncols;
+                    const double* __restrict__ pa = rowptr(m0 + (va ? ia : 0)) + j0;
+                    const double* __restrict__ pb = rowptr(m0 + (vb ? ib : 0)) + j0;
+                    chol_double4_t acc;
+                    double* cp[4]; bool cv[4];
 #pragma unroll
-                    for(int k = 0; k < CHOL_PB; k++)
-                        if(k < c) v -= o[k]*lc[k];
-                    o[c] = v*rdiag[c];
-                }
-                else o[c] = 0.0;
-            }
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++) if(c < jb) ri[c] = o[c];
-        }
-        __syncthreads();
-
-        // (c) trailing update: M[i][c] -= sum_k L[i][k] L[c][k], k in the panel;
-        //     n >= i >= c >= m0, c < n. Thread (ty,tx) owns i = m0+ty+32a, c = m0+tx+32b
-        {
-            const int ty = t >> 5, tx = t & 31;
-            const int nrows = n + 1 - m0;       // rows m0..n
-            const int ncols = n - m0;           // cols m0..n-1
-            if(ncols > 0)
-            {
-                constexpr int NT = 4;
-                static_assert(NT*32 >= 128, "");
-                // (n - m0 can exceed 128 only for n > 144: then loop over super-tiles)
-                for(int a0 = 0; a0 < nrows; a0 += 32*NT)
-                    for(int b0 = 0; b0 <= a0 && b0 < ncols; b0 += 32*NT)
+                    for(int v = 0; v < 4; v++)
                     {
-                        const double* __restrict__ pi[NT];
-                        const double* __restrict__ pc[NT];
-                        bool vi[NT], vc[NT];
-#pragma unroll
-                        for(int a = 0; a < NT; a++)
-                        {
-                            const int ii = a0 + ty + 32*a;
-                            vi[a] = ii < nrows;
-                            pi[a] = rowptr(m0 + (vi[a] ? ii : 0)) + j0;
-                            const int cc = b0 + tx + 32*a;
-                            vc[a] = cc < ncols;
-                            pc[a] = rowptr(m0 + (vc[a] ? cc : 0)) + j0;
-                        }
-                        double acc[NT][NT];
-#pragma unroll
-                        for(int a = 0; a < NT; a++)
-#pragma unroll
-                            for(int b = 0; b < NT; b++) acc[a][b] = 0.0;
-#pragma unroll
-                        for(int kk = 0; kk < CHOL_PB; kk++)
-                        {
-                            if(kk < jb)
-                            {
-                                double li[NT], lc[NT];
-#pragma unroll
-                                for(int a = 0; a < NT; a++) { li[a] = pi[a][kk]; lc[a] = pc[a][kk]; }
-#pragma unroll
-                                for(int a = 0; a < NT; a++)
-#pragma unroll
-                                    for(int b = 0; b < NT; b++) acc[a][b] += li[a]*lc[b];
-                            }
-                        }
-#pragma unroll
-                        for(int a = 0; a < NT; a++)
-#pragma unroll
-                            for(int b = 0; b < NT; b++)
-                            {
-                                const int ii = a0 + ty + 32*a, cc = b0 + tx + 32*b;
-                                if(vi[a] && vc[b] && cc <= ii)
-                                    rowptr(m0 + ii)[m0 + cc] -= acc[a][b];
-                            }
+                        const int ri = 16*ta + kq + 4*v, cj = 16*tb + r16;
+                        cv[v] = (ri < nrows) && (cj < ncols) && (cj <= ri);
+                        cp[v] = rowptr(m0 + (cv[v] ? ri : 0)) + m0 + (cv[v] ? cj : 0);
+                        const double cval = *cp[v];
+                        acc[v] = cv[v] ? cval : 0.0;
                     }
+#pragma unroll
+                    for(int s4 = 0; s4 < 4; s4++)
+                    {
+                        const int  k  = 4*s4 + kq;
+                        const bool vk = k < jb;
+                        const double al = pa[k], bl = pb[k];     // k < 16: inside the row
+                        const double av = (va && vk) ? -al : 0.0;
+                        const double bv = (vb && vk) ?  bl : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for(int v = 0; v < 4; v++) if(cv[v]) *cp[v] = acc[v];
+                }
             }
         }
         __syncthreads();
@@ -645,49 +672,119 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
-        if(t < 64)
+        if(wave == 0)
         {
             // lane c holds z[c] and column c of the diagonal block
             double col[CHOL_PB];
-#pragma unroll
-            for(int k = 0; k < CHOL_PB; k++)
-                col[k] = (t < jb && k < jb && k >= t) ? rowptr(j0 + k)[j0 + t] : 0.0;
-            double zc = (t < jb) ? z[j0 + t] : 0.0;
-#pragma unroll
-            for(int k = CHOL_PB-1; k >= 0; k--)
             {
-                if(k < jb)
-                {
-                    if(t == k) zc = zc/col[k];
-                    const double dk = readlane_f64(zc, k);
-                    if(t < k) zc -= col[k]*dk;
-                }
+                double tmp[CHOL_PB];
+#pragma unroll
+                for(int k = 0; k < CHOL_PB; k++) tmp[k] = rowptr(j0 + ((k < jb) ? k : 0))[j0 + ((lane <= k) ? lane : 0)];
+#pragma unroll
+                for(int k = 0; k < CHOL_PB; k++) col[k] = (lane < jb && k < jb && k > lane) ? tmp[k] : 0.0;
             }
-            if(t < jb) z[j0 + t] = zc;
+            double zc = (lane < jb) ? z[j0 + lane] : 0.0;
+            const double myrd = (lane < jb) ? rdiag_all[p*CHOL_PB + lane] : 0.0;
+            auto step = [&](auto K)
+            {
+                constexpr int k = decltype(K)::value;
+                zc -= col[k]*row_share_f64<k>(zc*myrd);      // col[k] = 0 for k <= lane
+            };
+#define CHOL_STEP(k) step(std::integral_constant<int,(k)>{});
+            CHOL_STEP(15) CHOL_STEP(14) CHOL_STEP(13) CHOL_STEP(12) CHOL_STEP(11) CHOL_STEP(10) CHOL_STEP(9) CHOL_STEP(8)
+            CHOL_STEP(7)  CHOL_STEP(6)  CHOL_STEP(5)  CHOL_STEP(4)  CHOL_STEP(3)  CHOL_STEP(2)  CHOL_STEP(1) CHOL_STEP(0)
+#undef CHOL_STEP
+            if(lane < jb) z[j0 + lane] = zc*myrd;
         }
         __syncthreads();
         // z[i] -= sum_c L[j0+c][i] d[c],  i < j0
         for(int i = t; i < j0; i += nt)
         {
             double acc = 0.0;
-            for(int c = 0; c < jb; c++) acc += rowptr(j0+c)[i]*z[j0+c];
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c++) if(c < jb) acc += rowptr(j0+c)[i]*z[j0+c];
             z[i] -= acc;
         }
         __syncthreads();
     }
     // r <- -d ; keep the factor for later solves (uncertainty, solve_xt_JtJ_bt)
-    if(IN_LDS)
-    {
-        for(int i = t; i < n; i += nt) r[i] = -z[i];
-        if(keep_factor)
+    for(int i = t; i < n; i += nt) r[i] = -z[i];
+    if(keep_factor)
         for(int idx = t; idx < n*n; idx += nt)
         {
             const int i = idx / n, j = idx - i*n;
             if(j <= i) S[(size_t)i*n + j] = rowptr(i)[j];
         }
+}
+
+// The same in place in global memory, row-major, for camera blocks that do not
+// fit the LDS: plain right-looking blocked algorithm, one workgroup. Correct,
+// slow (large camera blocks = splined models: next-round item)
+__global__ __launch_bounds__(1024)
+void schur_cholesky_solve_global_kernel(int n, const int* __restrict__ skip,
+                                        double* __restrict__ S, double* __restrict__ r,
+                                        int* __restrict__ status)
+{
+    if(skip != NULL && *skip) return;
+    const int t  = threadIdx.x;
+    const int nt = blockDim.x;
+    auto at = [&](int i, int j) -> double& { return (i == n) ? r[j] : S[(size_t)i*n + j]; };
+    __shared__ int notpd;
+    if(t == 0) notpd = 0;
+    __syncthreads();
+    constexpr int PB = 8;
+    for(int j0 = 0; j0 < n; j0 += PB)
+    {
+        const int jb = min(PB, n - j0);
+        for(int jj = 0; jj < jb; jj++)
+        {
+            const int j = j0 + jj;
+            if(t == 0)
+            {
+                double d = at(j,j);
+                if(!(d > 0.0)) { notpd = 1; d = 1.0; }
+                at(j,j) = sqrt(d);
+            }
+            __syncthreads();
+            const double djj = at(j,j);
+            for(int i = j + 1 + t; i <= n; i += nt) at(i,j) /= djj;
+            __syncthreads();
+            const int ncols = jb - jj - 1;
+            for(int idx = t; idx < ncols*(n - j); idx += nt)
+            {
+                const int cc = idx % ncols, ii = idx / ncols;
+                const int c = j + 1 + cc, i = j + 1 + ii;
+                if(i >= c) at(i,c) -= at(i,j)*at(c,j);
+            }
+            __syncthreads();
+        }
+        const int m0 = j0 + jb;
+        const int nm = n - m0;
+        for(int idx = t; idx < (nm+1)*nm; idx += nt)
+        {
+            const int ii = idx / nm, cc = idx - ii*nm;
+            if(cc > ii) continue;
+            const int i = m0 + ii, c = m0 + cc;
+            double acc = 0.0;
+#pragma unroll
+            for(int kk = 0; kk < PB; kk++)
+                if(kk < jb) acc += at(i, j0+kk)*at(c, j0+kk);
+            at(i,c) -= acc;
+        }
+        __syncthreads();
     }
-    else
-        for(int i = t; i < n; i += nt) r[i] = -r[i];
+    if(t == 0 && notpd) atomicExch(status, 1);
+    // r = z. L^T d = z, column-oriented
+    __shared__ double piv;
+    for(int j=n-1;j>=0;j--)
+    {
+        if(t == 0) { piv = r[j]/at(j,j); r[j] = piv; }
+        __syncthreads();
+        const double pj = piv;
+        for(int i=t;i<j;i+=nt) r[i] -= at(j,i)*pj;
+        __syncthreads();
+    }
+    for(int i=t;i<n;i+=nt) r[i] = -r[i];
 }
 
 // d_e = -L^-T (y_e + Wt_e d_s);  also scatters d_s into the state-ordered step
@@ -1171,12 +1268,12 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
     {
         const int n = nd.Nc;
         const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
-        if(lds <= 160*1024 - 512)
-            hipLaunchKernelGGL((schur_cholesky_solve_kernel<true>), dim3(1), dim3(1024), lds, stream,
+        if(lds <= 160*1024 - 4096 && n <= 256)
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel, dim3(1), dim3(1024), lds, stream,
                                n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
         else
-            hipLaunchKernelGGL((schur_cholesky_solve_kernel<false>), dim3(1), dim3(1024), 0, stream,
-                               n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
+            hipLaunchKernelGGL(schur_cholesky_solve_global_kernel, dim3(1), dim3(1024), 0, stream,
+                               n, R.skip, F.S, F.r, F.status);
     }
     hipLaunchKernelGGL(backsub_kernel, dim3(br.count()+1), dim3(64), 0, stream,
                        nd, br, R, skip_also, F.Wt, F.LD, F.y, F.r);
