@@ -149,7 +149,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
                          if(meta[a].icam_intrinsics != meta[b].icam_intrinsics) return meta[a].icam_intrinsics < meta[b].icam_intrinsics;
                          return meta[a].icam_extrinsics < meta[b].icam_extrinsics;
                      });
-    const int CHUNK = 32;
+    const int CHUNK = 16;
     std::vector<int> chunk_begin;
     for(int i=0;i<Nobs;)
     {

@@ -53,76 +53,63 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
     }
 }
 
-// The assembly kernels walk the "compact" columns of a board observation: the
-// columns that exist in the state, in state order, then the residual. Compact
-// column j -> state index (-1 for the residual column)
-__device__ __forceinline__ int board_tile_col_to_state(const DeviceProblem& P, const BoardObsMeta& m, int j)
-{
-    if(j < P.Nintr_state) return m.i_state_intrinsics + j;
-    j -= P.Nintr_state;
-    if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0)
-    {
-        if(j < 6) return m.i_state_extrinsics + j;
-        j -= 6;
-    }
-    if(P.do_optimize_frames)
-    {
-        if(j < 6) return m.i_state_frame + j;
-        j -= 6;
-    }
-    if(P.has_warp_state)
-    {
-        if(j < 2) return P.i_state_warp + j;
-        j -= 2;
-    }
-    return -1;
-}
-// compact column j -> column of the board kernel's fixed tile layout (problem.hpp)
-__device__ __forceinline__ int board_compact_to_tile_col(const DeviceProblem& P, const BoardObsMeta& m, int j)
-{
-    if(j < P.Ncore_state) return j;
-    j -= P.Ncore_state;
-    if(j < P.Ndist_state) return 4 + j;
-    j -= P.Ndist_state;
-    if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0)
-    {
-        if(j < 6) return tile_ext0(P.Ndist) + j;
-        j -= 6;
-    }
-    if(P.do_optimize_frames)
-    {
-        if(j < 6) return tile_frame0(P.Ndist) + j;
-        j -= 6;
-    }
-    if(P.has_warp_state)
-    {
-        if(j < 2) return tile_warp0(P.Ndist) + j;
-        j -= 2;
-    }
-    return tile_xcol(P.Ndist);
-}
-__device__ __forceinline__ int board_tile_ncols(const DeviceProblem& P, const BoardObsMeta& m)
-{
-    return P.Nintr_state +
-        ((P.do_optimize_extrinsics && m.icam_extrinsics >= 0) ? 6 : 0) +
-        (P.do_optimize_frames ? 6 : 0) +
-        (P.has_warp_state ? 2 : 0) + 1;
-}
-// G[i][j] by compact columns
-__device__ __forceinline__ double board_gram(const DeviceProblem& P, const BoardObsMeta& m,
-                                             const double* __restrict__ G, int i, int j)
-{
-    return gram_get(G, tile_nblk(P.Ndist),
-                    board_compact_to_tile_col(P, m, i), board_compact_to_tile_col(P, m, j));
-}
-
 ////////////////////////////////////////////////////////////////////////////////
 // assembly from the per-observation Grams
 ////////////////////////////////////////////////////////////////////////////////
 
+// What a column of the board kernel's tile (problem.hpp) is, for one observation
+enum { COL_ABSENT = 0, COL_S, COL_FRAME, COL_X };
+struct TileColInfo { int kind; int idx; };   // COL_S: state index; COL_FRAME: 0..5
+__device__ __forceinline__
+TileColInfo board_tile_col_info(const DeviceProblem& P, const BoardObsMeta& m, int col)
+{
+    TileColInfo r = { COL_ABSENT, 0 };
+    const int nd = P.Ndist;
+    if(col < 4)
+    {
+        if(P.Ncore_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + col; }
+    }
+    else if(col < 4 + nd)
+    {
+        if(P.Ndist_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + P.Ncore_state + (col - 4); }
+    }
+    else if(col < tile_frame0(nd))
+    {
+        if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0) { r.kind = COL_S; r.idx = m.i_state_extrinsics + (col - tile_ext0(nd)); }
+    }
+    else if(col < tile_warp0(nd))
+    {
+        if(P.do_optimize_frames) { r.kind = COL_FRAME; r.idx = col - tile_frame0(nd); }
+    }
+    else if(col < tile_xcol(nd))
+    {
+        if(P.has_warp_state) { r.kind = COL_S; r.idx = P.i_state_warp + (col - tile_warp0(nd)); }
+    }
+    else if(col == tile_xcol(nd))
+        r.kind = COL_X;
+    return r;
+}
+// position pos = 64 m + lane of a stored Gram -> the entry (i,j) it holds.
+// diag: the entry is in a diagonal 4x4 block, where (i,j) and (j,i) are both
+// stored; elsewhere only one of them is. Returns false for the unused slots
+__device__ __forceinline__
+bool gram_pos_to_entry(int nblk, int pos, int* i, int* j, bool* diag)
+{
+    const int lane = pos & 63;
+    const int p    = 4*(pos >> 6) + ((lane >> 2) & 3);
+    if(p >= nblk*(nblk+1)/2) return false;
+    int bi, bj;
+    gram_pair_unrank(nblk, p, &bi, &bj);
+    *i = 4*bi + (lane >> 4);
+    *j = 4*bj + (lane & 3);
+    *diag = (bi == bj);
+    return true;
+}
+
 // One workgroup per frame. Its observations are contiguous (the API requires
-// frame-sorted observations, mrcal-pywrap.c:1063-1138). Accumulates, in
-// observation order and without atomics:
+// frame-sorted observations, mrcal-pywrap.c:1063-1138). The Grams are read
+// coalesced, position by position; the frame's rows of Bt, its D block and its
+// part of g are accumulated in LDS and written out whole:
 //   D_f  += G[frame,frame]      g_f += G[frame,x]     Bt[frame rows][S cols] += G[S,frame]
 __global__ __launch_bounds__(256)
 void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
@@ -130,49 +117,79 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
                             const double* __restrict__ gram)
 {
     if(opref_skip(R)) return;
-    double* __restrict__ Bt = opref_get(R).Bt;
-    double* __restrict__ D  = opref_get(R).D;
-    double* __restrict__ g  = opref_get(R).g;
+    extern __shared__ double lds_f[];          // Btf[6][Nc] | Df[36] | gf[6]
+    double* __restrict__ Btf = lds_f;
+    double* __restrict__ Df  = lds_f + 6*nd.Nc;
+    double* __restrict__ gf  = Df + 36;
     const int f = blockIdx.x;
     const int t = threadIdx.x;
     const int o0 = frame_obs_begin[f], o1 = frame_obs_begin[f+1];
-    if(o0 >= o1) return;
-    const int e0 = 6*f;   // frame blocks come first in E
+    if(o0 >= o1) return;                       // not this shard's frame: its rows stay zero
+    for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
+    __syncthreads();
 
-    for(int o = o0; o < o1; o++)
+    const int nblk = tile_nblk(P.Ndist);
+    const int npos = gram_stride(P.Ndist);
+    for(int pos = t; pos < npos; pos += blockDim.x)
     {
-        const BoardObsMeta m = P.board_meta[o];
-        const double* __restrict__ G = gram + (size_t)o*gram_stride(P.Ndist);
-        const int ncols = board_tile_ncols(P, m);
-        // tile column of the frame block
-        const int jf = P.Nintr_state + ((P.do_optimize_extrinsics && m.icam_extrinsics >= 0) ? 6 : 0);
-        // D and g: 36 + 6 entries
-        if(t < 36)
+        int i, j; bool diag;
+        if(!gram_pos_to_entry(nblk, pos, &i, &j, &diag)) continue;
+        // is a frame column involved at all? (same answer for every observation)
         {
-            const int a = t/6, c = t - 6*a;
-            D[(size_t)f*36 + t] += board_gram(P, m, G, jf+a, jf+c);
+            const int fr0 = tile_frame0(P.Ndist);
+            const bool fi = (i >= fr0 && i < fr0 + 6), fj = (j >= fr0 && j < fr0 + 6);
+            if(!P.do_optimize_frames || !(fi || fj)) continue;
         }
-        else if(t < 42)
+        // the observations of the frame, 8 Gram loads in flight at a time
+        for(int ob = o0; ob < o1; ob += 8)
         {
-            const int a = t - 36;
-            g[nd.Nie + e0 + a] += board_gram(P, m, G, jf+a, ncols-1);
+            double vv[8];
+#pragma unroll
+            for(int u = 0; u < 8; u++)
+                vv[u] = (ob + u < o1) ? gram[(size_t)(ob + u)*npos + pos] : 0.0;
+#pragma unroll
+            for(int u = 0; u < 8; u++)
+            {
+            const int o = ob + u;
+            if(o >= o1) break;
+            const BoardObsMeta m = P.board_meta[o];
+            const TileColInfo ci = board_tile_col_info(P, m, i), cj = board_tile_col_info(P, m, j);
+            const double v = vv[u];
+            if(ci.kind == COL_FRAME && cj.kind == COL_FRAME)
+            {
+                atomicAdd(&Df[ci.idx*6 + cj.idx], v);
+                if(!diag) atomicAdd(&Df[cj.idx*6 + ci.idx], v);
+            }
+            else if(ci.kind == COL_FRAME)
+            {
+                // (frame, S) or (frame, x). In a diagonal block the mirrored
+                // position carries the same product: take it there only
+                if(diag) continue;
+                if(cj.kind == COL_S)      atomicAdd(&Btf[ci.idx*nd.Nc + state_to_SE(nd, cj.idx)], v);
+                else if(cj.kind == COL_X) atomicAdd(&gf[ci.idx], v);
+            }
+            else
+            {
+                if(ci.kind == COL_S)      atomicAdd(&Btf[cj.idx*nd.Nc + state_to_SE(nd, ci.idx)], v);
+                else if(ci.kind == COL_X) atomicAdd(&gf[cj.idx], v);
+            }
+            }
         }
-        // Bt: (ncols-1-6) S columns x 6
-        const int nS = ncols - 1 - 6;
-        for(int idx = t; idx < nS*6; idx += blockDim.x)
-        {
-            const int js = idx/6, a = idx - 6*js;
-            const int j  = (js < jf) ? js : js + 6;   // skip the frame columns
-            const int s  = state_to_SE(nd, board_tile_col_to_state(P, m, j));
-            Bt[(size_t)(e0 + a)*nd.Nc + s] += board_gram(P, m, G, j, jf+a);
-        }
-        __syncthreads(); // two observations of a frame may share S columns (the warp always)
     }
+    __syncthreads();
+    double* __restrict__ Bt = opref_get(R).Bt;
+    double* __restrict__ D  = opref_get(R).D;
+    double* __restrict__ g  = opref_get(R).g;
+    const int e0 = 6*f;   // frame blocks come first in E
+    for(int i = t; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] += Btf[i];
+    if(t < 36)      D[(size_t)f*36 + t]     += Df[t];
+    else if(t < 42) g[nd.Nie + e0 + (t-36)] += gf[t-36];
 }
 
 // S-S part: observations that see the same (intrinsics, extrinsics) pair
-// scatter to the same entries of A, so they are summed per pair first. One
-// workgroup per chunk of one pair's observation list
+// scatter to the same entries of A, so they are summed per pair first: one
+// workgroup per chunk of one pair's observation list, each thread summing its
+// Gram positions over the chunk (coalesced reads), then a few atomics
 __global__ __launch_bounds__(256)
 void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R,
                          const int* __restrict__ chunk_begin,  // [Nchunks+1] into pair_obs
@@ -186,36 +203,38 @@ void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R,
     const int c0 = chunk_begin[blockIdx.x], c1 = chunk_begin[blockIdx.x+1];
     if(c0 >= c1) return;
     const BoardObsMeta m0 = P.board_meta[pair_obs[c0]];
-    const int ncols = board_tile_ncols(P, m0);
-    const int jf    = P.Nintr_state + ((P.do_optimize_extrinsics && m0.icam_extrinsics >= 0) ? 6 : 0);
-    const int nfr   = P.do_optimize_frames ? 6 : 0;
-    const int nS1   = ncols - nfr;     // S columns + the residual column
-    // upper triangle incl. the residual column: entries (i<=j)
-    const int nent  = nS1*(nS1+1)/2;
-    for(int idx = threadIdx.x; idx < nent; idx += blockDim.x)
+    const int nblk = tile_nblk(P.Ndist);
+    const int npos = gram_stride(P.Ndist);
+    for(int pos = threadIdx.x; pos < npos; pos += blockDim.x)
     {
-        // unrank idx -> (i<=j) over an nS1 x nS1 upper triangle, row-major
-        int i = 0, rem = idx;
-        while(rem >= nS1 - i) { rem -= nS1 - i; i++; }
-        const int j  = i + rem;
-        const int ti = (i < jf) ? i : i + nfr;
-        const int tj = (j < jf) ? j : j + nfr;
+        int i, j; bool diag;
+        if(!gram_pos_to_entry(nblk, pos, &i, &j, &diag)) continue;
+        const TileColInfo ci = board_tile_col_info(P, m0, i), cj = board_tile_col_info(P, m0, j);
+        const bool si = (ci.kind == COL_S), sj = (cj.kind == COL_S);
+        const bool xi = (ci.kind == COL_X), xj = (cj.kind == COL_X);
+        if(!((si || xi) && (sj || xj))) continue;
+        if(diag && xi && sj) continue;          // the mirrored position takes it
+        // 8 loads in flight at a time
         double acc = 0.0;
-        for(int c = c0; c < c1; c++)
-            acc += board_gram(P, m0, gram + (size_t)pair_obs[c]*gram_stride(P.Ndist), ti, tj);
-
-        const int si = board_tile_col_to_state(P, m0, ti);
-        const int sj = board_tile_col_to_state(P, m0, tj);
-        if(sj < 0)
+        for(int cb = c0; cb < c1; cb += 8)
         {
-            if(si < 0) atomicAdd(norm2_x, acc);
-            else       atomicAdd(&g[si], acc);
+            int    oi[8];
+            double vv[8];
+#pragma unroll
+            for(int u = 0; u < 8; u++) oi[u] = pair_obs[(cb + u < c1) ? cb + u : c0];
+#pragma unroll
+            for(int u = 0; u < 8; u++) vv[u] = gram[(size_t)oi[u]*npos + pos];
+#pragma unroll
+            for(int u = 0; u < 8; u++) acc += (cb + u < c1) ? vv[u] : 0.0;
         }
+        if(xi && xj)      atomicAdd(norm2_x, acc);
+        else if(xj)       atomicAdd(&g[ci.idx], acc);
+        else if(xi)       atomicAdd(&g[cj.idx], acc);
         else
         {
-            const int a = state_to_SE(nd, si), bb = state_to_SE(nd, sj);
+            const int a = state_to_SE(nd, ci.idx), bb = state_to_SE(nd, cj.idx);
             atomicAdd(&A[(size_t)a*nd.Nc + bb], acc);
-            if(a != bb) atomicAdd(&A[(size_t)bb*nd.Nc + a], acc);
+            if(!diag) atomicAdd(&A[(size_t)bb*nd.Nc + a], acc);
         }
     }
 }
@@ -1211,7 +1230,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
     if(P.Nobs_board > 0)
     {
         if(P.do_optimize_frames)
-            hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), 0, stream,
+            hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), (6*nd.Nc + 42)*sizeof(double), stream,
                                P, nd, B.R, plan.frame_obs_begin, B.gram);
         hipLaunchKernelGGL(reduce_pairs_kernel, dim3(plan.Nchunks), dim3(256), 0, stream,
                            P, nd, B.R, plan.chunk_begin, plan.pair_obs, B.gram);
