@@ -648,11 +648,13 @@ void board_structure_kernel(DeviceProblem P, int32_t* __restrict__ rowptr, int32
         else
         {
             if(P.Ncore_state) c -= 2;
-            if(c < P.Ndist_state)
+            // splined models: the (order+1)^2 patch columns are data dependent
+            // and rewritten by every evaluation; this is a placeholder
+            if(c < P.Ndist_row)
                 col = m.i_state_intrinsics + P.Ncore_state + c;
             else
             {
-                c -= P.Ndist_state;
+                c -= P.Ndist_row;
                 if(has_ext && c < 6)
                     col = m.i_state_extrinsics + c;
                 else
@@ -897,6 +899,387 @@ void regularization_kernel(DeviceProblem P,
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// 5. SPLINED_STEREOGRAPHIC: its own kernels
+////////////////////////////////////////////////////////////////////////////////
+// The intrinsics columns of a row are the (order+1)^2 control points of one of
+// the two spline surfaces around the projected point: WHICH state variables a
+// row touches depends on the data, so colidx is rewritten by every evaluation
+// and the per-observation Gram of the parametric models does not apply (the
+// normal equations of these problems are assembled row by row,
+// solver_kernels.hip). One lane per chessboard corner, rows written directly.
+// Straightforward rather than fast: splined solves are a next-round item.
+// Reference: mrcal.c:2075-2293 (projection), 4734-4760 (row layout)
+template<bool WITH_J>
+__global__ __launch_bounds__(64)
+void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ joint,
+                          int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    double* __restrict__ x  = opref_get(R).x;
+    double* __restrict__ Jv = opref_get(R).Jv;
+    const int NPTS = P.W*P.H;
+    const int gi   = blockIdx.x*blockDim.x + threadIdx.x;
+    if(gi >= P.Nobs_board*NPTS) return;
+    const int iobs = gi / NPTS;
+    const int pt   = gi - iobs*NPTS;
+    const BoardObsMeta m = P.board_meta[iobs];
+    const double* __restrict__ jp   = joint + (size_t)iobs*JOINT_STRIDE;
+    const double* __restrict__ intr = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
+    const double* __restrict__ wp   = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
+    const int  k       = m.nnz_per_row;
+    const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
+
+    const int iy = pt / P.W;
+    const int ix = pt - iy*P.W;
+    const double bx = (double)ix * P.spacing;
+    const double by = (double)iy * P.spacing;
+    double bz = 0.0, dz_dw[2] = {0.0, 0.0};
+    if(P.has_warp_seed)
+    {
+        const double xr = (double)ix / (double)(P.W - 1);
+        const double yr = (double)iy / (double)(P.H - 1);
+        dz_dw[0] = 4.0*xr*(1.0 - xr);
+        dz_dw[1] = 4.0*yr*(1.0 - yr);
+        bz += wp[0]*dz_dw[0];
+        bz += wp[1]*dz_dw[1];
+    }
+    double p[3];
+    for(int i=0;i<3;i++)
+        p[i] = jp[JOINT_R+3*i+0]*bx + jp[JOINT_R+3*i+1]*by + jp[JOINT_R+3*i+2]*bz + jp[JOINT_T+i];
+
+    double q[2], dq_dp[2][3], dq_dfxy[2], cfx[4], cfy[4];
+    int ivar0;
+    project_splined<WITH_J>(q, dq_dp, dq_dfxy, &ivar0, cfx, cfy, p, intr, P.cfg);
+
+    const double* __restrict__ obs = P.board_pool + ((size_t)iobs*NPTS + pt)*3;
+    const double w = obs[2];
+    const bool inlier = (w >= 0.0);
+    x[m.i_meas0 + 2*pt + 0] = inlier ? (q[0] - obs[0])*w : 0.0;
+    x[m.i_meas0 + 2*pt + 1] = inlier ? (q[1] - obs[1])*w : 0.0;
+    if(!WITH_J) return;
+
+    const double ww = inlier ? w : 0.0;     // outliers: same columns, zero values
+    const int n = P.cfg.spline_order + 1;
+    for(int xy=0;xy<2;xy++)
+    {
+        double*  __restrict__ row = Jv     + m.i_nnz0 + (size_t)(2*pt + xy)*k;
+        int32_t* __restrict__ ci  = colidx + m.i_nnz0 + (size_t)(2*pt + xy)*k;
+        int c = 0;
+        if(P.Ncore_state)
+        {
+            row[c++] = inlier ? dq_dfxy[xy] * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
+            row[c++] = ww * SCALE_INTRINSICS_CENTER_PIXEL;
+        }
+        if(P.Ndist_state)
+        {
+            const int col0 = m.i_state_intrinsics + P.Ncore_state + (ivar0 - 4);
+            for(int jy=0;jy<n;jy++)
+                for(int jx=0;jx<n;jx++)
+                {
+                    ci[c]    = col0 + jy*2*P.cfg.spline_Nx + jx*2 + xy;
+                    row[c++] = inlier ? cfx[jx]*cfy[jy]*intr[xy] * w * SCALE_DISTORTION : 0.0;
+                }
+        }
+        if(has_ext)
+        {
+            for(int l=0;l<3;l++)
+            {
+                double dp[3];
+                for(int i=0;i<3;i++)
+                    dp[i] =
+                        bx*jp[JOINT_MC + 0  + 3*i + l] +
+                        by*jp[JOINT_MC + 9  + 3*i + l] +
+                        bz*jp[JOINT_MC + 18 + 3*i + l] +
+                        jp[JOINT_DTJ_DRC + 3*i + l];
+                const double g = dq_dp[xy][0]*dp[0] + dq_dp[xy][1]*dp[1] + dq_dp[xy][2]*dp[2];
+                row[c+l]   = inlier ? g * w * SCALE_ROTATION_CAMERA : 0.0;
+                row[c+3+l] = inlier ? dq_dp[xy][l] * w * SCALE_TRANSLATION_CAMERA : 0.0;
+            }
+            c += 6;
+        }
+        if(P.do_optimize_frames)
+        {
+            for(int l=0;l<3;l++)
+            {
+                double dpr[3], dpt[3];
+                for(int i=0;i<3;i++)
+                {
+                    dpr[i] =
+                        bx*jp[JOINT_MF + 0  + 3*i + l] +
+                        by*jp[JOINT_MF + 9  + 3*i + l] +
+                        bz*jp[JOINT_MF + 18 + 3*i + l];
+                    dpt[i] = jp[JOINT_DTJ_DTF + 3*i + l];
+                }
+                const double gr = dq_dp[xy][0]*dpr[0] + dq_dp[xy][1]*dpr[1] + dq_dp[xy][2]*dpr[2];
+                const double gt = dq_dp[xy][0]*dpt[0] + dq_dp[xy][1]*dpt[1] + dq_dp[xy][2]*dpt[2];
+                row[c+l]   = inlier ? gr * w * SCALE_ROTATION_FRAME    : 0.0;
+                row[c+3+l] = inlier ? gt * w * SCALE_TRANSLATION_FRAME : 0.0;
+            }
+            c += 6;
+        }
+        if(P.has_warp_state)
+        {
+            const double d =
+                dq_dp[xy][0]*jp[JOINT_R + 2] +
+                dq_dp[xy][1]*jp[JOINT_R + 5] +
+                dq_dp[xy][2]*jp[JOINT_R + 8];
+            row[c+0] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[0]) : 0.0;
+            row[c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
+        }
+    }
+}
+
+// discrete points, splined model: one lane per observation (2 rows)
+template<bool WITH_J>
+__global__ __launch_bounds__(64)
+void point_splined_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    const double* __restrict__ b  = opref_get(R).b;
+    double*       __restrict__ x  = opref_get(R).x;
+    double*       __restrict__ Jv = opref_get(R).Jv;
+    const int iobs = blockIdx.x*blockDim.x + threadIdx.x;
+    if(iobs >= P.Nobs_point) return;
+    const PointObsMeta m = P.point_meta[iobs];
+    const int k = m.nnz_per_row;
+    const int n = P.cfg.spline_order + 1;
+    const double* obs = P.point_pool + (size_t)iobs*3;
+    const double  w   = obs[2];
+    const bool inlier = !(w <= 0.0);      // <= here, < for boards (mrcal.c:4918 vs :4706)
+    const bool at_ref = (m.icam_extrinsics < 0);
+    const bool has_ext = P.do_optimize_extrinsics && !at_ref;
+
+    if(!inlier)
+    {
+        x[m.i_meas0+0] = 0.0;
+        x[m.i_meas0+1] = 0.0;
+        if(WITH_J)
+            for(int xy=0;xy<2;xy++)
+            {
+                // "it doesn't matter which points I say I depend on": the first
+                // (order+1)^2 control points (mrcal.c:4960-4972)
+                double*  row = Jv     + m.i_nnz0 + xy*k;
+                int32_t* ci  = colidx + m.i_nnz0 + xy*k;
+                for(int c=0;c<k;c++) row[c] = 0.0;
+                if(P.Ndist_state)
+                {
+                    const int c0 = P.Ncore_state ? 2 : 0;
+                    for(int i=0;i<n*n;i++) ci[c0+i] = m.i_state_intrinsics + P.Ncore_state + i;
+                }
+            }
+        return;
+    }
+
+    const double* __restrict__ intr = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
+    double pref[3];
+    if(m.i_state_point >= 0)
+        for(int i=0;i<3;i++) pref[i] = b[m.i_state_point + i] * SCALE_POSITION_POINT;
+    else
+        for(int i=0;i<3;i++) pref[i] = P.seed_points[3*m.i_point + i];
+
+    double p[3], dp_drc[3][3], dp_dpt[3][3];
+    if(at_ref)
+    {
+        for(int i=0;i<3;i++) p[i] = pref[i];
+        for(int i=0;i<3;i++) for(int l=0;l<3;l++) { dp_drc[i][l] = 0.0; dp_dpt[i][l] = (i==l) ? 1.0 : 0.0; }
+    }
+    else
+    {
+        double rt_cam[6];
+        get_rt_cam_ref(rt_cam, P, b, m.icam_extrinsics);
+        Dual<6> rc[3], xx[3], y[3];
+        for(int i=0;i<3;i++)
+        {
+            rc[i] = Dual<6>::variable(rt_cam[i], i);
+            xx[i] = Dual<6>::variable(pref[i],   3+i);
+        }
+        rotate_point_r_dual<6>(y, rc, xx, false);
+        for(int i=0;i<3;i++)
+        {
+            p[i] = y[i].x + rt_cam[3+i];
+            for(int l=0;l<3;l++) { dp_drc[i][l] = y[i].d[l]; dp_dpt[i][l] = y[i].d[3+l]; }
+        }
+    }
+    double q[2], dq_dp[2][3], dq_dfxy[2], cfx[4], cfy[4];
+    int ivar0;
+    project_splined<WITH_J>(q, dq_dp, dq_dfxy, &ivar0, cfx, cfy, p, intr, P.cfg);
+    x[m.i_meas0+0] = (q[0] - obs[0])*w;
+    x[m.i_meas0+1] = (q[1] - obs[1])*w;
+    if(!WITH_J) return;
+    for(int xy=0;xy<2;xy++)
+    {
+        double*  row = Jv     + m.i_nnz0 + xy*k;
+        int32_t* ci  = colidx + m.i_nnz0 + xy*k;
+        int c = 0;
+        if(P.Ncore_state)
+        {
+            row[c++] = dq_dfxy[xy] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
+            row[c++] = w * SCALE_INTRINSICS_CENTER_PIXEL;
+        }
+        if(P.Ndist_state)
+        {
+            const int col0 = m.i_state_intrinsics + P.Ncore_state + (ivar0 - 4);
+            for(int jy=0;jy<n;jy++)
+                for(int jx=0;jx<n;jx++)
+                {
+                    ci[c]    = col0 + jy*2*P.cfg.spline_Nx + jx*2 + xy;
+                    row[c++] = cfx[jx]*cfy[jy]*intr[xy] * w * SCALE_DISTORTION;
+                }
+        }
+        if(has_ext)
+        {
+            for(int l=0;l<3;l++)
+            {
+                const double g = dq_dp[xy][0]*dp_drc[0][l] + dq_dp[xy][1]*dp_drc[1][l] + dq_dp[xy][2]*dp_drc[2][l];
+                row[c+l]   = g * w * SCALE_ROTATION_CAMERA;
+                row[c+3+l] = dq_dp[xy][l] * w * SCALE_TRANSLATION_CAMERA;
+            }
+            c += 6;
+        }
+        if(m.i_state_point >= 0)
+            for(int l=0;l<3;l++)
+            {
+                const double g = dq_dp[xy][0]*dp_dpt[0][l] + dq_dp[xy][1]*dp_dpt[1][l] + dq_dp[xy][2]*dp_dpt[2][l];
+                row[c+l] = g * w * SCALE_POSITION_POINT;
+            }
+    }
+}
+
+// Regularization rows of a splined model, in order: per camera and knot
+// (iy-major) a radial and a tangential row, 2 nonzeros each; then the centre
+// pixel rows (1 nonzero), then unity_cam01 (3). Reference: mrcal.c:5717-5785,
+// 5854-5954. One lane per row
+template<bool WITH_J, bool WITH_STRUCTURE>
+__global__ __launch_bounds__(64)
+void regularization_splined_kernel(DeviceProblem P, OpRef R,
+                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    const double* __restrict__ b  = opref_get(R).b;
+    double*       __restrict__ x  = opref_get(R).x;
+    double*       __restrict__ Jv = opref_get(R).Jv;
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int Nx = P.cfg.spline_Nx, Ny = P.cfg.spline_Ny;
+    const int Nknot_rows   = (P.do_apply_regularization && P.Ndist_state) ? P.Ncameras_intrinsics*Nx*Ny*2 : 0;
+    const int Ncenter_rows = (P.do_apply_regularization && P.Ncore_state) ? P.Ncameras_intrinsics*2 : 0;
+    const int Nrows        = Nknot_rows + Ncenter_rows + (P.has_unity_cam01 ? 1 : 0);
+    const int64_t nnz_knots = (int64_t)2*Nknot_rows;
+    if(i == 0 && WITH_STRUCTURE)
+        rowptr[P.i_meas_regularization + Nrows] =
+            (int32_t)(P.i_nnz_regularization + nnz_knots + Ncenter_rows + (P.has_unity_cam01 ? 3 : 0));
+    if(i >= Nrows) return;
+    const double nominal_pixel_error = 0.1;
+    const int imeas = P.i_meas_regularization + i;
+
+    if(i < Nknot_rows)
+    {
+        const int64_t innz = P.i_nnz_regularization + (int64_t)2*i;
+        if(WITH_STRUCTURE) rowptr[imeas] = (int32_t)innz;
+        const int tangential = i & 1;
+        const int iknot = i >> 1;
+        const int icam  = iknot / (Nx*Ny);
+        const int kk    = iknot - icam*Nx*Ny;
+        const int iy = kk / Nx, ix = kk - iy*Nx;
+        const double scale = nominal_pixel_error / 10.0;
+        // direction from the centre of the knot grid to this knot
+        double ux = (double)(2*ix - Nx + 1), uy = (double)(2*iy - Ny + 1);
+        bool anisotropic = true;
+        if(2*ix == Nx - 1 && 2*iy == Ny - 1) { ux = 1.0; anisotropic = false; }
+        else
+        {
+            const double mag = sqrt(ux*ux + uy*uy);
+            ux /= mag; uy /= mag;
+        }
+        const int ivar = 2*kk;
+        const double d0 = get_intrinsic(P, b, icam, P.Ncore + ivar + 0);
+        const double d1 = get_intrinsic(P, b, icam, P.Ncore + ivar + 1);
+        const int col = P.i_state_intrinsics + icam*P.Nintr_state + P.Ncore_state + ivar;
+        if(!tangential)
+        {
+            x[imeas] = scale*(d0*ux + d1*uy);
+            if(WITH_J) { Jv[innz] = scale*ux*SCALE_DISTORTION; Jv[innz+1] = scale*uy*SCALE_DISTORTION; }
+        }
+        else
+        {
+            const double se = scale*(anisotropic ? 10. : 1.);
+            x[imeas] = se*(d0*uy - d1*ux);
+            if(WITH_J) { Jv[innz] = se*uy*SCALE_DISTORTION; Jv[innz+1] = -se*ux*SCALE_DISTORTION; }
+        }
+        if(WITH_STRUCTURE) { colidx[innz] = col; colidx[innz+1] = col+1; }
+        return;
+    }
+    if(i < Nknot_rows + Ncenter_rows)
+    {
+        const int ii = i - Nknot_rows;
+        const int64_t innz = P.i_nnz_regularization + nnz_knots + ii;
+        if(WITH_STRUCTURE) rowptr[imeas] = (int32_t)innz;
+        const int icam = ii >> 1, xy = ii & 1;
+        const double scale  = nominal_pixel_error / (P.imager_width_cam0 * 0.1);
+        const double target = 0.5 * (double)(P.imagersizes[2*icam + xy] - 1);
+        x[imeas] = scale * (get_intrinsic(P, b, icam, 2+xy) - target);
+        if(WITH_J)         Jv[innz]     = scale * SCALE_INTRINSICS_CENTER_PIXEL;
+        if(WITH_STRUCTURE) colidx[innz] = P.i_state_intrinsics + icam*P.Nintr_state + 2 + xy;
+        return;
+    }
+    {
+        const int64_t innz = P.i_nnz_regularization + nnz_knots + Ncenter_rows;
+        if(WITH_STRUCTURE) rowptr[imeas] = (int32_t)innz;
+        const double scale = nominal_pixel_error / (1.0 * 0.01);
+        double rt[6];
+        get_rt_cam_ref(rt, P, b, 0);
+        x[imeas] = scale * (rt[3]*rt[3] + rt[4]*rt[4] + rt[5]*rt[5] - 1.0);
+        for(int l=0;l<3;l++)
+        {
+            if(WITH_J)         Jv[innz+l]     = scale * SCALE_TRANSLATION_CAMERA * 2.0 * rt[3+l];
+            if(WITH_STRUCTURE) colidx[innz+l] = P.i_state_extrinsics + 3 + l;
+        }
+    }
+}
+
+static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
+                                hipStream_t stream, hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
+{
+    if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
+    {
+        const int nblocks_obs    = (P.Nobs_board + 63)/64;
+        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack), dim3(64), 0, stream,
+                           P, B.R, B.joint);
+    }
+    if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
+    {
+        if(ev_j0) hipEventRecord(ev_j0, stream);
+        const int n = P.Nobs_board*P.W*P.H;
+        if(with_jacobian)
+            hipLaunchKernelGGL((board_splined_kernel<true>),  dim3((n+63)/64), dim3(64), 0, stream, P, B.R, B.joint, B.Ji);
+        else
+            hipLaunchKernelGGL((board_splined_kernel<false>), dim3((n+63)/64), dim3(64), 0, stream, P, B.R, B.joint, B.Ji);
+        if(ev_j1) hipEventRecord(ev_j1, stream);
+    }
+    if(!(parts & EVAL_PART_REST)) return;
+    if(P.Nobs_point > 0)
+    {
+        if(P.Nobs_board <= 0)   // the unpacked intrinsics are the prologue kernel's job
+            hipLaunchKernelGGL(board_prologue_kernel, dim3((P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64), dim3(64), 0, stream,
+                               P, B.R, B.joint);
+        if(with_jacobian)
+            hipLaunchKernelGGL((point_splined_kernel<true>),  dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
+        else
+            hipLaunchKernelGGL((point_splined_kernel<false>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
+    }
+    const int Nreg = P.Nmeas - P.i_meas_regularization;
+    if(Nreg > 0)
+    {
+        if(with_jacobian)
+            hipLaunchKernelGGL((regularization_splined_kernel<true,false>),  dim3((Nreg + 63)/64), dim3(64), 0, stream,
+                               P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+        else
+            hipLaunchKernelGGL((regularization_splined_kernel<false,false>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
+                               P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+    }
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
 template<int PROJ, int NDIST>
@@ -961,6 +1344,7 @@ bool lens_supported(int lens_type)
     case MRCAL_LENSMODEL_OPENCV12:
     case MRCAL_LENSMODEL_CAHVOR:
     case MRCAL_LENSMODEL_CAHVORE:
+    case MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC:
         return true;
     default:
         return false;
@@ -983,6 +1367,7 @@ hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool wi
     case MRCAL_LENSMODEL_OPENCV12:      launch_eval_t<PROJ_OPENCV,        12>(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
     case MRCAL_LENSMODEL_CAHVOR:        launch_eval_t<PROJ_CAHVOR,        5 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
     case MRCAL_LENSMODEL_CAHVORE:       launch_eval_t<PROJ_CAHVORE,       8 >(P,B,with_jacobian,lds_bytes,stream,ev_j0,ev_j1,parts); break;
+    case MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC: launch_eval_splined(P,B,with_jacobian,stream,ev_j0,ev_j1,parts); break;
     default:
         return hipErrorInvalidValue;
     }
@@ -1001,8 +1386,14 @@ hipError_t launch_structure(const DeviceProblem& P, const EvalBuffers& B, hipStr
     // also writes the terminating rowptr[Nmeas] when there are regularization
     // rows; the host writes it otherwise
     if(Nreg > 0)
-        hipLaunchKernelGGL((regularization_kernel<false,true>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
-                           P, B.R, B.Jp, B.Ji);
+    {
+        if(P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+            hipLaunchKernelGGL((regularization_splined_kernel<false,true>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
+                               P, B.R, B.Jp, B.Ji);
+        else
+            hipLaunchKernelGGL((regularization_kernel<false,true>), dim3((Nreg + 63)/64), dim3(64), 0, stream,
+                               P, B.R, B.Jp, B.Ji);
+    }
     return hipGetLastError();
 }
 

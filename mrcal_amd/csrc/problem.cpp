@@ -87,7 +87,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->op[1].b,  (size_t)L.Nstate);
     ok = ok && dev_alloc(&P->op[1].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc(&P->op[1].Jv, (size_t)P->Nnz);
-    ok = ok && dev_alloc(&P->d_gram,   (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
+    ok = ok && dev_alloc(&P->d_gram,   (L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) ? (size_t)1 : (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
     for(int i=0;i<2 && ok;i++)
     {
         ok = ok && dev_alloc(&P->op[i].A,       (size_t)nd.Nc*nd.Nc);
@@ -374,7 +374,14 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     }
     const int64_t innz_reg = innz;
     if(L.Nmeas_regularization > 0)
-        innz += (int64_t)Ncameras_intrinsics*L.Nreg_percamera + (L.has_unity_cam01 ? 3 : 0);
+    {
+        // one nonzero per row, except the splined models' knot rows, which have 2 (mrcal.c:847-869)
+        if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+            innz += (int64_t)Ncameras_intrinsics*(L.Nreg_percamera + (sel.do_apply_regularization ? L.Ndist_state : 0));
+        else
+            innz += (int64_t)Ncameras_intrinsics*L.Nreg_percamera;
+        innz += (L.has_unity_cam01 ? 3 : 0);
+    }
     P->Nnz = innz;
     if(innz > 0x7fffffffLL)
     {
@@ -384,8 +391,10 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         return NULL;
     }
     // tile columns: k, +2 for the full core, +1 for the residual column (see board_kernel)
-    // LDS of the board kernel: the 64-row tile + the observation's pixels and weights
-    P->lds_bytes = (64*tile_stride(L.Ndist) + 3*NPTS) * (int)sizeof(double);
+    // LDS of the board kernel: the 64-row tile + the observation's pixels and
+    // weights (the splined models' kernels use none)
+    const bool splined = (lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
+    P->lds_bytes = splined ? 0 : (64*tile_stride(L.Ndist) + 3*NPTS) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
         set_error("the board has %d corners and the lens model %d distortion parameters: the LDS tile would not fit", NPTS, L.Ndist);
@@ -458,6 +467,7 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.lens_type   = (int)lensmodel->type;
     D.Nintrinsics = L.Nintrinsics;   D.Ncore = L.Ncore;        D.Ncore_state = L.Ncore_state;
     D.Ndist       = L.Ndist;         D.Ndist_state = L.Ndist_state; D.Nintr_state = L.Nintr_state;
+    D.Ndist_row   = L.Nintr_per_row - (L.Ncore_state ? 2 : 0);
     D.i_state_intrinsics = L.i_state_intrinsics < 0 ? 0 : L.i_state_intrinsics;
     D.i_state_extrinsics = L.i_state_extrinsics;
     D.i_state_frames     = L.i_state_frames;

@@ -141,6 +141,7 @@ struct DeviceProblem
     // layout
     int lens_type;
     int Nintrinsics, Ncore, Ncore_state, Ndist, Ndist_state, Nintr_state;
+    int Ndist_row;       // distortion columns in one board/point row: Ndist_state, or (order+1)^2 for splined models
     int i_state_intrinsics, i_state_extrinsics, i_state_frames, i_state_points, i_state_warp;
     int Nstate, Nmeas;
     int do_optimize_extrinsics, do_optimize_frames;

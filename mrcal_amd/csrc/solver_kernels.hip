@@ -1227,7 +1227,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
         int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
         hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, B.R);
     }
-    if(P.Nobs_board > 0)
+    // splined models: no per-observation Gram; every row goes through the generic path
+    const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
+    if(P.Nobs_board > 0 && !by_rows)
     {
         if(P.do_optimize_frames)
             hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), (6*nd.Nc + 42)*sizeof(double), stream,
@@ -1235,7 +1237,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
         hipLaunchKernelGGL(reduce_pairs_kernel, dim3(plan.Nchunks), dim3(256), 0, stream,
                            P, nd, B.R, plan.chunk_begin, plan.pair_obs, B.gram);
     }
-    const int row0 = 2*P.W*P.H*P.Nobs_board;
+    const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nmeas > row0)
         hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - row0 + 63)/64), dim3(64), 0, stream,
                            nd, B.R, row0, P.Nmeas, B.Jp, B.Ji);

@@ -50,9 +50,35 @@ def R_from_r(r):
     return np.eye(3) + a*K + b*(K @ K)
 
 
-def intrinsics_for(lensmodel, Ncameras):
-    """Truth intrinsics for a parametric lens model, cut down from the OPENCV8
-    fixture cameras as test-basic-calibration.py:38-41 does for OPENCV4"""
+def intrinsics_for(lensmodel, Ncameras, seed=0):
+    """Truth intrinsics for a lens model. The OPENCV family is cut down from
+    the OPENCV8 fixture cameras as test-basic-calibration.py:38-41 does for
+    OPENCV4; CAHVOR(E) and the splined models get small made-up distortions on
+    the same cores"""
+    import re
+    rng = np.random.RandomState(1000 + seed)
+    m = re.match(r"LENSMODEL_SPLINED_STEREOGRAPHIC_order=(\d+)_Nx=(\d+)_Ny=(\d+)_fov_x_deg=(\d+)", lensmodel)
+    if m:
+        Nx, Ny = int(m.group(2)), int(m.group(3))
+        out = np.zeros((Ncameras, 4 + 2*Nx*Ny))
+        for i in range(Ncameras):
+            out[i,:4] = CAM_OPENCV8[i % 2][:4]
+            # stereographic: q = 2 tan(th/2) f + c; keep the board inside the imager
+            out[i,:2] *= 0.9
+            out[i,4:] = rng.uniform(-0.01, 0.01, 2*Nx*Ny)
+        return out
+    if lensmodel.startswith("LENSMODEL_CAHVORE"):
+        out = np.zeros((Ncameras, 12))
+        for i in range(Ncameras):
+            out[i,:4] = CAM_OPENCV8[i % 2][:4]
+            out[i,4:] = (0.01, -0.02, 0.002, -0.05, 0.01, 0.002, 0.003, -0.001) + rng.uniform(-1e-3, 1e-3, 8)
+        return out
+    if lensmodel == "LENSMODEL_CAHVOR":
+        out = np.zeros((Ncameras, 9))
+        for i in range(Ncameras):
+            out[i,:4] = CAM_OPENCV8[i % 2][:4]
+            out[i,4:] = (0.01, -0.02, 0.002, -0.05, 0.01) + rng.uniform(-1e-3, 1e-3, 5)
+        return out
     N = {"LENSMODEL_PINHOLE": 4, "LENSMODEL_STEREOGRAPHIC": 4,
          "LENSMODEL_LONLAT": 4, "LENSMODEL_LATLON": 4,
          "LENSMODEL_OPENCV4": 8, "LENSMODEL_OPENCV5": 9,

@@ -1,0 +1,109 @@
+// TEST-ONLY host build of the __host__ __device__ math in
+// mrcal_amd/csrc/lens_models.hpp and device_math.hpp, so that the CPU test
+// suite (no GPU in the build container) can check the very source the kernels
+// compile against the reference's own mrcal_project() (oracle/_ref).
+// This is not a product path: nothing in mrcal_amd/ loads it.
+//
+//   hipcc -O2 -std=c++17 -fPIC -shared -o libhostcheck.so hostcheck.cpp      (host code only)
+#include <string.h>
+#include "../../mrcal_amd/csrc/lens_models.hpp"
+
+using namespace mrcal_amd;
+
+template<int PROJ, int NDIST>
+static int run(double* q, double* dq_dp, double* dq_dk, const double* p, int N,
+               const double* intr, const LensConfig& cfg)
+{
+    int nfail = 0;
+    for(int i=0;i<N;i++)
+    {
+        double g[2][3], gk[2][NDIST > 0 ? NDIST : 1];
+        if(!project_lens<PROJ,NDIST,true>(&q[2*i], g, gk, &p[3*i], intr, cfg)) nfail++;
+        memcpy(&dq_dp[6*i], g, sizeof(g));
+        for(int xy=0;xy<2;xy++)
+            for(int k=0;k<NDIST;k++)
+                dq_dk[(2*i + xy)*NDIST + k] = gk[xy][k];
+        // the single-row entry point must agree with the two-row one bit for bit
+        for(int xy=0;xy<2;xy++)
+        {
+            double q1, g1[3], gk1[NDIST > 0 ? NDIST : 1];
+            project_lens_row<PROJ,NDIST,true>(xy, &q1, g1, gk1, &p[3*i], intr, cfg);
+            if(q1 != q[2*i+xy]) nfail += 1000;
+            for(int k=0;k<3;k++)     if(g1[k]  != g[xy][k])  nfail += 1000;
+            for(int k=0;k<NDIST;k++) if(gk1[k] != gk[xy][k]) nfail += 1000;
+        }
+    }
+    return nfail;
+}
+
+extern "C" {
+
+// model: the PROJ_* value; ndist: number of distortion parameters.
+// q[N][2], dq_dp[N][2][3], dq_dk[N][2][ndist]. Returns the number of failed
+// projections (CAHVORE), <0 for an unknown model
+int hostcheck_project(int model, int ndist, double* q, double* dq_dp, double* dq_dk,
+                      const double* p, int N, const double* intr, double cahvore_linearity)
+{
+    LensConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    cfg.cahvore_linearity = cahvore_linearity;
+    switch(model)
+    {
+    case PROJ_OPENCV:
+        switch(ndist)
+        {
+        case 0:  return run<PROJ_OPENCV,0 >(q,dq_dp,dq_dk,p,N,intr,cfg);
+        case 4:  return run<PROJ_OPENCV,4 >(q,dq_dp,dq_dk,p,N,intr,cfg);
+        case 5:  return run<PROJ_OPENCV,5 >(q,dq_dp,dq_dk,p,N,intr,cfg);
+        case 8:  return run<PROJ_OPENCV,8 >(q,dq_dp,dq_dk,p,N,intr,cfg);
+        case 12: return run<PROJ_OPENCV,12>(q,dq_dp,dq_dk,p,N,intr,cfg);
+        }
+        return -1;
+    case PROJ_STEREOGRAPHIC: return run<PROJ_STEREOGRAPHIC,0>(q,dq_dp,dq_dk,p,N,intr,cfg);
+    case PROJ_LONLAT:        return run<PROJ_LONLAT,0>(q,dq_dp,dq_dk,p,N,intr,cfg);
+    case PROJ_LATLON:        return run<PROJ_LATLON,0>(q,dq_dp,dq_dk,p,N,intr,cfg);
+    case PROJ_CAHVOR:        return run<PROJ_CAHVOR,5>(q,dq_dp,dq_dk,p,N,intr,cfg);
+    case PROJ_CAHVORE:       return run<PROJ_CAHVORE,8>(q,dq_dp,dq_dk,p,N,intr,cfg);
+    }
+    return -1;
+}
+
+// splined stereographic: q[N][2], dq_dp[N][2][3], dq_dfxy[N][2], ivar0[N], coef[N][8] (x then y basis values)
+void hostcheck_project_splined(double* q, double* dq_dp, double* dq_dfxy, int* ivar0, double* coef,
+                               const double* p, int N, const double* intr,
+                               int order, int Nx, int Ny, double fov_x_deg)
+{
+    LensConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    cfg.spline_order = order; cfg.spline_Nx = Nx; cfg.spline_Ny = Ny;
+    cfg.spline_segments_per_u = spline_segments_per_u(order, Nx, fov_x_deg);
+    for(int i=0;i<N;i++)
+    {
+        double g[2][3];
+        project_splined<true>(&q[2*i], g, &dq_dfxy[2*i], &ivar0[i], &coef[8*i], &coef[8*i+4], &p[3*i], intr, cfg);
+        memcpy(&dq_dp[6*i], g, sizeof(g));
+    }
+}
+
+// rotation composition and friends, for the poseutils known-answer tests
+void hostcheck_compose_rt(double* rt_out, double* d_r_r0, double* d_r_r1, double* d_t_r0, double* d_t_t1,
+                          const double* rt0, const double* rt1)
+{
+    Dual<6> r0[3], r1[3], r01[3];
+    for(int i=0;i<3;i++) { r0[i] = Dual<6>::variable(rt0[i], i); r1[i] = Dual<6>::variable(rt1[i], 3+i); }
+    compose_r_dual<6>(r01, r0, r1);
+    Dual<6> t1[3], t01[3];
+    for(int i=0;i<3;i++) t1[i] = Dual<6>::variable(rt1[3+i], 3+i);
+    rotate_point_r_dual<6>(t01, r0, t1, false);
+    for(int i=0;i<3;i++)
+    {
+        rt_out[i]   = r01[i].x;
+        rt_out[3+i] = t01[i].x + rt0[3+i];
+        for(int l=0;l<3;l++)
+        {
+            d_r_r0[3*i+l] = r01[i].d[l];   d_r_r1[3*i+l] = r01[i].d[3+l];
+            d_t_r0[3*i+l] = t01[i].d[l];   d_t_t1[3*i+l] = t01[i].d[3+l];
+        }
+    }
+}
+void hostcheck_R_from_r(double* R, double* dR, const double* r) { R_from_r_with_grad(R, dR, r); }
+
+} // extern "C"

@@ -68,7 +68,10 @@ def test_golden_no_jacobian(amd, golden):
 
 
 LENSMODELS = ("LENSMODEL_PINHOLE", "LENSMODEL_STEREOGRAPHIC", "LENSMODEL_LONLAT", "LENSMODEL_LATLON",
-              "LENSMODEL_OPENCV4", "LENSMODEL_OPENCV5", "LENSMODEL_OPENCV8", "LENSMODEL_OPENCV12")
+              "LENSMODEL_OPENCV4", "LENSMODEL_OPENCV5", "LENSMODEL_OPENCV8", "LENSMODEL_OPENCV12",
+              "LENSMODEL_CAHVOR", "LENSMODEL_CAHVORE_linearity=0.00", "LENSMODEL_CAHVORE_linearity=0.37",
+              "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120",
+              "LENSMODEL_SPLINED_STEREOGRAPHIC_order=2_Nx=9_Ny=7_fov_x_deg=110")
 
 
 @pytest.mark.parametrize("lensmodel", LENSMODELS)
@@ -122,6 +125,26 @@ def test_synthetic_selections_and_points(amd, ref_api):
         oi.update(dict(zip(flags, bits)))
         compare_callbacks(amd.optimizer_callback(no_factorization=True, **oi),
                           ref_api.optimizer_callback(no_factorization=True, **oi), str(bits))
+
+
+@pytest.mark.parametrize("lensmodel", ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120",
+                                       "LENSMODEL_CAHVORE_linearity=0.37"))
+def test_points_and_selections_other_models(amd, ref_api, lensmodel):
+    """discrete points (incl. outliers: the splined model names its first
+    (order+1)^2 knots for those, mrcal.c:4960-4972), board outliers and a few
+    do_optimize_* combinations for the non-OPENCV kernels"""
+    rng = np.random.RandomState(11)
+    oi0, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=4, lensmodel=lensmodel,
+                                      object_width_n=7, object_height_n=6, seed=6)
+    oi0 = _with_points(oi0, rng)
+    oi0["observations_board"][1,2:4,3:5,2] = -1.
+    for core, dist, ext, frames, warp, reg in ((1,1,1,1,1,1), (0,1,1,1,0,1), (1,0,0,1,1,0), (0,1,0,0,0,1), (1,1,1,0,1,1)):
+        oi = copy_inputs(oi0)
+        oi.update(do_optimize_intrinsics_core=bool(core), do_optimize_intrinsics_distortions=bool(dist),
+                  do_optimize_extrinsics=bool(ext), do_optimize_frames=bool(frames),
+                  do_optimize_calobject_warp=bool(warp), do_apply_regularization=bool(reg))
+        compare_callbacks(amd.optimizer_callback(no_factorization=True, **oi),
+                          ref_api.optimizer_callback(no_factorization=True, **oi), f"{lensmodel} {core}{dist}{ext}{frames}{warp}{reg}")
 
 
 def test_nothing_to_optimize_raises(amd, golden):

@@ -89,10 +89,13 @@ def _solve_both(amd, ref_api, oi):
     return oa, sa, orr, sr
 
 
-@pytest.mark.parametrize("lensmodel,Ncam,Nf", (("LENSMODEL_OPENCV4", 1, 12),
-                                                ("LENSMODEL_OPENCV8", 3, 10),
-                                                ("LENSMODEL_PINHOLE", 2, 8)))
-def test_optimize_matches_checker(amd, ref_api, lensmodel, Ncam, Nf):
+# CAHVOR: the optical-axis angles trade off against the centre pixel almost
+# exactly; along that valley the two solvers stop up to ~1e-3 packed units apart
+@pytest.mark.parametrize("lensmodel,Ncam,Nf,btol", (("LENSMODEL_OPENCV4", 1, 12, 2e-5),
+                                                     ("LENSMODEL_OPENCV8", 3, 10, 2e-5),
+                                                     ("LENSMODEL_PINHOLE", 2, 8,  2e-5),
+                                                     ("LENSMODEL_CAHVOR",  2, 8,  2e-3)))
+def test_optimize_matches_checker(amd, ref_api, lensmodel, Ncam, Nf, btol):
     oi, truth = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
                                          object_width_n=10, object_height_n=10, seed=31)
     oa, sa, orr, sr = _solve_both(amd, ref_api, oi)
@@ -104,12 +107,12 @@ def test_optimize_matches_checker(amd, ref_api, lensmodel, Ncam, Nf):
         1e-6*sr["rms_reproj_error__pixels"]
     # the optimum. Both stop when a step is shorter than 1e-7 (packed units)
     db = np.abs(sa["b_packed"] - sr["b_packed"])
-    assert db.max() < 2e-5, f"packed state differs by {db.max()} at {db.argmax()}"
+    assert db.max() < btol, f"packed state differs by {db.max()} at {db.argmax()}"
     for k in ("intrinsics", "rt_cam_ref", "rt_ref_frame", "calobject_warp"):
         if oa[k] is not None and oa[k].size:
             # weakly-determined directions (high-order distortions) stop wherever
             # the last sub-1e-7 step left them: the cost there is flat
-            assert relative_error(oa[k], orr[k], eps=1e-3).max() < 1e-3, k
+            assert relative_error(oa[k], orr[k], eps=1e-3).max() < max(1e-3, 50*btol), k
     # residuals at the optimum (weighted pixels): both solvers stop within a
     # 1e-7 packed-units step of it, so compare absolutely
     assert np.abs(sa["x"] - sr["x"]).max() < 1e-5
@@ -126,3 +129,26 @@ def test_optimize_recovers_truth(amd):
     s = amd.optimize(**oi)
     assert s["rms_reproj_error__pixels"] < 1e-6
     assert np.abs(oi["calobject_warp"] - truth["calobject_warp"]).max() < 1e-6
+
+
+def test_optimize_splined(amd, ref_api):
+    """a splined-stereographic solve (core locked, as mrcal-calibrate-cameras
+    does for these models: mrcal-calibrate-cameras:641-643): the row-by-row
+    normal equations and the large-camera-block Cholesky path.
+
+    The knots only the regularization sees make this problem nearly singular;
+    the CPU checker (restated libdogleg + a textbook Cholesky) gives up on
+    positive definiteness there, adds lambda I and crawls to its iteration
+    limit. So this is not a same-optimum comparison: the GPU solve must
+    converge by itself (well under the iteration limit), to a cost no higher
+    than the checker's, and stay there when restarted from its solution"""
+    oi, truth = make_calibration_problem(amd._api, Ncameras=1, Nframes=30,
+                                         lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120",
+                                         object_width_n=10, object_height_n=10, seed=33)
+    oi["do_optimize_intrinsics_core"]  = False
+    oi["do_apply_outlier_rejection"]   = False
+    oa, sa, orr, sr = _solve_both(amd, ref_api, oi)
+    assert sa["rms_reproj_error__pixels"] <= sr["rms_reproj_error__pixels"]*(1. + 1e-9)
+    # restart from the solution: nothing left to gain
+    sa2 = amd.optimize(**oa)
+    assert abs(sa2["rms_reproj_error__pixels"] - sa["rms_reproj_error__pixels"]) < 1e-7*sa["rms_reproj_error__pixels"]
