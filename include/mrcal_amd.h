@@ -188,6 +188,14 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 bool verbose,
                 bool check_gradient);
 
+/* Stand-alone projection of N camera-frame points (reference: mrcal.h:165-174,
+   mrcal.c:2867-3069). Host pointers. dq_dp (N,2,3) and dq_dintrinsics
+   (N,2,Nintrinsics) may be NULL. Runs the same device functions as the solver's
+   kernels, one lane per point */
+bool mrcal_project(mrcal_point2_t* q, mrcal_point3_t* dq_dp, double* dq_dintrinsics,
+                   const mrcal_point3_t* p, int N,
+                   const mrcal_lensmodel_t* lensmodel, const double* intrinsics);
+
 /* reference: mrcal.h:539-609, mrcal.c:5972-6177. One evaluation of the cost
    function: b_packed, x and (if Jt != NULL) the CSR Jacobian: Jt->p
    (int32[Nmeas+1]), Jt->i (int32[Nnz]), Jt->x (double[Nnz]) */
@@ -502,6 +510,28 @@ bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* problem,
 bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* problem, double* step);
 /* the board observation pool of this shard, with any newly marked outliers */
 bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* problem, mrcal_point3_t* pool_local);
+
+/* ---- factorization of JtJ: the CHOLMOD_factorization equivalent -----------
+   Reference: the mrcal.CHOLMOD_factorization Python type, mrcal-pywrap.c:111-214
+   (constructor from Jt), :425-569 (solve_xt_JtJ_bt), :580-592 (rcond).
+   The Jacobian comes as a host CSR matrix (Nmeas x Nstate, int32 offsets, packed
+   units), exactly what optimizer_callback() returns. The state partition tells
+   the structured solver which variables form the dense shared block (the first
+   Nstate_shared_leading: intrinsics and extrinsics; plus the last Nwarp) and
+   which are the mutually independent 6x6 frame / 3x3 point blocks in between.
+   Pass (Nstate,0,0,0) for a matrix without that structure (dense; small only).
+   Returns NULL if JtJ is not positive definite (the reference returns None) */
+typedef struct mrcal_amd_factorization mrcal_amd_factorization_t;
+mrcal_amd_factorization_t*
+mrcal_amd_factorization_create(int Nmeas, int Nstate,
+                               const int32_t* rowptr, const int32_t* colidx, const double* values,
+                               int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp);
+void   mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f);
+int    mrcal_amd_factorization_Nstate (const mrcal_amd_factorization_t* f);
+/* xt[i,:] = (JtJ)^-1 bt[i,:]; host, C-contiguous (Nrhs,Nstate) */
+bool   mrcal_amd_factorization_solve  (mrcal_amd_factorization_t* f, const double* bt, int Nrhs, double* xt);
+/* (min diag L / max diag L)^2, like cholmod_rcond() */
+double mrcal_amd_factorization_rcond  (mrcal_amd_factorization_t* f);
 
 #ifdef __cplusplus
 }

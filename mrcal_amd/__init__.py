@@ -64,6 +64,7 @@ corresponding_icam_extrinsics         = _api.corresponding_icam_extrinsics
 pack_state                            = _api.pack_state
 unpack_state                          = _api.unpack_state
 lensmodel_num_params                  = _api.lensmodel_num_params
+project                               = _api.project
 
 from ._factorization import CHOLMOD_factorization
 

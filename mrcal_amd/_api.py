@@ -414,17 +414,54 @@ class Api:
         if Jt is not None:
             J = scipy.sparse.csr_matrix((X, I, P), shape=(Nmeas, Nstate))
             if not p.no_factorization:
-                factorization = self._factorization(J)
+                factorization = self._factorization(J, p)
         return b_packed, x, J, factorization
 
-    def _factorization(self, J):
+    def _factorization(self, J, p):
+        """the factorization of JtJ that optimizer_callback() returns; with the
+        product library the structured GPU solver, told how the state splits"""
+        if not self.lib.has_symbol("mrcal_amd_factorization_create"):
+            return None
         from ._factorization import CHOLMOD_factorization
+        s = (p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
+             p.Nobservations_board, p.sel, C.byref(p.lensmodel))
+        Ni  = self.clib.mrcal_num_states_intrinsics(p.Ncameras_intrinsics, p.sel, C.byref(p.lensmodel))
+        Ne  = self.clib.mrcal_num_states_extrinsics(p.Ncameras_extrinsics, p.sel)
+        Nf  = self.clib.mrcal_num_states_frames(p.Nframes, p.sel)
+        Np  = self.clib.mrcal_num_states_points(p.Npoints, p.Npoints_fixed, p.sel)
+        Nw  = self.clib.mrcal_num_states_calobject_warp(p.sel, p.Nobservations_board)
         try:
-            return CHOLMOD_factorization(J)
-        except Exception:
+            return CHOLMOD_factorization(J, _partition=(Ni + Ne, Nf//6, Np//3, Nw))
+        except RuntimeError:
             # a failed factorization is None, not an exception
             # (mrcal-pywrap.c:1981-1988)
             return None
+
+    def project(self, v, lensmodel, intrinsics_data, get_gradients=False):
+        """q = project(v): N camera-frame points (...,3) through a lens model
+        (mrcal.project(), mrcal-genpywrap.py:134-470, here without the
+        broadcasting over models). With get_gradients: (q, dq_dv (...,2,3),
+        dq_dintrinsics (...,2,Nintrinsics))"""
+        m = self.lib.lensmodel(lensmodel)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        if v.shape[-1] != 3:
+            raise RuntimeError("v must have shape (...,3)")
+        intr = np.ascontiguousarray(intrinsics_data, dtype=np.float64)
+        Ni = self.clib.mrcal_lensmodel_num_params(C.byref(m))
+        if intr.shape != (Ni,):
+            raise RuntimeError(f"intrinsics_data must have shape ({Ni},) for {lensmodel}")
+        N = v.size // 3
+        q = np.empty(v.shape[:-1] + (2,))
+        dq_dv = np.empty(v.shape[:-1] + (2,3)) if get_gradients else None
+        dq_di = np.empty(v.shape[:-1] + (2,Ni)) if get_gradients else None
+        f = self.clib.mrcal_project
+        f.restype  = C.c_bool
+        f.argtypes = [C.c_void_p]*4 + [C.c_int, C.c_void_p, C.c_void_p]
+        ok = f(_ptr(q), _ptr(dq_dv) if get_gradients else None, _ptr(dq_di) if get_gradients else None,
+               _ptr(v), N, C.byref(m), _ptr(intr))
+        if not ok:
+            raise RuntimeError("mrcal_project() failed!" + self._last_error())
+        return (q, dq_dv, dq_di) if get_gradients else q
 
     def _last_error(self):
         if self.lib.has_symbol("mrcal_amd_last_error"):

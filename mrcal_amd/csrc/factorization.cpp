@@ -1,0 +1,209 @@
+// The CHOLMOD_factorization equivalent: factor JtJ of a CSR Jacobian on the
+// GPU, solve against it.
+//
+// Reference behaviour: the mrcal.CHOLMOD_factorization Python type
+// (mrcal-pywrap.c:111-214: cholmod_analyze + cholmod_factorize of Jt;
+// :425-569 solve_xt_JtJ_bt(); :580-592 rcond()). CHOLMOD is a general sparse
+// direct solver; this is the structured solver of solver_kernels.hip given the
+// partition of the state: a dense leading block S (intrinsics, extrinsics, and
+// the trailing warp pair) and block-diagonal 6x6 / 3x3 blocks E (frames,
+// points) that no row couples to each other. A matrix without such a structure
+// is handled as all-S (dense), which is fine for small problems only.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include "layout.hpp"
+#include "host_state.hpp"
+#include "problem.hpp"
+#include "kernels.hpp"
+#include "solver_kernels.hpp"
+#include "../../include/mrcal_amd.h"
+
+using namespace mrcal_amd;
+
+#define HIP_TRY(expr, onfail)                                           \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if(_e != hipSuccess)                                            \
+        {                                                               \
+            set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            onfail;                                                     \
+        }                                                               \
+    } while(0)
+
+struct mrcal_amd_factorization
+{
+    NormalDims    nd;
+    BlockRanges   br;
+    OpDev         op;         // host copy of the pointers
+    OpDev*        d_op  = NULL;
+    FactorBuffers F     = {};
+    int32_t*      d_Jp  = NULL;
+    int32_t*      d_Ji  = NULL;
+    double*       d_rhs = NULL;
+    double*       d_sol = NULL;
+    double*       d_mm  = NULL;   // [2] min, max of the factor's diagonal
+    hipStream_t   stream = NULL;
+    std::vector<void*> allocs;
+
+    template<class T> bool alloc(T** p, size_t n)
+    {
+        *p = NULL;
+        if(n == 0) n = 1;
+        if(hipMalloc((void**)p, n*sizeof(T)) != hipSuccess)
+        {
+            set_error("out of device memory allocating %zu bytes for a factorization", n*sizeof(T));
+            return false;
+        }
+        allocs.push_back((void*)*p);
+        return true;
+    }
+    ~mrcal_amd_factorization()
+    {
+        for(void* p : allocs) hipFree(p);
+        if(stream) hipStreamDestroy(stream);
+    }
+};
+
+extern "C" {
+
+mrcal_amd_factorization_t*
+mrcal_amd_factorization_create(int Nmeas, int Nstate,
+                               const int32_t* rowptr, const int32_t* colidx, const double* values,
+                               int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0)
+    {
+        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
+        return NULL;
+    }
+    const int NE = 6*Nframe_blocks + 3*Npoint_blocks;
+    if(Nstate_shared_leading < 0 || Nstate_shared_leading + NE + Nwarp != Nstate ||
+       (Nwarp != 0 && Nwarp != 2) || Nmeas < 0)
+    {
+        set_error("inconsistent state partition: %d + 6*%d + 3*%d + %d != %d",
+                  Nstate_shared_leading, Nframe_blocks, Npoint_blocks, Nwarp, Nstate);
+        return NULL;
+    }
+    const int64_t Nnz = rowptr[Nmeas];
+    mrcal_amd_factorization* f = new mrcal_amd_factorization();
+    NormalDims& nd = f->nd;
+    nd.Nstate = Nstate; nd.Nie = Nstate_shared_leading; nd.Nwarp = Nwarp;
+    nd.i_state_warp = Nstate - Nwarp; nd.Nc = nd.Nie + nd.Nwarp;
+    nd.NE = NE; nd.Nfb = Nframe_blocks; nd.Npb = Npoint_blocks; nd.NEb = nd.Nfb + nd.Npb;
+    f->br.frame_lo = 0; f->br.frame_hi = nd.Nfb; f->br.point_lo = nd.Nfb; f->br.point_hi = nd.NEb;
+    if((double)nd.Nc*nd.Nc*8.0 > 64e9)
+    {
+        set_error("the dense block of this factorization would be %d x %d: too large", nd.Nc, nd.Nc);
+        delete f; return NULL;
+    }
+
+    bool ok = true;
+    memset(&f->op, 0, sizeof(f->op));
+    HIP_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking), ok = false);
+    ok = ok && f->alloc(&f->d_Jp, (size_t)Nmeas+1);
+    ok = ok && f->alloc(&f->d_Ji, (size_t)Nnz);
+    ok = ok && f->alloc(&f->op.Jv, (size_t)Nnz);
+    ok = ok && f->alloc(&f->op.x,  (size_t)Nmeas);
+    ok = ok && f->alloc(&f->op.A,  (size_t)nd.Nc*nd.Nc);
+    ok = ok && f->alloc(&f->op.Bt, (size_t)nd.NE*nd.Nc);
+    ok = ok && f->alloc(&f->op.D,  (size_t)nd.NEb*36);
+    ok = ok && f->alloc(&f->op.g,  (size_t)nd.Nstate);
+    ok = ok && f->alloc(&f->op.scalars, (size_t)NSCALARS);
+    ok = ok && f->alloc(&f->op.step_gn, (size_t)nd.Nstate);
+    ok = ok && f->alloc(&f->d_op, 1);
+    ok = ok && f->alloc(&f->F.Wt, (size_t)nd.NE*nd.Nc);
+    ok = ok && f->alloc(&f->F.LD, (size_t)nd.NEb*36);
+    ok = ok && f->alloc(&f->F.y,  (size_t)nd.NE);
+    ok = ok && f->alloc(&f->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc);
+    ok = ok && f->alloc(&f->F.status, 1);
+    ok = ok && f->alloc(&f->d_rhs, (size_t)nd.Nstate);
+    ok = ok && f->alloc(&f->d_sol, (size_t)nd.Nstate);
+    ok = ok && f->alloc(&f->d_mm, 2);
+    if(!ok) { delete f; return NULL; }
+    f->F.r = f->F.S + (size_t)nd.Nc*nd.Nc;
+
+    HIP_TRY(hipMemcpy(f->d_Jp, rowptr, ((size_t)Nmeas+1)*sizeof(int32_t), hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemcpy(f->d_Ji, colidx, (size_t)Nnz*sizeof(int32_t),        hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemcpy(f->op.Jv, values, (size_t)Nnz*sizeof(double),        hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemset(f->op.x, 0, (size_t)(Nmeas > 0 ? Nmeas : 1)*sizeof(double)), ok = false);
+    HIP_TRY(hipMemcpy(f->d_op, &f->op, sizeof(OpDev), hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemset(f->F.status, 0, sizeof(int)), ok = false);
+    if(!ok) { delete f; return NULL; }
+
+    // validate the partition: no row may touch two E blocks (checked on the host: cheap)
+    for(int r = 0; r < Nmeas; r++)
+    {
+        int blk = -1;
+        for(int32_t p = rowptr[r]; p < rowptr[r+1]; p++)
+        {
+            const int c = colidx[p];
+            if(c < 0 || c >= Nstate) { set_error("column index %d out of range in row %d", c, r); delete f; return NULL; }
+            if(c >= nd.Nie && c < nd.Nie + nd.NE)
+            {
+                const int e = c - nd.Nie;
+                const int b = (e < 6*nd.Nfb) ? e/6 : nd.Nfb + (e - 6*nd.Nfb)/3;
+                if(blk >= 0 && b != blk)
+                {
+                    set_error("row %d couples two eliminated blocks (%d and %d): this matrix does not have the declared structure", r, blk, b);
+                    delete f; return NULL;
+                }
+                blk = b;
+            }
+        }
+    }
+
+    const OpRef R = { f->d_op, NULL, NULL };
+    HIP_TRY(launch_assemble_rows(nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream), ok = false);
+    if(ok) HIP_TRY(launch_factor_local(nd, f->br, R, f->F, 0.0, NULL, true, f->stream), ok = false);
+    if(ok) HIP_TRY(launch_solve_backsub(nd, f->br, R, f->F, NULL, true, f->stream), ok = false);
+    int status = 0;
+    if(ok) HIP_TRY(hipMemcpyAsync(&status, f->F.status, sizeof(int), hipMemcpyDeviceToHost, f->stream), ok = false);
+    if(ok) HIP_TRY(hipStreamSynchronize(f->stream), ok = false);
+    if(!ok) { delete f; return NULL; }
+    if(status != 0)
+    {
+        // like the reference: "CHOLMOD factorization failed (singular JtJ)"
+        set_error("the factorization failed: JtJ is not positive definite");
+        delete f;
+        return NULL;
+    }
+    return f;
+}
+
+void mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f) { delete f; }
+int  mrcal_amd_factorization_Nstate(const mrcal_amd_factorization_t* f) { return f->nd.Nstate; }
+
+// xt[i,:] = (JtJ)^-1 bt[i,:], i in [0,Nrhs). Host pointers, C-contiguous (Nrhs,Nstate)
+bool mrcal_amd_factorization_solve(mrcal_amd_factorization_t* f, const double* bt, int Nrhs, double* xt)
+{
+    last_error_string().clear();
+    const size_t n = (size_t)f->nd.Nstate;
+    for(int i = 0; i < Nrhs; i++)
+    {
+        HIP_TRY(hipMemcpyAsync(f->d_rhs, bt + (size_t)i*n, n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
+        HIP_TRY(launch_fsolve(f->nd, f->F, f->d_rhs, f->d_sol, f->stream), return false);
+        HIP_TRY(hipMemcpyAsync(xt + (size_t)i*n, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
+    }
+    HIP_TRY(hipStreamSynchronize(f->stream), return false);
+    return true;
+}
+
+// like cholmod_rcond() for an LL' factorization: (min diag / max diag)^2
+double mrcal_amd_factorization_rcond(mrcal_amd_factorization_t* f)
+{
+    last_error_string().clear();
+    double mm[2] = { 1e300, 0.0 };
+    HIP_TRY(hipMemcpyAsync(f->d_mm, mm, sizeof(mm), hipMemcpyHostToDevice, f->stream), return -1.0);
+    HIP_TRY(launch_fsolve_diag_minmax(f->nd, f->F, f->d_mm, f->stream), return -1.0);
+    HIP_TRY(hipMemcpyAsync(mm, f->d_mm, sizeof(mm), hipMemcpyDeviceToHost, f->stream), return -1.0);
+    HIP_TRY(hipStreamSynchronize(f->stream), return -1.0);
+    if(!(mm[1] > 0.0)) return 0.0;
+    const double q = mm[0]/mm[1];
+    return q*q;
+}
+
+} // extern "C"

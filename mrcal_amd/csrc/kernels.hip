@@ -1280,6 +1280,97 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// 6. stand-alone projection of N points (mrcal_project(), mrcal.c:2867-3069)
+////////////////////////////////////////////////////////////////////////////////
+// One lane per point; the same device functions as the solver's kernels.
+// dq_dp (N,2,3) and dq_dintrinsics (N,2,Nintrinsics) may be NULL
+template<int PROJ, int NDIST>
+__global__ __launch_bounds__(64)
+void project_points_kernel(LensConfig cfg, int N, int Nintrinsics,
+                           const double* __restrict__ p, const double* __restrict__ intr_in,
+                           double* __restrict__ q, double* __restrict__ dq_dp, double* __restrict__ dq_di)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= N) return;
+    double intr[4 + NDIST];
+#pragma unroll
+    for(int k=0;k<4+NDIST;k++) intr[k] = intr_in[k];
+    const double pp[3] = { p[3*i], p[3*i+1], p[3*i+2] };
+    double qq[2], g[2][3], gk[2][NDIST > 0 ? NDIST : 1];
+    project_lens<PROJ,NDIST,true>(qq, g, gk, pp, intr, cfg);
+    q[2*i] = qq[0]; q[2*i+1] = qq[1];
+    if(dq_dp != NULL)
+        for(int xy=0;xy<2;xy++) for(int l=0;l<3;l++) dq_dp[6*i + 3*xy + l] = g[xy][l];
+    if(dq_di != NULL)
+        for(int xy=0;xy<2;xy++)
+        {
+            double* __restrict__ row = dq_di + ((size_t)2*i + xy)*Nintrinsics;
+            row[xy]     = (qq[xy] - intr[2+xy])/intr[xy];
+            row[1-xy]   = 0.0;
+            row[2+xy]   = 1.0;
+            row[3-xy]   = 0.0;
+            for(int k=0;k<NDIST;k++) row[4+k] = gk[xy][k];
+        }
+}
+__global__ __launch_bounds__(64)
+void project_points_splined_kernel(LensConfig cfg, int N, int Nintrinsics,
+                                   const double* __restrict__ p, const double* __restrict__ intr,
+                                   double* __restrict__ q, double* __restrict__ dq_dp, double* __restrict__ dq_di)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= N) return;
+    const double pp[3] = { p[3*i], p[3*i+1], p[3*i+2] };
+    double qq[2], g[2][3], dfxy[2], cfx[4], cfy[4];
+    int ivar0;
+    project_splined<true>(qq, g, dfxy, &ivar0, cfx, cfy, pp, intr, cfg);
+    q[2*i] = qq[0]; q[2*i+1] = qq[1];
+    if(dq_dp != NULL)
+        for(int xy=0;xy<2;xy++) for(int l=0;l<3;l++) dq_dp[6*i + 3*xy + l] = g[xy][l];
+    if(dq_di != NULL)
+    {
+        // the caller zeroed dq_di; the sparse gradient lands in its patch
+        const int n = cfg.spline_order + 1;
+        for(int xy=0;xy<2;xy++)
+        {
+            double* __restrict__ row = dq_di + ((size_t)2*i + xy)*Nintrinsics;
+            row[xy]   = dfxy[xy];
+            row[2+xy] = 1.0;
+            for(int jy=0;jy<n;jy++)
+                for(int jx=0;jx<n;jx++)
+                    row[ivar0 + jy*2*cfg.spline_Nx + 2*jx + xy] = cfx[jx]*cfy[jy]*intr[xy];
+        }
+    }
+}
+
+hipError_t launch_project_points(int lens_type, const LensConfig& cfg, int N, int Nintrinsics,
+                                 const double* p, const double* intr,
+                                 double* q, double* dq_dp, double* dq_di, hipStream_t stream)
+{
+    if(N <= 0) return hipSuccess;
+    const dim3 grid((N + 63)/64), block(64);
+#define MRCAL_AMD_PROJECT(PROJ, ND) hipLaunchKernelGGL((project_points_kernel<PROJ,ND>), grid, block, 0, stream, cfg, N, Nintrinsics, p, intr, q, dq_dp, dq_di)
+    switch(lens_type)
+    {
+    case MRCAL_LENSMODEL_PINHOLE:       MRCAL_AMD_PROJECT(PROJ_OPENCV,        0 ); break;
+    case MRCAL_LENSMODEL_STEREOGRAPHIC: MRCAL_AMD_PROJECT(PROJ_STEREOGRAPHIC, 0 ); break;
+    case MRCAL_LENSMODEL_LONLAT:        MRCAL_AMD_PROJECT(PROJ_LONLAT,        0 ); break;
+    case MRCAL_LENSMODEL_LATLON:        MRCAL_AMD_PROJECT(PROJ_LATLON,        0 ); break;
+    case MRCAL_LENSMODEL_OPENCV4:       MRCAL_AMD_PROJECT(PROJ_OPENCV,        4 ); break;
+    case MRCAL_LENSMODEL_OPENCV5:       MRCAL_AMD_PROJECT(PROJ_OPENCV,        5 ); break;
+    case MRCAL_LENSMODEL_OPENCV8:       MRCAL_AMD_PROJECT(PROJ_OPENCV,        8 ); break;
+    case MRCAL_LENSMODEL_OPENCV12:      MRCAL_AMD_PROJECT(PROJ_OPENCV,        12); break;
+    case MRCAL_LENSMODEL_CAHVOR:        MRCAL_AMD_PROJECT(PROJ_CAHVOR,        5 ); break;
+    case MRCAL_LENSMODEL_CAHVORE:       MRCAL_AMD_PROJECT(PROJ_CAHVORE,       8 ); break;
+    case MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC:
+        hipLaunchKernelGGL(project_points_splined_kernel, grid, block, 0, stream, cfg, N, Nintrinsics, p, intr, q, dq_dp, dq_di);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+#undef MRCAL_AMD_PROJECT
+    return hipGetLastError();
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
 template<int PROJ, int NDIST>

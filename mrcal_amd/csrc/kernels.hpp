@@ -64,4 +64,10 @@ hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool wi
 // rowptr/colidx; iteration-invariant
 hipError_t launch_structure(const DeviceProblem& P, const EvalBuffers& B, hipStream_t stream);
 
+// N points through a lens model, device pointers; dq_dp / dq_dintrinsics may be
+// NULL. For the splined model dq_dintrinsics must have been zeroed
+hipError_t launch_project_points(int lens_type, const LensConfig& cfg, int N, int Nintrinsics,
+                                 const double* p, const double* intrinsics,
+                                 double* q, double* dq_dp, double* dq_dintrinsics, hipStream_t stream);
+
 } // namespace mrcal_amd

@@ -760,4 +760,53 @@ bool mrcal_optimizer_callback(double* b_packed, int buffer_size_b_packed,
     return ok;
 }
 
+////////////////////////////////////////////////////////////////////////////////
+// drop-in: stand-alone projection (mrcal.h:165-174)
+////////////////////////////////////////////////////////////////////////////////
+bool mrcal_project(mrcal_point2_t* q, mrcal_point3_t* dq_dp, double* dq_dintrinsics,
+                   const mrcal_point3_t* p, int N,
+                   const mrcal_lensmodel_t* lensmodel, const double* intrinsics)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0)
+    {
+        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
+        return false;
+    }
+    if(!lens_supported(lensmodel->type))
+    {
+        set_error("mrcal_project(): lens model %d is not supported", (int)lensmodel->type);
+        return false;
+    }
+    if(N <= 0) return true;
+    const int Ni = lensmodel_num_params(*lensmodel);
+    LensConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+    {
+        cfg.spline_order = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.order;
+        cfg.spline_Nx    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Nx;
+        cfg.spline_Ny    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Ny;
+        cfg.spline_segments_per_u =
+            spline_segments_per_u(cfg.spline_order, cfg.spline_Nx,
+                                  (double)lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.fov_x_deg);
+    }
+    if(lensmodel->type == MRCAL_LENSMODEL_CAHVORE)
+        cfg.cahvore_linearity = lensmodel->LENSMODEL_CAHVORE__config.linearity;
+
+    double *d_p = NULL, *d_i = NULL, *d_q = NULL, *d_g = NULL, *d_gi = NULL;
+    bool ok = true;
+    ok = ok && dev_upload(&d_p, (const double*)p, (size_t)3*N);
+    ok = ok && dev_upload(&d_i, intrinsics, (size_t)Ni);
+    ok = ok && dev_alloc(&d_q, (size_t)2*N);
+    if(dq_dp)          ok = ok && dev_alloc(&d_g,  (size_t)6*N);
+    if(dq_dintrinsics) ok = ok && dev_alloc(&d_gi, (size_t)2*N*Ni);
+    if(ok && d_gi) HIP_TRY(hipMemset(d_gi, 0, (size_t)2*N*Ni*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(launch_project_points((int)lensmodel->type, cfg, N, Ni, d_p, d_i, d_q, d_g, d_gi, NULL), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(q, d_q, (size_t)2*N*sizeof(double), hipMemcpyDeviceToHost), ok = false);
+    if(ok && dq_dp)          HIP_TRY(hipMemcpy(dq_dp, d_g, (size_t)6*N*sizeof(double), hipMemcpyDeviceToHost), ok = false);
+    if(ok && dq_dintrinsics) HIP_TRY(hipMemcpy(dq_dintrinsics, d_gi, (size_t)2*N*Ni*sizeof(double), hipMemcpyDeviceToHost), ok = false);
+    hipFree(d_p); hipFree(d_i); hipFree(d_q); hipFree(d_g); hipFree(d_gi);
+    return ok;
+}
+
 } // extern "C"

@@ -1383,3 +1383,169 @@ hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stre
 }
 
 } // namespace mrcal_amd
+
+////////////////////////////////////////////////////////////////////////////////
+// solves against a kept factorization (the CHOLMOD_factorization equivalent):
+// (JtJ) x = b with N = JtJ = [A B; Bt D] factored as in launch_factor_local()
+// + schur_cholesky (keep_factor): the E blocks' L_e in LD, Wt = L_e^-1 Bt_e,
+// and the Cholesky factor of the Schur complement in the lower triangle of S.
+//   y_e = L_e^-1 b_e ;  r = b_S - Wt^T y ;  x_S = S^-1 r ;  x_e = L_e^-T (y_e - Wt_e x_S)
+////////////////////////////////////////////////////////////////////////////////
+namespace mrcal_amd {
+
+// y_e = L_e^-1 b_e, one thread per E block. b, y indexed by state / E index
+__global__ __launch_bounds__(64)
+void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
+                           const double* __restrict__ b, double* __restrict__ y)
+{
+    const int blk = blockIdx.x*blockDim.x + threadIdx.x;
+    if(blk >= nd.NEb) return;
+    const int de = (blk < nd.Nfb) ? 6 : 3;
+    const int e0 = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
+    const double* __restrict__ L = LD + (size_t)blk*36;
+    double w[6];
+    for(int i=0;i<de;i++)
+    {
+        double v = b[nd.Nie + e0 + i];
+        for(int k=0;k<i;k++) v -= L[i*6+k]*w[k];
+        w[i] = v / L[i*6+i];
+        y[e0+i] = w[i];
+    }
+}
+// r[c] = b_S[c] - sum_e Wt[e][c] y[e], one thread per S column
+__global__ __launch_bounds__(256)
+void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ y,
+                          const double* __restrict__ b, double* __restrict__ r)
+{
+    const int c = blockIdx.x*blockDim.x + threadIdx.x;
+    if(c >= nd.Nc) return;
+    double acc = b[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
+    for(int e = 0; e < nd.NE; e++) acc -= Wt[(size_t)e*nd.Nc + c]*y[e];
+    r[c] = acc;
+}
+// r <- (L L^T)^-1 r with L the lower triangle of S (row-major n x n), one workgroup
+__global__ __launch_bounds__(1024)
+void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict__ r)
+{
+    const int t = threadIdx.x, nt = blockDim.x;
+    __shared__ double piv;
+    for(int j=0;j<n;j++)
+    {
+        if(t == 0) { piv = r[j]/S[(size_t)j*n + j]; r[j] = piv; }
+        __syncthreads();
+        const double pj = piv;
+        for(int i=j+1+t;i<n;i+=nt) r[i] -= S[(size_t)i*n + j]*pj;
+        __syncthreads();
+    }
+    for(int j=n-1;j>=0;j--)
+    {
+        if(t == 0) { piv = r[j]/S[(size_t)j*n + j]; r[j] = piv; }
+        __syncthreads();
+        const double pj = piv;
+        for(int i=t;i<j;i+=nt) r[i] -= S[(size_t)j*n + i]*pj;
+        __syncthreads();
+    }
+}
+// x_e = L_e^-T (y_e - Wt_e x_S), one workgroup per E block; the extra block copies x_S
+__global__ __launch_bounds__(64)
+void fsolve_backsub_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ LD,
+                           const double* __restrict__ y, const double* __restrict__ xs,
+                           double* __restrict__ x)
+{
+    const int t = threadIdx.x;
+    if((int)blockIdx.x == nd.NEb)
+    {
+        for(int i=t;i<nd.Nc;i+=blockDim.x)
+            x[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = xs[i];
+        return;
+    }
+    const int blk = blockIdx.x;
+    const int de  = (blk < nd.Nfb) ? 6 : 3;
+    const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
+    __shared__ double red[6][64];
+    double part[6] = {0,0,0,0,0,0};
+    for(int c=t;c<nd.Nc;c+=blockDim.x)
+    {
+        const double d = xs[c];
+        for(int i=0;i<de;i++) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
+    }
+    for(int i=0;i<6;i++) red[i][t] = part[i];
+    __syncthreads();
+    if(t == 0)
+    {
+        double v[6];
+        const double* L = LD + (size_t)blk*36;
+        for(int i=0;i<de;i++)
+        {
+            double s = y[e0+i];
+            for(int k=0;k<64;k++) s -= red[i][k];
+            v[i] = s;
+        }
+        for(int i=de-1;i>=0;i--)
+        {
+            double s = v[i];
+            for(int k=i+1;k<de;k++) s -= L[k*6+i]*v[k];
+            v[i] = s/L[i*6+i];
+        }
+        for(int i=0;i<de;i++) x[nd.Nie + e0 + i] = v[i];
+    }
+}
+// min and max over the diagonal of the whole factor: out[0] = min, out[1] = max
+__global__ __launch_bounds__(256)
+void fsolve_diag_minmax_kernel(NormalDims nd, const double* __restrict__ S, const double* __restrict__ LD,
+                               double* __restrict__ out)
+{
+    double mn = 1e300, mx = 0.0;
+    const int total = nd.Nc + nd.NE;
+    for(int i = blockIdx.x*blockDim.x + threadIdx.x; i < total; i += gridDim.x*blockDim.x)
+    {
+        double d;
+        if(i < nd.Nc) d = S[(size_t)i*nd.Nc + i];
+        else
+        {
+            int blk, a, de, e0;
+            E_to_block(nd, i - nd.Nc, &blk, &a, &de, &e0);
+            d = LD[(size_t)blk*36 + a*6 + a];
+        }
+        mn = fmin(mn, d); mx = fmax(mx, d);
+    }
+    for(int off=32; off>0; off>>=1) { mn = fmin(mn, __shfl_down(mn, off)); mx = fmax(mx, __shfl_down(mx, off)); }
+    if((threadIdx.x & 63) == 0)
+    {
+        // positive doubles order like their bit patterns
+        atomicMin((unsigned long long*)&out[0], (unsigned long long)__double_as_longlong(mn));
+        atomicMax((unsigned long long*)&out[1], (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
+                         const double* b, double* x, hipStream_t stream)
+{
+    if(nd.NEb > 0)
+        hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64), dim3(64), 0, stream, nd, F.LD, b, F.y);
+    hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Wt, F.y, b, F.r);
+    hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r);
+    hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1), dim3(64), 0, stream, nd, F.Wt, F.LD, F.y, F.r, x);
+    return hipGetLastError();
+}
+hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fsolve_diag_minmax_kernel, dim3(64), dim3(256), 0, stream, nd, F.S, F.LD, out2);
+    return hipGetLastError();
+}
+// normal equations of a bare CSR matrix (every row through the generic path)
+hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
+                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream)
+{
+    {
+        const size_t total = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + nd.Nstate + NSCALARS;
+        int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, R);
+    }
+    if(Nmeas > 0)
+        hipLaunchKernelGGL(rows_generic_kernel, dim3((Nmeas + 63)/64), dim3(64), 0, stream,
+                           nd, R, 0, Nmeas, Jp, Ji);
+    return hipGetLastError();
+}
+
+} // namespace mrcal_amd

@@ -140,6 +140,16 @@ hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl*
 hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
 
+// solves against a kept factorization (F as left by launch_factor_local() +
+// launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order
+hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
+                         const double* b, double* x, hipStream_t stream);
+// out2[0] = min, out2[1] = max of the factor's diagonal; preset to (+big, 0)
+hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream);
+// the normal equations of a bare CSR matrix into the blocks of R's operating point
+hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
+                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream);
+
 // the control block is followed in memory by its derived flags
 size_t     solver_ctl_bytes();
 const int* solver_ctl_skip_factor(const SolverCtl* ctl);   // device pointers, given the device pointer of ctl
