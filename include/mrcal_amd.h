@@ -188,6 +188,13 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 bool verbose,
                 bool check_gradient);
 
+/* Pixel -> observation vector (not normalized). Reference: mrcal.h:177-206,
+   mrcal.c:3082-3286. HOST computation, like in the reference: it is the setup
+   step that turns triangulated-point pixel observations into the vectors
+   mrcal_observation_point_triangulated_t carries (mrcal-pywrap.c:1388-1395) */
+bool mrcal_unproject(mrcal_point3_t* out, const mrcal_point2_t* q, int N,
+                     const mrcal_lensmodel_t* lensmodel, const double* intrinsics);
+
 /* Stand-alone projection of N camera-frame points (reference: mrcal.h:165-174,
    mrcal.c:2867-3069). Host pointers. dq_dp (N,2,3) and dq_dintrinsics
    (N,2,Nintrinsics) may be NULL. Runs the same device functions as the solver's

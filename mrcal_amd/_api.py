@@ -241,9 +241,7 @@ class Api:
         c_point["icam_intrinsics"] = idx_point[:,1]
         c_point["icam_extrinsics"] = idx_point[:,2]
 
-        if Nobservations_tri > 0:
-            raise RuntimeError("triangulated-point observations are not supported by this build yet")
-        c_tri = np.empty((0,), dtype=observation_point_triangulated_dtype)
+        c_tri = self._fill_triangulated(observations_tri, idx_tri, lensmodel, intrinsics)
 
         p.lensmodel = lensmodel
         p.lensmodel_name = lensmodel_name
@@ -336,6 +334,50 @@ class Api:
             biggest = int(running[-1])
         if biggest != Npoints-1:
             raise RuntimeError(f"{name} should cover all point indices in [0,{Npoints-1}], but there are gaps. The biggest i_point={biggest}")
+
+    def _fill_triangulated(self, observations_tri, idx_tri, lensmodel, intrinsics):
+        """(px,py,weight) + (ipoint,icam_i,icam_e) rows -> the C records: the
+        pixel unprojected to an observation vector in the camera's coordinates,
+        the set boundaries, the outlier bit (mrcal-pywrap.c:1309-1440)"""
+        from ._cabi import TRIANGULATED_LAST_IN_SET, TRIANGULATED_OUTLIER
+        N = idx_tri.shape[0]
+        c_tri = np.zeros((N,), dtype=observation_point_triangulated_dtype)
+        if N == 0:
+            return c_tri
+        ipoint = idx_tri[:,0]
+        if ipoint[0] != 0 or np.any(ipoint < 0):
+            raise RuntimeError("Error in indices_point_triangulated_camintrinsics_camextrinsics: ipoint must start at 0 and be >= 0")
+        d = np.diff(ipoint)
+        if np.any((d != 0) & (d != 1)):
+            i = int(np.nonzero((d != 0) & (d != 1))[0][0]) + 1
+            raise RuntimeError(f"Error in indices_point_triangulated_camintrinsics_camextrinsics[{i}]. All ipoint must be consecutive and monotonic")
+        last = np.ones((N,), dtype=bool)
+        last[:-1] = d == 1
+        counts = np.bincount(ipoint)
+        if np.any(counts < 2):
+            raise RuntimeError(f"Error in indices_point_triangulated_camintrinsics_camextrinsics. Each point must be observed at least 2 times; point {int(np.argmin(counts))} is not")
+        c_tri["icam_intrinsics"] = idx_tri[:,1]
+        c_tri["icam_extrinsics"] = idx_tri[:,2]
+        flags = np.where(last, TRIANGULATED_LAST_IN_SET, 0).astype(np.uint8)
+        flags |= np.where(observations_tri[:,2] <= 0.0, TRIANGULATED_OUTLIER, 0).astype(np.uint8)
+        c_tri["flags"] = flags
+        if lensmodel is None:
+            return c_tri
+        # one mrcal_unproject() call per camera
+        f = self.clib.mrcal_unproject
+        f.restype  = C.c_bool
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        px = np.zeros((N,3))
+        for icam in np.unique(idx_tri[:,1]):
+            sel_ = np.nonzero(idx_tri[:,1] == icam)[0]
+            q = np.ascontiguousarray(observations_tri[sel_,:2])
+            v = np.zeros((len(sel_),3))
+            intr = np.ascontiguousarray(intrinsics[icam])
+            if not f(_ptr(v), _ptr(q), len(sel_), C.byref(lensmodel), _ptr(intr)):
+                raise RuntimeError("mrcal_unproject() failed" + self._last_error())
+            px[sel_] = v
+        c_tri["px"] = px
+        return c_tri
 
     def _common_args(self, p):
         return [
@@ -524,11 +566,17 @@ class Api:
             if name is None:
                 raise RuntimeError("The 'lensmodel' argument is required")
             lensmodel = self.lib.lensmodel(name)
+        # the triangulated observations matter to the layout through their set
+        # structure only (mrcal-pywrap.c:2278-2300)
+        tri, Ntri = None, 0
         tri_idx = kw.get("indices_point_triangulated_camintrinsics_camextrinsics", None)
         if tri_idx is not None and np.asarray(tri_idx).shape[0] > 0:
-            raise RuntimeError("triangulated-point observations are not supported by this build yet")
+            tri_idx = np.ascontiguousarray(tri_idx, dtype=np.int32)
+            c_tri = self._fill_triangulated(np.ones((tri_idx.shape[0],3)), tri_idx, None, None)
+            tri, Ntri = c_tri, tri_idx.shape[0]
         return dict(Nci=Nci, Nce=Nce, Nf=Nf, Np=Np, Npf=Npf, Nob=Nob, Nop=Nop,
-                    width_n=int(width_n), height_n=int(height_n), sel=sel, lensmodel=lensmodel)
+                    width_n=int(width_n), height_n=int(height_n), sel=sel, lensmodel=lensmodel,
+                    tri=tri, Ntri=Ntri)
 
     @staticmethod
     def _none_if_negative(i):
@@ -593,14 +641,14 @@ class Api:
     def measurement_index_points_triangulated(self, i_point_triangulated=0, **kw):
         a = self._layout_args(kw)
         return self._none_if_negative(self.clib.mrcal_measurement_index_points_triangulated(
-            i_point_triangulated, a["Nob"], a["Nop"], None, 0, a["width_n"], a["height_n"]))
+            i_point_triangulated, a["Nob"], a["Nop"], _ptr(a["tri"]), a["Ntri"], a["width_n"], a["height_n"]))
     def num_measurements_points_triangulated(self, **kw):
-        self._layout_args(kw)
-        return self.clib.mrcal_num_measurements_points_triangulated(None, 0)
+        a = self._layout_args(kw, need_lensmodel=False)
+        return self.clib.mrcal_num_measurements_points_triangulated(_ptr(a["tri"]), a["Ntri"])
     def measurement_index_regularization(self, **kw):
         a = self._layout_args(kw)
         return self._none_if_negative(self.clib.mrcal_measurement_index_regularization(
-            None, 0, a["width_n"], a["height_n"],
+            _ptr(a["tri"]), a["Ntri"], a["width_n"], a["height_n"],
             a["Nci"], a["Nce"], a["Nf"], a["Np"], a["Npf"], a["Nob"], a["Nop"],
             a["sel"], C.byref(a["lensmodel"])))
     def num_measurements_regularization(self, **kw):
@@ -609,7 +657,7 @@ class Api:
     def num_measurements(self, **kw):
         a = self._layout_args(kw)
         return self.clib.mrcal_num_measurements(
-            a["Nob"], a["Nop"], None, 0, a["width_n"], a["height_n"],
+            a["Nob"], a["Nop"], _ptr(a["tri"]), a["Ntri"], a["width_n"], a["height_n"],
             a["Nci"], a["Nce"], a["Nf"], a["Np"], a["Npf"], a["sel"], C.byref(a["lensmodel"]))
 
     def corresponding_icam_extrinsics(self, icam_intrinsics, **kw):

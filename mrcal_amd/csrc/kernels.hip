@@ -29,6 +29,7 @@
 #include "problem.hpp"
 #include "device_math.hpp"
 #include "lens_models.hpp"
+#include "triangulation.hpp"
 #include "kernels.hpp"
 
 namespace mrcal_amd {
@@ -1236,6 +1237,7 @@ void regularization_splined_kernel(DeviceProblem P, OpRef R,
     }
 }
 
+static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian, hipStream_t stream);
 static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                                 hipStream_t stream, hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
@@ -1267,6 +1269,7 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
         else
             hipLaunchKernelGGL((point_splined_kernel<false>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
     }
+    launch_triangulated(P, B, with_jacobian, stream);
     const int Nreg = P.Nmeas - P.i_meas_regularization;
     if(Nreg > 0)
     {
@@ -1371,6 +1374,78 @@ hipError_t launch_project_points(int lens_type, const LensConfig& cfg, int N, in
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// 7. triangulated points: one lane per pair of observations (1 row)
+////////////////////////////////////////////////////////////////////////////////
+// Row = [6 columns of camera 0's rt, if it is not the reference]
+//       [6 columns of camera 1's rt, ...], in that order (mrcal.c:5383-5506).
+// A pair with an outlier observation keeps its columns, x = 0, values 0
+template<bool WITH_J, bool WITH_STRUCTURE>
+__global__ __launch_bounds__(64)
+void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    const int ip = blockIdx.x*blockDim.x + threadIdx.x;
+    if(ip >= P.Npairs_tri) return;
+    const TriPairMeta m = P.tri_meta[ip];
+    if(WITH_STRUCTURE)
+    {
+        rowptr[m.i_meas] = (int32_t)m.i_nnz0;
+        int c = 0;
+        if(m.i_state_extrinsics0 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics0 + i; c += 6; }
+        if(m.i_state_extrinsics1 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics1 + i; }
+        return;
+    }
+    const double* __restrict__ b  = opref_get(R).b;
+    double*       __restrict__ x  = opref_get(R).x;
+    double*       __restrict__ Jv = opref_get(R).Jv;
+    const int n0 = (m.i_state_extrinsics0 >= 0) ? 6 : 0;
+    const int n1 = (m.i_state_extrinsics1 >= 0) ? 6 : 0;
+    if(P.tri_outlier[m.i0] || P.tri_outlier[m.i1])
+    {
+        x[m.i_meas] = 0.0;
+        if(WITH_J) for(int c=0;c<n0+n1;c++) Jv[m.i_nnz0 + c] = 0.0;
+        return;
+    }
+    double rt0[6], rt1[6];
+    if(m.icam_extrinsics0 >= 0) get_rt_cam_ref(rt0, P, b, m.icam_extrinsics0);
+    if(m.icam_extrinsics1 >= 0) get_rt_cam_ref(rt1, P, b, m.icam_extrinsics1);
+    const double* v0 = P.tri_px + 3*(size_t)m.i0;
+    const double* v1 = P.tri_px + 3*(size_t)m.i1;
+    const double v0l[3] = { v0[0], v0[1], v0[2] }, v1l[3] = { v1[0], v1[1], v1[2] };
+    if(!WITH_J)
+    {
+        const Dual<0> e = tri_pair_error<0>(v0l, v1l, (m.icam_extrinsics0 >= 0) ? rt0 : NULL,
+                                            (m.icam_extrinsics1 >= 0) ? rt1 : NULL, NULL);
+        x[m.i_meas] = e.x;
+        return;
+    }
+    const Dual<12> e = tri_pair_error<12>(v0l, v1l, (m.icam_extrinsics0 >= 0) ? rt0 : NULL,
+                                          (m.icam_extrinsics1 >= 0) ? rt1 : NULL, NULL);
+    x[m.i_meas] = e.x;
+    int c = 0;
+    if(n0)
+    {
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + i]     = e.d[i]   * SCALE_ROTATION_CAMERA;
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + 3 + i] = e.d[3+i] * SCALE_TRANSLATION_CAMERA;
+        c += 6;
+    }
+    if(n1)
+    {
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + i]     = e.d[6+i] * SCALE_ROTATION_CAMERA;
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + 3 + i] = e.d[9+i] * SCALE_TRANSLATION_CAMERA;
+    }
+}
+static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian, hipStream_t stream)
+{
+    if(P.Npairs_tri <= 0) return;
+    const dim3 grid((P.Npairs_tri + 63)/64), block(64);
+    if(with_jacobian)
+        hipLaunchKernelGGL((triangulated_kernel<true,false>),  grid, block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+    else
+        hipLaunchKernelGGL((triangulated_kernel<false,false>), grid, block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
 template<int PROJ, int NDIST>
@@ -1409,6 +1484,7 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
             hipLaunchKernelGGL((point_kernel<PROJ,NDIST,false>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream,
                                P, B.R);
     }
+    launch_triangulated(P, B, with_jacobian, stream);
     const int Nreg = P.Nmeas - P.i_meas_regularization;
     if(Nreg > 0)
     {
@@ -1473,6 +1549,9 @@ hipError_t launch_structure(const DeviceProblem& P, const EvalBuffers& B, hipStr
     if(P.Nobs_point > 0)
         hipLaunchKernelGGL(point_structure_kernel, dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream,
                            P, B.Jp, B.Ji);
+    if(P.Npairs_tri > 0)
+        hipLaunchKernelGGL((triangulated_kernel<false,true>), dim3((P.Npairs_tri + 63)/64), dim3(64), 0, stream,
+                           P, B.R, B.Jp, B.Ji);
     const int Nreg = P.Nmeas - P.i_meas_regularization;
     // also writes the terminating rowptr[Nmeas] when there are regularization
     // rows; the host writes it otherwise

@@ -53,6 +53,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_seed_intrinsics); hipFree(d_seed_rt_cam_ref); hipFree(d_seed_rt_ref_frame);
     hipFree(d_seed_points); hipFree(d_board_meta); hipFree(d_board_pool);
     hipFree(d_point_meta); hipFree(d_point_pool); hipFree(d_imagersizes);
+    hipFree(d_tri_meta); hipFree(d_tri_px); hipFree(d_tri_outlier);
     hipFree(d_joint); hipFree(d_gram); hipFree(d_Jp); hipFree(d_Ji);
     for(int i=0;i<2;i++)
     {
@@ -265,10 +266,10 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         set_error("lens model %s (%d) is not implemented on the GPU yet", name, (int)lensmodel->type);
         return NULL;
     }
-    if(observations_point_triangulated != NULL && Nobservations_point_triangulated > 0)
+    if(observations_point_triangulated == NULL || Nobservations_point_triangulated <= 0)
     {
-        set_error("triangulated-point observations are not implemented on the GPU yet");
-        return NULL;
+        observations_point_triangulated = NULL;
+        Nobservations_point_triangulated = 0;
     }
     if(Nobservations_board > 0 &&
        (calibration_object_width_n <= 0 || calibration_object_height_n <= 0))
@@ -296,7 +297,7 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     dg.Nobservations_point = Nobservations_point;
     dg.object_width_n      = calibration_object_width_n;
     dg.object_height_n     = calibration_object_height_n;
-    const Layout Lg = make_layout(dg, sel, *lensmodel, NULL, 0);
+    const Layout Lg = make_layout(dg, sel, *lensmodel, observations_point_triangulated, Nobservations_point_triangulated);
 
     // The MEASUREMENT layout is local to the shard
     const bool sharded = !(shard_begin_frame <= 0 && (shard_end_frame < 0 || shard_end_frame >= Nframes));
@@ -317,12 +318,13 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     L.dims.Nobservations_point = Npoint_local;
     L.Nmeas_boards         = Nboard_local * calibration_object_width_n*calibration_object_height_n * 2;
     L.Nmeas_points         = Npoint_local * 2;
-    L.Nmeas_triangulated   = 0;
+    // the triangulated points stay whole, with the shard leader
+    L.Nmeas_triangulated   = is_shard_leader ? Lg.Nmeas_triangulated : 0;
     if(!is_shard_leader) { L.Nmeas_regularization = 0; L.has_unity_cam01 = false; L.Nreg_percamera = 0; }
     L.i_meas_boards         = 0;
     L.i_meas_points         = L.Nmeas_boards;
     L.i_meas_triangulated   = L.i_meas_points + L.Nmeas_points;
-    L.i_meas_regularization = L.i_meas_triangulated;
+    L.i_meas_regularization = L.i_meas_triangulated + L.Nmeas_triangulated;
     L.Nmeas                 = L.i_meas_regularization + L.Nmeas_regularization;
     P->L = L;
 
@@ -371,6 +373,38 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         m.i_nnz0             = innz;
         imeas += 2;
         innz  += 2*m.nnz_per_row;
+    }
+    // triangulated points: one row per pair (i0 < i1) of observations of a point
+    std::vector<TriPairMeta> tmeta;
+    if(L.Nmeas_triangulated > 0)
+    {
+        const mrcal_observation_point_triangulated_t* ot = observations_point_triangulated;
+        for(int i0 = 0; i0 < Nobservations_point_triangulated; i0++)
+        {
+            if(ot[i0].last_in_set) continue;
+            for(int i1 = i0+1; i1 < Nobservations_point_triangulated; i1++)
+            {
+                TriPairMeta m;
+                memset(&m, 0, sizeof(m));
+                m.i0 = i0; m.i1 = i1;
+                m.icam_extrinsics0 = ot[i0].icam.extrinsics;
+                m.icam_extrinsics1 = ot[i1].icam.extrinsics;
+                m.i_state_extrinsics0 = (L.Nstate_extrinsics > 0 && m.icam_extrinsics0 >= 0) ? L.i_state_extrinsics + 6*m.icam_extrinsics0 : -1;
+                m.i_state_extrinsics1 = (L.Nstate_extrinsics > 0 && m.icam_extrinsics1 >= 0) ? L.i_state_extrinsics + 6*m.icam_extrinsics1 : -1;
+                m.i_meas = imeas;
+                m.i_nnz0 = innz;
+                imeas += 1;
+                innz  += (m.i_state_extrinsics0 >= 0 ? 6 : 0) + (m.i_state_extrinsics1 >= 0 ? 6 : 0);
+                tmeta.push_back(m);
+                if(ot[i1].last_in_set) break;
+            }
+        }
+        if((int)tmeta.size() != L.Nmeas_triangulated)
+        {
+            set_error("internal error: %d triangulated pairs, the layout says %d", (int)tmeta.size(), L.Nmeas_triangulated);
+            delete P;
+            return NULL;
+        }
     }
     const int64_t innz_reg = innz;
     if(L.Nmeas_regularization > 0)
@@ -430,6 +464,20 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     ok = ok && dev_upload(&P->d_point_meta,        pmeta.data(),                (size_t)Npoint_local);
     ok = ok && dev_upload(&P->d_point_pool,        (const double*)observations_point_pool, (size_t)Npoint_local*3);
     ok = ok && dev_upload(&P->d_imagersizes,       imagersizes,                 (size_t)Ncameras_intrinsics*2);
+    {
+        const int Nt = Nobservations_point_triangulated;
+        P->tri_meta_host = tmeta;
+        P->tri_px_host.resize((size_t)3*Nt + 1);
+        P->tri_outlier_host.resize((size_t)Nt + 1);
+        for(int i=0;i<Nt;i++)
+        {
+            for(int j=0;j<3;j++) P->tri_px_host[3*i+j] = observations_point_triangulated[i].px.xyz[j];
+            P->tri_outlier_host[i] = observations_point_triangulated[i].outlier ? 1 : 0;
+        }
+        ok = ok && dev_upload(&P->d_tri_meta,    tmeta.data(),                tmeta.size());
+        ok = ok && dev_upload(&P->d_tri_px,      P->tri_px_host.data(),       (size_t)3*Nt);
+        ok = ok && dev_upload(&P->d_tri_outlier, P->tri_outlier_host.data(),  (size_t)Nt);
+    }
     ok = ok && dev_alloc (&P->op[0].b,  (size_t)L.Nstate);
     // + the unpacked intrinsics and warp (DeviceProblem::unpacked)
     ok = ok && dev_alloc (&P->d_joint,  (size_t)Nboard_local*JOINT_STRIDE + (size_t)Ncameras_intrinsics*L.Nintrinsics + 2);
@@ -509,6 +557,10 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.point_meta        = P->d_point_meta;
     D.point_pool        = P->d_point_pool;
     D.imagersizes       = P->d_imagersizes;
+    D.Npairs_tri        = (int)P->tri_meta_host.size();
+    D.tri_meta          = P->d_tri_meta;
+    D.tri_px            = P->d_tri_px;
+    D.tri_outlier       = P->d_tri_outlier;
     D.unpacked          = P->d_joint + (size_t)Nboard_local*JOINT_STRIDE;
 
     // the seed state

@@ -60,6 +60,21 @@ struct PointObsMeta
 };
 static_assert(sizeof(PointObsMeta) == 48, "PointObsMeta layout");
 
+// One row of the triangulated-point residuals: a pair (i0 < i1) of observations
+// of one point (mrcal.c:5180-5653)
+struct TriPairMeta
+{
+    int32_t i0, i1;                 // indices into the triangulated observations
+    int32_t icam_extrinsics0;       // <0: that camera sits at the reference
+    int32_t icam_extrinsics1;
+    int32_t i_state_extrinsics0;    // first state index of camera 0's rt; <0 if none in this row
+    int32_t i_state_extrinsics1;
+    int32_t i_meas;
+    int32_t _pad;
+    int64_t i_nnz0;
+};
+static_assert(sizeof(TriPairMeta) == 40, "TriPairMeta layout");
+
 // The per-observation geometry the board kernel needs, produced by the
 // prologue kernel (one lane per observation) and consumed wave-uniformly.
 //
@@ -176,6 +191,12 @@ struct DeviceProblem
     const double*       board_pool;
     const PointObsMeta* point_meta;
     const double*       point_pool;
+    // triangulated points: pairs, the observation vectors (3 doubles each, in
+    // their camera's coordinates) and the outlier marks (one int per observation)
+    int                 Npairs_tri;
+    const TriPairMeta*  tri_meta;
+    const double*       tri_px;
+    const int*          tri_outlier;
     const int*          imagersizes;
 
     // state unpacked by the prologue kernel, every evaluation:

@@ -20,6 +20,7 @@ struct mrcal_amd_oppoint : public mrcal_amd::OpDev
 struct mrcal_amd_solver_stats
 {
     int    Niterations = 0, Nevaluations = 0, Nfactorizations = 0, Noutlier_passes = 0;
+    int    Noutliers_triangulated = 0;
     double norm2_x = -1.0, lambda = 0.0;
     double seconds_solve = 0.0;
 };
@@ -56,6 +57,13 @@ struct mrcal_amd_problem
     mrcal_amd::PointObsMeta* d_point_meta = NULL;
     double*                  d_point_pool = NULL;
     int*                     d_imagersizes = NULL;
+    mrcal_amd::TriPairMeta*  d_tri_meta    = NULL;
+    double*                  d_tri_px      = NULL;
+    int*                     d_tri_outlier = NULL;
+    // host copies, for the outlier logic (sequential, mrcal.c:3978-4402)
+    std::vector<mrcal_amd::TriPairMeta> tri_meta_host;
+    std::vector<double>      tri_px_host;
+    std::vector<int>         tri_outlier_host;
 
     // shared between the operating points
     double*  d_joint = NULL;

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include "host_state.hpp"
 #include "problem_object.hpp"
+#include "triangulation.hpp"
 #include "../../include/mrcal_amd.h"
 
 using namespace mrcal_amd;
@@ -286,19 +287,26 @@ bool compute_gauss_newton(mrcal_amd_problem* P, int i)
     }
 }
 
-// mrcal.c:3978-4402 markOutliers(), boards only. Returns true if new outliers
-// were marked
-bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, bool* found)
+// mrcal.c:3978-4402 markOutliers(): board corners on the GPU; the triangulated
+// pairs on the host, because the reference's pass over them is sequential (an
+// observation marked by one pair is an outlier for the pairs that follow).
+// found: new outliers were marked
+bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tri, bool* found)
 {
     *found = false;
-    const int Npts = P->D.Nobs_board * P->D.W * P->D.H;
-    if(Npts <= 0) { *Noutliers_board = 0; return true; }
+    *Noutliers_board = 0;
+    *Noutliers_tri   = 0;
+    const int Npts   = P->D.Nobs_board * P->D.W * P->D.H;
+    const int Npairs = (int)P->tri_meta_host.size();
+    if(Npts <= 0 && Npairs <= 0) return true;
     const double k0 = 4.0, k1 = 5.0;
     const double* x = P->op[P->icur].x;
     double* sums = P->op[P->icur].scalars + SC_TMP0;
 
-    auto stats = [&](double thresh_sq, int* counts, double* sum) -> bool
+    auto board_stats = [&](double thresh_sq, int* counts, double* sum) -> bool
     {
+        counts[0] = counts[1] = counts[2] = counts[3] = 0; *sum = 0.0;
+        if(Npts <= 0) return true;
         HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
         HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double), P->stream), return false);
         HIP_TRY(launch_outlier_stats(Npts, thresh_sq, x, P->d_board_pool, P->d_counts, sums, P->stream), return false);
@@ -307,22 +315,88 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, bool* found)
         memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
         return true;
     };
-    int counts[4]; double sum;
-    if(!stats(-1.0, counts, &sum)) return false;
-    const int Noutliers = counts[0];
-    const int Ninliers  = Npts - Noutliers;
-    *Noutliers_board = Noutliers;
-    if(Ninliers <= 0) return true;
-    const double var = sum / (double)(Ninliers*2);
-    if(!stats(k1*k1*var, counts, &sum)) return false;
-    if(counts[1] == 0) return true;
+    int counts[4]; double sum_board;
+    if(!board_stats(-1.0, counts, &sum_board)) return false;
+    int Nout_board = counts[0];
+    const int Nin_board = Npts - Nout_board;
 
-    HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
-    HIP_TRY(launch_mark_outliers(Npts, k0*k0*var, x, P->d_board_pool, P->d_counts, P->stream), return false);
-    HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
-    HIP_TRY(hipStreamSynchronize(P->stream), return false);
-    memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
-    *Noutliers_board = Noutliers + counts[0];
+    // triangulated pairs: divergent ones are thrown out right away
+    std::vector<double> x_tri(Npairs > 0 ? Npairs : 1), b(P->L.Nstate > 0 ? P->L.Nstate : 1);
+    std::vector<int>&   out = P->tri_outlier_host;
+    double sum_tri = 0.0;
+    int    Nin_tri = 0, Nout_tri = 0;
+    bool   marked_tri = false;
+    if(Npairs > 0)
+    {
+        HIP_TRY(hipMemcpyAsync(x_tri.data(), x + P->L.i_meas_triangulated, (size_t)Npairs*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+        HIP_TRY(hipMemcpyAsync(b.data(), P->op[P->icur].b, (size_t)P->L.Nstate*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+        HIP_TRY(hipStreamSynchronize(P->stream), return false);
+        auto rt_of = [&](int icam, double* rt) -> const double*
+        {
+            if(icam < 0) return NULL;
+            const double* s = &b[P->L.i_state_extrinsics + 6*icam];
+            for(int i=0;i<3;i++) { rt[i] = s[i]*SCALE_ROTATION_CAMERA; rt[3+i] = s[3+i]*SCALE_TRANSLATION_CAMERA; }
+            return rt;
+        };
+        for(int ip = 0; ip < Npairs; ip++)
+        {
+            const TriPairMeta& m = P->tri_meta_host[ip];
+            if(!(out[m.i0] || out[m.i1]))
+            {
+                double rt0[6], rt1[6];
+                bool convergent = true;
+                tri_pair_error<0>(&P->tri_px_host[3*m.i0], &P->tri_px_host[3*m.i1],
+                                  rt_of(m.icam_extrinsics0, rt0), rt_of(m.icam_extrinsics1, rt1), &convergent);
+                if(!convergent) { out[m.i0] = out[m.i1] = 1; marked_tri = true; }
+            }
+            if(out[m.i0] || out[m.i1]) Nout_tri++;
+            else { sum_tri += x_tri[ip]*x_tri[ip]; Nin_tri++; }
+        }
+    }
+    *Noutliers_board = Nout_board;
+    *Noutliers_tri   = Nout_tri;
+    bool any = marked_tri;
+    const int Ndenom = Nin_board*2 + Nin_tri;
+    if(Ndenom > 0)
+    {
+        const double var = (sum_board + sum_tri)/(double)Ndenom;
+        if(!any && Npts > 0)
+        {
+            double dummy;
+            if(!board_stats(k1*k1*var, counts, &dummy)) return false;
+            if(counts[1] > 0) any = true;
+        }
+        if(!any)
+            for(int ip = 0; ip < Npairs; ip++)
+            {
+                const TriPairMeta& m = P->tri_meta_host[ip];
+                if(!out[m.i0] && !out[m.i1] && x_tri[ip]*x_tri[ip] > k1*k1*var) { any = true; break; }
+            }
+        if(any)
+        {
+            if(Npts > 0)
+            {
+                HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
+                HIP_TRY(launch_mark_outliers(Npts, k0*k0*var, x, P->d_board_pool, P->d_counts, P->stream), return false);
+                HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
+                HIP_TRY(hipStreamSynchronize(P->stream), return false);
+                memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
+                *Noutliers_board = Nout_board + counts[0];
+            }
+            for(int ip = 0; ip < Npairs; ip++)
+            {
+                const TriPairMeta& m = P->tri_meta_host[ip];
+                if(!out[m.i0] && !out[m.i1] && x_tri[ip]*x_tri[ip] > k0*k0*var)
+                {
+                    out[m.i0] = out[m.i1] = 1;
+                    (*Noutliers_tri)++;
+                }
+            }
+        }
+    }
+    if(!any) return true;
+    if(Npairs > 0)
+        HIP_TRY(hipMemcpy(P->d_tri_outlier, out.data(), (size_t)(out.size()-1)*sizeof(int), hipMemcpyHostToDevice), return false);
     *found = true;
     return true;
 }
@@ -343,13 +417,14 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
 
     const auto t0 = std::chrono::steady_clock::now();
     P->stats = mrcal_amd_solver_stats();
-    int Noutliers = 0;
+    int Noutliers = 0, Noutliers_tri = 0;
     for(;;)
     {
         if(!run_dogleg(P, prm)) return -1.0;
         if(!P->L.sel.do_apply_outlier_rejection) break;
         bool found;
-        if(!mark_outliers(P, &Noutliers, &found)) return -1.0;
+        if(!mark_outliers(P, &Noutliers, &Noutliers_tri, &found)) return -1.0;
+        P->stats.Noutliers_triangulated = Noutliers_tri;
         if(!found) break;
         P->stats.Noutlier_passes++;
         fprintf(stderr, "mrcal_amd: Threw out some outliers. New count = %d/%d (%.1f%%). Going again\n",
@@ -644,7 +719,7 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
 
     stats.rms_reproj_error__pixels     = rms;
     stats.Noutliers_board              = Noutliers;
-    stats.Noutliers_triangulated_point = 0;
+    stats.Noutliers_triangulated_point = P->stats.Noutliers_triangulated;
 
  done:
     mrcal_amd_problem_destroy(P);

@@ -107,3 +107,22 @@ void hostcheck_compose_rt(double* rt_out, double* d_r_r0, double* d_r_r1, double
 void hostcheck_R_from_r(double* R, double* dR, const double* r) { R_from_r_with_grad(R, dR, r); }
 
 } // extern "C"
+
+#include "../../mrcal_amd/csrc/triangulation.hpp"
+extern "C" {
+// the triangulated-pair residual and its 12 derivatives (rt0 then rt1; a NULL rt
+// = that camera is at the reference, its 6 derivatives are returned as 0)
+double hostcheck_tri_pair_error(double* derr_drt0, double* derr_drt1, int* convergent,
+                                const double* v0, const double* v1, const double* rt0, const double* rt1)
+{
+    bool conv = true;
+    const Dual<12> e = tri_pair_error<12>(v0, v1, rt0, rt1, &conv);
+    for(int i=0;i<6;i++) { derr_drt0[i] = e.d[i]; derr_drt1[i] = e.d[6+i]; }
+    *convergent = conv ? 1 : 0;
+    // the value-only instantiation must agree
+    bool conv0 = true;
+    const Dual<0> e0 = tri_pair_error<0>(v0, v1, rt0, rt1, &conv0);
+    if(e0.x != e.x || conv0 != conv) return -12345.0;
+    return e.x;
+}
+}

@@ -1,0 +1,204 @@
+"""Triangulated-point observations: the SfM-style residual, one
+row per pair of observations of a point.
+
+CPU: mrcal_unproject() (host code of libmrcal_amd.so) against the reference's;
+     the pair residual + its 12 derivatives (host build of
+     mrcal_amd/csrc/triangulation.hpp) against the reference's callback.
+GPU: optimizer_callback() x, J, CSR structure against the reference; the solve.
+
+Scene: the shape of the reference's test/test-sfm-triangulated-points.py cut
+down: PINHOLE f=600 cameras (one at the reference), points on a plane, pixel
+noise, intrinsics locked, extrinsics optimized, unity_cam01 regularization."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from conftest import relative_error, ROOT
+from mrcal_amd._cabi import Lensmodel
+from mrcal_amd.synthetic import copy_inputs
+
+REL_TOL = 1e-6
+
+
+def R_from_r(r):
+    th = np.linalg.norm(r)
+    if th < 1e-12: return np.eye(3)
+    k = r/th
+    K = np.array(((0,-k[2],k[1]),(k[2],0,-k[0]),(-k[1],k[0],0)))
+    return np.eye(3) + np.sin(th)*K + (1-np.cos(th))*(K@K)
+
+
+def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise=0.5, Nboard_frames=0):
+    rng = np.random.RandomState(seed)
+    W, H = 4000, 2200
+    core = np.array((600., 600., (W-1)/2., (H-1)/2.))
+    if lensmodel == "LENSMODEL_PINHOLE":
+        intr = np.tile(core, (Ncam,1))
+    elif lensmodel == "LENSMODEL_OPENCV4":
+        intr = np.tile(np.r_[core, -0.01, 0.02, 1e-3, -2e-3], (Ncam,1))
+    else:
+        raise ValueError(lensmodel)
+    # camera 0 at the reference, the others ~1m apart along x, slightly rotated
+    rt_cam_ref = np.zeros((Ncam-1, 6))
+    for i in range(1, Ncam):
+        rt_cam_ref[i-1,:3] = rng.uniform(-0.05, 0.05, 3)
+        rt_cam_ref[i-1,3:] = (-1.0*i, rng.uniform(-0.1,0.1), rng.uniform(-0.1,0.1))
+    pts = np.column_stack((rng.uniform(-3, 5, Npoints), rng.uniform(-2, 2, Npoints), rng.uniform(8, 30, Npoints)))
+    obs, idx = [], []
+    for ip in range(Npoints):
+        cams = np.sort(rng.choice(Ncam, size=rng.randint(2, Ncam+1), replace=False))
+        for ic in cams:
+            p = pts[ip] if ic == 0 else R_from_r(rt_cam_ref[ic-1,:3]) @ pts[ip] + rt_cam_ref[ic-1,3:]
+            x, y = p[0]/p[2], p[1]/p[2]
+            if lensmodel == "LENSMODEL_OPENCV4":
+                k = intr[ic,4:]
+                r2 = x*x + y*y
+                cd = 1 + k[0]*r2 + k[1]*r2*r2
+                x, y = x*cd + 2*k[2]*x*y + k[3]*(r2+2*x*x), y*cd + k[2]*(r2+2*y*y) + 2*k[3]*x*y
+            q = core[:2]*np.array((x,y)) + core[2:] + rng.normal(0, noise, 2)
+            obs.append((q[0], q[1], 1.0))
+            idx.append((ip, ic, ic-1))
+    obs = np.array(obs); idx = np.array(idx, dtype=np.int32)
+    obs[5,2] = -1.      # an outlier on input
+    # seed: the truth, perturbed
+    seedrt = rt_cam_ref + rng.normal(0, 1, rt_cam_ref.shape)*np.array((0.01,0.01,0.01,0.05,0.05,0.05))
+    oi = dict(intrinsics = intr, lensmodel = lensmodel,
+              imagersizes = np.tile(np.array((W,H), dtype=np.int32), (Ncam,1)),
+              rt_cam_ref = np.ascontiguousarray(seedrt),
+              observations_point_triangulated = np.ascontiguousarray(obs),
+              indices_point_triangulated_camintrinsics_camextrinsics = np.ascontiguousarray(idx),
+              do_optimize_intrinsics_core = False, do_optimize_intrinsics_distortions = False,
+              do_optimize_extrinsics = True, do_optimize_frames = False, do_optimize_calobject_warp = False,
+              do_apply_regularization = True, do_apply_regularization_unity_cam01 = True,
+              do_apply_outlier_rejection = False, verbose = False)
+    return oi, dict(rt_cam_ref=rt_cam_ref, points=pts)
+
+
+# ------------------------------------------------------------------ CPU ---
+UNPROJECT_MODELS = [
+    ("LENSMODEL_PINHOLE",       (1512., 1112, 500., 333.)),
+    ("LENSMODEL_STEREOGRAPHIC", (1512., 1112, 500., 333.)),
+    ("LENSMODEL_LONLAT",        (1200., 1150, 500., 333.)),
+    ("LENSMODEL_LATLON",        (1200., 1150, 500., 333.)),
+    ("LENSMODEL_OPENCV4",  (1512., 1112, 500., 333., -0.012, 0.035, -0.001, 0.002)),
+    ("LENSMODEL_OPENCV8",  (1512., 1112, 500., 333., -0.012, 0.035, -0.001, 0.002, 0.019, 0.014, -0.056, 0.050)),
+    ("LENSMODEL_CAHVOR",   (4842.918, 4842.771, 1970.528, 1085.302, -0.001, 0.002, -0.637, -0.002, 0.016)),
+    ("LENSMODEL_CAHVORE_linearity=0.40", (4842.918, 4842.771, 1970.528, 1085.302, -0.001, 0.002, -0.637, -0.002, 0.016, 0., 0., 0.)),
+]
+
+
+@pytest.mark.parametrize("lensmodel,intrinsics", UNPROJECT_MODELS, ids=[m[0] for m in UNPROJECT_MODELS])
+def test_unproject_matches_reference(amd, ref_api, lensmodel, intrinsics):
+    """host code: runs without a GPU"""
+    rng = np.random.RandomState(2)
+    intr = np.array(intrinsics, dtype=float)
+    q = np.ascontiguousarray(intr[2:4] + rng.uniform(-0.6, 0.6, (200,2))*intr[:2])
+    out = []
+    for lib in (amd._lib.lib, ref_api.clib):
+        lib.mrcal_unproject.restype  = C.c_bool
+        lib.mrcal_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Lensmodel), C.c_void_p]
+        m = Lensmodel()
+        assert lib.mrcal_lensmodel_from_name(C.byref(m), lensmodel.encode())
+        v = np.zeros((q.shape[0],3))
+        assert lib.mrcal_unproject(v.ctypes.data, q.ctypes.data, q.shape[0], C.byref(m), intr.ctypes.data)
+        out.append(v / np.linalg.norm(v, axis=1, keepdims=True))   # "may have any length"
+    assert np.isfinite(out[0]).all()
+    assert np.abs(out[0] - out[1]).max() < 1e-8
+
+
+def test_pair_residual_matches_reference_cpu(ref_api):
+    """the pair residual and its derivatives (host build of triangulation.hpp)
+    against the rows the reference's callback produces. No GPU"""
+    import subprocess, os
+    from test_lens_models_host import HERE
+    so = os.path.join(HERE, "libhostcheck.so")
+    src = os.path.join(HERE, "hostcheck.cpp")
+    deps = [src] + [os.path.join(ROOT, "mrcal_amd", "csrc", f) for f in ("lens_models.hpp", "device_math.hpp", "triangulation.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-function", "-o", so, src])
+    L = C.CDLL(so)
+    L.hostcheck_tri_pair_error.restype  = C.c_double
+    L.hostcheck_tri_pair_error.argtypes = [C.c_void_p]*3 + [C.c_void_p]*4
+
+    oi, _ = sfm_problem(seed=3, noise=2.0)
+    oi["do_apply_regularization"] = False
+    oi["do_apply_regularization_unity_cam01"] = False
+    b, x, J, _ = ref_api.optimizer_callback(no_factorization=True, **oi)
+    Jd = J.toarray()
+    # the C records the reference saw: observation vectors and set structure
+    p = ref_api._ingest(dict(oi), callback=True)
+    px, flags = p.c_tri["px"], p.c_tri["flags"]
+    ice = p.c_tri["icam_extrinsics"]
+    rt = oi["rt_cam_ref"]
+    SR, ST = 0.1*np.pi/180., 1.0
+    irow = 0
+    N = len(px)
+    Nsteep = 0
+    for i0 in range(N):
+        if flags[i0] & 1: continue
+        for i1 in range(i0+1, N):
+            e0, e1 = ice[i0], ice[i1]
+            d0, d1, conv = np.zeros(6), np.zeros(6), C.c_int(0)
+            rt0 = np.ascontiguousarray(rt[e0]) if e0 >= 0 else None
+            rt1 = np.ascontiguousarray(rt[e1]) if e1 >= 0 else None
+            err = L.hostcheck_tri_pair_error(d0.ctypes.data, d1.ctypes.data, C.byref(conv),
+                                             np.ascontiguousarray(px[i0]).ctypes.data, np.ascontiguousarray(px[i1]).ctypes.data,
+                                             rt0.ctypes.data if rt0 is not None else None,
+                                             rt1.ctypes.data if rt1 is not None else None)
+            assert err != -12345.0
+            outlier = bool((flags[i0] | flags[i1]) & 2)
+            if outlier:
+                assert x[irow] == 0 and not Jd[irow].any()
+            else:
+                assert relative_error(err, x[irow]) < REL_TOL
+                scale = np.array((SR,SR,SR,ST,ST,ST))
+                if e0 >= 0: assert relative_error(d0*scale, Jd[irow, 6*e0:6*e0+6]).max() < REL_TOL
+                if e1 >= 0: assert relative_error(d1*scale, Jd[irow, 6*e1:6*e1+6]).max() < REL_TOL
+                Nsteep += 1
+            irow += 1
+            if flags[i1] & 1: break
+    assert irow == x.size and Nsteep > 50
+
+
+# ------------------------------------------------------------------ GPU ---
+@pytest.mark.gpu
+@pytest.mark.parametrize("lensmodel", ("LENSMODEL_PINHOLE", "LENSMODEL_OPENCV4"))
+def test_callback_matches_reference(amd, ref_api, lensmodel):
+    from test_callback_parity import compare_callbacks
+    oi, _ = sfm_problem(lensmodel=lensmodel, seed=1, noise=1.0)
+    for unity in (True, False):
+        oi["do_apply_regularization_unity_cam01"] = unity
+        compare_callbacks(amd.optimizer_callback(no_factorization=True, **oi),
+                          ref_api.optimizer_callback(no_factorization=True, **oi), f"{lensmodel} unity={unity}")
+    assert amd.num_measurements(**oi) == ref_api.num_measurements(**oi)
+    assert amd.num_measurements_points_triangulated(**oi) == ref_api.num_measurements_points_triangulated(**oi)
+    assert amd.measurement_index_regularization(**oi) == ref_api.measurement_index_regularization(**oi)
+
+
+@pytest.mark.gpu
+def test_divergent_rays_and_x_only(amd, ref_api):
+    """a badly wrong seed makes rays diverge: the penalty branch"""
+    from test_callback_parity import compare_callbacks
+    oi, _ = sfm_problem(seed=4, noise=0.3)
+    oi["rt_cam_ref"][1,:3] += (0.0, 0.3, 0.0)     # yaw one camera outwards
+    ra = amd.optimizer_callback(no_factorization=True, **oi)
+    rr = ref_api.optimizer_callback(no_factorization=True, **oi)
+    compare_callbacks(ra, rr, "divergent")
+    xa = amd.optimizer_callback(no_jacobian=True, no_factorization=True, **oi)[1]
+    assert relative_error(xa, rr[1]).max() < REL_TOL
+
+
+@pytest.mark.gpu
+def test_solve_matches_checker_and_truth(amd, ref_api):
+    oi, truth = sfm_problem(seed=7, noise=0.3, Npoints=80)
+    oi["do_apply_outlier_rejection"] = True
+    oa, orr = copy_inputs(oi), copy_inputs(oi)
+    sa = amd.optimize(**oa)
+    sr = ref_api.optimize(**orr)
+    assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+    assert sa["Noutliers_triangulated_point"] == sr["Noutliers_triangulated_point"]
+    assert np.abs(oa["rt_cam_ref"] - orr["rt_cam_ref"]).max() < 1e-5
+    # unity_cam01 fixes the scale: camera 1 is 1m from the reference; the
+    # geometry comes out close to the truth
+    assert abs(np.linalg.norm(oa["rt_cam_ref"][0,3:]) - 1.0) < 1e-3
+    assert np.abs(oa["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 0.01
