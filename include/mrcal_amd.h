@@ -483,6 +483,35 @@ bool  mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* problem, int io
 bool  mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* problem, int iop, double thresh_sq, int* counts_dev);
 /* which operating point get_b_packed()/get_x()/get_J() read */
 void  mrcal_amd_problem_set_current(mrcal_amd_problem_t* problem, int iop);
+int   mrcal_amd_problem_current(mrcal_amd_problem_t* problem);
+
+/* Sharded step (multi-GPU; no counterpart in the reference): one
+   device-controlled dog-leg trial step, cut where a quantity is summed over the
+   shards. Per trial step the driver queues, on the problem's stream,
+       enqueue(0,0) | all-reduce comm_buffer(0) | enqueue(0,1) | all-reduce
+       comm_buffer(1) | enqueue(0,2) | all-reduce comm_buffer(2) | enqueue(0,3) |
+       all-reduce comm_buffer(3) | enqueue(0,4)
+   and never reads anything back in between: the trust-region state is a
+   replicated control block in device memory, every rank takes the same
+   decisions from the same sums. initial=1 (segments 2,3,4 only): evaluation of
+   the starting point, after sharded_reset().
+     comm_buffer 0: [S (Nc*Nc) | r (Nc)]   this shard's summand of the Schur complement
+                 1: [NE]                   the frame/point part of the Gauss-Newton step
+                 2: [Nstate + 2]           g = Jt x, |x|^2, step^T JtJ step
+                 3: [1]                    g^T JtJ g
+   snapshot(slot)/wait(slot): a pinned copy of the control block, queued after
+   a trial step and waited for a few steps later, tells the host when the device
+   has declared the solve finished; wait() writes out[4] = { done, error,
+   Nsteps_accepted, Ntrials }. finish() drains the stream and makes the final
+   point current; out_i[5] = { Nsteps_accepted, Nevaluations, Nfactorizations,
+   Ntrials, error }, out_d[3] = { trust region, |x|^2, lambda } */
+bool  mrcal_amd_problem_sharded_reset      (mrcal_amd_problem_t* problem, int check_termination, int max_iterations,
+                                            double trustregion0);
+bool  mrcal_amd_problem_sharded_enqueue    (mrcal_amd_problem_t* problem, int initial, int segment);
+void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* problem, int segment, int64_t* Nelements);
+bool  mrcal_amd_problem_sharded_snapshot   (mrcal_amd_problem_t* problem, int slot);
+bool  mrcal_amd_problem_sharded_wait       (mrcal_amd_problem_t* problem, int slot, int* out);
+bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* out_i, double* out_d);
 
 /* The whole solve on a resident problem: dog-leg iterations + outlier
    rejection (if the problem selections ask for it), exactly what

@@ -64,7 +64,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Linv); hipFree(F.status);
-    hipFree(d_step); hipFree(d_counts); hipFree(d_ctl);
+    hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
     for(hipEvent_t e : ctl_events) hipEventDestroy(e);
@@ -113,6 +113,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
     ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
+    ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.NE + nd.Nstate + 2 + 32);
     ok = ok && dev_alloc(&P->d_counts, 4);
     if(!ok) return false;
     // rows of blocks this shard does not own are never written: they must read as 0

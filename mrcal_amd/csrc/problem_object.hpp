@@ -80,6 +80,12 @@ struct mrcal_amd_problem
     mrcal_amd::AssemblyPlan    plan = {};
     mrcal_amd::FactorBuffers   F    = {};
     double*                    d_step   = NULL;   // [Nstate]
+    // staging for the sums over shards: [NE] the E part of the Gauss-Newton
+    // step | [Nstate+2] g, |x|^2, s^T N s | [1] g^T N g
+    double*                    d_comm   = NULL;
+    double* comm_gn()    const { return d_comm; }
+    double* comm_point() const { return d_comm + ((nd.NE + 7) & ~7); }
+    double* comm_gng()   const { return comm_point() + ((nd.Nstate + 2 + 7) & ~7); }
     int*                       d_counts = NULL;   // [4]
     double*                    h_scalars = NULL;  // pinned [64]
     // device-side dog-leg control (solver_kernels.hpp): the block, and a ring

@@ -5,9 +5,10 @@
 // [unpack state, stats]. dogleg_optimize2() is libdogleg's (third party, not in
 // the reference tree): Powell's dog leg with a trust region. Its algorithm is
 // restated in oracle/dogleg_restated.c (CPU checker); THIS file is the
-// product: the same algorithm with every vector/matrix operation running on
-// the GPU (solver_kernels.hip) and only the scalar trust-region decisions on
-// the host.
+// product: the same algorithm with every vector/matrix operation AND the
+// scalar trust-region decisions on the GPU (solver_kernels.hip, "dog-leg
+// control"). The host queues trial steps (one captured hipGraph each) and
+// polls a pinned snapshot of the device's control block a few steps behind.
 //
 // mrcal's solver settings (mrcal.c:6296-6299): Jt_x_threshold 0,
 // update_threshold 1e-7, trustregion_threshold 0, max_iterations 300; the rest
@@ -591,6 +592,127 @@ bool mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* P, int iop, doub
     return true;
 }
 void mrcal_amd_problem_set_current(mrcal_amd_problem_t* P, int iop) { P->icur = iop & 1; }
+
+////////////////////////////////////////////////////////////////////////////////
+// Sharded step: the device-controlled trial step of enqueue_trial_step(), cut
+// at the four points where a quantity has to be summed over the shards. The
+// driver (mrcal_amd/parallel.py) queues   segment 0 | all-reduce buffer 0 |
+// segment 1 | all-reduce buffer 1 | ... | segment 4   on the problem's stream,
+// for as many trial steps as it likes, without ever reading anything back: the
+// control block is replicated, every rank computes the same decisions from the
+// same sums. initial: the evaluation of the starting point (segments 2..4)
+//   seg 0  step_begin, local block elimination, local Schur summand   -> [S | r]
+//   seg 1  Cholesky of the summed S (replicated), local back-substitution -> E part of step_gn
+//   seg 2  step selection, s^T N s (local part), evaluation of x, J, Gram and
+//          the block normal equations of the trial point              -> [g | |x|^2 | s^T N s]
+//   seg 3  g^T N g (local part)                                       -> g^T N g
+//   seg 4  Cauchy step of the new point, rho test, accept/reject
+////////////////////////////////////////////////////////////////////////////////
+bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_termination, int max_iterations,
+                                     double trustregion0)
+{
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return false;
+    DoglegParameters prm;
+    if(max_iterations > 0)  prm.max_iterations = max_iterations;
+    if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
+    return ctl_reset(P, prm, check_termination != 0);
+}
+
+bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int segment)
+{
+    if(!P->ctl_initialized) { set_error("mrcal_amd_problem_sharded_reset() first"); return false; }
+    SolverCtl* ctl = P->d_ctl;
+    const bool init = initial != 0;
+    const OpRef Rfrom = { P->d_ops, &ctl->ib, solver_ctl_skip_factor(ctl) };
+    const OpRef Rto   = { P->d_ops, init ? &ctl->ib : &ctl->ia, init ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
+    switch(segment)
+    {
+    case 0:
+        if(init) return true;
+        HIP_TRY(launch_step_begin(P->d_ops, ctl, P->F.status, P->stream), return false);
+        HIP_TRY(launch_factor_local(P->nd, P->br, Rfrom, P->F, 0.0, ctl, P->is_leader, P->stream), return false);
+        HIP_TRY(launch_shard_prepare_schur(P->nd, ctl, P->F, P->stream), return false);
+        return true;
+    case 1:
+        if(init) return true;
+        HIP_TRY(launch_solve_backsub(P->nd, P->br, Rfrom, P->F, NULL, false, P->stream), return false);
+        HIP_TRY(launch_shard_gn(P->nd, P->br, P->d_ops, ctl, false, P->comm_gn(), P->stream), return false);
+        return true;
+    case 2:
+        if(!init)
+        {
+            HIP_TRY(launch_shard_gn(P->nd, P->br, P->d_ops, ctl, true, P->comm_gn(), P->stream), return false);
+            HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, true), return false);
+        }
+        if(!problem_evaluate_ref(P, Rto, true, true)) return false;
+        HIP_TRY(launch_shard_point(P->nd, P->d_ops, ctl, init, false, P->comm_point(), P->stream), return false);
+        return true;
+    case 3:
+        HIP_TRY(launch_shard_point(P->nd, P->d_ops, ctl, init, true, P->comm_point(), P->stream), return false);
+        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, init, P->stream, 1), return false);
+        HIP_TRY(launch_shard_dots_g(P->nd, P->d_ops, ctl, init, P->stream), return false);
+        HIP_TRY(launch_shard_gng(P->d_ops, ctl, init, false, P->comm_gng(), P->stream), return false);
+        return true;
+    case 4:
+        HIP_TRY(launch_shard_gng(P->d_ops, ctl, init, true, P->comm_gng(), P->stream), return false);
+        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, init, P->stream, 2), return false);
+        if(!init) HIP_TRY(launch_step_accept(P->d_ops, ctl, P->stream), return false);
+        return true;
+    }
+    set_error("mrcal_amd_problem_sharded_enqueue(): segment %d", segment);
+    return false;
+}
+
+// the buffer to all-reduce (sum) after segment 0..3; Nelements may be 0
+void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* P, int segment, int64_t* Nelements)
+{
+    if(!problem_prepare_solver(P)) return NULL;
+    const NormalDims& nd = P->nd;
+    void* p = NULL; int64_t n = 0;
+    switch(segment)
+    {
+    case 0: p = P->F.S;          n = (int64_t)nd.Nc*nd.Nc + nd.Nc; break;
+    case 1: p = P->comm_gn();    n = nd.NE;         break;
+    case 2: p = P->comm_point(); n = nd.Nstate + 2; break;
+    case 3: p = P->comm_gng();   n = 1;             break;
+    default: set_error("mrcal_amd_problem_sharded_comm_buffer(): segment %d", segment);
+    }
+    if(Nelements) *Nelements = n;
+    return p;
+}
+
+// queues a copy of the control block into slot (0..7) of the pinned ring
+bool mrcal_amd_problem_sharded_snapshot(mrcal_amd_problem_t* P, int slot)
+{
+    if(!ctl_prepare(P)) return false;
+    slot = ((slot % CTL_RING) + CTL_RING) % CTL_RING;
+    HIP_TRY(hipMemcpyAsync(&P->h_ctl_ring[slot], P->d_ctl, sizeof(SolverCtl), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipEventRecord(P->ctl_events[slot], P->stream), return false);
+    return true;
+}
+// waits for that copy. out: done, error, Nsteps_accepted, Ntrials
+bool mrcal_amd_problem_sharded_wait(mrcal_amd_problem_t* P, int slot, int* out)
+{
+    slot = ((slot % CTL_RING) + CTL_RING) % CTL_RING;
+    HIP_TRY(hipEventSynchronize(P->ctl_events[slot]), return false);
+    const SolverCtl& c = P->h_ctl_ring[slot];
+    out[0] = c.done; out[1] = c.error; out[2] = c.Nsteps_accepted; out[3] = c.Ntrials;
+    return true;
+}
+// drains the stream and makes the final point current. out_i: Nsteps_accepted,
+// Nevaluations, Nfactorizations, Ntrials, error; out_d: trustregion, |x|^2, lambda
+bool mrcal_amd_problem_sharded_finish(mrcal_amd_problem_t* P, int* out_i, double* out_d)
+{
+    SolverCtl c;
+    if(!read_ctl(P, &c)) return false;
+    absorb_ctl(P, c);
+    out_i[0] = c.Nsteps_accepted; out_i[1] = c.Nevaluations; out_i[2] = c.Nfactorizations;
+    out_i[3] = c.Ntrials;         out_i[4] = c.error;
+    out_d[0] = c.trustregion;     out_d[1] = c.norm2_x[c.ib]; out_d[2] = c.lambda;
+    return true;
+}
+int mrcal_amd_problem_current(mrcal_amd_problem_t* P) { return P->icur; }
 
 // copies the (possibly outlier-marked) board observation pool back
 bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* P, mrcal_point3_t* pool_local)

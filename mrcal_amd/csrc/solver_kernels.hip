@@ -1217,6 +1217,128 @@ __global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// the sharded step: staging of what is summed over the shards
+////////////////////////////////////////////////////////////////////////////////
+// The trust-region logic runs replicated: every rank executes the same control
+// kernels on the same (all-reduced) numbers and so takes the same decisions.
+// The collectives are unconditional (a rank cannot know on the host whether
+// this trial factors or evaluates); a skipped phase contributes zeros.
+
+// [S | r] before its all-reduce. A shard whose 6x6/3x3 block factorization
+// failed poisons the first pivot, so that EVERY rank's Cholesky of the sum
+// fails and every rank voids the trial
+__global__ __launch_bounds__(256)
+void shard_prepare_schur_kernel(int n, const SolverCtlFlags* __restrict__ fl, const int* __restrict__ status,
+                                double* __restrict__ Sr)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(fl->skip_factor) { if(i < n) Sr[i] = 0.0; return; }
+    if(i == 0 && *status != 0) Sr[0] = __longlong_as_double(0x7ff8000000000000ll);
+}
+
+// the E part of the Gauss-Newton step: each shard has back-substituted its
+// own blocks [e0,e1) and [e2,e3)
+__global__ __launch_bounds__(256)
+void shard_pack_gn_kernel(NormalDims nd, int e0, int e1, int e2, int e3,
+                          const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                          const SolverCtlFlags* __restrict__ fl, double* __restrict__ comm)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= nd.NE) return;
+    const bool mine = (i >= e0 && i < e1) || (i >= e2 && i < e3);
+    comm[i] = (!fl->skip_factor && mine) ? ops[ctl->ib].step_gn[nd.Nie + i] : 0.0;
+}
+__global__ __launch_bounds__(256)
+void shard_unpack_gn_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                            const SolverCtlFlags* __restrict__ fl, const double* __restrict__ comm)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= nd.NE || fl->skip_factor) return;
+    ops[ctl->ib].step_gn[nd.Nie + i] = comm[i];
+}
+
+// [g | |x|^2 | s^T N s] of the point just evaluated (s^T N s belongs to the
+// point the step started from; it rides along)
+__global__ __launch_bounds__(256)
+void shard_pack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                             const SolverCtlFlags* __restrict__ fl, int initial, double* __restrict__ comm)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= nd.Nstate + 2) return;
+    const bool skip = !initial && fl->skip_eval;
+    const OpDev& O = ops[initial ? ctl->ib : ctl->ia];
+    double v = 0.0;
+    if(!skip)
+    {
+        if(i < nd.Nstate)       v = O.g[i];
+        else if(i == nd.Nstate) v = O.scalars[SC_NORM2_X];
+        else                    v = initial ? 0.0 : ops[ctl->ib].scalars[SC_STEP_SNS];
+    }
+    comm[i] = v;
+}
+__global__ __launch_bounds__(256)
+void shard_unpack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                               const SolverCtlFlags* __restrict__ fl, int initial, const double* __restrict__ comm)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= nd.Nstate + 2) return;
+    if(!initial && fl->skip_eval) return;
+    const OpDev& O = ops[initial ? ctl->ib : ctl->ia];
+    if(i < nd.Nstate)       O.g[i] = comm[i];
+    else if(i == nd.Nstate) O.scalars[SC_NORM2_X] = comm[i];
+    else if(!initial)       ops[ctl->ib].scalars[SC_STEP_SNS] = comm[i];
+}
+// The replicated control state must stay BIT-identical on all ranks (a rank
+// whose "done" differs would stop queueing collectives). What goes through an
+// all-reduce is identical by construction; the dot products every rank computes
+// for itself from replicated vectors must not depend on the order of atomics.
+// One workgroup, fixed reduction tree; overwrites what the atomic versions left.
+//   which 0: |step_gn|^2, step_gn.step_cauchy of ctl->ib
+//         1: g.step, |step|^2 of ctl->ib
+//         2: g.g of the point just evaluated
+__global__ __launch_bounds__(1024)
+void shard_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                       const SolverCtlFlags* __restrict__ fl, const double* __restrict__ step, int which, int initial)
+{
+    if(which == 0 && fl->skip_factor) return;
+    if(which == 1 && fl->skip_eval)   return;
+    if(which == 2 && !initial && fl->skip_eval) return;
+    const OpDev& O = ops[(which == 2 && !initial) ? ctl->ia : ctl->ib];
+    const double* __restrict__ u = (which == 0) ? O.step_gn : (which == 1) ? step : O.g;
+    const double* __restrict__ w = (which == 0) ? O.step_cauchy : O.g;
+    double a = 0.0, b = 0.0;
+    for(int i = threadIdx.x; i < n; i += 1024)
+    {
+        const double ui = u[i];
+        a += ui*ui;
+        b += ui*w[i];
+    }
+    for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    __shared__ double part[16][2];
+    if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        a = b = 0.0;
+        for(int k=0;k<16;k++) { a += part[k][0]; b += part[k][1]; }
+        if(which == 0)      { O.scalars[SC_GN_LENSQ] = a; O.scalars[SC_GN_DOT_CAUCHY] = b; }
+        else if(which == 1) { O.scalars[SC_STEP_SS]  = a; O.scalars[SC_STEP_GS] = b; }
+        else                { O.scalars[SC_G_GG]     = a; O.scalars[SC_G_GG2]   = a; }
+    }
+}
+
+// g^T N g of the point just evaluated
+__global__ void shard_gng_kernel(const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                                 const SolverCtlFlags* __restrict__ fl, int initial, int unpack, double* __restrict__ comm)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool skip = !initial && fl->skip_eval;
+    double* p = &ops[initial ? ctl->ib : ctl->ia].scalars[SC_G_GNG];
+    if(unpack) { if(!skip) *p = comm[0]; }
+    else       comm[0] = skip ? 0.0 : *p;
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
@@ -1354,26 +1476,85 @@ hipError_t launch_step_begin(const OpDev* ops, SolverCtl* ctl, int* chol_status,
     return hipGetLastError();
 }
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream)
+                              double* step, hipStream_t stream, bool deterministic)
 {
     int nb = (nd.Nstate + 255)/256; if(nb > 64) nb = 64;
-    hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
+    if(deterministic)
+        hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
+                           (const double*)step, 0, 0);
+    else
+        hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
     hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
                        nd, ops, ctl, ctl_flags(ctl), F.status, step);
     // for the expected improvement: (step^T N step, g.step, |step|^2) of ctl->ib
     OpRef Rfrom = { ops, &ctl->ib, solver_ctl_skip_eval(ctl) };
     hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
                        nd, Rfrom, step, 0, (double*)NULL, (int)SC_STEP_SNS, 3);
+    if(deterministic)
+        hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
+                           (const double*)step, 1, 0);
     return hipGetLastError();
 }
-hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)
+hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)
+{
+    hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
+                       (const double*)NULL, 2, initial ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
+                               int parts)
 {
     // (g^T N g, g.g, g.g) -> SC_G_GNG..
     OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
-    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                       nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
-    hipLaunchKernelGGL(finish_point_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0);
+    if(parts & 1)
+        hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                           nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
+    if(parts & 2)
+        hipLaunchKernelGGL(finish_point_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
+                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream)
+{
+    const int n = nd.Nc*nd.Nc + nd.Nc;
+    hipLaunchKernelGGL(shard_prepare_schur_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
+                       n, ctl_flags(ctl), F.status, F.S);
+    return hipGetLastError();
+}
+hipError_t launch_shard_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
+                           bool unpack, double* comm, hipStream_t stream)
+{
+    if(nd.NE <= 0) return hipSuccess;
+    if(unpack)
+        hipLaunchKernelGGL(shard_unpack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
+                           nd, ops, ctl, ctl_flags(ctl), comm);
+    else
+    {
+        int e[4];
+        br.e_range(nd, 0, &e[0], &e[1]);
+        br.e_range(nd, 1, &e[2], &e[3]);
+        hipLaunchKernelGGL(shard_pack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
+                           nd, e[0], e[1], e[2], e[3], ops, ctl, ctl_flags(ctl), comm);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                              bool unpack, double* comm, hipStream_t stream)
+{
+    const int n = nd.Nstate + 2;
+    if(unpack)
+        hipLaunchKernelGGL(shard_unpack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
+                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
+    else
+        hipLaunchKernelGGL(shard_pack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
+                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
+    return hipGetLastError();
+}
+hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream)
+{
+    hipLaunchKernelGGL(shard_gng_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl),
+                       initial ? 1 : 0, unpack ? 1 : 0, comm);
     return hipGetLastError();
 }
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream)

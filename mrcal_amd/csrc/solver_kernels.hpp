@@ -135,9 +135,20 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
 //   begin -> [factor_local, solve_backsub] -> choose -> [evaluate, assemble] -> finish_point -> accept
 hipError_t launch_step_begin (const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream);
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream);
+                              double* step, hipStream_t stream,
+                              bool deterministic = false);
 // |g|^2, g N g, the Cauchy step of the point just evaluated (ctl->ia, or ctl->ib if initial)
-hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
+// parts: 1 = the reduction g^T N g, 2 = the Cauchy step + bookkeeping
+hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
+                               int parts = 3);
+// the sharded step: staging around the collectives (see solver_kernels.hip)
+hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream);
+hipError_t launch_shard_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
+                           bool unpack, double* comm, hipStream_t stream);
+hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                              bool unpack, double* comm, hipStream_t stream);
+hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
+hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream);
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
 
 // solves against a kept factorization (F as left by launch_factor_local() +

@@ -1,5 +1,5 @@
-"""The N>1 control flow (mrcal_amd/parallel.py) on CPU: world_size 2 and 3 over
-gloo, with a numpy shard standing in for the GPU phase kernels. The numpy shard
+"""The N>1 flow (mrcal_amd/parallel.py) on CPU: world_size 2 and 3 over gloo,
+with a numpy shard standing in for the GPU's sharded-step kernels. The numpy shard
 gets its x and J from the CPU checker (the reference's own optimizer_callback,
 oracle/_ref), keeps only the rows of ITS frames, and does the block algebra
 densely. Checked:
@@ -11,6 +11,7 @@ densely. Checked:
     is identical up to summation order)
 """
 import contextlib
+import math
 import os
 import sys
 import numpy as np
@@ -37,7 +38,9 @@ def test_partition_frames():
 
 
 class NumpyShard:
-    """CPU stand-in for GpuShard (same interface), for ONE rank"""
+    """CPU stand-in for GpuShard (same interface), for ONE rank: the segments
+    of the sharded trial step in numpy, the device-side control kernels
+    (csrc/solver_kernels.hip, "dog-leg control") restated in Python"""
     def __init__(self, ref_api, oi, frame_range, is_leader):
         import torch
         self.torch, self.api, self.oi = torch, ref_api, oi
@@ -65,28 +68,212 @@ class NumpyShard:
         if is_leader:
             rows = np.concatenate((rows, np.arange(Nboard_rows, self.Nmeas_global)))
         self.rows = rows
-        self.bufs = {}
-        self.N = [None, None]
-        self.xs = [None, None]
+        z = lambda n: np.zeros(n)
+        self.op = [dict(b=z(self.Nstate), g=z(self.Nstate), N=None, x=None, norm2_x=0.0, gNg=0.0, gg=0.0,
+                        step_cauchy=z(self.Nstate), step_gn=z(self.Nstate),
+                        gn_lensq=0.0, gn_dot_cauchy=0.0, sNs=0.0, gs=0.0) for _ in range(2)]
+        self.comm = [torch.zeros(self.Nc*self.Nc + self.Nc, dtype=torch.float64),
+                     torch.zeros(self.NE, dtype=torch.float64),
+                     torch.zeros(self.Nstate + 2, dtype=torch.float64),
+                     torch.zeros(1, dtype=torch.float64)]
+        self.step = z(self.Nstate)
         self.current = 0
+        self.lam = 0.0
+        self.ring = [None]*8
+        self.Nsegments_run = 0
         # the seed
-        b0 = ref_api.optimizer_callback(no_jacobian=True, no_factorization=True, **oi)[0]
-        self.vec("b", 0)[:] = torch.from_numpy(b0)
+        self.op[0]["b"][:] = ref_api.optimizer_callback(no_jacobian=True, no_factorization=True, **oi)[0]
 
     def context(self):
         return contextlib.nullcontext()
-    def new_buffer(self, n):
-        return self.torch.zeros(n, dtype=self.torch.float64)
-    def vec(self, name, iop):
-        sizes = dict(b=self.Nstate, g=self.Nstate, step_cauchy=self.Nstate, step_gn=self.Nstate,
-                     scalars=8, step=self.Nstate, schur=self.Nc*self.Nc+self.Nc, status=1)
-        key = (name, iop if name not in ("step", "schur", "status") else 0)
-        if key not in self.bufs:
-            dt = self.torch.int32 if name == "status" else self.torch.float64
-            self.bufs[key] = self.torch.zeros(sizes[name], dtype=dt)
-        return self.bufs[key]
-    def set_current(self, iop):
-        self.current = iop
+    def b_current(self):
+        return self.op[self.current]["b"].copy()
+
+    # ---- the interface ---------------------------------------------------
+    def reset(self, check_termination, max_iterations, trustregion0):
+        self.ctl = dict(done=0, error=0, check=int(bool(check_termination)), maxit=max_iterations,
+                        tr=float(trustregion0), lam=self.lam, ib=self.current, ia=1-self.current,
+                        Nsteps_accepted=0, Ntrials=0, Nfactorizations=0, Nevaluations=0,
+                        norm2_x=[0.0,0.0], cauchy_lensq=[0.0,0.0], gn_valid=[0,0], gn_lensq=[0.0,0.0],
+                        edge=[0,0], need_gn=0, step_len_sq=0.0)
+        self.skip_factor = self.skip_eval = 0
+        self.status = 0
+    def comm_buffer(self, segment):
+        return self.comm[segment] if self.comm[segment].numel() else None
+    def snapshot(self, slot):
+        self.ring[slot] = dict(self.ctl)
+    def wait(self, slot):
+        return self.ring[slot]
+    def finish(self):
+        c = self.ctl
+        self.current = c["ib"]
+        self.lam     = c["lam"]
+        return dict(Nsteps_accepted=c["Nsteps_accepted"], Nevaluations=c["Nevaluations"],
+                    Nfactorizations=c["Nfactorizations"], Ntrials=c["Ntrials"], error=c["error"],
+                    trustregion=c["tr"], norm2_x=c["norm2_x"][c["ib"]], lambda_=c["lam"])
+    def enqueue(self, initial, seg):
+        self.Nsegments_run += 1
+        getattr(self, f"_seg{seg}")(bool(initial))
+
+    # ---- segments ---------------------------------------------------------
+    def _seg0(self, initial):
+        if initial: return
+        c = self.ctl
+        # step_begin_kernel
+        self.status = 0
+        O = self.op[c["ib"]]
+        O["sNs"] = O["gs"] = 0.0
+        if not c["done"] and c["check"] and c["Nsteps_accepted"] >= c["maxit"]:
+            c["done"] = 1
+        if c["done"]:
+            self.skip_factor = self.skip_eval = 1
+            c["need_gn"] = 0
+        else:
+            cauchy_only = c["cauchy_lensq"][c["ib"]] >= c["tr"]**2
+            c["need_gn"] = int(not cauchy_only and not c["gn_valid"][c["ib"]])
+            if c["need_gn"]: c["Nfactorizations"] += 1
+            self.skip_factor = 0 if c["need_gn"] else 1
+            self.skip_eval   = 0
+        Sr = self.comm[0].numpy()
+        if self.skip_factor:
+            Sr[:] = 0.0
+            return
+        self._factor_local(c["ib"], c["lam"], Sr)
+        if self.status: Sr[0] = np.nan
+
+    def _seg1(self, initial):
+        if initial: return
+        out = self.comm[1].numpy()
+        out[:] = 0.0
+        if self.skip_factor: return
+        c  = self.ctl
+        O  = self.op[c["ib"]]
+        Sr = self.comm[0].numpy()
+        S  = Sr[:self.Nc*self.Nc].reshape(self.Nc, self.Nc)
+        r  = Sr[self.Nc*self.Nc:]
+        ok = np.all(np.isfinite(S))
+        if ok:
+            try:    np.linalg.cholesky(S)
+            except np.linalg.LinAlgError: ok = False
+        if not ok:
+            self.status = 1
+            ds = np.full(self.Nc, np.nan)
+        else:
+            ds = -np.linalg.solve(S, r)
+        O["step_gn"][self.sidx] = ds
+        for e, B, Dinv in self.fact:
+            v = -Dinv @ (O["g"][e] + B.T @ ds)
+            O["step_gn"][e] = v
+            out[e - self.Nie] = v
+
+    def _seg2(self, initial):
+        c = self.ctl
+        if not initial:
+            ib, ia = c["ib"], c["ia"]
+            O = self.op[ib]
+            if not self.skip_factor:
+                O["step_gn"][self.Nie:self.Nie+self.NE] = self.comm[1].numpy()
+                O["gn_lensq"]      = float(O["step_gn"] @ O["step_gn"])
+                O["gn_dot_cauchy"] = float(O["step_gn"] @ O["step_cauchy"])
+            self._step_choose()
+            if not self.skip_eval:
+                O["sNs"] = float(self.step @ O["N"] @ self.step)     # local part
+                O["gs"]  = float(O["g"] @ self.step)
+        ip = c["ib"] if initial else c["ia"]
+        out = self.comm[2].numpy()
+        if not initial and self.skip_eval:
+            out[:] = 0.0
+            return
+        self._evaluate(ip)
+        P = self.op[ip]
+        out[:self.Nstate]  = P["g"]
+        out[self.Nstate]   = P["norm2_x"]
+        out[self.Nstate+1] = 0.0 if initial else self.op[c["ib"]]["sNs"]
+
+    def _seg3(self, initial):
+        c = self.ctl
+        out = self.comm[3].numpy()
+        if not initial and self.skip_eval:
+            out[0] = 0.0
+            return
+        P  = self.op[c["ib"] if initial else c["ia"]]
+        v  = self.comm[2].numpy()
+        P["g"][:]    = v[:self.Nstate]
+        P["norm2_x"] = float(v[self.Nstate])
+        if not initial: self.op[c["ib"]]["sNs"] = float(v[self.Nstate+1])
+        P["gNg"] = float(P["g"] @ P["N"] @ P["g"])                   # local part
+        P["gg"]  = float(P["g"] @ P["g"])
+        out[0] = P["gNg"]
+
+    def _seg4(self, initial):
+        c = self.ctl
+        if not initial and self.skip_eval: return
+        ip = c["ib"] if initial else c["ia"]
+        P  = self.op[ip]
+        P["gNg"] = float(self.comm[3][0])
+        # finish_point_kernel
+        k = -P["gg"]/P["gNg"] if P["gNg"] > 0.0 else 0.0
+        P["step_cauchy"][:] = k*P["g"]
+        c["norm2_x"][ip]      = P["norm2_x"]
+        c["cauchy_lensq"][ip] = k*k*P["gg"]
+        c["gn_valid"][ip]     = 0
+        c["edge"][ip]         = 0
+        c["Nevaluations"]    += 1
+        if initial: return
+        # step_accept_kernel
+        ib, ia = c["ib"], c["ia"]
+        expected = -2.0*self.op[ib]["gs"] - self.op[ib]["sNs"]
+        rho = (c["norm2_x"][ib] - c["norm2_x"][ia])/expected
+        if rho < 0.25:                  c["tr"] *= 0.1
+        elif rho > 0.75 and c["edge"][ib]: c["tr"] *= 2.0
+        if rho > 0.0:
+            c["ib"], c["ia"] = ia, ib
+            c["Nsteps_accepted"] += 1
+        elif c["check"] and (c["tr"] < 0.0 or c["tr"] == 0.0 or c["tr"] != c["tr"]):
+            c["done"] = 1
+
+    # ---- pieces -----------------------------------------------------------
+    def _step_choose(self):
+        c = self.ctl
+        if c["done"]: return
+        ib, ia = c["ib"], c["ia"]
+        O = self.op[ib]
+        fresh = bool(c["need_gn"])
+        if fresh and (self.status != 0 or not np.isfinite(O["gn_lensq"])):
+            lam = 1e-10 if c["lam"] == 0.0 else c["lam"]*10.0
+            c["lam"] = lam
+            if not lam < 1e30:
+                c["error"] = c["done"] = 1
+            self.skip_eval = 1
+            return
+        tr, dsq = c["tr"], c["tr"]**2
+        norm2a = c["cauchy_lensq"][ib]
+        if norm2a >= dsq:
+            kc, kg, len_sq, edge = tr/math.sqrt(norm2a), 0.0, dsq, 1
+        else:
+            norm2b = O["gn_lensq"] if fresh else c["gn_lensq"][ib]
+            ab     = O["gn_dot_cauchy"]
+            if norm2b <= dsq:
+                kc, kg, len_sq, edge = 0.0, 1.0, norm2b, 0
+            else:
+                l2    = norm2a - 2.0*ab + norm2b
+                neg_c = norm2a - ab
+                disc  = max(neg_c*neg_c - l2*(norm2a - dsq), 0.0)
+                k     = (neg_c + math.sqrt(disc))/l2
+                kc, kg = 1.0-k, k
+                len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b
+                edge = 1
+            if fresh:
+                c["gn_lensq"][ib] = norm2b
+                c["gn_valid"][ib] = 1
+        self.step[:] = kc*O["step_cauchy"] + (kg*O["step_gn"] if kg != 0.0 else 0.0)
+        self.op[ia]["b"][:] = O["b"] + self.step
+        c["step_len_sq"] = len_sq
+        c["edge"][ib] = edge
+        c["Ntrials"] += 1
+        if c["check"] and len_sq < 1e-7**2:
+            c["done"] = 1
+            self.skip_eval = 1
 
     def inputs_at(self, b):
         """optimization_inputs with the state b (all variables optimized)"""
@@ -100,31 +287,23 @@ class NumpyShard:
         oi["calobject_warp"] = np.ascontiguousarray(u[self.iwarp:self.iwarp+2])
         return oi
 
-    def evaluate(self, iop):
-        b = self.vec("b", iop).numpy()
-        _, x, J, _ = self.api.optimizer_callback(no_factorization=True, **self.inputs_at(b))
+    def _evaluate(self, iop):
+        O = self.op[iop]
+        _, x, J, _ = self.api.optimizer_callback(no_factorization=True, **self.inputs_at(O["b"]))
         Jl = J[self.rows].toarray()
         xl = x[self.rows]
-        self.xs[iop] = x
-        self.N[iop] = Jl.T @ Jl
-        self.vec("g", iop)[:] = self.torch.from_numpy(Jl.T @ xl)
-        sc = self.vec("scalars", iop)
-        sc.zero_()
-        sc[0] = float(xl @ xl)
-    def quadform(self, iop, v, out):
-        vn = v.numpy()
-        out += float(vn @ self.N[iop] @ vn)
-    def _local_E(self):
-        return np.concatenate([self.Nie + 6*f + np.arange(6) for f in range(self.f0, self.f1)]).astype(int) \
-            if self.f1 > self.f0 else np.zeros((0,), dtype=int)
-    def factor_local(self, iop, lam):
-        N, g = self.N[iop], self.vec("g", iop).numpy()
+        O["x"] = x
+        O["N"] = Jl.T @ Jl
+        O["g"][:] = Jl.T @ xl
+        O["norm2_x"] = float(xl @ xl)
+
+    def _factor_local(self, iop, lam, Sr):
+        N, g = self.op[iop]["N"], self.op[iop]["g"]
         S = N[np.ix_(self.sidx, self.sidx)].copy()
         r = np.zeros(self.Nc)
         if self.is_leader:
             S += lam*np.eye(self.Nc)
             r += g[self.sidx]
-        status = 0
         self.fact = []
         for f in range(self.f0, self.f1):
             e = self.Nie + 6*f + np.arange(6)
@@ -133,39 +312,22 @@ class NumpyShard:
             try:
                 np.linalg.cholesky(D)
             except np.linalg.LinAlgError:
-                status = 1
+                self.status = 1
                 D = np.eye(6)
             Dinv = np.linalg.inv(D)
             S -= B @ Dinv @ B.T
             r -= B @ Dinv @ g[e]
             self.fact.append((e, B, Dinv))
-        sr = self.vec("schur", 0).numpy()
-        sr[:self.Nc*self.Nc] = S.ravel()
-        sr[self.Nc*self.Nc:] = r
-        self.vec("status", 0)[0] = status
-    def solve_backsub(self, iop):
-        sr = self.vec("schur", 0).numpy()
-        S = sr[:self.Nc*self.Nc].reshape(self.Nc, self.Nc)
-        r = sr[self.Nc*self.Nc:]
-        g = self.vec("g", iop).numpy()
-        gn = self.vec("step_gn", iop).numpy()
-        gn[:] = 0
-        try:
-            np.linalg.cholesky(S)
-            ds = -np.linalg.solve(S, r)
-        except np.linalg.LinAlgError:
-            self.vec("status", 0)[0] = 1
-            ds = np.zeros(self.Nc)
-        gn[self.sidx] = ds
-        for e, B, Dinv in self.fact:
-            gn[e] = -Dinv @ (g[e] + B.T @ ds)
-    def _local_corners(self, iop):
-        x = self.xs[iop]
+        Sr[:self.Nc*self.Nc] = S.ravel()
+        Sr[self.Nc*self.Nc:] = r
+
+    def _local_corners(self):
+        x = self.op[self.current]["x"]
         pool = self.oi["observations_board"].reshape(-1,3)
         idx = (self.local_obs[:,None]*self.HW + np.arange(self.HW)[None,:]).ravel()
         return idx, x[2*idx], x[2*idx+1], pool
-    def outlier_stats(self, iop, thresh_sq):
-        idx, dx, dy, pool = self._local_corners(iop)
+    def outlier_stats(self, thresh_sq):
+        idx, dx, dy, pool = self._local_corners()
         w = pool[idx,2]
         inl = w > 0
         nbig = 0
@@ -173,8 +335,8 @@ class NumpyShard:
             nbig = int(np.count_nonzero(inl & ((dx*dx > thresh_sq) | (dy*dy > thresh_sq))))
         return self.torch.tensor([float(np.count_nonzero(~inl)), float(nbig),
                                   float(np.sum((dx*dx + dy*dy)[inl]))], dtype=self.torch.float64)
-    def mark_outliers(self, iop, thresh_sq):
-        idx, dx, dy, pool = self._local_corners(iop)
+    def mark_outliers(self, thresh_sq):
+        idx, dx, dy, pool = self._local_corners()
         m = (pool[idx,2] > 0) & ((dx*dx > thresh_sq) | (dy*dy > thresh_sq))
         pool[idx[m],2] *= -1.   # in the caller's array, like the reference
         return self.torch.tensor([float(np.count_nonzero(m))], dtype=self.torch.float64)
@@ -199,7 +361,7 @@ def _worker(rank, world, port, seed, out_path):
     shard  = NumpyShard(ref, oi, ranges[rank], rank == 0)
     dl     = ShardedDogleg(shard, Communicator())
     stats  = dl.solve()
-    b      = shard.vec("b", dl.ib).numpy().copy()
+    b      = shard.b_current()
     # every rank must hold the same state
     if world > 1:
         tb = torch.from_numpy(b.copy())

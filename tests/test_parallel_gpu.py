@@ -1,8 +1,10 @@
 """The multi-GPU driver (mrcal_amd/parallel.py) on real hardware, as far as one
 GPU allows:
-  - world 1: GpuShard + the Python dog-leg loop == the C++ single-GPU solver
+  - world 1: GpuShard + the segmented, device-controlled step == the C++ single-GPU solver
   - world 2 on ONE device over gloo (RCCL refuses two ranks per device): the
-    frame-sharded phase kernels + the collectives == the single-GPU solve
+    frame-sharded kernels + the four collectives per trial step == the
+    single-GPU solve, with bit-identical replicated state on both ranks
+  - run_steps() continues where the previous call stopped
 """
 import os
 import sys
@@ -51,6 +53,13 @@ def _worker(rank, world, port, out_path):
     sp = ShardedProblem(**oi)
     st = sp.solve()
     b  = sp.b_packed()
+    # the replicated control state and the state vector must be BIT-identical on all ranks
+    tb = torch.from_numpy(np.stack((b, -b)))
+    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+    assert np.array_equal(tb[0].numpy(), b) and np.array_equal(-tb[1].numpy(), b), "ranks disagree on the solution"
+    ti = torch.tensor([st["Niterations"], -st["Niterations"], st["Nevaluations"], -st["Nevaluations"]])
+    dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+    assert ti[0] == -ti[1] and ti[2] == -ti[3], "ranks disagree on the iteration counts"
     if rank == 0:
         np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], Noutliers=st["Noutliers_board"],
                  Ncollectives=st.get("Ncollectives", sp.comm.Ncollectives), frames=np.array(sp.frame_range))
@@ -79,3 +88,23 @@ def test_world2_sharded_on_one_device_matches_single(amd, tmp_path):
     assert abs(float(r["rms"]) - s1["rms_reproj_error__pixels"]) < 1e-8
     assert np.abs(r["b"] - b1).max() < 2e-5
     assert int(r["Ncollectives"]) > 0
+
+
+def test_run_steps_continues(amd):
+    from mrcal_amd.parallel import ShardedProblem
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.synthetic import copy_inputs
+    oi = _problem(amd._api)
+    sp = ShardedProblem(**copy_inputs(oi))
+    n, tr = sp.run_steps(3, None)
+    assert n == 3 and tr > 0
+    n, tr = sp.run_steps(4, tr)
+    st = sp.solver_stats()
+    sp.close()
+    with Problem(**copy_inputs(oi)) as p:
+        _, tr1 = p.run_steps(7, None)
+        s1 = p.solver_stats()
+    assert n == 4
+    assert st["Nevaluations"] == s1["Nevaluations"] == 8          # the seed + 7 trial points
+    assert abs(st["norm2_x"] - s1["norm2_x"]) < 1e-6*s1["norm2_x"]
+    assert tr == tr1
