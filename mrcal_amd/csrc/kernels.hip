@@ -26,6 +26,7 @@
 // The CSR structure (rowptr, colidx) never changes between evaluations, so it
 // is produced once by the *_structure kernels at problem creation.
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "problem.hpp"
 #include "device_math.hpp"
 #include "lens_models.hpp"
@@ -243,32 +244,215 @@ void board_prologue_kernel(DeviceProblem P, OpRef R, double* __restrict__ joint)
 // staged in LDS up front, the intrinsics were unpacked by the prologue kernel.
 // The stores are fire-and-forget.
 
-// CSR column c of a board row with image coordinate xy -> tile column
+// CSR column c of a board row with image coordinate xy -> tile column. A
+// chain of selects on wave-uniform boundaries: no divergent branches
 __device__ __forceinline__
 int board_csr_to_tile_col(const DeviceProblem& P, bool has_ext, int c, int xy)
 {
-    if(P.Ncore_state)
-    {
-        if(c < 2) return 2*c + xy;      // f, then c, of this row's own coordinate
-        c -= 2;
-    }
-    if(c < P.Ndist_state) return 4 + c;
-    c -= P.Ndist_state;
-    if(has_ext)
-    {
-        if(c < 6) return tile_ext0(P.Ndist) + c;
-        c -= 6;
-    }
-    if(P.do_optimize_frames)
-    {
-        if(c < 6) return tile_frame0(P.Ndist) + c;
-        c -= 6;
-    }
-    return tile_warp0(P.Ndist) + c;
+    const int b1 = P.Ncore_state ? 2 : 0;                   // f, then c, of this row's own coordinate
+    const int b2 = b1 + P.Ndist_state;
+    const int b3 = b2 + (has_ext ? 6 : 0);
+    const int b4 = b3 + (P.do_optimize_frames ? 6 : 0);
+    int col = tile_warp0(P.Ndist) + (c - b4);
+    col = (c < b4) ? tile_frame0(P.Ndist) + (c - b3) : col;
+    col = (c < b3) ? tile_ext0(P.Ndist)   + (c - b2) : col;
+    col = (c < b2) ? 4 + (c - b1)                    : col;
+    col = (c < b1) ? 2*c + xy                        : col;
+    return col;
 }
 
+// rotation within each 16-lane row: lane i takes the value of lane (i - N) mod 16
+// (measured, tools/exp/dpp_ror_probe.hip)
+template<int N>
+__device__ __forceinline__ double row_ror_f64(double v)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    // bound_ctrl with full row/bank masks: no lane keeps its old value, so the
+    // destination needs no initialization
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x120 + N, 0xf, 0xf, true);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x120 + N, 0xf, 0xf, true);
+    return u.d;
+}
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) d2_t   gdouble2;
+
+// tile[a] and tile[a + 16 doubles] in one DS instruction; the caller waits (lgkmcnt)
+typedef double gram_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gram_d2 lds_read2_b64_16(unsigned lds_byte_address)
+{
+    gram_d2 v;
+    asm volatile("ds_read2_b64 %0, %1 offset1:16" : "=v"(v) : "v"(lds_byte_address) : "memory");
+    return v;
+}
+
+// Copy-out of a FULL half-tile (64 rows) whose rows have K nonzeros, K even and
+// known at compile time: a lane owns one pair of CSR columns and every R-th
+// row, R = 64/(K/2) rows per wave instruction. Two row steps (2R rows) keep the
+// row parity of a lane fixed, so its four LDS byte offsets (two columns for
+// each of its two rows per double step) are loop invariants (A0,A1: row rsub;
+// B0,B1: row rsub+R) and everything else folds into immediate offsets: no
+// address arithmetic, no selects in the loop. 4 rows per lane are in flight
+template<int K, int KS>
+__device__ __forceinline__
+void copy_out_full(const double* __restrict__ tile, gdouble* __restrict__ out,
+                   int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
+{
+    constexpr int PAIRS = K/2, R = 64/PAIRS;
+    constexpr int NIT   = (64 + 2*R - 1)/(2*R);       // double steps
+    const char* __restrict__ t = reinterpret_cast<const char*>(tile);
+#pragma unroll
+    for(int it0 = 0; it0 < NIT; it0 += 2)
+    {
+        d2_t v[4];
+#pragma unroll
+        for(int q=0;q<4;q++)
+        {
+            const int it = it0 + (q >> 1), u = q & 1;
+            const int rb = it*2*R + u*R;                // first row of this wave instruction
+            if(it >= NIT || rb >= 64) continue;
+            const int o  = it*2*R*KS*(int)sizeof(double);
+            v[q].x = *reinterpret_cast<const double*>(t + (u ? B0 : A0) + o);
+            v[q].y = *reinterpret_cast<const double*>(t + (u ? B1 : A1) + o);
+        }
+#pragma unroll
+        for(int q=0;q<4;q++)
+        {
+            const int it = it0 + (q >> 1), u = q & 1;
+            const int rb = it*2*R + u*R;
+            if(it >= NIT || rb >= 64) continue;
+            gdouble* __restrict__ o = out + rb*K;       // wave-uniform
+            if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v[q];
+            else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v[q];
+        }
+    }
+}
+
+// the MFMAs of one Gram k-step, candidates resolved at compile time (problem.hpp)
+template<int NBLK, int MM> struct GramCand
+{
+    static constexpr int c  = gram_cand(NBLK, MM);
+    static constexpr int gA = (c < 3) ? 0 : (c < 6) ? 1 : 0;
+    static constexpr int gB = (c < 3) ? 0 : 1;
+    static constexpr int r  = (c < 3) ? c : (c < 6) ? c - 3 : c - 6;
+};
+template<int NBLK, int NACC, int... MM>
+__device__ __forceinline__ void gram_mfmas(double (&acc)[NACC], const double (&op)[2][4], std::integer_sequence<int, MM...>)
+{
+    ((acc[MM] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[GramCand<NBLK,MM>::gA][0],
+                                                   op[GramCand<NBLK,MM>::gB][GramCand<NBLK,MM>::r],
+                                                   acc[MM], 0, 0, 0)), ...);
+}
+
+// ---- explicit DS instructions and waits for the fused Gram + copy-out path
+template<int OFF>
+__device__ __forceinline__ double lds_read_b64_at(unsigned lds_byte_address)
+{
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "n"(OFF) : "memory");
+    return v;
+}
+
+// One k-step of the Gram on operands (x16, y16): rotations + MFMAs
+template<int NBLK, int NM>
+__device__ __forceinline__ void gram_step_ops(double (&acc)[NM], double x16, double y16)
+{
+    double op[2][4];    // [group][slot rotation]
+    op[0][0] = x16;
+    op[1][0] = y16;
+#pragma unroll
+    for(int g=0; g<2; g++)
+    {
+        op[g][1] = row_ror_f64<12>(op[g][0]);
+        op[g][2] = row_ror_f64<8 >(op[g][0]);
+        op[g][3] = row_ror_f64<4 >(op[g][0]);
+    }
+    gram_mfmas<NBLK>(acc, op, std::make_integer_sequence<int, NM>{});
+}
+
+// Step S of the fused loop over a FULL half-tile (64 rows = 16 k-steps) with K
+// nonzeros per row (K even, compile time). The MFMAs of a k-step keep the
+// FP64 pipe busy for ~160 cycles during which the wave can issue anything else:
+// the copy-out of row group S (R = 64/(K/2) rows, one wave-wide 16 B/lane store)
+// rides in that shadow. Every LDS instruction and wait here is explicit:
+//     request the Gram operands of step S+1
+//     request this lane's two tile values of row group S
+//     rotations + MFMAs of step S                       (operands waited for at the end of step S-1)
+//     wait for everything requested; store row group S
+// Lanes past the last whole row of a group (64 % (K/2) of them) repeat the
+// work of the first lanes: same address, same data.
+template<int S, int NBLK, int K, int KS, int NM>
+__device__ __forceinline__
+void fused_step(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile_a0,
+                gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
+{
+    constexpr int PAIRS = K/2, R = 64/PAIRS, NGRP = (64 + R - 1)/R;
+    constexpr bool have_grp = S < NGRP;
+    constexpr int  u  = S & 1;
+    constexpr int  go = (S >> 1)*2*R*KS*(int)sizeof(double);         // LDS byte offset of the group's double step
+    constexpr int  rb = S*R;                                          // its first row
+    gram_d2 nxt = cur;
+    if(S < 15)
+    {
+        constexpr int so = (S < 15 ? S+1 : 0)*4*KS*(int)sizeof(double);
+        nxt.x = lds_read_b64_at<so>(gram_a0);
+        nxt.y = lds_read_b64_at<so + 16*(int)sizeof(double)>(gram_a0);
+    }
+    d2_t v = {0.0, 0.0};
+    if(have_grp)
+    {
+        v.x = lds_read_b64_at<go>(tile_a0 + (unsigned)(u ? B0 : A0));
+        v.y = lds_read_b64_at<go>(tile_a0 + (unsigned)(u ? B1 : A1));
+    }
+    if(S == 0)
+        // the only wait for Gram operands: 4 requests are younger than step 0's
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    gram_step_ops<NBLK>(acc, cur.x, cur.y);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt), "+v"(v) :: "memory");
+    if(have_grp)
+    {
+        gdouble* __restrict__ o = out + rb*K;       // wave-uniform
+        if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+        else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur = nxt;
+}
+template<int NBLK, int K, int KS, int NM, int... S>
+__device__ __forceinline__
+void fused_steps(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile_a0,
+                 gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub,
+                 std::integer_sequence<int, S...>)
+{
+    (fused_step<S,NBLK,K,KS>(acc, cur, gram_a0, tile_a0, out, A0, A1, B0, B1, gofs, rsub), ...);
+}
+template<int NBLK, int K, int KS, int NM>
+__device__ __forceinline__
+void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, int goff,
+                     gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
+{
+    const unsigned tile_a0 = (unsigned)(size_t)tile;
+    const unsigned gram_a0 = tile_a0 + (unsigned)(goff*sizeof(double));
+    gram_d2 cur;
+    cur.x = lds_read_b64_at<0>(gram_a0);
+    cur.y = lds_read_b64_at<16*(int)sizeof(double)>(gram_a0);
+    fused_steps<NBLK,K,KS>(acc, cur, gram_a0, tile_a0, out, A0, A1, B0, B1, gofs, rsub,
+                           std::make_integer_sequence<int, 16>{});
+}
+
+#ifdef BOARD_TS
+#define TS(i) do { ts[i] = clock64(); } while(0)
+#define TSACC(i, t0) do { const long long _t = clock64(); ts[i] += _t - (t0); (t0) = _t; } while(0)
+#else
+#define TS(i)
+#define TSACC(i, t0)
+#endif
+
 template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void board_kernel(DeviceProblem P,
                   OpRef R,
                   const double* __restrict__ joint,
@@ -276,8 +460,11 @@ void board_kernel(DeviceProblem P,
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if(opref_skip(R)) return;
-    double* __restrict__ x  = opref_get(R).x;
-    double* __restrict__ Jv = opref_get(R).Jv;
+    // the output pointers come out of a table in memory: say that they are
+    // global, or every store becomes a FLAT store (which also counts against the
+    // LDS counter and stalls the LDS waits)
+    gdouble* __restrict__ x  = (gdouble*)opref_get(R).x;
+    gdouble* __restrict__ Jv = (gdouble*)opref_get(R).Jv;
 
     constexpr int EXT0   = 4 + NDIST;
     constexpr int FRAME0 = EXT0 + 6;
@@ -287,13 +474,18 @@ void board_kernel(DeviceProblem P,
     constexpr int NBLK   = (NCOLS + 3)/4;
     constexpr int NCOLS4 = 4*NBLK;              // columns written per row, incl. the zero padding
     constexpr int KS     = NCOLS4 | 1;          // odd LDS row stride
-    constexpr int NPAIRS = NBLK*(NBLK+1)/2;
-    constexpr int NM     = (NPAIRS + 3)/4;      // MFMAs per k-step
+    constexpr int NG     = gram_ngroups(NBLK);  // 16-column groups of the tile
+    constexpr int NM     = gram_nmfma_blk(NBLK); // accumulators (problem.hpp)
+    static_assert(NBLK <= 8, "the Gram scheme covers 32 tile columns");
 
     const int iobs = blockIdx.x;
     const int lane = threadIdx.x;
+#ifdef BOARD_TS
+    long long ts[8] = {0,0,0,0,0,0,0,0};
+    TS(0);
+#endif
     const BoardObsMeta m = P.board_meta[iobs];
-    const double* __restrict__ jp = joint + (size_t)iobs*JOINT_STRIDE;
+    const double* __restrict__ jp_global = joint + (size_t)iobs*JOINT_STRIDE;
 
     const int  k       = m.nnz_per_row;
     const int  NPTS    = P.W*P.H;
@@ -301,26 +493,41 @@ void board_kernel(DeviceProblem P,
 
     double* __restrict__ tile    = lds;
     double* __restrict__ obs_lds = lds + 64*KS;
+    // the joint pose record of this observation, staged in LDS: it is too big
+    // for the scalar registers (84 doubles), and re-reading it from memory in
+    // every pass puts a memory latency (long, under this kernel's own write
+    // stream) in front of the chain rule. Reads from here are broadcasts
+    double* __restrict__ jp      = obs_lds + ((3*NPTS + 63) & ~63);
 
     // stage the observation: qx,qy,weight of every corner. All the loads are
-    // issued before the first wait
+    // issued before the first wait; no lane predication (the tail lanes re-read
+    // the last element and write into the padding of obs_lds, which is
+    // allocated in whole 64-element chunks)
     {
         const double* __restrict__ pool = P.board_pool + (size_t)iobs*NPTS*3;
-        for(int base = 0; base < 3*NPTS; base += 64*8)
+        const int n3 = 3*NPTS, last = n3 - 1;
+        const double j0 = jp_global[lane];
+        const double j1 = jp_global[(lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1];
+        // the first 512 values (boards of up to 170 corners: all of them) in
+        // straight-line code: 8 loads in flight, then the LDS writes
+        double v[8];
+#pragma unroll
+        for(int j=0;j<8;j++)
+            if(64*j < n3)                       // wave-uniform
+            {
+                const int idx = 64*j + lane;
+                v[j] = pool[idx < last ? idx : last];
+            }
+#pragma unroll
+        for(int j=0;j<8;j++)
+            if(64*j < n3)
+                obs_lds[64*j + lane] = v[j];
+        jp[lane] = j0;
+        if(lane < JOINT_STRIDE - 64) jp[64 + lane] = j1;
+        for(int base = 512; base < n3; base += 64)
         {
-            double v[8];
-#pragma unroll
-            for(int j=0;j<8;j++)
-            {
-                const int idx = base + 64*j + lane;
-                v[j] = (idx < 3*NPTS) ? pool[idx] : 0.0;
-            }
-#pragma unroll
-            for(int j=0;j<8;j++)
-            {
-                const int idx = base + 64*j + lane;
-                if(idx < 3*NPTS) obs_lds[idx] = v[j];
-            }
+            const int idx = base + lane;
+            obs_lds[idx] = pool[idx < last ? idx : last];
         }
     }
 
@@ -332,54 +539,63 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
     const double warp0 = wp[0], warp1 = wp[1];
 
-    // Gram operand addressing: for MFMA mm this lane reads, at tile row
-    // 4 s + lane/16, column 4 bi + lane%4 (A) and 4 bj + lane%4 (B) of the
-    // block pair in its slot
-    int goffA[WITH_GRAM ? NM : 1], goffB[WITH_GRAM ? NM : 1];
-    double acc[WITH_GRAM ? NM : 1];
-    if(WITH_GRAM)
+    // Gram operands: at k-step s this lane reads tile[4 s + lane/16][16 g + lane%16]
+    const int goff = (lane >> 4)*KS + (lane & 15);
+    double acc[NM];
+#pragma unroll
+    for(int mm=0;mm<NM;mm++) acc[mm] = 0.0;
+    // one k-step on the operands (x, y) = the two 16-column groups of 4 tile rows
+    auto gram_step = [&](double x16, double y16) { gram_step_ops<NBLK>(acc, x16, y16); };
+    auto gram_load = [&](const double* __restrict__ ts, double* x16, double* y16)
     {
-        const int slot = (lane >> 2) & 3;
-#pragma unroll
-        for(int mm=0;mm<NM;mm++)
-        {
-            int p = 4*mm + slot;
-            if(p >= NPAIRS) p = 0;
-            // unrank p -> (bi <= bj) without a data-dependent loop: block row
-            // i starts at pair index i NBLK - i(i-1)/2
-            int bi = 0, first = 0;
-#pragma unroll
-            for(int i=1;i<NBLK;i++)
-            {
-                const int first_i = i*NBLK - i*(i-1)/2;
-                if(p >= first_i) { bi = i; first = first_i; }
-            }
-            const int bj = bi + (p - first);
-            goffA[mm] = (lane >> 4)*KS + 4*bi + (lane & 3);
-            goffB[mm] = (lane >> 4)*KS + 4*bj + (lane & 3);
-            acc[mm] = 0.0;
-        }
-    }
+        *x16 = ts[goff];
+        *y16 = (NG > 1) ? ts[goff + 16] : 0.0;
+    };
 
     // copy-out: this lane's fixed pair of CSR columns (k even), as tile
     // columns for an x row and for a y row
     const int  pairs_per_row = k >> 1;
     const int  rows_per_iter = (k > 0 && !(k & 1)) ? 64 / pairs_per_row : 0;
-    const bool co_active     = lane < rows_per_iter*pairs_per_row;
-    const int  co_rsub       = co_active ? lane / pairs_per_row : 0;
-    const int  co_c0         = 2*(lane - co_rsub*pairs_per_row);
-    int co_tx0 = 0, co_tx1 = 0, co_ty0 = 0, co_ty1 = 0;
-    if(WITH_J && co_active)
+    const int  co_nactive    = rows_per_iter*pairs_per_row;
+    const bool co_active     = lane < co_nactive;
+    // the lanes past the last whole row repeat the work of the first ones
+    // (harmless: same address, same data) instead of being masked off
+    const int  co_lane       = co_active ? lane : lane - co_nactive;
+    const int  co_rsub       = (rows_per_iter > 0) ? co_lane / pairs_per_row : 0;
+    const int  co_c0         = 2*(co_lane - co_rsub*pairs_per_row);
+    // (recomputed where needed rather than kept in registers for the whole kernel)
+    auto co_tile_cols = [&](int* tx0, int* tx1, int* ty0, int* ty1)
     {
-        co_tx0 = board_csr_to_tile_col(P, has_ext, co_c0,   0);
-        co_tx1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 0);
-        co_ty0 = board_csr_to_tile_col(P, has_ext, co_c0,   1);
-        co_ty1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 1);
+        *tx0 = board_csr_to_tile_col(P, has_ext, co_c0,   0);
+        *tx1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 0);
+        *ty0 = board_csr_to_tile_col(P, has_ext, co_c0,   1);
+        *ty1 = board_csr_to_tile_col(P, has_ext, co_c0+1, 1);
+    };
+    // the fast path's invariants (copy_out_full): LDS byte offsets for the rows
+    // co_rsub and co_rsub + rows_per_iter, element offset in the output
+    constexpr int KFULL = 2 + NDIST + 14;       // core, distortions, extrinsics, frame, warp: everything optimized
+    const bool co_fast  = WITH_J && !(KFULL & 1) && (k == KFULL || k == KFULL - 6);
+    int co_A0 = 0, co_A1 = 0, co_B0 = 0, co_B1 = 0;
+    unsigned co_gofs = 0;
+    if(co_fast)
+    {
+        int co_tx0, co_tx1, co_ty0, co_ty1;
+        co_tile_cols(&co_tx0, &co_tx1, &co_ty0, &co_ty1);
+        const bool y0 = (co_rsub & 1) != 0, y1 = ((co_rsub + rows_per_iter) & 1) != 0;
+        co_A0 = (co_rsub*KS                 + (y0 ? co_ty0 : co_tx0))*(int)sizeof(double);
+        co_A1 = (co_rsub*KS                 + (y0 ? co_ty1 : co_tx1))*(int)sizeof(double);
+        co_B0 = ((co_rsub+rows_per_iter)*KS + (y1 ? co_ty0 : co_tx0))*(int)sizeof(double);
+        co_B1 = ((co_rsub+rows_per_iter)*KS + (y1 ? co_ty1 : co_tx1))*(int)sizeof(double);
+        co_gofs = (unsigned)(co_rsub*k + co_c0);
     }
 
     __builtin_amdgcn_wave_barrier();   // obs_lds is complete (one wave: the LDS is in order)
     if(P.debug_ablate & 16) { if(obs_lds[lane] + intr[0] + warp0 + jp[0] == 12345.678) x[0] = 1.0; return; }
 
+#ifdef BOARD_TS
+    TS(1);
+    long long tcur = ts[1];
+#endif
     for(int pt0 = 0; pt0 < NPTS; pt0 += 64)
     {
         const int  pt    = pt0 + lane;
@@ -435,7 +651,7 @@ void board_kernel(DeviceProblem P,
             double2 err;
             err.x = inlier ? (q[0] - qx_obs)*w : 0.0;
             err.y = inlier ? (q[1] - qy_obs)*w : 0.0;
-            *reinterpret_cast<double2*>(&x[m.i_meas0 + 2*pt]) = err;
+            { d2_t e2; e2.x = err.x; e2.y = err.y; *reinterpret_cast<gdouble2*>(&x[m.i_meas0 + 2*pt]) = e2; }
 
             // outliers keep their columns and get all-zero values: everything
             // below is skipped for them and the rows stay 0
@@ -527,6 +743,7 @@ void board_kernel(DeviceProblem P,
         }
 
         if(!WITH_J) continue;
+        TSACC(2, tcur);     // projection + rows
 
         // the two halves of the pass go through the tile one after the other
         for(int h = 0; h < 2; h++)
@@ -548,21 +765,37 @@ void board_kernel(DeviceProblem P,
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            TSACC(3, tcur);     // tile write
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
-            double* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
+            gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
+            if(WITH_GRAM && co_fast && nrows == 64 && !(P.debug_ablate & 3))
+            {
+                // full half, all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
+                if(k == KFULL) gram_copy_fused<NBLK,KFULL,  KS>(acc, tile, goff, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                else           gram_copy_fused<NBLK,KFULL-6,KS>(acc, tile, goff, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                TSACC(5, tcur);
+                continue;
+            }
             if(!(P.debug_ablate & 1))
             {
-                if(rows_per_iter > 0)
+                if(co_fast && nrows == 64)
                 {
+                    if(k == KFULL) copy_out_full<KFULL,   KS>(tile, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                    else           copy_out_full<KFULL-6, KS>(tile, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                }
+                else if(rows_per_iter > 0)
+                {
+                    int co_tx0, co_tx1, co_ty0, co_ty1;
+                    co_tile_cols(&co_tx0, &co_tx1, &co_ty0, &co_ty1);
                     if(co_active)
                         for(int r = co_rsub; r < nrows; r += rows_per_iter)
                         {
                             const bool isy = (r & 1) != 0;
-                            double2 v;
+                            d2_t v;
                             v.x = tile[r*KS + (isy ? co_ty0 : co_tx0)];
                             v.y = tile[r*KS + (isy ? co_ty1 : co_tx1)];
-                            *reinterpret_cast<double2*>(&out[r*k + co_c0]) = v;
+                            *reinterpret_cast<gdouble2*>(&out[r*k + co_c0]) = v;
                         }
                 }
                 else
@@ -573,14 +806,15 @@ void board_kernel(DeviceProblem P,
                     {
                         const int r0 = e / k,       c0 = e - r0*k;
                         const int r1 = (e+1) / k,   c1 = (e+1) - r1*k;
-                        double2 v;
+                        d2_t v;
                         v.x = tile[r0*KS + board_csr_to_tile_col(P, has_ext, c0, r0 & 1)];
                         v.y = tile[r1*KS + board_csr_to_tile_col(P, has_ext, c1, r1 & 1)];
-                        *reinterpret_cast<double2*>(&out[e]) = v;
+                        *reinterpret_cast<gdouble2*>(&out[e]) = v;
                     }
                 }
             }
 
+            TSACC(4, tcur);     // copy-out
             if(WITH_GRAM && !(P.debug_ablate & 2))
             {
                 // G += Tt T over this half. 4 tile rows per k-step; the rows
@@ -593,33 +827,61 @@ void board_kernel(DeviceProblem P,
                 const int nsteps = (nrows + 3) >> 2;
                 if(nsteps == 16)
                 {
+                    // The operands of step s+1 are requested before the work of
+                    // step s, and step s waits for ITS operands only. Written
+                    // with explicit DS instructions and waits: the compiler's own
+                    // wait insertion drains the queue completely (lgkmcnt(0))
+                    // at every other step, exposing a full LDS latency there
+                    const unsigned a0 = (unsigned)(size_t)(tile + goff);    // LDS byte address
+                    gram_d2 cur = lds_read2_b64_16(a0), nxt = cur;
 #pragma unroll
                     for(int s = 0; s < 16; s++)
-#pragma unroll
-                        for(int mm=0;mm<NM;mm++)
-                            acc[mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tile[goffA[mm] + s*4*KS],
-                                                                         tile[goffB[mm] + s*4*KS],
-                                                                         acc[mm], 0, 0, 0);
+                    {
+                        if(s < 15)
+                        {
+                            nxt = lds_read2_b64_16(a0 + (unsigned)((s+1)*4*KS*sizeof(double)));
+                            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cur) :: "memory");
+                        }
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur) :: "memory");
+                        gram_step(cur.x, cur.y);
+                        __builtin_amdgcn_sched_barrier(0);
+                        cur = nxt;
+                    }
                 }
                 else
                     for(int s = 0; s < nsteps; s++)
                     {
-                        const double* __restrict__ ts = tile + s*4*KS;
-#pragma unroll
-                        for(int mm=0;mm<NM;mm++)
-                            acc[mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(ts[goffA[mm]], ts[goffB[mm]], acc[mm], 0, 0, 0);
+                        double cx, cy;
+                        gram_load(tile + s*4*KS, &cx, &cy);
+                        gram_step(cx, cy);
                     }
             }
+#ifdef BOARD_TS
+            { const double dep = acc[0]; asm volatile("" :: "v"(dep)); }
+#endif
+            TSACC(5, tcur);     // Gram
         }
     }
 
     if(WITH_J && WITH_GRAM)
     {
-        double* __restrict__ g = gram + (size_t)iobs*(NM*64);
+        gdouble* __restrict__ g = (gdouble*)gram + (size_t)iobs*(NM*64);
 #pragma unroll
         for(int mm=0;mm<NM;mm++)
             g[mm*64 + lane] = acc[mm];
     }
+#ifdef BOARD_TS
+    TS(6);
+    if(P.debug_ts != NULL && lane == 0)
+    {
+        long long* o = P.debug_ts + (size_t)iobs*8;
+        // start, end of startup, [projection, tile write, copy-out, Gram] cycles, end, hw id
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4]; o[5] = ts[5]; o[6] = ts[6]; o[7] = hwid;
+    }
+#endif
 }
 
 // CSR structure of the board rows: rowptr and colidx. Same tiling as above,

@@ -429,7 +429,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     // LDS of the board kernel: the 64-row tile + the observation's pixels and
     // weights (the splined models' kernels use none)
     const bool splined = (lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
-    P->lds_bytes = splined ? 0 : (64*tile_stride(L.Ndist) + 3*NPTS) * (int)sizeof(double);
+    // the tile + the staged observation (in whole 64-element chunks) + the joint pose record
+    P->lds_bytes = splined ? 0 : (64*tile_stride(L.Ndist) + ((3*NPTS + 63) & ~63) + JOINT_STRIDE + 4) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
         set_error("the board has %d corners and the lens model %d distortion parameters: the LDS tile would not fit", NPTS, L.Ndist);
@@ -693,6 +694,28 @@ double mrcal_amd_problem_debug_time_evaluate(mrcal_amd_problem_t* p, bool with_g
     }
     p->D.debug_ablate = saved;
     return total/nrep;
+}
+
+// profiling builds (-DBOARD_TS): per-observation phase timestamps of ONE board
+// kernel launch, out[Nobs_board][8]. Returns the number of observations
+int mrcal_amd_problem_debug_timestamps(mrcal_amd_problem_t* p, bool with_gram, long long* out)
+{
+    if(with_gram && !problem_prepare_solver(p)) return -1;
+    const size_t n = (size_t)p->D.Nobs_board*8;
+    long long* d = NULL;
+    if(hipMalloc((void**)&d, n*sizeof(long long)) != hipSuccess) return -1;
+    hipMemset(d, 0, n*sizeof(long long));
+    const EvalBuffers B = p->eval_buffers(p->icur, with_gram);
+    for(int i=0;i<3;i++)
+    {
+        p->D.debug_ts = (i == 2) ? d : NULL;
+        if(launch_evaluate(p->D, B, true, p->lds_bytes, p->stream, p->ev_j0, p->ev_j1) != hipSuccess) return -1;
+        hipStreamSynchronize(p->stream);
+    }
+    p->D.debug_ts = NULL;
+    hipMemcpy(out, d, n*sizeof(long long), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return p->D.Nobs_board;
 }
 
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* p)

@@ -122,33 +122,76 @@ __host__ __device__ inline int tile_nblk  (int ndist) { return (tile_ncols(ndist
 __host__ __device__ inline int tile_stride(int ndist) { return (4*tile_nblk(ndist)) | 1; }
 
 // Per-board-observation Gram matrix G = Tt T of the tile, formed with
-// v_mfma_f64_4x4x4f64 (4 independent 4x4 blocks per instruction, k = 4 tile
-// rows per step). G is cut into 4x4 blocks; the NBLK(NBLK+1)/2 blocks (bi<=bj)
-// are numbered row-major over the upper triangle, block pair p goes to MFMA
-// p/4, block slot p%4. Measured operand layout on gfx950
+// v_mfma_f64_4x4x4f64 (4 independent 4x4 products per instruction, one per
+// "slot"; k = 4 tile rows per step). Measured operand layout on gfx950
 // (tools/mfma_f64_4x4x4_layout_probe.hip):
 //   A lane = 16 k + 4 slot + i     B lane = 16 k + 4 slot + j     D lane = 16 i + 4 slot + j
-// so accumulator m, lane l holds G[4 bi + l/16][4 bj + l%4] of the pair in slot (l%16)/4.
-// Storage: gram[iobs][m][lane], gram_nmfma(ndist)*64 doubles per observation
-__host__ __device__ inline int gram_npairs(int ndist) { const int n = tile_nblk(ndist); return n*(n+1)/2; }
-__host__ __device__ inline int gram_nmfma (int ndist) { return (gram_npairs(ndist) + 3) >> 2; }
-__host__ __device__ inline int gram_stride(int ndist) { return gram_nmfma(ndist)*64; }
-__host__ __device__ inline int gram_pair_index(int nblk, int bi, int bj) // bi <= bj
+// With lane l reading tile[row 4 step + l/16][16 g + l%16], ONE LDS read is a
+// valid operand (A and B alike) holding the 4x4 column blocks 4g..4g+3 of
+// "group" g in its four slots. G is cut into 4x4 blocks; the block pairs are
+// produced by multiplying a group operand with a slot-ROTATED group operand
+// (DPP row_ror within each 16-lane row, no LDS traffic):
+//   candidate (gA, gB, r): slot s holds block pair (4 gA + s, 4 gB + (s+r)%4)
+//     same group: r = 0 the diagonal blocks, r = 1 (s,s+1) incl. the mirrored
+//                 (3,0), r = 2 (0,2),(1,3) [slots 2,3 would repeat them]
+//     groups 0x1: r = 0..3, all 16 pairs
+// i.e. 2 LDS reads and <= 10 MFMAs per step for up to 32 tile columns, where
+// gathering each pair's operands separately costs 2 reads per MFMA. The LDS
+// pipe, shared by all the waves of a CU, is what this kernel runs out of first.
+// Candidates with no valid slot (a short last group) are dropped; the
+// remaining ones are the accumulators m = 0.., stored as gram[iobs][m][lane]:
+// lane l of accumulator m holds G[4 bA + l/16][4 bB + l%4], (bA,bB) the pair
+// in slot (l%16)/4.
+__host__ __device__ constexpr int  gram_ngroups(int nblk) { return (nblk + 3) >> 2; }
+__host__ __device__ constexpr void gram_cand_decode(int c, int* gA, int* gB, int* r)
 {
-    return bi*nblk - bi*(bi-1)/2 + (bj - bi);
+    if(c < 3)      { *gA = 0; *gB = 0; *r = c; }
+    else if(c < 6) { *gA = 1; *gB = 1; *r = c - 3; }
+    else           { *gA = 0; *gB = 1; *r = c - 6; }
 }
-__host__ __device__ inline void gram_pair_unrank(int nblk, int p, int* bi, int* bj)
+__host__ __device__ constexpr bool gram_slot_valid(int nblk, int c, int s)
 {
-    int i = 0;
-    while(i < nblk-1 && p >= nblk - i) { p -= nblk - i; i++; }
-    *bi = i; *bj = i + p;
+    int gA = 0, gB = 0, r = 0;
+    gram_cand_decode(c, &gA, &gB, &r);
+    const int bA = 4*gA + s, bB = 4*gB + ((s + r) & 3);
+    if(bA >= nblk || bB >= nblk)        return false;
+    if(gA == gB && r == 2 && s >= 2)    return false;   // (2,0),(3,1): repeats of (0,2),(1,3)
+    return true;
 }
-// G[i][j], any i,j
-__host__ __device__ inline double gram_get(const double* g, int nblk, int i, int j)
+__host__ __device__ constexpr bool gram_cand_valid(int nblk, int c)
 {
-    if((i >> 2) > (j >> 2)) { int t = i; i = j; j = t; }
-    const int p = gram_pair_index(nblk, i >> 2, j >> 2);
-    return g[(p >> 2)*64 + 16*(i & 3) + 4*(p & 3) + (j & 3)];
+    return gram_slot_valid(nblk,c,0) || gram_slot_valid(nblk,c,1) || gram_slot_valid(nblk,c,2) || gram_slot_valid(nblk,c,3);
+}
+// number of accumulators, and the candidate behind accumulator m
+__host__ __device__ constexpr int gram_nmfma_blk(int nblk)
+{
+    int n = 0;
+    for(int c = 0; c < 10; c++) if(gram_cand_valid(nblk, c)) n++;
+    return n;
+}
+__host__ __device__ constexpr int gram_cand(int nblk, int m)
+{
+    for(int c = 0; c < 10; c++)
+        if(gram_cand_valid(nblk, c)) { if(m == 0) return c; m--; }
+    return -1;
+}
+__host__ __device__ inline int gram_stride(int ndist) { return gram_nmfma_blk(tile_nblk(ndist))*64; }
+// position pos = 64 m + lane of a stored Gram -> the entry G[i][j] it holds.
+// diag: the entry is in a diagonal 4x4 block, where (i,j) and (j,i) are both
+// stored; elsewhere only one of them is (i > j can happen: the mirrored (3,0)
+// block). Returns false for the unused slots
+__host__ __device__ inline bool gram_pos_to_entry(int nblk, int pos, int* i, int* j, bool* diag)
+{
+    const int lane = pos & 63, s = (lane >> 2) & 3;
+    const int c = gram_cand(nblk, pos >> 6);
+    if(c < 0 || !gram_slot_valid(nblk, c, s)) return false;
+    int gA = 0, gB = 0, r = 0;
+    gram_cand_decode(c, &gA, &gB, &r);
+    const int bA = 4*gA + s, bB = 4*gB + ((s + r) & 3);
+    *i = 4*bA + (lane >> 4);
+    *j = 4*bB + (lane & 3);
+    *diag = (bA == bB);
+    return true;
 }
 
 struct DeviceProblem
@@ -174,6 +217,7 @@ struct DeviceProblem
     // performance-debugging knob (tools/probe_board.py): bit0 skip the J copy-out,
     // bit1 skip the MFMAs, bit2 skip the projection arithmetic. 0 in production
     int debug_ablate;
+    long long* debug_ts;     // per-observation phase timestamps (profiling builds, -DBOARD_TS)
 
     // regularization
     int do_apply_regularization;

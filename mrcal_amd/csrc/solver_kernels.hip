@@ -89,23 +89,6 @@ TileColInfo board_tile_col_info(const DeviceProblem& P, const BoardObsMeta& m, i
         r.kind = COL_X;
     return r;
 }
-// position pos = 64 m + lane of a stored Gram -> the entry (i,j) it holds.
-// diag: the entry is in a diagonal 4x4 block, where (i,j) and (j,i) are both
-// stored; elsewhere only one of them is. Returns false for the unused slots
-__device__ __forceinline__
-bool gram_pos_to_entry(int nblk, int pos, int* i, int* j, bool* diag)
-{
-    const int lane = pos & 63;
-    const int p    = 4*(pos >> 6) + ((lane >> 2) & 3);
-    if(p >= nblk*(nblk+1)/2) return false;
-    int bi, bj;
-    gram_pair_unrank(nblk, p, &bi, &bj);
-    *i = 4*bi + (lane >> 4);
-    *j = 4*bj + (lane & 3);
-    *diag = (bi == bj);
-    return true;
-}
-
 // One workgroup per frame. Its observations are contiguous (the API requires
 // frame-sorted observations, mrcal-pywrap.c:1063-1138). The Grams are read
 // coalesced, position by position; the frame's rows of Bt, its D block and its
