@@ -332,17 +332,36 @@ void copy_out_full(const double* __restrict__ tile, gdouble* __restrict__ out,
 // the MFMAs of one Gram k-step, candidates resolved at compile time (problem.hpp)
 template<int NBLK, int MM> struct GramCand
 {
-    static constexpr int c  = gram_cand(NBLK, MM);
-    static constexpr int gA = (c < 3) ? 0 : (c < 6) ? 1 : 0;
-    static constexpr int gB = (c < 3) ? 0 : 1;
-    static constexpr int r  = (c < 3) ? c : (c < 6) ? c - 3 : c - 6;
+    static constexpr int      c    = gram_cand(NBLK, MM);
+    static constexpr GramDesc d    = gram_cand_desc(NBLK, c);
+    static constexpr bool     roty = gram_rotated_y(NBLK);
+    static constexpr int srcA = (d.kind == GRAM_YY) ? 1 : 0;                       // X, or Y / Y_0
+    static constexpr int srcB = (d.kind == GRAM_XX) ? 0 : (roty ? 1 : 1 + d.q);   // X, Y or Y_q
+    static constexpr int rotB = (d.kind == GRAM_XX || roty) ? d.q : 0;
 };
+struct GramRd { double v[4]; };     // the LDS reads of one k-step: X, then Y or Y_0..Y_2
 template<int NBLK, int NACC, int... MM>
-__device__ __forceinline__ void gram_mfmas(double (&acc)[NACC], const double (&op)[2][4], std::integer_sequence<int, MM...>)
+__device__ __forceinline__ void gram_mfmas(double (&acc)[NACC], const double (&op)[4][4], std::integer_sequence<int, MM...>)
 {
-    ((acc[MM] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[GramCand<NBLK,MM>::gA][0],
-                                                   op[GramCand<NBLK,MM>::gB][GramCand<NBLK,MM>::r],
+    ((acc[MM] = __builtin_amdgcn_mfma_f64_4x4x4f64(op[GramCand<NBLK,MM>::srcA][0],
+                                                   op[GramCand<NBLK,MM>::srcB][GramCand<NBLK,MM>::rotB],
                                                    acc[MM], 0, 0, 0)), ...);
+}
+// One k-step of the Gram: slot rotations + MFMAs. (Rotations nobody uses are
+// dropped by the compiler)
+template<int NBLK, int NM>
+__device__ __forceinline__ void gram_step_ops(double (&acc)[NM], const GramRd& rd)
+{
+    double op[4][4];    // [read][slot rotation]
+#pragma unroll
+    for(int g=0; g<4; g++)
+    {
+        op[g][0] = rd.v[g];
+        op[g][1] = row_ror_f64<12>(op[g][0]);
+        op[g][2] = row_ror_f64<8 >(op[g][0]);
+        op[g][3] = row_ror_f64<4 >(op[g][0]);
+    }
+    gram_mfmas<NBLK>(acc, op, std::make_integer_sequence<int, NM>{});
 }
 
 // ---- explicit DS instructions and waits for the fused Gram + copy-out path
@@ -352,23 +371,6 @@ __device__ __forceinline__ double lds_read_b64_at(unsigned lds_byte_address)
     double v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "n"(OFF) : "memory");
     return v;
-}
-
-// One k-step of the Gram on operands (x16, y16): rotations + MFMAs
-template<int NBLK, int NM>
-__device__ __forceinline__ void gram_step_ops(double (&acc)[NM], double x16, double y16)
-{
-    double op[2][4];    // [group][slot rotation]
-    op[0][0] = x16;
-    op[1][0] = y16;
-#pragma unroll
-    for(int g=0; g<2; g++)
-    {
-        op[g][1] = row_ror_f64<12>(op[g][0]);
-        op[g][2] = row_ror_f64<8 >(op[g][0]);
-        op[g][3] = row_ror_f64<4 >(op[g][0]);
-    }
-    gram_mfmas<NBLK>(acc, op, std::make_integer_sequence<int, NM>{});
 }
 
 // Step S of the fused loop over a FULL half-tile (64 rows = 16 k-steps) with K
@@ -382,22 +384,31 @@ __device__ __forceinline__ void gram_step_ops(double (&acc)[NM], double x16, dou
 //     wait for everything requested; store row group S
 // Lanes past the last whole row of a group (64 % (K/2) of them) repeat the
 // work of the first lanes: same address, same data.
+// "these registers are written by the DS reads waited for here"
+template<int NREAD>
+__device__ __forceinline__ void lgkm_wait0(GramRd& a, d2_t& b)
+{
+    if(NREAD == 2)      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(b) :: "memory");
+    else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b) :: "memory");
+    else                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b) :: "memory");
+}
 template<int S, int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
-void fused_step(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile_a0,
+void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
                 gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
 {
     constexpr int PAIRS = K/2, R = 64/PAIRS, NGRP = (64 + R - 1)/R;
+    constexpr int NREAD = gram_nreads(NBLK);
     constexpr bool have_grp = S < NGRP;
     constexpr int  u  = S & 1;
     constexpr int  go = (S >> 1)*2*R*KS*(int)sizeof(double);         // LDS byte offset of the group's double step
     constexpr int  rb = S*R;                                          // its first row
-    gram_d2 nxt = cur;
+    GramRd nxt = cur;
     if(S < 15)
     {
         constexpr int so = (S < 15 ? S+1 : 0)*4*KS*(int)sizeof(double);
-        nxt.x = lds_read_b64_at<so>(gram_a0);
-        nxt.y = lds_read_b64_at<so + 16*(int)sizeof(double)>(gram_a0);
+#pragma unroll
+        for(int q=0;q<NREAD;q++) nxt.v[q] = lds_read_b64_at<so>(gram_a[q]);
     }
     d2_t v = {0.0, 0.0};
     if(have_grp)
@@ -406,12 +417,17 @@ void fused_step(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile
         v.y = lds_read_b64_at<go>(tile_a0 + (unsigned)(u ? B1 : A1));
     }
     if(S == 0)
-        // the only wait for Gram operands: 4 requests are younger than step 0's
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur) :: "memory");
+    {
+        // the only wait for Gram operands: NREAD + 2 requests are younger than step 0's
+        d2_t none = {0.0, 0.0};
+        if(NREAD == 2)      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(none) :: "memory");
+        else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(none) :: "memory");
+        else                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]), "+v"(none) :: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
-    gram_step_ops<NBLK>(acc, cur.x, cur.y);
+    gram_step_ops<NBLK>(acc, cur);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt), "+v"(v) :: "memory");
+    lgkm_wait0<NREAD>(nxt, v);
     if(have_grp)
     {
         gdouble* __restrict__ o = out + rb*K;       // wave-uniform
@@ -423,23 +439,29 @@ void fused_step(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile
 }
 template<int NBLK, int K, int KS, int NM, int... S>
 __device__ __forceinline__
-void fused_steps(double (&acc)[NM], gram_d2& cur, unsigned gram_a0, unsigned tile_a0,
+void fused_steps(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
                  gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub,
                  std::integer_sequence<int, S...>)
 {
-    (fused_step<S,NBLK,K,KS>(acc, cur, gram_a0, tile_a0, out, A0, A1, B0, B1, gofs, rsub), ...);
+    (fused_step<S,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub), ...);
 }
 template<int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
-void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, int goff,
+void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const int (&goffs)[4],
                      gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
 {
+    constexpr int NREAD = gram_nreads(NBLK);
+    static_assert(NREAD >= 2 && NREAD <= 4, "board tiles have 5..8 column blocks");
     const unsigned tile_a0 = (unsigned)(size_t)tile;
-    const unsigned gram_a0 = tile_a0 + (unsigned)(goff*sizeof(double));
-    gram_d2 cur;
-    cur.x = lds_read_b64_at<0>(gram_a0);
-    cur.y = lds_read_b64_at<16*(int)sizeof(double)>(gram_a0);
-    fused_steps<NBLK,K,KS>(acc, cur, gram_a0, tile_a0, out, A0, A1, B0, B1, gofs, rsub,
+    unsigned gram_a[4];
+#pragma unroll
+    for(int q=0;q<4;q++) gram_a[q] = tile_a0 + (unsigned)(goffs[q < NREAD ? q : 0]*sizeof(double));
+    GramRd cur;
+#pragma unroll
+    for(int q=0;q<4;q++) cur.v[q] = 0.0;
+#pragma unroll
+    for(int q=0;q<NREAD;q++) cur.v[q] = lds_read_b64_at<0>(gram_a[q]);
+    fused_steps<NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub,
                            std::make_integer_sequence<int, 16>{});
 }
 
@@ -474,7 +496,6 @@ void board_kernel(DeviceProblem P,
     constexpr int NBLK   = (NCOLS + 3)/4;
     constexpr int NCOLS4 = 4*NBLK;              // columns written per row, incl. the zero padding
     constexpr int KS     = NCOLS4 | 1;          // odd LDS row stride
-    constexpr int NG     = gram_ngroups(NBLK);  // 16-column groups of the tile
     constexpr int NM     = gram_nmfma_blk(NBLK); // accumulators (problem.hpp)
     static_assert(NBLK <= 8, "the Gram scheme covers 32 tile columns");
 
@@ -539,18 +560,15 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
     const double warp0 = wp[0], warp1 = wp[1];
 
-    // Gram operands: at k-step s this lane reads tile[4 s + lane/16][16 g + lane%16]
-    const int goff = (lane >> 4)*KS + (lane & 15);
+    // Gram operands (problem.hpp): at k-step s this lane reads
+    // tile[4 s + lane/16][gram_read_col(iread, lane)] for each of the NREAD operands
+    constexpr int NREAD = gram_nreads(NBLK);
+    int goffs[4];
+#pragma unroll
+    for(int q=0;q<4;q++) goffs[q] = (lane >> 4)*KS + gram_read_col(NBLK, q < NREAD ? q : 0, lane);
     double acc[NM];
 #pragma unroll
     for(int mm=0;mm<NM;mm++) acc[mm] = 0.0;
-    // one k-step on the operands (x, y) = the two 16-column groups of 4 tile rows
-    auto gram_step = [&](double x16, double y16) { gram_step_ops<NBLK>(acc, x16, y16); };
-    auto gram_load = [&](const double* __restrict__ ts, double* x16, double* y16)
-    {
-        *x16 = ts[goff];
-        *y16 = (NG > 1) ? ts[goff + 16] : 0.0;
-    };
 
     // copy-out: this lane's fixed pair of CSR columns (k even), as tile
     // columns for an x row and for a y row
@@ -772,8 +790,8 @@ void board_kernel(DeviceProblem P,
             if(WITH_GRAM && co_fast && nrows == 64 && !(P.debug_ablate & 3))
             {
                 // full half, all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
-                if(k == KFULL) gram_copy_fused<NBLK,KFULL,  KS>(acc, tile, goff, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
-                else           gram_copy_fused<NBLK,KFULL-6,KS>(acc, tile, goff, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                if(k == KFULL) gram_copy_fused<NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                else           gram_copy_fused<NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
                 TSACC(5, tcur);
                 continue;
             }
@@ -820,42 +838,15 @@ void board_kernel(DeviceProblem P,
                 // G += Tt T over this half. 4 tile rows per k-step; the rows
                 // between nrows and the end of the last step belong to lanes
                 // without a corner, which stored zeros
-                // A full half (64 rows, 16 steps) runs fully unrolled: the
-                // step's row offset folds into the DS instructions' immediate
-                // offsets, and with no branches in between the loads of the
-                // next steps are issued under the MFMAs of this one
+                // (the full halves of the usual problems take the fused path above)
                 const int nsteps = (nrows + 3) >> 2;
-                if(nsteps == 16)
+                for(int s = 0; s < nsteps; s++)
                 {
-                    // The operands of step s+1 are requested before the work of
-                    // step s, and step s waits for ITS operands only. Written
-                    // with explicit DS instructions and waits: the compiler's own
-                    // wait insertion drains the queue completely (lgkmcnt(0))
-                    // at every other step, exposing a full LDS latency there
-                    const unsigned a0 = (unsigned)(size_t)(tile + goff);    // LDS byte address
-                    gram_d2 cur = lds_read2_b64_16(a0), nxt = cur;
+                    GramRd rd;
 #pragma unroll
-                    for(int s = 0; s < 16; s++)
-                    {
-                        if(s < 15)
-                        {
-                            nxt = lds_read2_b64_16(a0 + (unsigned)((s+1)*4*KS*sizeof(double)));
-                            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cur) :: "memory");
-                        }
-                        else
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur) :: "memory");
-                        gram_step(cur.x, cur.y);
-                        __builtin_amdgcn_sched_barrier(0);
-                        cur = nxt;
-                    }
+                    for(int q=0;q<4;q++) rd.v[q] = (q < NREAD) ? tile[s*4*KS + goffs[q]] : 0.0;
+                    gram_step_ops<NBLK>(acc, rd);
                 }
-                else
-                    for(int s = 0; s < nsteps; s++)
-                    {
-                        double cx, cy;
-                        gram_load(tile + s*4*KS, &cx, &cy);
-                        gram_step(cx, cy);
-                    }
             }
 #ifdef BOARD_TS
             { const double dep = acc[0]; asm volatile("" :: "v"(dep)); }

@@ -63,7 +63,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     }
     hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Linv); hipFree(F.status);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.status);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -99,7 +99,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         ok = ok && dev_alloc(&P->op[i].step_cauchy, (size_t)nd.Nstate);
         ok = ok && dev_alloc(&P->op[i].step_gn,     (size_t)nd.Nstate);
     }
-    ok = ok && dev_alloc(&P->F.Linv, (size_t)((nd.Nc + 15)/16)*256);
+    ok = ok && dev_alloc(&P->F.Spart, schur_partial_doubles(nd));
     {
         char* ctl = NULL;
         ok = ok && dev_alloc(&ctl, solver_ctl_bytes());
@@ -116,6 +116,9 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.NE + nd.Nstate + 2 + 32);
     ok = ok && dev_alloc(&P->d_counts, 4);
     if(!ok) return false;
+    // only the lower triangle of S is ever written; the rest rides along in the
+    // all-reduce of [S | r] and should be numbers
+    HIP_TRY(hipMemset(P->F.S, 0, ((size_t)nd.Nc*nd.Nc + nd.Nc)*sizeof(double)), return false);
     // rows of blocks this shard does not own are never written: they must read as 0
     HIP_TRY(hipMemset(P->F.Wt, 0, (size_t)(nd.NE*nd.Nc > 0 ? nd.NE*nd.Nc : 1)*sizeof(double)), return false);
     HIP_TRY(hipMemset(P->F.y,  0, (size_t)(nd.NE > 0 ? nd.NE : 1)*sizeof(double)), return false);

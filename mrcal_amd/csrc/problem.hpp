@@ -126,72 +126,121 @@ __host__ __device__ inline int tile_stride(int ndist) { return (4*tile_nblk(ndis
 // "slot"; k = 4 tile rows per step). Measured operand layout on gfx950
 // (tools/mfma_f64_4x4x4_layout_probe.hip):
 //   A lane = 16 k + 4 slot + i     B lane = 16 k + 4 slot + j     D lane = 16 i + 4 slot + j
-// With lane l reading tile[row 4 step + l/16][16 g + l%16], ONE LDS read is a
-// valid operand (A and B alike) holding the 4x4 column blocks 4g..4g+3 of
-// "group" g in its four slots. G is cut into 4x4 blocks; the block pairs are
-// produced by multiplying a group operand with a slot-ROTATED group operand
-// (DPP row_ror within each 16-lane row, no LDS traffic):
-//   candidate (gA, gB, r): slot s holds block pair (4 gA + s, 4 gB + (s+r)%4)
-//     same group: r = 0 the diagonal blocks, r = 1 (s,s+1) incl. the mirrored
-//                 (3,0), r = 2 (0,2),(1,3) [slots 2,3 would repeat them]
-//     groups 0x1: r = 0..3, all 16 pairs
-// i.e. 2 LDS reads and <= 10 MFMAs per step for up to 32 tile columns, where
-// gathering each pair's operands separately costs 2 reads per MFMA. The LDS
-// pipe, shared by all the waves of a CU, is what this kernel runs out of first.
-// Candidates with no valid slot (a short last group) are dropped; the
-// remaining ones are the accumulators m = 0.., stored as gram[iobs][m][lane]:
-// lane l of accumulator m holds G[4 bA + l/16][4 bB + l%4], (bA,bB) the pair
-// in slot (l%16)/4.
-__host__ __device__ constexpr int  gram_ngroups(int nblk) { return (nblk + 3) >> 2; }
-__host__ __device__ constexpr void gram_cand_decode(int c, int* gA, int* gB, int* r)
+// G is cut into 4x4 blocks (NBLK = ncols/4 of them per side). An operand is ONE
+// LDS read per lane, tile[row 4 step + l/16][4 blk(slot) + l%4], which serves
+// as A or B alike and holds one column block per slot:
+//   X     blocks (0,1,2,3): lane l reads column l%16, 16 contiguous doubles per row
+//   Y_q   q = 0..ny-1, ny = NBLK-4 < 4: the remaining blocks in cyclic order,
+//         slot s holds block 4 + (s+q) % ny
+//   Y     (ny = 4) blocks (4,5,6,7)
+// and the block pairs come from
+//   X . rot_r(X), r = 0,1,2   (rot_r: slots rotated by DPP row_ror, no LDS traffic)
+//                             r = 0 the diagonal blocks, r = 1 (s,s+1) incl. the
+//                             mirrored (3,0), r = 2 (0,2),(1,3) [slots 2,3 repeat them]
+//   ny < 4:  X . Y_q (all of X x Y in ny instructions), Y_0 . Y_0, Y_0 . Y_1
+//   ny = 4:  Y . rot_r(Y) r = 0,1,2 and X . rot_r(Y) r = 0..3
+// 8 MFMAs, 4 LDS reads and 2 rotations per step for the 27 columns of OPENCV8,
+// where gathering every pair's operands separately costs 2 reads per MFMA and
+// makes the LDS pipe (shared by all the waves of a CU) the limit, and forming
+// everything from X, Y and their rotations costs 10 MFMAs.
+// The accumulators are stored as they are, gram[iobs][m][lane]: lane l of
+// accumulator m holds G[4 bA + l/16][4 bB + l%4], (bA,bB) the pair in slot (l%16)/4.
+enum { GRAM_XX = 0, GRAM_YY, GRAM_XY };
+struct GramDesc { int kind, q; };     // q: the rotation r, or the index of the Y_q operand
+__host__ __device__ constexpr int  gram_nx(int nblk) { return nblk < 4 ? nblk : 4; }
+__host__ __device__ constexpr int  gram_ny(int nblk) { return nblk - gram_nx(nblk); }
+__host__ __device__ constexpr bool gram_rotated_y(int nblk) { return gram_ny(nblk) == 4; }
+// LDS reads per step: X, then Y (ny = 4) or Y_0..Y_{ny-1}
+__host__ __device__ constexpr int  gram_nreads(int nblk) { return 1 + (gram_rotated_y(nblk) ? 1 : gram_ny(nblk)); }
+// the candidate accumulators, in order: XX r=0,1,2 | YY | XY
+__host__ __device__ constexpr int  gram_ncand(int nblk)
 {
-    if(c < 3)      { *gA = 0; *gB = 0; *r = c; }
-    else if(c < 6) { *gA = 1; *gB = 1; *r = c - 3; }
-    else           { *gA = 0; *gB = 1; *r = c - 6; }
+    const int ny = gram_ny(nblk);
+    if(ny == 0) return 3;
+    if(ny == 4) return 3 + 3 + 4;
+    return 3 + (ny >= 2 ? 2 : 1) + ny;
 }
-__host__ __device__ constexpr bool gram_slot_valid(int nblk, int c, int s)
+__host__ __device__ constexpr GramDesc gram_cand_desc(int nblk, int c)
 {
-    int gA = 0, gB = 0, r = 0;
-    gram_cand_decode(c, &gA, &gB, &r);
-    const int bA = 4*gA + s, bB = 4*gB + ((s + r) & 3);
-    if(bA >= nblk || bB >= nblk)        return false;
-    if(gA == gB && r == 2 && s >= 2)    return false;   // (2,0),(3,1): repeats of (0,2),(1,3)
-    return true;
+    const int ny  = gram_ny(nblk);
+    const int nyy = (ny == 4) ? 3 : (ny >= 2 ? 2 : (ny == 1 ? 1 : 0));
+    if(c < 3)       return GramDesc{ GRAM_XX, c };
+    if(c < 3 + nyy) return GramDesc{ GRAM_YY, c - 3 };
+    return GramDesc{ GRAM_XY, c - 3 - nyy };
+}
+// slot s of candidate c: its block pair; false if the slot is unused or repeats another
+__host__ __device__ constexpr bool gram_slot_pair(int nblk, int c, int s, int* bA, int* bB)
+{
+    const int nx = gram_nx(nblk), ny = gram_ny(nblk);
+    const GramDesc d = gram_cand_desc(nblk, c);
+    int a = 0, b = 0;
+    bool ok = true;
+    if(d.kind == GRAM_XX)
+    {
+        a = s; b = (s + d.q) & 3;
+        ok = a < nx && b < nx && !(d.q == 2 && s >= 2);
+    }
+    else if(ny == 4)
+    {
+        b = 4 + ((s + d.q) & 3);
+        if(d.kind == GRAM_YY) { a = 4 + s; ok = !(d.q == 2 && s >= 2); }
+        else                  { a = s;     ok = a < nx; }
+    }
+    else if(d.kind == GRAM_XY)
+    {
+        a = s; b = 4 + (s + d.q) % ny;
+        ok = a < nx;
+    }
+    else
+    {
+        a = 4 + s % ny; b = 4 + (s + d.q) % ny;
+        ok = s < ny && (d.q == 0 || ny == 3 || s == 0);
+    }
+    *bA = a; *bB = b;
+    return ok;
 }
 __host__ __device__ constexpr bool gram_cand_valid(int nblk, int c)
 {
-    return gram_slot_valid(nblk,c,0) || gram_slot_valid(nblk,c,1) || gram_slot_valid(nblk,c,2) || gram_slot_valid(nblk,c,3);
+    int a = 0, b = 0;
+    return gram_slot_pair(nblk,c,0,&a,&b) || gram_slot_pair(nblk,c,1,&a,&b) ||
+           gram_slot_pair(nblk,c,2,&a,&b) || gram_slot_pair(nblk,c,3,&a,&b);
 }
 // number of accumulators, and the candidate behind accumulator m
 __host__ __device__ constexpr int gram_nmfma_blk(int nblk)
 {
     int n = 0;
-    for(int c = 0; c < 10; c++) if(gram_cand_valid(nblk, c)) n++;
+    for(int c = 0; c < gram_ncand(nblk); c++) if(gram_cand_valid(nblk, c)) n++;
     return n;
 }
 __host__ __device__ constexpr int gram_cand(int nblk, int m)
 {
-    for(int c = 0; c < 10; c++)
+    for(int c = 0; c < gram_ncand(nblk); c++)
         if(gram_cand_valid(nblk, c)) { if(m == 0) return c; m--; }
     return -1;
 }
 __host__ __device__ inline int gram_stride(int ndist) { return gram_nmfma_blk(tile_nblk(ndist))*64; }
 // position pos = 64 m + lane of a stored Gram -> the entry G[i][j] it holds.
 // diag: the entry is in a diagonal 4x4 block, where (i,j) and (j,i) are both
-// stored; elsewhere only one of them is (i > j can happen: the mirrored (3,0)
-// block). Returns false for the unused slots
+// stored; elsewhere only one of them is (i > j can happen: mirrored blocks).
+// Returns false for the unused slots
 __host__ __device__ inline bool gram_pos_to_entry(int nblk, int pos, int* i, int* j, bool* diag)
 {
     const int lane = pos & 63, s = (lane >> 2) & 3;
     const int c = gram_cand(nblk, pos >> 6);
-    if(c < 0 || !gram_slot_valid(nblk, c, s)) return false;
-    int gA = 0, gB = 0, r = 0;
-    gram_cand_decode(c, &gA, &gB, &r);
-    const int bA = 4*gA + s, bB = 4*gB + ((s + r) & 3);
+    int bA = 0, bB = 0;
+    if(c < 0 || !gram_slot_pair(nblk, c, s, &bA, &bB)) return false;
     *i = 4*bA + (lane >> 4);
     *j = 4*bB + (lane & 3);
     *diag = (bA == bB);
     return true;
+}
+// tile column this lane reads for operand `iread` (0: X; then Y or Y_q)
+__host__ __device__ inline int gram_read_col(int nblk, int iread, int lane)
+{
+    if(iread == 0) return lane & 15;
+    const int ny = gram_ny(nblk), s = (lane >> 2) & 3;
+    if(ny == 4) return 16 + (lane & 15);
+    return 16 + 4*((s + (iread - 1)) % ny) + (lane & 3);
 }
 
 struct DeviceProblem

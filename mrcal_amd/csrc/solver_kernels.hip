@@ -25,6 +25,7 @@
 // 1200-parameter splined camera x 800 frames): trivial against 288 GB of HBM,
 // and it turns the Schur complement into one SYRK.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "problem.hpp"
 #include "solver_kernels.hpp"
 #include <type_traits>
@@ -351,91 +352,138 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
     }
 }
 
-// S = A + lambda I ;  r = g_S.  The SYRK then subtracts Wt^T Wt and Wt^T y
+// S = A + lambda I - sum_slots partial(Wt^T Wt) ;  r = g_S - sum_slots partial(Wt^T y).
+// The SYRK below leaves, per slot (= slice of E rows), the 16x16 tiles of its
+// part of Wt^T Wt in the MFMA's register order, Spart[slot][pair][v][lane] with
+// element (i = 16 bi + lane/16 + 4 v, j = 16 bj + lane%16), and behind all of
+// those its part of Wt^T y, rpart[slot][16 nb]. One thread per tile element
+// sums over the slots (coalesced) and writes the LOWER triangle S[j][i], j >= i,
+// which is what the Cholesky reads. (A lives in the full square; only its lower
+// triangle is copied.) No atomics anywhere: the result does not depend on the
+// order in which workgroups finish
+#define SRED_SPLIT 4      // threads sharing one output element (adjacent lanes)
 __global__ __launch_bounds__(256)
-void schur_init_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
-                       double* __restrict__ S, double* __restrict__ r)
+void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
+                         int nslots, const double* __restrict__ Spart,
+                         double* __restrict__ S, double* __restrict__ r)
 {
     if(opref_skip(R)) return;
     const OpDev& O = opref_get(R);
     const double lambda = is_leader ? (ctl ? ctl->lambda : lambda_host) : 0.0;
-    const size_t idx = (size_t)blockIdx.x*blockDim.x + threadIdx.x;
-    const size_t n2  = (size_t)nd.Nc*nd.Nc;
-    if(idx < n2)
+    const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
+    // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
+    // loads in flight; the 64-byte groups they read are still whole cache lines
+    // across the wave (16 consecutive elements x SRED_SPLIT slots)
+    const int gid = blockIdx.x*blockDim.x + threadIdx.x;
+    const int sub = (gid >> 4) & (SRED_SPLIT-1);
+    const int idx = ((gid >> 6) << 4) | (gid & 15);      // 16 elements per wave
+    const int nS  = npairs*256, nTot = nS + nb*16;
+    if(idx >= nTot) return;
+    const bool is_r = idx >= nS;
+    const double* __restrict__ base = is_r ? Spart + (size_t)nslots*nS + (idx - nS) : Spart + idx;
+    const size_t stride = is_r ? (size_t)nb*16 : (size_t)nS;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int s = sub;
+    for(; s + 3*SRED_SPLIT < nslots; s += 4*SRED_SPLIT)
     {
-        const int i = (int)(idx / nd.Nc), j = (int)(idx - (size_t)i*nd.Nc);
-        S[idx] = O.A[idx] + ((i==j) ? lambda : 0.0);
+        a0 += base[(size_t)(s                )*stride];
+        a1 += base[(size_t)(s +   SRED_SPLIT)*stride];
+        a2 += base[(size_t)(s + 2*SRED_SPLIT)*stride];
+        a3 += base[(size_t)(s + 3*SRED_SPLIT)*stride];
     }
-    if(idx < (size_t)nd.Nc)
+    for(; s < nslots; s += SRED_SPLIT) a0 += base[(size_t)s*stride];
+    double acc = (a0 + a1) + (a2 + a3);
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if(sub != 0) return;
+    if(!is_r)
     {
-        const int i = (int)idx;
-        r[i] = is_leader ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0;
+        int bi = 0, p = idx >> 8;
+        while(p >= nb - bi) { p -= nb - bi; bi++; }
+        const int bj = bi + p;
+        const int v = (idx >> 6) & 3, lane = idx & 63;
+        const int i = 16*bi + (lane >> 4) + 4*v, j = 16*bj + (lane & 15);
+        if(i < nd.Nc && j < nd.Nc && j >= i)
+            S[(size_t)j*nd.Nc + i] = O.A[(size_t)j*nd.Nc + i] + ((i==j) ? lambda : 0.0) - acc;
+    }
+    else
+    {
+        const int i = idx - nS;
+        if(i < nd.Nc)
+            r[i] = (is_leader ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0) - acc;
     }
 }
 
-// S -= Wt^T Wt ,  r -= Wt^T y.   Tile (32 x 32 of S) x (slice of E rows) per
-// workgroup; partial products are added atomically. Tiles with bj < bi are
-// skipped and the result goes to the LOWER triangle (S[j][i], j >= i), which is
-// what the Cholesky reads
-#define SYRK_TILE 32
-__global__ __launch_bounds__(256)
-void schur_syrk_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
-                       const double* __restrict__ Wt, const double* __restrict__ y,
-                       double* __restrict__ S, double* __restrict__ r)
+// Wt^T Wt and Wt^T y on the FP64 matrix cores: one wave per (16x16 tile of S,
+// slice of E rows), v_mfma_f64_16x16x4: with lane l holding
+// Wt[k0 + l/16][c0 + l%16], one 8-byte load per lane is a whole A operand
+// (A[i][k] = Wt[k][i0+i]) and, for another column block, a whole B operand:
+// 2 loads feed 1024 multiply-adds, no LDS, no barriers. Each wave stores its
+// accumulators as they are (coalesced) into its slot of Spart;
+// schur_reduce_kernel sums the slots. The products of the diagonal tiles with
+// y give r. Result layout of the instruction (measured): register v of lane l
+// holds D[l/16 + 4 v][l%16]
+typedef double syrk_d4 __attribute__((ext_vector_type(4)));
+#define SYRK_UNROLL 16
+__global__ __launch_bounds__(64)
+void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
+                            int slot0, int nslots_total,
+                            const double* __restrict__ Wt, const double* __restrict__ y,
+                            double* __restrict__ Spart)
 {
     if(skip != NULL && *skip) return;
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if(bj < bi) return;
-    const int e_begin = e_lo + blockIdx.z*e_per_slice;
-    const int e_end   = min(e_hi, e_begin + e_per_slice);
-    if(e_begin >= e_end) return;
+    // tile pair p -> (bi <= bj)
+    const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
+    int bi = 0, p = blockIdx.x;
+    while(p >= nb - bi) { p -= nb - bi; bi++; }
+    const int bj = bi + p;
+    const int e_begin = e_lo + blockIdx.y*e_per_slice;
+    const int e_end   = min(e_hi, e_begin + e_per_slice);   // may be empty: the slot is then written as zeros
 
-    __shared__ double Wi[16][SYRK_TILE+1];
-    __shared__ double Wj[16][SYRK_TILE+1];
-    __shared__ double ys[16];
+    const int lane = threadIdx.x;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int ci = 16*bi + cc, cj = 16*bj + cc;
+    const bool oki = ci < nd.Nc, okj = cj < nd.Nc;
+    const double* __restrict__ pi = Wt + (oki ? ci : 0);
+    const double* __restrict__ pj = Wt + (okj ? cj : 0);
+    const bool diag = (bi == bj);
 
-    const int t  = threadIdx.x;
-    const int tx = t & 15, ty = t >> 4;     // 16 x 16 threads, 2x2 outputs each
-    const int i0 = bi*SYRK_TILE, j0 = bj*SYRK_TILE;
-    double acc[2][2] = {{0,0},{0,0}};
-    double accr[2]   = {0,0};
-
-    for(int e = e_begin; e < e_end; e += 16)
+    syrk_d4 acc  = {0.0, 0.0, 0.0, 0.0};
+    syrk_d4 accr = {0.0, 0.0, 0.0, 0.0};
+    for(int e0 = e_begin; e0 < e_end; e0 += 4*SYRK_UNROLL)
     {
-        // stage 16 E rows x 32 columns of each block
-        for(int idx = t; idx < 16*SYRK_TILE; idx += 256)
-        {
-            const int ee = idx / SYRK_TILE, cc = idx - ee*SYRK_TILE;
-            const bool ok = (e + ee < e_end);
-            Wi[ee][cc] = (ok && i0+cc < nd.Nc) ? Wt[(size_t)(e+ee)*nd.Nc + i0 + cc] : 0.0;
-            Wj[ee][cc] = (ok && j0+cc < nd.Nc) ? Wt[(size_t)(e+ee)*nd.Nc + j0 + cc] : 0.0;
-        }
-        if(t < 16) ys[t] = (e + t < e_end) ? y[e+t] : 0.0;
-        __syncthreads();
+        double a[SYRK_UNROLL], b[SYRK_UNROLL], yy[SYRK_UNROLL];
 #pragma unroll
-        for(int ee=0; ee<16; ee++)
+        for(int u=0;u<SYRK_UNROLL;u++)
         {
-            const double a0 = Wi[ee][ty], a1 = Wi[ee][ty+16];
-            const double b0 = Wj[ee][tx], b1 = Wj[ee][tx+16];
-            acc[0][0] += a0*b0; acc[0][1] += a0*b1;
-            acc[1][0] += a1*b0; acc[1][1] += a1*b1;
-            if(bj == bi && tx == 0) { accr[0] += a0*ys[ee]; accr[1] += a1*ys[ee]; }
+            const int  e  = e0 + 4*u + kk;
+            const bool ok = e < e_end;
+            const size_t row = (size_t)(ok ? e : e_begin)*nd.Nc;
+            a[u] = pi[row];
+            b[u] = diag ? 0.0 : pj[row];
+            yy[u] = (diag && cc == 0) ? y[ok ? e : e_begin] : 0.0;
+            if(!ok || !oki) a[u] = 0.0;
+            if(!ok || !okj) b[u] = 0.0;
+            if(!ok) yy[u] = 0.0;
         }
-        __syncthreads();
+#pragma unroll
+        for(int u=0;u<SYRK_UNROLL;u++)
+        {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], diag ? a[u] : b[u], acc, 0, 0, 0);
+            if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
+        }
     }
-    for(int a=0;a<2;a++)
-        for(int bb=0;bb<2;bb++)
-        {
-            const int i = i0 + ty + 16*a, j = j0 + tx + 16*bb;
-            if(i < nd.Nc && j < nd.Nc && j >= i)
-                atomicAdd(&S[(size_t)j*nd.Nc + i], -acc[a][bb]);
-        }
-    if(bj == bi && tx == 0)
-        for(int a=0;a<2;a++)
-        {
-            const int i = i0 + ty + 16*a;
-            if(i < nd.Nc) atomicAdd(&r[i], -accr[a]);
-        }
+    const int slot = slot0 + blockIdx.y;
+    double* __restrict__ o = Spart + ((size_t)slot*npairs + blockIdx.x)*256;
+#pragma unroll
+    for(int v=0;v<4;v++) o[64*v + lane] = acc[v];
+    if(diag && cc == 0)
+    {
+        // column 0 of the y product: D[i][0] = sum_k Wt[k][i0+i] y[k]
+        double* __restrict__ rpart = Spart + (size_t)nslots_total*npairs*256 + (size_t)slot*nb*16 + 16*bi;
+#pragma unroll
+        for(int v=0;v<4;v++) rpart[kk + 4*v] = accr[v];
+    }
 }
 
 // Dense Cholesky of S (lower triangle valid on input) and the solve S d = -r,
@@ -1355,6 +1403,30 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
 // r_loc = (g_S) - sum_local Wt^T y. The "(...)" terms are added by the shard
 // leader only, so that the sum over shards has them once. lambda comes from
 // the control block if one is given
+// SYRK slicing: ~SYRK_TARGET_WAVES one-wave workgroups per part, slices a
+// multiple of the unrolled k-loop. Both parts (frame blocks, point blocks) get
+// the same number of slots whether or not they are populated
+#define SYRK_TARGET_WAVES 2048
+static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_per_slice)
+{
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    int ns = SYRK_TARGET_WAVES / npairs;
+    if(ns < 1) ns = 1;
+    int per = (nrows + ns - 1)/ns;
+    per = ((per + 4*SYRK_UNROLL - 1)/(4*SYRK_UNROLL))*(4*SYRK_UNROLL);
+    if(per < 4*SYRK_UNROLL) per = 4*SYRK_UNROLL;
+    ns = (nrows + per - 1)/per;
+    *nslices = ns; *e_per_slice = per;
+}
+size_t schur_partial_doubles(const NormalDims& nd)
+{
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    int ns = SYRK_TARGET_WAVES / npairs;
+    if(ns < 1) ns = 1;
+    const size_t nslots = 2*(size_t)ns;
+    return nslots*npairs*256 + nslots*nb*16 + 64;
+}
+
 hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
                                const OpRef& R, const FactorBuffers& F,
                                double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream)
@@ -1362,25 +1434,23 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
     if(br.count() > 0)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
                            nd, br, R, lambda, ctl, F.Wt, F.LD, F.y, F.status);
-    {
-        const size_t n2 = (size_t)nd.Nc*nd.Nc;
-        hipLaunchKernelGGL(schur_init_kernel, dim3((unsigned)((n2 + 255)/256)), dim3(256), 0, stream,
-                           nd, R, lambda, ctl, is_leader ? 1 : 0, F.S, F.r);
-    }
     // the E rows of the local blocks: two contiguous ranges (frames, points)
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    int e_lo[2], e_hi[2], ns[2] = {0,0}, per[2] = {0,0};
     for(int part = 0; part < 2; part++)
     {
-        int e_lo, e_hi;
-        br.e_range(nd, part, &e_lo, &e_hi);
-        if(e_hi <= e_lo) continue;
-        const int ntile  = (nd.Nc + SYRK_TILE - 1)/SYRK_TILE;
-        int nslices = 2048 / (ntile*(ntile+1)/2);
-        if(nslices < 1) nslices = 1;
-        int e_per_slice = (e_hi - e_lo + nslices - 1)/nslices;
-        e_per_slice = ((e_per_slice + 15)/16)*16;
-        nslices = (e_hi - e_lo + e_per_slice - 1)/e_per_slice;
-        hipLaunchKernelGGL(schur_syrk_kernel, dim3(ntile, ntile, nslices), dim3(256), 0, stream,
-                           nd, R.skip, e_lo, e_hi, e_per_slice, F.Wt, F.y, F.S, F.r);
+        br.e_range(nd, part, &e_lo[part], &e_hi[part]);
+        if(e_hi[part] > e_lo[part]) syrk_slicing(nd, e_hi[part] - e_lo[part], &ns[part], &per[part]);
+    }
+    const int nslots = ns[0] + ns[1];
+    for(int part = 0, slot0 = 0; part < 2; slot0 += ns[part], part++)
+        if(ns[part] > 0)
+            hipLaunchKernelGGL(schur_syrk_mfma_kernel, dim3(npairs, ns[part]), dim3(64), 0, stream,
+                               nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
+    {
+        const int n = (npairs*256 + nb*16)*SRED_SPLIT;
+        hipLaunchKernelGGL(schur_reduce_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
+                           nd, R, lambda, ctl, is_leader ? 1 : 0, nslots, F.Spart, F.S, F.r);
     }
     return hipGetLastError();
 }

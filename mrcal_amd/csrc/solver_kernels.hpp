@@ -68,9 +68,12 @@ struct FactorBuffers
     double* y;        // [NE]       L_e^-1 g_e
     double* S;        // [Nc][Nc]   Schur complement -> its Cholesky factor (lower)
     double* r;        // [Nc]       reduced rhs -> d_s
-    double* Linv;     // [ceil(Nc/16)][16][16] inverses of the diagonal blocks (large Nc only)
+    double* Spart;    // [schur_partial_doubles(nd)] per-slice partial products of the SYRK, summed by schur_reduce_kernel
     int*    status;   // [1] nonzero: not positive definite
 };
+
+// size of FactorBuffers::Spart (solver_kernels.hip: SYRK slicing)
+size_t schur_partial_doubles(const NormalDims& nd);
 
 // iteration-invariant work lists for the assembly
 struct AssemblyPlan
