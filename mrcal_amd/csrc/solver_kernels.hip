@@ -308,12 +308,28 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
     const double lambda = ctl ? ctl->lambda : lambda_host;
 
     __shared__ double L[36];
+    __shared__ double rinv[6];
     const int blk = br.block(blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
     const int t   = threadIdx.x;
 
-    if(t < 36) L[t] = D[(size_t)blk*36 + t] + (((t/6) == (t%6)) ? lambda : 0.0);
+    // everything this workgroup reads is requested up front: the block, and this
+    // lane's columns of Bt_e (column Nc is g_e). The 6x6 factorization below
+    // then runs under the latency of the big loads
+    const double dval = (t < 36) ? D[(size_t)blk*36 + t] : 0.0;
+    constexpr int MAXC = 4;                // columns per lane held in registers: Nc <= 255
+    double bt[MAXC][6];
+#pragma unroll
+    for(int cc = 0; cc < MAXC; cc++)
+    {
+        const int c = t + 64*cc;
+#pragma unroll
+        for(int i=0;i<6;i++)
+            bt[cc][i] = (i < de && c <= nd.Nc) ? ((c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.Nie + e0 + i]) : 0.0;
+    }
+
+    if(t < 36) L[t] = dval + (((t/6) == (t%6)) ? lambda : 0.0);
     __syncthreads();
     if(t == 0)
     {
@@ -324,12 +340,14 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
             for(int k=0;k<j;k++) d -= L[j*6+k]*L[j*6+k];
             if(!(d > 0.0)) { ok = false; d = 1.0; }
             d = sqrt(d);
+            const double rd = 1.0/d;
             L[j*6+j] = d;
+            rinv[j]  = rd;
             for(int i=j+1;i<de;i++)
             {
                 double v = L[i*6+j];
                 for(int k=0;k<j;k++) v -= L[i*6+k]*L[j*6+k];
-                L[i*6+j] = v/d;
+                L[i*6+j] = v*rd;
             }
         }
         if(!ok) atomicExch(status, 1);
@@ -337,15 +355,41 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
     __syncthreads();
     if(t < 36) LD[(size_t)blk*36 + t] = L[t];
 
-    // forward substitution, one column of Bt_e per lane; column Nc is g_e
-    for(int c = t; c <= nd.Nc; c += blockDim.x)
+    // forward substitution, one column of Bt_e per lane and pass
+    double Lr[6][6], ri[6];
+#pragma unroll
+    for(int i=0;i<6;i++)
+    {
+        ri[i] = rinv[i < de ? i : 0];
+#pragma unroll
+        for(int k=0;k<6;k++) Lr[i][k] = L[i*6+k];
+    }
+#pragma unroll
+    for(int cc = 0; cc < MAXC; cc++)
+    {
+        const int c = t + 64*cc;
+        if(c > nd.Nc) break;
+        double w[6];
+#pragma unroll
+        for(int i=0;i<6;i++)
+        {
+            double v = bt[cc][i];
+#pragma unroll
+            for(int k=0;k<i;k++) v -= Lr[i][k]*w[k];
+            w[i] = v*ri[i];
+        }
+        if(c < nd.Nc) { for(int i=0;i<de;i++) Wt[(size_t)(e0+i)*nd.Nc + c] = w[i]; }
+        else          { for(int i=0;i<de;i++) y[e0+i] = w[i]; }
+    }
+    // wider camera blocks: the remaining columns, plainly
+    for(int c = t + 64*MAXC; c <= nd.Nc; c += blockDim.x)
     {
         double w[6];
         for(int i=0;i<de;i++)
         {
             double v = (c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.Nie + e0 + i];
             for(int k=0;k<i;k++) v -= L[i*6+k]*w[k];
-            w[i] = v / L[i*6+i];
+            w[i] = v*rinv[i];
         }
         if(c < nd.Nc) for(int i=0;i<de;i++) Wt[(size_t)(e0+i)*nd.Nc + c] = w[i];
         else          for(int i=0;i<de;i++) y[e0+i] = w[i];
@@ -514,8 +558,9 @@ template<int N>
 __device__ __forceinline__ double row_share_f64(double v)   // lane N of each 16-lane row, to the row
 {
     union { double d; int i[2]; } u; u.d = v;
-    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + N, 0xf, 0xf, false);
-    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + N, 0xf, 0xf, false);
+    // bound_ctrl with full masks: every lane is written, no need to initialize the destination
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + N, 0xf, 0xf, true);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + N, 0xf, 0xf, true);
     return u.d;
 }
 typedef double chol_double4_t __attribute__((ext_vector_type(4)));
@@ -530,6 +575,7 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     const int t    = threadIdx.x;
     const int nt   = blockDim.x;
     const int lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // the same, known to be wave-uniform
     const int l16  = t & 15;                  // lane within its DPP row
     const int npanels = (n + CHOL_PB - 1)/CHOL_PB;
 
@@ -571,14 +617,11 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     __syncthreads();
 
-    for(int p = 0; p < npanels; p++)
+    // (a) diagonal block of panel p: wave 0, lanes 0..15 hold rows j0..j0+15
+    auto factor_diag = [&](int p) __attribute__((always_inline))
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
-        const int m0 = j0 + jb;
-
-        // (a) diagonal block: wave 0, lanes 0..15 hold rows j0..j0+15
-        if(wave == 0)
         {
             double row[CHOL_PB];
             {
@@ -593,33 +636,60 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                 for(int c = 0; c < CHOL_PB; c++) row[c] = (mine && c <= lane) ? tmp[c] : 0.0;
             }
             // No predication anywhere: the entries above the diagonal (row[c]
-            // of lane i < c) are simply never read for anything that matters
+            // of lane i < c) are simply never read for anything that matters.
+            //
+            // The pivot chain (broadcast, 1/sqrt with two Newton steps, scaling)
+            // is a string of dependent FP64 instructions; the rank-1 update of
+            // the columns to the right is independent work. Column j's update
+            // touches column j+1 first (the next pivot needs only that), the
+            // rest of it is deferred and issued in between the instructions
+            // of column j+1's pivot chain, where it fills their latency
             double myrd = 1.0;
             bool   bad  = false;
-            auto column = [&](auto J)
+            // row[c] -= L[i][j] L[c][j] for c in [C0,C1], c > j; L[c][j] = lane c's row[j]
+            auto upd = [&](auto J, auto C0, auto C1)
             {
-                constexpr int j = decltype(J)::value;
-                if(j >= jb) return;
-                double piv = row_share_f64<j>(row[j]);
-                bad = bad || !(piv > 0.0);
-                piv = (piv > 0.0) ? piv : 1.0;
-                // 1/sqrt(piv): hardware estimate + 2 Newton steps, sqrt = piv*rsqrt
-                double rd = __builtin_amdgcn_rsq(piv);
-                rd = rd*(1.5 - 0.5*piv*rd*rd);
-                rd = rd*(1.5 - 0.5*piv*rd*rd);
-                myrd = (lane == j) ? rd : myrd;
-                row[j] *= rd;      // lane j: piv*rd = sqrt(piv)
-                // L[i][c] -= L[i][j] L[c][j]; L[c][j] = lane c's row[j]
-#define CHOL_UPD(c) if((c) > j) row[(c) & 15] -= row[j]*row_share_f64<(c) & 15>(row[j]);
+                constexpr int j = decltype(J)::value, c0 = decltype(C0)::value, c1 = decltype(C1)::value;
+#define CHOL_UPD(c) if(j >= 0 && (c) > j && (c) >= c0 && (c) <= c1 && j < jb) row[(c) & 15] -= row[j & 15]*row_share_f64<(c) & 15>(row[j & 15]);
                 CHOL_UPD(1)  CHOL_UPD(2)  CHOL_UPD(3)  CHOL_UPD(4)  CHOL_UPD(5)
                 CHOL_UPD(6)  CHOL_UPD(7)  CHOL_UPD(8)  CHOL_UPD(9)  CHOL_UPD(10)
                 CHOL_UPD(11) CHOL_UPD(12) CHOL_UPD(13) CHOL_UPD(14) CHOL_UPD(15)
 #undef CHOL_UPD
             };
-#define CHOL_COL(j) column(std::integral_constant<int,(j)>{});
+#define IC(v) std::integral_constant<int,(v)>{}
+            auto column = [&](auto J)
+            {
+                constexpr int j = decltype(J)::value;
+                if(j >= jb) return;
+                // pending: the update from column j-1 of the columns j+1..15, in slices
+                double piv = row_share_f64<j>(row[j]);
+                upd(IC(j-1), IC(j+1), IC(j+2));
+                bad = bad || !(piv > 0.0);
+                piv = (piv > 0.0) ? piv : 1.0;
+                // 1/sqrt(piv): hardware estimate + 2 Newton steps rd <- rd (1.5 - 0.5 piv rd^2)
+                double rd = __builtin_amdgcn_rsq(piv);
+                const double hp = -0.5*piv;
+                upd(IC(j-1), IC(j+3), IC(j+4));
+                double sq = rd*rd;
+                upd(IC(j-1), IC(j+5), IC(j+6));
+                double u  = fma(hp, sq, 1.5);
+                upd(IC(j-1), IC(j+7), IC(j+8));
+                rd = rd*u;
+                upd(IC(j-1), IC(j+9), IC(j+10));
+                sq = rd*rd;
+                upd(IC(j-1), IC(j+11), IC(j+12));
+                u  = fma(hp, sq, 1.5);
+                upd(IC(j-1), IC(j+13), IC(15));
+                rd = rd*u;
+                myrd = (lane == j) ? rd : myrd;
+                row[j] *= rd;      // lane j: piv*rd = sqrt(piv)
+                upd(IC(j), IC(j+1), IC(j+1));       // the next pivot's column first
+            };
+#define CHOL_COL(j) column(IC(j));
             CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
             CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
 #undef CHOL_COL
+#undef IC
             if(lane < jb)
             {
                 double* __restrict__ dst = rowptr(j0 + lane) + j0;
@@ -629,7 +699,29 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             }
             if(bad && lane == 0) notpd = 1;
         }
-        __syncthreads();
+    };
+
+    // Look-ahead: the diagonal block of panel p+1 is final as soon as ONE tile of
+    // panel p's trailing update is done. Wave 0 does that tile first and factors
+    // the block (a long dependent chain, 16 lanes) while waves 1..15 do the rest
+    // of the update: the chain is off the critical path of everything but itself
+#ifdef CHOL_TS
+    __shared__ long long sts[16][3];
+    long long cts[64]; int ncts = 0;
+#define CTS() do { if(t == 0 && ncts < 64) cts[ncts++] = clock64(); } while(0)
+#else
+#define CTS()
+#endif
+    CTS();
+    if(wave == 0) factor_diag(0);
+    __syncthreads();
+    CTS();
+
+    for(int p = 0; p < npanels; p++)
+    {
+        const int j0 = p*CHOL_PB;
+        const int jb = min(CHOL_PB, n - j0);
+        const int m0 = j0 + jb;
 
         // (b) rows below (and the rhs row): L[i][j0..] <- A[i][j0..] L11^-T. 16 lanes per row
         {
@@ -664,6 +756,7 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             }
         }
         __syncthreads();
+        CTS();
 
         // (c) trailing update with MFMA: C[i][c] -= sum_k L[i][k] L[c][k], k in the
         //     panel; rows m0..n (incl. the rhs row), columns m0..n-1, c <= i.
@@ -672,16 +765,22 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         //     tools/mfma_f64_layout_probe.hip): A lane = A[i=l%16][k=l/16],
         //     B lane = B[k=l/16][j=l%16], D register v of lane l = D[l/16 + 4v][l%16]
         {
+#ifdef CHOL_TS
+            if(p == 0 && lane == 0) sts[wave][0] = clock64();
+#endif
             const int nrows = n + 1 - m0, ncols = n - m0;
             const int ntr = (nrows + 15) >> 4, ntc = (ncols + 15) >> 4;
             const int r16 = lane & 15, kq = lane >> 4;
-            int tidx = 0;
-            for(int ta = 0; ta < ntr; ta++)
+            // tile (0,0) = the next diagonal block: wave 0; tiles 1.. : waves 1..15
+            // round-robin. Wave-uniform (scalar) bookkeeping: no wave walks
+            // through the other waves' tiles
+            int ntiles = 0;
+            for(int ta = 0; ta < ntr; ta++) ntiles += min(ta + 1, ntc);
+            for(int tix = wave_u; tix < ntiles; tix += (wave_u == 0 ? ntiles : 15))
             {
-                const int ntb = min(ta + 1, ntc);
-                for(int tb = 0; tb < ntb; tb++, tidx++)
+                int ta = 0, tb = tix;
+                for(;;) { const int ntb = min(ta + 1, ntc); if(tb < ntb) break; tb -= ntb; ta++; }
                 {
-                    if((tidx & 15) != wave) continue;
                     const int  ia = 16*ta + r16, ib = 16*tb + r16;
                     const bool va = ia < nrows, vb = ib < ncols;
                     const double* __restrict__ pa = rowptr(m0 + (va ? ia : 0)) + j0;
@@ -711,10 +810,21 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                     for(int v = 0; v < 4; v++) if(cv[v]) *cp[v] = acc[v];
                 }
             }
+#ifdef CHOL_TS
+            if(p == 0 && lane == 0) sts[wave][1] = clock64();
+#endif
+            if(wave == 0 && p + 1 < npanels) factor_diag(p + 1);
+#ifdef CHOL_TS
+            if(p == 0 && lane == 0) sts[wave][2] = clock64();
+#endif
         }
         __syncthreads();
+        CTS();
     }
     if(t == 0 && notpd) atomicExch(status, 1);
+#ifdef CHOL_TS
+    if(t == 0) { printf("chol ts:"); for(int i=1;i<ncts;i++) printf(" %lld", cts[i]-cts[i-1]); printf(" | c0 per wave:"); for(int w=0;w<16;w++) printf(" %lld+%lld", sts[w][1]-sts[w][0], sts[w][2]-sts[w][1]); printf("\n"); }
+#endif
 
     // row n now holds z = L^-1 r. Solve L^T d = z backwards, panel by panel
     double* __restrict__ z = rowptr(n);
@@ -857,30 +967,33 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
     const int blk = br.block(blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
-    __shared__ double red[6][64];
+    // all the loads first: L, y, and this lane's columns of Wt_e against d_s
+    const double Lv = (t < 36) ? LD[(size_t)blk*36 + t] : 0.0;
+    const double yv = (t < de) ? y[e0 + t] : 0.0;
     double part[6] = {0,0,0,0,0,0};
     for(int c=t;c<nd.Nc;c+=blockDim.x)
     {
         const double d = ds[c];
-        for(int i=0;i<de;i++) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
+#pragma unroll
+        for(int i=0;i<6;i++) if(i < de) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
     }
-    for(int i=0;i<6;i++) red[i][t] = part[i];
+#pragma unroll
+    for(int i=0;i<6;i++)
+        for(int off=32; off>0; off>>=1) part[i] += __shfl_down(part[i], off);
+    __shared__ double Ls[36];
+    if(t < 36) Ls[t] = Lv;
     __syncthreads();
+    // lane 0 holds the sums; y comes from the lanes that loaded it
+    double v[6];
+#pragma unroll
+    for(int i=0;i<6;i++) v[i] = __shfl(yv, i) + part[i];
     if(t == 0)
     {
-        double v[6];
-        const double* L = LD + (size_t)blk*36;
-        for(int i=0;i<de;i++)
-        {
-            double s = y[e0+i];
-            for(int k=0;k<64;k++) s += red[i][k];
-            v[i] = s;
-        }
         for(int i=de-1;i>=0;i--)
         {
             double s = v[i];
-            for(int k=i+1;k<de;k++) s -= L[k*6+i]*v[k];
-            v[i] = s/L[i*6+i];
+            for(int k=i+1;k<de;k++) s -= Ls[k*6+i]*v[k];
+            v[i] = s/Ls[i*6+i];
         }
         for(int i=0;i<de;i++) step[nd.Nie + e0 + i] = -v[i];
     }
