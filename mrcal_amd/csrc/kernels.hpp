@@ -56,7 +56,8 @@ bool lens_supported(int lens_type);
 // board Jacobian kernel on the stream
 // parts: which of the evaluation's kernels to queue (the solver splits an
 // evaluation around the board kernel when that kernel is being timed)
-enum { EVAL_PART_PROLOGUE = 1, EVAL_PART_BOARD = 2, EVAL_PART_REST = 4, EVAL_PART_ALL = 7 };
+// ZERO: clearing the point's normal equations (needed before REST assembles them; independent of the rest)
+enum { EVAL_PART_PROLOGUE = 1, EVAL_PART_BOARD = 2, EVAL_PART_REST = 4, EVAL_PART_ZERO = 8, EVAL_PART_ALL = 15 };
 hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                            int lds_bytes, hipStream_t stream,
                            hipEvent_t ev_j0, hipEvent_t ev_j1, int parts = EVAL_PART_ALL);

@@ -184,10 +184,14 @@ bool problem_sync_ops(mrcal_amd_problem* P)
     return true;
 }
 
-bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobian, bool with_normal, int parts)
+bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobian, bool with_normal, int parts,
+                          hipStream_t stream)
 {
     if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
+    if(stream == NULL) stream = P->stream;
     const EvalBuffers B = P->eval_buffers(R, with_normal);
+    if(with_normal && (parts & EVAL_PART_ZERO))
+        HIP_TRY(launch_zero_normal(P->nd, R, stream), return false);
     hipEvent_t e0 = NULL, e1 = NULL;
     if(with_jacobian && (parts & EVAL_PART_BOARD) && !P->capturing)
     {
@@ -198,12 +202,12 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
             e1 = P->ev_pool[P->ev_pool_used++];
         }
     }
-    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, P->stream, e0, e1, parts),
+    HIP_TRY(launch_evaluate(P->D, B, with_jacobian, P->lds_bytes, stream, e0, e1, parts),
             return false);
     if(parts & EVAL_PART_BOARD)
         P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0 && e0 != NULL;
     if(with_normal && (parts & EVAL_PART_REST))
-        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, P->stream), return false);
+        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, stream), return false);
     return true;
 }
 

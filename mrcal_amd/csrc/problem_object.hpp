@@ -124,7 +124,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P);
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal);
 // the same, with the operating point possibly resolved on the device
 bool problem_evaluate_ref(mrcal_amd_problem* P, const mrcal_amd::OpRef& R, bool with_jacobian, bool with_normal,
-                          int parts = mrcal_amd::EVAL_PART_ALL);
+                          int parts = mrcal_amd::EVAL_PART_ALL, hipStream_t stream = NULL /* default: the problem's */);
 // uploads op[0..1] to d_ops
 bool problem_sync_ops(mrcal_amd_problem* P);
 }

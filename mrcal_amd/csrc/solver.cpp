@@ -124,8 +124,12 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
             HIP_TRY(launch_factor_local(P->nd, P->br, R, P->F, 0.0, ctl, true, P->stream), return false);
             HIP_TRY(launch_solve_backsub(P->nd, P->br, R, P->F, NULL, false, P->stream), return false);
         }
-        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream), return false);
-        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE)) return false;
+        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, false, 1), return false);
+        // (Running the joint poses and the clearing on a second stream next to this
+        // quadratic form was tried: the cross-stream dependencies cost more than the
+        // ~10 us of overlap they buy, in a graph and eagerly alike)
+        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, false, 2), return false);
+        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
     }
     if(segment == 0 || segment == 2)
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_BOARD)) return false;
@@ -157,12 +161,17 @@ bool capture_segment(mrcal_amd_problem* P, int segment, hipGraphExec_t* exec)
     return true;
 }
 
-// Queues one trial step: as ONE captured graph normally; when the board kernel
-// is being timed with per-launch events, as graph | event | kernel | event |
-// graph. Graphs are captured on first use (MRCAL_AMD_NO_GRAPH=1: eager launches)
+// Queues one trial step: eagerly, or (MRCAL_AMD_GRAPH=1) as ONE captured graph;
+// when the board kernel is being timed with per-launch events, as graph |
+// event | kernel | event | graph. Graphs are captured on first use
 bool queue_trial_step(mrcal_amd_problem* P)
 {
-    static const bool use_graph = (getenv("MRCAL_AMD_NO_GRAPH") == NULL);
+    // Measured (8 cameras x 1000 frames): the ~21 launches of a step queued
+    // eagerly take 277 us, replayed as one graph 279 us, as graph|kernel|graph
+    // (when the board kernel is timed with events) 297 us. Eager is the default;
+    // MRCAL_AMD_GRAPH=1 selects the graph, which does not depend on the host
+    // keeping up with the queue
+    static const bool use_graph = (getenv("MRCAL_AMD_GRAPH") != NULL);
     if(!use_graph) return enqueue_trial_step(P, 0);
     if(!P->ev_pool_enabled)
     {

@@ -1485,14 +1485,17 @@ __global__ void shard_gng_kernel(const OpDev* __restrict__ ops, const SolverCtl*
 ////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
+hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t stream)
+{
+    const size_t total = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + nd.Nstate + NSCALARS;
+    int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, R);
+    return hipGetLastError();
+}
+// the point's normal equations must have been cleared (launch_zero_normal)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream)
 {
-    {
-        const size_t total = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + nd.Nstate + NSCALARS;
-        int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, B.R);
-    }
     // splined models: no per-observation Gram; every row goes through the generic path
     const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
     if(P.Nobs_board > 0 && !by_rows)
@@ -1641,24 +1644,32 @@ hipError_t launch_step_begin(const OpDev* ops, SolverCtl* ctl, int* chol_status,
     hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl), chol_status);
     return hipGetLastError();
 }
+// parts: 1 = the step (dot products, coefficients, b[ia] = b[ib] + step), 2 = its
+// quadratic form for the expected improvement
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream, bool deterministic)
+                              double* step, hipStream_t stream, bool deterministic, int parts)
 {
-    int nb = (nd.Nstate + 255)/256; if(nb > 64) nb = 64;
-    if(deterministic)
-        hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                           (const double*)step, 0, 0);
-    else
-        hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
-    hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), F.status, step);
-    // for the expected improvement: (step^T N step, g.step, |step|^2) of ctl->ib
-    OpRef Rfrom = { ops, &ctl->ib, solver_ctl_skip_eval(ctl) };
-    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                       nd, Rfrom, step, 0, (double*)NULL, (int)SC_STEP_SNS, 3);
-    if(deterministic)
-        hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                           (const double*)step, 1, 0);
+    if(parts & 1)
+    {
+        int nb = (nd.Nstate + 255)/256; if(nb > 64) nb = 64;
+        if(deterministic)
+            hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
+                               (const double*)step, 0, 0);
+        else
+            hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
+        hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
+                           nd, ops, ctl, ctl_flags(ctl), F.status, step);
+    }
+    if(parts & 2)
+    {
+        // for the expected improvement: (step^T N step, g.step, |step|^2) of ctl->ib
+        OpRef Rfrom = { ops, &ctl->ib, solver_ctl_skip_eval(ctl) };
+        hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                           nd, Rfrom, step, 0, (double*)NULL, (int)SC_STEP_SNS, 3);
+        if(deterministic)
+            hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
+                               (const double*)step, 1, 0);
+    }
     return hipGetLastError();
 }
 hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)

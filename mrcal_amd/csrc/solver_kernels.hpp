@@ -116,6 +116,7 @@ struct SolverCtl
     int    Nsteps_accepted, Ntrials, Nfactorizations, Nevaluations;
 };
 
+hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t stream);
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream);
 hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
@@ -139,7 +140,7 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
 hipError_t launch_step_begin (const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream);
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
                               double* step, hipStream_t stream,
-                              bool deterministic = false);
+                              bool deterministic = false, int parts = 3);
 // |g|^2, g N g, the Cauchy step of the point just evaluated (ctl->ia, or ctl->ib if initial)
 // parts: 1 = the reduction g^T N g, 2 = the Cauchy step + bookkeeping
 hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
