@@ -162,14 +162,35 @@ void joint_pose_record(double* __restrict__ out,
         }
 }
 
+#define PROLOGUE_ZERO_BLOCKS 1024
 __global__ __launch_bounds__(64)
-void board_prologue_kernel(DeviceProblem P, OpRef R, double* __restrict__ joint)
+void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack)
 {
+    const OpRef R = B.R;
+    double* __restrict__ joint = B.joint;
     if(opref_skip(R)) return;
     const double* __restrict__ b = opref_get(R).b;
     // the blocks past the observations unpack the intrinsics of every camera
-    // and the board warp from the packed state (or copy the seeds)
+    // and the board warp from the packed state (or copy the seeds); the blocks
+    // past those clear the point's normal equations (a bandwidth job that runs
+    // next to the long dependent chains of the pose blocks instead of costing a
+    // launch of its own)
     const int nblocks_obs = (P.Nobs_board + 63)/64;
+    if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
+    {
+        const OpDev& O = opref_get(R);
+        const long long nz = (long long)gridDim.x - nblocks_obs - nblocks_unpack;
+        for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*64 + threadIdx.x; i < B.zero_total; i += nz*64)
+        {
+            long long j = i;
+            if(j < B.zero_n[0]) { O.A[j] = 0.0; continue; }        j -= B.zero_n[0];
+            if(j < B.zero_n[1]) { O.Bt[j] = 0.0; continue; }       j -= B.zero_n[1];
+            if(j < B.zero_n[2]) { O.D[j] = 0.0; continue; }        j -= B.zero_n[2];
+            if(j < B.zero_n[3]) { O.g[j] = 0.0; continue; }        j -= B.zero_n[3];
+            O.scalars[j] = 0.0;
+        }
+        return;
+    }
     if((int)blockIdx.x >= nblocks_obs)
     {
         double* __restrict__ u = joint + (size_t)P.Nobs_board*JOINT_STRIDE;
@@ -1498,8 +1519,9 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
     {
         const int nblocks_obs    = (P.Nobs_board + 63)/64;
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack), dim3(64), 0, stream,
-                           P, B.R, B.joint);
+        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero), dim3(64), 0, stream,
+                           P, B, nblocks_unpack);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
@@ -1515,8 +1537,12 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
     if(P.Nobs_point > 0)
     {
         if(P.Nobs_board <= 0)   // the unpacked intrinsics are the prologue kernel's job
-            hipLaunchKernelGGL(board_prologue_kernel, dim3((P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64), dim3(64), 0, stream,
-                               P, B.R, B.joint);
+        {
+            EvalBuffers Bu = B;
+            Bu.zero_total = 0;
+            const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
+            hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack);
+        }
         if(with_jacobian)
             hipLaunchKernelGGL((point_splined_kernel<true>),  dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
         else
@@ -1710,8 +1736,9 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     {
         const int nblocks_obs    = (P.Nobs_board + 63)/64;
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack), dim3(64), 0, stream,
-                           P, B.R, B.joint);
+        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero), dim3(64), 0, stream,
+                           P, B, nblocks_unpack);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {

@@ -48,6 +48,10 @@ struct EvalBuffers
     int32_t* Jp;     // CSR rowptr               [Nmeas+1]
     int32_t* Ji;     // CSR colidx               [Nnz]
     double*  gram;   // per-observation Gram     [Nobs_board][gram_stride(Ndist)]; NULL: don't form it
+    // if zero_total > 0 the prologue kernel also clears the point's normal
+    // equations: A[zero_n[0]], Bt[zero_n[1]], D[zero_n[2]], g[zero_n[3]], scalars[zero_n[4]]
+    long long zero_n[5];
+    long long zero_total;
 };
 
 bool lens_supported(int lens_type);

@@ -189,9 +189,20 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
 {
     if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
     if(stream == NULL) stream = P->stream;
-    const EvalBuffers B = P->eval_buffers(R, with_normal);
+    EvalBuffers B = P->eval_buffers(R, with_normal);
     if(with_normal && (parts & EVAL_PART_ZERO))
-        HIP_TRY(launch_zero_normal(P->nd, R, stream), return false);
+    {
+        if((parts & EVAL_PART_PROLOGUE) && P->D.Nobs_board > 0)
+        {
+            // the prologue kernel clears the normal equations on the side
+            const NormalDims& nd = P->nd;
+            B.zero_n[0] = (long long)nd.Nc*nd.Nc; B.zero_n[1] = (long long)nd.NE*nd.Nc; B.zero_n[2] = (long long)nd.NEb*36;
+            B.zero_n[3] = nd.Nstate;               B.zero_n[4] = NSCALARS;
+            B.zero_total = B.zero_n[0] + B.zero_n[1] + B.zero_n[2] + B.zero_n[3] + B.zero_n[4];
+        }
+        else
+            HIP_TRY(launch_zero_normal(P->nd, R, stream), return false);
+    }
     hipEvent_t e0 = NULL, e1 = NULL;
     if(with_jacobian && (parts & EVAL_PART_BOARD) && !P->capturing)
     {

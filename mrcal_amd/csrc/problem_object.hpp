@@ -109,6 +109,8 @@ struct mrcal_amd_problem
     {
         mrcal_amd::EvalBuffers B;
         B.R = R; B.joint = d_joint; B.Jp = d_Jp; B.Ji = d_Ji; B.gram = with_gram ? d_gram : NULL;
+        for(int i=0;i<5;i++) B.zero_n[i] = 0;
+        B.zero_total = 0;
         return B;
     }
     mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const { return eval_buffers(opref(i), with_gram); }

@@ -104,7 +104,8 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
 {
     const OpRef R = { P->d_ops, &P->d_ctl->ib, NULL };
     if(!problem_evaluate_ref(P, R, true, true)) return false;
-    HIP_TRY(launch_finish_point(P->nd, P->d_ops, P->d_ctl, true, P->stream), return false);
+    // ... and the start of the first trial
+    HIP_TRY(launch_step_finish(P->nd, P->d_ops, P->d_ctl, P->F.status, true, P->stream), return false);
     return true;
 }
 
@@ -117,7 +118,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval(ctl) };
     if(segment == 0 || segment == 1)
     {
-        HIP_TRY(launch_step_begin(P->d_ops, ctl, P->F.status, P->stream), return false);
+        // (the trial was started by the kernel that ended the previous one: step_finish_kernel)
         {
             // the Gauss-Newton step from the current point, if this trial needs it
             const OpRef R = { P->d_ops, &ctl->ib, solver_ctl_skip_factor(ctl) };
@@ -136,8 +137,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     if(segment == 0 || segment == 3)
     {
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_REST)) return false;
-        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, false, P->stream), return false);
-        HIP_TRY(launch_step_accept(P->d_ops, ctl, P->stream), return false);
+        HIP_TRY(launch_step_finish(P->nd, P->d_ops, ctl, P->F.status, false, P->stream), return false);
     }
     return true;
 }

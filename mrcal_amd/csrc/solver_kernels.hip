@@ -1171,9 +1171,9 @@ void outlier_stats_kernel(int Npoints_board, double thresh_sq,
 struct SolverCtlFlags { int skip_factor, skip_eval; };
 static_assert(sizeof(SolverCtlFlags) == 8, "");
 
-__global__ void step_begin_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
+// start of a trial step (one thread): does this trial factor, does it evaluate
+__device__ __forceinline__ void ctl_begin(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
 {
-    if(threadIdx.x != 0 || blockIdx.x != 0) return;
     ctl->abort_step = 0;
     *chol_status = 0;
     {
@@ -1192,6 +1192,11 @@ __global__ void step_begin_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl,
     if(ctl->need_gn) ctl->Nfactorizations++;
     fl->skip_factor = ctl->need_gn ? 0 : 1;
     fl->skip_eval   = 0;
+}
+__global__ void step_begin_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctl_begin(ops, ctl, fl, chol_status);
 }
 
 // |step_gn|^2 -> scalars[SC_GN_LENSQ], step_cauchy . step_gn -> scalars[SC_GN_DOT_CAUCHY] of the point ctl->ib
@@ -1332,11 +1337,9 @@ void finish_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl
     }
 }
 
-// rho test, trust-region update, accept/reject
-__global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, const SolverCtlFlags* __restrict__ fl)
+// rho test, trust-region update, accept/reject (one thread)
+__device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, SolverCtl* ctl)
 {
-    if(threadIdx.x != 0 || blockIdx.x != 0) return;
-    if(fl->skip_eval) return;     // finished, or the trial was voided
     const int ib = ctl->ib, ia = ctl->ia;
     const OpDev& from = ops[ib];
     // expected improvement: |x|^2 - |x + J s|^2 = -2 g.s - s^T N s
@@ -1358,6 +1361,45 @@ __global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl
     else if(ctl->check_termination &&
             (tr < ctl->trustregion_threshold || tr == 0.0 || !(tr == tr)))
         ctl->done = 1;
+}
+__global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, const SolverCtlFlags* __restrict__ fl)
+{
+    if(threadIdx.x != 0 || blockIdx.x != 0) return;
+    if(fl->skip_eval) return;     // finished, or the trial was voided
+    ctl_accept(ops, ctl);
+}
+
+// End of a trial step on ONE GPU, in one launch of ONE workgroup: the Cauchy
+// step of the point just evaluated (finish_point_kernel), the rho test with
+// accept/reject (step_accept_kernel) and the start of the NEXT trial
+// (step_begin_kernel). One workgroup so that a barrier separates "everyone has
+// read the control state" from "thread 0 rewrites it"; the vector part is
+// Nstate elements. initial: the evaluation of the starting point (no accept)
+__global__ __launch_bounds__(1024)
+void step_finish_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
+                        int* chol_status, int initial)
+{
+    const bool skip = !initial && fl->skip_eval;
+    const int  ip   = initial ? ctl->ib : ctl->ia;
+    const OpDev& O  = ops[ip];
+    const double gNg = O.scalars[SC_G_GNG], norm2_g = O.scalars[SC_G_GG], norm2_x = O.scalars[SC_NORM2_X];
+    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
+    __syncthreads();
+    if(!skip)
+        for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x) O.step_cauchy[i] = k*O.g[i];
+    if(threadIdx.x == 0)
+    {
+        if(!skip)
+        {
+            ctl->norm2_x[ip]      = norm2_x;
+            ctl->cauchy_lensq[ip] = k*k*norm2_g;
+            ctl->gn_valid[ip]     = 0;
+            ctl->did_step_to_edge[ip] = 0;
+            ctl->Nevaluations++;
+            if(!initial) ctl_accept(ops, ctl);
+        }
+        ctl_begin(ops, ctl, fl, chol_status);
+    }
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -1732,6 +1774,17 @@ hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool
 {
     hipLaunchKernelGGL(shard_gng_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl),
                        initial ? 1 : 0, unpack ? 1 : 0, comm);
+    return hipGetLastError();
+}
+// single-GPU end of a trial step: g^T N g, then step_finish_kernel (which also starts the next trial)
+hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
+                              hipStream_t stream)
+{
+    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
+    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                       nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
+    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
+                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream)

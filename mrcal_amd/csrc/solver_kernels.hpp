@@ -154,6 +154,8 @@ hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl*
 hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
 hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream);
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
+hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
+                              hipStream_t stream);
 
 // solves against a kept factorization (F as left by launch_factor_local() +
 // launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order
