@@ -1228,7 +1228,7 @@ void gn_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __res
 // this launch
 __global__ __launch_bounds__(256)
 void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                        const int* __restrict__ chol_status, double* __restrict__ step)
+                        const int* __restrict__ chol_status, double* __restrict__ step, int compute_dots)
 {
     if(ctl->done) return;
     const int  ib = ctl->ib, ia = ctl->ia;
@@ -1236,9 +1236,38 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const bool fresh_gn = ctl->need_gn != 0;
 
+    // |step_gn|^2 and step_gn . step_cauchy of a fresh Gauss-Newton step: every
+    // workgroup sums the whole vectors itself, in the same fixed order (so all
+    // of them, on every rank, get the same bits), instead of a reduction kernel
+    // of its own in front of this one
+    __shared__ double dots[2];
+    if(fresh_gn && compute_dots)
+    {
+        double a = 0.0, b = 0.0;
+        for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x)
+        {
+            const double gn = from.step_gn[i];
+            a += gn*gn;
+            b += gn*from.step_cauchy[i];
+        }
+        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        __shared__ double part[4][2];
+        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
+        __syncthreads();
+        if(threadIdx.x == 0)
+        {
+            dots[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+            dots[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
+        }
+        __syncthreads();
+        if(leader) { from.scalars[SC_GN_LENSQ] = dots[0]; from.scalars[SC_GN_DOT_CAUCHY] = dots[1]; }
+    }
+    const double gn_lensq_now = (fresh_gn && compute_dots) ? dots[0] : from.scalars[SC_GN_LENSQ];
+    const double gn_dot_now   = (fresh_gn && compute_dots) ? dots[1] : from.scalars[SC_GN_DOT_CAUCHY];
+
     if(fresh_gn)
     {
-        const double lensq = from.scalars[SC_GN_LENSQ];
+        const double lensq = gn_lensq_now;
         if(*chol_status != 0 || !(lensq == lensq))
         {
             // JtJ is singular: regularize, like libdogleg does, and void this trial
@@ -1268,8 +1297,8 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     {
         // Gauss-Newton step: fresh from this trial's factorization, or kept
         // from an earlier, rejected trial from the same point
-        norm2b = fresh_gn ? from.scalars[SC_GN_LENSQ] : ctl->gn_lensq[ib];
-        ab     = from.scalars[SC_GN_DOT_CAUCHY];
+        norm2b = fresh_gn ? gn_lensq_now : ctl->gn_lensq[ib];
+        ab     = gn_dot_now;
         if(norm2b <= dsq)
         {
             kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
@@ -1693,14 +1722,9 @@ hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl*
 {
     if(parts & 1)
     {
-        int nb = (nd.Nstate + 255)/256; if(nb > 64) nb = 64;
-        if(deterministic)
-            hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                               (const double*)step, 0, 0);
-        else
-            hipLaunchKernelGGL(gn_dots_kernel, dim3(nb), dim3(256), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl));
+        // (the dot products of the Gauss-Newton step are formed inside, deterministically)
         hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), F.status, step);
+                           nd, ops, ctl, ctl_flags(ctl), F.status, step, 1);
     }
     if(parts & 2)
     {
