@@ -178,7 +178,7 @@ def main():
                        Nnz_J = problem.Nnz_global,
                        parallelism = "single GPU" if world == 1 else f"frames sharded over {world} GPUs, all-reduce of the reduced normal equations"),
         roofline = dict(bound = "hbm",
-                        kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram)",
+                        kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
                         frac = achieved/HBM_PEAK_GBS,
                         traffic = traffic,
