@@ -62,7 +62,8 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
     }
     hipFree(d_ops);
-    hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs);
+    hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
+    hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.status);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -154,7 +155,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
                          if(meta[a].icam_intrinsics != meta[b].icam_intrinsics) return meta[a].icam_intrinsics < meta[b].icam_intrinsics;
                          return meta[a].icam_extrinsics < meta[b].icam_extrinsics;
                      });
-    const int CHUNK = 16;
+    const int CHUNK = REDUCE_CHUNK;
     std::vector<int> chunk_begin;
     for(int i=0;i<Nobs;)
     {
@@ -170,8 +171,72 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_upload(&P->plan.frame_obs_begin, frame_begin.data(), frame_begin.size());
     ok = ok && dev_upload(&P->plan.chunk_begin,     chunk_begin.data(), chunk_begin.size());
     ok = ok && dev_upload(&P->plan.pair_obs,        order.data(),       order.size());
+    {
+        // the (intrinsics, extrinsics) pairs, in the order of `order`
+        std::vector<int> obs_pair(Nobs > 0 ? Nobs : 1, 0), pair_rep;
+        for(int k=0;k<Nobs;k++)
+        {
+            const int o = order[k];
+            if(k == 0 || meta[o].icam_intrinsics != meta[order[k-1]].icam_intrinsics ||
+                         meta[o].icam_extrinsics != meta[order[k-1]].icam_extrinsics)
+                pair_rep.push_back(o);
+            obs_pair[o] = (int)pair_rep.size() - 1;
+        }
+        std::vector<int> chunk_pair(P->plan.Nchunks > 0 ? P->plan.Nchunks : 1, 0);
+        for(int c=0;c<P->plan.Nchunks;c++) chunk_pair[c] = obs_pair[order[chunk_begin[c]]];
+        P->plan.Npairs = (int)pair_rep.size();
+
+        const int nblk = tile_nblk(L.Ndist), npos = gram_stride(L.Ndist);
+        std::vector<int>    tab(npos, 0);
+        std::vector<PairOp> ptab((size_t)(pair_rep.empty() ? 1 : pair_rep.size())*npos, PairOp{PAIROP_NONE, 0});
+        for(int pos = 0; pos < npos; pos++)
+        {
+            int i, j; bool diag;
+            if(!gram_pos_to_entry(nblk, pos, &i, &j, &diag)) continue;
+            tab[pos] = (int)(0x80000000u | (diag ? 0x10000u : 0u) | ((unsigned)i << 8) | (unsigned)j);
+            for(size_t ip = 0; ip < pair_rep.size(); ip++)
+            {
+                const BoardObsMeta& m = meta[pair_rep[ip]];
+                const TileColInfo ci = board_tile_col_info(P->D, m, i), cj = board_tile_col_info(P->D, m, j);
+                PairOp op = { PAIROP_NONE, 0 };
+                const bool fi = ci.kind == COL_FRAME, fj = cj.kind == COL_FRAME;
+                const bool si = ci.kind == COL_S,     sj = cj.kind == COL_S;
+                const bool xi = ci.kind == COL_X,     xj = cj.kind == COL_X;
+                if(fi && fj)
+                    op = PairOp{ PAIROP_D | (diag ? 0 : PAIROP_MIRROR), ci.idx | (cj.idx << 16) };
+                else if(fi)
+                {
+                    // (frame, S) or (frame, x). In a diagonal block the mirrored
+                    // position carries the same product: it is taken there only
+                    if(!diag && sj)      op = PairOp{ PAIROP_BT, ci.idx | (state_to_SE(nd, cj.idx) << 16) };
+                    else if(!diag && xj) op = PairOp{ PAIROP_GF, ci.idx };
+                }
+                else if(fj)
+                {
+                    if(si)      op = PairOp{ PAIROP_BT, cj.idx | (state_to_SE(nd, ci.idx) << 16) };
+                    else if(xi) op = PairOp{ PAIROP_GF, cj.idx };
+                }
+                else if((si || xi) && (sj || xj) && !(diag && xi && sj))
+                {
+                    if(xi && xj)   op = PairOp{ PAIROP_NORM, 0 };
+                    else if(xj)    op = PairOp{ PAIROP_G, ci.idx };
+                    else if(xi)    op = PairOp{ PAIROP_G, cj.idx };
+                    else           op = PairOp{ PAIROP_A | (diag ? 0 : PAIROP_MIRROR),
+                                                state_to_SE(nd, ci.idx) | (state_to_SE(nd, cj.idx) << 16) };
+                }
+                ptab[ip*npos + pos] = op;
+                const int k = op.op & 0xff;
+                if(k == PAIROP_D || k == PAIROP_BT || k == PAIROP_GF) tab[pos] |= 0x20000;
+            }
+        }
+        ok = ok && dev_upload(&P->plan.pos_table,  tab.data(),        tab.size());
+        ok = ok && dev_upload(&P->plan.pair_table, ptab.data(),       ptab.size());
+        ok = ok && dev_upload(&P->plan.obs_pair,   obs_pair.data(),   obs_pair.size());
+        ok = ok && dev_upload(&P->plan.chunk_pair, chunk_pair.data(), chunk_pair.size());
+    }
     if(!ok) return false;
 
+    if(getenv("MRCAL_AMD_DEBUG_ABLATE")) P->D.debug_ablate = atoi(getenv("MRCAL_AMD_DEBUG_ABLATE"));
     P->solver_ready = true;
     return true;
 }

@@ -35,13 +35,6 @@ namespace mrcal_amd {
 ////////////////////////////////////////////////////////////////////////////////
 // index helpers
 ////////////////////////////////////////////////////////////////////////////////
-// state index -> S index (>=0) or -(1 + E index)
-__device__ __forceinline__ int state_to_SE(const NormalDims& nd, int col)
-{
-    if(col < nd.Nie) return col;
-    if(nd.Nwarp && col >= nd.i_state_warp) return nd.Nie + (col - nd.i_state_warp);
-    return -(1 + (col - nd.Nie));
-}
 // E index -> (block, offset in block, block size, E index of block start)
 __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk, int* a, int* de, int* e0)
 {
@@ -58,46 +51,19 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
 // assembly from the per-observation Grams
 ////////////////////////////////////////////////////////////////////////////////
 
-// What a column of the board kernel's tile (problem.hpp) is, for one observation
-enum { COL_ABSENT = 0, COL_S, COL_FRAME, COL_X };
-struct TileColInfo { int kind; int idx; };   // COL_S: state index; COL_FRAME: 0..5
-__device__ __forceinline__
-TileColInfo board_tile_col_info(const DeviceProblem& P, const BoardObsMeta& m, int col)
-{
-    TileColInfo r = { COL_ABSENT, 0 };
-    const int nd = P.Ndist;
-    if(col < 4)
-    {
-        if(P.Ncore_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + col; }
-    }
-    else if(col < 4 + nd)
-    {
-        if(P.Ndist_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + P.Ncore_state + (col - 4); }
-    }
-    else if(col < tile_frame0(nd))
-    {
-        if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0) { r.kind = COL_S; r.idx = m.i_state_extrinsics + (col - tile_ext0(nd)); }
-    }
-    else if(col < tile_warp0(nd))
-    {
-        if(P.do_optimize_frames) { r.kind = COL_FRAME; r.idx = col - tile_frame0(nd); }
-    }
-    else if(col < tile_xcol(nd))
-    {
-        if(P.has_warp_state) { r.kind = COL_S; r.idx = P.i_state_warp + (col - tile_warp0(nd)); }
-    }
-    else if(col == tile_xcol(nd))
-        r.kind = COL_X;
-    return r;
-}
+// What to do with each position of an observation's Gram is known in advance:
+// it depends on the position and on which (intrinsics, extrinsics) pair the
+// observation belongs to, nothing else. problem_prepare_solver() evaluates it
+// once into plan.pair_table[pair][pos] (PairOp, solver_kernels.hpp); the kernels
+// below only read Grams and add.
+
 // One workgroup per frame. Its observations are contiguous (the API requires
 // frame-sorted observations, mrcal-pywrap.c:1063-1138). The Grams are read
 // coalesced, position by position; the frame's rows of Bt, its D block and its
 // part of g are accumulated in LDS and written out whole:
 //   D_f  += G[frame,frame]      g_f += G[frame,x]     Bt[frame rows][S cols] += G[S,frame]
 __global__ __launch_bounds__(256)
-void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
-                            const int* __restrict__ frame_obs_begin, // [Nframes+1], local obs indices
+void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
                             const double* __restrict__ gram)
 {
     if(opref_skip(R)) return;
@@ -107,56 +73,43 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
     double* __restrict__ gf  = Df + 36;
     const int f = blockIdx.x;
     const int t = threadIdx.x;
-    const int o0 = frame_obs_begin[f], o1 = frame_obs_begin[f+1];
+    const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
     if(o0 >= o1) return;                       // not this shard's frame: its rows stay zero
     for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
     __syncthreads();
 
-    const int nblk = tile_nblk(P.Ndist);
     const int npos = gram_stride(P.Ndist);
     for(int pos = t; pos < npos; pos += blockDim.x)
     {
-        int i, j; bool diag;
-        if(!gram_pos_to_entry(nblk, pos, &i, &j, &diag)) continue;
-        // is a frame column involved at all? (same answer for every observation)
-        {
-            const int fr0 = tile_frame0(P.Ndist);
-            const bool fi = (i >= fr0 && i < fr0 + 6), fj = (j >= fr0 && j < fr0 + 6);
-            if(!P.do_optimize_frames || !(fi || fj)) continue;
-        }
+        if(!(plan.pos_table[pos] & 0x20000)) continue;      // no frame column in this position, for any pair
         // the observations of the frame, 8 Gram loads in flight at a time
         for(int ob = o0; ob < o1; ob += 8)
         {
             double vv[8];
+            PairOp op[8];
 #pragma unroll
             for(int u = 0; u < 8; u++)
-                vv[u] = (ob + u < o1) ? gram[(size_t)(ob + u)*npos + pos] : 0.0;
+            {
+                const int o = (ob + u < o1) ? ob + u : o0;
+                vv[u] = gram[(size_t)o*npos + pos];
+                op[u] = plan.pair_table[(size_t)plan.obs_pair[o]*npos + pos];
+            }
 #pragma unroll
             for(int u = 0; u < 8; u++)
             {
-            const int o = ob + u;
-            if(o >= o1) break;
-            const BoardObsMeta m = P.board_meta[o];
-            const TileColInfo ci = board_tile_col_info(P, m, i), cj = board_tile_col_info(P, m, j);
-            const double v = vv[u];
-            if(ci.kind == COL_FRAME && cj.kind == COL_FRAME)
-            {
-                atomicAdd(&Df[ci.idx*6 + cj.idx], v);
-                if(!diag) atomicAdd(&Df[cj.idx*6 + ci.idx], v);
-            }
-            else if(ci.kind == COL_FRAME)
-            {
-                // (frame, S) or (frame, x). In a diagonal block the mirrored
-                // position carries the same product: take it there only
-                if(diag) continue;
-                if(cj.kind == COL_S)      atomicAdd(&Btf[ci.idx*nd.Nc + state_to_SE(nd, cj.idx)], v);
-                else if(cj.kind == COL_X) atomicAdd(&gf[ci.idx], v);
-            }
-            else
-            {
-                if(ci.kind == COL_S)      atomicAdd(&Btf[cj.idx*nd.Nc + state_to_SE(nd, ci.idx)], v);
-                else if(ci.kind == COL_X) atomicAdd(&gf[cj.idx], v);
-            }
+                if(ob + u >= o1) break;
+                const double v = vv[u];
+                const int a = op[u].aux & 0xffff, b = op[u].aux >> 16;
+                switch(op[u].op & 0xff)
+                {
+                case PAIROP_D:
+                    atomicAdd(&Df[a*6 + b], v);
+                    if(op[u].op & PAIROP_MIRROR) atomicAdd(&Df[b*6 + a], v);
+                    break;
+                case PAIROP_BT: atomicAdd(&Btf[a*nd.Nc + b], v); break;
+                case PAIROP_GF: atomicAdd(&gf[a], v); break;
+                default: break;
+                }
             }
         }
     }
@@ -175,50 +128,42 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R,
 // workgroup per chunk of one pair's observation list, each thread summing its
 // Gram positions over the chunk (coalesced reads), then a few atomics
 __global__ __launch_bounds__(256)
-void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R,
-                         const int* __restrict__ chunk_begin,  // [Nchunks+1] into pair_obs
-                         const int* __restrict__ pair_obs,     // observation indices grouped by pair
+void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
                          const double* __restrict__ gram)
 {
     if(opref_skip(R)) return;
     double* __restrict__ A = opref_get(R).A;
     double* __restrict__ g = opref_get(R).g;
     double* __restrict__ norm2_x = &opref_get(R).scalars[SC_NORM2_X];
-    const int c0 = chunk_begin[blockIdx.x], c1 = chunk_begin[blockIdx.x+1];
+    const int c0 = plan.chunk_begin[blockIdx.x], c1 = plan.chunk_begin[blockIdx.x+1];
     if(c0 >= c1) return;
-    const BoardObsMeta m0 = P.board_meta[pair_obs[c0]];
-    const int nblk = tile_nblk(P.Ndist);
     const int npos = gram_stride(P.Ndist);
+    const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[blockIdx.x]*npos;
+    // the chunk's observations (at most REDUCE_CHUNK), once; then every load of
+    // a position is independent of everything but these: all in flight together
+    const int nobs = c1 - c0;
+    size_t base[REDUCE_CHUNK];
+#pragma unroll
+    for(int u = 0; u < REDUCE_CHUNK; u++)
+        base[u] = (size_t)plan.pair_obs[(u < nobs) ? c0 + u : c0]*npos;
     for(int pos = threadIdx.x; pos < npos; pos += blockDim.x)
     {
-        int i, j; bool diag;
-        if(!gram_pos_to_entry(nblk, pos, &i, &j, &diag)) continue;
-        const TileColInfo ci = board_tile_col_info(P, m0, i), cj = board_tile_col_info(P, m0, j);
-        const bool si = (ci.kind == COL_S), sj = (cj.kind == COL_S);
-        const bool xi = (ci.kind == COL_X), xj = (cj.kind == COL_X);
-        if(!((si || xi) && (sj || xj))) continue;
-        if(diag && xi && sj) continue;          // the mirrored position takes it
-        // 8 loads in flight at a time
+        const PairOp op = ops[pos];
+        const int kind = op.op & 0xff;
+        if(kind != PAIROP_A && kind != PAIROP_G && kind != PAIROP_NORM) continue;
+        double vv[REDUCE_CHUNK];
+#pragma unroll
+        for(int u = 0; u < REDUCE_CHUNK; u++) vv[u] = gram[base[u] + pos];
         double acc = 0.0;
-        for(int cb = c0; cb < c1; cb += 8)
-        {
-            int    oi[8];
-            double vv[8];
 #pragma unroll
-            for(int u = 0; u < 8; u++) oi[u] = pair_obs[(cb + u < c1) ? cb + u : c0];
-#pragma unroll
-            for(int u = 0; u < 8; u++) vv[u] = gram[(size_t)oi[u]*npos + pos];
-#pragma unroll
-            for(int u = 0; u < 8; u++) acc += (cb + u < c1) ? vv[u] : 0.0;
-        }
-        if(xi && xj)      atomicAdd(norm2_x, acc);
-        else if(xj)       atomicAdd(&g[ci.idx], acc);
-        else if(xi)       atomicAdd(&g[cj.idx], acc);
+        for(int u = 0; u < REDUCE_CHUNK; u++) acc += (u < nobs) ? vv[u] : 0.0;
+        if(kind == PAIROP_NORM)   atomicAdd(norm2_x, acc);
+        else if(kind == PAIROP_G) atomicAdd(&g[op.aux], acc);
         else
         {
-            const int a = state_to_SE(nd, ci.idx), bb = state_to_SE(nd, cj.idx);
-            atomicAdd(&A[(size_t)a*nd.Nc + bb], acc);
-            if(!diag) atomicAdd(&A[(size_t)bb*nd.Nc + a], acc);
+            const int a = op.aux & 0xffff, b = op.aux >> 16;
+            atomicAdd(&A[(size_t)a*nd.Nc + b], acc);
+            if(op.op & PAIROP_MIRROR) atomicAdd(&A[(size_t)b*nd.Nc + a], acc);
         }
     }
 }
@@ -1573,9 +1518,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
     {
         if(P.do_optimize_frames)
             hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), (6*nd.Nc + 42)*sizeof(double), stream,
-                               P, nd, B.R, plan.frame_obs_begin, B.gram);
+                               P, nd, B.R, plan, B.gram);
         hipLaunchKernelGGL(reduce_pairs_kernel, dim3(plan.Nchunks), dim3(256), 0, stream,
-                           P, nd, B.R, plan.chunk_begin, plan.pair_obs, B.gram);
+                           P, nd, B.R, plan, B.gram);
     }
     const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nmeas > row0)

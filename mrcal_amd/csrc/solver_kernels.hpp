@@ -76,13 +76,71 @@ struct FactorBuffers
 size_t schur_partial_doubles(const NormalDims& nd);
 
 // iteration-invariant work lists for the assembly
+// what one position of one observation's Gram contributes to
+enum { PAIROP_NONE = 0,
+       PAIROP_A,      // A[a][b] (+ A[b][a])          aux = a | b << 16 (S indices)
+       PAIROP_G,      // g[aux]                       aux = state index
+       PAIROP_NORM,   // |x|^2
+       PAIROP_D,      // D_f[a][b] (+ D_f[b][a])      aux = a | b << 16 (0..5)
+       PAIROP_BT,     // Bt_f[a][b]                   aux = frame variable a | S index b << 16
+       PAIROP_GF,     // g_f[a]
+       PAIROP_MIRROR = 0x100 };
+struct PairOp { int op, aux; };
+
+#define REDUCE_CHUNK 16     // observations of one pair summed by one workgroup of reduce_pairs_kernel
 struct AssemblyPlan
 {
     int* frame_obs_begin;  // [Nframes+1]
     int* chunk_begin;      // [Nchunks+1]
-    int* pair_obs;         // [Nobs_board]
-    int  Nchunks;
+    int* pair_obs;         // [Nobs_board] observation indices grouped by (intrinsics, extrinsics) pair
+    int* chunk_pair;       // [Nchunks] the pair of each chunk
+    int* obs_pair;         // [Nobs_board] the pair of each observation
+    int  Nchunks, Npairs;
+    // what each position of a stored Gram holds (gram_pos_to_entry(), evaluated once):
+    // bit 31 valid, bit 17 "involves a frame column", bit 16 "in a diagonal block", bits 8..15 i, bits 0..7 j
+    int*    pos_table;     // [gram_stride]
+    PairOp* pair_table;    // [Npairs][gram_stride]
 };
+
+// state index -> S index (>=0) or -(1 + E index)
+__host__ __device__ inline int state_to_SE(const NormalDims& nd, int col)
+{
+    if(col < nd.Nie) return col;
+    if(nd.Nwarp && col >= nd.i_state_warp) return nd.Nie + (col - nd.i_state_warp);
+    return -(1 + (col - nd.Nie));
+}
+// What a column of the board kernel's tile (problem.hpp) is, for one observation
+enum { COL_ABSENT = 0, COL_S, COL_FRAME, COL_X };
+struct TileColInfo { int kind; int idx; };   // COL_S: state index; COL_FRAME: 0..5
+__host__ __device__ inline
+TileColInfo board_tile_col_info(const DeviceProblem& P, const BoardObsMeta& m, int col)
+{
+    TileColInfo r = { COL_ABSENT, 0 };
+    const int nd = P.Ndist;
+    if(col < 4)
+    {
+        if(P.Ncore_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + col; }
+    }
+    else if(col < 4 + nd)
+    {
+        if(P.Ndist_state) { r.kind = COL_S; r.idx = m.i_state_intrinsics + P.Ncore_state + (col - 4); }
+    }
+    else if(col < tile_frame0(nd))
+    {
+        if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0) { r.kind = COL_S; r.idx = m.i_state_extrinsics + (col - tile_ext0(nd)); }
+    }
+    else if(col < tile_warp0(nd))
+    {
+        if(P.do_optimize_frames) { r.kind = COL_FRAME; r.idx = col - tile_frame0(nd); }
+    }
+    else if(col < tile_xcol(nd))
+    {
+        if(P.has_warp_state) { r.kind = COL_S; r.idx = P.i_state_warp + (col - tile_warp0(nd)); }
+    }
+    else if(col == tile_xcol(nd))
+        r.kind = COL_X;
+    return r;
+}
 
 // The dog-leg control block: everything the trust-region logic needs, in
 // device memory. libdogleg keeps this on the host between callbacks; here the
