@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iterations", type=int, default=3)
     ap.add_argument("--no-full-solve", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="diagnostic: take the multi-GPU code path (frame shards + RCCL collectives) even with one rank")
     return ap.parse_args()
 
 
@@ -98,8 +100,11 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl")
 
     import mrcal_amd
@@ -111,9 +116,9 @@ def main():
     workload = f"{args.cameras} cameras x {args.frames} frames x 10x10 corners, LENSMODEL_OPENCV8, " \
                "all variables optimized, warp + regularization"
 
-    if world > 1:
+    if sharded:
         from mrcal_amd.parallel import ShardedProblem
-        problem = ShardedProblem(**oi)
+        problem = ShardedProblem(_always_communicate=True, **oi)
         barrier = lambda: (dist.barrier(), torch.cuda.synchronize())
     else:
         from mrcal_amd.resident import Problem
@@ -137,7 +142,7 @@ def main():
     nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
     assert n == args.steps
 
-    if world > 1:
+    if sharded:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -152,7 +157,7 @@ def main():
     achieved   = alg_bytes/1e9/(kernel_ms*1e-3) if kernel_ms > 0 else 0.0
     traffic    = None
     tpath = os.path.join(ROOT, "profiles", "board_kernel_hbm_traffic.json")
-    if os.path.exists(tpath) and world == 1:
+    if os.path.exists(tpath) and not sharded:
         try:
             tj = json.load(open(tpath))
             if tj.get("workload_cameras") == args.cameras and tj.get("workload_frames") == args.frames:
@@ -176,7 +181,7 @@ def main():
         config  = dict(workload = workload,
                        Nstate = problem.Nstate_global, Nmeasurements = problem.Nmeas_global,
                        Nnz_J = problem.Nnz_global,
-                       parallelism = "single GPU" if world == 1 else f"frames sharded over {world} GPUs, all-reduce of the reduced normal equations"),
+                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), 4 all-reduces per step (reduced normal equations, frame steps, gradient, g^T JtJ g)"),
         roofline = dict(bound = "hbm",
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
@@ -188,7 +193,7 @@ def main():
         solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"]),
     )
 
-    if rank == 0 and not args.no_full_solve and world == 1:
+    if rank == 0 and not args.no_full_solve and not sharded:
         # the second half of the metric: one full solve, seed to return,
         # outlier rejection included, on a fresh copy
         from mrcal_amd.resident import Problem
@@ -206,15 +211,22 @@ def main():
 
     if rank == 0:
         cb = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             cb = cpu_baseline(oi, args.cpu_baseline_iterations)
         result["cpu_baseline"] = cb
-        print(json.dumps(result))
 
     problem.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE line, and the last thing on stdout (RCCL prints its banner at teardown)
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
+    if sharded:
+        # RCCL writes a version banner to stdout when the process exits: keep the JSON line the last one
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
 
 
 if __name__ == "__main__":

@@ -64,20 +64,23 @@ def partition_frames(indices_frame_camintrinsics_camextrinsics, Nframes, world):
 
 
 class Communicator:
-    """sum/max all-reduce over torch.distributed; no-ops for a single process"""
-    def __init__(self, group=None):
+    """sum/max all-reduce over torch.distributed; no-ops for a single process
+    (unless always=True: a world of one still goes through the backend, which is
+    how the RCCL plumbing is exercised on a one-GPU box)"""
+    def __init__(self, group=None, always=False):
         import torch.distributed as dist
         self.dist  = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = group
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank  = self.dist.get_rank(group)       if self.dist else 0
+        self.active = self.dist is not None and (self.world > 1 or always)
         self.Ncollectives = 0
     def sum(self, t):
-        if self.world > 1:
+        if self.active:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
             self.Ncollectives += 1
     def max(self, t):
-        if self.world > 1:
+        if self.active:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
             self.Ncollectives += 1
 
@@ -304,10 +307,10 @@ class ShardedProblem:
     torch.distributed process group (backend nccl = RCCL). Every rank passes
     the SAME optimization_inputs. API-compatible with resident.Problem where
     the benchmark needs it"""
-    def __init__(self, group=None, **optimization_inputs):
+    def __init__(self, group=None, _always_communicate=False, **optimization_inputs):
         from . import _api
         from .resident import Problem
-        self.comm = Communicator(group)
+        self.comm = Communicator(group, always=_always_communicate)
         p = _api._ingest(optimization_inputs, callback=False)
         ranges = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.comm.world)
         self.frame_range = ranges[self.comm.rank]
@@ -316,7 +319,7 @@ class ShardedProblem:
         self.Nstate_global, self.Nmeas_global = _api._sizes(p)
         self.Nstate = self.Nstate_global
         self.Nnz_global = self.problem.Nnz
-        if self.comm.world > 1:
+        if self.comm.active:
             import torch
             t = torch.tensor([float(self.problem.Nnz)], dtype=torch.float64, device="cuda")
             self.comm.sum(t)

@@ -108,3 +108,51 @@ def test_run_steps_continues(amd):
     assert st["Nevaluations"] == s1["Nevaluations"] == 8          # the seed + 7 trial points
     assert abs(st["norm2_x"] - s1["norm2_x"]) < 1e-6*s1["norm2_x"]
     assert tr == tr1
+
+
+def _nccl_worker(out_path, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import mrcal_amd
+    from mrcal_amd.parallel import ShardedProblem
+    oi = _problem(mrcal_amd._api)
+    sp = ShardedProblem(_always_communicate=True, **oi)
+    st = sp.solve()
+    b  = sp.b_packed()
+    np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], Noutliers=st["Noutliers_board"],
+             Ncollectives=sp.comm.Ncollectives)
+    sp.close()
+    dist.destroy_process_group()
+
+
+def test_rccl_plumbing_world1(amd, tmp_path):
+    """RCCL cannot put two ranks on one device, so the real backend is exercised
+    with a world of ONE: every all-reduce of the sharded step still goes through
+    torch.distributed/nccl on the problem's HIP stream, on tensors aliasing the
+    library's HBM buffers: the plumbing the 8-GPU run depends on"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    oi = _problem(amd._api)
+    with Problem(**oi) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "nccl1.npz")
+    port = 29900 + (os.getpid() % 90)
+    ctx = mp.get_context("spawn")
+    proc = ctx.Process(target=_nccl_worker, args=(out, port))
+    proc.start()
+    proc.join(300)
+    if proc.is_alive():
+        proc.terminate()
+        pytest.fail("the nccl world-1 run hung")
+    assert proc.exitcode == 0
+    r = np.load(out)
+    assert int(r["Ncollectives"]) > 100
+    assert int(r["Noutliers"]) == s1["Noutliers_board"]
+    assert abs(float(r["rms"]) - s1["rms_reproj_error__pixels"]) < 1e-8
+    assert np.abs(r["b"] - b1).max() < 2e-5
