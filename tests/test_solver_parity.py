@@ -46,6 +46,30 @@ def _with_points(oi, rng, Npoints=5, Npoints_fixed=1):
     return f(oi, rng, Npoints, Npoints_fixed)
 
 
+@pytest.mark.parametrize("lensmodel", ("LENSMODEL_PINHOLE", "LENSMODEL_STEREOGRAPHIC", "LENSMODEL_OPENCV4",
+                                       "LENSMODEL_OPENCV5", "LENSMODEL_OPENCV12", "LENSMODEL_CAHVOR",
+                                       "LENSMODEL_CAHVORE_linearity=0.34"))
+@pytest.mark.parametrize("frames_opt", (True, False))
+def test_normal_equations_lens_models(amd, lensmodel, frames_opt):
+    """every shape of the Gram (5, 6, 7, 8 column blocks: problem.hpp) and both
+    copy-out paths (fused with the Gram for the usual rows, stand-alone otherwise),
+    on boards of 100 and of 35 corners"""
+    from mrcal_amd.resident import Problem
+    for W, H in ((10,10), (7,5)):
+        oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=5, lensmodel=lensmodel,
+                                         object_width_n=W, object_height_n=H, seed=23)
+        oi["do_optimize_frames"] = frames_opt
+        with Problem(**oi) as p:
+            ne = p.normal_equations()
+            J, x = p.J(), p.x()
+        N, g = dense_normal(J, x)
+        N_gpu = blocks_to_dense(ne, p.Nstate)
+        scale = np.abs(N).max()
+        assert np.abs(N_gpu - N).max() < 1e-10*scale, f"{lensmodel} {W}x{H}"
+        assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+        assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+
+
 @pytest.mark.parametrize("case", ("boards", "boards+points", "no-extrinsics-opt", "monocular"))
 def test_normal_equations_match_JtJ(amd, case):
     from mrcal_amd.resident import Problem
