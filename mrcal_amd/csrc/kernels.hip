@@ -421,11 +421,14 @@ __device__ __forceinline__ void lgkm_wait0(GramRd& a, d2_t& b)
     else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b) :: "memory");
     else                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b) :: "memory");
 }
-template<int S, int NBLK, int K, int KS, int NM>
+template<int S, bool FULL, int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
 void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
-                gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
+                gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows)
 {
+    // a partial half (FULL = false: the last corners of a board): the steps past
+    // its rows are skipped, the stores are predicated on the row
+    if(!FULL && 4*S >= nrows) return;
     constexpr int PAIRS = K/2, R = 64/PAIRS, NGRP = (64 + R - 1)/R;
     constexpr int NREAD = gram_nreads(NBLK);
     constexpr bool have_grp = S < NGRP;
@@ -449,7 +452,8 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     {
         // the only wait for Gram operands: NREAD + 2 requests are younger than step 0's
         d2_t none = {0.0, 0.0};
-        if(NREAD == 2)      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(none) :: "memory");
+        if(!FULL)           lgkm_wait0<NREAD>(cur, none);
+        else if(NREAD == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(none) :: "memory");
         else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(none) :: "memory");
         else                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]), "+v"(none) :: "memory");
     }
@@ -460,24 +464,28 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     if(have_grp)
     {
         gdouble* __restrict__ o = out + rb*K;       // wave-uniform
-        if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
-        else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+        if(FULL)
+        {
+            if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+            else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+        }
+        else if(rb + rsub < nrows)   *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
 }
-template<int NBLK, int K, int KS, int NM, int... S>
+template<bool FULL, int NBLK, int K, int KS, int NM, int... S>
 __device__ __forceinline__
 void fused_steps(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
-                 gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub,
+                 gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows,
                  std::integer_sequence<int, S...>)
 {
-    (fused_step<S,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub), ...);
+    (fused_step<S,FULL,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows), ...);
 }
-template<int NBLK, int K, int KS, int NM>
+template<bool FULL, int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
 void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const int (&goffs)[4],
-                     gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub)
+                     gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows)
 {
     constexpr int NREAD = gram_nreads(NBLK);
     static_assert(NREAD >= 2 && NREAD <= 4, "board tiles have 5..8 column blocks");
@@ -490,8 +498,8 @@ void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const i
     for(int q=0;q<4;q++) cur.v[q] = 0.0;
 #pragma unroll
     for(int q=0;q<NREAD;q++) cur.v[q] = lds_read_b64_at<0>(gram_a[q]);
-    fused_steps<NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub,
-                           std::make_integer_sequence<int, 16>{});
+    fused_steps<FULL,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows,
+                                std::make_integer_sequence<int, 16>{});
 }
 
 #ifdef BOARD_TS
@@ -816,11 +824,19 @@ void board_kernel(DeviceProblem P,
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
             gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
-            if(WITH_GRAM && co_fast && nrows == 64 && !(P.debug_ablate & 3))
+            if(WITH_GRAM && co_fast && !(P.debug_ablate & 3))
             {
-                // full half, all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
-                if(k == KFULL) gram_copy_fused<NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
-                else           gram_copy_fused<NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub);
+                // all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
+                if(nrows == 64)
+                {
+                    if(k == KFULL) gram_copy_fused<true,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, 64);
+                    else           gram_copy_fused<true,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, 64);
+                }
+                else
+                {
+                    if(k == KFULL) gram_copy_fused<false,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, nrows);
+                    else           gram_copy_fused<false,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, nrows);
+                }
                 TSACC(5, tcur);
                 continue;
             }
