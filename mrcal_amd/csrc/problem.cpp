@@ -236,7 +236,6 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     }
     if(!ok) return false;
 
-    if(getenv("MRCAL_AMD_DEBUG_ABLATE")) P->D.debug_ablate = atoi(getenv("MRCAL_AMD_DEBUG_ABLATE"));
     P->solver_ready = true;
     return true;
 }
