@@ -530,6 +530,14 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     __shared__ int    notpd;
     __shared__ double rdiag_all[16*CHOL_PB];     // 1/L[j][j], every panel's (n <= 256)
     if(t == 0) notpd = 0;
+#ifdef CHOL_TS
+    __shared__ long long sts[16][3];
+    long long cts[64]; int ncts = 0;
+#define CTS() do { if(t == 0 && ncts < 64) cts[ncts++] = clock64(); } while(0)
+#else
+#define CTS()
+#endif
+    CTS();
 
     // the lower triangle into LDS. Wave w takes rows w, w+16, ..., 64 columns
     // per lane pass; 12 loads in flight per thread, no divisions
@@ -650,25 +658,18 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     // panel p's trailing update is done. Wave 0 does that tile first and factors
     // the block (a long dependent chain, 16 lanes) while waves 1..15 do the rest
     // of the update: the chain is off the critical path of everything but itself
-#ifdef CHOL_TS
-    __shared__ long long sts[16][3];
-    long long cts[64]; int ncts = 0;
-#define CTS() do { if(t == 0 && ncts < 64) cts[ncts++] = clock64(); } while(0)
-#else
-#define CTS()
-#endif
+    // (p = -1: nothing but the factorization of the first diagonal block, so
+    // that there is ONE copy of that long inlined code, not a cold one for the
+    // first block and another for the rest)
     CTS();
-    if(wave == 0) factor_diag(0);
-    __syncthreads();
-    CTS();
-
-    for(int p = 0; p < npanels; p++)
+    for(int p = -1; p < npanels; p++)
     {
-        const int j0 = p*CHOL_PB;
+        const int j0 = (p < 0) ? 0 : p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
         const int m0 = j0 + jb;
 
         // (b) rows below (and the rhs row): L[i][j0..] <- A[i][j0..] L11^-T. 16 lanes per row
+        if(p >= 0)
         {
             double lrow[CHOL_PB];      // row l16 of the diagonal block
             {
@@ -680,27 +681,32 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                 for(int c = 0; c < CHOL_PB; c++) lrow[c] = (l16 < jb && c < l16) ? tmp[c] : 0.0;
             }
             const double myrd = (l16 < jb) ? rdiag_all[p*CHOL_PB + l16] : 0.0;
+            // Lane c carries the SCALED entry a' = a/L[c][c], which is what the other
+            // lanes need from it and what is stored in the end; its multipliers are
+            // pre-scaled accordingly. A step of the dependent chain is then one
+            // broadcast and one FMA, not multiply + broadcast + FMA
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c++) lrow[c] *= myrd;
             // the 16 lanes of a DPP row work on the same matrix row: they leave the loop together
             for(int i = m0 + (t >> 4); i <= n; i += (nt >> 4))
             {
                 const bool ok = (l16 < jb);
                 double a = rowptr(i)[j0 + ((l16 < jb) ? l16 : 0)];
-                a = ok ? a : 0.0;
-                // lane c's value is final once the steps k < c are done (lrow[k] = 0
-                // for k >= c): its output is a*myrd, before and after step c
+                a = ok ? a*myrd : 0.0;
+                // lane c's value is final once the steps k < c are done (lrow[k] = 0 for k >= c)
                 auto step = [&](auto C)
                 {
                     constexpr int c = decltype(C)::value;
-                    a -= row_share_f64<c>(a*myrd)*lrow[c];
+                    a -= row_share_f64<c>(a)*lrow[c];
                 };
 #define CHOL_STEP(c) step(std::integral_constant<int,(c)>{});
                 CHOL_STEP(0)  CHOL_STEP(1)  CHOL_STEP(2)  CHOL_STEP(3)  CHOL_STEP(4)  CHOL_STEP(5)  CHOL_STEP(6)  CHOL_STEP(7)
                 CHOL_STEP(8)  CHOL_STEP(9)  CHOL_STEP(10) CHOL_STEP(11) CHOL_STEP(12) CHOL_STEP(13) CHOL_STEP(14) CHOL_STEP(15)
 #undef CHOL_STEP
-                if(ok) rowptr(i)[j0 + l16] = a*myrd;
+                if(ok) rowptr(i)[j0 + l16] = a;
             }
         }
-        __syncthreads();
+        if(p >= 0) __syncthreads();
         CTS();
 
         // (c) trailing update with MFMA: C[i][c] -= sum_k L[i][k] L[c][k], k in the
@@ -714,7 +720,7 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             if(p == 0 && lane == 0) sts[wave][0] = clock64();
 #endif
             const int nrows = n + 1 - m0, ncols = n - m0;
-            const int ntr = (nrows + 15) >> 4, ntc = (ncols + 15) >> 4;
+            const int ntr = (p < 0) ? 0 : (nrows + 15) >> 4, ntc = (ncols + 15) >> 4;     // p = -1: no tiles
             const int r16 = lane & 15, kq = lane >> 4;
             // tile (0,0) = the next diagonal block: wave 0; tiles 1.. : waves 1..15
             // round-robin. Wave-uniform (scalar) bookkeeping: no wave walks
@@ -741,6 +747,8 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                         const double cval = *cp[v];
                         acc[v] = cv[v] ? cval : 0.0;
                     }
+                    // (batching several tiles per wave - all LDS reads first, MFMA
+                    // chains interleaved - was measured and is slower: 12k vs 8.5k cycles)
 #pragma unroll
                     for(int s4 = 0; s4 < 4; s4++)
                     {
@@ -767,51 +775,89 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         CTS();
     }
     if(t == 0 && notpd) atomicExch(status, 1);
-#ifdef CHOL_TS
-    if(t == 0) { printf("chol ts:"); for(int i=1;i<ncts;i++) printf(" %lld", cts[i]-cts[i-1]); printf(" | c0 per wave:"); for(int w=0;w<16;w++) printf(" %lld+%lld", sts[w][1]-sts[w][0], sts[w][2]-sts[w][1]); printf("\n"); }
-#endif
 
-    // row n now holds z = L^-1 r. Solve L^T d = z backwards, panel by panel
+
+    // row n now holds z = L^-1 r. Solve L^T d = z backwards, panel by panel.
+    // The same look-ahead as in the factorization: once panel p is solved, wave 0
+    // updates the 16 entries of panel p-1 and solves that panel (a 16-step
+    // dependent chain) while waves 1..15 update everything above it
     double* __restrict__ z = rowptr(n);
-    for(int p = npanels-1; p >= 0; p--)
+    auto back_diag = [&](int p) __attribute__((always_inline))
+    {
+        const int j0 = p*CHOL_PB;
+        const int jb = min(CHOL_PB, n - j0);
+        // lane c holds z[c] and column c of the diagonal block
+        double col[CHOL_PB];
+        {
+            double tmp[CHOL_PB];
+#pragma unroll
+            for(int k = 0; k < CHOL_PB; k++) tmp[k] = rowptr(j0 + ((k < jb) ? k : 0))[j0 + ((lane <= k) ? lane : 0)];
+#pragma unroll
+            for(int k = 0; k < CHOL_PB; k++) col[k] = (lane < jb && k < jb && k > lane) ? tmp[k] : 0.0;
+        }
+        const double myrd = (lane < jb) ? rdiag_all[p*CHOL_PB + lane] : 0.0;
+        // the same scaling trick as in the panel solve: lane c carries d_c-to-be
+        // = z_c/L[c][c] and pre-scaled multipliers; one broadcast + one FMA per step
+        double zc = (lane < jb) ? z[j0 + lane]*myrd : 0.0;
+#pragma unroll
+        for(int k = 0; k < CHOL_PB; k++) col[k] *= myrd;
+        auto step = [&](auto K)
+        {
+            constexpr int k = decltype(K)::value;
+            zc -= col[k]*row_share_f64<k>(zc);           // col[k] = 0 for k <= lane
+        };
+#define CHOL_STEP(k) step(std::integral_constant<int,(k)>{});
+        CHOL_STEP(15) CHOL_STEP(14) CHOL_STEP(13) CHOL_STEP(12) CHOL_STEP(11) CHOL_STEP(10) CHOL_STEP(9) CHOL_STEP(8)
+        CHOL_STEP(7)  CHOL_STEP(6)  CHOL_STEP(5)  CHOL_STEP(4)  CHOL_STEP(3)  CHOL_STEP(2)  CHOL_STEP(1) CHOL_STEP(0)
+#undef CHOL_STEP
+        if(lane < jb) z[j0 + lane] = zc;
+    };
+    // z[i] -= sum_c L[j0+c][i] d[c]
+    auto back_update = [&](int i, int j0, int jb) __attribute__((always_inline))
+    {
+        // Full panels (all but possibly the last): 32 unconditional LDS reads in
+        // flight together, row bases wave-uniform. (A branch per term, as the
+        // generic form below has, serializes the reads: one LDS latency each)
+        if(jb == CHOL_PB)
+        {
+            const double* __restrict__ zp = z + j0;
+            double lv[CHOL_PB], zv[CHOL_PB];
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c++) { lv[c] = rowptr(j0+c)[i]; zv[c] = zp[c]; }
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for(int c = 0; c < CHOL_PB; c += 2) { acc0 += lv[c]*zv[c]; acc1 += lv[c+1]*zv[c+1]; }
+            z[i] -= acc0 + acc1;
+        }
+        else
+        {
+            double acc = 0.0;
+            for(int c = 0; c < jb; c++) acc += rowptr(j0+c)[i]*z[j0+c];
+            z[i] -= acc;
+        }
+    };
+    CTS();
+    if(wave == 0) back_diag(npanels-1);
+    CTS();
+    __syncthreads();
+    CTS();
+    for(int p = npanels-1; p >= 1; p--)
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
         if(wave == 0)
         {
-            // lane c holds z[c] and column c of the diagonal block
-            double col[CHOL_PB];
-            {
-                double tmp[CHOL_PB];
-#pragma unroll
-                for(int k = 0; k < CHOL_PB; k++) tmp[k] = rowptr(j0 + ((k < jb) ? k : 0))[j0 + ((lane <= k) ? lane : 0)];
-#pragma unroll
-                for(int k = 0; k < CHOL_PB; k++) col[k] = (lane < jb && k < jb && k > lane) ? tmp[k] : 0.0;
-            }
-            double zc = (lane < jb) ? z[j0 + lane] : 0.0;
-            const double myrd = (lane < jb) ? rdiag_all[p*CHOL_PB + lane] : 0.0;
-            auto step = [&](auto K)
-            {
-                constexpr int k = decltype(K)::value;
-                zc -= col[k]*row_share_f64<k>(zc*myrd);      // col[k] = 0 for k <= lane
-            };
-#define CHOL_STEP(k) step(std::integral_constant<int,(k)>{});
-            CHOL_STEP(15) CHOL_STEP(14) CHOL_STEP(13) CHOL_STEP(12) CHOL_STEP(11) CHOL_STEP(10) CHOL_STEP(9) CHOL_STEP(8)
-            CHOL_STEP(7)  CHOL_STEP(6)  CHOL_STEP(5)  CHOL_STEP(4)  CHOL_STEP(3)  CHOL_STEP(2)  CHOL_STEP(1) CHOL_STEP(0)
-#undef CHOL_STEP
-            if(lane < jb) z[j0 + lane] = zc*myrd;
+            if(lane < CHOL_PB) back_update(j0 - CHOL_PB + lane, j0, jb);     // panel p-1 is full
+            CTS();
+            back_diag(p - 1);
+            CTS();
         }
+        else
+            for(int i = t - 64; i < j0 - CHOL_PB; i += nt - 64) back_update(i, j0, jb);
         __syncthreads();
-        // z[i] -= sum_c L[j0+c][i] d[c],  i < j0
-        for(int i = t; i < j0; i += nt)
-        {
-            double acc = 0.0;
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++) if(c < jb) acc += rowptr(j0+c)[i]*z[j0+c];
-            z[i] -= acc;
-        }
-        __syncthreads();
+        CTS();
     }
+    CTS();
     // r <- -d ; keep the factor for later solves (uncertainty, solve_xt_JtJ_bt)
     for(int i = t; i < n; i += nt) r[i] = -z[i];
     if(keep_factor)
@@ -820,6 +866,10 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             const int i = idx / n, j = idx - i*n;
             if(j <= i) S[(size_t)i*n + j] = rowptr(i)[j];
         }
+    CTS();
+#ifdef CHOL_TS
+    if(t == 0) { printf("chol ts (load | diag0 | b,c per panel ... | backward | store):"); for(int i=1;i<ncts;i++) printf(" %lld", cts[i]-cts[i-1]); printf("\n"); }
+#endif
 }
 
 // The same in place in global memory, row-major, for camera blocks that do not
