@@ -61,6 +61,7 @@ num_measurements_points               = _api.num_measurements_points
 num_measurements_points_triangulated  = _api.num_measurements_points_triangulated
 num_measurements_regularization       = _api.num_measurements_regularization
 corresponding_icam_extrinsics         = _api.corresponding_icam_extrinsics
+decode_observation_indices_points_triangulated = _api.decode_observation_indices_points_triangulated
 pack_state                            = _api.pack_state
 unpack_state                          = _api.unpack_state
 lensmodel_num_params                  = _api.lensmodel_num_params

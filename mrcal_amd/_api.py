@@ -642,6 +642,19 @@ class Api:
         a = self._layout_args(kw)
         return self._none_if_negative(self.clib.mrcal_measurement_index_points_triangulated(
             i_point_triangulated, a["Nob"], a["Nop"], _ptr(a["tri"]), a["Ntri"], a["width_n"], a["height_n"]))
+    def decode_observation_indices_points_triangulated(self, imeasurement, **kw):
+        """mrcal-pywrap.c:3336-3420: which pair of triangulated observations a
+        measurement (counted from the first triangulated one) belongs to"""
+        a = self._layout_args(kw, need_lensmodel=False)
+        if a["Ntri"] <= 0:
+            raise RuntimeError("No triangulated points in this solve. Nothing to decode")
+        out = [C.c_int(0) for _ in range(6)]
+        if not self.clib.mrcal_decode_observation_indices_points_triangulated(
+                *[C.byref(v) for v in out], int(imeasurement), _ptr(a["tri"]), a["Ntri"]):
+            raise RuntimeError("Error decoding indices")
+        names = ("iobservation0", "iobservation1", "iobservation_point0",
+                 "Nobservations_this_point", "Nmeasurements_this_point", "ipoint")
+        return {k: v.value for k, v in zip(names, out)}
     def num_measurements_points_triangulated(self, **kw):
         a = self._layout_args(kw, need_lensmodel=False)
         return self.clib.mrcal_num_measurements_points_triangulated(_ptr(a["tri"]), a["Ntri"])

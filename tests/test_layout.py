@@ -147,6 +147,25 @@ def test_triangulated_decode(amd_api, ref_api):
         assert outs[0] == outs[1], (m, outs)
 
 
+def test_python_decode_observation_indices_points_triangulated(amd_api, ref_api):
+    """the Python-level wrapper (mrcal-pywrap.c:3336-3420) over the same C function"""
+    idx = np.array(((0,0,-1), (0,1,0), (0,2,1),  (1,0,-1), (1,2,1),  (2,0,-1), (2,1,0), (2,2,1), (2,3,2)), dtype=np.int32)
+    kw = dict(indices_point_triangulated_camintrinsics_camextrinsics = idx,
+              observations_point_triangulated = np.zeros((len(idx),3)))
+    N = amd_api.num_measurements_points_triangulated(**kw)
+    assert N == ref_api.num_measurements_points_triangulated(**kw) == 3 + 1 + 6
+    for m in range(N):
+        d = amd_api.decode_observation_indices_points_triangulated(m, **kw)
+        assert d == ref_api.decode_observation_indices_points_triangulated(m, **kw)
+        assert set(d) == {"iobservation0", "iobservation1", "iobservation_point0",
+                          "Nobservations_this_point", "Nmeasurements_this_point", "ipoint"}
+    assert amd_api.decode_observation_indices_points_triangulated(4, **kw)["ipoint"] == 2
+    with pytest.raises(RuntimeError):
+        amd_api.decode_observation_indices_points_triangulated(N, **kw)
+    with pytest.raises(RuntimeError):
+        amd_api.decode_observation_indices_points_triangulated(0)
+
+
 def test_python_helpers_match_reference_test_values(amd):
     """the values test/test-basic-calibration.py:168-232 asserts for its
     problem: 4 cameras, 50 frames, 10x9 board, OPENCV4"""
