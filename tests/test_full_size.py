@@ -1,0 +1,258 @@
+"""The configurations of BASELINE.json at FULL size, through properties that
+do not need an oracle run (the CPU checker takes minutes to hours at these
+sizes; the small-size parity against it is in test_callback_parity.py,
+test_solver_parity.py, test_triangulated.py):
+
+  sizes         Nstate, Nmeasurements, Nnz == the (bit-exact) layout functions
+  structure     CSR rowptr monotone and ending at Nnz, columns sorted and
+                in range, outlier rows all-zero with their columns present
+  J vs x        central finite difference of x along a random direction d
+                == J d   (every row, every block of the state at once)
+  blocks vs J   g == Jt x, |x|^2, and v^T (JtJ) v from the solver's block
+                normal equations == |J v|^2 for a random v
+  shards        the sum of the frame shards' normal equations == the unsharded
+                ones (what the multi-GPU all-reduce relies on)
+  solve         optimize() lands on a stationary point: the cost went down,
+                |Jt x| is small against |J||x|, a second optimize() from the
+                solution does not move
+
+Configurations: 0 (1 camera x 40 frames OPENCV4), 1 (4 x 400 OPENCV8), the
+metric's 8 x 1000, 2 (splined 30x20 knots, 800 frames), 3 (16 x 2000), 4 (SfM:
+4 cameras, 20k triangulated points + board frames)."""
+import numpy as np
+import pytest
+
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks_quadform(ne, v):
+    """v^T N v from the solver's blocks: N = [A B; Bt D] in (S, E) order"""
+    Nie, NE, Nwarp, Nfb = ne["Nie"], ne["NE"], ne["Nwarp"], ne["Nfb"]
+    vS = np.concatenate((v[:Nie], v[Nie+NE:Nie+NE+Nwarp]))
+    vE = v[Nie:Nie+NE]
+    q = vS @ ne["A"] @ vS + 2.0*(vE @ (ne["Bt"] @ vS))
+    for b in range(ne["NEb"]):
+        if b < Nfb: e0, de = 6*b, 6
+        else:       e0, de = 6*Nfb + 3*(b-Nfb), 3
+        q += vE[e0:e0+de] @ ne["D"][b,:de,:de] @ vE[e0:e0+de]
+    return q
+
+
+def _check_structure(amd, oi, p, J, x):
+    Nstate, Nmeas = amd.num_states(**oi), amd.num_measurements(**oi)
+    assert J.shape == (Nmeas, Nstate) and x.shape == (Nmeas,)
+    assert p.Nnz == J.nnz == J.indptr[-1]
+    assert J.indptr[0] == 0 and np.all(np.diff(J.indptr) >= 0)
+    assert J.indices.min() >= 0 and J.indices.max() < Nstate
+    # columns sorted within every row: a decrease may only happen at a row start
+    dec = np.nonzero(np.diff(J.indices) < 0)[0] + 1
+    assert np.all(np.isin(dec, J.indptr)), "unsorted columns inside a row"
+    assert np.all(np.isfinite(J.data)) and np.all(np.isfinite(x))
+    return Nstate, Nmeas
+
+
+def _check_J_against_finite_differences(p, J, rng, eps=1e-6, tol=2e-5, max_bad_fraction=0.0):
+    b0 = p.b_packed()
+    d  = rng.normal(size=b0.shape)
+    d /= np.abs(d).max()
+    p.set_b_packed(b0 + eps*d); p.evaluate(with_jacobian=False); xp = p.x()
+    p.set_b_packed(b0 - eps*d); p.evaluate(with_jacobian=False); xm = p.x()
+    p.set_b_packed(b0);         p.evaluate(with_jacobian=True)
+    fd = (xp - xm)/(2*eps)
+    Jd = J @ d
+    scale = np.abs(Jd).max()
+    bad = np.abs(fd - Jd) > tol*scale
+    # max_bad_fraction > 0: residuals with kinks (the triangulated error has
+    # a chirality test, a divergence penalty and a small-angle branch): a central
+    # difference that straddles one is not a derivative
+    assert bad.mean() <= max_bad_fraction, \
+        f"J d vs finite differences: {bad.sum()} rows off, worst {np.abs(fd - Jd).max()/scale}"
+
+
+def _check_blocks_against_J(p, J, x, rng):
+    ne = p.normal_equations()
+    g  = J.T @ x
+    assert np.abs(ne["g"] - g).max() < 1e-9*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    v = rng.normal(size=J.shape[1])
+    Jv = J @ v
+    assert abs(_blocks_quadform(ne, v) - Jv @ Jv) < 1e-9*(Jv @ Jv)
+    return ne
+
+
+def _check_shards_add_up(oi, ne, Nframes, nshards=3):
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.parallel import partition_frames
+    ranges = partition_frames(oi["indices_frame_camintrinsics_camextrinsics"], Nframes, nshards)
+    acc = None
+    for r, fr in enumerate(ranges):
+        with Problem(_shard=fr, _leader=(r == 0), **oi) as ps:
+            n = ps.normal_equations()
+        if acc is None: acc = {k: np.array(n[k], dtype=float) for k in ("A", "Bt", "D", "g")}; acc["norm2_x"] = n["norm2_x"]
+        else:
+            for k in ("A", "Bt", "D", "g"): acc[k] += n[k]
+            acc["norm2_x"] += n["norm2_x"]
+    for k in ("A", "Bt", "D", "g"):
+        assert np.abs(acc[k] - ne[k]).max() < 1e-10*np.abs(ne[k]).max(), k
+    assert abs(acc["norm2_x"] - ne["norm2_x"]) < 1e-10*ne["norm2_x"]
+
+
+def _check_solve(amd, oi, check_state=True):
+    from mrcal_amd.resident import Problem
+    oi = copy_inputs(oi)
+    with Problem(**oi) as p0:
+        p0.evaluate(with_jacobian=False)
+        cost0 = float(p0.x() @ p0.x())
+    s = amd.optimize(**oi)
+    Nmeas = amd.num_measurements(**oi)
+    cost1 = s["rms_reproj_error__pixels"]**2 * Nmeas
+    assert cost1 < cost0
+    # stationarity at the returned point (the inputs were updated in place)
+    with Problem(**oi) as p:
+        p.evaluate(with_jacobian=True)
+        x, J = p.x(), p.J()
+    g = J.T @ x
+    Jnorm = np.sqrt((J.data**2).sum())
+    assert np.linalg.norm(g) < 1e-5*Jnorm*np.linalg.norm(x), np.linalg.norm(g)/(Jnorm*np.linalg.norm(x))
+    # idempotence: solving again from the solution stays there
+    b1 = s["b_packed"].copy()
+    oi["do_apply_outlier_rejection"] = False
+    s2 = amd.optimize(**oi)
+    # (the big problems end in the damped crawl described in DESIGN.md section 3,
+    # like the reference's libdogleg does once JtJ has been found singular: a
+    # second solve may still take up to the 4th digit off the rms; it must not go up)
+    rms1 = np.sqrt(float(x @ x)/Nmeas)
+    assert s2["rms_reproj_error__pixels"] <= rms1 + 1e-9
+    assert rms1 - s2["rms_reproj_error__pixels"] < 1e-3*rms1
+    # the state itself is only pinned where the problem is well conditioned: the
+    # biggest configuration has a nearly flat direction along which the crawl moves
+    if check_state:
+        assert np.abs(s2["b_packed"] - b1).max() < 5e-3
+    return s
+
+
+BOARD_CONFIGS = {
+    "config0: 1 camera x 40 frames OPENCV4":      dict(Ncameras=1,  Nframes=40,   lensmodel="LENSMODEL_OPENCV4"),
+    "config1: 4 cameras x 400 frames OPENCV8":    dict(Ncameras=4,  Nframes=400,  lensmodel="LENSMODEL_OPENCV8"),
+    "metric: 8 cameras x 1000 frames OPENCV8":    dict(Ncameras=8,  Nframes=1000, lensmodel="LENSMODEL_OPENCV8"),
+    "config3: 16 cameras x 2000 frames OPENCV8":  dict(Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8"),
+}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", list(BOARD_CONFIGS))
+def test_board_configurations_full_size(amd, name):
+    from mrcal_amd.resident import Problem
+    cfg = BOARD_CONFIGS[name]
+    rng = np.random.RandomState(1)
+    oi, _ = make_calibration_problem(amd._api, object_width_n=10, object_height_n=10, seed=2, **cfg)
+    with Problem(**oi) as p:
+        p.evaluate(with_jacobian=True)
+        x, J = p.x(), p.J()
+        Nstate, Nmeas = _check_structure(amd, oi, p, J, x)
+        Nobs = cfg["Ncameras"]*cfg["Nframes"]
+        Ni = oi["intrinsics"].shape[1]
+        assert Nmeas >= 200*Nobs
+        assert Nstate == Ni*cfg["Ncameras"] + 6*(cfg["Ncameras"]-1) + 6*cfg["Nframes"] + 2
+        # input outliers: zero rows, columns still there
+        w = oi["observations_board"][...,2].ravel()
+        out_rows = np.nonzero(np.repeat(w < 0, 2))[0]
+        if len(out_rows):
+            r = out_rows[:50]
+            assert np.all(x[r] == 0)
+            for i in r:
+                assert J.indptr[i+1] > J.indptr[i] and np.all(J.data[J.indptr[i]:J.indptr[i+1]] == 0)
+        _check_J_against_finite_differences(p, J, rng)
+        ne = _check_blocks_against_J(p, J, x, rng)
+    if cfg["Nframes"] <= 1000:
+        _check_shards_add_up(oi, ne, cfg["Nframes"])
+    del J
+    s = _check_solve(amd, oi, check_state=(cfg["Nframes"] <= 1000))
+    # the data were generated with 1.5 pixel noise and ~1% outliers
+    assert 1.0 < s["rms_reproj_error__pixels"] < 2.0
+    assert s["Noutliers_board"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_splined_configuration_full_size(amd):
+    """config2: 1 camera, LENSMODEL_SPLINED_STEREOGRAPHIC 30x20 knots, 800 frames"""
+    from mrcal_amd.resident import Problem
+    rng = np.random.RandomState(3)
+    oi, _ = make_calibration_problem(amd._api, Ncameras=1, Nframes=800, object_width_n=10, object_height_n=10,
+                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     seed=4)
+    assert oi["intrinsics"].shape[1] == 4 + 2*30*20
+    with Problem(**oi) as p:
+        p.evaluate(with_jacobian=True)
+        x, J = p.x(), p.J()
+        _check_structure(amd, oi, p, J, x)
+        # a board row: 2 core + 16 spline patch + 6 frame + 2 warp columns (monocular: no extrinsics)
+        assert np.all(np.diff(J.indptr)[:2*100*800] == 2 + 16 + 6 + 2)
+        _check_J_against_finite_differences(p, J, rng, tol=1e-4)
+        _check_blocks_against_J(p, J, x, rng)
+        # a few dog-leg steps reduce the cost
+        c0 = float(x @ x)
+        p.run_steps(3)
+        p.evaluate(with_jacobian=False)
+        assert float(p.x() @ p.x()) < c0
+
+
+@pytest.mark.timeout(900)
+def test_sfm_configuration_full_size(amd, ref_api):
+    """config4: 4 cameras, 20k triangulated points (+ their pairs), unity_cam01
+    regularization (test-sfm-triangulated-points.py shape)"""
+    from test_triangulated import sfm_problem
+    from mrcal_amd.resident import Problem
+    rng = np.random.RandomState(5)
+    oi, truth = sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=6, noise=0.3)
+    with Problem(**oi) as p:
+        p.evaluate(with_jacobian=True)
+        x, J = p.x(), p.J()
+        Nstate, Nmeas = _check_structure(amd, oi, p, J, x)
+        assert Nstate == 18
+        Ntri = amd.num_measurements_points_triangulated(**oi)
+        assert Ntri >= 20000 and Nmeas == Ntri + amd.num_measurements_regularization(**oi)
+        # This configuration is light enough for the CPU checker at full size: x and
+        # J against the reference's own code. Same bar as the small-size parity
+        # (1e-6 by the reference's relative-error measure) on every pair whose
+        # residual is above the noise floor of the angle formula: the residual of
+        # a pair is the angle between two nearly parallel unit vectors, formed
+        # from a cross product of O(1) components, so it carries ~1e-16/angle of
+        # relative rounding noise in ANY implementation. Below 1e-4 rad (a few
+        # percent of the pairs here) the two implementations agree to 1e-8 absolute
+        # in x - which is all the digits there are - and their gradients, which
+        # divide by that angle, to a few percent at worst.
+        from conftest import relative_error
+        _, x_ref, J_ref, _ = ref_api.optimizer_callback(no_factorization=True, **oi)
+        assert np.array_equal(J.indptr, J_ref.indptr) and np.array_equal(J.indices, J_ref.indices)
+        conditioned = np.abs(x_ref) > 1e-4
+        assert conditioned.mean() > 0.9
+        assert relative_error(x[conditioned], x_ref[conditioned]).max() < 1e-6
+        assert np.abs(x - x_ref).max() < 1e-8
+        # (the gradient divides by the angle once more: 1e-6 from 1e-3 rad up)
+        row_of = np.repeat(np.arange(Nmeas), np.diff(J.indptr))
+        conditioned_J = np.abs(x_ref) > 1e-3
+        assert conditioned_J.mean() > 0.2
+        cJ = conditioned_J[row_of]
+        assert relative_error(J.data[cJ], J_ref.data[cJ]).max() < 1e-6
+        assert np.abs(J.data - J_ref.data).max() < 5e-2*np.abs(J_ref.data).max()
+        # (finite differences are a weak check here: the triangulated error has a
+        # chirality test, a divergence penalty and a small-angle branch, and its
+        # analytic gradient is approximate where the residual is ~0, in the
+        # reference too: a fraction of a percent of the rows disagree)
+        _check_J_against_finite_differences(p, J, rng, eps=1e-7, tol=1e-4, max_bad_fraction=2e-2)
+        ne = p.normal_equations()
+        g  = J.T @ x
+        assert np.abs(ne["g"] - g).max() < 1e-9*np.abs(g).max()
+        assert np.abs(ne["A"] - (J.T @ J).toarray()).max() < 1e-9*np.abs(ne["A"]).max()
+    oi2 = copy_inputs(oi)
+    oi2["do_apply_outlier_rejection"] = True
+    s = amd.optimize(**oi2)
+    # the relative poses are recovered up to the noise (scale is pinned by unity_cam01)
+    t_true = truth["rt_cam_ref"][:,3:]
+    scale  = np.linalg.norm(t_true[0])
+    assert np.abs(oi2["rt_cam_ref"][:,3:]/np.linalg.norm(oi2["rt_cam_ref"][0,3:]) - t_true/scale).max() < 2e-2
+    assert np.abs(oi2["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 5e-3
+    assert s["Noutliers_triangulated_point"] >= 0
