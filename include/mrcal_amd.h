@@ -497,7 +497,7 @@ int   mrcal_amd_problem_current(mrcal_amd_problem_t* problem);
    the starting point, after sharded_reset().
      comm_buffer 0: [S (Nc*Nc) | r (Nc)]   this shard's summand of the Schur complement
                  1: [NE]                   the frame/point part of the Gauss-Newton step
-                 2: [Nstate + 2]           g = Jt x, |x|^2, step^T JtJ step
+                 2: [Nstate + 2]           g = Jt x, |x|^2, (spare)
                  3: [1]                    g^T JtJ g
    snapshot(slot)/wait(slot): a pinned copy of the control block, queued after
    a trial step and waited for a few steps later, tells the host when the device

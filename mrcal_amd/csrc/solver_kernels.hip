@@ -1235,25 +1235,23 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     // workgroup sums the whole vectors itself, in the same fixed order (so all
     // of them, on every rank, get the same bits), instead of a reduction kernel
     // of its own in front of this one
-    __shared__ double dots[2];
+    __shared__ double dots[3];
     if(fresh_gn && compute_dots)
     {
-        double a = 0.0, b = 0.0;
+        double a = 0.0, b = 0.0, c = 0.0;
         for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x)
         {
             const double gn = from.step_gn[i];
             a += gn*gn;
             b += gn*from.step_cauchy[i];
+            c += gn*from.g[i];
         }
-        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-        __shared__ double part[4][2];
-        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
+        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+        __shared__ double part[4][3];
+        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
         __syncthreads();
-        if(threadIdx.x == 0)
-        {
-            dots[0] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
-            dots[1] = (part[0][1] + part[1][1]) + (part[2][1] + part[3][1]);
-        }
+        if(threadIdx.x < 3)
+            dots[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
         __syncthreads();
         if(leader) { from.scalars[SC_GN_LENSQ] = dots[0]; from.scalars[SC_GN_DOT_CAUCHY] = dots[1]; }
     }
@@ -1324,7 +1322,32 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
 
     if(leader)
     {
-        if(fresh_gn) { ctl->gn_lensq[ib] = norm2b; ctl->gn_valid[ib] = 1; }
+        if(fresh_gn)
+        {
+            ctl->gn_lensq[ib] = norm2b; ctl->gn_valid[ib] = 1;
+            ctl->gn_dot_g[ib]  = compute_dots ? dots[2] : 0.0;
+            ctl->gn_lambda[ib] = ctl->lambda;
+        }
+        // The expected improvement |x|^2 - |x + J s|^2 = -2 g.s - s^T N s WITHOUT a
+        // pass over N: the step is kc s_c + kg s_gn with s_c = k g and
+        // (N + lambda I) s_gn = -g, so every term is a dot product already at hand:
+        //   s_c^T N s_c   = k^2 g^T N g
+        //   s_c^T N s_gn  = -k g.g - lambda s_c.s_gn
+        //   s_gn^T N s_gn = -g.s_gn - lambda |s_gn|^2
+        {
+            const double gNg = from.scalars[SC_G_GNG], gg = from.scalars[SC_G_GG];
+            const double k   = (gNg > 0.0) ? -gg/gNg : 0.0;
+            double sNs = kc*kc*k*k*gNg, gs = kc*k*gg;
+            if(kg != 0.0)
+            {
+                const double a = ctl->gn_dot_g[ib], lam = ctl->gn_lambda[ib];
+                sNs += 2.0*kc*kg*(-k*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
+                gs  += kg*a;
+            }
+            from.scalars[SC_STEP_SNS] = sNs;
+            from.scalars[SC_STEP_GS]  = gs;
+            from.scalars[SC_STEP_SS]  = len_sq;
+        }
         ctl->k_cauchy = kc; ctl->k_gn = kg;
         ctl->step_len_sq = len_sq;
         ctl->did_step_to_edge[ib] = edge;
@@ -1482,7 +1505,7 @@ void shard_pack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const
     {
         if(i < nd.Nstate)       v = O.g[i];
         else if(i == nd.Nstate) v = O.scalars[SC_NORM2_X];
-        else                    v = initial ? 0.0 : ops[ctl->ib].scalars[SC_STEP_SNS];
+        else                    v = 0.0;       // (spare slot)
     }
     comm[i] = v;
 }
@@ -1496,7 +1519,7 @@ void shard_unpack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, con
     const OpDev& O = ops[initial ? ctl->ib : ctl->ia];
     if(i < nd.Nstate)       O.g[i] = comm[i];
     else if(i == nd.Nstate) O.scalars[SC_NORM2_X] = comm[i];
-    else if(!initial)       ops[ctl->ib].scalars[SC_STEP_SNS] = comm[i];
+    (void)initial;
 }
 // The replicated control state must stay BIT-identical on all ranks (a rank
 // whose "done" differs would stop queueing collectives). What goes through an
@@ -1721,16 +1744,9 @@ hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl*
         hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
                            nd, ops, ctl, ctl_flags(ctl), F.status, step, 1);
     }
-    if(parts & 2)
-    {
-        // for the expected improvement: (step^T N step, g.step, |step|^2) of ctl->ib
-        OpRef Rfrom = { ops, &ctl->ib, solver_ctl_skip_eval(ctl) };
-        hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                           nd, Rfrom, step, 0, (double*)NULL, (int)SC_STEP_SNS, 3);
-        if(deterministic)
-            hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                               (const double*)step, 1, 0);
-    }
+    // (parts & 2 used to be the quadratic form step^T N step: the expected
+    // improvement now comes out of step_choose_kernel itself)
+    (void)deterministic;
     return hipGetLastError();
 }
 hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)

@@ -159,6 +159,8 @@ struct SolverCtl
     double trustregion;
     double lambda;              // diagonal regularization, raised when JtJ is not positive definite
     double norm2_x[2], cauchy_lensq[2], gn_lensq[2];
+    double gn_dot_g[2];         // g . step_gn, and the lambda the step was computed with
+    double gn_lambda[2];
     int    gn_valid[2], did_step_to_edge[2];
     int    ib, ia;              // operating point before / after the step being tried
     int    done;                // the solve has terminated: every later kernel is a no-op

@@ -11,9 +11,10 @@ the board warp: Nc = 140 variables at 8 cameras). Per dog-leg step each rank
          complement [S | r]                   (Nc^2+Nc doubles: 158 KB at NS)
   seg 1  factors the same Nc x Nc system redundantly, back-substitutes its own
          frames -> all-reduce of the frame steps           (NE doubles: 48 KB)
-  seg 2  chooses the dog-leg step, evaluates x, J and its blocks of JtJ at the
-         trial point for ITS frames -> all-reduce of [Jt x | |x|^2 | s^T JtJ s]
-                                                 (Nstate+2 doubles: 49 KB at NS)
+  seg 2  chooses the dog-leg step (the expected improvement comes from dot
+         products of replicated vectors: nothing to sum), evaluates x, J and its
+         blocks of JtJ at the trial point for ITS frames
+         -> all-reduce of [Jt x | |x|^2]       (Nstate+2 doubles: 49 KB at NS)
   seg 3  -> all-reduce of g^T JtJ g                                 (1 double)
   seg 4  Cauchy step of the new point, rho test, accept/reject
 
