@@ -612,8 +612,8 @@ void mrcal_amd_problem_set_current(mrcal_amd_problem_t* P, int iop) { P->icur = 
 // same sums. initial: the evaluation of the starting point (segments 2..4)
 //   seg 0  step_begin, local block elimination, local Schur summand   -> [S | r]
 //   seg 1  Cholesky of the summed S (replicated), local back-substitution -> E part of step_gn
-//   seg 2  step selection, s^T N s (local part), evaluation of x, J, Gram and
-//          the block normal equations of the trial point              -> [g | |x|^2 | s^T N s]
+//   seg 2  step selection, evaluation of x, J, Gram and the block normal
+//          equations of the trial point                               -> [g | |x|^2]
 //   seg 3  g^T N g (local part)                                       -> g^T N g
 //   seg 4  Cauchy step of the new point, rho test, accept/reject
 ////////////////////////////////////////////////////////////////////////////////
