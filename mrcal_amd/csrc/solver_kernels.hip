@@ -278,22 +278,47 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
     __syncthreads();
     if(t == 0)
     {
+        // the 6x6 (3x3) factorization in REGISTERS: one batch of LDS reads, fully
+        // unrolled arithmetic, one batch of writes. (Working in LDS puts an LDS
+        // round trip, ~100 cycles, on every one of the ~90 dependent accesses.)
+        // A 3x3 point block is padded with the identity
+        double M[6][6];
+#pragma unroll
+        for(int i=0;i<6;i++)
+#pragma unroll
+            for(int j=0;j<6;j++)
+            {
+                const double v = L[i*6+j];
+                M[i][j] = (i < de && j < de) ? v : ((i == j) ? 1.0 : 0.0);
+            }
         bool ok = true;
-        for(int j=0;j<de;j++)
+        double ri[6];
+#pragma unroll
+        for(int j=0;j<6;j++)
         {
-            double d = L[j*6+j];
-            for(int k=0;k<j;k++) d -= L[j*6+k]*L[j*6+k];
+            double d = M[j][j];
+#pragma unroll
+            for(int k=0;k<j;k++) d -= M[j][k]*M[j][k];
             if(!(d > 0.0)) { ok = false; d = 1.0; }
             d = sqrt(d);
             const double rd = 1.0/d;
-            L[j*6+j] = d;
-            rinv[j]  = rd;
-            for(int i=j+1;i<de;i++)
+            M[j][j] = d;
+            ri[j]   = rd;
+#pragma unroll
+            for(int i=j+1;i<6;i++)
             {
-                double v = L[i*6+j];
-                for(int k=0;k<j;k++) v -= L[i*6+k]*L[j*6+k];
-                L[i*6+j] = v*rd;
+                double v = M[i][j];
+#pragma unroll
+                for(int k=0;k<j;k++) v -= M[i][k]*M[j][k];
+                M[i][j] = v*rd;
             }
+        }
+#pragma unroll
+        for(int i=0;i<6;i++)
+        {
+            rinv[i] = ri[i];
+#pragma unroll
+            for(int j=0;j<=i;j++) if(i < de) L[i*6+j] = M[i][j];
         }
         if(!ok) atomicExch(status, 1);
     }
