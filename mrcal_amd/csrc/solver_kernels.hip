@@ -62,16 +62,14 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
 // coalesced, position by position; the frame's rows of Bt, its D block and its
 // part of g are accumulated in LDS and written out whole:
 //   D_f  += G[frame,frame]      g_f += G[frame,x]     Bt[frame rows][S cols] += G[S,frame]
-__global__ __launch_bounds__(256)
-void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                            const double* __restrict__ gram)
+__device__ __forceinline__
+void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const OpRef& R, const AssemblyPlan& plan,
+                          const double* __restrict__ gram, int f, double* __restrict__ lds_f)
 {
-    if(opref_skip(R)) return;
-    extern __shared__ double lds_f[];          // Btf[6][Nc] | Df[36] | gf[6]
+    // lds_f: Btf[6][Nc] | Df[36] | gf[6]
     double* __restrict__ Btf = lds_f;
     double* __restrict__ Df  = lds_f + 6*nd.Nc;
     double* __restrict__ gf  = Df + 36;
-    const int f = blockIdx.x;
     const int t = threadIdx.x;
     const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
     if(o0 >= o1) return;                       // not this shard's frame: its rows stay zero
@@ -127,18 +125,17 @@ void assemble_frames_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPla
 // scatter to the same entries of A, so they are summed per pair first: one
 // workgroup per chunk of one pair's observation list, each thread summing its
 // Gram positions over the chunk (coalesced reads), then a few atomics
-__global__ __launch_bounds__(256)
-void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                         const double* __restrict__ gram)
+__device__ __forceinline__
+void reduce_pair_chunk(const DeviceProblem& P, const NormalDims& nd, const OpRef& R, const AssemblyPlan& plan,
+                       const double* __restrict__ gram, int ichunk)
 {
-    if(opref_skip(R)) return;
     double* __restrict__ A = opref_get(R).A;
     double* __restrict__ g = opref_get(R).g;
     double* __restrict__ norm2_x = &opref_get(R).scalars[SC_NORM2_X];
-    const int c0 = plan.chunk_begin[blockIdx.x], c1 = plan.chunk_begin[blockIdx.x+1];
+    const int c0 = plan.chunk_begin[ichunk], c1 = plan.chunk_begin[ichunk+1];
     if(c0 >= c1) return;
     const int npos = gram_stride(P.Ndist);
-    const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[blockIdx.x]*npos;
+    const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[ichunk]*npos;
     // the chunk's observations (at most REDUCE_CHUNK), once; then every load of
     // a position is independent of everything but these: all in flight together
     const int nobs = c1 - c0;
@@ -167,6 +164,23 @@ void reduce_pairs_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan p
         }
     }
 }
+
+// Both of the above in ONE launch (they are independent): workgroups
+// [0, nframe_blocks) take a frame each, the rest a pair chunk each. One launch
+// and one cold start less, and the two kinds of work overlap
+__global__ __launch_bounds__(256)
+void assemble_gram_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
+                          const double* __restrict__ gram, int nframe_blocks)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double lds_f[];
+    if((int)blockIdx.x < nframe_blocks) assemble_frame_block(P, nd, R, plan, gram, blockIdx.x, lds_f);
+    else                                reduce_pair_chunk(P, nd, R, plan, gram, blockIdx.x - nframe_blocks);
+}
+
+// (Ending the trial in the LAST workgroup of the g^T N g reduction - ticket
+// counter after a device-scope fence - instead of a launch of its own was
+// measured: the fence costs a write-back of the L2, 30+ us. Not used)
 
 // Rows that do not come from board observations (discrete points,
 // regularization): one lane per CSR row, scattered with atomics. These are few
@@ -1614,11 +1628,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
     const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
     if(P.Nobs_board > 0 && !by_rows)
     {
-        if(P.do_optimize_frames)
-            hipLaunchKernelGGL(assemble_frames_kernel, dim3(P.Nframes), dim3(256), (6*nd.Nc + 42)*sizeof(double), stream,
-                               P, nd, B.R, plan, B.gram);
-        hipLaunchKernelGGL(reduce_pairs_kernel, dim3(plan.Nchunks), dim3(256), 0, stream,
-                           P, nd, B.R, plan, B.gram);
+        const int nframe_blocks = P.do_optimize_frames ? P.Nframes : 0;
+        hipLaunchKernelGGL(assemble_gram_kernel, dim3(nframe_blocks + plan.Nchunks), dim3(256),
+                           (6*nd.Nc + 42)*sizeof(double), stream, P, nd, B.R, plan, B.gram, nframe_blocks);
     }
     const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nmeas > row0)
