@@ -170,13 +170,30 @@ void joint_pose_record(double* __restrict__ out,
 // 2e-5 by the reference's relative-error measure. Parity first: the reference's
 // route is followed literally)
 
+template<bool WITH_J, bool WITH_STRUCTURE>
+__device__ __forceinline__
+void regularization_row(const DeviceProblem& P, const OpRef& R,
+                        int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i);
+
 #define PROLOGUE_ZERO_BLOCKS 1024
+// Workgroups, in order: [pose records, 64 observations each] [unpacking of the
+// intrinsics and the warp] [clearing of the normal equations, if asked for]
+// [regularization rows, 64 each: reg_mode 0 = x only, 1 = x and J, -1 = none].
+// Only the first kind is long; the others are independent of it and of each
+// other and ride along instead of costing launches of their own
 __global__ __launch_bounds__(64)
-void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack)
+void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode)
 {
     const OpRef R = B.R;
     double* __restrict__ joint = B.joint;
     if(opref_skip(R)) return;
+    if((int)blockIdx.x >= (P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero)
+    {
+        const int i = ((int)blockIdx.x - ((P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero))*64 + threadIdx.x;
+        if(reg_mode == 1)      regularization_row<true, false>(P, R, (int32_t*)NULL, (int32_t*)NULL, i);
+        else if(reg_mode == 0) regularization_row<false,false>(P, R, (int32_t*)NULL, (int32_t*)NULL, i);
+        return;
+    }
     const double* __restrict__ b = opref_get(R).b;
     // the blocks past the observations unpack the intrinsics of every camera
     // and the board warp from the packed state (or copy the seeds); the blocks
@@ -187,7 +204,7 @@ void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack)
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
     {
         const OpDev& O = opref_get(R);
-        const long long nz = (long long)gridDim.x - nblocks_obs - nblocks_unpack;
+        const long long nz = nblocks_zero;
         for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*64 + threadIdx.x; i < B.zero_total; i += nz*64)
         {
             long long j = i;
@@ -1130,17 +1147,13 @@ void point_structure_kernel(DeviceProblem P, int32_t* __restrict__ rowptr, int32
 // Rows, in order: [distortions of cam0..camN] [centre pixel x,y of cam0..camN]
 // [unity_cam01]. Reference: mrcal.c:5795-5954
 template<bool WITH_J, bool WITH_STRUCTURE>
-__global__ __launch_bounds__(64)
-void regularization_kernel(DeviceProblem P,
-                           OpRef R,
-                           int32_t*      __restrict__ rowptr,
-                           int32_t*      __restrict__ colidx)
+__device__ __forceinline__
+void regularization_row(const DeviceProblem& P, const OpRef& R,
+                        int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i)
 {
-    if(opref_skip(R)) return;
     const double* __restrict__ b  = opref_get(R).b;
     double*       __restrict__ x  = opref_get(R).x;
     double*       __restrict__ Jv = opref_get(R).Jv;
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
     const int Ndist_rows   = P.do_apply_regularization ? P.Ncameras_intrinsics*P.Ndist_state : 0;
     const int Ncenter_rows = (P.do_apply_regularization && P.Ncore_state) ? P.Ncameras_intrinsics*2 : 0;
     const int Nrows        = Ndist_rows + Ncenter_rows + (P.has_unity_cam01 ? 1 : 0);
@@ -1195,6 +1208,14 @@ void regularization_kernel(DeviceProblem P,
             if(WITH_STRUCTURE) colidx[innz+l] = P.i_state_extrinsics + 3 + l;
         }
     }
+}
+
+template<bool WITH_J, bool WITH_STRUCTURE>
+__global__ __launch_bounds__(64)
+void regularization_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    regularization_row<WITH_J,WITH_STRUCTURE>(P, R, rowptr, colidx, blockIdx.x*blockDim.x + threadIdx.x);
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -1544,8 +1565,10 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
         const int nblocks_obs    = (P.Nobs_board + 63)/64;
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero), dim3(64), 0, stream,
-                           P, B, nblocks_unpack);
+        const int Nreg_rows      = 0;      // the splined regularization has its own kernel
+        const int nblocks_reg    = (Nreg_rows + 63)/64;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg), dim3(64), 0, stream,
+                           P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? (with_jacobian ? 1 : 0) : -1);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
@@ -1565,7 +1588,7 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
             EvalBuffers Bu = B;
             Bu.zero_total = 0;
             const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
-            hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack);
+            hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack, 0, -1);
         }
         if(with_jacobian)
             hipLaunchKernelGGL((point_splined_kernel<true>),  dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
@@ -1761,8 +1784,10 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
         const int nblocks_obs    = (P.Nobs_board + 63)/64;
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero), dim3(64), 0, stream,
-                           P, B, nblocks_unpack);
+        const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
+        const int nblocks_reg    = (Nreg_rows + 63)/64;
+        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg), dim3(64), 0, stream,
+                           P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? (with_jacobian ? 1 : 0) : -1);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
@@ -1790,7 +1815,8 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     }
     launch_triangulated(P, B, with_jacobian, stream);
     const int Nreg = P.Nmeas - P.i_meas_regularization;
-    if(Nreg > 0)
+    // (with board observations the regularization rows were written by the prologue launch)
+    if(Nreg > 0 && P.Nobs_board <= 0)
     {
         if(with_jacobian)
             hipLaunchKernelGGL((regularization_kernel<true,false>), dim3((Nreg + 63)/64), dim3(64), 0, stream,

@@ -165,30 +165,16 @@ void reduce_pair_chunk(const DeviceProblem& P, const NormalDims& nd, const OpRef
     }
 }
 
-// Both of the above in ONE launch (they are independent): workgroups
-// [0, nframe_blocks) take a frame each, the rest a pair chunk each. One launch
-// and one cold start less, and the two kinds of work overlap
-__global__ __launch_bounds__(256)
-void assemble_gram_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                          const double* __restrict__ gram, int nframe_blocks)
-{
-    if(opref_skip(R)) return;
-    extern __shared__ double lds_f[];
-    if((int)blockIdx.x < nframe_blocks) assemble_frame_block(P, nd, R, plan, gram, blockIdx.x, lds_f);
-    else                                reduce_pair_chunk(P, nd, R, plan, gram, blockIdx.x - nframe_blocks);
-}
-
 // (Ending the trial in the LAST workgroup of the g^T N g reduction - ticket
 // counter after a device-scope fence - instead of a launch of its own was
 // measured: the fence costs a write-back of the L2, 30+ us. Not used)
 
 // Rows that do not come from board observations (discrete points,
 // regularization): one lane per CSR row, scattered with atomics. These are few
-__global__ __launch_bounds__(64)
-void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
-                         const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+__device__ __forceinline__
+void rows_generic_row(const NormalDims& nd, const OpRef& R, int r, int row1,
+                      const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
-    if(opref_skip(R)) return;
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
     const double* __restrict__ x  = O.x;
@@ -197,7 +183,6 @@ void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
     double* __restrict__ D  = O.D;
     double* __restrict__ g  = O.g;
     double* __restrict__ norm2_x = &O.scalars[SC_NORM2_X];
-    const int r = row0 + blockIdx.x*blockDim.x + threadIdx.x;
     if(r >= row1) return;
     const int p0 = Jp[r], p1 = Jp[r+1];
     const double xr = x[r];
@@ -227,6 +212,30 @@ void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64)
+void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
+                         const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    if(opref_skip(R)) return;
+    rows_generic_row(nd, R, row0 + blockIdx.x*blockDim.x + threadIdx.x, row1, Jp, Ji);
+}
+
+// The Gram assembly and the generic rows in ONE launch (all three kinds of
+// work are independent): workgroups [0, nframe_blocks) take a frame each, the
+// next Nchunks a pair chunk each, the rest 256 generic rows each
+__global__ __launch_bounds__(256)
+void assemble_all_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
+                         const double* __restrict__ gram, int nframe_blocks,
+                         int row0, int row1, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double lds_f[];
+    const int b = blockIdx.x;
+    if(b < nframe_blocks)                     assemble_frame_block(P, nd, R, plan, gram, b, lds_f);
+    else if(b < nframe_blocks + plan.Nchunks) reduce_pair_chunk(P, nd, R, plan, gram, b - nframe_blocks);
+    else rows_generic_row(nd, R, row0 + (b - nframe_blocks - plan.Nchunks)*256 + threadIdx.x, row1, Jp, Ji);
 }
 
 // A, Bt, D, g and the scalars of an operating point, zeroed in one launch
@@ -1626,14 +1635,16 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
 {
     // splined models: no per-observation Gram; every row goes through the generic path
     const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
+    const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nobs_board > 0 && !by_rows)
     {
         const int nframe_blocks = P.do_optimize_frames ? P.Nframes : 0;
-        hipLaunchKernelGGL(assemble_gram_kernel, dim3(nframe_blocks + plan.Nchunks), dim3(256),
-                           (6*nd.Nc + 42)*sizeof(double), stream, P, nd, B.R, plan, B.gram, nframe_blocks);
+        const int nrow_blocks   = (P.Nmeas > row0) ? (P.Nmeas - row0 + 255)/256 : 0;
+        hipLaunchKernelGGL(assemble_all_kernel, dim3(nframe_blocks + plan.Nchunks + nrow_blocks), dim3(256),
+                           (6*nd.Nc + 42)*sizeof(double), stream, P, nd, B.R, plan, B.gram, nframe_blocks,
+                           row0, P.Nmeas, B.Jp, B.Ji);
     }
-    const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
-    if(P.Nmeas > row0)
+    else if(P.Nmeas > row0)
         hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - row0 + 63)/64), dim3(64), 0, stream,
                            nd, B.R, row0, P.Nmeas, B.Jp, B.Ji);
     return hipGetLastError();
