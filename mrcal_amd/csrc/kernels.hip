@@ -535,12 +535,6 @@ void board_kernel(DeviceProblem P,
                   double*       __restrict__ gram)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if(opref_skip(R)) return;
-    // the output pointers come out of a table in memory: say that they are
-    // global, or every store becomes a FLAT store (which also counts against the
-    // LDS counter and stalls the LDS waits)
-    gdouble* __restrict__ x  = (gdouble*)opref_get(R).x;
-    gdouble* __restrict__ Jv = (gdouble*)opref_get(R).Jv;
 
     constexpr int EXT0   = 4 + NDIST;
     constexpr int FRAME0 = EXT0 + 6;
@@ -559,11 +553,40 @@ void board_kernel(DeviceProblem P,
     long long ts[8] = {0,0,0,0,0,0,0,0};
     TS(0);
 #endif
-    const BoardObsMeta m = P.board_meta[iobs];
-    const double* __restrict__ jp_global = joint + (size_t)iobs*JOINT_STRIDE;
+    const int NPTS = P.W*P.H;
 
+    // FIRST: request everything whose address depends on the observation index
+    // alone - the observed pixels (qx,qy,weight of every corner) and the joint
+    // pose record. What comes after (the skip flag, the operating point's
+    // pointers, the observation's metadata, the camera's intrinsics) is a chain
+    // of small dependent scalar loads: it runs under the latency of these. No
+    // lane predication (the tail lanes re-read the last element and write into
+    // the padding of obs_lds, which is allocated in whole 64-element chunks)
+    const double* __restrict__ pool      = P.board_pool + (size_t)iobs*NPTS*3;
+    const double* __restrict__ jp_global = joint + (size_t)iobs*JOINT_STRIDE;
+    const int n3 = 3*NPTS, last = n3 - 1;
+    const double j0 = jp_global[lane];
+    const double j1 = jp_global[(lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1];
+    // the first 512 values (boards of up to 170 corners: all of them) in
+    // straight-line code: 8 loads in flight
+    double v_obs[8];
+#pragma unroll
+    for(int j=0;j<8;j++)
+        if(64*j < n3)                       // wave-uniform
+        {
+            const int idx = 64*j + lane;
+            v_obs[j] = pool[idx < last ? idx : last];
+        }
+
+    if(opref_skip(R)) return;
+    // the output pointers come out of a table in memory: say that they are
+    // global, or every store becomes a FLAT store (which also counts against the
+    // LDS counter and stalls the LDS waits)
+    gdouble* __restrict__ x  = (gdouble*)opref_get(R).x;
+    gdouble* __restrict__ Jv = (gdouble*)opref_get(R).Jv;
+
+    const BoardObsMeta m = P.board_meta[iobs];
     const int  k       = m.nnz_per_row;
-    const int  NPTS    = P.W*P.H;
     const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
 
     double* __restrict__ tile    = lds;
@@ -573,38 +596,6 @@ void board_kernel(DeviceProblem P,
     // every pass puts a memory latency (long, under this kernel's own write
     // stream) in front of the chain rule. Reads from here are broadcasts
     double* __restrict__ jp      = obs_lds + ((3*NPTS + 63) & ~63);
-
-    // stage the observation: qx,qy,weight of every corner. All the loads are
-    // issued before the first wait; no lane predication (the tail lanes re-read
-    // the last element and write into the padding of obs_lds, which is
-    // allocated in whole 64-element chunks)
-    {
-        const double* __restrict__ pool = P.board_pool + (size_t)iobs*NPTS*3;
-        const int n3 = 3*NPTS, last = n3 - 1;
-        const double j0 = jp_global[lane];
-        const double j1 = jp_global[(lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1];
-        // the first 512 values (boards of up to 170 corners: all of them) in
-        // straight-line code: 8 loads in flight, then the LDS writes
-        double v[8];
-#pragma unroll
-        for(int j=0;j<8;j++)
-            if(64*j < n3)                       // wave-uniform
-            {
-                const int idx = 64*j + lane;
-                v[j] = pool[idx < last ? idx : last];
-            }
-#pragma unroll
-        for(int j=0;j<8;j++)
-            if(64*j < n3)
-                obs_lds[64*j + lane] = v[j];
-        jp[lane] = j0;
-        if(lane < JOINT_STRIDE - 64) jp[64 + lane] = j1;
-        for(int base = 512; base < n3; base += 64)
-        {
-            const int idx = base + lane;
-            obs_lds[idx] = pool[idx < last ? idx : last];
-        }
-    }
 
     // intrinsics of this camera and the board warp, unpacked by the prologue kernel
     const double* __restrict__ ip = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
@@ -661,6 +652,18 @@ void board_kernel(DeviceProblem P,
         co_gofs = (unsigned)(co_rsub*k + co_c0);
     }
 
+    // ... and only now are the staged loads needed
+#pragma unroll
+    for(int j=0;j<8;j++)
+        if(64*j < n3)
+            obs_lds[64*j + lane] = v_obs[j];
+    jp[lane] = j0;
+    if(lane < JOINT_STRIDE - 64) jp[64 + lane] = j1;
+    for(int base = 512; base < n3; base += 64)
+    {
+        const int idx = base + lane;
+        obs_lds[idx] = pool[idx < last ? idx : last];
+    }
     __builtin_amdgcn_wave_barrier();   // obs_lds is complete (one wave: the LDS is in order)
     if(P.debug_ablate & 16) { if(obs_lds[lane] + intr[0] + warp0 + jp[0] == 12345.678) x[0] = 1.0; return; }
 
