@@ -66,6 +66,7 @@ pack_state                            = _api.pack_state
 unpack_state                          = _api.unpack_state
 lensmodel_num_params                  = _api.lensmodel_num_params
 project                               = _api.project
+unproject                             = _api.unproject
 
 from ._factorization import CHOLMOD_factorization
 

@@ -505,6 +505,34 @@ class Api:
             raise RuntimeError("mrcal_project() failed!" + self._last_error())
         return (q, dq_dv, dq_di) if get_gradients else q
 
+    def unproject(self, q, lensmodel, intrinsics_data, normalize=False, get_gradients=False):
+        """v = unproject(q): pixel coordinates (...,2) to observation vectors
+        (...,3) in camera coordinates (mrcal.unproject(), mrcal/projections.py:112,
+        over mrcal_unproject(), mrcal.h:401-411; here without the broadcasting
+        over models). Not normalized unless asked: like the reference, the
+        parametric models return (x/z, y/z, 1)-style vectors. The gradients of
+        the reference's Python routine (obtained there by differentiating
+        project() at the solution) are not provided"""
+        if get_gradients:
+            raise NotImplementedError("unproject(get_gradients=True) is not available")
+        m = self.lib.lensmodel(lensmodel)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if q.shape[-1] != 2:
+            raise RuntimeError("q must have shape (...,2)")
+        intr = np.ascontiguousarray(intrinsics_data, dtype=np.float64)
+        Ni = self.clib.mrcal_lensmodel_num_params(C.byref(m))
+        if intr.shape != (Ni,):
+            raise RuntimeError(f"intrinsics_data must have shape ({Ni},) for {lensmodel}")
+        v = np.empty(q.shape[:-1] + (3,))
+        f = self.clib.mrcal_unproject
+        f.restype  = C.c_bool
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        if not f(_ptr(v), _ptr(q), q.size // 2, C.byref(m), _ptr(intr)):
+            raise RuntimeError("mrcal_unproject() failed!" + self._last_error())
+        if normalize:
+            v /= np.linalg.norm(v, axis=-1, keepdims=True)
+        return v
+
     def _last_error(self):
         if self.lib.has_symbol("mrcal_amd_last_error"):
             f = self.clib.mrcal_amd_last_error

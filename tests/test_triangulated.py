@@ -106,6 +106,33 @@ def test_unproject_matches_reference(amd, ref_api, lensmodel, intrinsics):
     assert np.abs(out[0] - out[1]).max() < 1e-8
 
 
+@pytest.mark.parametrize("lensmodel,intrinsics", UNPROJECT_MODELS[:6], ids=[m[0] for m in UNPROJECT_MODELS[:6]])
+def test_python_unproject(amd_api, ref_api, lensmodel, intrinsics):
+    """mrcal_amd.unproject(): shapes, normalize, against the reference's C
+    function, and project(unproject(q)) == q through the reference's project"""
+    rng  = np.random.RandomState(4)
+    intr = np.array(intrinsics, dtype=float)
+    q    = np.array((1512., 1112.)) + rng.uniform(-400, 400, size=(5, 7, 2))
+    v    = amd_api.unproject(q, lensmodel, intr)
+    assert v.shape == (5, 7, 3)
+    assert np.allclose(v, ref_api.unproject(q, lensmodel, intr), rtol=0, atol=1e-9)
+    vn = amd_api.unproject(q, lensmodel, intr, normalize=True)
+    assert np.allclose(np.linalg.norm(vn, axis=-1), 1.0)
+    assert np.allclose(np.cross(vn, v), 0, atol=1e-9)
+    # the reference's mrcal_project() brings them back to the pixels
+    from mrcal_amd._cabi import Lensmodel
+    m = ref_api.lib.lensmodel(lensmodel)
+    f = ref_api.clib.mrcal_project
+    f.restype  = C.c_bool
+    f.argtypes = [C.c_void_p]*4 + [C.c_int, C.c_void_p, C.c_void_p]
+    q2 = np.empty((35, 2))
+    vv = np.ascontiguousarray(v.reshape(-1, 3))
+    assert f(q2.ctypes.data, None, None, vv.ctypes.data, 35, C.byref(m), intr.ctypes.data)
+    assert np.abs(q2 - q.reshape(-1, 2)).max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        amd_api.unproject(q, lensmodel, intr, get_gradients=True)
+
+
 def test_pair_residual_matches_reference_cpu(ref_api):
     """the pair residual and its derivatives (host build of triangulation.hpp)
     against the rows the reference's callback produces. No GPU"""
