@@ -120,6 +120,7 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     ok = ok && f->alloc(&f->F.y,  (size_t)nd.NE);
     ok = ok && f->alloc(&f->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc);
     ok = ok && f->alloc(&f->F.Spart, schur_partial_doubles(nd));
+    ok = ok && f->alloc(&f->F.Linv,  cholesky_large_workspace_doubles(nd.Nc));
     ok = ok && f->alloc(&f->F.status, 1);
     ok = ok && f->alloc(&f->d_rhs, (size_t)nd.Nstate);
     ok = ok && f->alloc(&f->d_sol, (size_t)nd.Nstate);

@@ -64,7 +64,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.status);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -101,6 +101,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         ok = ok && dev_alloc(&P->op[i].step_gn,     (size_t)nd.Nstate);
     }
     ok = ok && dev_alloc(&P->F.Spart, schur_partial_doubles(nd));
+    ok = ok && dev_alloc(&P->F.Linv,  cholesky_large_workspace_doubles(nd.Nc));
     {
         char* ctl = NULL;
         ok = ok && dev_alloc(&ctl, solver_ctl_bytes());

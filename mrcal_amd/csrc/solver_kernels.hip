@@ -990,6 +990,226 @@ void schur_cholesky_solve_global_kernel(int n, const int* __restrict__ skip,
     for(int i=t;i<n;i+=nt) r[i] = -r[i];
 }
 
+////////////////////////////////////////////////////////////////////////////////
+// Large camera blocks (the splined models: Nc = 4 + 2 Nx Ny + ..., ~1200): the
+// same factorization and solve as a sequence of launches over the WHOLE device.
+// M = [S ; r] is (n+1) x n row-major (r is stored right behind S: the right-hand
+// side is row n and rides through the factorization, as in the LDS kernel).
+// Right-looking, panels of LCH_NB = 64 columns; per panel three launches:
+//   diag   1 workgroup   L11 = chol(M11) in LDS, and its inverse (kept: the
+//                        backward solve needs it again)
+//   trsm   1 workgroup / 64 rows below    L21 = M21 L11^-T   (a small GEMM with the inverse)
+//   syrk   1 workgroup / 32x32 tile of the trailing matrix, M22 -= L21 L21^T, v_mfma_f64_16x16x4
+// then ONE launch solves L^T d = z panel by panel, backwards (z = row n), r <- -d.
+// ~20 x 3 launches and ~0.6 GFLOP for n = 1200: about a millisecond, where the
+// one-workgroup fallback above takes 160 ms
+////////////////////////////////////////////////////////////////////////////////
+#define LCH_NB 64
+__global__ __launch_bounds__(256)
+void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
+                       double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status)
+{
+    if(skip != NULL && *skip) return;
+    __shared__ double L[LCH_NB][LCH_NB+1];
+    __shared__ double X[LCH_NB][LCH_NB+1];
+    __shared__ int notpd;
+    const int t  = threadIdx.x;
+    const int nb = min(LCH_NB, n - j0);
+    if(t == 0) notpd = 0;
+    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    {
+        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
+        // the block is padded with the identity
+        L[i][j] = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for(int j = 0; j < nb; j++)
+    {
+        // column j: the pivot (every thread computes it for itself), the scaling
+        double d = L[j][j];
+        if(!(d > 0.0)) { if(t == 0) notpd = 1; d = 1.0; }
+        const double rd = 1.0/sqrt(d);
+        __syncthreads();
+        if(t >= j && t < nb) L[t][j] = (t == j) ? d*rd : L[t][j]*rd;
+        __syncthreads();
+        // rank-1 update of the columns to the right, lower triangle
+        const int m = nb - j - 1;
+        for(int idx = t; idx < m*m; idx += 256)
+        {
+            const int a = idx / m, b = idx - a*m;
+            if(b <= a) L[j+1+a][j+1+b] -= L[j+1+a][j]*L[j+1+b][j];
+        }
+        __syncthreads();
+    }
+    // X = L^-1: thread c solves L x = e_c (column c of the inverse)
+    if(t < LCH_NB)
+    {
+        const int c = t;
+        for(int i = 0; i < LCH_NB; i++)
+        {
+            double v = (i == c) ? 1.0 : 0.0;
+            for(int k = c; k < i; k++) v -= L[i][k]*X[k][c];
+            X[i][c] = (i >= c) ? v/L[i][i] : 0.0;
+        }
+    }
+    __syncthreads();
+    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    {
+        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
+        if(i < nb && j < nb && j <= i) M[(size_t)(j0+i)*n + j0 + j] = L[i][j];
+        Linv[idx] = X[i][j];
+    }
+    if(t == 0 && notpd) atomicExch(status, 1);
+}
+
+// rows m0 + 64 b .. of the panel (incl. the rhs row n):  L21 = M21 L11^-T,
+// i.e. out[i][j] = sum_{k<=j} M21[i][k] Linv[j][k]
+__global__ __launch_bounds__(256)
+void lchol_trsm_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
+                       const double* __restrict__ Linv)
+{
+    if(skip != NULL && *skip) return;
+    __shared__ double A[LCH_NB][LCH_NB+1];
+    __shared__ double X[LCH_NB][LCH_NB+1];
+    const int t  = threadIdx.x;
+    const int nb = min(LCH_NB, n - j0);
+    const int m0 = j0 + nb;
+    const int r0 = m0 + blockIdx.x*LCH_NB;          // first row of this chunk; rows up to n (inclusive)
+    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    {
+        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
+        X[i][j] = Linv[idx];
+        A[i][j] = (r0 + i <= n && j < nb) ? M[(size_t)(r0+i)*n + j0 + j] : 0.0;
+    }
+    __syncthreads();
+    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    {
+        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
+        if(r0 + i > n || j >= nb) continue;
+        double acc = 0.0;
+        for(int k = 0; k <= j; k++) acc += A[i][k]*X[j][k];
+        M[(size_t)(r0+i)*n + j0 + j] = acc;
+    }
+}
+
+// trailing update, 32 x 32 tiles (ti >= tj) of the rows/columns from m0 on:
+//   M[i][c] -= sum_k L[i][j0+k] L[c][j0+k]        i in [m0, n], c in [m0, n), c <= i
+// 4 waves, one 16x16 MFMA tile each; operands staged in LDS
+__global__ __launch_bounds__(256)
+void lchol_syrk_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0, int ntile)
+{
+    if(skip != NULL && *skip) return;
+    // tile pair from the linear index: ti >= tj
+    int ti = 0, p = blockIdx.x;
+    while(p > ti) { p -= ti + 1; ti++; }
+    const int tj = p;
+    (void)ntile;
+    const int nb = min(LCH_NB, n - j0);
+    const int m0 = j0 + nb;
+    const int i0 = m0 + 32*ti, c0 = m0 + 32*tj;
+    __shared__ double Li[32][LCH_NB+1];
+    __shared__ double Lc[32][LCH_NB+1];
+    const int t = threadIdx.x;
+    for(int idx = t; idx < 32*LCH_NB; idx += 256)
+    {
+        const int i = idx / LCH_NB, k = idx - i*LCH_NB;
+        Li[i][k] = (i0 + i <= n && k < nb) ? M[(size_t)(i0+i)*n + j0 + k] : 0.0;
+        Lc[i][k] = (c0 + i <  n && k < nb) ? M[(size_t)(c0+i)*n + j0 + k] : 0.0;
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    const int wi = wave >> 1, wc = wave & 1;            // this wave's 16x16 sub-tile
+    const int r16 = lane & 15, kq = lane >> 4;
+    syrk_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
+    {
+        // A[i][k] = L[i][k] (lane: i = l%16, k = l/16); B[k][j] = L[c][k] (lane: j = l%16, k = l/16)
+        const double av = Li[16*wi + r16][k0 + kq];
+        const double bv = Lc[16*wc + r16][k0 + kq];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    // D register v of lane l = D[l/16 + 4 v][l%16]
+#pragma unroll
+    for(int v = 0; v < 4; v++)
+    {
+        const int i = i0 + 16*wi + kq + 4*v, c = c0 + 16*wc + r16;
+        if(i <= n && c < n && c <= i) M[(size_t)i*n + c] -= acc[v];
+    }
+}
+
+// L^T d = z, panel by panel from the last: one workgroup. z is row n of M; on
+// return r (= that row) holds -d
+__global__ __launch_bounds__(1024)
+void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
+                           const double* __restrict__ Linv_all)
+{
+    if(skip != NULL && *skip) return;
+    double* __restrict__ z = M + (size_t)n*n;
+    __shared__ double part[16][LCH_NB];
+    __shared__ double w[LCH_NB];
+    const int t = threadIdx.x;
+    const int c = t & (LCH_NB-1), slice = t >> 6;       // 16 slices of rows for each of the 64 columns
+    const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    for(int p = npanels-1; p >= 0; p--)
+    {
+        const int j0 = p*LCH_NB;
+        const int nb = min(LCH_NB, n - j0);
+        const int m0 = j0 + nb;
+        // w[c] = z[j0+c] - sum_{i >= m0} L[i][j0+c] d[i]
+        double acc = 0.0;
+        if(c < nb)
+            for(int i = m0 + slice; i < n; i += 16) acc += M[(size_t)i*n + j0 + c]*z[i];
+        part[slice][c] = acc;
+        __syncthreads();
+        if(t < LCH_NB)
+        {
+            double s = 0.0;
+            for(int k = 0; k < 16; k++) s += part[k][t];
+            w[t] = (t < nb) ? z[j0 + t] - s : 0.0;
+        }
+        __syncthreads();
+        // d_p = L11^-T w:  d[c] = sum_{k >= c} Linv[k][c] w[k]
+        if(t < nb)
+        {
+            const double* __restrict__ X = Linv_all + (size_t)p*LCH_NB*LCH_NB;
+            double s = 0.0;
+            for(int k = t; k < nb; k++) s += X[k*LCH_NB + t]*w[k];
+            z[j0 + t] = s;
+        }
+        __syncthreads();
+    }
+    for(int i = t; i < n; i += blockDim.x) z[i] = -z[i];
+}
+
+hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
+{
+    const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    for(int p = 0; p < npanels; p++)
+    {
+        const int j0 = p*LCH_NB;
+        const int nb = (n - j0 < LCH_NB) ? n - j0 : LCH_NB;
+        const int m0 = j0 + nb;
+        double* Lp = Linv + (size_t)p*LCH_NB*LCH_NB;
+        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(256), 0, stream, n, skip, M, j0, Lp, status);
+        const int nrows = n + 1 - m0;       // rows below, incl. the rhs row
+        hipLaunchKernelGGL(lchol_trsm_kernel, dim3((nrows + LCH_NB - 1)/LCH_NB), dim3(256), 0, stream, n, skip, M, j0, Lp);
+        if(m0 < n)
+        {
+            const int ntile = (nrows + 31)/32;
+            hipLaunchKernelGGL(lchol_syrk_kernel, dim3(ntile*(ntile+1)/2), dim3(256), 0, stream, n, skip, M, j0, ntile);
+        }
+    }
+    hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, Linv);
+    return hipGetLastError();
+}
+size_t cholesky_large_workspace_doubles(int n)
+{
+    const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
+    if(lds <= 160*1024 - 4096 && n <= 256) return 1;       // the LDS kernel serves
+    return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB*LCH_NB;
+}
+
 // d_e = -L^-T (y_e + Wt_e d_s);  also scatters d_s into the state-ordered step
 __global__ __launch_bounds__(64)
 void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restrict__ skip_also,
@@ -1720,6 +1940,8 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
         if(lds <= 160*1024 - 4096 && n <= 256)
             hipLaunchKernelGGL(schur_cholesky_solve_kernel, dim3(1), dim3(1024), lds, stream,
                                n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
+        else if(F.Linv != NULL)
+            launch_cholesky_large(n, R.skip, F.S, F.Linv, F.status, stream);
         else
             hipLaunchKernelGGL(schur_cholesky_solve_global_kernel, dim3(1), dim3(1024), 0, stream,
                                n, R.skip, F.S, F.r, F.status);

@@ -69,9 +69,12 @@ struct FactorBuffers
     double* S;        // [Nc][Nc]   Schur complement -> its Cholesky factor (lower)
     double* r;        // [Nc]       reduced rhs -> d_s
     double* Spart;    // [schur_partial_doubles(nd)] per-slice partial products of the SYRK, summed by schur_reduce_kernel
+    double* Linv;     // [cholesky_large_workspace_doubles(Nc)] inverses of the 64x64 diagonal blocks (large Nc only)
     int*    status;   // [1] nonzero: not positive definite
 };
 
+// size of FactorBuffers::Linv: the multi-launch Cholesky of camera blocks that do not fit the LDS
+size_t cholesky_large_workspace_doubles(int n);
 // size of FactorBuffers::Spart (solver_kernels.hip: SYRK slicing)
 size_t schur_partial_doubles(const NormalDims& nd);
 
