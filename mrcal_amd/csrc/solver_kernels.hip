@@ -214,6 +214,147 @@ void rows_generic_row(const NormalDims& nd, const OpRef& R, int r, int row1,
     }
 }
 
+// Board rows of the SPLINED models. There is no per-observation Gram for them
+// (the columns of a row depend on where the corner lands in the knot grid), and
+// one lane per row with global atomics for every pair of its ~26 entries is 108 M
+// atomics at 160k rows: 13 ms. But the rows of ONE observation only ever touch
+// a small set of camera-block variables: the core, the extrinsics, the warp and
+// the knots under the board, (order+1 + span)^2 of them. One workgroup per frame
+// therefore forms each observation's little dense Gram over that local set in
+// LDS (LDS atomics), plus the frame's rows of Bt, D_f, g_f, and flushes it:
+// ~6000 global atomics per observation instead of ~110 000. An observation whose
+// board covers more knots than the LDS budget goes the generic way, row by row.
+//   local index: 0..3 core | 4..9 extrinsics | 10..11 warp | 12.. knots of the bounding box, (iy, ix, xy)
+#define SPL_DENSE 12
+__global__ __launch_bounds__(256)
+void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
+                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int umax)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double lds_s[];                   // G[umax][umax] | BtL[6][umax] | gL[umax] | Df[36] | gf[6] | n2[1]
+    double* __restrict__ G   = lds_s;
+    double* __restrict__ BtL = G + (size_t)umax*umax;
+    double* __restrict__ gL  = BtL + 6*umax;
+    double* __restrict__ Df  = gL + umax;
+    double* __restrict__ gf  = Df + 36;
+    double* __restrict__ n2  = gf + 6;
+    __shared__ int bbox[4];
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Jv = O.Jv;
+    const double* __restrict__ x  = O.x;
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
+    const int NPTS = P.W*P.H, Nx = P.cfg.spline_Nx, order1 = P.cfg.spline_order + 1;
+    const int Ncs = P.Ncore_state;
+
+    for(int o = o0; o < o1; o++)
+    {
+        const BoardObsMeta m = P.board_meta[o];
+        const int r0 = m.i_meas0, r1 = m.i_meas0 + 2*NPTS;
+        // bounding box of the knots under this observation: from the first spline column of every x row
+        if(t < 4) bbox[t] = (t & 1) ? -1 : 0x7fffffff;
+        __syncthreads();
+        if(P.Ndist_row > 0)
+            for(int c = t; c < NPTS; c += blockDim.x)
+            {
+                // (outliers have x == 0 and all-zero rows: whatever columns they carry do not matter)
+                if(x[r0 + 2*c] == 0.0 && x[r0 + 2*c + 1] == 0.0) continue;
+                const int rel  = Ji[Jp[r0 + 2*c] + (Ncs ? 2 : 0)] - (m.i_state_intrinsics + Ncs);
+                const int knot = rel >> 1, ix = knot % Nx, iy = knot / Nx;
+                atomicMin(&bbox[0], ix); atomicMax(&bbox[1], ix + order1 - 1);
+                atomicMin(&bbox[2], iy); atomicMax(&bbox[3], iy + order1 - 1);
+            }
+        __syncthreads();
+        const int ix0 = bbox[0], iy0 = bbox[2];
+        const int wx = (P.Ndist_row > 0) ? bbox[1] - bbox[0] + 1 : 0, wy = (P.Ndist_row > 0) ? bbox[3] - bbox[2] + 1 : 0;
+        const int UN = SPL_DENSE + 2*wx*wy;
+        __syncthreads();            // bbox is reused by the next observation
+        if(UN > umax)
+        {
+            for(int r = r0 + t; r < r1; r += blockDim.x) rows_generic_row(nd, R, r, r1, Jp, Ji);
+            continue;
+        }
+        for(int i = t; i < UN*UN; i += blockDim.x) G[i] = 0.0;
+        for(int i = t; i < 7*umax + 43; i += blockDim.x) BtL[i] = 0.0;      // BtL, gL, Df, gf, n2
+        __syncthreads();
+
+        // state index -> local index (>= 0), or -(1 + frame variable) for this frame's columns
+        auto local_of = [&](int col) -> int
+        {
+            if(P.do_optimize_frames && col >= nd.Nie && col < nd.Nie + nd.NE) return -(1 + (col - (nd.Nie + 6*f)));
+            if(m.i_state_intrinsics >= 0 && col >= m.i_state_intrinsics && col < m.i_state_intrinsics + P.Nintr_state)
+            {
+                const int rel = col - m.i_state_intrinsics;
+                if(rel < Ncs) return rel;
+                const int knot = (rel - Ncs) >> 1, xy = (rel - Ncs) & 1;
+                return SPL_DENSE + 2*((knot / Nx - iy0)*wx + (knot % Nx - ix0)) + xy;
+            }
+            if(m.i_state_extrinsics >= 0 && col >= m.i_state_extrinsics && col < m.i_state_extrinsics + 6)
+                return 4 + (col - m.i_state_extrinsics);
+            return 10 + (col - P.i_state_warp);
+        };
+        for(int r = r0 + t; r < r1; r += blockDim.x)
+        {
+            const int p0 = Jp[r], p1 = Jp[r+1];
+            const double xr = x[r];
+            atomicAdd(n2, xr*xr);
+            for(int p = p0; p < p1; p++)
+            {
+                const double vp = Jv[p];
+                if(vp == 0.0) continue;
+                const int lp = local_of(Ji[p]);
+                if(lp >= 0) atomicAdd(&gL[lp], vp*xr); else atomicAdd(&gf[-lp-1], vp*xr);
+                for(int q = p0; q < p1; q++)
+                {
+                    const double v  = vp*Jv[q];
+                    if(v == 0.0) continue;
+                    const int lq = local_of(Ji[q]);
+                    if(lp >= 0 && lq >= 0)      atomicAdd(&G[lp*UN + lq], v);
+                    else if(lp < 0 && lq >= 0)  atomicAdd(&BtL[(-lp-1)*umax + lq], v);
+                    else if(lp < 0 && lq < 0)   atomicAdd(&Df[(-lp-1)*6 + (-lq-1)], v);
+                }
+            }
+        }
+        __syncthreads();
+
+        // flush. local index -> S index
+        auto S_of = [&](int l) -> int
+        {
+            int col;
+            if(l < 4)               col = m.i_state_intrinsics + l;
+            else if(l < 10)         col = m.i_state_extrinsics + (l - 4);
+            else if(l < SPL_DENSE)  col = P.i_state_warp + (l - 10);
+            else
+            {
+                const int k = (l - SPL_DENSE) >> 1, xy = (l - SPL_DENSE) & 1;
+                col = m.i_state_intrinsics + Ncs + 2*((iy0 + k / wx)*Nx + ix0 + k % wx) + xy;
+            }
+            return state_to_SE(nd, col);
+        };
+        for(int i = t; i < UN*UN; i += blockDim.x)
+        {
+            const double v = G[i];
+            if(v != 0.0) atomicAdd(&O.A[(size_t)S_of(i / UN)*nd.Nc + S_of(i % UN)], v);
+        }
+        for(int i = t; i < UN; i += blockDim.x)
+        {
+            const double v = gL[i];
+            if(v != 0.0) atomicAdd(&O.g[(S_of(i) < nd.Nie) ? S_of(i) : nd.i_state_warp + (S_of(i) - nd.Nie)], v);
+        }
+        // this frame's own rows: no other workgroup touches them
+        for(int i = t; i < 6*UN; i += blockDim.x)
+        {
+            const int fi = i / UN, l = i - fi*UN;
+            const double v = BtL[fi*umax + l];
+            if(v != 0.0) O.Bt[(size_t)(6*f + fi)*nd.Nc + S_of(l)] += v;
+        }
+        if(t < 36)      O.D[(size_t)f*36 + t]        += Df[t];
+        else if(t < 42) O.g[nd.Nie + 6*f + (t-36)]   += gf[t-36];
+        else if(t == 42) atomicAdd(&O.scalars[SC_NORM2_X], n2[0]);
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(64)
 void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
                          const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
@@ -1864,9 +2005,23 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
                            (6*nd.Nc + 42)*sizeof(double), stream, P, nd, B.R, plan, B.gram, nframe_blocks,
                            row0, P.Nmeas, B.Jp, B.Ji);
     }
-    else if(P.Nmeas > row0)
-        hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - row0 + 63)/64), dim3(64), 0, stream,
-                           nd, B.R, row0, P.Nmeas, B.Jp, B.Ji);
+    else
+    {
+        // splined models: the board rows observation by observation (local Grams in
+        // LDS), everything else row by row
+        int rows_from = row0;
+        if(by_rows && P.Nobs_board > 0 && P.Nframes > 0)
+        {
+            const int umax = 96;
+            const size_t lds = ((size_t)umax*umax + 7*umax + 43)*sizeof(double);
+            hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), lds, stream,
+                               P, nd, B.R, plan, B.Jp, B.Ji, umax);
+            rows_from = 2*P.W*P.H*P.Nobs_board;
+        }
+        if(P.Nmeas > rows_from)
+            hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - rows_from + 63)/64), dim3(64), 0, stream,
+                               nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+    }
     return hipGetLastError();
 }
 
