@@ -1146,61 +1146,90 @@ void schur_cholesky_solve_global_kernel(int n, const int* __restrict__ skip,
 // one-workgroup fallback above takes 160 ms
 ////////////////////////////////////////////////////////////////////////////////
 #define LCH_NB 64
-__global__ __launch_bounds__(256)
+template<int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr(I < N) { f(std::integral_constant<int,I>{}); static_for<I+1,N>(f); }
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+// ONE wave, the 64x64 block in registers: lane i holds matrix row i. No
+// barriers: the pivot and the multipliers L[c][j] are lane c's register j, read
+// with v_readlane into scalar registers. Then X = L^-1 the same way round: lane
+// c holds column c of X; the L[i][k] it needs are wave-uniform LDS reads.
+// (A 256-thread version with a workgroup barrier per column took 160 us per
+// panel; this takes ~25)
+__global__ __launch_bounds__(64)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
                        double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status)
 {
     if(skip != NULL && *skip) return;
     __shared__ double L[LCH_NB][LCH_NB+1];
-    __shared__ double X[LCH_NB][LCH_NB+1];
-    __shared__ int notpd;
-    const int t  = threadIdx.x;
+    const int lane = threadIdx.x;
     const int nb = min(LCH_NB, n - j0);
-    if(t == 0) notpd = 0;
-    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    // coalesced load into LDS; the block is padded with the identity
+    for(int idx = lane; idx < LCH_NB*LCH_NB; idx += 64)
     {
         const int i = idx / LCH_NB, j = idx - i*LCH_NB;
-        // the block is padded with the identity
         L[i][j] = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    for(int j = 0; j < nb; j++)
+    double row[LCH_NB];
+    static_for<0,LCH_NB>([&](auto J) { constexpr int j = decltype(J)::value; row[j] = L[lane][j]; });
+    bool bad = false;
+    double my_rdiag = 1.0;                  // 1/L[lane][lane]
+    static_for<0,LCH_NB>([&](auto J)
     {
-        // column j: the pivot (every thread computes it for itself), the scaling
-        double d = L[j][j];
-        if(!(d > 0.0)) { if(t == 0) notpd = 1; d = 1.0; }
-        const double rd = 1.0/sqrt(d);
-        __syncthreads();
-        if(t >= j && t < nb) L[t][j] = (t == j) ? d*rd : L[t][j]*rd;
-        __syncthreads();
-        // rank-1 update of the columns to the right, lower triangle
-        const int m = nb - j - 1;
-        for(int idx = t; idx < m*m; idx += 256)
+        constexpr int j = decltype(J)::value;
+        double piv = readlane_f64(row[j], j);
+        bad = bad || !(piv > 0.0);
+        piv = (piv > 0.0) ? piv : 1.0;
+        double rd = __builtin_amdgcn_rsq(piv);
+        rd = rd*(1.5 - 0.5*piv*rd*rd);
+        rd = rd*(1.5 - 0.5*piv*rd*rd);
+        row[j] *= rd;                       // lane j: sqrt(piv); lanes below: L[i][j]
+        my_rdiag = (lane == j) ? rd : my_rdiag;     // (a select, not a branch: with control flow here the
+                                                    //  compiler sinks the updates below across the blocks)
+        // the multipliers L[c][j] = lane c's row[j], broadcast through SGPRs.
+        // Scheduling fences every 8 columns: left alone the scheduler hoists
+        // hundreds of readlanes and spills thousands of SGPRs
+        static_for<j+1,LCH_NB>([&](auto Cc)
         {
-            const int a = idx / m, b = idx - a*m;
-            if(b <= a) L[j+1+a][j+1+b] -= L[j+1+a][j]*L[j+1+b][j];
-        }
-        __syncthreads();
-    }
-    // X = L^-1: thread c solves L x = e_c (column c of the inverse)
-    if(t < LCH_NB)
-    {
-        const int c = t;
-        for(int i = 0; i < LCH_NB; i++)
-        {
-            double v = (i == c) ? 1.0 : 0.0;
-            for(int k = c; k < i; k++) v -= L[i][k]*X[k][c];
-            X[i][c] = (i >= c) ? v/L[i][i] : 0.0;
-        }
-    }
+            constexpr int c = decltype(Cc)::value;
+            row[c] -= row[j]*readlane_f64(row[j], c);
+            if constexpr ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
     __syncthreads();
-    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    static_for<0,LCH_NB>([&](auto J) { constexpr int j = decltype(J)::value; L[lane][j] = (j <= lane) ? row[j] : 0.0; });
+    __syncthreads();
+    // X = L^-1, lane c = column c:  X[i] = (delta_ic - sum_{k<i} L[i][k] X[k]) / L[i][i]
+    static_for<0,LCH_NB>([&](auto I)
+    {
+        constexpr int i = decltype(I)::value;
+        double v = (lane == i) ? 1.0 : 0.0;
+        static_for<0,i>([&](auto K)
+        {
+            constexpr int k = decltype(K)::value;
+            v -= L[i][k]*row[k];
+            if constexpr ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);    // (as above)
+        });
+        row[i] = v*readlane_f64(my_rdiag, i);       // (row[] now holds X's column)
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<0,LCH_NB>([&](auto I) { constexpr int i = decltype(I)::value; Linv[i*LCH_NB + lane] = row[i]; });
+    for(int idx = lane; idx < LCH_NB*LCH_NB; idx += 64)
     {
         const int i = idx / LCH_NB, j = idx - i*LCH_NB;
         if(i < nb && j < nb && j <= i) M[(size_t)(j0+i)*n + j0 + j] = L[i][j];
-        Linv[idx] = X[i][j];
     }
-    if(t == 0 && notpd) atomicExch(status, 1);
+    if(bad && lane == 0) atomicExch(status, 1);
 }
 
 // rows m0 + 64 b .. of the panel (incl. the rhs row n):  L21 = M21 L11^-T,
@@ -1332,7 +1361,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         const int nb = (n - j0 < LCH_NB) ? n - j0 : LCH_NB;
         const int m0 = j0 + nb;
         double* Lp = Linv + (size_t)p*LCH_NB*LCH_NB;
-        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(256), 0, stream, n, skip, M, j0, Lp, status);
+        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(64), 0, stream, n, skip, M, j0, Lp, status);
         const int nrows = n + 1 - m0;       // rows below, incl. the rhs row
         hipLaunchKernelGGL(lchol_trsm_kernel, dim3((nrows + LCH_NB - 1)/LCH_NB), dim3(256), 0, stream, n, skip, M, j0, Lp);
         if(m0 < n)
