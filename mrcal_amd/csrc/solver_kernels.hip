@@ -215,34 +215,38 @@ void rows_generic_row(const NormalDims& nd, const OpRef& R, int r, int row1,
 }
 
 // Board rows of the SPLINED models. There is no per-observation Gram for them
-// (the columns of a row depend on where the corner lands in the knot grid), and
-// one lane per row with global atomics for every pair of its ~26 entries is 108 M
-// atomics at 160k rows: 13 ms. But the rows of ONE observation only ever touch
-// a small set of camera-block variables: the core, the extrinsics, the warp and
-// the knots under the board, (order+1 + span)^2 of them. One workgroup per frame
-// therefore forms each observation's little dense Gram over that local set in
-// LDS (LDS atomics), plus the frame's rows of Bt, D_f, g_f, and flushes it:
-// ~6000 global atomics per observation instead of ~110 000. An observation whose
-// board covers more knots than the LDS budget goes the generic way, row by row.
-//   local index: 0..3 core | 4..9 extrinsics | 10..11 warp | 12.. knots of the bounding box, (iy, ix, xy)
-#define SPL_DENSE 12
-__global__ __launch_bounds__(256)
+// from the Jacobian kernel (the columns of a row depend on where the corner
+// lands in the knot grid), and one lane per row with global atomics for every
+// pair of its ~26 entries is 108 M atomics at 160k rows: 13 ms. But:
+//   - the rows of ONE observation only touch a small set of camera-block
+//     variables: the core, the extrinsics, the warp and the knots under the
+//     board, K = (order+1 + span)^2 of them per surface;
+//   - an x row touches the x surface only, a y row the y surface only
+//     (board_splined_kernel: column col0 + .. + xy), and all rows are equally long
+// One workgroup per frame, two passes per observation (x rows, y rows). A pass
+// writes its rows DENSELY over the local columns
+//     [ K knots | 4 core | 6 extrinsics | 2 warp | 6 frame | x ]
+// into LDS and the 256 threads form that matrix's Gram product in 8x8 register
+// tiles: no LDS atomics, and the one product yields the A, Bt, D_f, g and |x|^2
+// contributions at once. Nonzero tile entries are flushed with global atomics,
+// ~8000 per observation instead of ~135 000. An observation covering more than
+// SPL_TW-19 knots goes the generic way, row by row.
+#define SPL_TW      128         // local columns, 16 tiles of 8
+#define SPL_NDENSE  12
+#define SPL_NEXTRA  (SPL_NDENSE + 6 + 1)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int umax)
+                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int rows_cap)
 {
     if(opref_skip(R)) return;
-    extern __shared__ double lds_s[];                   // G[umax][umax] | BtL[6][umax] | gL[umax] | Df[36] | gf[6] | n2[1]
-    double* __restrict__ G   = lds_s;
-    double* __restrict__ BtL = G + (size_t)umax*umax;
-    double* __restrict__ gL  = BtL + 6*umax;
-    double* __restrict__ Df  = gL + umax;
-    double* __restrict__ gf  = Df + 36;
-    double* __restrict__ n2  = gf + 6;
+    extern __shared__ double lds_s[];                   // Jd[rows_cap][SPL_TW]
+    double* __restrict__ Jd = lds_s;
     __shared__ int bbox[4];
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
     const double* __restrict__ x  = O.x;
     const int f = blockIdx.x, t = threadIdx.x;
+    const int ty = t >> 4, tx = t & 15;
     const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
     const int NPTS = P.W*P.H, Nx = P.cfg.spline_Nx, order1 = P.cfg.spline_order + 1;
     const int Ncs = P.Ncore_state;
@@ -251,6 +255,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     {
         const BoardObsMeta m = P.board_meta[o];
         const int r0 = m.i_meas0, r1 = m.i_meas0 + 2*NPTS;
+        const int L  = Jp[r0+1] - Jp[r0];               // entries per row, the same for all rows of the observation
         // bounding box of the knots under this observation: from the first spline column of every x row
         if(t < 4) bbox[t] = (t & 1) ? -1 : 0x7fffffff;
         __syncthreads();
@@ -265,93 +270,122 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                 atomicMin(&bbox[2], iy); atomicMax(&bbox[3], iy + order1 - 1);
             }
         __syncthreads();
-        const int ix0 = bbox[0], iy0 = bbox[2];
-        const int wx = (P.Ndist_row > 0) ? bbox[1] - bbox[0] + 1 : 0, wy = (P.Ndist_row > 0) ? bbox[3] - bbox[2] + 1 : 0;
-        const int UN = SPL_DENSE + 2*wx*wy;
+        const bool any = (P.Ndist_row > 0) && bbox[1] >= 0;
+        const int ix0 = any ? bbox[0] : 0, iy0 = any ? bbox[2] : 0;
+        const int wx = any ? bbox[1] - bbox[0] + 1 : 0, wy = any ? bbox[3] - bbox[2] + 1 : 0;
+        const int K  = wx*wy;
         __syncthreads();            // bbox is reused by the next observation
-        if(UN > umax)
+        if(K + SPL_NEXTRA > SPL_TW)
         {
             for(int r = r0 + t; r < r1; r += blockDim.x) rows_generic_row(nd, R, r, r1, Jp, Ji);
             continue;
         }
-        for(int i = t; i < UN*UN; i += blockDim.x) G[i] = 0.0;
-        for(int i = t; i < 7*umax + 43; i += blockDim.x) BtL[i] = 0.0;      // BtL, gL, Df, gf, n2
-        __syncthreads();
+        const int NC = K + SPL_NEXTRA;                  // local columns in use
+        const bool tile_live = (8*ty < NC) && (8*tx < NC);
 
-        // state index -> local index (>= 0), or -(1 + frame variable) for this frame's columns
-        auto local_of = [&](int col) -> int
+        for(int xy = 0; xy < 2; xy++)
         {
-            if(P.do_optimize_frames && col >= nd.Nie && col < nd.Nie + nd.NE) return -(1 + (col - (nd.Nie + 6*f)));
-            if(m.i_state_intrinsics >= 0 && col >= m.i_state_intrinsics && col < m.i_state_intrinsics + P.Nintr_state)
+            // state index -> local column of this pass
+            auto local_of = [&](int col) -> int
             {
-                const int rel = col - m.i_state_intrinsics;
-                if(rel < Ncs) return rel;
-                const int knot = (rel - Ncs) >> 1, xy = (rel - Ncs) & 1;
-                return SPL_DENSE + 2*((knot / Nx - iy0)*wx + (knot % Nx - ix0)) + xy;
-            }
-            if(m.i_state_extrinsics >= 0 && col >= m.i_state_extrinsics && col < m.i_state_extrinsics + 6)
-                return 4 + (col - m.i_state_extrinsics);
-            return 10 + (col - P.i_state_warp);
-        };
-        for(int r = r0 + t; r < r1; r += blockDim.x)
-        {
-            const int p0 = Jp[r], p1 = Jp[r+1];
-            const double xr = x[r];
-            atomicAdd(n2, xr*xr);
-            for(int p = p0; p < p1; p++)
-            {
-                const double vp = Jv[p];
-                if(vp == 0.0) continue;
-                const int lp = local_of(Ji[p]);
-                if(lp >= 0) atomicAdd(&gL[lp], vp*xr); else atomicAdd(&gf[-lp-1], vp*xr);
-                for(int q = p0; q < p1; q++)
+                if(P.do_optimize_frames && col >= nd.Nie && col < nd.Nie + nd.NE) return K + SPL_NDENSE + (col - (nd.Nie + 6*f));
+                if(m.i_state_intrinsics >= 0 && col >= m.i_state_intrinsics && col < m.i_state_intrinsics + P.Nintr_state)
                 {
-                    const double v  = vp*Jv[q];
-                    if(v == 0.0) continue;
-                    const int lq = local_of(Ji[q]);
-                    if(lp >= 0 && lq >= 0)      atomicAdd(&G[lp*UN + lq], v);
-                    else if(lp < 0 && lq >= 0)  atomicAdd(&BtL[(-lp-1)*umax + lq], v);
-                    else if(lp < 0 && lq < 0)   atomicAdd(&Df[(-lp-1)*6 + (-lq-1)], v);
+                    const int rel = col - m.i_state_intrinsics;
+                    if(rel < Ncs) return K + rel;
+                    const int knot = (rel - Ncs) >> 1;
+                    return (knot / Nx - iy0)*wx + (knot % Nx - ix0);
+                }
+                if(m.i_state_extrinsics >= 0 && col >= m.i_state_extrinsics && col < m.i_state_extrinsics + 6)
+                    return K + 4 + (col - m.i_state_extrinsics);
+                return K + 10 + (col - P.i_state_warp);
+            };
+            double acc[8][8];
+#pragma unroll
+            for(int i = 0; i < 8; i++)
+#pragma unroll
+                for(int j = 0; j < 8; j++) acc[i][j] = 0.0;
+
+            for(int c0 = 0; c0 < NPTS; c0 += rows_cap)
+            {
+                const int nr = min(rows_cap, NPTS - c0);
+                for(int i = t; i < nr*(SPL_TW/2); i += blockDim.x) ((double2*)Jd)[i] = make_double2(0.0, 0.0);
+                __syncthreads();
+                const int pbase = Jp[r0] + (2*c0 + xy)*L;
+                for(int e = t; e < nr*L; e += blockDim.x)
+                {
+                    const int i = e / L, k = e - i*L;
+                    const int p = pbase + 2*i*L + k;
+                    const double v = Jv[p];
+                    if(v != 0.0) Jd[i*SPL_TW + local_of(Ji[p])] = v;
+                }
+                for(int i = t; i < nr; i += blockDim.x) Jd[i*SPL_TW + K + SPL_NDENSE + 6] = x[r0 + 2*(c0 + i) + xy];
+                __syncthreads();
+                if(tile_live)
+                    for(int i = 0; i < nr; i++)
+                    {
+                        const double2* __restrict__ ra = (const double2*)(Jd + i*SPL_TW + 8*ty);
+                        const double2* __restrict__ rb = (const double2*)(Jd + i*SPL_TW + 8*tx);
+                        double va[8], vb[8];
+#pragma unroll
+                        for(int u = 0; u < 4; u++)
+                        {
+                            const double2 a2 = ra[u], b2 = rb[u];
+                            va[2*u] = a2.x; va[2*u+1] = a2.y; vb[2*u] = b2.x; vb[2*u+1] = b2.y;
+                        }
+#pragma unroll
+                        for(int a = 0; a < 8; a++)
+#pragma unroll
+                            for(int b = 0; b < 8; b++) acc[a][b] += va[a]*vb[b];
+                    }
+                __syncthreads();
+            }
+
+            // flush. local column -> what it is
+            //   kind 0: camera-block variable, idx = state index;  1: frame variable 0..5;  2: x;  3: nothing
+            auto what = [&](int c, int* idx) -> int
+            {
+                if(c < K)
+                {
+                    *idx = m.i_state_intrinsics + Ncs + 2*((iy0 + c / wx)*Nx + ix0 + c % wx) + xy;
+                    return 0;
+                }
+                const int d = c - K;
+                if(d < 4)           { *idx = m.i_state_intrinsics + d;       return (Ncs && m.i_state_intrinsics >= 0) ? 0 : 3; }
+                if(d < 10)          { *idx = m.i_state_extrinsics + (d - 4); return (m.i_state_extrinsics >= 0) ? 0 : 3; }
+                if(d < SPL_NDENSE)  { *idx = P.i_state_warp + (d - 10);      return 0; }
+                if(d < SPL_NDENSE+6){ *idx = d - SPL_NDENSE;                 return 1; }
+                *idx = 0;
+                return (d == SPL_NDENSE+6) ? 2 : 3;
+            };
+            if(tile_live)
+            {
+                int kb[8], ib[8];
+#pragma unroll
+                for(int b = 0; b < 8; b++) kb[b] = what(8*tx + b, &ib[b]);
+#pragma unroll
+                for(int a = 0; a < 8; a++)
+                {
+                    int ia;
+                    const int ka = what(8*ty + a, &ia);
+                    if(ka == 3) continue;
+#pragma unroll
+                    for(int b = 0; b < 8; b++)
+                    {
+                        const double v = acc[a][b];
+                        if(v == 0.0) continue;
+                        if(ka == 0 && kb[b] == 0)
+                            atomicAdd(&O.A[(size_t)state_to_SE(nd, ia)*nd.Nc + state_to_SE(nd, ib[b])], v);
+                        else if(ka == 0 && kb[b] == 2) atomicAdd(&O.g[ia], v);
+                        else if(ka == 1 && kb[b] == 0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, ib[b])], v);
+                        else if(ka == 1 && kb[b] == 1) atomicAdd(&O.D[(size_t)f*36 + ia*6 + ib[b]], v);
+                        else if(ka == 1 && kb[b] == 2) atomicAdd(&O.g[nd.Nie + 6*f + ia], v);
+                        else if(ka == 2 && kb[b] == 2) atomicAdd(&O.scalars[SC_NORM2_X], v);
+                        // (the other combinations are the mirrors of these)
+                    }
                 }
             }
         }
-        __syncthreads();
-
-        // flush. local index -> S index
-        auto S_of = [&](int l) -> int
-        {
-            int col;
-            if(l < 4)               col = m.i_state_intrinsics + l;
-            else if(l < 10)         col = m.i_state_extrinsics + (l - 4);
-            else if(l < SPL_DENSE)  col = P.i_state_warp + (l - 10);
-            else
-            {
-                const int k = (l - SPL_DENSE) >> 1, xy = (l - SPL_DENSE) & 1;
-                col = m.i_state_intrinsics + Ncs + 2*((iy0 + k / wx)*Nx + ix0 + k % wx) + xy;
-            }
-            return state_to_SE(nd, col);
-        };
-        for(int i = t; i < UN*UN; i += blockDim.x)
-        {
-            const double v = G[i];
-            if(v != 0.0) atomicAdd(&O.A[(size_t)S_of(i / UN)*nd.Nc + S_of(i % UN)], v);
-        }
-        for(int i = t; i < UN; i += blockDim.x)
-        {
-            const double v = gL[i];
-            if(v != 0.0) atomicAdd(&O.g[(S_of(i) < nd.Nie) ? S_of(i) : nd.i_state_warp + (S_of(i) - nd.Nie)], v);
-        }
-        // this frame's own rows: no other workgroup touches them
-        for(int i = t; i < 6*UN; i += blockDim.x)
-        {
-            const int fi = i / UN, l = i - fi*UN;
-            const double v = BtL[fi*umax + l];
-            if(v != 0.0) O.Bt[(size_t)(6*f + fi)*nd.Nc + S_of(l)] += v;
-        }
-        if(t < 36)      O.D[(size_t)f*36 + t]        += Df[t];
-        else if(t < 42) O.g[nd.Nie + 6*f + (t-36)]   += gf[t-36];
-        else if(t == 42) atomicAdd(&O.scalars[SC_NORM2_X], n2[0]);
-        __syncthreads();
     }
 }
 
@@ -2041,10 +2075,10 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
         int rows_from = row0;
         if(by_rows && P.Nobs_board > 0 && P.Nframes > 0)
         {
-            const int umax = 96;
-            const size_t lds = ((size_t)umax*umax + 7*umax + 43)*sizeof(double);
+            const int rows_cap = std::min(P.W*P.H, 64);          // 64 KB of LDS: two workgroups per CU
+            const size_t lds = (size_t)rows_cap*SPL_TW*sizeof(double);
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), lds, stream,
-                               P, nd, B.R, plan, B.Jp, B.Ji, umax);
+                               P, nd, B.R, plan, B.Jp, B.Ji, rows_cap);
             rows_from = 2*P.W*P.H*P.Nobs_board;
         }
         if(P.Nmeas > rows_from)
