@@ -1192,18 +1192,25 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
     return u.d;
 }
-// ONE wave, the 64x64 block in registers: lane i holds matrix row i. No
-// barriers: the pivot and the multipliers L[c][j] are lane c's register j, read
-// with v_readlane into scalar registers. Then X = L^-1 the same way round: lane
-// c holds column c of X; the L[i][k] it needs are wave-uniform LDS reads.
-// (A 256-thread version with a workgroup barrier per column took 160 us per
-// panel; this takes ~25)
+// The 64x64 diagonal block of a panel: L11 L11^T = M11 and X = L11^-1, by ONE
+// wave with no workgroup barriers in the column loops. Lane i owns matrix row i
+// (factorization), then lane c owns column c of X (inversion).
+// Blocked by 16 with DYNAMIC outer loops: a panel of 16 columns sits in
+// registers, the pivot and the multipliers L[c][j] are other lanes' registers
+// (v_readlane, scalar lane index), and the columns to the right are updated in
+// LDS with broadcast reads of the finished panel.
+// (Measured alternatives: 256 threads with a barrier per column, 160 us per
+// panel; the whole 64-column row in registers, fully unrolled, 65 us - 126 KB of
+// straight-line code executed once is instruction-fetch bound. This: ~25 us)
+#define LCH_PB 16
 __global__ __launch_bounds__(64)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
                        double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status)
 {
     if(skip != NULL && *skip) return;
-    __shared__ double L[LCH_NB][LCH_NB+1];
+    __shared__ double L[LCH_NB][LCH_NB+1];              // L[i][j]: lane i walks its row conflict-free
+    __shared__ __attribute__((aligned(16))) double Lt[LCH_NB][LCH_NB+2];    // Lt[j][i] = L[i][j]: 16 rows of a column in one sweep
+    __shared__ double X[LCH_NB][LCH_NB];                // X[i][c]
     const int lane = threadIdx.x;
     const int nb = min(LCH_NB, n - j0);
     // coalesced load into LDS; the block is padded with the identity
@@ -1213,51 +1220,91 @@ void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__
         L[i][j] = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
     }
     __syncthreads();
-    double row[LCH_NB];
-    static_for<0,LCH_NB>([&](auto J) { constexpr int j = decltype(J)::value; row[j] = L[lane][j]; });
+
     bool bad = false;
-    double my_rdiag = 1.0;                  // 1/L[lane][lane]
-    static_for<0,LCH_NB>([&](auto J)
+    double my_rdiag = 1.0;                              // 1/L[lane][lane]
+#pragma unroll 1
+    for(int base = 0; base < LCH_NB; base += LCH_PB)
     {
-        constexpr int j = decltype(J)::value;
-        double piv = readlane_f64(row[j], j);
-        bad = bad || !(piv > 0.0);
-        piv = (piv > 0.0) ? piv : 1.0;
-        double rd = __builtin_amdgcn_rsq(piv);
-        rd = rd*(1.5 - 0.5*piv*rd*rd);
-        rd = rd*(1.5 - 0.5*piv*rd*rd);
-        row[j] *= rd;                       // lane j: sqrt(piv); lanes below: L[i][j]
-        my_rdiag = (lane == j) ? rd : my_rdiag;     // (a select, not a branch: with control flow here the
-                                                    //  compiler sinks the updates below across the blocks)
-        // the multipliers L[c][j] = lane c's row[j], broadcast through SGPRs.
-        // Scheduling fences every 8 columns: left alone the scheduler hoists
-        // hundreds of readlanes and spills thousands of SGPRs
-        static_for<j+1,LCH_NB>([&](auto Cc)
+        double pr[LCH_PB];                              // this lane's row, columns base..base+15
+#pragma unroll
+        for(int jj = 0; jj < LCH_PB; jj++) pr[jj] = L[lane][base + jj];
+        static_for<0,LCH_PB>([&](auto J)
         {
-            constexpr int c = decltype(Cc)::value;
-            row[c] -= row[j]*readlane_f64(row[j], c);
-            if constexpr ((c & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            constexpr int jj = decltype(J)::value;
+            double piv = readlane_f64(pr[jj], base + jj);
+            bad = bad || !(piv > 0.0);
+            piv = (piv > 0.0) ? piv : 1.0;
+            double rd = __builtin_amdgcn_rsq(piv);
+            rd = rd*(1.5 - 0.5*piv*rd*rd);
+            rd = rd*(1.5 - 0.5*piv*rd*rd);
+            pr[jj] *= rd;                               // lane base+jj: sqrt(piv); lanes below: L[i][j]
+            my_rdiag = (lane == base + jj) ? rd : my_rdiag;     // (a select, not a branch)
+            static_for<jj+1,LCH_PB>([&](auto Cc)
+            {
+                constexpr int cc = decltype(Cc)::value;
+                pr[cc] -= pr[jj]*readlane_f64(pr[jj], base + cc);
+            });
         });
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    __syncthreads();
-    static_for<0,LCH_NB>([&](auto J) { constexpr int j = decltype(J)::value; L[lane][j] = (j <= lane) ? row[j] : 0.0; });
-    __syncthreads();
-    // X = L^-1, lane c = column c:  X[i] = (delta_ic - sum_{k<i} L[i][k] X[k]) / L[i][i]
-    static_for<0,LCH_NB>([&](auto I)
+        // the finished panel, zero above the diagonal
+#pragma unroll
+        for(int jj = 0; jj < LCH_PB; jj++)
+        {
+            const double v = (base + jj <= lane) ? pr[jj] : 0.0;
+            pr[jj] = v;
+            L[lane][base + jj]  = v;
+            Lt[base + jj][lane] = v;
+        }
+        __syncthreads();
+        // columns to the right: L[i][c] -= sum_jj L[i][base+jj] L[c][base+jj]
+#pragma unroll 2
+        for(int c = base + LCH_PB; c < LCH_NB; c++)
+        {
+            double acc = L[lane][c];
+#pragma unroll
+            for(int jj = 0; jj < LCH_PB; jj++) acc -= pr[jj]*L[c][base + jj];      // (uniform address: a broadcast)
+            L[lane][c] = acc;
+        }
+        __syncthreads();
+    }
+
+    // X = L^-1, lane c = column c, 16 rows at a time:
+    //   X[i] = (delta_ic - sum_{k<i} L[i][k] X[k]) / L[i][i]
+#pragma unroll 1
+    for(int base = 0; base < LCH_NB; base += LCH_PB)
     {
-        constexpr int i = decltype(I)::value;
-        double v = (lane == i) ? 1.0 : 0.0;
-        static_for<0,i>([&](auto K)
+        double v[LCH_PB];
+#pragma unroll
+        for(int r = 0; r < LCH_PB; r++) v[r] = (lane == base + r) ? 1.0 : 0.0;
+        // the finished rows above
+#pragma unroll 2
+        for(int k = 0; k < base; k++)
         {
-            constexpr int k = decltype(K)::value;
-            v -= L[i][k]*row[k];
-            if constexpr ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);    // (as above)
+            const double xk = X[k][lane];
+            const double2* __restrict__ lt = (const double2*)&Lt[k][base];      // L[base+r][k], r = 0..15
+#pragma unroll
+            for(int r2 = 0; r2 < LCH_PB/2; r2++)
+            {
+                const double2 l2 = lt[r2];
+                v[2*r2]   -= l2.x*xk;
+                v[2*r2+1] -= l2.y*xk;
+            }
+        }
+        static_for<0,LCH_PB>([&](auto Rr)
+        {
+            constexpr int r = decltype(Rr)::value;
+            double a = v[r];
+            static_for<0,r>([&](auto Kk) { constexpr int k = decltype(Kk)::value; a -= L[base + r][base + k]*v[k]; });
+            v[r] = a*readlane_f64(my_rdiag, base + r);
         });
-        row[i] = v*readlane_f64(my_rdiag, i);       // (row[] now holds X's column)
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    static_for<0,LCH_NB>([&](auto I) { constexpr int i = decltype(I)::value; Linv[i*LCH_NB + lane] = row[i]; });
+#pragma unroll
+        for(int r = 0; r < LCH_PB; r++)
+        {
+            X[base + r][lane] = v[r];
+            Linv[(base + r)*LCH_NB + lane] = v[r];
+        }
+        __syncthreads();
+    }
     for(int idx = lane; idx < LCH_NB*LCH_NB; idx += 64)
     {
         const int i = idx / LCH_NB, j = idx - i*LCH_NB;
@@ -1286,14 +1333,32 @@ void lchol_trsm_kernel(int n, const int* __restrict__ skip, double* __restrict__
         A[i][j] = (r0 + i <= n && j < nb) ? M[(size_t)(r0+i)*n + j0 + j] : 0.0;
     }
     __syncthreads();
-    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
+    // out = A X^T (X is lower triangular, zero above the diagonal: no special
+    // casing). Wave w: rows 16w.., the four 16-column tiles, k in steps of 4
+    const int wave = t >> 6, lane = t & 63;
+    const int r16 = lane & 15, kq = lane >> 4;
+    syrk_d4 acc[4];
+#pragma unroll
+    for(int c = 0; c < 4; c++) acc[c] = syrk_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
     {
-        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
-        if(r0 + i > n || j >= nb) continue;
-        double acc = 0.0;
-        for(int k = 0; k <= j; k++) acc += A[i][k]*X[j][k];
-        M[(size_t)(r0+i)*n + j0 + j] = acc;
+        // A operand: lane (i = l%16, k = l/16); B operand B[k][j] = X[j][k]: lane (j = l%16, k = l/16)
+        const double av = A[16*wave + r16][k0 + kq];
+#pragma unroll
+        for(int c = 0; c < 4; c++)
+            if(k0 < 16*(c+1))           // X[j][k] = 0 for k > j: tile c has nothing beyond k = 16c+15
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[16*c + r16][k0 + kq], acc[c], 0, 0, 0);
     }
+    // D register v of lane l = D[l/16 + 4 v][l%16]
+#pragma unroll
+    for(int c = 0; c < 4; c++)
+#pragma unroll
+        for(int v = 0; v < 4; v++)
+        {
+            const int i = 16*wave + kq + 4*v, j = 16*c + r16;
+            if(r0 + i <= n && j < nb) M[(size_t)(r0+i)*n + j0 + j] = acc[c][v];
+        }
 }
 
 // trailing update, 32 x 32 tiles (ti >= tj) of the rows/columns from m0 on:

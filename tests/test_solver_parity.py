@@ -70,6 +70,30 @@ def test_normal_equations_lens_models(amd, lensmodel, frames_opt):
         assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
+@pytest.mark.parametrize("grid", ("order=3_Nx=11_Ny=8", "order=2_Nx=16_Ny=12", "order=3_Nx=40_Ny=30"))
+@pytest.mark.parametrize("frames_opt,core_opt", ((True, True), (True, False), (False, True)))
+def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
+    """the splined assembly (solver_kernels.hip assemble_splined_kernel): coarse
+    grids, where every observation's knot set fits the local tile, and a fine one
+    where the near boards overflow it and go row by row"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6,
+                                     lensmodel=f"LENSMODEL_SPLINED_STEREOGRAPHIC_{grid}_fov_x_deg=120",
+                                     object_width_n=10, object_height_n=10, seed=29)
+    oi["do_optimize_frames"] = frames_opt
+    oi["do_optimize_intrinsics_core"] = core_opt
+    oi["observations_board"][3,2:4,1:5,2] = -1.   # some input outliers
+    with Problem(**oi) as p:
+        ne = p.normal_equations()
+        J, x = p.J(), p.x()
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    scale = np.abs(N).max()
+    assert np.abs(N_gpu - N).max() < 1e-10*scale
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+
+
 @pytest.mark.parametrize("case", ("boards", "boards+points", "no-extrinsics-opt", "monocular"))
 def test_normal_equations_match_JtJ(amd, case):
     from mrcal_amd.resident import Problem
