@@ -118,16 +118,27 @@ def test_normal_equations_match_JtJ(amd, case):
     assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
-def test_gauss_newton_step_matches_dense_solve(amd):
+# camera blocks of 30 (one LDS-resident Cholesky), 212 (past the LDS kernel: the
+# panel-by-panel Cholesky in HBM, three full 64-column panels and a partial one)
+# and 780 variables (splined: 13 panels)
+@pytest.mark.parametrize("lensmodel,Ncam,Nf,W,H", (("LENSMODEL_OPENCV4", 2, 8, 8, 7),
+                                                   ("LENSMODEL_OPENCV8", 12, 6, 10, 10),
+                                                   ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", 2, 40, 10, 10)))
+def test_gauss_newton_step_matches_dense_solve(amd, lensmodel, Ncam, Nf, W, H):
     from mrcal_amd.resident import Problem
-    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=8, lensmodel="LENSMODEL_OPENCV4",
-                                     object_width_n=8, object_height_n=7, seed=4)
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
+                                     object_width_n=W, object_height_n=H, seed=4)
     with Problem(**oi) as p:
         d = p.gauss_newton_step()
         J, x = p.J(), p.x()
     N, g = dense_normal(J, x)
     d_ref = -np.linalg.solve(N, g)
-    assert relative_error(d, d_ref, eps=1e-9*np.abs(d_ref).max()).max() < 1e-6
+    # what the solve can deliver is set by the conditioning of JtJ: compare through
+    # the residual of the normal equations as well as entry by entry
+    assert np.abs(N @ d + g).max() < 1e-7*max(np.abs(g).max(), 1.0)
+    # entry by entry: 1e-6, or what the conditioning leaves of a double-precision solve (either one's)
+    tol = max(1e-6, 10.*np.linalg.cond(N)*np.finfo(float).eps)
+    assert relative_error(d, d_ref, eps=1e-9*np.abs(d_ref).max()).max() < tol
 
 
 def _solve_both(amd, ref_api, oi):
