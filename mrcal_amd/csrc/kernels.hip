@@ -527,7 +527,44 @@ void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const i
 #define TSACC(i, t0)
 #endif
 
-template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM>
+// The copy-out invariants of a lane (copy_out_full) when every variable group
+// is optimized: k and the CSR -> tile column map are compile-time constants
+// (divisions by constants, selects on constants)
+template<int K, int NDIST, int KS, bool HAS_EXT>
+__device__ __forceinline__
+void copy_out_invariants(int lane, int& A0, int& A1, int& B0, int& B1, unsigned& gofs, int& rsub)
+{
+    constexpr int PPR = K/2, RPI = 64/PPR, NACT = RPI*PPR;
+    constexpr int b1 = 2, b2 = 2 + NDIST, b3 = b2 + (HAS_EXT ? 6 : 0), b4 = b3 + 6;
+    const int cl = (lane < NACT) ? lane : lane - NACT;
+    rsub = cl / PPR;
+    const int c0 = 2*(cl - rsub*PPR);
+    auto tcol = [&](int c, int xy) -> int
+    {
+        int col = tile_warp0(NDIST) + (c - b4);
+        col = (c < b4) ? tile_frame0(NDIST) + (c - b3) : col;
+        col = (c < b3) ? tile_ext0(NDIST)   + (c - b2) : col;
+        col = (c < b2) ? 4 + (c - b1)                  : col;
+        col = (c < b1) ? 2*c + xy                      : col;
+        return col;
+    };
+    const int y0 = rsub & 1, y1 = (rsub + RPI) & 1;
+    A0 = (rsub*KS       + tcol(c0,   y0))*(int)sizeof(double);
+    A1 = (rsub*KS       + tcol(c0+1, y0))*(int)sizeof(double);
+    B0 = ((rsub+RPI)*KS + tcol(c0,   y1))*(int)sizeof(double);
+    B1 = ((rsub+RPI)*KS + tcol(c0+1, y1))*(int)sizeof(double);
+    gofs = (unsigned)(rsub*K + c0);
+}
+
+// ALLOPT: the caller vouches that the core, the distortions, the extrinsics,
+// the frames and the warp are all being optimized. The variable groups are then
+// not tested at run time: with the tests, the compiler zero-initializes every
+// group's columns in front of its branch (170 register moves per pass, a
+// quarter of the pass's vector instructions). The reference camera's
+// extrinsics columns (absent from its rows) are computed regardless in this
+// variant: they are never copied out, and the Gram entries they produce sit at
+// positions that the assembly has no destination for
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void board_kernel(DeviceProblem P,
                   OpRef R,
@@ -637,10 +674,17 @@ void board_kernel(DeviceProblem P,
     // the fast path's invariants (copy_out_full): LDS byte offsets for the rows
     // co_rsub and co_rsub + rows_per_iter, element offset in the output
     constexpr int KFULL = 2 + NDIST + 14;       // core, distortions, extrinsics, frame, warp: everything optimized
-    const bool co_fast  = WITH_J && !(KFULL & 1) && (k == KFULL || k == KFULL - 6);
+    static_assert(!ALLOPT || (WITH_J && WITH_GRAM && !(KFULL & 1)), "ALLOPT: the fused Gram + copy-out path only");
+    const bool co_fast  = ALLOPT || (WITH_J && !(KFULL & 1) && (k == KFULL || k == KFULL - 6));
     int co_A0 = 0, co_A1 = 0, co_B0 = 0, co_B1 = 0;
     unsigned co_gofs = 0;
-    if(co_fast)
+    int co_rsub_c = 0;
+    if(ALLOPT)
+    {
+        if(has_ext) copy_out_invariants<KFULL,   NDIST, KS, true >(lane, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub_c);
+        else        copy_out_invariants<KFULL-6, NDIST, KS, false>(lane, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub_c);
+    }
+    else if(co_fast)
     {
         int co_tx0, co_tx1, co_ty0, co_ty1;
         co_tile_cols(&co_tx0, &co_tx1, &co_ty0, &co_ty1);
@@ -683,14 +727,18 @@ void board_kernel(DeviceProblem P,
 #pragma unroll
             for(int c=0;c<NCOLS4;c++) row[xy][c] = 0.0;
 
-        if(valid)
+        // The lanes past the last corner repeat the last corner's arithmetic
+        // (and write nothing) rather than branching around it: ONE conditional
+        // region below - the rows of a live inlier - means one zero
+        // initialization of the row registers, not one per nesting level
         {
-            const int iy = pt / P.W;
-            const int ix = pt - iy*P.W;
+            const int ptc = valid ? pt : NPTS - 1;
+            const int iy = ptc / P.W;
+            const int ix = ptc - iy*P.W;
             const double bx = (double)ix * P.spacing;
             const double by = (double)iy * P.spacing;
             double bz = 0.0, dz_dw0 = 0.0, dz_dw1 = 0.0;
-            if(P.has_warp_seed)
+            if(ALLOPT || P.has_warp_seed)
             {
                 // parabolic flex along each board axis, max deflection at the centre
                 const double xr = (double)ix / (double)(P.W - 1);
@@ -718,28 +766,28 @@ void board_kernel(DeviceProblem P,
             else
             project_lens<PROJ,NDIST,WITH_J>(q, dq_dp, dq_dk, p, intr, P.cfg);
 
-            const double qx_obs = obs_lds[3*pt + 0];
-            const double qy_obs = obs_lds[3*pt + 1];
-            const double w      = obs_lds[3*pt + 2];
-            const bool   inlier = (w >= 0.0);
+            const double qx_obs = obs_lds[3*ptc + 0];
+            const double qy_obs = obs_lds[3*ptc + 1];
+            const double w      = obs_lds[3*ptc + 2];
+            const bool   inlier = valid && (w >= 0.0);
 
             double2 err;
             err.x = inlier ? (q[0] - qx_obs)*w : 0.0;
             err.y = inlier ? (q[1] - qy_obs)*w : 0.0;
-            { d2_t e2; e2.x = err.x; e2.y = err.y; *reinterpret_cast<gdouble2*>(&x[m.i_meas0 + 2*pt]) = e2; }
+            if(valid) { d2_t e2; e2.x = err.x; e2.y = err.y; *reinterpret_cast<gdouble2*>(&x[m.i_meas0 + 2*pt]) = e2; }
 
             // outliers keep their columns and get all-zero values: everything
             // below is skipped for them and the rows stay 0
             if(WITH_J && inlier)
             {
-                if(P.Ncore_state)
+                if(ALLOPT || P.Ncore_state)
                 {
                     row[0][0] = (q[0] - intr[2])/intr[0] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
                     row[0][2] = w * SCALE_INTRINSICS_CENTER_PIXEL;
                     row[1][1] = (q[1] - intr[3])/intr[1] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
                     row[1][3] = w * SCALE_INTRINSICS_CENTER_PIXEL;
                 }
-                if(NDIST > 0 && P.Ndist_state)
+                if(NDIST > 0 && (ALLOPT || P.Ndist_state))
                 {
 #pragma unroll
                     for(int xy=0;xy<2;xy++)
@@ -747,7 +795,7 @@ void board_kernel(DeviceProblem P,
                         for(int i=0;i<NDIST;i++)
                             row[xy][4+i] = dq_dk[xy][i] * w * SCALE_DISTORTION;
                 }
-                if(has_ext)
+                if(ALLOPT || has_ext)
                 {
                     // dp/drc = X Mc0 + Y Mc1 + Z Mc2 + dtj/drc ; dp/dtc = I
 #pragma unroll
@@ -770,7 +818,7 @@ void board_kernel(DeviceProblem P,
                         }
                     }
                 }
-                if(P.do_optimize_frames)
+                if(ALLOPT || P.do_optimize_frames)
                 {
 #pragma unroll
                     for(int l=0;l<3;l++)
@@ -795,7 +843,7 @@ void board_kernel(DeviceProblem P,
                         }
                     }
                 }
-                if(P.has_warp_state)
+                if(ALLOPT || P.has_warp_state)
                 {
                     // dq/dwarp_i = (dq/dt . Rj[:,2]) dz/dwarp_i
 #pragma unroll
@@ -844,18 +892,20 @@ void board_kernel(DeviceProblem P,
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
             gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
-            if(WITH_GRAM && co_fast && !(P.debug_ablate & 3))
+            if(ALLOPT || (WITH_GRAM && co_fast && !(P.debug_ablate & 3)))
             {
                 // all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
+                const int  rs    = ALLOPT ? co_rsub_c : co_rsub;
+                const bool kfull = ALLOPT ? has_ext : (k == KFULL);
                 if(nrows == 64)
                 {
-                    if(k == KFULL) gram_copy_fused<true,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, 64);
-                    else           gram_copy_fused<true,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, 64);
+                    if(kfull) gram_copy_fused<true,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
+                    else      gram_copy_fused<true,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
                 }
                 else
                 {
-                    if(k == KFULL) gram_copy_fused<false,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, nrows);
-                    else           gram_copy_fused<false,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, co_rsub, nrows);
+                    if(kfull) gram_copy_fused<false,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
+                    else      gram_copy_fused<false,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
                 }
                 TSACC(5, tcur);
                 continue;
@@ -1795,7 +1845,17 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
         if(ev_j0) hipEventRecord(ev_j0, stream);
-        if(with_jacobian && B.gram != NULL)
+        // (the ablation probes keep the general kernel)
+        constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
+        const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
+                            P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !P.debug_ablate;
+        if(with_jacobian && B.gram != NULL && allopt)
+        {
+            if constexpr (kfull_even)
+                hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                                   P, B.R, B.joint, B.gram);
+        }
+        else if(with_jacobian && B.gram != NULL)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
                                P, B.R, B.joint, B.gram);
         else if(with_jacobian)
