@@ -41,22 +41,31 @@ struct LensConfig
 ////////////////////////////////////////////////////////////////////////////////
 // OpenCV rational + tangential + thin-prism family
 ////////////////////////////////////////////////////////////////////////////////
-// One image row (xy = 0: qx, 1: qy) of the projection. The x and y rows are
-// the same expression with (X,Y), (k2,k3), (k8,k9 | k10,k11), (fx,fy) swapped,
-// so a lane that owns one Jacobian row evaluates only that row. The k[] slots
-// beyond NDIST are compile-time zeros and fold away
-// NOTE on the coding style here: everything that gets selected by the row
-// parity is a named scalar, never an element of a local array. A select
-// between two array elements ("isy ? k[2] : k[3]") is turned by the compiler
-// into a load from a selected ADDRESS if it gets to it before the array has
-// been promoted to registers (which happens whenever the array was filled in a
-// loop that is unrolled late); the array then lives in scratch memory, and
-// every access to it waits for vmcnt(0), i.e. for all the outstanding stores of
-// the Jacobian. Measured: +20 us on the 8x1000 benchmark.
+// Both image rows at once, for a lane that owns a corner (the board and point
+// kernels). Same model, but the gradients go through the four partials of the
+// distorted coordinates with respect to (X,Y) = (x/z, y/z) instead of three
+// general directional derivatives per row:
+//   ud_x = X g + k2 a1 + k3 a2 + k8 r2 + k9 r4       g = num/den,  a1 = 2XY,
+//   ud_y = Y g + k3 a1 + k2 a3 + k10 r2 + k11 r4     a2 = r2 + 2X^2,  a3 = r2 + 2Y^2
+//   d ud_x/dX = g + 2X (X g' + 3 k3 + k8 + 2 k9 r2) + 2 k2 Y      g' = dg/dr2 = (num' - g den')/den
+//   d ud_x/dY =     2Y (X g' +   k3 + k8 + 2 k9 r2) + 2 k2 X
+//   d ud_y/dX =     2X (Y g' +   k2 + k10 + 2 k11 r2) + 2 k3 Y
+//   d ud_y/dY = g + 2Y (Y g' + 3 k2 + k10 + 2 k11 r2) + 2 k3 X
+//   dq/dp = f (d ud/dX, d ud/dY, -(X d ud/dX + Y d ud/dY)) / z
+// About half the arithmetic of evaluating the rows one by one with directional
+// derivatives (180 -> 103 FP64 instructions at OPENCV8), in a kernel that is
+// bound by FP64 issue.
+// The k[] slots beyond NDIST are compile-time zeros and fold away.
+// NOTE on the coding style: everything is a named scalar, never an element of a
+// local array picked by a run-time index. A select between two array elements
+// is turned by the compiler into a load from a selected ADDRESS if it gets to
+// it before the array has been promoted to registers; the array then lives in
+// scratch memory, and every access to it waits for vmcnt(0), i.e. for all the
+// outstanding stores of the Jacobian (measured once: +20 us at the benchmark)
 template<int NDIST, bool WITH_GRAD>
 MRCAL_AMD_HD
-void project_opencv_row(int xy, double* q, double* dq_dp /*[3]*/, double* dq_dk /*[NDIST]*/,
-                        const double* p, const double* intr)
+void project_opencv_both(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDIST : 1],
+                         const double* p, const double* intr)
 {
     const double k0  = (NDIST > 0 ) ? intr[4 + 0 ] : 0.0;
     const double k1  = (NDIST > 1 ) ? intr[4 + 1 ] : 0.0;
@@ -72,68 +81,64 @@ void project_opencv_row(int xy, double* q, double* dq_dp /*[3]*/, double* dq_dk 
     const double k11 = (NDIST > 11) ? intr[4 + 11] : 0.0;
     const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
 
-    const bool isy = (xy != 0);
-    const double f  = isy ? fy : fx;
-    const double c  = isy ? cy : cx;
-    const double kt_own   = isy ? k2  : k3;   // multiplies aU
-    const double kt_cross = isy ? k3  : k2;   // multiplies a1
-    const double kp2      = isy ? k10 : k8;
-    const double kp4      = isy ? k11 : k9;
-
     const double iz = 1.0/p[2];
     const double X  = p[0]*iz;
     const double Y  = p[1]*iz;
     const double r2 = X*X + Y*Y;
     const double r4 = r2*r2;
     const double r6 = r4*r2;
-    const double U  = isy ? Y : X;           // this row's own coordinate
     const double a1 = 2.0*X*Y;
-    const double aU = r2 + 2.0*U*U;          // a2 for the x row, a3 for the y row
+    const double a2 = r2 + 2.0*X*X;
+    const double a3 = r2 + 2.0*Y*Y;
     const double num  = 1.0 + k0*r2 + k1*r4 + k4*r6;
-    const double iden = 1.0/(1.0 + k5*r2 + k6*r4 + k7*r6);
-    const double ud = U*num*iden + kt_cross*a1 + kt_own*aU + kp2*r2 + kp4*r4;
-    *q = ud*f + c;
+    const double iden = (NDIST > 5) ? 1.0/(1.0 + k5*r2 + k6*r4 + k7*r6) : 1.0;
+    const double g    = num*iden;
+    q[0] = (X*g + k2*a1 + k3*a2 + k8 *r2 + k9 *r4)*fx + cx;
+    q[1] = (Y*g + k3*a1 + k2*a3 + k10*r2 + k11*r4)*fy + cy;
 
     if(!WITH_GRAD) return;
 
-    // d/dp_j, given dX/dp_j and dY/dp_j
-    auto grad = [&](double dXj, double dYj) -> double
-    {
-        const double dU    = isy ? dYj : dXj;
-        const double dr2   = 2.0*X*dXj + 2.0*Y*dYj;
-        const double dnum  = k0*dr2 + 2.0*k1*r2*dr2 + 3.0*k4*r4*dr2;
-        const double diden = -iden*iden*(k5*dr2 + 2.0*k6*r2*dr2 + 3.0*k7*r4*dr2);
-        const double da1   = 2.0*(X*dYj + Y*dXj);
-        const double dud   = dU*num*iden + U*dnum*iden + U*num*diden +
-            kt_cross*da1 + kt_own*(dr2 + 4.0*U*dU) + kp2*dr2 + 2.0*r2*kp4*dr2;
-        return f*dud;
-    };
-    dq_dp[0] = grad(iz,    0.0);
-    dq_dp[1] = grad(0.0,   iz);
-    dq_dp[2] = grad(-X*iz, -Y*iz);
+    const double dnum = k0 + 2.0*k1*r2 + 3.0*k4*r4;     // d/dr2
+    const double dden = k5 + 2.0*k6*r2 + 3.0*k7*r4;
+    const double dg   = (dnum - g*dden)*iden;
+    const double Xdg  = X*dg, Ydg = Y*dg;
+    const double ex   = k8  + 2.0*k9 *r2;
+    const double ey   = k10 + 2.0*k11*r2;
+    const double X2 = 2.0*X, Y2 = 2.0*Y;
+    const double dxX = g + X2*(Xdg + 3.0*k3 + ex) + k2*Y2;
+    const double dxY =     Y2*(Xdg +     k3 + ex) + k2*X2;
+    const double dyX =     X2*(Ydg +     k2 + ey) + k3*Y2;
+    const double dyY = g + Y2*(Ydg + 3.0*k2 + ey) + k3*X2;
+    const double fxz = fx*iz, fyz = fy*iz;
+    dq_dp[0][0] = fxz*dxX;
+    dq_dp[0][1] = fxz*dxY;
+    dq_dp[0][2] = -(X*dq_dp[0][0] + Y*dq_dp[0][1]);
+    dq_dp[1][0] = fyz*dyX;
+    dq_dp[1][1] = fyz*dyY;
+    dq_dp[1][2] = -(X*dq_dp[1][0] + Y*dq_dp[1][1]);
 
-    if(NDIST >= 4)
+    if constexpr (NDIST >= 4)
     {
-        dq_dk[0] = f*U*iden*r2;
-        dq_dk[1] = f*U*iden*r4;
-        dq_dk[2] = f*(isy ? aU : a1);
-        dq_dk[3] = f*(isy ? a1 : aU);
-    }
-    if(NDIST >= 5)
-        dq_dk[4] = f*U*iden*r6;
-    if(NDIST >= 8)
-    {
-        const double t = num*(-iden)*iden;
-        dq_dk[5] = f*U*t*r2;
-        dq_dk[6] = f*U*t*r4;
-        dq_dk[7] = f*U*t*r6;
-    }
-    if(NDIST >= 12)
-    {
-        dq_dk[8]  = isy ? 0.0 : f*r2;
-        dq_dk[9]  = isy ? 0.0 : f*r4;
-        dq_dk[10] = isy ? f*r2 : 0.0;
-        dq_dk[11] = isy ? f*r4 : 0.0;
+        const double ux = fx*X*iden, uy = fy*Y*iden;
+        dq_dk[0][0] = ux*r2;   dq_dk[1][0] = uy*r2;
+        dq_dk[0][1] = ux*r4;   dq_dk[1][1] = uy*r4;
+        dq_dk[0][2] = fx*a1;   dq_dk[1][2] = fy*a3;
+        dq_dk[0][3] = fx*a2;   dq_dk[1][3] = fy*a1;
+        if constexpr (NDIST >= 5) { dq_dk[0][4] = ux*r6;   dq_dk[1][4] = uy*r6; }
+        if constexpr (NDIST >= 8)
+        {
+            const double tx = -ux*g, ty = -uy*g;        // f U num (-iden) iden
+            dq_dk[0][5] = tx*r2;   dq_dk[1][5] = ty*r2;
+            dq_dk[0][6] = tx*r4;   dq_dk[1][6] = ty*r4;
+            dq_dk[0][7] = tx*r6;   dq_dk[1][7] = ty*r6;
+        }
+        if constexpr (NDIST >= 12)
+        {
+            dq_dk[0][8]  = fx*r2;  dq_dk[1][8]  = 0.0;
+            dq_dk[0][9]  = fx*r4;  dq_dk[1][9]  = 0.0;
+            dq_dk[0][10] = 0.0;    dq_dk[1][10] = fy*r2;
+            dq_dk[0][11] = 0.0;    dq_dk[1][11] = fy*r4;
+        }
     }
 }
 
@@ -401,10 +406,7 @@ bool project_lens(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDI
                   const double* p, const double* intr, const LensConfig& cfg)
 {
     if(PROJ == PROJ_OPENCV)
-    {
-        project_opencv_row<NDIST,WITH_GRAD>(0, &q[0], WITH_GRAD ? dq_dp[0] : NULL, WITH_GRAD ? dq_dk[0] : NULL, p, intr);
-        project_opencv_row<NDIST,WITH_GRAD>(1, &q[1], WITH_GRAD ? dq_dp[1] : NULL, WITH_GRAD ? dq_dk[1] : NULL, p, intr);
-    }
+        project_opencv_both<NDIST,WITH_GRAD>(q, dq_dp, dq_dk, p, intr);
     else if(PROJ == PROJ_STEREOGRAPHIC) project_stereographic<WITH_GRAD>(q, dq_dp, p, intr);
     else if(PROJ == PROJ_LONLAT)        project_lonlat<WITH_GRAD>(q, dq_dp, p, intr);
     else if(PROJ == PROJ_LATLON)        project_latlon<WITH_GRAD>(q, dq_dp, p, intr);
@@ -425,30 +427,6 @@ bool project_lens(double* q, double (*dq_dp)[3], double (*dq_dk)[NDIST > 0 ? NDI
         }
     }
     return true;
-}
-
-// One image row. OPENCV has a real single-row evaluation; the others compute
-// both rows and keep one
-template<int PROJ, int NDIST, bool WITH_GRAD>
-MRCAL_AMD_HD
-bool project_lens_row(int xy, double* q, double* dq_dp /*[3]*/, double* dq_dk /*[NDIST]*/,
-                      const double* p, const double* intr, const LensConfig& cfg)
-{
-    if(PROJ == PROJ_OPENCV)
-    {
-        project_opencv_row<NDIST,WITH_GRAD>(xy, q, dq_dp, dq_dk, p, intr);
-        return true;
-    }
-    double q2[2], g[2][3], gk[2][NDIST > 0 ? NDIST : 1];
-    const bool ok = project_lens<PROJ,NDIST,WITH_GRAD>(q2, g, gk, p, intr, cfg);
-    const bool isy = (xy != 0);
-    *q = isy ? q2[1] : q2[0];
-    if(WITH_GRAD)
-    {
-        for(int i=0;i<3;i++)     dq_dp[i] = isy ? g[1][i]  : g[0][i];
-        for(int i=0;i<NDIST;i++) dq_dk[i] = isy ? gk[1][i] : gk[0][i];
-    }
-    return ok;
 }
 
 ////////////////////////////////////////////////////////////////////////////////

@@ -23,15 +23,6 @@ static int run(double* q, double* dq_dp, double* dq_dk, const double* p, int N,
         for(int xy=0;xy<2;xy++)
             for(int k=0;k<NDIST;k++)
                 dq_dk[(2*i + xy)*NDIST + k] = gk[xy][k];
-        // the single-row entry point must agree with the two-row one bit for bit
-        for(int xy=0;xy<2;xy++)
-        {
-            double q1, g1[3], gk1[NDIST > 0 ? NDIST : 1];
-            project_lens_row<PROJ,NDIST,true>(xy, &q1, g1, gk1, &p[3*i], intr, cfg);
-            if(q1 != q[2*i+xy]) nfail += 1000;
-            for(int k=0;k<3;k++)     if(g1[k]  != g[xy][k])  nfail += 1000;
-            for(int k=0;k<NDIST;k++) if(gk1[k] != gk[xy][k]) nfail += 1000;
-        }
     }
     return nfail;
 }

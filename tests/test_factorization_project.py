@@ -55,6 +55,10 @@ def test_callback_factorization_solves(amd, lensmodel, Ncam, Nf, with_points):
     if with_points:
         from test_callback_parity import _with_points
         oi = _with_points(oi, np.random.RandomState(2))
+        # (_with_points() leaves two points with a single live observation: their range
+        #  is free and JtJ singular, cond 7e20 - numpy's Cholesky fails on it too.
+        #  Here every point is seen twice)
+        oi["observations_point"][:,2] = np.abs(oi["observations_point"][:,2]) + 0.5
     if "SPLINED" in lensmodel:
         oi["do_optimize_intrinsics_core"] = False
     b, x, J, F = amd.optimizer_callback(**oi)

@@ -67,7 +67,7 @@ def host_project(L, lensmodel, intrinsics, p):
     q, dq_dp, dq_dk = np.zeros((N,2)), np.zeros((N,2,3)), np.zeros((N,2,max(ndist,1)))
     intr = np.ascontiguousarray(intrinsics, dtype=float)
     nfail = L.hostcheck_project(proj, ndist, _ptr(q), _ptr(dq_dp), _ptr(dq_dk), _ptr(p), N, _ptr(intr), lin)
-    assert 0 <= nfail < 1000, "single-row and two-row evaluations disagree, or unknown model"
+    assert 0 <= nfail < 1000, "unknown model"
     return q, dq_dp, dq_dk[:,:,:ndist], nfail
 
 
