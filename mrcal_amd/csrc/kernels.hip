@@ -1278,9 +1278,9 @@ void regularization_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowpt
 // the two spline surfaces around the projected point: WHICH state variables a
 // row touches depends on the data, so colidx is rewritten by every evaluation
 // and the per-observation Gram of the parametric models does not apply (the
-// normal equations of these problems are assembled row by row,
-// solver_kernels.hip). One lane per chessboard corner, rows written directly.
-// Straightforward rather than fast: splined solves are a next-round item.
+// normal equations of these problems are assembled from the rows, observation
+// by observation: assemble_splined_kernel, solver_kernels.hip). One lane per
+// chessboard corner, rows written directly.
 // Reference: mrcal.c:2075-2293 (projection), 4734-4760 (row layout)
 template<bool WITH_J>
 __global__ __launch_bounds__(64)
