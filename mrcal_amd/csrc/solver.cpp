@@ -625,6 +625,8 @@ bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_terminati
     DoglegParameters prm;
     if(max_iterations > 0)  prm.max_iterations = max_iterations;
     if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
+    // the g^T N g slot is accumulated into, and cleared again by the kernel that consumes it
+    HIP_TRY(hipMemsetAsync(P->comm_gng(), 0, sizeof(double), P->stream), return false);
     return ctl_reset(P, prm, check_termination != 0);
 }
 
@@ -639,7 +641,7 @@ bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int 
     {
     case 0:
         if(init) return true;
-        HIP_TRY(launch_step_begin(P->d_ops, ctl, P->F.status, P->stream), return false);
+        // (the trial was started by the previous step's last kernel)
         HIP_TRY(launch_factor_local(P->nd, P->br, Rfrom, P->F, 0.0, ctl, P->is_leader, P->stream), return false);
         HIP_TRY(launch_shard_prepare_schur(P->nd, ctl, P->F, P->stream), return false);
         return true;
@@ -651,22 +653,19 @@ bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int 
     case 2:
         if(!init)
         {
-            HIP_TRY(launch_shard_gn(P->nd, P->br, P->d_ops, ctl, true, P->comm_gn(), P->stream), return false);
-            HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, true), return false);
+            // (the summed frame/point part of the Gauss-Newton step is read from the buffer)
+            HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, true, 3,
+                                       P->nd.NE > 0 ? P->comm_gn() : NULL), return false);
         }
         if(!problem_evaluate_ref(P, Rto, true, true)) return false;
         HIP_TRY(launch_shard_point(P->nd, P->d_ops, ctl, init, false, P->comm_point(), P->stream), return false);
         return true;
     case 3:
-        HIP_TRY(launch_shard_point(P->nd, P->d_ops, ctl, init, true, P->comm_point(), P->stream), return false);
-        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, init, P->stream, 1), return false);
-        HIP_TRY(launch_shard_dots_g(P->nd, P->d_ops, ctl, init, P->stream), return false);
-        HIP_TRY(launch_shard_gng(P->d_ops, ctl, init, false, P->comm_gng(), P->stream), return false);
+        HIP_TRY(launch_shard_point_sums(P->nd, P->d_ops, ctl, init, P->comm_point(), P->comm_gng(), P->stream), return false);
         return true;
     case 4:
-        HIP_TRY(launch_shard_gng(P->d_ops, ctl, init, true, P->comm_gng(), P->stream), return false);
-        HIP_TRY(launch_finish_point(P->nd, P->d_ops, ctl, init, P->stream, 2), return false);
-        if(!init) HIP_TRY(launch_step_accept(P->d_ops, ctl, P->stream), return false);
+        // Cauchy step of the new point, accept/reject, and the start of the next trial: one launch
+        HIP_TRY(launch_shard_step_finish(P->nd, P->d_ops, ctl, P->F.status, init, P->comm_gng(), P->stream), return false);
         return true;
     }
     set_error("mrcal_amd_problem_sharded_enqueue(): segment %d", segment);

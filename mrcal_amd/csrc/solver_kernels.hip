@@ -1762,13 +1762,22 @@ void gn_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __res
 // this launch
 __global__ __launch_bounds__(256)
 void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                        const int* __restrict__ chol_status, double* __restrict__ step, int compute_dots)
+                        const int* __restrict__ chol_status, double* __restrict__ step, int compute_dots,
+                        const double* __restrict__ gn_E)
 {
     if(ctl->done) return;
     const int  ib = ctl->ib, ia = ctl->ia;
     const OpDev& from = ops[ib];
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     const bool fresh_gn = ctl->need_gn != 0;
+    // sharded: the frame/point part of a fresh Gauss-Newton step arrives summed
+    // over the shards in a communication buffer (every shard back-substituted
+    // its own blocks); it is stored into the point on the way
+    const bool from_comm = (gn_E != NULL) && !fl->skip_factor;
+    auto gn_at = [&](int i) -> double
+    {
+        return (from_comm && i >= nd.Nie && i < nd.Nie + nd.NE) ? gn_E[i - nd.Nie] : from.step_gn[i];
+    };
 
     // |step_gn|^2 and step_gn . step_cauchy of a fresh Gauss-Newton step: every
     // workgroup sums the whole vectors itself, in the same fixed order (so all
@@ -1780,7 +1789,7 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
         double a = 0.0, b = 0.0, c = 0.0;
         for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x)
         {
-            const double gn = from.step_gn[i];
+            const double gn = gn_at(i);
             a += gn*gn;
             b += gn*from.step_cauchy[i];
             c += gn*from.g[i];
@@ -1853,8 +1862,11 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if(i < nd.Nstate)
     {
+        const double gni = gn_at(i);
+        // (the other workgroups read these entries from the buffer, not from here)
+        if(from_comm && fresh_gn && i >= nd.Nie && i < nd.Nie + nd.NE) from.step_gn[i] = gni;
         double s = kc*from.step_cauchy[i];
-        if(kg != 0.0) s += kg*from.step_gn[i];
+        if(kg != 0.0) s += kg*gni;
         step[i] = s;
         ops[ia].b[i] = from.b[i] + s;
     }
@@ -1963,20 +1975,24 @@ __global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl
 // Nstate elements. initial: the evaluation of the starting point (no accept)
 __global__ __launch_bounds__(1024)
 void step_finish_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                        int* chol_status, int initial)
+                        int* chol_status, int initial, double* __restrict__ gng_src)
 {
     const bool skip = !initial && fl->skip_eval;
     const int  ip   = initial ? ctl->ib : ctl->ia;
     const OpDev& O  = ops[ip];
-    const double gNg = O.scalars[SC_G_GNG], norm2_g = O.scalars[SC_G_GG], norm2_x = O.scalars[SC_NORM2_X];
+    // (sharded: g^T N g arrives summed over the shards in a communication buffer)
+    const double gNg = (gng_src != NULL) ? gng_src[0] : O.scalars[SC_G_GNG];
+    const double norm2_g = O.scalars[SC_G_GG], norm2_x = O.scalars[SC_NORM2_X];
     const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
     __syncthreads();
+    if(gng_src != NULL && threadIdx.x == 0) gng_src[0] = 0.0;       // the next point accumulates into it
     if(!skip)
         for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x) O.step_cauchy[i] = k*O.g[i];
     if(threadIdx.x == 0)
     {
         if(!skip)
         {
+            if(gng_src != NULL) O.scalars[SC_G_GNG] = gNg;
             ctl->norm2_x[ip]      = norm2_x;
             ctl->cauchy_lensq[ip] = k*k*norm2_g;
             ctl->gn_valid[ip]     = 0;
@@ -2068,23 +2084,29 @@ void shard_unpack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, con
 //   which 0: |step_gn|^2, step_gn.step_cauchy of ctl->ib
 //         1: g.step, |step|^2 of ctl->ib
 //         2: g.g of the point just evaluated
+//   unpack_g (which 2 only): the all-reduced [g | |x|^2]; it is copied into the
+//   point on the way (this launch replaces an unpack kernel in front of it)
 __global__ __launch_bounds__(1024)
 void shard_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                       const SolverCtlFlags* __restrict__ fl, const double* __restrict__ step, int which, int initial)
+                       const SolverCtlFlags* __restrict__ fl, const double* __restrict__ step, int which, int initial,
+                       const double* __restrict__ unpack_g)
 {
     if(which == 0 && fl->skip_factor) return;
     if(which == 1 && fl->skip_eval)   return;
     if(which == 2 && !initial && fl->skip_eval) return;
     const OpDev& O = ops[(which == 2 && !initial) ? ctl->ia : ctl->ib];
-    const double* __restrict__ u = (which == 0) ? O.step_gn : (which == 1) ? step : O.g;
-    const double* __restrict__ w = (which == 0) ? O.step_cauchy : O.g;
+    const bool unpack = (which == 2 && unpack_g != NULL);
+    const double* __restrict__ u = (which == 0) ? O.step_gn : (which == 1) ? step : (unpack ? unpack_g : O.g);
+    const double* __restrict__ w = (which == 0) ? O.step_cauchy : (unpack ? unpack_g : O.g);
     double a = 0.0, b = 0.0;
     for(int i = threadIdx.x; i < n; i += 1024)
     {
         const double ui = u[i];
         a += ui*ui;
         b += ui*w[i];
+        if(unpack) O.g[i] = ui;
     }
+    if(unpack && threadIdx.x == 0) O.scalars[SC_NORM2_X] = unpack_g[n];
     for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     __shared__ double part[16][2];
     if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
@@ -2291,23 +2313,30 @@ hipError_t launch_step_begin(const OpDev* ops, SolverCtl* ctl, int* chol_status,
 // parts: 1 = the step (dot products, coefficients, b[ia] = b[ib] + step), 2 = its
 // quadratic form for the expected improvement
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream, bool deterministic, int parts)
+                              double* step, hipStream_t stream, bool deterministic, int parts, const double* gn_E)
 {
     if(parts & 1)
     {
         // (the dot products of the Gauss-Newton step are formed inside, deterministically)
         hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), F.status, step, 1);
+                           nd, ops, ctl, ctl_flags(ctl), F.status, step, 1, gn_E);
     }
     // (parts & 2 used to be the quadratic form step^T N step: the expected
     // improvement now comes out of step_choose_kernel itself)
     (void)deterministic;
     return hipGetLastError();
 }
-hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream)
+// After the all-reduce of [g | |x|^2]: into the point, g.g in a fixed order, and this
+// shard's part of g^T N g accumulated straight into its communication slot
+// (cleared by the kernel that consumed it last: step_finish_kernel)
+hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                                   const double* comm_point, double* comm_gng, hipStream_t stream)
 {
     hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                       (const double*)NULL, 2, initial ? 1 : 0);
+                       (const double*)NULL, 2, initial ? 1 : 0, comm_point);
+    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
+    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
+                       nd, Rp, comm_point, 0, comm_gng, 0, 1);
     return hipGetLastError();
 }
 hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
@@ -2374,7 +2403,15 @@ hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl*
     hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
                        nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
     hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0);
+                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, (double*)NULL);
+    return hipGetLastError();
+}
+// the sharded end of a trial step: the same kernel, g^T N g from the all-reduced buffer
+hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
+                                    double* gng, hipStream_t stream)
+{
+    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
+                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, gng);
     return hipGetLastError();
 }
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream)

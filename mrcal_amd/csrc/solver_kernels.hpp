@@ -203,7 +203,7 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
 hipError_t launch_step_begin (const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream);
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
                               double* step, hipStream_t stream,
-                              bool deterministic = false, int parts = 3);
+                              bool deterministic = false, int parts = 3, const double* gn_E = NULL);
 // |g|^2, g N g, the Cauchy step of the point just evaluated (ctl->ia, or ctl->ib if initial)
 // parts: 1 = the reduction g^T N g, 2 = the Cauchy step + bookkeeping
 hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
@@ -214,9 +214,12 @@ hipError_t launch_shard_gn(const NormalDims& nd, const BlockRanges& br, const Op
                            bool unpack, double* comm, hipStream_t stream);
 hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
                               bool unpack, double* comm, hipStream_t stream);
-hipError_t launch_shard_dots_g(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream);
+hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                                   const double* comm_point, double* comm_gng, hipStream_t stream);
 hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream);
 hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
+hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
+                                    double* gng, hipStream_t stream);
 hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
                               hipStream_t stream);
 
