@@ -648,7 +648,7 @@ bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int 
     case 1:
         if(init) return true;
         HIP_TRY(launch_solve_backsub(P->nd, P->br, Rfrom, P->F, NULL, false, P->stream), return false);
-        HIP_TRY(launch_shard_gn(P->nd, P->br, P->d_ops, ctl, false, P->comm_gn(), P->stream), return false);
+        HIP_TRY(launch_shard_pack_gn(P->nd, P->br, P->d_ops, ctl, P->comm_gn(), P->stream), return false);
         return true;
     case 2:
         if(!init)
@@ -658,7 +658,7 @@ bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int 
                                        P->nd.NE > 0 ? P->comm_gn() : NULL), return false);
         }
         if(!problem_evaluate_ref(P, Rto, true, true)) return false;
-        HIP_TRY(launch_shard_point(P->nd, P->d_ops, ctl, init, false, P->comm_point(), P->stream), return false);
+        HIP_TRY(launch_shard_pack_point(P->nd, P->d_ops, ctl, init, P->comm_point(), P->stream), return false);
         return true;
     case 3:
         HIP_TRY(launch_shard_point_sums(P->nd, P->d_ops, ctl, init, P->comm_point(), P->comm_gng(), P->stream), return false);

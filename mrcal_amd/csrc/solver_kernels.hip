@@ -1727,11 +1727,6 @@ __device__ __forceinline__ void ctl_begin(const OpDev* __restrict__ ops, SolverC
     fl->skip_factor = ctl->need_gn ? 0 : 1;
     fl->skip_eval   = 0;
 }
-__global__ void step_begin_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
-{
-    if(threadIdx.x != 0 || blockIdx.x != 0) return;
-    ctl_begin(ops, ctl, fl, chol_status);
-}
 
 // |step_gn|^2 -> scalars[SC_GN_LENSQ], step_cauchy . step_gn -> scalars[SC_GN_DOT_CAUCHY] of the point ctl->ib
 __global__ __launch_bounds__(256)
@@ -1911,30 +1906,6 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     }
 }
 
-// After the evaluation of a point and the reduction g N g, g.g: its Cauchy
-// step -(|g|^2/|Jg|^2) g and the bookkeeping. which: 0 = the point ctl->ia
-// (a trial), 1 = the point ctl->ib (the initial evaluation)
-__global__ __launch_bounds__(256)
-void finish_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl,
-                         const SolverCtlFlags* __restrict__ fl, int initial)
-{
-    if(!initial && fl->skip_eval) return;
-    const int ip = initial ? ctl->ib : ctl->ia;
-    const OpDev& O = ops[ip];
-    const double gNg = O.scalars[SC_G_GNG], norm2_g = O.scalars[SC_G_GG];
-    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i < nd.Nstate) O.step_cauchy[i] = k*O.g[i];
-    if(blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        ctl->norm2_x[ip]      = O.scalars[SC_NORM2_X];
-        ctl->cauchy_lensq[ip] = k*k*norm2_g;
-        ctl->gn_valid[ip]     = 0;
-        ctl->did_step_to_edge[ip] = 0;
-        ctl->Nevaluations++;
-    }
-}
-
 // rho test, trust-region update, accept/reject (one thread)
 __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, SolverCtl* ctl)
 {
@@ -1960,19 +1931,13 @@ __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, Solver
             (tr < ctl->trustregion_threshold || tr == 0.0 || !(tr == tr)))
         ctl->done = 1;
 }
-__global__ void step_accept_kernel(const OpDev* __restrict__ ops, SolverCtl* ctl, const SolverCtlFlags* __restrict__ fl)
-{
-    if(threadIdx.x != 0 || blockIdx.x != 0) return;
-    if(fl->skip_eval) return;     // finished, or the trial was voided
-    ctl_accept(ops, ctl);
-}
-
-// End of a trial step on ONE GPU, in one launch of ONE workgroup: the Cauchy
-// step of the point just evaluated (finish_point_kernel), the rho test with
-// accept/reject (step_accept_kernel) and the start of the NEXT trial
-// (step_begin_kernel). One workgroup so that a barrier separates "everyone has
-// read the control state" from "thread 0 rewrites it"; the vector part is
-// Nstate elements. initial: the evaluation of the starting point (no accept)
+// End of a trial step, in one launch of ONE workgroup: the Cauchy step
+// -(|g|^2/|Jg|^2) g of the point just evaluated and its bookkeeping, the rho
+// test with accept/reject (ctl_accept) and the start of the NEXT trial
+// (ctl_begin). One workgroup so that a barrier separates "everyone has read the
+// control state" from "thread 0 rewrites it"; the vector part is Nstate
+// elements. initial: the evaluation of the starting point (no accept).
+// gng_src (sharded): g^T N g summed over the shards, in its communication slot
 __global__ __launch_bounds__(1024)
 void step_finish_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
                         int* chol_status, int initial, double* __restrict__ gng_src)
@@ -2036,15 +2001,6 @@ void shard_pack_gn_kernel(NormalDims nd, int e0, int e1, int e2, int e3,
     const bool mine = (i >= e0 && i < e1) || (i >= e2 && i < e3);
     comm[i] = (!fl->skip_factor && mine) ? ops[ctl->ib].step_gn[nd.Nie + i] : 0.0;
 }
-__global__ __launch_bounds__(256)
-void shard_unpack_gn_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                            const SolverCtlFlags* __restrict__ fl, const double* __restrict__ comm)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i >= nd.NE || fl->skip_factor) return;
-    ops[ctl->ib].step_gn[nd.Nie + i] = comm[i];
-}
-
 // [g | |x|^2 | s^T N s] of the point just evaluated (s^T N s belongs to the
 // point the step started from; it rides along)
 __global__ __launch_bounds__(256)
@@ -2063,18 +2019,6 @@ void shard_pack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const
         else                    v = 0.0;       // (spare slot)
     }
     comm[i] = v;
-}
-__global__ __launch_bounds__(256)
-void shard_unpack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                               const SolverCtlFlags* __restrict__ fl, int initial, const double* __restrict__ comm)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i >= nd.Nstate + 2) return;
-    if(!initial && fl->skip_eval) return;
-    const OpDev& O = ops[initial ? ctl->ib : ctl->ia];
-    if(i < nd.Nstate)       O.g[i] = comm[i];
-    else if(i == nd.Nstate) O.scalars[SC_NORM2_X] = comm[i];
-    (void)initial;
 }
 // The replicated control state must stay BIT-identical on all ranks (a rank
 // whose "done" differs would stop queueing collectives). What goes through an
@@ -2119,17 +2063,6 @@ void shard_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __
         else if(which == 1) { O.scalars[SC_STEP_SS]  = a; O.scalars[SC_STEP_GS] = b; }
         else                { O.scalars[SC_G_GG]     = a; O.scalars[SC_G_GG2]   = a; }
     }
-}
-
-// g^T N g of the point just evaluated
-__global__ void shard_gng_kernel(const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                                 const SolverCtlFlags* __restrict__ fl, int initial, int unpack, double* __restrict__ comm)
-{
-    if(threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool skip = !initial && fl->skip_eval;
-    double* p = &ops[initial ? ctl->ib : ctl->ia].scalars[SC_G_GNG];
-    if(unpack) { if(!skip) *p = comm[0]; }
-    else       comm[0] = skip ? 0.0 : *p;
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -2305,11 +2238,6 @@ const int* solver_ctl_skip_factor(const SolverCtl* ctl) { return &((const Solver
 const int* solver_ctl_skip_eval  (const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
 size_t     solver_ctl_bytes() { return sizeof(SolverCtl) + sizeof(SolverCtlFlags); }
 
-hipError_t launch_step_begin(const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream)
-{
-    hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl), chol_status);
-    return hipGetLastError();
-}
 // parts: 1 = the step (dot products, coefficients, b[ia] = b[ib] + step), 2 = its
 // quadratic form for the expected improvement
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
@@ -2339,19 +2267,6 @@ hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, Solve
                        nd, Rp, comm_point, 0, comm_gng, 0, 1);
     return hipGetLastError();
 }
-hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
-                               int parts)
-{
-    // (g^T N g, g.g, g.g) -> SC_G_GNG..
-    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
-    if(parts & 1)
-        hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                           nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
-    if(parts & 2)
-        hipLaunchKernelGGL(finish_point_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0);
-    return hipGetLastError();
-}
 
 hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream)
 {
@@ -2360,39 +2275,23 @@ hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, cons
                        n, ctl_flags(ctl), F.status, F.S);
     return hipGetLastError();
 }
-hipError_t launch_shard_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
-                           bool unpack, double* comm, hipStream_t stream)
+hipError_t launch_shard_pack_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
+                                double* comm, hipStream_t stream)
 {
     if(nd.NE <= 0) return hipSuccess;
-    if(unpack)
-        hipLaunchKernelGGL(shard_unpack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), comm);
-    else
-    {
-        int e[4];
-        br.e_range(nd, 0, &e[0], &e[1]);
-        br.e_range(nd, 1, &e[2], &e[3]);
-        hipLaunchKernelGGL(shard_pack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
-                           nd, e[0], e[1], e[2], e[3], ops, ctl, ctl_flags(ctl), comm);
-    }
+    int e[4];
+    br.e_range(nd, 0, &e[0], &e[1]);
+    br.e_range(nd, 1, &e[2], &e[3]);
+    hipLaunchKernelGGL(shard_pack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
+                       nd, e[0], e[1], e[2], e[3], ops, ctl, ctl_flags(ctl), comm);
     return hipGetLastError();
 }
-hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                              bool unpack, double* comm, hipStream_t stream)
+hipError_t launch_shard_pack_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                                   double* comm, hipStream_t stream)
 {
     const int n = nd.Nstate + 2;
-    if(unpack)
-        hipLaunchKernelGGL(shard_unpack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
-    else
-        hipLaunchKernelGGL(shard_pack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
-    return hipGetLastError();
-}
-hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream)
-{
-    hipLaunchKernelGGL(shard_gng_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl),
-                       initial ? 1 : 0, unpack ? 1 : 0, comm);
+    hipLaunchKernelGGL(shard_pack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
+                       nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
     return hipGetLastError();
 }
 // single-GPU end of a trial step: g^T N g, then step_finish_kernel (which also starts the next trial)
@@ -2412,11 +2311,6 @@ hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, Solv
 {
     hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
                        nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, gng);
-    return hipGetLastError();
-}
-hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream)
-{
-    hipLaunchKernelGGL(step_accept_kernel, dim3(1), dim3(64), 0, stream, ops, ctl, ctl_flags(ctl));
     return hipGetLastError();
 }
 

@@ -198,30 +198,25 @@ hipError_t launch_outlier_stats(int Npoints_board, double thresh_sq, const doubl
 hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const double* x, double* pool,
                                 int* counts, hipStream_t stream);
 
-// The device-controlled dog-leg step (single GPU), in the order they are queued:
-//   begin -> [factor_local, solve_backsub] -> choose -> [evaluate, assemble] -> finish_point -> accept
-hipError_t launch_step_begin (const OpDev* ops, SolverCtl* ctl, int* chol_status, hipStream_t stream);
+// The device-controlled dog-leg step, in the order the kernels are queued:
+//   [factor_local, solve_backsub] -> choose -> [evaluate, assemble] -> finish (g^T N g, Cauchy step,
+//   accept/reject, start of the next trial)
+// gn_E (sharded): the frame/point part of the Gauss-Newton step summed over the shards
 hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
                               double* step, hipStream_t stream,
                               bool deterministic = false, int parts = 3, const double* gn_E = NULL);
-// |g|^2, g N g, the Cauchy step of the point just evaluated (ctl->ia, or ctl->ib if initial)
-// parts: 1 = the reduction g^T N g, 2 = the Cauchy step + bookkeeping
-hipError_t launch_finish_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial, hipStream_t stream,
-                               int parts = 3);
-// the sharded step: staging around the collectives (see solver_kernels.hip)
-hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream);
-hipError_t launch_shard_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
-                           bool unpack, double* comm, hipStream_t stream);
-hipError_t launch_shard_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                              bool unpack, double* comm, hipStream_t stream);
-hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                                   const double* comm_point, double* comm_gng, hipStream_t stream);
-hipError_t launch_shard_gng(const OpDev* ops, SolverCtl* ctl, bool initial, bool unpack, double* comm, hipStream_t stream);
-hipError_t launch_step_accept(const OpDev* ops, SolverCtl* ctl, hipStream_t stream);
-hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
-                                    double* gng, hipStream_t stream);
 hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
                               hipStream_t stream);
+// the sharded step: staging around the collectives (see solver_kernels.hip)
+hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream);
+hipError_t launch_shard_pack_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
+                                double* comm, hipStream_t stream);
+hipError_t launch_shard_pack_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                                   double* comm, hipStream_t stream);
+hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
+                                   const double* comm_point, double* comm_gng, hipStream_t stream);
+hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
+                                    double* gng, hipStream_t stream);
 
 // solves against a kept factorization (F as left by launch_factor_local() +
 // launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order

@@ -119,7 +119,7 @@ class NumpyShard:
     def _seg0(self, initial):
         if initial: return
         c = self.ctl
-        # step_begin_kernel
+        # ctl_begin (solver_kernels.hip)
         self.status = 0
         O = self.op[c["ib"]]
         O["sNs"] = O["gs"] = 0.0
@@ -211,7 +211,7 @@ class NumpyShard:
         ip = c["ib"] if initial else c["ia"]
         P  = self.op[ip]
         P["gNg"] = float(self.comm[3][0])
-        # finish_point_kernel
+        # step_finish_kernel: the Cauchy step
         k = -P["gg"]/P["gNg"] if P["gNg"] > 0.0 else 0.0
         P["step_cauchy"][:] = k*P["g"]
         c["norm2_x"][ip]      = P["norm2_x"]
@@ -220,7 +220,7 @@ class NumpyShard:
         c["edge"][ip]         = 0
         c["Nevaluations"]    += 1
         if initial: return
-        # step_accept_kernel
+        # ctl_accept (solver_kernels.hip)
         ib, ia = c["ib"], c["ia"]
         expected = -2.0*self.op[ib]["gs"] - self.op[ib]["sNs"]
         rho = (c["norm2_x"][ib] - c["norm2_x"][ia])/expected
