@@ -1781,13 +1781,31 @@ void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
     __shared__ double dots[3];
     if(fresh_gn && compute_dots)
     {
+        // (all of a batch's loads in flight together: each thread walks 24 elements
+        //  of three vectors at NS, and one L2 round trip per element is most of
+        //  this kernel's time)
         double a = 0.0, b = 0.0, c = 0.0;
-        for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x)
+        constexpr int UB = 6;
+        for(int i0 = threadIdx.x; i0 < nd.Nstate; i0 += UB*blockDim.x)
         {
-            const double gn = gn_at(i);
-            a += gn*gn;
-            b += gn*from.step_cauchy[i];
-            c += gn*from.g[i];
+            double vg[UB], vc[UB], vx[UB];
+#pragma unroll
+            for(int u = 0; u < UB; u++)
+            {
+                const int  i  = i0 + u*blockDim.x;
+                const bool ok = i < nd.Nstate;
+                const int  ic = ok ? i : 0;
+                vg[u] = ok ? gn_at(ic) : 0.0;
+                vc[u] = from.step_cauchy[ic];
+                vx[u] = from.g[ic];
+            }
+#pragma unroll
+            for(int u = 0; u < UB; u++)
+            {
+                a += vg[u]*vg[u];
+                b += vg[u]*vc[u];
+                c += vg[u]*vx[u];
+            }
         }
         for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
         __shared__ double part[4][3];
