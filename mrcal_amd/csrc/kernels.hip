@@ -642,6 +642,11 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
     const double warp0 = wp[0], warp1 = wp[1];
 
+    // wave-uniform reciprocals, once per observation: an FP64 division is ~12
+    // instructions, and the pass loop had four of these per corner
+    const double inv_Wm1 = P.inv_Wm1,   inv_Hm1 = P.inv_Hm1;
+    const double inv_fx  = 1.0/intr[0], inv_fy  = 1.0/intr[1];
+
     // Gram operands (problem.hpp): at k-step s this lane reads
     // tile[4 s + lane/16][gram_read_col(iread, lane)] for each of the NREAD operands
     constexpr int NREAD = gram_nreads(NBLK);
@@ -741,8 +746,8 @@ void board_kernel(DeviceProblem P,
             if(ALLOPT || P.has_warp_seed)
             {
                 // parabolic flex along each board axis, max deflection at the centre
-                const double xr = (double)ix / (double)(P.W - 1);
-                const double yr = (double)iy / (double)(P.H - 1);
+                const double xr = (double)ix * inv_Wm1;
+                const double yr = (double)iy * inv_Hm1;
                 dz_dw0 = 4.0*xr*(1.0 - xr);
                 dz_dw1 = 4.0*yr*(1.0 - yr);
                 bz += warp0*dz_dw0;
@@ -782,9 +787,9 @@ void board_kernel(DeviceProblem P,
             {
                 if(ALLOPT || P.Ncore_state)
                 {
-                    row[0][0] = (q[0] - intr[2])/intr[0] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
+                    row[0][0] = (q[0] - intr[2])*inv_fx * w * SCALE_INTRINSICS_FOCAL_LENGTH;
                     row[0][2] = w * SCALE_INTRINSICS_CENTER_PIXEL;
-                    row[1][1] = (q[1] - intr[3])/intr[1] * w * SCALE_INTRINSICS_FOCAL_LENGTH;
+                    row[1][1] = (q[1] - intr[3])*inv_fy * w * SCALE_INTRINSICS_FOCAL_LENGTH;
                     row[1][3] = w * SCALE_INTRINSICS_CENTER_PIXEL;
                 }
                 if(NDIST > 0 && (ALLOPT || P.Ndist_state))

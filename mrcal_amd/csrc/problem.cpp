@@ -616,6 +616,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     D.Nobs_board = Nboard_local; D.Nobs_point = Npoint_local;
     D.W = calibration_object_width_n; D.H = calibration_object_height_n;
     D.spacing = calibration_object_spacing;
+    D.inv_Wm1 = 1.0/(double)(D.W - 1);      // (W = 1 or H = 1 with a warp: the reference divides by zero just the same)
+    D.inv_Hm1 = 1.0/(double)(D.H - 1);
     if(calobject_warp) { D.seed_warp[0] = calobject_warp->x2; D.seed_warp[1] = calobject_warp->y2; }
     if(lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
     {

@@ -258,6 +258,7 @@ struct DeviceProblem
     int Nobs_board, Nobs_point;
     int W, H;
     double spacing;
+    double inv_Wm1, inv_Hm1;   // 1/(W-1), 1/(H-1): the board warp's normalized coordinates
     double seed_warp[2];
 
     // model configuration that is not in the intrinsics vector
