@@ -455,7 +455,8 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     GramRd nxt = cur;
     if(S < 15)
     {
-        constexpr int so = (S < 15 ? S+1 : 0)*4*KS*(int)sizeof(double);
+        // FULL: k-step s takes the tile rows s, s+16, s+32, s+48 (gram_copy_fused)
+        constexpr int so = (S < 15 ? S+1 : 0)*(FULL ? 1 : 4)*KS*(int)sizeof(double);
 #pragma unroll
         for(int q=0;q<NREAD;q++) nxt.v[q] = lds_read_b64_at<so>(gram_a[q]);
     }
@@ -507,9 +508,19 @@ void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const i
     constexpr int NREAD = gram_nreads(NBLK);
     static_assert(NREAD >= 2 && NREAD <= 4, "board tiles have 5..8 column blocks");
     const unsigned tile_a0 = (unsigned)(size_t)tile;
+    // WHICH four tile rows make up a k-step is free (the Gram is a sum over all
+    // rows). Consecutive rows (4s .. 4s+3, goffs) sit 58 dwords apart: the two
+    // rows that a 32-lane half of the wave reads overlap in 26 of their 32 LDS
+    // banks - 795 of the kernel's 1028 active LDS cycles were bank conflicts. A
+    // full half-tile therefore takes rows s, s+16, s+32, s+48: 16 rows apart is
+    // 928 = 32 (mod 64) dwords, disjoint banks. (A partial one keeps the
+    // consecutive rows: it stops after ceil(nrows/4) steps.) Measured: the
+    // conflict cycles halve (the rest are the tile writes and the copy-out
+    // reads); the kernel's time does not move - the LDS is not what it waits for
+    const unsigned row_skew = FULL ? (unsigned)((threadIdx.x >> 4)*15*KS*sizeof(double)) : 0u;
     unsigned gram_a[4];
 #pragma unroll
-    for(int q=0;q<4;q++) gram_a[q] = tile_a0 + (unsigned)(goffs[q < NREAD ? q : 0]*sizeof(double));
+    for(int q=0;q<4;q++) gram_a[q] = tile_a0 + row_skew + (unsigned)(goffs[q < NREAD ? q : 0]*sizeof(double));
     GramRd cur;
 #pragma unroll
     for(int q=0;q<4;q++) cur.v[q] = 0.0;
