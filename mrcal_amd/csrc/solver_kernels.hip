@@ -70,55 +70,91 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
     double* __restrict__ Btf = lds_f;
     double* __restrict__ Df  = lds_f + 6*nd.Nc;
     double* __restrict__ gf  = Df + 36;
+    __shared__ int pair_of[8];                 // the pairs of the 8 observations in flight
     const int t = threadIdx.x;
     const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
     if(o0 >= o1) return;                       // not this shard's frame: its rows stay zero
+
+    // What this workgroup will add to at the end, requested now: the chain of
+    // dependent memory round trips is what this kernel's time is made of
+    double* __restrict__ Bt = opref_get(R).Bt;
+    double* __restrict__ D  = opref_get(R).D;
+    double* __restrict__ g  = opref_get(R).g;
+    const int e0 = 6*f;   // frame blocks come first in E
+    constexpr int NOLD = 4;                    // 6 Nc / 256 entries of Bt per thread: Nc <= 170 (else the rest is read late)
+    double old_bt[NOLD];
+#pragma unroll
+    for(int u = 0; u < NOLD; u++)
+    {
+        const int i = t + 256*u;
+        old_bt[u] = (i < 6*nd.Nc) ? Bt[(size_t)e0*nd.Nc + i] : 0.0;
+    }
+    const double old_dg = (t < 36) ? D[(size_t)f*36 + t] : (t < 42) ? g[nd.Nie + e0 + (t-36)] : 0.0;
+
     for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
-    __syncthreads();
 
     const int npos = gram_stride(P.Ndist);
-    for(int pos = t; pos < npos; pos += blockDim.x)
+    for(int ob = o0; ob < o1; ob += 8)
     {
-        if(!(plan.pos_table[pos] & 0x20000)) continue;      // no frame column in this position, for any pair
-        // the observations of the frame, 8 Gram loads in flight at a time
-        for(int ob = o0; ob < o1; ob += 8)
+        if(ob > o0) __syncthreads();           // pair_of is free again
+        if(t < 8) pair_of[t] = plan.obs_pair[(ob + t < o1) ? ob + t : o0];
+        __syncthreads();                       // pair_of is there (and, the first time, the accumulators are zero)
+        // 8 Gram loads per position in flight, together with the position's flag and the pair indices
+        for(int pos0 = t; pos0 < npos; pos0 += 2*blockDim.x)
         {
-            double vv[8];
-            PairOp op[8];
+            double vv[2][8];
+            int    flag[2];
 #pragma unroll
-            for(int u = 0; u < 8; u++)
+            for(int w = 0; w < 2; w++)
             {
-                const int o = (ob + u < o1) ? ob + u : o0;
-                vv[u] = gram[(size_t)o*npos + pos];
-                op[u] = plan.pair_table[(size_t)plan.obs_pair[o]*npos + pos];
+                const int pos = pos0 + w*blockDim.x;
+                const int pc  = (pos < npos) ? pos : t;
+                flag[w] = (pos < npos) ? plan.pos_table[pc] : 0;
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                {
+                    const int o = (ob + u < o1) ? ob + u : o0;
+                    vv[w][u] = gram[(size_t)o*npos + pc];
+                }
             }
 #pragma unroll
-            for(int u = 0; u < 8; u++)
+            for(int w = 0; w < 2; w++)
             {
-                if(ob + u >= o1) break;
-                const double v = vv[u];
-                const int a = op[u].aux & 0xffff, b = op[u].aux >> 16;
-                switch(op[u].op & 0xff)
+                const int pos = pos0 + w*blockDim.x;
+                if(!(flag[w] & 0x20000)) continue;              // no frame column in this position, for any pair
+                PairOp op[8];
+#pragma unroll
+                for(int u = 0; u < 8; u++) op[u] = plan.pair_table[(size_t)pair_of[u]*npos + pos];
+#pragma unroll
+                for(int u = 0; u < 8; u++)
                 {
-                case PAIROP_D:
-                    atomicAdd(&Df[a*6 + b], v);
-                    if(op[u].op & PAIROP_MIRROR) atomicAdd(&Df[b*6 + a], v);
-                    break;
-                case PAIROP_BT: atomicAdd(&Btf[a*nd.Nc + b], v); break;
-                case PAIROP_GF: atomicAdd(&gf[a], v); break;
-                default: break;
+                    if(ob + u >= o1) break;
+                    const double v = vv[w][u];
+                    const int a = op[u].aux & 0xffff, b = op[u].aux >> 16;
+                    switch(op[u].op & 0xff)
+                    {
+                    case PAIROP_D:
+                        atomicAdd(&Df[a*6 + b], v);
+                        if(op[u].op & PAIROP_MIRROR) atomicAdd(&Df[b*6 + a], v);
+                        break;
+                    case PAIROP_BT: atomicAdd(&Btf[a*nd.Nc + b], v); break;
+                    case PAIROP_GF: atomicAdd(&gf[a], v); break;
+                    default: break;
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    double* __restrict__ Bt = opref_get(R).Bt;
-    double* __restrict__ D  = opref_get(R).D;
-    double* __restrict__ g  = opref_get(R).g;
-    const int e0 = 6*f;   // frame blocks come first in E
-    for(int i = t; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] += Btf[i];
-    if(t < 36)      D[(size_t)f*36 + t]     += Df[t];
-    else if(t < 42) g[nd.Nie + e0 + (t-36)] += gf[t-36];
+#pragma unroll
+    for(int u = 0; u < NOLD; u++)
+    {
+        const int i = t + 256*u;
+        if(i < 6*nd.Nc) Bt[(size_t)e0*nd.Nc + i] = old_bt[u] + Btf[i];
+    }
+    for(int i = t + 256*NOLD; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] += Btf[i];
+    if(t < 36)      D[(size_t)f*36 + t]     = old_dg + Df[t];
+    else if(t < 42) g[nd.Nie + e0 + (t-36)] = old_dg + gf[t-36];
 }
 
 // S-S part: observations that see the same (intrinsics, extrinsics) pair
