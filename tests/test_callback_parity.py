@@ -127,6 +127,49 @@ def test_synthetic_selections_and_points(amd, ref_api):
                           ref_api.optimizer_callback(no_factorization=True, **oi), str(bits))
 
 
+def points_only_problem(api, seed=3, Ncam=3, Np=30, Nfixed=4, lens="LENSMODEL_OPENCV4"):
+    """discrete points seen by every camera, NO chessboards: extrinsics and the free
+    points are optimized against a few fixed points (the gauge)"""
+    from mrcal_amd.synthetic import intrinsics_for, IMAGERSIZE, R_from_r
+    rng  = np.random.RandomState(seed)
+    intr = intrinsics_for(lens, Ncam)
+    rt = np.zeros((Ncam-1,6))
+    rt[:,:3] = rng.uniform(-0.05, 0.05, (Ncam-1,3))
+    rt[:,3]  = -0.3*np.arange(1, Ncam)
+    rt[:,4:] = rng.uniform(-0.05, 0.05, (Ncam-1,2))
+    pts = rng.uniform(-1, 1, (Np,3))*np.array((1.5, 1.0, 1.0)) + np.array((0.3, 0, 5.))
+    idx = np.array([(ip, ic, ic-1) for ip in range(Np) for ic in range(Ncam)], dtype=np.int32)
+    q = np.zeros((len(idx),3))
+    for n, (ip, ic, ie) in enumerate(idx):
+        p = pts[ip] if ie < 0 else R_from_r(rt[ie,:3]) @ pts[ip] + rt[ie,3:]
+        q[n,:2] = api.project(p[None], lens, intr[ic])[0]
+    q[:,:2] += rng.normal(0, 0.3, (len(idx),2))
+    q[:,2]   = rng.uniform(0.5, 1.5, len(idx))
+    return dict(intrinsics=intr.copy(), rt_cam_ref=rt + rng.normal(0, 0.01, rt.shape), rt_ref_frame=None,
+                points=pts + np.r_[rng.normal(0, 0.05, (Np-Nfixed,3)), np.zeros((Nfixed,3))],
+                observations_board=None, indices_frame_camintrinsics_camextrinsics=None,
+                observations_point=q, indices_point_camintrinsics_camextrinsics=idx,
+                lensmodel=lens, imagersizes=np.array((IMAGERSIZE,)*Ncam, dtype=np.int32),
+                do_optimize_intrinsics_core=False, do_optimize_intrinsics_distortions=False,
+                do_optimize_extrinsics=True, do_optimize_frames=True,
+                do_optimize_calobject_warp=False, calobject_warp=None, calibration_object_spacing=0.,
+                do_apply_regularization=False, do_apply_outlier_rejection=False, Npoints_fixed=Nfixed, verbose=False)
+
+
+def test_points_only_no_boards(amd, ref_api):
+    """no board observations at all: the point kernels, 3x3 blocks only in the
+    Schur elimination, no frames"""
+    oi = points_only_problem(ref_api)
+    compare_callbacks(amd.optimizer_callback(no_factorization=True, **copy_inputs(oi)),
+                      ref_api.optimizer_callback(no_factorization=True, **copy_inputs(oi)), "points only")
+    oa, orr = copy_inputs(oi), copy_inputs(oi)
+    sa, sr = amd.optimize(**oa), ref_api.optimize(**orr)
+    assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+    assert np.abs(oa["points"] - orr["points"]).max() < 1e-5
+    assert np.abs(oa["rt_cam_ref"] - orr["rt_cam_ref"]).max() < 1e-5
+    assert np.array_equal(oa["points"][-4:], oi["points"][-4:])          # the fixed points stay put
+
+
 @pytest.mark.parametrize("lensmodel", ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120",
                                        "LENSMODEL_CAHVORE_linearity=0.37"))
 def test_points_and_selections_other_models(amd, ref_api, lensmodel):
