@@ -127,6 +127,27 @@ def test_synthetic_selections_and_points(amd, ref_api):
                           ref_api.optimizer_callback(no_factorization=True, **oi), str(bits))
 
 
+@pytest.mark.parametrize("Ncam,Nf,W,H,lensmodel", ((1, 1, 2, 2, "LENSMODEL_PINHOLE"),
+                                                   (2, 1, 3, 2, "LENSMODEL_OPENCV4"),
+                                                   (1, 3, 13, 11, "LENSMODEL_OPENCV8"),        # 143 corners: three passes
+                                                   (20, 3, 5, 4, "LENSMODEL_OPENCV4")))        # 276 camera-block variables
+def test_edge_shapes(amd, ref_api, Ncam, Nf, W, H, lensmodel):
+    """the smallest boards, one frame, an observation that is all outliers, a weight of
+    exactly 0, many cameras"""
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
+                                     object_width_n=W, object_height_n=H, seed=11, make_outliers=False)
+    oi["observations_board"][0,:,:,2]  = -1.       # the first observation: nothing but outliers
+    oi["observations_board"][-1,0,0,2] = 0.        # a weight of exactly 0
+    oi["do_apply_outlier_rejection"] = False
+    compare_callbacks(amd.optimizer_callback(no_factorization=True, **copy_inputs(oi)),
+                      ref_api.optimizer_callback(no_factorization=True, **copy_inputs(oi)), f"{Ncam}x{Nf} {W}x{H}")
+    if Ncam >= 20:
+        # ... and the solve, through the panel-by-panel Cholesky of a camera block that does not fit the LDS
+        oa, orr = copy_inputs(oi), copy_inputs(oi)
+        sa, sr = amd.optimize(**oa), ref_api.optimize(**orr)
+        assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+
+
 def points_only_problem(api, seed=3, Ncam=3, Np=30, Nfixed=4, lens="LENSMODEL_OPENCV4"):
     """discrete points seen by every camera, NO chessboards: extrinsics and the free
     points are optimized against a few fixed points (the gauge)"""
