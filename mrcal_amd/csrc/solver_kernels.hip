@@ -433,6 +433,81 @@ void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
     rows_generic_row(nd, R, row0 + blockIdx.x*blockDim.x + threadIdx.x, row1, Jp, Ji);
 }
 
+// The same for problems made of such rows (structure from motion: tens of
+// thousands of triangulated pairs against a camera block of a few variables;
+// discrete points only). Every row then adds to the SAME few entries of A and g,
+// and one global atomic per product serializes on them: 5.4 M atomics on 324
+// addresses took 7.8 ms at BASELINE configuration 4. Here a workgroup of 256
+// rows sums its camera-block products in LDS first (per wave, to keep the waves
+// off each other's addresses) and flushes Nc^2 values; the frame/point parts,
+// which are spread out, go straight to memory as before. Nc <= ROWS_LDS_NC
+#define ROWS_LDS_NC 40
+__global__ __launch_bounds__(256)
+void rows_generic_lds_kernel(NormalDims nd, OpRef R, int row0, int row1,
+                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double lds_r[];               // per wave: A[Nc][Nc] | g[Nc]
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Jv = O.Jv;
+    const double* __restrict__ x  = O.x;
+    const int Nc = nd.Nc, per_wave = Nc*Nc + Nc;
+    const int t = threadIdx.x, wave = t >> 6;
+    for(int i = t; i < 4*per_wave; i += 256) lds_r[i] = 0.0;
+    __syncthreads();
+    double* __restrict__ Aw = lds_r + wave*per_wave;
+    double* __restrict__ gw = Aw + Nc*Nc;
+
+    const int r = row0 + blockIdx.x*256 + t;
+    double n2 = 0.0;
+    if(r < row1)
+    {
+        const int p0 = Jp[r], p1 = Jp[r+1];
+        const double xr = x[r];
+        n2 = xr*xr;
+        for(int p = p0; p < p1; p++)
+        {
+            const int    ci = Ji[p];
+            const double vi = Jv[p];
+            if(vi == 0.0) continue;
+            const int si = state_to_SE(nd, ci);
+            if(si >= 0) atomicAdd(&gw[si], vi*xr); else atomicAdd(&O.g[ci], vi*xr);
+            for(int q = p0; q < p1; q++)
+            {
+                const int    cj = Ji[q];
+                const double v  = vi*Jv[q];
+                if(v == 0.0) continue;
+                const int    sj = state_to_SE(nd, cj);
+                if(si >= 0 && sj >= 0)
+                    atomicAdd(&Aw[si*Nc + sj], v);
+                else if(si < 0 && sj >= 0)
+                    atomicAdd(&O.Bt[(size_t)(-si-1)*Nc + sj], v);
+                else if(si < 0 && sj < 0)
+                {
+                    int bi, ai, di, e0i, bj, aj, dj, e0j;
+                    E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
+                    E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
+                    if(bi == bj) atomicAdd(&O.D[(size_t)bi*36 + ai*6 + aj], v);
+                }
+            }
+        }
+    }
+    for(int off=32; off>0; off>>=1) n2 += __shfl_down(n2, off);
+    if((t & 63) == 0 && n2 != 0.0) atomicAdd(&O.scalars[SC_NORM2_X], n2);
+    __syncthreads();
+    for(int i = t; i < per_wave; i += 256)
+    {
+        const double v = (lds_r[i] + lds_r[per_wave + i]) + (lds_r[2*per_wave + i] + lds_r[3*per_wave + i]);
+        if(v == 0.0) continue;
+        if(i < Nc*Nc) atomicAdd(&O.A[i], v);
+        else
+        {
+            const int sc = i - Nc*Nc;
+            atomicAdd(&O.g[(sc < nd.Nie) ? sc : nd.i_state_warp + (sc - nd.Nie)], v);
+        }
+    }
+}
+
 // The Gram assembly and the generic rows in ONE launch (all three kinds of
 // work are independent): workgroups [0, nframe_blocks) take a frame each, the
 // next Nchunks a pair chunk each, the rest 256 generic rows each
@@ -2158,8 +2233,16 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
             rows_from = 2*P.W*P.H*P.Nobs_board;
         }
         if(P.Nmeas > rows_from)
-            hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - rows_from + 63)/64), dim3(64), 0, stream,
-                               nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+        {
+            // many rows on a small camera block: sum in LDS first (rows_generic_lds_kernel)
+            if(nd.Nc <= ROWS_LDS_NC && P.Nmeas - rows_from >= 4096)
+                hipLaunchKernelGGL(rows_generic_lds_kernel, dim3((P.Nmeas - rows_from + 255)/256), dim3(256),
+                                   4*(size_t)(nd.Nc*nd.Nc + nd.Nc)*sizeof(double), stream,
+                                   nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+            else
+                hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - rows_from + 63)/64), dim3(64), 0, stream,
+                                   nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+        }
     }
     return hipGetLastError();
 }
