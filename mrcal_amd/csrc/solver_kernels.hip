@@ -1305,125 +1305,125 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
     return u.d;
 }
-// The 64x64 diagonal block of a panel: L11 L11^T = M11 and X = L11^-1, by ONE
-// wave with no workgroup barriers in the column loops. Lane i owns matrix row i
-// (factorization), then lane c owns column c of X (inversion).
-// Blocked by 16 with DYNAMIC outer loops: a panel of 16 columns sits in
-// registers, the pivot and the multipliers L[c][j] are other lanes' registers
-// (v_readlane, scalar lane index), and the columns to the right are updated in
-// LDS with broadcast reads of the finished panel.
-// (Measured alternatives: 256 threads with a barrier per column, 160 us per
-// panel; the whole 64-column row in registers, fully unrolled, 65 us - 126 KB of
-// straight-line code executed once is instruction-fetch bound. This: ~25 us)
+// The 64x64 diagonal block of a panel: L11 L11^T = M11 and X = L11^-1.
+// One workgroup of 1024 factors the 128x64 matrix [M11; I] by columns, blocked
+// by 16: what the factorization does to rows appended below the matrix is to
+// multiply them by L^-T from the right (the way schur_cholesky_solve_kernel gets
+// L^-1 r out of its rhs row), so the identity comes out as L^-T = X^T. Per panel
+// of 16 columns:
+//   (a) wave 0 factors the 16x16 diagonal block in registers: lane i = row i,
+//       pivots and multipliers by v_readlane
+//   (b) one thread per row below: its 16 entries times L_pp^-T (forward
+//       substitution against the block, read as LDS broadcasts)
+//   (c) every thread: rank-16 update of the columns to the right
+// 3 barriers per panel, 4 panels. (Measured history of this kernel: 256 threads
+// with a barrier per column 160 us; one wave with the whole block in registers,
+// unrolled, 65 us - instruction fetch; one wave blocked by 16 with dynamic loops
+// 53 us - latency, no second wave to hide it. This: 25 us)
 #define LCH_PB 16
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(1024)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
                        double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status)
 {
     if(skip != NULL && *skip) return;
-    __shared__ double L[LCH_NB][LCH_NB+1];              // L[i][j]: lane i walks its row conflict-free
-    __shared__ __attribute__((aligned(16))) double Lt[LCH_NB][LCH_NB+2];    // Lt[j][i] = L[i][j]: 16 rows of a column in one sweep
-    __shared__ double X[LCH_NB][LCH_NB];                // X[i][c]
-    const int lane = threadIdx.x;
-    const int nb = min(LCH_NB, n - j0);
-    // coalesced load into LDS; the block is padded with the identity
-    for(int idx = lane; idx < LCH_NB*LCH_NB; idx += 64)
+    constexpr int NB = LCH_NB, NR = 2*LCH_NB, LD = LCH_NB + 1;
+    __shared__ double A[NR*LD];                 // rows 0..63: the block; rows 64..127: the identity -> L^-T
+    __shared__ double rdiag[LCH_PB];            // 1/L[j][j] of the current panel
+    __shared__ int    notpd;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nb = min(NB, n - j0);
+    if(t == 0) notpd = 0;
+    // the block, padded with the identity (so that a short last panel factors too)
+    for(int idx = t; idx < NB*NB; idx += 1024)
     {
-        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
-        L[i][j] = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
+        const int i = idx / NB, j = idx - i*NB;
+        A[i*LD + j]        = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
+        A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
 
-    bool bad = false;
-    double my_rdiag = 1.0;                              // 1/L[lane][lane]
 #pragma unroll 1
-    for(int base = 0; base < LCH_NB; base += LCH_PB)
+    for(int base = 0; base < NB; base += LCH_PB)
     {
-        double pr[LCH_PB];                              // this lane's row, columns base..base+15
-#pragma unroll
-        for(int jj = 0; jj < LCH_PB; jj++) pr[jj] = L[lane][base + jj];
-        static_for<0,LCH_PB>([&](auto J)
+        // (a)
+        if(wave == 0)
         {
-            constexpr int jj = decltype(J)::value;
-            double piv = readlane_f64(pr[jj], base + jj);
-            bad = bad || !(piv > 0.0);
-            piv = (piv > 0.0) ? piv : 1.0;
-            double rd = __builtin_amdgcn_rsq(piv);
-            rd = rd*(1.5 - 0.5*piv*rd*rd);
-            rd = rd*(1.5 - 0.5*piv*rd*rd);
-            pr[jj] *= rd;                               // lane base+jj: sqrt(piv); lanes below: L[i][j]
-            my_rdiag = (lane == base + jj) ? rd : my_rdiag;     // (a select, not a branch)
-            static_for<jj+1,LCH_PB>([&](auto Cc)
+            const int  r   = (lane < LCH_PB) ? lane : 0;
+            double pr[LCH_PB];
+#pragma unroll
+            for(int c = 0; c < LCH_PB; c++) pr[c] = A[(base + r)*LD + base + c];
+            bool   bad  = false;
+            double myrd = 1.0;
+            static_for<0,LCH_PB>([&](auto J)
             {
-                constexpr int cc = decltype(Cc)::value;
-                pr[cc] -= pr[jj]*readlane_f64(pr[jj], base + cc);
+                constexpr int j = decltype(J)::value;
+                double piv = readlane_f64(pr[j], j);
+                bad = bad || !(piv > 0.0);
+                piv = (piv > 0.0) ? piv : 1.0;
+                double rd = __builtin_amdgcn_rsq(piv);
+                rd = rd*(1.5 - 0.5*piv*rd*rd);
+                rd = rd*(1.5 - 0.5*piv*rd*rd);
+                pr[j] *= rd;
+                myrd = (lane == j) ? rd : myrd;
+                static_for<j+1,LCH_PB>([&](auto Cc)
+                {
+                    constexpr int c = decltype(Cc)::value;
+                    pr[c] -= pr[j]*readlane_f64(pr[j], c);
+                });
             });
-        });
-        // the finished panel, zero above the diagonal
-#pragma unroll
-        for(int jj = 0; jj < LCH_PB; jj++)
-        {
-            const double v = (base + jj <= lane) ? pr[jj] : 0.0;
-            pr[jj] = v;
-            L[lane][base + jj]  = v;
-            Lt[base + jj][lane] = v;
-        }
-        __syncthreads();
-        // columns to the right: L[i][c] -= sum_jj L[i][base+jj] L[c][base+jj]
-#pragma unroll 2
-        for(int c = base + LCH_PB; c < LCH_NB; c++)
-        {
-            double acc = L[lane][c];
-#pragma unroll
-            for(int jj = 0; jj < LCH_PB; jj++) acc -= pr[jj]*L[c][base + jj];      // (uniform address: a broadcast)
-            L[lane][c] = acc;
-        }
-        __syncthreads();
-    }
-
-    // X = L^-1, lane c = column c, 16 rows at a time:
-    //   X[i] = (delta_ic - sum_{k<i} L[i][k] X[k]) / L[i][i]
-#pragma unroll 1
-    for(int base = 0; base < LCH_NB; base += LCH_PB)
-    {
-        double v[LCH_PB];
-#pragma unroll
-        for(int r = 0; r < LCH_PB; r++) v[r] = (lane == base + r) ? 1.0 : 0.0;
-        // the finished rows above
-#pragma unroll 2
-        for(int k = 0; k < base; k++)
-        {
-            const double xk = X[k][lane];
-            const double2* __restrict__ lt = (const double2*)&Lt[k][base];      // L[base+r][k], r = 0..15
-#pragma unroll
-            for(int r2 = 0; r2 < LCH_PB/2; r2++)
+            if(lane < LCH_PB)
             {
-                const double2 l2 = lt[r2];
-                v[2*r2]   -= l2.x*xk;
-                v[2*r2+1] -= l2.y*xk;
+#pragma unroll
+                for(int c = 0; c < LCH_PB; c++) A[(base + lane)*LD + base + c] = (c <= lane) ? pr[c] : 0.0;
+                rdiag[lane] = myrd;
+            }
+            if(bad && lane == 0) notpd = 1;
+        }
+        __syncthreads();
+        // (b) rows base+16 .. 127:  x_c = (a_c - sum_{k<c} x_k L[c][k]) / L[c][c]
+        {
+            const int i = base + LCH_PB + t;
+            if(i < NR)
+            {
+                double xr[LCH_PB];
+#pragma unroll
+                for(int c = 0; c < LCH_PB; c++) xr[c] = A[i*LD + base + c];
+#pragma unroll
+                for(int c = 0; c < LCH_PB; c++)
+                {
+                    double a = xr[c];
+#pragma unroll
+                    for(int k = 0; k < c; k++) a -= xr[k]*A[(base + c)*LD + base + k];
+                    xr[c] = a*rdiag[c];
+                }
+#pragma unroll
+                for(int c = 0; c < LCH_PB; c++) A[i*LD + base + c] = xr[c];
             }
         }
-        static_for<0,LCH_PB>([&](auto Rr)
+        __syncthreads();
+        // (c) A[i][c] -= sum_k L[i][base+k] L[c][base+k]   for c in the columns to the right, i >= c
         {
-            constexpr int r = decltype(Rr)::value;
-            double a = v[r];
-            static_for<0,r>([&](auto Kk) { constexpr int k = decltype(Kk)::value; a -= L[base + r][base + k]*v[k]; });
-            v[r] = a*readlane_f64(my_rdiag, base + r);
-        });
+            const int c0 = base + LCH_PB, ncol = NB - c0, nrow = NR - c0;
+            for(int e = t; e < nrow*ncol; e += 1024)
+            {
+                const int i = c0 + e / ncol, c = c0 + e % ncol;
+                if(c > i) continue;             // (above the diagonal of the block: never read)
+                double acc = 0.0;
 #pragma unroll
-        for(int r = 0; r < LCH_PB; r++)
-        {
-            X[base + r][lane] = v[r];
-            Linv[(base + r)*LCH_NB + lane] = v[r];
+                for(int k = 0; k < LCH_PB; k++) acc += A[i*LD + base + k]*A[c*LD + base + k];
+                A[i*LD + c] -= acc;
+            }
         }
         __syncthreads();
     }
-    for(int idx = lane; idx < LCH_NB*LCH_NB; idx += 64)
+    // L back into the matrix; X[i][k] = (L^-T)[k][i] = row 64+k, column i
+    for(int idx = t; idx < NB*NB; idx += 1024)
     {
-        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
-        if(i < nb && j < nb && j <= i) M[(size_t)(j0+i)*n + j0 + j] = L[i][j];
+        const int i = idx / NB, j = idx - i*NB;
+        if(i < nb && j < nb && j <= i) M[(size_t)(j0+i)*n + j0 + j] = A[i*LD + j];
+        Linv[idx] = (j <= i) ? A[(NB + j)*LD + i] : 0.0;
     }
-    if(bad && lane == 0) atomicExch(status, 1);
+    if(t == 0 && notpd) atomicExch(status, 1);
 }
 
 // rows m0 + 64 b .. of the panel (incl. the rhs row n):  L21 = M21 L11^-T,
@@ -1573,7 +1573,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         const int nb = (n - j0 < LCH_NB) ? n - j0 : LCH_NB;
         const int m0 = j0 + nb;
         double* Lp = Linv + (size_t)p*LCH_NB*LCH_NB;
-        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(64), 0, stream, n, skip, M, j0, Lp, status);
+        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, j0, Lp, status);
         const int nrows = n + 1 - m0;       // rows below, incl. the rhs row
         hipLaunchKernelGGL(lchol_trsm_kernel, dim3((nrows + LCH_NB - 1)/LCH_NB), dim3(256), 0, stream, n, skip, M, j0, Lp);
         if(m0 < n)
