@@ -1527,41 +1527,76 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
                            const double* __restrict__ Linv_all)
 {
     if(skip != NULL && *skip) return;
+    extern __shared__ double zs[];                      // z, n doubles: read by every thread in every panel
     double* __restrict__ z = M + (size_t)n*n;
     __shared__ double part[16][LCH_NB];
     __shared__ double w[LCH_NB];
+    __shared__ double Xs[LCH_NB*LCH_NB];
     const int t = threadIdx.x;
     const int c = t & (LCH_NB-1), slice = t >> 6;       // 16 slices of rows for each of the 64 columns
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    for(int i = t; i < n; i += blockDim.x) zs[i] = z[i];
+    __syncthreads();
     for(int p = npanels-1; p >= 0; p--)
     {
         const int j0 = p*LCH_NB;
         const int nb = min(LCH_NB, n - j0);
         const int m0 = j0 + nb;
-        // w[c] = z[j0+c] - sum_{i >= m0} L[i][j0+c] d[i]
+        // w[c] = z[j0+c] - sum_{i >= m0} L[i][j0+c] d[i].  One workgroup streams the
+        // block column: 24 loads in flight per thread (one at a time, a panel's
+        // column of 1100 rows is 70 dependent memory round trips: this kernel took 318 us)
+        // (this panel's inverse diagonal block into LDS on the way: read from memory
+        //  inside the 64-step product below it was 64 dependent round trips per panel)
+        {
+            const double* __restrict__ X = Linv_all + (size_t)p*LCH_NB*LCH_NB;
+#pragma unroll
+            for(int u = 0; u < LCH_NB*LCH_NB/1024; u++) Xs[t + 1024*u] = X[t + 1024*u];
+        }
         double acc = 0.0;
         if(c < nb)
-            for(int i = m0 + slice; i < n; i += 16) acc += M[(size_t)i*n + j0 + c]*z[i];
+        {
+            const double* __restrict__ col = M + j0 + c;
+            int i = m0 + slice;
+            constexpr int UB = 24;
+            for(; i + 16*(UB-1) < n; i += 16*UB)
+            {
+                double v[UB];
+#pragma unroll
+                for(int u = 0; u < UB; u++) v[u] = col[(size_t)(i + 16*u)*n];
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for(int u = 0; u < UB; u += 2) { a0 += v[u]*zs[i + 16*u]; a1 += v[u+1]*zs[i + 16*(u+1)]; }
+                acc += a0 + a1;
+            }
+            for(; i + 16*3 < n; i += 16*4)
+            {
+                double v[4];
+#pragma unroll
+                for(int u = 0; u < 4; u++) v[u] = col[(size_t)(i + 16*u)*n];
+#pragma unroll
+                for(int u = 0; u < 4; u++) acc += v[u]*zs[i + 16*u];
+            }
+            for(; i < n; i += 16) acc += col[(size_t)i*n]*zs[i];
+        }
         part[slice][c] = acc;
         __syncthreads();
         if(t < LCH_NB)
         {
-            double s = 0.0;
-            for(int k = 0; k < 16; k++) s += part[k][t];
-            w[t] = (t < nb) ? z[j0 + t] - s : 0.0;
+            double sacc = 0.0;
+            for(int k = 0; k < 16; k++) sacc += part[k][t];
+            w[t] = (t < nb) ? zs[j0 + t] - sacc : 0.0;
         }
         __syncthreads();
-        // d_p = L11^-T w:  d[c] = sum_{k >= c} Linv[k][c] w[k]
+        // d_p = L11^-T w:  d[c] = sum_{k >= c} Linv[k][c] w[k]   (Xs: staged below, under the streaming)
         if(t < nb)
         {
-            const double* __restrict__ X = Linv_all + (size_t)p*LCH_NB*LCH_NB;
-            double s = 0.0;
-            for(int k = t; k < nb; k++) s += X[k*LCH_NB + t]*w[k];
-            z[j0 + t] = s;
+            double sacc = 0.0;
+            for(int k = t; k < nb; k++) sacc += Xs[k*LCH_NB + t]*w[k];
+            zs[j0 + t] = sacc;
         }
         __syncthreads();
     }
-    for(int i = t; i < n; i += blockDim.x) z[i] = -z[i];
+    for(int i = t; i < n; i += blockDim.x) z[i] = -zs[i];
 }
 
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
@@ -1582,7 +1617,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
             hipLaunchKernelGGL(lchol_syrk_kernel, dim3(ntile*(ntile+1)/2), dim3(256), 0, stream, n, skip, M, j0, ntile);
         }
     }
-    hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, Linv);
+    hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), (size_t)n*sizeof(double), stream, n, skip, M, Linv);
     return hipGetLastError();
 }
 size_t cholesky_large_workspace_doubles(int n)
