@@ -129,6 +129,16 @@ def main():
         barrier()
         problem.synchronize()
 
+    if not sharded:
+        # clocks, code objects and allocator warm before anything is measured: a
+        # scratch copy of the problem takes a few dozen steps and is thrown away.
+        # (Not the --warmup steps: those belong to the measured solve's trajectory)
+        from mrcal_amd.synthetic import copy_inputs
+        scratch = Problem(**copy_inputs(oi))
+        scratch.run_steps(30, None)
+        scratch.synchronize()
+        scratch.close()
+
     # untimed warmup, then EXACTLY --steps timed steps
     tr = None
     if args.warmup > 0:
