@@ -809,6 +809,94 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
     }
 }
 
+// The same for big camera blocks (splined models: 76 x 76 tiles), where the
+// kernel above is bound by the L2: every wave loads two operands per MFMA and
+// an element of Wt is loaded Nc/16 times. Here a wave takes a STRIP of up to
+// four tiles (bi, bj0 .. bj0+3): one A operand serves four B operands, 5 loads
+// per 4 MFMAs instead of 8. Same slots, same reduction
+#define SYRK_STRIP 4
+#define SYRK_STRIP_UNROLL 8
+__global__ __launch_bounds__(64)
+void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
+                             int slot0, int nslots_total,
+                             const double* __restrict__ Wt, const double* __restrict__ y,
+                             double* __restrict__ Spart)
+{
+    if(skip != NULL && *skip) return;
+    const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
+    // strip -> (bi, first bj)
+    int bi = 0, sidx = blockIdx.x;
+    for(;;) { const int ng = (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP; if(sidx < ng) break; sidx -= ng; bi++; }
+    const int bj0 = bi + SYRK_STRIP*sidx;
+    const int ntile = min(SYRK_STRIP, nb - bj0);
+    const int pair0 = bi*nb - (bi*(bi-1))/2 + (bj0 - bi);          // pair index of (bi, bj0); the strip's follow
+    const int e_begin = e_lo + blockIdx.y*e_per_slice;
+    const int e_end   = min(e_hi, e_begin + e_per_slice);
+
+    const int lane = threadIdx.x;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int ci = 16*bi + cc;
+    const bool oki = ci < nd.Nc;
+    const double* __restrict__ pi = Wt + (oki ? ci : 0);
+    const double* __restrict__ pj[SYRK_STRIP];
+    bool okj[SYRK_STRIP];
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++)
+    {
+        const int cj = 16*(bj0 + q) + cc;
+        okj[q] = (q < ntile) && cj < nd.Nc;
+        pj[q]  = Wt + (okj[q] ? cj : 0);
+    }
+    const bool diag = (bj0 == bi);                                  // tile 0 of the strip is a diagonal tile
+
+    syrk_d4 acc[SYRK_STRIP];
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++) acc[q] = syrk_d4{0.0, 0.0, 0.0, 0.0};
+    syrk_d4 accr = {0.0, 0.0, 0.0, 0.0};
+    for(int e0 = e_begin; e0 < e_end; e0 += 4*SYRK_STRIP_UNROLL)
+    {
+        double a[SYRK_STRIP_UNROLL], b[SYRK_STRIP][SYRK_STRIP_UNROLL], yy[SYRK_STRIP_UNROLL];
+#pragma unroll
+        for(int u=0;u<SYRK_STRIP_UNROLL;u++)
+        {
+            const int  e  = e0 + 4*u + kk;
+            const bool ok = e < e_end;
+            const size_t row = (size_t)(ok ? e : e_begin)*nd.Nc;
+            a[u] = pi[row];
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++) b[q][u] = pj[q][row];
+            yy[u] = (diag && cc == 0) ? y[ok ? e : e_begin] : 0.0;
+            if(!ok || !oki) a[u] = 0.0;
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++) if(!ok || !okj[q]) b[q][u] = 0.0;
+            if(!ok) yy[u] = 0.0;
+        }
+#pragma unroll
+        for(int u=0;u<SYRK_STRIP_UNROLL;u++)
+        {
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[q][u], acc[q], 0, 0, 0);
+            if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
+        }
+    }
+    const int slot = slot0 + blockIdx.y;
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++)
+    {
+        if(q >= ntile) break;
+        double* __restrict__ o = Spart + ((size_t)slot*npairs + pair0 + q)*256;
+#pragma unroll
+        for(int v=0;v<4;v++) o[64*v + lane] = acc[q][v];
+    }
+    if(diag && cc == 0)
+    {
+        double* __restrict__ rpart = Spart + (size_t)nslots_total*npairs*256 + (size_t)slot*nb*16 + 16*bi;
+#pragma unroll
+        for(int v=0;v<4;v++) rpart[kk + 4*v] = accr[v];
+    }
+}
+
 // Dense Cholesky of S (lower triangle valid on input) and the solve S d = -r,
 // one workgroup of 1024 (16 waves). On output r holds d and, if keep_factor,
 // the lower triangle of S holds L.
@@ -2292,10 +2380,18 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
 // multiple of the unrolled k-loop. Both parts (frame blocks, point blocks) get
 // the same number of slots whether or not they are populated
 #define SYRK_TARGET_WAVES 2048
+// workgroups along x of the SYRK launch: tile pairs, or strips of up to SYRK_STRIP of them (big camera blocks)
+static int syrk_grid_x(const NormalDims& nd)
+{
+    const int nb = (nd.Nc + 15)/16;
+    if(nd.Nc <= 256) return nb*(nb+1)/2;
+    int nstrips = 0;
+    for(int bi = 0; bi < nb; bi++) nstrips += (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP;
+    return nstrips;
+}
 static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_per_slice)
 {
-    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
-    int ns = SYRK_TARGET_WAVES / npairs;
+    int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
     if(ns < 1) ns = 1;
     int per = (nrows + ns - 1)/ns;
     per = ((per + 4*SYRK_UNROLL - 1)/(4*SYRK_UNROLL))*(4*SYRK_UNROLL);
@@ -2306,7 +2402,7 @@ static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_p
 size_t schur_partial_doubles(const NormalDims& nd)
 {
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
-    int ns = SYRK_TARGET_WAVES / npairs;
+    int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
     if(ns < 1) ns = 1;
     const size_t nslots = 2*(size_t)ns;
     return nslots*npairs*256 + nslots*nb*16 + 64;
@@ -2330,8 +2426,16 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
     const int nslots = ns[0] + ns[1];
     for(int part = 0, slot0 = 0; part < 2; slot0 += ns[part], part++)
         if(ns[part] > 0)
-            hipLaunchKernelGGL(schur_syrk_mfma_kernel, dim3(npairs, ns[part]), dim3(64), 0, stream,
-                               nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
+        {
+            if(nd.Nc > 256)
+            {
+                hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part]), dim3(64), 0, stream,
+                                   nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
+            }
+            else
+                hipLaunchKernelGGL(schur_syrk_mfma_kernel, dim3(npairs, ns[part]), dim3(64), 0, stream,
+                                   nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
+        }
     {
         const int n = (npairs*256 + nb*16)*SRED_SPLIT;
         hipLaunchKernelGGL(schur_reduce_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
