@@ -28,10 +28,9 @@ CAM_OPENCV8 = (
     np.array((1761.181055, 1761.250444, 1965.706996, 1087.518797,
               -0.01266096516, 0.03590794372, -0.0002547045941, 0.0005275929652,
               0.01968883397, 0.01482863541, -0.0562239888, 0.0500223357)),
-    np.array((1761.181055, 1761.250444, 1965.706996, 1087.518797,
-              -0.01266096516, 0.03590794372, -0.0002547045941, 0.0005275929652,
-              0.01968883397, 0.01482863541, -0.0562239888, 0.0500223357)) * \
-    np.array((1.004, 0.996, 1.003, 0.99, 1.1, 0.9, 1.2, 0.8, 1.05, 0.95, 1.02, 0.98)))
+    np.array((1761., 1761., 1965., 1087.,
+              -0.02, 0.03, 0.0002, 0.0005,
+              0.0196, 0.01, -0.05, 0.04)))
 IMAGERSIZE = (4000, 2200)
 
 
@@ -106,11 +105,14 @@ def make_calibration_problem(api, *,
                              seed              = 0,
                              seed_perturbation = 1.0,
                              camera_spacing    = 0.3,
-                             board_distance    = 4.0):
+                             board_distance    = 4.0,
+                             do_optimize_intrinsics_core = True):
     """Returns (optimization_inputs, truth). optimization_inputs is a dict
     ready for api.optimize(**optimization_inputs); all blocks optimized,
     regularization and outlier rejection on. api: a mrcal_amd._api.Api (any
-    backing library)"""
+    backing library). do_optimize_intrinsics_core=False is what
+    mrcal-calibrate-cameras:638-643 does for the splined models (BASELINE.json's
+    configuration 2)"""
     rng = np.random.RandomState(seed)
     W, H = object_width_n, object_height_n
 
@@ -214,7 +216,7 @@ def make_calibration_problem(api, *,
         imagersizes  = imagersizes,
         calobject_warp = None if warp_true is None else np.zeros((2,)),
         calibration_object_spacing = object_spacing,
-        do_optimize_intrinsics_core        = True,
+        do_optimize_intrinsics_core        = bool(do_optimize_intrinsics_core),
         do_optimize_intrinsics_distortions = intrinsics.shape[1] > 4,
         do_optimize_extrinsics             = Ncameras > 1,
         do_optimize_frames                 = True,

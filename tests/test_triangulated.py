@@ -187,6 +187,88 @@ def test_pair_residual_matches_reference_cpu(ref_api):
     assert irow == x.size and Nsteep > 50
 
 
+def enumerate_pairs(flags):
+    """(i0,i1) of every measurement row, in row order: mrcal.c:5180-5290 (a
+    point's observations are consecutive; bit 0 of the flags = last of its set)"""
+    pairs = []
+    N = len(flags)
+    for i0 in range(N):
+        if flags[i0] & 1: continue
+        for i1 in range(i0+1, N):
+            pairs.append((i0, i1))
+            if flags[i1] & 1: break
+    return pairs
+
+
+def exact_rows(rows, pairs, px, flags, ice, rt):
+    """the mpmath evaluation (mp_triangulated.py) of the given rows: x, and the
+    packed-state gradient wrt (camera 0 extrinsics, camera 1 extrinsics) as
+    present in the row. Rows of outlier pairs are skipped. -> {row: (x, J)}"""
+    import mp_triangulated as M
+    scale = np.array((M.SCALE_ROTATION_CAMERA,)*3 + (M.SCALE_TRANSLATION_CAMERA,)*3)
+    out = {}
+    for r in rows:
+        i0, i1 = pairs[r]
+        if (flags[i0] | flags[i1]) & 2: continue
+        e0, e1 = ice[i0], ice[i1]
+        ex, g0, g1, _ = M.pair_error(px[i0], px[i1], rt[e0] if e0 >= 0 else None, rt[e1] if e1 >= 0 else None)
+        Je = []
+        if e0 >= 0: Je += list(np.array([float(v) for v in g0])*scale)
+        if e1 >= 0: Je += list(np.array([float(v) for v in g1])*scale)
+        out[int(r)] = (float(ex), np.array(Je))
+    return out
+
+
+K_ENVELOPE = 16.   # roundings of the cosine, with margin: observed 5 (x), 3.5 (J)
+
+
+def test_pair_residual_rounding_envelope_cpu(ref_api):
+    """The third opinion behind the small-angle tolerance of the full-size
+    test (test_full_size.py::test_sfm_configuration_full_size): at 3000 points,
+    for the 150 pairs with the smallest residual and 60 random ones, BOTH the
+    reference's rows and the host build of triangulation.hpp are within
+    K eps/|x| (x) and K eps/x^2 relative (J) of the 60-digit evaluation of the
+    same formula. No GPU"""
+    import mp_triangulated as M
+    from test_lens_models_host import HERE
+    import os
+    L = C.CDLL(os.path.join(HERE, "libhostcheck.so"))
+    L.hostcheck_tri_pair_error.restype  = C.c_double
+    L.hostcheck_tri_pair_error.argtypes = [C.c_void_p]*3 + [C.c_void_p]*4
+    oi, _ = sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=3000, seed=6, noise=0.3)
+    oi["do_apply_regularization"] = False
+    oi["do_apply_regularization_unity_cam01"] = False
+    _, x, J, _ = ref_api.optimizer_callback(no_factorization=True, **oi)
+    p = ref_api._ingest(dict(oi), callback=True)
+    px, flags, ice = p.c_tri["px"], p.c_tri["flags"], p.c_tri["icam_extrinsics"]
+    rt = oi["rt_cam_ref"]
+    pairs = enumerate_pairs(flags)
+    assert len(pairs) == x.size
+    rows = list(np.argsort(np.abs(x))[:150]) + list(np.random.RandomState(0).choice(x.size, 60, replace=False))
+    exact = exact_rows(rows, pairs, px, flags, ice, rt)
+    assert len(exact) > 190
+    scale = np.array((M.SCALE_ROTATION_CAMERA,)*3 + (M.SCALE_TRANSLATION_CAMERA,)*3)
+    Nsmall = 0
+    for r, (xe, Je) in exact.items():
+        i0, i1 = pairs[r]
+        e0, e1 = ice[i0], ice[i1]
+        rt0 = np.ascontiguousarray(rt[e0]) if e0 >= 0 else None
+        rt1 = np.ascontiguousarray(rt[e1]) if e1 >= 0 else None
+        d0, d1, conv = np.zeros(6), np.zeros(6), C.c_int(0)
+        xo = L.hostcheck_tri_pair_error(d0.ctypes.data, d1.ctypes.data, C.byref(conv),
+                                        np.ascontiguousarray(px[i0]).ctypes.data, np.ascontiguousarray(px[i1]).ctypes.data,
+                                        rt0.ctypes.data if rt0 is not None else None,
+                                        rt1.ctypes.data if rt1 is not None else None)
+        Jo = np.concatenate(([d0*scale] if e0 >= 0 else []) + ([d1*scale] if e1 >= 0 else []))
+        Jr = J.data[J.indptr[r]:J.indptr[r+1]]
+        tol_x = M.noise_envelope_x(xe, K_ENVELOPE)
+        tol_J = M.noise_envelope_J_rel(xe, K_ENVELOPE)*np.abs(Je).max()
+        assert abs(xo   - xe) <= tol_x and abs(x[r] - xe) <= tol_x, (r, xe, xo, x[r])
+        assert np.abs(Jo - Je).max() <= tol_J and np.abs(Jr - Je).max() <= tol_J, (r, xe)
+        Nsmall += abs(xe) < 1e-4
+    assert Nsmall > 50
+
+
 # ------------------------------------------------------------------ GPU ---
 @pytest.mark.gpu
 @pytest.mark.parametrize("lensmodel", ("LENSMODEL_PINHOLE", "LENSMODEL_OPENCV4"))
