@@ -131,9 +131,10 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     HIP_TRY(hipMemcpy(f->d_Jp, rowptr, ((size_t)Nmeas+1)*sizeof(int32_t), hipMemcpyHostToDevice), ok = false);
     HIP_TRY(hipMemcpy(f->d_Ji, colidx, (size_t)Nnz*sizeof(int32_t),        hipMemcpyHostToDevice), ok = false);
     HIP_TRY(hipMemcpy(f->op.Jv, values, (size_t)Nnz*sizeof(double),        hipMemcpyHostToDevice), ok = false);
-    HIP_TRY(hipMemset(f->op.x, 0, (size_t)(Nmeas > 0 ? Nmeas : 1)*sizeof(double)), ok = false);
+    // (on f->stream: it is a non-blocking stream, which does not order itself behind the null stream's memsets)
+    HIP_TRY(hipMemsetAsync(f->op.x, 0, (size_t)(Nmeas > 0 ? Nmeas : 1)*sizeof(double), f->stream), ok = false);
     HIP_TRY(hipMemcpy(f->d_op, &f->op, sizeof(OpDev), hipMemcpyHostToDevice), ok = false);
-    HIP_TRY(hipMemset(f->F.status, 0, sizeof(int)), ok = false);
+    HIP_TRY(hipMemsetAsync(f->F.status, 0, sizeof(int), f->stream), ok = false);
     if(!ok) { delete f; return NULL; }
 
     // validate the partition: no row may touch two E blocks (checked on the host: cheap)

@@ -384,7 +384,11 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     const Layout Lg = make_layout(dg, sel, *lensmodel, observations_point_triangulated, Nobservations_point_triangulated);
 
     // The MEASUREMENT layout is local to the shard
-    const bool sharded = !(shard_begin_frame <= 0 && (shard_end_frame < 0 || shard_end_frame >= Nframes));
+    // shard_end_frame < 0: the whole problem. Anything else is a shard, even an
+    // empty frame range (a points-only problem under the multi-GPU driver gives
+    // every rank the range (0,0)): only the leader then owns the points, the
+    // triangulated pairs and the regularization rows
+    const bool sharded = shard_end_frame >= 0;
     if(!sharded) is_shard_leader = true;
     std::vector<int> board_sel;
     board_sel.reserve(Nobservations_board);

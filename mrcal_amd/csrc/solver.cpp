@@ -260,6 +260,11 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
         set_error("could not make JtJ positive definite");
         return false;
     }
+    if(!c.done)
+    {
+        set_error("the dog-leg did not terminate within %d trial steps", max_trials);
+        return false;
+    }
     absorb_ctl(P, c);
     P->stats.Niterations     += c.Nsteps_accepted;
     P->stats.Nevaluations    += c.Nevaluations;
@@ -430,6 +435,9 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
     int Noutliers = 0, Noutliers_tri = 0;
     for(;;)
     {
+        // the reference makes a new libdogleg context for every pass
+        // (mrcal.c:6433-6439): the diagonal regularization starts over at 0
+        P->stats.lambda = 0.0;
         if(!run_dogleg(P, prm)) return -1.0;
         if(!P->L.sel.do_apply_outlier_rejection) break;
         bool found;
@@ -627,6 +635,7 @@ bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_terminati
     if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
     // the g^T N g slot is accumulated into, and cleared again by the kernel that consumes it
     HIP_TRY(hipMemsetAsync(P->comm_gng(), 0, sizeof(double), P->stream), return false);
+    P->stats.lambda = 0.0;      // a new run starts unregularized, like a new libdogleg context
     return ctl_reset(P, prm, check_termination != 0);
 }
 

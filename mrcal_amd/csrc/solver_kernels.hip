@@ -2167,7 +2167,11 @@ __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, Solver
     const double expected = -2.0*from.scalars[SC_STEP_GS] - from.scalars[SC_STEP_SNS];
     ctl->expected_improvement = expected;
     const double observed = ctl->norm2_x[ib] - ctl->norm2_x[ia];
-    const double rho = observed/expected;
+    double rho = observed/expected;
+    // a trial point where the cost function is not finite (or a 0/0) is a
+    // rejected step with a shrinking trust region, not a comparison with NaN
+    // that neither accepts nor shrinks
+    if(!(rho == rho) || !(ctl->norm2_x[ia] == ctl->norm2_x[ia])) rho = -1.0;
     double tr = ctl->trustregion;
     if(rho < ctl->trustregion_decrease_threshold)
         tr *= ctl->trustregion_decrease_factor;

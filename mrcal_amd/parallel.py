@@ -194,6 +194,11 @@ class ShardedDogleg:
             self.started = False
             self.run()
             if not self.s.do_outlier_rejection:
+                # the outliers given on input are still reported (mrcal.c:6418-6421)
+                with self.s.context():
+                    st = self.s.outlier_stats(-1.0)
+                    self.comm.sum(st)
+                Noutliers = int(st[0].item())
                 break
             found, Noutliers = self.mark_outliers()
             if not found:
@@ -313,6 +318,10 @@ class ShardedProblem:
         from .resident import Problem
         self.comm = Communicator(group, always=_always_communicate)
         p = _api._ingest(optimization_inputs, callback=False)
+        if len(p.c_tri) > 0:
+            # the outlier logic of triangulated pairs is sequential over the pairs
+            # (mrcal.c:3978-4402) and lives with the single-GPU solve
+            raise NotImplementedError("ShardedProblem: triangulated points are solved on one GPU (mrcal_amd.optimize())")
         ranges = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.comm.world)
         self.frame_range = ranges[self.comm.rank]
         self.problem = Problem(_shard=self.frame_range, _leader=(self.comm.rank == 0),

@@ -720,7 +720,12 @@ static double takeStepFrom(dogleg_operatingPoint_t* pointFrom, double* p_new, do
 
 static int runOptimizer(dogleg_solverContext_t* ctx)
 {
-    const dogleg_parameters2_t* P = ctx->parameters;
+    // oracle-only knob: DOGLEG_RESTATED_TRACE=1 prints the iteration trace even
+    // when the caller did not ask for dogleg_debug (mrcal's verbose also floods
+    // stderr with every observation)
+    dogleg_parameters2_t Ptrace = *ctx->parameters;
+    if(getenv("DOGLEG_RESTATED_TRACE") != NULL) Ptrace.dogleg_debug = 1;
+    const dogleg_parameters2_t* P = &Ptrace;
     double  trustregion = P->trustregion0;
     int     stepCount   = 0;
     double* step_scratch = (double*)malloc((ctx->Nstate>0?ctx->Nstate:1)*sizeof(double));
