@@ -61,7 +61,9 @@ bool lens_supported(int lens_type);
 // parts: which of the evaluation's kernels to queue (the solver splits an
 // evaluation around the board kernel when that kernel is being timed)
 // ZERO: clearing the point's normal equations (needed before REST assembles them; independent of the rest)
-enum { EVAL_PART_PROLOGUE = 1, EVAL_PART_BOARD = 2, EVAL_PART_REST = 4, EVAL_PART_ZERO = 8, EVAL_PART_ALL = 15 };
+// ASSEMBLE: the block normal equations from what was evaluated (the fused solver step does that itself)
+enum { EVAL_PART_PROLOGUE = 1, EVAL_PART_BOARD = 2, EVAL_PART_REST = 4, EVAL_PART_ZERO = 8, EVAL_PART_ASSEMBLE = 16,
+       EVAL_PART_ALL = 31 };
 hipError_t launch_evaluate(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                            int lds_bytes, hipStream_t stream,
                            hipEvent_t ev_j0, hipEvent_t ev_j1, int parts = EVAL_PART_ALL);

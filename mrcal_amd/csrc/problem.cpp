@@ -64,6 +64,8 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
+    hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
+    hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -234,8 +236,74 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         ok = ok && dev_upload(&P->plan.pair_table, ptab.data(),       ptab.size());
         ok = ok && dev_upload(&P->plan.obs_pair,   obs_pair.data(),   obs_pair.size());
         ok = ok && dev_upload(&P->plan.chunk_pair, chunk_pair.data(), chunk_pair.size());
+
+        // The fixed-order reduction of the camera-block part (solver_kernels.hpp):
+        // for every destination - entry of A, of g (S part), |x|^2 - the (pair,
+        // position) sources that add to it, in (pair, position) order
+        // (the splined models have no Grams: nothing is reduced this way)
+        const bool with_grams = (L.lensmodel.type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
+        const int Npairs = with_grams ? (int)pair_rep.size() : 0;
+        if(with_grams && npos > 1024)
+        {
+            set_error("internal error: %d Gram positions per observation", npos);
+            return false;
+        }
+        std::vector<int> pair_chunk_begin(Npairs + 1, 0);
+        for(int c=0;c<P->plan.Nchunks && Npairs > 0;c++) pair_chunk_begin[chunk_pair[c] + 1]++;
+        for(int ip=0;ip<Npairs;ip++) pair_chunk_begin[ip+1] += pair_chunk_begin[ip];
+        const int nA = nd.Nc*nd.Nc, Ndest_all = nA + nd.Nc + 1;
+        std::vector<std::vector<int>> src(Npairs > 0 ? Ndest_all : 0);
+        for(int ip = 0; ip < Npairs; ip++)
+            for(int pos = 0; pos < npos; pos++)
+            {
+                const PairOp op = ptab[(size_t)ip*npos + pos];
+                const int k = op.op & 0xff, code = (ip << 10) | pos;
+                if(k == PAIROP_NORM) src[nA + nd.Nc].push_back(code);
+                else if(k == PAIROP_G)
+                {
+                    const int sc = state_to_SE(nd, op.aux);     // a camera-block variable: S index >= 0
+                    if(sc >= 0) src[nA + sc].push_back(code);
+                }
+                else if(k == PAIROP_A)
+                {
+                    const int a = op.aux & 0xffff, b = op.aux >> 16;
+                    src[a*nd.Nc + b].push_back(code);
+                    if(op.op & PAIROP_MIRROR) src[b*nd.Nc + a].push_back(code);
+                }
+            }
+        std::vector<int> dest_id, dest_begin(1, 0), dest_src;
+        for(int d = 0; d < (int)src.size(); d++)
+        {
+            // |x|^2 is always a destination when there are rows outside the Grams (their partials are added there)
+            if(src[d].empty() && d != nA + nd.Nc) continue;
+            dest_id.push_back(d);
+            dest_src.insert(dest_src.end(), src[d].begin(), src[d].end());
+            dest_begin.push_back((int)dest_src.size());
+        }
+        P->plan.Ndest = (int)dest_id.size();
+        if(dest_id.empty())  dest_id.push_back(0);
+        if(dest_src.empty()) dest_src.push_back(0);
+        ok = ok && dev_upload(&P->plan.dest_id,          dest_id.data(),          dest_id.size());
+        ok = ok && dev_upload(&P->plan.dest_begin,       dest_begin.data(),       dest_begin.size());
+        ok = ok && dev_upload(&P->plan.dest_src,         dest_src.data(),         dest_src.size());
+        ok = ok && dev_upload(&P->plan.pair_chunk_begin, pair_chunk_begin.data(), pair_chunk_begin.size());
+        ok = ok && dev_alloc (&P->plan.chunk_part, with_grams ? (size_t)(P->plan.Nchunks > 0 ? P->plan.Nchunks : 1)*npos : (size_t)1);
+        {
+            const int row0 = 2*P->D.W*P->D.H*Nobs;
+            P->plan.row_part_n = (Nobs > 0 && L.Nmeas > row0) ? (L.Nmeas - row0 + 255)/256 : 0;
+            ok = ok && dev_alloc(&P->plan.row_part, (size_t)(P->plan.row_part_n > 0 ? P->plan.row_part_n : 1));
+            P->plan.qf_part_n = (nd.Nc + nd.NE + 31)/32;
+            ok = ok && dev_alloc(&P->plan.qf_part, (size_t)4*(P->plan.qf_part_n > 0 ? P->plan.qf_part_n : 1));
+        }
     }
     if(!ok) return false;
+    // rows of blocks nobody writes (frames without observations in this shard) must read as zero
+    for(int i=0;i<2;i++)
+    {
+        HIP_TRY(hipMemset(P->op[i].Bt, 0, (size_t)(nd.NE*nd.Nc > 0 ? nd.NE*nd.Nc : 1)*sizeof(double)), return false);
+        HIP_TRY(hipMemset(P->op[i].D,  0, (size_t)(nd.NEb > 0 ? nd.NEb*36 : 1)*sizeof(double)), return false);
+        HIP_TRY(hipMemset(P->op[i].g,  0, (size_t)(nd.Nstate > 0 ? nd.Nstate : 1)*sizeof(double)), return false);
+    }
 
     P->solver_ready = true;
     return true;
@@ -282,8 +350,8 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
             return false);
     if(parts & EVAL_PART_BOARD)
         P->have_jacobian_timing = with_jacobian && P->D.Nobs_board > 0 && e0 != NULL;
-    if(with_normal && (parts & EVAL_PART_REST))
-        HIP_TRY(launch_assemble(P->D, P->nd, P->plan, B, stream), return false);
+    if(with_normal && (parts & EVAL_PART_ASSEMBLE))
+        HIP_TRY(launch_assemble(P->D, P->nd, P->br, P->plan, B, stream), return false);
     return true;
 }
 

@@ -93,43 +93,48 @@ bool ctl_reset(mrcal_amd_problem* P, const DoglegParameters& prm, bool check_ter
     c.trustregion                    = prm.trustregion0;
     c.lambda                         = P->stats.lambda;
     c.ib = P->icur; c.ia = 1 - P->icur;
+    solver_ctl_init_flags(buf.data(), P->icur);
+    HIP_TRY(hipMemsetAsync(P->F.status, 0, sizeof(int), P->stream), return false);
     HIP_TRY(hipMemcpyAsync(P->d_ctl, buf.data(), buf.size(), hipMemcpyHostToDevice, P->stream), return false);
     HIP_TRY(hipStreamSynchronize(P->stream), return false);   // buf goes out of scope
     P->ctl_initialized = true;
     return true;
 }
 
-// x, J, the normal equations, g, |x|^2 and the Cauchy step at the starting point
+Step2Args step2_args(mrcal_amd_problem* P)
+{
+    Step2Args a;
+    a.P = &P->D; a.nd = &P->nd; a.br = &P->br; a.plan = &P->plan;
+    a.ops = P->d_ops; a.ctl = P->d_ctl; a.F = &P->F; a.gram = P->d_gram;
+    a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
+    return a;
+}
+
+// x, J, the normal equations, g, |x|^2, the Cauchy step and (unless the Cauchy
+// step already leaves the trust region) the Gauss-Newton step at the starting point
 bool enqueue_initial_point(mrcal_amd_problem* P)
 {
     const OpRef R = { P->d_ops, &P->d_ctl->ib, NULL };
-    if(!problem_evaluate_ref(P, R, true, true)) return false;
-    // ... and the start of the first trial
-    HIP_TRY(launch_step_finish(P->nd, P->d_ops, P->d_ctl, P->F.status, true, P->stream), return false);
+    if(!problem_evaluate_ref(P, R, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
+    const Step2Args a = step2_args(P);
+    HIP_TRY(launch_step2_assemble(a, true, P->stream), return false);
+    HIP_TRY(launch_step2_solve(a, true, P->stream), return false);
     return true;
 }
 
 // One trial step of the dog-leg, entirely queued: every decision is taken on
-// the device (solver_kernels.hip, "dog-leg control"). segment: 0 = all of it;
+// the device (solver_kernels.hip, "the fused step"). segment: 0 = all of it;
 // 1 = up to the board kernel, 2 = the board kernel alone, 3 = after it
 bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
 {
     SolverCtl* ctl = P->d_ctl;
-    const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval(ctl) };
+    const Step2Args a = step2_args(P);
+    const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
     if(segment == 0 || segment == 1)
     {
-        // (the trial was started by the kernel that ended the previous one: step_finish_kernel)
-        {
-            // the Gauss-Newton step from the current point, if this trial needs it
-            const OpRef R = { P->d_ops, &ctl->ib, solver_ctl_skip_factor(ctl) };
-            HIP_TRY(launch_factor_local(P->nd, P->br, R, P->F, 0.0, ctl, true, P->stream), return false);
-            HIP_TRY(launch_solve_backsub(P->nd, P->br, R, P->F, NULL, false, P->stream), return false);
-        }
-        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, false, 1), return false);
-        // (Running the joint poses and the clearing on a second stream next to this
-        // quadratic form was tried: the cross-stream dependencies cost more than the
-        // ~10 us of overlap they buy, in a graph and eagerly alike)
-        HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, false, 2), return false);
+        // the step from the current point (its Gauss-Newton step, if one is needed, was
+        // computed when the point was accepted); then the joint poses of the trial point
+        HIP_TRY(launch_step2_choose(a, P->stream), return false);
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
     }
     if(segment == 0 || segment == 2)
@@ -137,7 +142,8 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     if(segment == 0 || segment == 3)
     {
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_REST)) return false;
-        HIP_TRY(launch_step_finish(P->nd, P->d_ops, ctl, P->F.status, false, P->stream), return false);
+        HIP_TRY(launch_step2_assemble(a, false, P->stream), return false);
+        HIP_TRY(launch_step2_solve(a, false, P->stream), return false);
     }
     return true;
 }
@@ -229,8 +235,8 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
             const SolverCtl& s = P->h_ctl_ring[slot];
             int st = 0;
             hipMemcpy(&st, P->F.status, sizeof(int), hipMemcpyDeviceToHost);
-            fprintf(stderr, "trial %3d: accepted %3d tr %-10.4g |x|^2 %.10g lambda %-8.3g need_gn %d abort %d chol_status %d step_len %.3g expected %.6g kc %.3g kg %.3g done %d\n",
-                    nqueued, s.Nsteps_accepted, s.trustregion, s.norm2_x[s.ib], s.lambda, s.need_gn, s.abort_step, st,
+            fprintf(stderr, "trial %3d: accepted %3d tr %-10.4g |x|^2 %.10g lambda %-8.3g refactor %d abort %d chol_status %d step_len %.3g expected %.6g kc %.3g kg %.3g done %d\n",
+                    nqueued, s.Nsteps_accepted, s.trustregion, s.norm2_x[s.ib], s.lambda, s.refactor, s.abort_step, st,
                     sqrt(s.step_len_sq), s.expected_improvement, s.k_cauchy, s.k_gn, s.done);
         }
         // look at the newest snapshot that is at least LAG steps old, or any

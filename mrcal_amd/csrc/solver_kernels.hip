@@ -26,6 +26,7 @@
 // and it turns the Schur complement into one SYRK.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 #include "problem.hpp"
 #include "solver_kernels.hpp"
 #include <type_traits>
@@ -61,143 +62,245 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
 // frame-sorted observations, mrcal-pywrap.c:1063-1138). The Grams are read
 // coalesced, position by position; the frame's rows of Bt, its D block and its
 // part of g are accumulated in LDS and written out whole:
-//   D_f  += G[frame,frame]      g_f += G[frame,x]     Bt[frame rows][S cols] += G[S,frame]
+//   D_f  = sum G[frame,frame]      g_f = sum G[frame,x]     Bt[frame rows][S cols] = sum G[S,frame]
+// NO ATOMICS: within one observation every Gram position adds to a different
+// entry (gram_pos_to_entry: each unordered block pair is stored once), so the
+// observations of the frame are applied one after the other, a barrier in
+// between, each thread adding its positions with plain LDS read-modify-writes.
+// The sums therefore do not depend on scheduling: the solve is bit-reproducible.
+//
+// mode 1: from the Grams (the point was just evaluated). mode 2: the blocks are
+// read back from the point (re-elimination with a new lambda).
+// do_factor: the frame is eliminated on the spot, while its blocks are in LDS:
+//   L L^T = D_f + lambda I;  Wt_f = L^-1 Bt_f;  y_f = L^-1 g_f        (what eblock_factor_kernel does)
+// lds_f: Btf[6][Nc] | Df[36] | gf[6] | L[36] | rinv[6]
 __device__ __forceinline__
-void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const OpRef& R, const AssemblyPlan& plan,
-                          const double* __restrict__ gram, int f, double* __restrict__ lds_f)
+void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, const AssemblyPlan& plan,
+                          const double* __restrict__ gram, int f, int mode, bool do_factor, double lambda,
+                          const FactorBuffers& F, double* __restrict__ lds_f)
 {
-    // lds_f: Btf[6][Nc] | Df[36] | gf[6]
-    double* __restrict__ Btf = lds_f;
-    double* __restrict__ Df  = lds_f + 6*nd.Nc;
-    double* __restrict__ gf  = Df + 36;
+    double* __restrict__ Btf  = lds_f;
+    double* __restrict__ Df   = lds_f + 6*nd.Nc;
+    double* __restrict__ gf   = Df + 36;
+    double* __restrict__ Ls   = gf + 6;
+    double* __restrict__ rinv = Ls + 36;
     __shared__ int pair_of[8];                 // the pairs of the 8 observations in flight
     const int t = threadIdx.x;
-    const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
-    if(o0 >= o1) return;                       // not this shard's frame: its rows stay zero
-
-    // What this workgroup will add to at the end, requested now: the chain of
-    // dependent memory round trips is what this kernel's time is made of
-    double* __restrict__ Bt = opref_get(R).Bt;
-    double* __restrict__ D  = opref_get(R).D;
-    double* __restrict__ g  = opref_get(R).g;
     const int e0 = 6*f;   // frame blocks come first in E
-    constexpr int NOLD = 4;                    // 6 Nc / 256 entries of Bt per thread: Nc <= 170 (else the rest is read late)
-    double old_bt[NOLD];
-#pragma unroll
-    for(int u = 0; u < NOLD; u++)
-    {
-        const int i = t + 256*u;
-        old_bt[u] = (i < 6*nd.Nc) ? Bt[(size_t)e0*nd.Nc + i] : 0.0;
-    }
-    const double old_dg = (t < 36) ? D[(size_t)f*36 + t] : (t < 42) ? g[nd.Nie + e0 + (t-36)] : 0.0;
+    double* __restrict__ Bt = O.Bt;
+    double* __restrict__ D  = O.D;
+    double* __restrict__ g  = O.g;
 
-    for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
-
-    const int npos = gram_stride(P.Ndist);
-    for(int ob = o0; ob < o1; ob += 8)
+    if(mode == 1)
     {
-        if(ob > o0) __syncthreads();           // pair_of is free again
-        if(t < 8) pair_of[t] = plan.obs_pair[(ob + t < o1) ? ob + t : o0];
-        __syncthreads();                       // pair_of is there (and, the first time, the accumulators are zero)
-        // 8 Gram loads per position in flight, together with the position's flag and the pair indices
-        for(int pos0 = t; pos0 < npos; pos0 += 2*blockDim.x)
+        const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
+        for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
+        const int npos = gram_stride(P.Ndist);
+        for(int ob = o0; ob < o1; ob += 8)
         {
-            double vv[2][8];
-            int    flag[2];
-#pragma unroll
-            for(int w = 0; w < 2; w++)
+            __syncthreads();                       // pair_of is free again (and, the first time, the accumulators are zero)
+            if(t < 8) pair_of[t] = plan.obs_pair[(ob + t < o1) ? ob + t : o0];
+            __syncthreads();
+            // 8 Gram loads per position in flight, together with the position's flag and the pairs' operations
+            for(int base = 0; base < npos; base += 2*blockDim.x)        // (uniform trip count: barriers inside)
             {
-                const int pos = pos0 + w*blockDim.x;
-                const int pc  = (pos < npos) ? pos : t;
-                flag[w] = (pos < npos) ? plan.pos_table[pc] : 0;
+                const int pos0 = base + t;
+                double vv[2][8];
+                PairOp op[2][8];
+                int    flag[2];
 #pragma unroll
-                for(int u = 0; u < 8; u++)
+                for(int w = 0; w < 2; w++)
                 {
-                    const int o = (ob + u < o1) ? ob + u : o0;
-                    vv[w][u] = gram[(size_t)o*npos + pc];
-                }
-            }
+                    const int pos = pos0 + w*blockDim.x;
+                    const int pc  = (pos < npos) ? pos : t;
+                    flag[w] = (pos < npos) ? plan.pos_table[pc] : 0;
 #pragma unroll
-            for(int w = 0; w < 2; w++)
-            {
-                const int pos = pos0 + w*blockDim.x;
-                if(!(flag[w] & 0x20000)) continue;              // no frame column in this position, for any pair
-                PairOp op[8];
-#pragma unroll
-                for(int u = 0; u < 8; u++) op[u] = plan.pair_table[(size_t)pair_of[u]*npos + pos];
-#pragma unroll
-                for(int u = 0; u < 8; u++)
-                {
-                    if(ob + u >= o1) break;
-                    const double v = vv[w][u];
-                    const int a = op[u].aux & 0xffff, b = op[u].aux >> 16;
-                    switch(op[u].op & 0xff)
+                    for(int u = 0; u < 8; u++)
                     {
-                    case PAIROP_D:
-                        atomicAdd(&Df[a*6 + b], v);
-                        if(op[u].op & PAIROP_MIRROR) atomicAdd(&Df[b*6 + a], v);
-                        break;
-                    case PAIROP_BT: atomicAdd(&Btf[a*nd.Nc + b], v); break;
-                    case PAIROP_GF: atomicAdd(&gf[a], v); break;
-                    default: break;
+                        const int o = (ob + u < o1) ? ob + u : o0;
+                        vv[w][u] = gram[(size_t)o*npos + pc];
+                        op[w][u] = plan.pair_table[(size_t)pair_of[u]*npos + pc];
                     }
                 }
+                // one observation at a time: distinct positions of ONE observation never share a destination
+#pragma unroll
+                for(int u = 0; u < 8; u++)
+                {
+                    if(ob + u < o1)
+                    {
+#pragma unroll
+                        for(int w = 0; w < 2; w++)
+                        {
+                            if(!(flag[w] & 0x20000)) continue;          // no frame column in this position, for any pair
+                            const double v = vv[w][u];
+                            const int a = op[w][u].aux & 0xffff, b = op[w][u].aux >> 16;
+                            switch(op[w][u].op & 0xff)
+                            {
+                            case PAIROP_D:
+                                Df[a*6 + b] += v;
+                                if(op[w][u].op & PAIROP_MIRROR) Df[b*6 + a] += v;
+                                break;
+                            case PAIROP_BT: Btf[a*nd.Nc + b] += v; break;
+                            case PAIROP_GF: gf[a] += v; break;
+                            default: break;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
             }
         }
+        __syncthreads();
+        for(int i = t; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] = Btf[i];
+        if(t < 36)      D[(size_t)f*36 + t]     = Df[t];
+        else if(t < 42) g[nd.Nie + e0 + (t-36)] = gf[t-36];
+    }
+    else
+    {
+        for(int i = t; i < 6*nd.Nc; i += blockDim.x) Btf[i] = Bt[(size_t)e0*nd.Nc + i];
+        if(t < 36)      Df[t]    = D[(size_t)f*36 + t];
+        else if(t < 42) gf[t-36] = g[nd.Nie + e0 + (t-36)];
+        __syncthreads();
+    }
+    if(!do_factor) return;
+
+    // the 6x6 factorization in registers, one thread (eblock_factor_kernel explains why)
+    if(t == 0)
+    {
+        double M[6][6];
+#pragma unroll
+        for(int i=0;i<6;i++)
+#pragma unroll
+            for(int j=0;j<6;j++) M[i][j] = Df[i*6+j] + ((i == j) ? lambda : 0.0);
+        bool ok = true;
+#pragma unroll
+        for(int j=0;j<6;j++)
+        {
+            double d = M[j][j];
+#pragma unroll
+            for(int k=0;k<j;k++) d -= M[j][k]*M[j][k];
+            if(!(d > 0.0)) { ok = false; d = 1.0; }
+            d = sqrt(d);
+            const double rd = 1.0/d;
+            M[j][j] = d;
+            rinv[j] = rd;
+#pragma unroll
+            for(int i=j+1;i<6;i++)
+            {
+                double v = M[i][j];
+#pragma unroll
+                for(int k=0;k<j;k++) v -= M[i][k]*M[j][k];
+                M[i][j] = v*rd;
+            }
+        }
+#pragma unroll
+        for(int i=0;i<6;i++)
+#pragma unroll
+            for(int j=0;j<6;j++) Ls[i*6+j] = (j <= i) ? M[i][j] : 0.0;
+        if(!ok) atomicExch(F.status, 1);
     }
     __syncthreads();
+    if(t < 36) F.LD[(size_t)f*36 + t] = Ls[t];
+    double Lr[6][6], ri[6];
 #pragma unroll
-    for(int u = 0; u < NOLD; u++)
+    for(int i=0;i<6;i++)
     {
-        const int i = t + 256*u;
-        if(i < 6*nd.Nc) Bt[(size_t)e0*nd.Nc + i] = old_bt[u] + Btf[i];
+        ri[i] = rinv[i];
+#pragma unroll
+        for(int k=0;k<6;k++) Lr[i][k] = Ls[i*6+k];
     }
-    for(int i = t + 256*NOLD; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] += Btf[i];
-    if(t < 36)      D[(size_t)f*36 + t]     = old_dg + Df[t];
-    else if(t < 42) g[nd.Nie + e0 + (t-36)] = old_dg + gf[t-36];
+    // forward substitution, one column of [Bt_f | g_f] per thread and pass
+    for(int c = t; c <= nd.Nc; c += blockDim.x)
+    {
+        double w[6];
+#pragma unroll
+        for(int i=0;i<6;i++)
+        {
+            double v = (c < nd.Nc) ? Btf[i*nd.Nc + c] : gf[i];
+#pragma unroll
+            for(int k=0;k<i;k++) v -= Lr[i][k]*w[k];
+            w[i] = v*ri[i];
+        }
+        if(c < nd.Nc) { for(int i=0;i<6;i++) F.Wt[(size_t)(e0+i)*nd.Nc + c] = w[i]; }
+        else          { for(int i=0;i<6;i++) F.y[e0+i] = w[i]; }
+    }
 }
 
-// S-S part: observations that see the same (intrinsics, extrinsics) pair
-// scatter to the same entries of A, so they are summed per pair first: one
-// workgroup per chunk of one pair's observation list, each thread summing its
-// Gram positions over the chunk (coalesced reads), then a few atomics
+// S-S part: observations that see the same (intrinsics, extrinsics) pair add to
+// the same entries of A. One workgroup per chunk of one pair's observation list:
+// each thread sums its Gram positions over the chunk, in order (coalesced reads,
+// 16 in flight), and leaves the sum in chunk_part[chunk][pos]. assemble_finalize()
+// adds the chunks up, again in a fixed order. No atomics
 __device__ __forceinline__
-void reduce_pair_chunk(const DeviceProblem& P, const NormalDims& nd, const OpRef& R, const AssemblyPlan& plan,
+void reduce_pair_chunk(const DeviceProblem& P, const AssemblyPlan& plan,
                        const double* __restrict__ gram, int ichunk)
 {
-    double* __restrict__ A = opref_get(R).A;
-    double* __restrict__ g = opref_get(R).g;
-    double* __restrict__ norm2_x = &opref_get(R).scalars[SC_NORM2_X];
     const int c0 = plan.chunk_begin[ichunk], c1 = plan.chunk_begin[ichunk+1];
-    if(c0 >= c1) return;
     const int npos = gram_stride(P.Ndist);
     const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[ichunk]*npos;
-    // the chunk's observations (at most REDUCE_CHUNK), once; then every load of
-    // a position is independent of everything but these: all in flight together
+    double* __restrict__ out = plan.chunk_part + (size_t)ichunk*npos;
     const int nobs = c1 - c0;
-    size_t base[REDUCE_CHUNK];
-#pragma unroll
-    for(int u = 0; u < REDUCE_CHUNK; u++)
-        base[u] = (size_t)plan.pair_obs[(u < nobs) ? c0 + u : c0]*npos;
     for(int pos = threadIdx.x; pos < npos; pos += blockDim.x)
     {
-        const PairOp op = ops[pos];
-        const int kind = op.op & 0xff;
-        if(kind != PAIROP_A && kind != PAIROP_G && kind != PAIROP_NORM) continue;
-        double vv[REDUCE_CHUNK];
-#pragma unroll
-        for(int u = 0; u < REDUCE_CHUNK; u++) vv[u] = gram[base[u] + pos];
+        const int kind = ops[pos].op & 0xff;
+        if(kind != PAIROP_A && kind != PAIROP_G && kind != PAIROP_NORM) { out[pos] = 0.0; continue; }
         double acc = 0.0;
-#pragma unroll
-        for(int u = 0; u < REDUCE_CHUNK; u++) acc += (u < nobs) ? vv[u] : 0.0;
-        if(kind == PAIROP_NORM)   atomicAdd(norm2_x, acc);
-        else if(kind == PAIROP_G) atomicAdd(&g[op.aux], acc);
-        else
+        for(int u0 = 0; u0 < nobs; u0 += 16)
         {
-            const int a = op.aux & 0xffff, b = op.aux >> 16;
-            atomicAdd(&A[(size_t)a*nd.Nc + b], acc);
-            if(op.op & PAIROP_MIRROR) atomicAdd(&A[(size_t)b*nd.Nc + a], acc);
+            double vv[16];
+#pragma unroll
+            for(int u = 0; u < 16; u++)
+            {
+                const int k = (u0 + u < nobs) ? c0 + u0 + u : c0;
+                vv[u] = gram[(size_t)plan.pair_obs[k]*npos + pos];
+            }
+#pragma unroll
+            for(int u = 0; u < 16; u++) acc += (u0 + u < nobs) ? vv[u] : 0.0;
         }
+        out[pos] = acc;
+    }
+}
+
+// Every destination of the camera-block part - an entry of A, of g (S part) or
+// |x|^2 - adds its sources (chunk partials of the pairs that touch it) in the
+// order of the plan. One thread per destination that has sources. What the rows
+// that do not come from Grams added earlier (atomically, into the zeroed
+// buffers: regularization rows, which have disjoint destinations; discrete
+// points) stays. |x|^2 also takes those rows' per-workgroup partials, in order
+__device__ __forceinline__
+void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const AssemblyPlan& plan,
+                       int k /* index into the destination list */)
+{
+    if(k >= plan.Ndest) return;
+    const int d  = plan.dest_id[k];
+    const int s0 = plan.dest_begin[k], s1 = plan.dest_begin[k+1];
+    double acc = 0.0;
+    for(int s = s0; s < s1; s++)
+    {
+        const int src = plan.dest_src[s];
+        const int pair = src >> 10, pos = src & 1023;
+        const int c0 = plan.pair_chunk_begin[pair], c1 = plan.pair_chunk_begin[pair+1];
+        const double* __restrict__ cp = plan.chunk_part + pos;
+        double a = 0.0;
+        int c = c0;
+        for(; c + 8 <= c1; c += 8)
+        {
+            double v[8];
+#pragma unroll
+            for(int u = 0; u < 8; u++) v[u] = cp[(size_t)(c + u)*npos];
+#pragma unroll
+            for(int u = 0; u < 8; u++) a += v[u];
+        }
+        for(; c < c1; c++) a += cp[(size_t)c*npos];
+        acc += a;
+    }
+    const int nA = nd.Nc*nd.Nc;
+    if(d < nA)              O.A[d] += acc;
+    else if(d < nA + nd.Nc) { const int sc = d - nA; O.g[(sc < nd.Nie) ? sc : nd.i_state_warp + (sc - nd.Nie)] += acc; }
+    else
+    {
+        for(int b = 0; b < plan.row_part_n; b++) acc += plan.row_part[b];
+        O.scalars[SC_NORM2_X] += acc;
     }
 }
 
@@ -208,10 +311,10 @@ void reduce_pair_chunk(const DeviceProblem& P, const NormalDims& nd, const OpRef
 // Rows that do not come from board observations (discrete points,
 // regularization): one lane per CSR row, scattered with atomics. These are few
 __device__ __forceinline__
-void rows_generic_row(const NormalDims& nd, const OpRef& R, int r, int row1,
-                      const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
+                      const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                      double* n2_local = NULL /* if given: x^2 goes there instead of into |x|^2 (atomically) */)
 {
-    const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
     const double* __restrict__ x  = O.x;
     double* __restrict__ A  = O.A;
@@ -222,7 +325,7 @@ void rows_generic_row(const NormalDims& nd, const OpRef& R, int r, int row1,
     if(r >= row1) return;
     const int p0 = Jp[r], p1 = Jp[r+1];
     const double xr = x[r];
-    atomicAdd(norm2_x, xr*xr);
+    if(n2_local) *n2_local = xr*xr; else atomicAdd(norm2_x, xr*xr);
     for(int p = p0; p < p1; p++)
     {
         const int    ci = Ji[p];
@@ -313,7 +416,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         __syncthreads();            // bbox is reused by the next observation
         if(K + SPL_NEXTRA > SPL_TW)
         {
-            for(int r = r0 + t; r < r1; r += blockDim.x) rows_generic_row(nd, R, r, r1, Jp, Ji);
+            for(int r = r0 + t; r < r1; r += blockDim.x) rows_generic_row(nd, O, r, r1, Jp, Ji);
             continue;
         }
         const int NC = K + SPL_NEXTRA;                  // local columns in use
@@ -430,7 +533,7 @@ void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
                          const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
     if(opref_skip(R)) return;
-    rows_generic_row(nd, R, row0 + blockIdx.x*blockDim.x + threadIdx.x, row1, Jp, Ji);
+    rows_generic_row(nd, opref_get(R), row0 + blockIdx.x*blockDim.x + threadIdx.x, row1, Jp, Ji);
 }
 
 // The same for problems made of such rows (structure from motion: tens of
@@ -508,20 +611,70 @@ void rows_generic_lds_kernel(NormalDims nd, OpRef R, int row0, int row1,
     }
 }
 
-// The Gram assembly and the generic rows in ONE launch (all three kinds of
-// work are independent): workgroups [0, nframe_blocks) take a frame each, the
-// next Nchunks a pair chunk each, the rest 256 generic rows each
+// The Gram assembly (+ elimination of the frame blocks) and the generic rows in
+// ONE launch (all three kinds of work are independent): workgroups
+// [0, nframe_blocks) take a frame each, the next Nchunks a pair chunk each, the
+// rest 256 generic rows each.
+//   mode (device flag, or mode_host): 0 nothing; 1 the point *sel_eval was just
+//   evaluated; 2 re-eliminate the point *sel_cur from its stored blocks
 __global__ __launch_bounds__(256)
-void assemble_all_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                         const double* __restrict__ gram, int nframe_blocks,
-                         int row0, int row1, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRanges br, const OpDev* __restrict__ ops,
+                            const int* __restrict__ sel_eval, const int* __restrict__ sel_cur,
+                            const SolverCtl* __restrict__ ctl, const int* __restrict__ skip,
+                            const int* __restrict__ mode_ptr, int mode_host,
+                            int do_factor, double lambda_host,
+                            AssemblyPlan plan, const double* __restrict__ gram, FactorBuffers F,
+                            int nframe_blocks, int row0, int row1,
+                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
-    if(opref_skip(R)) return;
+    if(skip != NULL && *skip) return;
+    const int mode = mode_ptr ? *mode_ptr : mode_host;
+    if(mode == 0) return;
     extern __shared__ double lds_f[];
+    const OpDev& O = ops[(mode == 1) ? (sel_eval ? *sel_eval : 0) : (sel_cur ? *sel_cur : 0)];
+    const double lambda = ctl ? ctl->lambda : lambda_host;
     const int b = blockIdx.x;
-    if(b < nframe_blocks)                     assemble_frame_block(P, nd, R, plan, gram, b, lds_f);
-    else if(b < nframe_blocks + plan.Nchunks) reduce_pair_chunk(P, nd, R, plan, gram, b - nframe_blocks);
-    else rows_generic_row(nd, R, row0 + (b - nframe_blocks - plan.Nchunks)*256 + threadIdx.x, row1, Jp, Ji);
+    if(b < nframe_blocks)
+        assemble_frame_block(P, nd, O, plan, gram, br.frame_lo + b, mode, do_factor != 0, lambda, F, lds_f);
+    else if(mode != 1) return;
+    else if(b < nframe_blocks + plan.Nchunks) reduce_pair_chunk(P, plan, gram, b - nframe_blocks);
+    else
+    {
+        // rows that do not come from board observations; |x|^2 of each workgroup's
+        // rows goes to its slot of row_part, summed in order by assemble_finalize()
+        const int rb = b - nframe_blocks - plan.Nchunks;
+        double n2 = 0.0;
+        rows_generic_row(nd, O, row0 + rb*256 + threadIdx.x, row1, Jp, Ji, &n2);
+        for(int off=32; off>0; off>>=1) n2 += __shfl_down(n2, off);
+        __shared__ double part[4];
+        if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n2;
+        __syncthreads();
+        if(threadIdx.x == 0) plan.row_part[rb] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+}
+
+__global__ __launch_bounds__(64)
+void assemble_finalize_kernel(int npos, NormalDims nd, const OpDev* __restrict__ ops, const int* __restrict__ sel,
+                              const int* __restrict__ skip, AssemblyPlan plan)
+{
+    if(skip != NULL && *skip) return;
+    assemble_finalize(npos, nd, ops[sel ? *sel : 0], plan, blockIdx.x*blockDim.x + threadIdx.x);
+}
+// the same, riding along in the SYRK launch (row nslices of its grid): the two are independent
+struct FinalizeRide
+{
+    int           npos;      // 0: nothing rides along
+    const OpDev*  ops;
+    const int*    sel;
+    const int*    skip;
+    AssemblyPlan  plan;
+};
+__device__ __forceinline__ void finalize_ride(const FinalizeRide& fr, const NormalDims& nd)
+{
+    if(fr.skip != NULL && *fr.skip) return;
+    const OpDev& O = fr.ops[fr.sel ? *fr.sel : 0];
+    for(int k = blockIdx.x*blockDim.x + threadIdx.x; k < fr.plan.Ndest; k += gridDim.x*blockDim.x)
+        assemble_finalize(fr.npos, nd, O, fr.plan, k);
 }
 
 // A, Bt, D, g and the scalars of an operating point, zeroed in one launch
@@ -550,7 +703,7 @@ void zero_normal_kernel(NormalDims nd, OpRef R)
 // One workgroup per E block: L L^T = D_e + lambda I;  Wt_e = L^-1 Bt_e;  y_e = L^-1 g_e.
 // status[0] is set to 1 if any block is not positive definite
 __global__ __launch_bounds__(64)
-void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_host, const SolverCtl* ctl,
+void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
                           int* __restrict__ status)
 {
@@ -563,7 +716,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
 
     __shared__ double L[36];
     __shared__ double rinv[6];
-    const int blk = br.block(blockIdx.x);
+    const int blk = br.block(first + blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
     const int t   = threadIdx.x;
@@ -685,19 +838,16 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, OpRef R, double lambda_
 // triangle is copied.) No atomics anywhere: the result does not depend on the
 // order in which workgroups finish
 #define SRED_SPLIT 4      // threads sharing one output element (adjacent lanes)
-__global__ __launch_bounds__(256)
-void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
-                         int nslots, const double* __restrict__ Spart,
-                         double* __restrict__ S, double* __restrict__ r)
+__device__ __forceinline__
+void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int is_leader,
+                       int nslots, const double* __restrict__ Spart,
+                       double* __restrict__ S, double* __restrict__ r, int block)
 {
-    if(opref_skip(R)) return;
-    const OpDev& O = opref_get(R);
-    const double lambda = is_leader ? (ctl ? ctl->lambda : lambda_host) : 0.0;
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
     // loads in flight; the 64-byte groups they read are still whole cache lines
     // across the wave (16 consecutive elements x SRED_SPLIT slots)
-    const int gid = blockIdx.x*blockDim.x + threadIdx.x;
+    const int gid = block*blockDim.x + threadIdx.x;
     const int sub = (gid >> 4) & (SRED_SPLIT-1);
     const int idx = ((gid >> 6) << 4) | (gid & 15);      // 16 elements per wave
     const int nS  = npairs*256, nTot = nS + nb*16;
@@ -736,6 +886,15 @@ void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const Solve
             r[i] = (is_leader ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0) - acc;
     }
 }
+__global__ __launch_bounds__(256)
+void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
+                         int nslots, const double* __restrict__ Spart,
+                         double* __restrict__ S, double* __restrict__ r)
+{
+    if(opref_skip(R)) return;
+    const double lambda = is_leader ? (ctl ? ctl->lambda : lambda_host) : 0.0;
+    schur_reduce_body(nd, opref_get(R), lambda, is_leader, nslots, Spart, S, r, blockIdx.x);
+}
 
 // Wt^T Wt and Wt^T y on the FP64 matrix cores: one wave per (16x16 tile of S,
 // slice of E rows), v_mfma_f64_16x16x4: with lane l holding
@@ -752,8 +911,9 @@ __global__ __launch_bounds__(64)
 void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
                             int slot0, int nslots_total,
                             const double* __restrict__ Wt, const double* __restrict__ y,
-                            double* __restrict__ Spart)
+                            double* __restrict__ Spart, int nslices, FinalizeRide fr)
 {
+    if((int)blockIdx.y >= nslices) { finalize_ride(fr, nd); return; }
     if(skip != NULL && *skip) return;
     // tile pair p -> (bi <= bj)
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
@@ -820,8 +980,9 @@ __global__ __launch_bounds__(64)
 void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
                              int slot0, int nslots_total,
                              const double* __restrict__ Wt, const double* __restrict__ y,
-                             double* __restrict__ Spart)
+                             double* __restrict__ Spart, int nslices, FinalizeRide fr)
 {
+    if((int)blockIdx.y >= nslices) { finalize_ride(fr, nd); return; }
     if(skip != NULL && *skip) return;
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // strip -> (bi, first bj)
@@ -932,12 +1093,26 @@ __device__ __forceinline__ double row_share_f64(double v)   // lane N of each 16
 }
 typedef double chol_double4_t __attribute__((ext_vector_type(4)));
 
+// The fused step (see "dog-leg control" below) puts the end of a trial - accept
+// or reject, the trust region, does the current point need its Gauss-Newton
+// step - in front of the factorization, in the same launch (FINISH)
+struct SolverCtlFlags;
+struct Step2Dev
+{
+    NormalDims nd; const OpDev* ops; SolverCtl* ctl; SolverCtlFlags* fl;
+    int initial; const double* qf_part; int qf_n;
+};
+__device__ bool step2_finish(const Step2Dev& sd, int* chol_status);        // one workgroup; true: factor
+__device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite);   // one thread
+
+template<bool FINISH>
 __global__ __launch_bounds__(1024)
 void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_factor,
                                  double* __restrict__ S, double* __restrict__ r,
-                                 int* __restrict__ status)
+                                 int* __restrict__ status, Step2Dev sd)
 {
     if(skip != NULL && *skip) return;
+    if constexpr(FINISH) { if(!step2_finish(sd, status)) return; }
     extern __shared__ __attribute__((aligned(16))) double Mp[];
     const int t    = threadIdx.x;
     const int nt   = blockDim.x;
@@ -1289,6 +1464,7 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             if(j <= i) S[(size_t)i*n + j] = rowptr(i)[j];
         }
     CTS();
+    if constexpr(FINISH) { if(t == 0) step2_chol_done(sd, notpd != 0); }
 #ifdef CHOL_TS
     if(t == 0) { printf("chol ts (load | diag0 | b,c per panel ... | backward | store):"); for(int i=1;i<ncts;i++) printf(" %lld", cts[i]-cts[i-1]); printf("\n"); }
 #endif
@@ -1774,17 +1950,13 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
 // of the operating point: v^T N v = v_S^T A v_S + 2 v_E^T (Bt v_S) + v_E^T D v_E.
 // One wave per group of rows of [A ; Bt]; one atomic triple per workgroup
 #define QF_ROWS_PER_WAVE 8
-__global__ __launch_bounds__(256)
-void quadform_kernel(NormalDims nd, OpRef R, const double* __restrict__ v_in, int v_is_g,
-                     double* __restrict__ out_in, int out_in_scalars_at, int nout)
+// this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
+__device__ __forceinline__
+double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block)
 {
-    if(opref_skip(R)) return;
-    const OpDev& O = opref_get(R);
-    const double* __restrict__ v   = v_is_g ? O.g : v_in;
-    double*       __restrict__ out = (out_in != NULL) ? out_in : (O.scalars + out_in_scalars_at);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nrows = nd.Nc + nd.NE;
-    const int row0  = (blockIdx.x*4 + wave)*QF_ROWS_PER_WAVE;
+    const int row0  = (block*4 + wave)*QF_ROWS_PER_WAVE;
 
     // the 8 rows of this wave against v_S, all loads in flight together
     const double* __restrict__ M[QF_ROWS_PER_WAVE];
@@ -1846,8 +2018,20 @@ void quadform_kernel(NormalDims nd, OpRef R, const double* __restrict__ v_in, in
     __shared__ double part[4][3];
     if(lane == 0) { part[wave][0] = t_vNv; part[wave][1] = t_gv; part[wave][2] = t_vv; }
     __syncthreads();
-    if(threadIdx.x < nout)
-        atomicAdd(&out[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if(threadIdx.x < 3)
+        return (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    return 0.0;
+}
+__global__ __launch_bounds__(256)
+void quadform_kernel(NormalDims nd, OpRef R, const double* __restrict__ v_in, int v_is_g,
+                     double* __restrict__ out_in, int out_in_scalars_at, int nout)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ v   = v_is_g ? O.g : v_in;
+    double*       __restrict__ out = (out_in != NULL) ? out_in : (O.scalars + out_in_scalars_at);
+    const double mine = quadform_body(nd, O, v, blockIdx.x);
+    if(threadIdx.x < nout) atomicAdd(&out[threadIdx.x], mine);
 }
 
 __global__ __launch_bounds__(256)
@@ -1936,8 +2120,12 @@ void outlier_stats_kernel(int Npoints_board, double thresh_sq,
 // flags derived from the control state, for the kernels' skip pointers
 //   skip_factor: this trial does not need a factorization
 //   skip_eval:   this trial does not evaluate a new point
-struct SolverCtlFlags { int skip_factor, skip_eval; };
-static_assert(sizeof(SolverCtlFlags) == 8, "");
+//   (the fused step) elim_mode: 0 nothing to eliminate; 1 the trial point was evaluated: its blocks come from the
+//   Grams; 2 the current point is re-eliminated from its stored blocks. elim_sel: which operating point that is.
+//   skip_elim = (elim_mode == 0), skip_asm = (elim_mode != 1); skip_chol / skip_backsub: set by the finish logic
+struct SolverCtlFlags { int skip_factor, skip_eval;
+                        int elim_mode, elim_sel, skip_elim, skip_asm, skip_chol, skip_backsub; };
+static_assert(sizeof(SolverCtlFlags) == 32, "");
 
 // start of a trial step (one thread): does this trial factor, does it evaluate
 __device__ __forceinline__ void ctl_begin(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
@@ -2226,6 +2414,319 @@ void step_finish_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl*
 }
 
 ////////////////////////////////////////////////////////////////////////////////
+// the fused step (single GPU): choose | evaluate | assemble+eliminate | SYRK+finalize
+// | reduce+quadform | finish+Cholesky | backsub.  See solver_kernels.hpp
+////////////////////////////////////////////////////////////////////////////////
+// The Gauss-Newton step is computed EAGERLY: a point that is accepted (and whose
+// Cauchy step does not already leave the trust region) is factored in the launch
+// that accepts it, from the elimination that rode along in its assembly.
+// libdogleg computes it lazily at the start of the next trial; the step taken is
+// the same. ctl->refactor: the current point must be eliminated (again) before a
+// step can be chosen from it - lambda was raised after a failed factorization
+// (libdogleg: "singular JtJ: adding lambda I from now on"), or its Gauss-Newton
+// step is needed after all and was never computed.
+
+__device__ __forceinline__ void ctl_raise_lambda(SolverCtl* ctl)
+{
+    double lam = ctl->lambda;
+    lam = (lam == 0.0) ? 1e-10 : lam*10.0;
+    ctl->lambda = lam;
+    if(!(lam < 1e30)) { ctl->error = 1; ctl->done = 1; }
+}
+
+// Chooses the dog-leg step from the point ctl->ib for the current trust region,
+// writes step and the trial state b[ia] = b[ib] + step; sets the flags of this
+// trial. As step_choose_kernel: every workgroup derives the same coefficients;
+// workgroup 0 records them; fields written here are not read by the other
+// workgroups of this launch
+__global__ __launch_bounds__(256)
+void step2_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
+                         int* __restrict__ chol_status, double* __restrict__ step)
+{
+    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+    if(ctl->done)
+    {
+        if(leader) { fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1; }
+        return;
+    }
+    const int  ib = ctl->ib, ia = ctl->ia;
+    const OpDev& from = ops[ib];
+    const double tr = ctl->trustregion, dsq = tr*tr;
+    const double norm2a = ctl->cauchy_lensq[ib];
+    const bool cauchy_only = norm2a >= dsq;
+    if(ctl->refactor || (!cauchy_only && !ctl->gn_valid[ib]))
+    {
+        // no step can be chosen: this trial eliminates the current point (again)
+        if(leader)
+        {
+            ctl->refactor = 1; ctl->abort_step = 1;
+            *chol_status = 0;
+            fl->skip_eval = 1; fl->elim_mode = 2; fl->elim_sel = ib; fl->skip_elim = 0; fl->skip_asm = 1;
+        }
+        return;
+    }
+    const bool fresh_gn = !cauchy_only && ctl->gn_fresh != 0;
+
+    // |step_gn|^2, step_gn . step_cauchy, step_gn . g of a fresh Gauss-Newton step:
+    // every workgroup sums the whole vectors itself, in the same fixed order
+    __shared__ double dots[3];
+    if(fresh_gn)
+    {
+        double a = 0.0, b = 0.0, c = 0.0;
+        constexpr int UB = 6;
+        for(int i0 = threadIdx.x; i0 < nd.Nstate; i0 += UB*blockDim.x)
+        {
+            double vg[UB], vc[UB], vx[UB];
+#pragma unroll
+            for(int u = 0; u < UB; u++)
+            {
+                const int  i  = i0 + u*blockDim.x;
+                const bool ok = i < nd.Nstate;
+                const int  ic = ok ? i : 0;
+                vg[u] = ok ? from.step_gn[ic] : 0.0;
+                vc[u] = from.step_cauchy[ic];
+                vx[u] = from.g[ic];
+            }
+#pragma unroll
+            for(int u = 0; u < UB; u++)
+            {
+                a += vg[u]*vg[u];
+                b += vg[u]*vc[u];
+                c += vg[u]*vx[u];
+            }
+        }
+        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
+        __shared__ double part[4][3];
+        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
+        __syncthreads();
+        if(threadIdx.x < 3)
+            dots[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        __syncthreads();
+        if(leader) { from.scalars[SC_GN_LENSQ] = dots[0]; from.scalars[SC_GN_DOT_CAUCHY] = dots[1]; }
+        if(!(dots[0] == dots[0]))
+        {
+            // a Gauss-Newton step that is not a number: treat the factorization as failed
+            if(leader)
+            {
+                ctl_raise_lambda(ctl);
+                ctl->refactor = 1; ctl->abort_step = 1; ctl->gn_valid[ib] = 0;
+                *chol_status = 0;
+                fl->skip_eval = 1; fl->elim_mode = ctl->done ? 0 : 2; fl->elim_sel = ib;
+                fl->skip_elim = ctl->done ? 1 : 0; fl->skip_asm = 1;
+            }
+            return;
+        }
+    }
+    const double gn_lensq_now = fresh_gn ? dots[0] : ctl->gn_lensq[ib];
+    const double gn_dot_now   = fresh_gn ? dots[1] : from.scalars[SC_GN_DOT_CAUCHY];
+
+    double kc, kg, len_sq;
+    int edge;
+    double norm2b = 0.0, ab = 0.0;
+    if(cauchy_only)
+    {
+        kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
+    }
+    else
+    {
+        norm2b = gn_lensq_now;
+        ab     = gn_dot_now;
+        if(norm2b <= dsq)
+        {
+            kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
+        }
+        else
+        {
+            // point on the Cauchy->GN segment at the trust-region edge:
+            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
+            const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
+            const double neg_c = norm2a - ab;                // a.(a-b)
+            double disc = neg_c*neg_c - l2*(norm2a - dsq);
+            if(disc < 0.0) disc = 0.0;
+            const double k = (neg_c + sqrt(disc))/l2;
+            kc = 1.0 - k; kg = k;
+            len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
+            edge = 1;
+        }
+    }
+
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i < nd.Nstate)
+    {
+        double sv = kc*from.step_cauchy[i];
+        if(kg != 0.0) sv += kg*from.step_gn[i];
+        step[i] = sv;
+        ops[ia].b[i] = from.b[i] + sv;
+    }
+
+    if(leader)
+    {
+        if(fresh_gn)
+        {
+            ctl->gn_lensq[ib] = norm2b;
+            ctl->gn_dot_g[ib] = dots[2];
+        }
+        // the expected improvement -2 g.s - s^T N s from dot products (step_choose_kernel explains)
+        {
+            const double gNg = from.scalars[SC_G_GNG], gg = from.scalars[SC_G_GG];
+            const double k   = (gNg > 0.0) ? -gg/gNg : 0.0;
+            double sNs = kc*kc*k*k*gNg, gs = kc*k*gg;
+            if(kg != 0.0)
+            {
+                const double a = fresh_gn ? dots[2] : ctl->gn_dot_g[ib], lam = ctl->gn_lambda[ib];
+                sNs += 2.0*kc*kg*(-k*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
+                gs  += kg*a;
+            }
+            from.scalars[SC_STEP_SNS] = sNs;
+            from.scalars[SC_STEP_GS]  = gs;
+            from.scalars[SC_STEP_SS]  = len_sq;
+        }
+        ctl->k_cauchy = kc; ctl->k_gn = kg;
+        ctl->step_len_sq = len_sq;
+        ctl->did_step_to_edge[ib] = edge;
+        ctl->abort_step = 0;
+        ctl->Ntrials++;
+        *chol_status = 0;
+        if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
+        {
+            ctl->done = 1;
+            fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1;
+        }
+        else
+        {
+            fl->skip_eval = 0; fl->elim_mode = 1; fl->elim_sel = ia; fl->skip_elim = 0; fl->skip_asm = 0;
+        }
+    }
+}
+
+// S, r of the point being eliminated (reduction of the SYRK's slots) and, side by
+// side in the same launch, the quadratic form g^T N g of the point just evaluated
+// (per-workgroup partials into qf_part: no atomics)
+__global__ __launch_bounds__(256)
+void step2_reduce_quadform_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                                  const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
+                                  int nslots, const double* __restrict__ Spart,
+                                  double* __restrict__ S, double* __restrict__ r, double* __restrict__ qf_part)
+{
+    if(fl->skip_elim) return;
+    const OpDev& O = ops[fl->elim_sel];
+    if((int)blockIdx.x < nred)
+    {
+        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, is_leader, nslots, Spart, S, r, blockIdx.x);
+        return;
+    }
+    if(fl->skip_asm) return;
+    const int qb = blockIdx.x - nred;
+    const double mine = quadform_body(nd, O, O.g, qb);
+    if(threadIdx.x < 3) qf_part[4*qb + threadIdx.x] = mine;
+}
+
+// End of a trial, in ONE workgroup, in front of the factorization: the Cauchy
+// step -(|g|^2/|Jg|^2) g of the point just evaluated, the rho test with
+// accept/reject (ctl_accept), the termination tests; then: does the (possibly new)
+// current point need its Gauss-Newton step now? Returns that, to every thread
+__device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
+{
+    const NormalDims& nd = sd.nd;
+    SolverCtl* ctl = sd.ctl;
+    SolverCtlFlags* fl = sd.fl;
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int mode = fl->elim_mode;
+    __shared__ double s_part[16][2];
+    __shared__ double s_tot[2];
+    __shared__ int    s_go;
+    const int ip = sd.initial ? ctl->ib : ctl->ia;        // the point that was evaluated (mode 1)
+    if(mode == 1)
+    {
+        const OpDev& O = sd.ops[ip];
+        double a = 0.0, b = 0.0;
+        for(int i = t; i < sd.qf_n; i += nt) { a += sd.qf_part[4*i]; b += sd.qf_part[4*i + 1]; }
+        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+        if((t & 63) == 0) { s_part[t >> 6][0] = a; s_part[t >> 6][1] = b; }
+        __syncthreads();
+        if(t < 2)
+        {
+            double v = 0.0;
+            for(int k = 0; k < (nt >> 6); k++) v += s_part[k][t];
+            s_tot[t] = v;
+        }
+        __syncthreads();
+        const double gNg = s_tot[0], norm2_g = s_tot[1];
+        const double norm2_x = O.scalars[SC_NORM2_X];
+        const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
+        for(int i = t; i < nd.Nstate; i += nt) O.step_cauchy[i] = k*O.g[i];
+        __syncthreads();                  // everyone has read the control state
+        if(t == 0)
+        {
+            O.scalars[SC_G_GNG] = gNg; O.scalars[SC_G_GG] = norm2_g; O.scalars[SC_G_GG2] = norm2_g;
+            ctl->norm2_x[ip]      = norm2_x;
+            ctl->cauchy_lensq[ip] = k*k*norm2_g;
+            ctl->gn_valid[ip]     = 0;
+            ctl->did_step_to_edge[ip] = 0;
+            ctl->Nevaluations++;
+            if(!sd.initial) ctl_accept(sd.ops, ctl);
+        }
+    }
+    if(t == 0)
+    {
+        int go = 0;
+        ctl->gn_fresh = 0;
+        if(!ctl->done && ctl->check_termination && ctl->Nsteps_accepted >= ctl->max_iterations)
+            ctl->done = 1;
+        if(!ctl->done)
+        {
+            const int ib = ctl->ib;
+            const double tr = ctl->trustregion;
+            if(mode == 2)      go = 1;
+            else if(mode == 1) go = (ib == ip) && !ctl->gn_valid[ib] && !(ctl->cauchy_lensq[ib] >= tr*tr);
+        }
+        if(go && *chol_status != 0)
+        {
+            // a 6x6 (3x3) block was not positive definite: regularize, like libdogleg does
+            ctl_raise_lambda(ctl);
+            ctl->refactor = 1;
+            go = 0;
+        }
+        if(go) ctl->Nfactorizations++;
+        fl->skip_backsub = 1;             // until the factorization has succeeded
+        fl->skip_chol    = go ? 0 : 1;
+        s_go = go;
+    }
+    __syncthreads();
+    return s_go != 0;
+}
+__device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite)
+{
+    SolverCtl* ctl = sd.ctl;
+    if(not_positive_definite)
+    {
+        ctl_raise_lambda(ctl);
+        ctl->refactor = 1;
+        sd.fl->skip_backsub = 1;
+    }
+    else
+    {
+        const int ib = ctl->ib;
+        ctl->refactor      = 0;
+        ctl->gn_valid[ib]  = 1;
+        ctl->gn_lambda[ib] = ctl->lambda;
+        ctl->gn_fresh      = 1;
+        sd.fl->skip_backsub = 0;
+    }
+}
+// the same around the multi-launch Cholesky of big camera blocks
+__global__ __launch_bounds__(1024)
+void step2_finish_kernel(Step2Dev sd, int* chol_status)
+{
+    (void)step2_finish(sd, chol_status);
+}
+__global__ __launch_bounds__(64)
+void step2_post_kernel(Step2Dev sd, const int* __restrict__ chol_status)
+{
+    if(threadIdx.x == 0 && !sd.fl->skip_chol) step2_chol_done(sd, *chol_status != 0);
+}
+
+////////////////////////////////////////////////////////////////////////////////
 // the sharded step: staging of what is summed over the shards
 ////////////////////////////////////////////////////////////////////////////////
 // The trust-region logic runs replicated: every rank executes the same control
@@ -2331,8 +2832,18 @@ hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t 
     hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, R);
     return hipGetLastError();
 }
-// the point's normal equations must have been cleared (launch_zero_normal)
-hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
+static size_t assemble_lds_bytes(const NormalDims& nd) { return (size_t)(6*nd.Nc + 42 + 48)*sizeof(double); }
+static int    assemble_row_blocks(const DeviceProblem& P)
+{
+    const int row0 = 2*P.W*P.H*P.Nobs_board;
+    return (P.Nmeas > row0) ? (P.Nmeas - row0 + 255)/256 : 0;
+}
+// The block normal equations of a point that was just evaluated, from the Grams
+// (or row by row where there are none). The point's normal equations must have
+// been cleared (launch_zero_normal / the prologue's side workgroups).
+//   board problems with Grams: assemble_factor_kernel (frames | pair chunks | generic rows), then
+//   assemble_finalize (here: its own launch; in the fused step it rides along in the SYRK launch)
+hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream)
 {
     // splined models: no per-observation Gram; every row goes through the generic path
@@ -2340,11 +2851,14 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const A
     const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nobs_board > 0 && !by_rows)
     {
-        const int nframe_blocks = P.do_optimize_frames ? P.Nframes : 0;
-        const int nrow_blocks   = (P.Nmeas > row0) ? (P.Nmeas - row0 + 255)/256 : 0;
-        hipLaunchKernelGGL(assemble_all_kernel, dim3(nframe_blocks + plan.Nchunks + nrow_blocks), dim3(256),
-                           (6*nd.Nc + 42)*sizeof(double), stream, P, nd, B.R, plan, B.gram, nframe_blocks,
-                           row0, P.Nmeas, B.Jp, B.Ji);
+        const int nframe_blocks = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
+        FactorBuffers none; memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks + assemble_row_blocks(P)), dim3(256),
+                           assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
+                           (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, row0, P.Nmeas, B.Jp, B.Ji);
+        if(plan.Ndest > 0)
+            hipLaunchKernelGGL(assemble_finalize_kernel, dim3((plan.Ndest + 63)/64), dim3(64), 0, stream,
+                               gram_stride(P.Ndist), nd, B.R.ops, B.R.sel, B.R.skip, plan);
     }
     else
     {
@@ -2412,14 +2926,11 @@ size_t schur_partial_doubles(const NormalDims& nd)
     return nslots*npairs*256 + nslots*nb*16 + 64;
 }
 
-hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
-                               const OpRef& R, const FactorBuffers& F,
-                               double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream)
+// the SYRK of the local E rows (two contiguous ranges: frames, points) into
+// Spart; ride (optional): assemble_finalize() in an extra row of the first launch
+static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* skip, const FactorBuffers& F,
+                       const FinalizeRide* ride, hipStream_t stream)
 {
-    if(br.count() > 0)
-        hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
-                           nd, br, R, lambda, ctl, F.Wt, F.LD, F.y, F.status);
-    // the E rows of the local blocks: two contiguous ranges (frames, points)
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     int e_lo[2], e_hi[2], ns[2] = {0,0}, per[2] = {0,0};
     for(int part = 0; part < 2; part++)
@@ -2428,18 +2939,37 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
         if(e_hi[part] > e_lo[part]) syrk_slicing(nd, e_hi[part] - e_lo[part], &ns[part], &per[part]);
     }
     const int nslots = ns[0] + ns[1];
+    FinalizeRide none; memset(&none, 0, sizeof(none));
+    bool rode = false;
     for(int part = 0, slot0 = 0; part < 2; slot0 += ns[part], part++)
         if(ns[part] > 0)
         {
+            const bool with_ride = (ride != NULL && !rode);
+            const FinalizeRide& fr = with_ride ? *ride : none;
+            const int extra = with_ride ? 1 : 0;
+            rode = rode || with_ride;
             if(nd.Nc > 256)
-            {
-                hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part]), dim3(64), 0, stream,
-                                   nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
-            }
+                hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
+                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
             else
-                hipLaunchKernelGGL(schur_syrk_mfma_kernel, dim3(npairs, ns[part]), dim3(64), 0, stream,
-                                   nd, R.skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart);
+                hipLaunchKernelGGL(schur_syrk_mfma_kernel, dim3(npairs, ns[part] + extra), dim3(64), 0, stream,
+                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
         }
+    if(ride != NULL && !rode && ride->plan.Ndest > 0)
+        hipLaunchKernelGGL(assemble_finalize_kernel, dim3((ride->plan.Ndest + 63)/64), dim3(64), 0, stream,
+                           ride->npos, nd, ride->ops, ride->sel, ride->skip, ride->plan);
+    return nslots;
+}
+
+hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
+                               const OpRef& R, const FactorBuffers& F,
+                               double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream)
+{
+    if(br.count() > 0)
+        hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
+                           nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status);
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    const int nslots = launch_syrk(nd, br, R.skip, F, NULL, stream);
     {
         const int n = (npairs*256 + nb*16)*SRED_SPLIT;
         hipLaunchKernelGGL(schur_reduce_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
@@ -2458,8 +2988,11 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
         const int n = nd.Nc;
         const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
         if(lds <= 160*1024 - 4096 && n <= 256)
-            hipLaunchKernelGGL(schur_cholesky_solve_kernel, dim3(1), dim3(1024), lds, stream,
-                               n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status);
+        {
+            Step2Dev none; memset(&none, 0, sizeof(none));
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel<false>, dim3(1), dim3(1024), lds, stream,
+                               n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status, none);
+        }
         else if(F.Linv != NULL)
             launch_cholesky_large(n, R.skip, F.S, F.Linv, F.status, stream);
         else
@@ -2517,6 +3050,14 @@ static SolverCtlFlags* ctl_flags(SolverCtl* ctl) { return (SolverCtlFlags*)(ctl 
 const int* solver_ctl_skip_factor(const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_factor; }
 const int* solver_ctl_skip_eval  (const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
 size_t     solver_ctl_bytes() { return sizeof(SolverCtl) + sizeof(SolverCtlFlags); }
+// host image of [ctl | flags] before a run: the first thing the fused step does is
+// the assembly + elimination of the starting point icur
+void       solver_ctl_init_flags(void* ctl_image, int icur)
+{
+    SolverCtlFlags* fl = (SolverCtlFlags*)((SolverCtl*)ctl_image + 1);
+    memset(fl, 0, sizeof(*fl));
+    fl->elim_mode = 1; fl->elim_sel = icur; fl->skip_chol = 1; fl->skip_backsub = 1;
+}
 
 // parts: 1 = the step (dot products, coefficients, b[ia] = b[ib] + step), 2 = its
 // quadratic form for the expected improvement
@@ -2591,6 +3132,96 @@ hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, Solv
 {
     hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
                        nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, gng);
+    return hipGetLastError();
+}
+
+// ---- the fused step
+const int* solver_ctl_skip_eval2(const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
+
+hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream)
+{
+    const NormalDims& nd = *a.nd;
+    hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
+                       nd, a.ops, a.ctl, ctl_flags(a.ctl), a.F->status, a.step);
+    return hipGetLastError();
+}
+
+// the block normal equations of the point the flags name, and the elimination of its frame/point blocks
+hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream)
+{
+    const DeviceProblem& P = *a.P;
+    const NormalDims& nd = *a.nd;
+    const BlockRanges& br = *a.br;
+    SolverCtlFlags* fl = ctl_flags(a.ctl);
+    const int* sel_eval = initial ? &a.ctl->ib : &a.ctl->ia;
+    const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
+    int nframes_fused = 0;
+    if(P.Nobs_board > 0 && !by_rows)
+    {
+        const int row0 = 2*P.W*P.H*P.Nobs_board;
+        nframes_fused = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks + assemble_row_blocks(P)), dim3(256),
+                           assemble_lds_bytes(nd), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
+                           &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, row0, P.Nmeas, a.Jp, a.Ji);
+    }
+    else
+    {
+        // no Grams (splined models, problems without boards): the atomic row-by-row assembly of the evaluated point
+        EvalBuffers B; memset(&B, 0, sizeof(B));
+        B.R = OpRef{ a.ops, sel_eval, &fl->skip_asm }; B.Jp = (int32_t*)a.Jp; B.Ji = (int32_t*)a.Ji;
+        launch_assemble(P, nd, br, *a.plan, B, stream);
+    }
+    // the blocks the fused kernel did not eliminate: all of them on the row-by-row
+    // path; the point blocks otherwise (their rows are accumulated in the same launch)
+    const int nrest = br.count() - nframes_fused;
+    if(nrest > 0)
+    {
+        const OpRef R = { a.ops, &fl->elim_sel, &fl->skip_elim };
+        hipLaunchKernelGGL(eblock_factor_kernel, dim3(nrest), dim3(64), 0, stream,
+                           nd, br, nframes_fused, R, 0.0, a.ctl, a.F->Wt, a.F->LD, a.F->y, a.F->status);
+    }
+    return hipGetLastError();
+}
+
+// SYRK (+ finalize of A, g, |x|^2) | S, r + g^T N g | finish + Cholesky | back-substitution
+hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stream)
+{
+    const DeviceProblem& P = *a.P;
+    const NormalDims& nd = *a.nd;
+    const BlockRanges& br = *a.br;
+    const FactorBuffers& F = *a.F;
+    SolverCtlFlags* fl = ctl_flags(a.ctl);
+    const bool with_grams = P.Nobs_board > 0 && P.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC;
+    FinalizeRide ride; memset(&ride, 0, sizeof(ride));
+    if(with_grams && a.plan->Ndest > 0)
+    {
+        ride.npos = gram_stride(P.Ndist); ride.ops = a.ops; ride.sel = &fl->elim_sel; ride.skip = &fl->skip_asm; ride.plan = *a.plan;
+    }
+    const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream);
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    const int nred = ((npairs*256 + nb*16)*SRED_SPLIT + 255)/256;
+    const int nqf  = quadform_blocks(nd);
+    hipLaunchKernelGGL(step2_reduce_quadform_kernel, dim3(nred + nqf), dim3(256), 0, stream,
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, a.plan->qf_part);
+    Step2Dev sd;
+    sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0;
+    sd.qf_part = a.plan->qf_part; sd.qf_n = nqf;
+    {
+        const int n = nd.Nc;
+        const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
+        if(lds <= 160*1024 - 4096 && n <= 256)
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel<true>, dim3(1), dim3(1024), lds, stream,
+                               n, (const int*)NULL, 0, F.S, F.r, F.status, sd);
+        else
+        {
+            hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
+            launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream);
+            hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
+        }
+    }
+    const OpRef Rcur = { a.ops, &a.ctl->ib, NULL };
+    hipLaunchKernelGGL(backsub_kernel, dim3(br.count()+1), dim3(64), 0, stream,
+                       nd, br, Rcur, &fl->skip_backsub, F.Wt, F.LD, F.y, F.r);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ enum { PAIROP_NONE = 0,
        PAIROP_MIRROR = 0x100 };
 struct PairOp { int op, aux; };
 
-#define REDUCE_CHUNK 16     // observations of one pair summed by one workgroup of reduce_pairs_kernel
+#define REDUCE_CHUNK 64     // observations of one pair summed by one workgroup (reduce_pair_chunk), in batches of 16 loads
 struct AssemblyPlan
 {
     int* frame_obs_begin;  // [Nframes+1]
@@ -103,6 +103,23 @@ struct AssemblyPlan
     // bit 31 valid, bit 17 "involves a frame column", bit 16 "in a diagonal block", bits 8..15 i, bits 0..7 j
     int*    pos_table;     // [gram_stride]
     PairOp* pair_table;    // [Npairs][gram_stride]
+    // Fixed-order reduction of the camera-block part (no atomics: the sums do
+    // not depend on scheduling). reduce_pair_chunk() leaves one partial sum per
+    // (chunk, Gram position); assemble_finalize() then adds, for every
+    // destination (an entry of A, of g, or |x|^2), its sources in a fixed order:
+    //   dest_id[k]    destination: [0,Nc^2) entry of A, then Nc entries of g (S index), then |x|^2
+    //   dest_begin[k] .. dest_begin[k+1]: its sources in dest_src, each pair << 10 | pos
+    //   pair_chunk_begin[pair] .. [pair+1]: the chunks of a pair (contiguous)
+    double* chunk_part;       // [Nchunks][gram_stride]
+    int*    dest_id;          // [Ndest]
+    int*    dest_begin;       // [Ndest+1]
+    int*    dest_src;         // [dest_begin[Ndest]]
+    int*    pair_chunk_begin; // [Npairs+1]
+    int     Ndest;
+    double* row_part;         // [row_part_n] per-workgroup partial |x|^2 of the rows that do not come from board Grams
+    int     row_part_n;
+    double* qf_part;          // [qf_part_n][4] per-workgroup partials of the quadratic form g^T N g (and g.g)
+    int     qf_part_n;
 };
 
 // state index -> S index (>=0) or -(1 + E index)
@@ -177,11 +194,14 @@ struct SolverCtl
 
     // counters
     int    Nsteps_accepted, Ntrials, Nfactorizations, Nevaluations;
+
+    // (the fused step, launch_step2_*)
+    int    refactor;            // the current point must be (re-)eliminated before a step can be chosen:
+                                // lambda was just raised, or its Gauss-Newton step was never computed
+    int    gn_fresh;            // step_gn of the current point was just computed: its dot products are not known yet
 };
 
 hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t stream);
-hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const AssemblyPlan& plan,
-                           const EvalBuffers& B, hipStream_t stream);
 hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
                                const OpRef& R, const FactorBuffers& F,
                                double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream);
@@ -228,8 +248,35 @@ hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& 
 hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
                                 const int32_t* Jp, const int32_t* Ji, hipStream_t stream);
 
+// ---- The fused trial step (single GPU; solver.cpp enqueue_trial_step()). Per trial, in this order:
+//   choose            the dog-leg step from the current point, b_trial                 (launch_step2_choose)
+//   [prologue, board] x, J, Grams at the trial point                                   (launch_evaluate)
+//   assemble+factor   block normal equations of the trial point from the Grams, in a fixed order; the
+//                     frame blocks are eliminated on the spot (L, Wt, y): a Gauss-Newton solve of the
+//                     point, should it be accepted, is already under way                (launch_step2_assemble)
+//   syrk + finalize   Wt^T Wt partial tiles ; A, g_S, |x|^2 from the chunk partials
+//   reduce + quadform S, r ; g^T N g
+//   finish + Cholesky accept/reject, trust region, start of the next trial; Cholesky of S if the (new) current
+//                     point needs its Gauss-Newton step
+//   backsub           the frame/point part of the Gauss-Newton step
+// initial: the evaluation of the starting point (no choose, no accept)
+struct Step2Args
+{
+    const DeviceProblem* P; const NormalDims* nd; const BlockRanges* br; const AssemblyPlan* plan;
+    const OpDev* ops; SolverCtl* ctl; const FactorBuffers* F; const double* gram;
+    const int32_t* Jp; const int32_t* Ji; double* step; bool is_leader;
+};
+hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
+hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
+hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stream);
+const int* solver_ctl_skip_eval2(const SolverCtl* ctl);
+// host-driven evaluation: deterministic block normal equations of the point R from the Grams (no elimination)
+hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
+                           const EvalBuffers& B, hipStream_t stream);
+
 // the control block is followed in memory by its derived flags
 size_t     solver_ctl_bytes();
+void       solver_ctl_init_flags(void* ctl_image, int icur);
 const int* solver_ctl_skip_factor(const SolverCtl* ctl);   // device pointers, given the device pointer of ctl
 const int* solver_ctl_skip_eval  (const SolverCtl* ctl);
 
