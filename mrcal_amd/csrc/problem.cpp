@@ -67,7 +67,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status);
-    hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_ctl);
+    hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
     for(hipEvent_t e : ctl_events) hipEventDestroy(e);
@@ -119,6 +119,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
     ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.NE + nd.Nstate + 2 + 32);
     ok = ok && dev_alloc(&P->d_counts, 4);
+    ok = ok && dev_alloc(&P->d_outlier_part, outlier_partial_doubles());
     if(!ok) return false;
     // only the lower triangle of S is ever written; the rest rides along in the
     // all-reduce of [S | r] and should be numbers

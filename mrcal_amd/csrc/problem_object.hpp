@@ -87,6 +87,7 @@ struct mrcal_amd_problem
     double* comm_point() const { return d_comm + ((nd.NE + 7) & ~7); }
     double* comm_gng()   const { return comm_point() + ((nd.Nstate + 2 + 7) & ~7); }
     int*                       d_counts = NULL;   // [4]
+    double*                    d_outlier_part = NULL;   // [outlier_partial_doubles()]
     double*                    h_scalars = NULL;  // pinned [64]
     // device-side dog-leg control (solver_kernels.hpp): the block, and a ring
     // of pinned host copies the host polls without stalling the queue

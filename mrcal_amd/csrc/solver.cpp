@@ -330,7 +330,7 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
         if(Npts <= 0) return true;
         HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
         HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double), P->stream), return false);
-        HIP_TRY(launch_outlier_stats(Npts, thresh_sq, x, P->d_board_pool, P->d_counts, sums, P->stream), return false);
+        HIP_TRY(launch_outlier_stats(Npts, thresh_sq, x, P->d_board_pool, P->d_counts, sums, P->d_outlier_part, P->stream), return false);
         HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
         if(!read_scalars(P, sums, 1, sum)) return false;
         memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
@@ -605,7 +605,7 @@ bool mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* P, int iop, doub
                                            int* counts_dev, double* sums_dev)
 {
     const int Npts = P->D.Nobs_board * P->D.W * P->D.H;
-    HIP_TRY(launch_outlier_stats(Npts, thresh_sq, P->op[iop & 1].x, P->d_board_pool, counts_dev, sums_dev, P->stream), return false);
+    HIP_TRY(launch_outlier_stats(Npts, thresh_sq, P->op[iop & 1].x, P->d_board_pool, counts_dev, sums_dev, P->d_outlier_part, P->stream), return false);
     return true;
 }
 bool mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* P, int iop, double thresh_sq, int* counts_dev)

@@ -114,6 +114,9 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
                     const int pos = pos0 + w*blockDim.x;
                     const int pc  = (pos < npos) ? pos : t;
                     flag[w] = (pos < npos) ? plan.pos_table[pc] : 0;
+                    // (Masking the loads of the positions without a frame column - whole 64-byte
+                    //  lines of a Gram are camera-block only - was measured: 28 us against 26.
+                    //  The kernel is not bound by its traffic)
 #pragma unroll
                     for(int u = 0; u < 8; u++)
                     {
@@ -240,24 +243,47 @@ void reduce_pair_chunk(const DeviceProblem& P, const AssemblyPlan& plan,
     const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[ichunk]*npos;
     double* __restrict__ out = plan.chunk_part + (size_t)ichunk*npos;
     const int nobs = c1 - c0;
-    for(int pos = threadIdx.x; pos < npos; pos += blockDim.x)
+    // two positions per thread and 16 observations of each in flight together
+    for(int base = 0; base < npos; base += 2*blockDim.x)
     {
-        const int kind = ops[pos].op & 0xff;
-        if(kind != PAIROP_A && kind != PAIROP_G && kind != PAIROP_NORM) { out[pos] = 0.0; continue; }
-        double acc = 0.0;
+        int  pos[2]; bool live[2];
+#pragma unroll
+        for(int w = 0; w < 2; w++)
+        {
+            pos[w] = base + w*blockDim.x + threadIdx.x;
+            const int kind = (pos[w] < npos) ? (ops[pos[w]].op & 0xff) : PAIROP_NONE;
+            live[w] = (kind == PAIROP_A || kind == PAIROP_G || kind == PAIROP_NORM);
+        }
+        double acc[2] = {0.0, 0.0};
         for(int u0 = 0; u0 < nobs; u0 += 16)
         {
-            double vv[16];
+            double vv[2][16];
+            size_t ob[16];
 #pragma unroll
             for(int u = 0; u < 16; u++)
             {
                 const int k = (u0 + u < nobs) ? c0 + u0 + u : c0;
-                vv[u] = gram[(size_t)plan.pair_obs[k]*npos + pos];
+                ob[u] = (size_t)plan.pair_obs[k]*npos;
+            }
+            // (per position ONE masked region holding its 16 loads: in flight together)
+#pragma unroll
+            for(int w = 0; w < 2; w++)
+            {
+#pragma unroll
+                for(int u = 0; u < 16; u++) vv[w][u] = 0.0;
+                if(live[w])
+                {
+#pragma unroll
+                    for(int u = 0; u < 16; u++) vv[w][u] = gram[ob[u] + pos[w]];
+                }
             }
 #pragma unroll
-            for(int u = 0; u < 16; u++) acc += (u0 + u < nobs) ? vv[u] : 0.0;
+            for(int w = 0; w < 2; w++)
+#pragma unroll
+                for(int u = 0; u < 16; u++) acc[w] += (u0 + u < nobs) ? vv[w][u] : 0.0;
         }
-        out[pos] = acc;
+#pragma unroll
+        for(int w = 0; w < 2; w++) if(pos[w] < npos) out[pos[w]] = acc[w];
     }
 }
 
@@ -267,13 +293,18 @@ void reduce_pair_chunk(const DeviceProblem& P, const AssemblyPlan& plan,
 // that do not come from Grams added earlier (atomically, into the zeroed
 // buffers: regularization rows, which have disjoint destinations; discrete
 // points) stays. |x|^2 also takes those rows' per-workgroup partials, in order
+// 16 lanes (one DPP row) per destination: the lanes split the chunks of each source,
+// then add up in a fixed order
+#define FIN_LANES 16
 __device__ __forceinline__
 void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const AssemblyPlan& plan,
-                       int k /* index into the destination list */)
+                       int gid /* global thread index: destination gid/16, lane gid%16 */)
 {
-    if(k >= plan.Ndest) return;
-    const int d  = plan.dest_id[k];
-    const int s0 = plan.dest_begin[k], s1 = plan.dest_begin[k+1];
+    const int k = gid / FIN_LANES, j = gid % FIN_LANES;
+    const bool live = k < plan.Ndest;
+    const int kc = live ? k : 0;
+    const int d  = plan.dest_id[kc];
+    const int s0 = plan.dest_begin[kc], s1 = live ? plan.dest_begin[kc+1] : s0;
     double acc = 0.0;
     for(int s = s0; s < s1; s++)
     {
@@ -281,19 +312,19 @@ void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const Ass
         const int pair = src >> 10, pos = src & 1023;
         const int c0 = plan.pair_chunk_begin[pair], c1 = plan.pair_chunk_begin[pair+1];
         const double* __restrict__ cp = plan.chunk_part + pos;
-        double a = 0.0;
-        int c = c0;
-        for(; c + 8 <= c1; c += 8)
+        double a0 = 0.0, a1 = 0.0;
+        int c = c0 + j;
+        for(; c + FIN_LANES < c1; c += 2*FIN_LANES)
         {
-            double v[8];
-#pragma unroll
-            for(int u = 0; u < 8; u++) v[u] = cp[(size_t)(c + u)*npos];
-#pragma unroll
-            for(int u = 0; u < 8; u++) a += v[u];
+            const double v0 = cp[(size_t)c*npos], v1 = cp[(size_t)(c + FIN_LANES)*npos];
+            a0 += v0; a1 += v1;
         }
-        for(; c < c1; c++) a += cp[(size_t)c*npos];
-        acc += a;
+        if(c < c1) a0 += cp[(size_t)c*npos];
+        acc += a0 + a1;
     }
+    // (all 16 lanes of the row take part, whether the destination is live or not)
+    for(int off = FIN_LANES/2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if(!live || j != 0) return;
     const int nA = nd.Nc*nd.Nc;
     if(d < nA)              O.A[d] += acc;
     else if(d < nA + nd.Nc) { const int sc = d - nA; O.g[(sc < nd.Nie) ? sc : nd.i_state_warp + (sc - nd.Nie)] += acc; }
@@ -303,10 +334,6 @@ void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const Ass
         O.scalars[SC_NORM2_X] += acc;
     }
 }
-
-// (Ending the trial in the LAST workgroup of the g^T N g reduction - ticket
-// counter after a device-scope fence - instead of a launch of its own was
-// measured: the fence costs a write-back of the L2, 30+ us. Not used)
 
 // Rows that do not come from board observations (discrete points,
 // regularization): one lane per CSR row, scattered with atomics. These are few
@@ -663,6 +690,7 @@ void assemble_finalize_kernel(int npos, NormalDims nd, const OpDev* __restrict__
 // the same, riding along in the SYRK launch (row nslices of its grid): the two are independent
 struct FinalizeRide
 {
+    int           row0;      // first row (blockIdx.y) of the grid that is the ride's
     int           npos;      // 0: nothing rides along
     const OpDev*  ops;
     const int*    sel;
@@ -673,8 +701,7 @@ __device__ __forceinline__ void finalize_ride(const FinalizeRide& fr, const Norm
 {
     if(fr.skip != NULL && *fr.skip) return;
     const OpDev& O = fr.ops[fr.sel ? *fr.sel : 0];
-    for(int k = blockIdx.x*blockDim.x + threadIdx.x; k < fr.plan.Ndest; k += gridDim.x*blockDim.x)
-        assemble_finalize(fr.npos, nd, O, fr.plan, k);
+    assemble_finalize(fr.npos, nd, O, fr.plan, ((blockIdx.y - fr.row0)*gridDim.x + blockIdx.x)*blockDim.x + threadIdx.x);
 }
 
 // A, Bt, D, g and the scalars of an operating point, zeroed in one launch
@@ -2081,23 +2108,26 @@ void mark_outliers_kernel(int Npoints_board, double thresh_sq,
 // outlier statistics (mrcal.c:4107-4124, 4282-4306): counts[0] = current
 // outliers (weight <= 0), counts[1] = inliers beyond k1 sigma given var,
 // sums[0] = sum of inlier x^2
+// Fixed grid, grid-stride loop, per-workgroup partial sums in part[], summed in
+// order by outlier_stats_sum_kernel: the variance (and with it the outlier
+// threshold) does not depend on scheduling
+#define OUTLIER_BLOCKS 512
 __global__ __launch_bounds__(256)
 void outlier_stats_kernel(int Npoints_board, double thresh_sq,
                           const double* __restrict__ x, const double* __restrict__ pool,
-                          int* __restrict__ counts, double* __restrict__ sums)
+                          int* __restrict__ counts, double* __restrict__ part)
 {
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
     double s = 0.0;
     int nout = 0, nbig = 0;
-    if(i < Npoints_board)
+    for(int i = blockIdx.x*blockDim.x + threadIdx.x; i < Npoints_board; i += gridDim.x*blockDim.x)
     {
         const double w = pool[3*(size_t)i + 2];
-        if(w <= 0.0) nout = 1;
+        if(w <= 0.0) nout++;
         else
         {
             const double dx = x[2*(size_t)i], dy = x[2*(size_t)i+1];
-            s = dx*dx + dy*dy;
-            if(thresh_sq >= 0.0 && (dx*dx > thresh_sq || dy*dy > thresh_sq)) nbig = 1;
+            s += dx*dx + dy*dy;
+            if(thresh_sq >= 0.0 && (dx*dx > thresh_sq || dy*dy > thresh_sq)) nbig++;
         }
     }
     for(int off=32; off>0; off>>=1)
@@ -2106,12 +2136,23 @@ void outlier_stats_kernel(int Npoints_board, double thresh_sq,
         nout += __shfl_down(nout, off);
         nbig += __shfl_down(nbig, off);
     }
+    __shared__ double ps[4];
     if((threadIdx.x & 63) == 0)
     {
-        if(s != 0.0) atomicAdd(&sums[0], s);
-        if(nout)     atomicAdd(&counts[0], nout);
-        if(nbig)     atomicAdd(&counts[1], nbig);
+        ps[threadIdx.x >> 6] = s;
+        if(nout) atomicAdd(&counts[0], nout);       // (integers: any order gives the same sum)
+        if(nbig) atomicAdd(&counts[1], nbig);
     }
+    __syncthreads();
+    if(threadIdx.x == 0) part[blockIdx.x] = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+}
+__global__ __launch_bounds__(64)
+void outlier_stats_sum_kernel(int n, const double* __restrict__ part, double* __restrict__ sums)
+{
+    if(threadIdx.x != 0) return;
+    double s = 0.0;
+    for(int i = 0; i < n; i++) s += part[i];
+    sums[0] += s;
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -2857,7 +2898,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                            assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
                            (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, row0, P.Nmeas, B.Jp, B.Ji);
         if(plan.Ndest > 0)
-            hipLaunchKernelGGL(assemble_finalize_kernel, dim3((plan.Ndest + 63)/64), dim3(64), 0, stream,
+            hipLaunchKernelGGL(assemble_finalize_kernel, dim3((plan.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,
                                gram_stride(P.Ndist), nd, B.R.ops, B.R.sel, B.R.skip, plan);
     }
     else
@@ -2945,8 +2986,10 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
         if(ns[part] > 0)
         {
             const bool with_ride = (ride != NULL && !rode);
-            const FinalizeRide& fr = with_ride ? *ride : none;
-            const int extra = with_ride ? 1 : 0;
+            FinalizeRide fr = with_ride ? *ride : none;
+            const int gx = (nd.Nc > 256) ? syrk_grid_x(nd) : npairs;
+            const int extra = with_ride ? (ride->plan.Ndest*FIN_LANES + gx*64 - 1)/(gx*64) : 0;
+            fr.row0 = ns[part];
             rode = rode || with_ride;
             if(nd.Nc > 256)
                 hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
@@ -2956,7 +2999,7 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
                                    nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
         }
     if(ride != NULL && !rode && ride->plan.Ndest > 0)
-        hipLaunchKernelGGL(assemble_finalize_kernel, dim3((ride->plan.Ndest + 63)/64), dim3(64), 0, stream,
+        hipLaunchKernelGGL(assemble_finalize_kernel, dim3((ride->plan.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,
                            ride->npos, nd, ride->ops, ride->sel, ride->skip, ride->plan);
     return nslots;
 }
@@ -3028,12 +3071,15 @@ hipError_t launch_axpby(int n, double alpha, const double* a, double beta, const
     hipLaunchKernelGGL(axpby_kernel, dim3((n+255)/256), dim3(256), 0, stream, n, alpha, a, beta, b, y);
     return hipGetLastError();
 }
+size_t outlier_partial_doubles() { return OUTLIER_BLOCKS; }
 hipError_t launch_outlier_stats(int Npoints_board, double thresh_sq, const double* x, const double* pool,
-                                int* counts, double* sums, hipStream_t stream)
+                                int* counts, double* sums, double* part, hipStream_t stream)
 {
     if(Npoints_board <= 0) return hipSuccess;
-    hipLaunchKernelGGL(outlier_stats_kernel, dim3((Npoints_board+255)/256), dim3(256), 0, stream,
-                       Npoints_board, thresh_sq, x, pool, counts, sums);
+    int nb = (Npoints_board + 255)/256; if(nb > OUTLIER_BLOCKS) nb = OUTLIER_BLOCKS;
+    hipLaunchKernelGGL(outlier_stats_kernel, dim3(nb), dim3(256), 0, stream,
+                       Npoints_board, thresh_sq, x, pool, counts, part);
+    hipLaunchKernelGGL(outlier_stats_sum_kernel, dim3(1), dim3(64), 0, stream, nb, part, sums);
     return hipGetLastError();
 }
 hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const double* x, double* pool,

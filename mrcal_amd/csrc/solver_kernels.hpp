@@ -213,8 +213,10 @@ hipError_t launch_quadform(const NormalDims& nd, const OpRef& R, const double* v
 hipError_t launch_dot(int n, const double* a, const double* b, double* out, hipStream_t stream);
 hipError_t launch_axpby(int n, double alpha, const double* a, double beta, const double* b, double* y,
                         hipStream_t stream);
+// part: scratch of outlier_partial_doubles() doubles (per-workgroup partial sums, added up in a fixed order)
+size_t     outlier_partial_doubles();
 hipError_t launch_outlier_stats(int Npoints_board, double thresh_sq, const double* x, const double* pool,
-                                int* counts, double* sums, hipStream_t stream);
+                                int* counts, double* sums, double* part, hipStream_t stream);
 hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const double* x, double* pool,
                                 int* counts, hipStream_t stream);
 

@@ -302,3 +302,32 @@ def test_sfm_configuration_full_size(amd, ref_api):
     assert np.abs(oi2["rt_cam_ref"][:,3:]/np.linalg.norm(oi2["rt_cam_ref"][0,3:]) - t_true/scale).max() < 2e-2
     assert np.abs(oi2["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 5e-3
     assert s["Noutliers_triangulated_point"] >= 0
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("Ncameras,Nframes", ((3, 60), (8, 1000)))
+def test_solve_is_bit_reproducible(amd, Ncameras, Nframes):
+    """The block normal equations are summed in a fixed order (no floating-point
+    atomics between the Grams and the Cholesky: DESIGN.md section 5): the same
+    problem solved again takes the same steps and ends on the same bits. The
+    metric's configuration, outlier rejection included, three times"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel="LENSMODEL_OPENCV8",
+                                     object_width_n=10, object_height_n=10, seed=0)
+    runs = []
+    for i in range(3):
+        with Problem(**copy_inputs(oi)) as p:
+            s = p.solve()
+            runs.append((s["Niterations"], s["Nevaluations"], s["Nfactorizations"], s["Noutliers_board"],
+                         s["norm2_x"], p.b_packed()))
+    for r in runs[1:]:
+        assert r[:4] == runs[0][:4], (r[:4], runs[0][:4])
+        assert r[4] == runs[0][4]
+        assert np.array_equal(r[5], runs[0][5])
+    # and the normal equations of one evaluation
+    with Problem(**copy_inputs(oi)) as p:
+        n0 = p.normal_equations()
+        n1 = p.normal_equations()
+    for k in ("A", "Bt", "D", "g"):
+        assert np.array_equal(n0[k], n1[k]), k
+    assert n0["norm2_x"] == n1["norm2_x"]
