@@ -446,72 +446,70 @@ bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int c
 bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
                                            double* total_ms, double* min_ms, double* max_ms);
 
-/* ---- Phase API: the pieces of one dog-leg step ---------------------------
-   For the multi-GPU driver (one process per GPU, observations sharded by
-   frame): it runs these phases on every rank and all-reduces (RCCL) the
-   buffers in between. All phases are queued on the problem's stream and do not
-   synchronize with the host. iop in {0,1} selects one of the two operating
-   points (libdogleg's beforeStep/afterStep).
+/* ---- multi-GPU: one process per GPU, frames sharded over the ranks ----------
+   No counterpart in the reference (it is single-threaded). Every rank creates
+   its shard with mrcal_amd_problem_create(shard_begin_frame, shard_end_frame,
+   is_shard_leader) from the SAME inputs, attaches a communicator, and calls
+   mrcal_amd_problem_solve() / _run_steps() like a single-GPU caller: the
+   device-controlled dog-leg step then runs with TWO all-reduces per trial
+   step, issued from C++ on the problem's stream (RCCL over xGMI):
+       comm 0  [ S (Nc*Nc) | r (Nc) | g_S (Nc) | |x|^2 | status ]   after the local Schur reduction
+       comm 1  [ g^T JtJ g | |g_E|^2 | |gn_E|^2 | gn_E . g_E ]       after the local back-substitution
+   Rank-local: the frame poses of the shard's frames (state, gradient, steps),
+   its rows of x and J. Replicated, and advanced identically by every rank from
+   the same sums: the camera block of the state (intrinsics, extrinsics, warp)
+   and the trust-region control block. Nothing is read back between trial steps.
 
-     phase_evaluate(iop)        x, J, this shard's blocks of JtJ, its part of
-                                g = Jt x (BUF_G) and of |x|^2 (BUF_SCALARS[0])
-     phase_quadform(iop,v,out)  *out += v^T (local JtJ) v
-     phase_factor_local(iop,l)  factor the local frame/point blocks; this shard's
-                                summand of the Schur complement and of the reduced
-                                rhs in BUF_SCHUR = [S (Nc*Nc) | r (Nc)]
-     phase_solve_backsub(iop)   Cholesky of BUF_SCHUR (after its all-reduce),
-                                d_S, and the local frame/point steps, into
-                                BUF_STEP_GN (other shards' frame entries stay 0)
-*/
-enum
-{
-    MRCAL_AMD_BUF_B = 0, MRCAL_AMD_BUF_X, MRCAL_AMD_BUF_G,
-    MRCAL_AMD_BUF_STEP_CAUCHY, MRCAL_AMD_BUF_STEP_GN, MRCAL_AMD_BUF_SCALARS,
-    MRCAL_AMD_BUF_STEP, MRCAL_AMD_BUF_SCHUR, MRCAL_AMD_BUF_STATUS
-};
-/* device pointer + element count of a solver buffer (doubles; BUF_STATUS: int) */
-void* mrcal_amd_problem_buffer(mrcal_amd_problem_t* problem, int which, int iop, int64_t* Nelements);
+   The communicator: rank 0 makes a 128-byte id (mrcal_amd_comm_unique_id),
+   any side channel carries it to the other ranks, every rank calls
+   mrcal_amd_comm_create(id, rank, world). RCCL is opened at run time */
+typedef struct mrcal_amd_comm mrcal_amd_comm_t;
+bool              mrcal_amd_comm_unique_id(void* id128);
+mrcal_amd_comm_t* mrcal_amd_comm_create(const void* id128, int rank, int world);
+void              mrcal_amd_comm_destroy(mrcal_amd_comm_t* comm);
+int               mrcal_amd_comm_rank (const mrcal_amd_comm_t* comm);
+int               mrcal_amd_comm_world(const mrcal_amd_comm_t* comm);
+long              mrcal_amd_comm_Ncollectives(const mrcal_amd_comm_t* comm);
+/* in-place sum over the ranks of n doubles in device memory, queued on the HIP stream */
+bool              mrcal_amd_comm_allreduce_sum(mrcal_amd_comm_t* comm, double* buf_dev, int64_t n, void* stream);
+
+/* From now on solve()/run_steps() of this shard run the sharded step over comm
+   (not owned; must outlive the problem or be detached with NULL) */
+bool  mrcal_amd_problem_attach_comm(mrcal_amd_problem_t* problem, mrcal_amd_comm_t* comm);
+/* after a solve: every rank gets the whole state (the frame poses of the
+   other ranks' frames) into its resident b_packed. One all-reduce of Nstate doubles */
+bool  mrcal_amd_problem_gather_state(mrcal_amd_problem_t* problem);
+
+/* The same step for a driver that brings its OWN collectives (the protocol
+   tests: mrcal_amd/parallel.py drives two shards on one device over gloo). Per
+   trial step the driver queues, on the problem's stream,
+       enqueue(0,0) | all-reduce comm_buffer(0) | enqueue(0,1) | all-reduce comm_buffer(1)
+   and never reads anything back in between. initial=1: the evaluation of the
+   starting point, after sharded_reset(). snapshot(slot)/wait(slot): a pinned copy
+   of the control block, queued after a trial step and waited for a few steps
+   later, tells the host when the device has declared the solve finished; wait()
+   writes out[4] = { done, error, Nsteps_accepted, Ntrials }. finish() drains the
+   stream and makes the final point current; out_i[5] = { Nsteps_accepted,
+   Nevaluations, Nfactorizations, Ntrials, error }, out_d[3] = { trust region,
+   |x|^2, lambda } */
+bool  mrcal_amd_problem_sharded_reset      (mrcal_amd_problem_t* problem, int check_termination, int max_iterations,
+                                            double trustregion0);
+bool  mrcal_amd_problem_sharded_enqueue    (mrcal_amd_problem_t* problem, int initial, int segment);
+void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* problem, int which, int64_t* Nelements);
+bool  mrcal_amd_problem_sharded_snapshot   (mrcal_amd_problem_t* problem, int slot);
+bool  mrcal_amd_problem_sharded_wait       (mrcal_amd_problem_t* problem, int slot, int* out);
+bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* out_i, double* out_d);
 /* info[8] = { Nstate, Nie, NE, Nc, frame_lo, frame_hi, is_leader, Ncorners_local }.
    State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames+points, then the warp */
 void  mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info);
-bool  mrcal_amd_problem_phase_evaluate     (mrcal_amd_problem_t* problem, int iop);
-bool  mrcal_amd_problem_phase_quadform     (mrcal_amd_problem_t* problem, int iop, const double* v_dev, double* out_dev);
-bool  mrcal_amd_problem_phase_factor_local (mrcal_amd_problem_t* problem, int iop, double lambda);
-bool  mrcal_amd_problem_phase_solve_backsub(mrcal_amd_problem_t* problem, int iop);
+/* outlier statistics / marking on the local board observations (mrcal.c:3978-4402);
+   counts (device int[4]) and sums (device double[1]) are accumulated into */
 bool  mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* problem, int iop, double thresh_sq,
                                             int* counts_dev, double* sums_dev);
 bool  mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* problem, int iop, double thresh_sq, int* counts_dev);
 /* which operating point get_b_packed()/get_x()/get_J() read */
 void  mrcal_amd_problem_set_current(mrcal_amd_problem_t* problem, int iop);
 int   mrcal_amd_problem_current(mrcal_amd_problem_t* problem);
-
-/* Sharded step (multi-GPU; no counterpart in the reference): one
-   device-controlled dog-leg trial step, cut where a quantity is summed over the
-   shards. Per trial step the driver queues, on the problem's stream,
-       enqueue(0,0) | all-reduce comm_buffer(0) | enqueue(0,1) | all-reduce
-       comm_buffer(1) | enqueue(0,2) | all-reduce comm_buffer(2) | enqueue(0,3) |
-       all-reduce comm_buffer(3) | enqueue(0,4)
-   and never reads anything back in between: the trust-region state is a
-   replicated control block in device memory, every rank takes the same
-   decisions from the same sums. initial=1 (segments 2,3,4 only): evaluation of
-   the starting point, after sharded_reset().
-     comm_buffer 0: [S (Nc*Nc) | r (Nc)]   this shard's summand of the Schur complement
-                 1: [NE]                   the frame/point part of the Gauss-Newton step
-                 2: [Nstate + 2]           g = Jt x, |x|^2, (spare)
-                 3: [1]                    g^T JtJ g
-   snapshot(slot)/wait(slot): a pinned copy of the control block, queued after
-   a trial step and waited for a few steps later, tells the host when the device
-   has declared the solve finished; wait() writes out[4] = { done, error,
-   Nsteps_accepted, Ntrials }. finish() drains the stream and makes the final
-   point current; out_i[5] = { Nsteps_accepted, Nevaluations, Nfactorizations,
-   Ntrials, error }, out_d[3] = { trust region, |x|^2, lambda } */
-bool  mrcal_amd_problem_sharded_reset      (mrcal_amd_problem_t* problem, int check_termination, int max_iterations,
-                                            double trustregion0);
-bool  mrcal_amd_problem_sharded_enqueue    (mrcal_amd_problem_t* problem, int initial, int segment);
-void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* problem, int segment, int64_t* Nelements);
-bool  mrcal_amd_problem_sharded_snapshot   (mrcal_amd_problem_t* problem, int slot);
-bool  mrcal_amd_problem_sharded_wait       (mrcal_amd_problem_t* problem, int slot, int* out);
-bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* out_i, double* out_d);
 
 /* The whole solve on a resident problem: dog-leg iterations + outlier
    rejection (if the problem selections ask for it), exactly what

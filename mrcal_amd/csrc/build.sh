@@ -7,6 +7,6 @@ OUT=../libmrcal_amd.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -o $OUT \
-    kernels.hip solver_kernels.hip problem.cpp cabi_layout.cpp solver.cpp factorization.cpp unproject.cpp "$@"
+    -o $OUT -ldl \
+    kernels.hip solver_kernels.hip problem.cpp cabi_layout.cpp solver.cpp factorization.cpp unproject.cpp comm.cpp "$@"
 echo "built $(readlink -f $OUT)"

@@ -65,7 +65,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
-    hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part);
+    hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -113,17 +113,18 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->F.LD, (size_t)nd.NEb*36);
     ok = ok && dev_alloc(&P->F.y,  (size_t)nd.NE);
     // S and r contiguous: one all-reduce moves both
-    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + nd.Nc + 64 + 256);
+    // [S | r | g_S | |x|^2 | status]: comm1 of the sharded step (step2_comm1_doubles())
+    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2 + 64);
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
     ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
-    ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.NE + nd.Nstate + 2 + 32);
+    ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.Nstate + 64);
     ok = ok && dev_alloc(&P->d_counts, 4);
     ok = ok && dev_alloc(&P->d_outlier_part, outlier_partial_doubles());
     if(!ok) return false;
     // only the lower triangle of S is ever written; the rest rides along in the
     // all-reduce of [S | r] and should be numbers
-    HIP_TRY(hipMemset(P->F.S, 0, ((size_t)nd.Nc*nd.Nc + nd.Nc)*sizeof(double)), return false);
+    HIP_TRY(hipMemset(P->F.S, 0, ((size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2)*sizeof(double)), return false);
     // rows of blocks this shard does not own are never written: they must read as 0
     HIP_TRY(hipMemset(P->F.Wt, 0, (size_t)(nd.NE*nd.Nc > 0 ? nd.NE*nd.Nc : 1)*sizeof(double)), return false);
     HIP_TRY(hipMemset(P->F.y,  0, (size_t)(nd.NE > 0 ? nd.NE : 1)*sizeof(double)), return false);
@@ -295,6 +296,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             ok = ok && dev_alloc(&P->plan.row_part, (size_t)(P->plan.row_part_n > 0 ? P->plan.row_part_n : 1));
             P->plan.qf_part_n = (nd.Nc + nd.NE + 31)/32;
             ok = ok && dev_alloc(&P->plan.qf_part, (size_t)4*(P->plan.qf_part_n > 0 ? P->plan.qf_part_n : 1));
+            ok = ok && dev_alloc(&P->plan.dots_part, (size_t)2*(nd.NEb > 0 ? nd.NEb : 1));
         }
     }
     if(!ok) return false;

@@ -80,12 +80,9 @@ struct mrcal_amd_problem
     mrcal_amd::AssemblyPlan    plan = {};
     mrcal_amd::FactorBuffers   F    = {};
     double*                    d_step   = NULL;   // [Nstate]
-    // staging for the sums over shards: [NE] the E part of the Gauss-Newton
-    // step | [Nstate+2] g, |x|^2, s^T N s | [1] g^T N g
-    double*                    d_comm   = NULL;
-    double* comm_gn()    const { return d_comm; }
-    double* comm_point() const { return d_comm + ((nd.NE + 7) & ~7); }
-    double* comm_gng()   const { return comm_point() + ((nd.Nstate + 2 + 7) & ~7); }
+    double*                    d_comm   = NULL;   // comm2 of the sharded step (4 doubles) + scratch for host-side sums
+    struct mrcal_amd_comm*     comm     = NULL;   // attached communicator (not owned): solve/run_steps run sharded
+    bool                       sharded_external = false;   // sharded step, the CALLER does the collectives
     int*                       d_counts = NULL;   // [4]
     double*                    d_outlier_part = NULL;   // [outlier_partial_doubles()]
     double*                    h_scalars = NULL;  // pinned [64]

@@ -107,7 +107,19 @@ Step2Args step2_args(mrcal_amd_problem* P)
     a.P = &P->D; a.nd = &P->nd; a.br = &P->br; a.plan = &P->plan;
     a.ops = P->d_ops; a.ctl = P->d_ctl; a.F = &P->F; a.gram = P->d_gram;
     a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
+    a.comm2 = (P->comm != NULL || P->sharded_external) ? P->d_comm : NULL;
     return a;
+}
+
+// The two sums over the ranks of a sharded trial step (include/mrcal_amd.h):
+// 0 = [S | r | g_S | |x|^2 | status] behind launch_step2_reduce(), 1 = the four
+// scalars behind launch_step2_factor(). Queued on the problem's stream; nothing
+// to do on a single GPU, or when the caller brings its own collectives
+bool step_collective(mrcal_amd_problem* P, int which)
+{
+    if(P->comm == NULL) return true;
+    if(which == 0) return mrcal_amd_comm_allreduce_sum(P->comm, P->F.S, step2_comm1_doubles(P->nd), (void*)P->stream);
+    return mrcal_amd_comm_allreduce_sum(P->comm, P->d_comm, 4, (void*)P->stream);
 }
 
 // x, J, the normal equations, g, |x|^2, the Cauchy step and (unless the Cauchy
@@ -118,7 +130,10 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
     if(!problem_evaluate_ref(P, R, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
     const Step2Args a = step2_args(P);
     HIP_TRY(launch_step2_assemble(a, true, P->stream), return false);
-    HIP_TRY(launch_step2_solve(a, true, P->stream), return false);
+    HIP_TRY(launch_step2_reduce(a, P->stream), return false);
+    if(!step_collective(P, 0)) return false;
+    HIP_TRY(launch_step2_factor(a, true, P->stream), return false);
+    if(!step_collective(P, 1)) return false;
     return true;
 }
 
@@ -132,8 +147,8 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
     if(segment == 0 || segment == 1)
     {
-        // the step from the current point (its Gauss-Newton step, if one is needed, was
-        // computed when the point was accepted); then the joint poses of the trial point
+        // the step from the current point (its Gauss-Newton step was computed when the
+        // point was accepted); then the joint poses of the trial point
         HIP_TRY(launch_step2_choose(a, P->stream), return false);
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
     }
@@ -143,7 +158,10 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     {
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_REST)) return false;
         HIP_TRY(launch_step2_assemble(a, false, P->stream), return false);
-        HIP_TRY(launch_step2_solve(a, false, P->stream), return false);
+        HIP_TRY(launch_step2_reduce(a, P->stream), return false);
+        if(!step_collective(P, 0)) return false;
+        HIP_TRY(launch_step2_factor(a, false, P->stream), return false);
+        if(!step_collective(P, 1)) return false;
     }
     return true;
 }
@@ -178,7 +196,7 @@ bool queue_trial_step(mrcal_amd_problem* P)
     // MRCAL_AMD_GRAPH=1 selects the graph, which does not depend on the host
     // keeping up with the queue
     static const bool use_graph = (getenv("MRCAL_AMD_GRAPH") != NULL);
-    if(!use_graph) return enqueue_trial_step(P, 0);
+    if(!use_graph || P->comm != NULL) return enqueue_trial_step(P, 0);
     if(!P->ev_pool_enabled)
     {
         if(P->step_graph[0] == NULL && !capture_segment(P, 0, &P->step_graph[0])) return false;
@@ -319,7 +337,7 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
     *Noutliers_tri   = 0;
     const int Npts   = P->D.Nobs_board * P->D.W * P->D.H;
     const int Npairs = (int)P->tri_meta_host.size();
-    if(Npts <= 0 && Npairs <= 0) return true;
+    if(Npts <= 0 && Npairs <= 0 && P->comm == NULL) return true;
     const double k0 = 4.0, k1 = 5.0;
     const double* x = P->op[P->icur].x;
     double* sums = P->op[P->icur].scalars + SC_TMP0;
@@ -336,10 +354,27 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
         memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
         return true;
     };
+    // sharded: the statistics are those of the whole problem (one tiny sum over the ranks per number)
+    auto over_ranks = [&](double* v, int n) -> bool
+    {
+        if(P->comm == NULL) return true;
+        double* d = P->d_comm + 8;
+        HIP_TRY(hipMemcpyAsync(d, v, n*sizeof(double), hipMemcpyHostToDevice, P->stream), return false);
+        if(!mrcal_amd_comm_allreduce_sum(P->comm, d, n, (void*)P->stream)) return false;
+        HIP_TRY(hipMemcpyAsync(v, d, n*sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
+        HIP_TRY(hipStreamSynchronize(P->stream), return false);
+        return true;
+    };
     int counts[4]; double sum_board;
     if(!board_stats(-1.0, counts, &sum_board)) return false;
+    double Npts_all = (double)Npts;
+    {
+        double v[3] = { (double)counts[0], sum_board, Npts_all };
+        if(!over_ranks(v, 3)) return false;
+        counts[0] = (int)v[0]; sum_board = v[1]; Npts_all = v[2];
+    }
     int Nout_board = counts[0];
-    const int Nin_board = Npts - Nout_board;
+    const int Nin_board = (int)Npts_all - Nout_board;
 
     // triangulated pairs: divergent ones are thrown out right away
     std::vector<double> x_tri(Npairs > 0 ? Npairs : 1), b(P->L.Nstate > 0 ? P->L.Nstate : 1);
@@ -385,7 +420,9 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
         {
             double dummy;
             if(!board_stats(k1*k1*var, counts, &dummy)) return false;
-            if(counts[1] > 0) any = true;
+            double v[1] = { (double)counts[1] };
+            if(!over_ranks(v, 1)) return false;
+            if(v[0] > 0) any = true;
         }
         if(!any)
             for(int ip = 0; ip < Npairs; ip++)
@@ -402,7 +439,9 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
                 HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
                 HIP_TRY(hipStreamSynchronize(P->stream), return false);
                 memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
-                *Noutliers_board = Nout_board + counts[0];
+                double v[1] = { (double)counts[0] };
+                if(!over_ranks(v, 1)) return false;
+                *Noutliers_board = Nout_board + (int)v[0];
             }
             for(int ip = 0; ip < Npairs; ip++)
             {
@@ -451,11 +490,13 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
         P->stats.Noutliers_triangulated = Noutliers_tri;
         if(!found) break;
         P->stats.Noutlier_passes++;
+        if(P->is_leader)
         fprintf(stderr, "mrcal_amd: Threw out some outliers. New count = %d/%d (%.1f%%). Going again\n",
                 Noutliers, P->L.Nmeas_boards,
                 (double)(Noutliers*100)/(double)(P->L.Nmeas_boards > 0 ? P->L.Nmeas_boards : 1));
     }
     if(Noutliers_board_out) *Noutliers_board_out = Noutliers;
+    if(P->comm != NULL && !mrcal_amd_problem_gather_state(P)) return -1.0;
     P->stats.seconds_solve = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return sqrt(P->stats.norm2_x / (double)P->L.Nmeas);
 }
@@ -539,64 +580,34 @@ bool mrcal_amd_problem_gauss_newton_step(mrcal_amd_problem_t* P, double* step)
 }
 
 ////////////////////////////////////////////////////////////////////////////////
-// Phase API: the pieces of one dog-leg step, for the multi-GPU driver
-// (mrcal_amd/parallel.py), which interleaves them with RCCL all-reduces of the
-// buffers exposed by mrcal_amd_problem_buffer(). Everything is queued on the
-// problem's stream; nothing here synchronizes with the host
+// multi-GPU (include/mrcal_amd.h). The sharded step IS the single-GPU step with
+// two all-reduces in it (enqueue_trial_step); what is here is the attachment of
+// the communicator, the final gather of the state, and the same step cut at the
+// collectives for a driver that brings its own (the protocol tests)
 ////////////////////////////////////////////////////////////////////////////////
-void* mrcal_amd_problem_buffer(mrcal_amd_problem_t* P, int which, int iop, int64_t* Nelements)
+bool mrcal_amd_problem_attach_comm(mrcal_amd_problem_t* P, mrcal_amd_comm_t* comm)
 {
-    if(!problem_prepare_solver(P)) return NULL;
-    const NormalDims& nd = P->nd;
-    mrcal_amd_oppoint& op = P->op[iop & 1];
-    void* p = NULL; int64_t n = 0;
-    switch(which)
-    {
-    case MRCAL_AMD_BUF_B:           p = op.b;           n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_X:           p = op.x;           n = P->L.Nmeas; break;
-    case MRCAL_AMD_BUF_G:           p = op.g;           n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_STEP_CAUCHY: p = op.step_cauchy; n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_STEP_GN:     p = op.step_gn;     n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_SCALARS:     p = op.scalars;     n = NSCALARS;  break;
-    case MRCAL_AMD_BUF_STEP:        p = P->d_step;      n = nd.Nstate; break;
-    case MRCAL_AMD_BUF_SCHUR:       p = P->F.S;         n = (int64_t)nd.Nc*nd.Nc + nd.Nc; break;
-    case MRCAL_AMD_BUF_STATUS:      p = P->F.status;    n = 1; break;
-    default: set_error("unknown buffer %d", which);
-    }
-    if(Nelements) *Nelements = n;
-    return p;
+    last_error_string().clear();
+    if(!problem_prepare_solver(P)) return false;
+    P->comm = comm;
+    P->ctl_initialized = false;
+    return true;
+}
+bool mrcal_amd_problem_gather_state(mrcal_amd_problem_t* P)
+{
+    last_error_string().clear();
+    if(P->comm == NULL) return true;
+    // everybody zeroes what it does not own (the camera block belongs to the leader), then the sum is the state
+    HIP_TRY(launch_mask_state(P->nd, P->br, P->is_leader, P->op[P->icur].b, P->stream), return false);
+    if(!mrcal_amd_comm_allreduce_sum(P->comm, P->op[P->icur].b, P->nd.Nstate, (void*)P->stream)) return false;
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    return true;
 }
 void mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info)
 {
     info[0] = P->nd.Nstate; info[1] = P->nd.Nie; info[2] = P->nd.NE; info[3] = P->nd.Nc;
     info[4] = P->br.frame_lo; info[5] = P->br.frame_hi; info[6] = P->is_leader ? 1 : 0;
     info[7] = P->D.Nobs_board * P->D.W * P->D.H;
-}
-bool mrcal_amd_problem_phase_evaluate(mrcal_amd_problem_t* P, int iop)
-{
-    if(!problem_prepare_solver(P)) return false;
-    return problem_evaluate_op(P, iop & 1, true, true);
-}
-bool mrcal_amd_problem_phase_quadform(mrcal_amd_problem_t* P, int iop, const double* v_dev, double* out_dev)
-{
-    HIP_TRY(launch_quadform(P->nd, P->opref(iop & 1), v_dev, out_dev, P->stream), return false);
-    return true;
-}
-bool mrcal_amd_problem_phase_factor_local(mrcal_amd_problem_t* P, int iop, double lambda)
-{
-    P->stats.Nfactorizations++;
-    HIP_TRY(hipMemsetAsync(P->F.status, 0, sizeof(int), P->stream), return false);
-    HIP_TRY(launch_factor_local(P->nd, P->br, P->opref(iop & 1), P->F, lambda, NULL, P->is_leader, P->stream), return false);
-    return true;
-}
-bool mrcal_amd_problem_phase_solve_backsub(mrcal_amd_problem_t* P, int iop)
-{
-    if(P->br.count() < P->nd.NEb && P->nd.NE > 0)
-        // a shard writes only its own blocks; the others' entries must be 0 for
-        // the all-reduce that follows (they may hold the previous sum)
-        HIP_TRY(hipMemsetAsync(P->op[iop & 1].step_gn + P->nd.Nie, 0, (size_t)P->nd.NE*sizeof(double), P->stream), return false);
-    HIP_TRY(launch_solve_backsub(P->nd, P->br, P->opref(iop & 1), P->F, NULL, true, P->stream), return false);
-    return true;
 }
 // outlier statistics / marking on the local board observations
 // (mrcal.c:3978-4402). counts (device int[4]) and sums (device double[1]) are
@@ -616,21 +627,6 @@ bool mrcal_amd_problem_phase_mark_outliers(mrcal_amd_problem_t* P, int iop, doub
 }
 void mrcal_amd_problem_set_current(mrcal_amd_problem_t* P, int iop) { P->icur = iop & 1; }
 
-////////////////////////////////////////////////////////////////////////////////
-// Sharded step: the device-controlled trial step of enqueue_trial_step(), cut
-// at the four points where a quantity has to be summed over the shards. The
-// driver (mrcal_amd/parallel.py) queues   segment 0 | all-reduce buffer 0 |
-// segment 1 | all-reduce buffer 1 | ... | segment 4   on the problem's stream,
-// for as many trial steps as it likes, without ever reading anything back: the
-// control block is replicated, every rank computes the same decisions from the
-// same sums. initial: the evaluation of the starting point (segments 2..4)
-//   seg 0  step_begin, local block elimination, local Schur summand   -> [S | r]
-//   seg 1  Cholesky of the summed S (replicated), local back-substitution -> E part of step_gn
-//   seg 2  step selection, evaluation of x, J, Gram and the block normal
-//          equations of the trial point                               -> [g | |x|^2]
-//   seg 3  g^T N g (local part)                                       -> g^T N g
-//   seg 4  Cauchy step of the new point, rho test, accept/reject
-////////////////////////////////////////////////////////////////////////////////
 bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_termination, int max_iterations,
                                      double trustregion0)
 {
@@ -639,67 +635,54 @@ bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_terminati
     DoglegParameters prm;
     if(max_iterations > 0)  prm.max_iterations = max_iterations;
     if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
-    // the g^T N g slot is accumulated into, and cleared again by the kernel that consumes it
-    HIP_TRY(hipMemsetAsync(P->comm_gng(), 0, sizeof(double), P->stream), return false);
-    P->stats.lambda = 0.0;      // a new run starts unregularized, like a new libdogleg context
+    P->sharded_external = true;     // the caller sums comm_buffer(0), comm_buffer(1) over the shards itself
+    P->stats.lambda = 0.0;          // a new run starts unregularized, like a new libdogleg context
     return ctl_reset(P, prm, check_termination != 0);
 }
 
+// segment 0: up to the first sum over the shards; 1: from there to the second
 bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int segment)
 {
     if(!P->ctl_initialized) { set_error("mrcal_amd_problem_sharded_reset() first"); return false; }
     SolverCtl* ctl = P->d_ctl;
     const bool init = initial != 0;
-    const OpRef Rfrom = { P->d_ops, &ctl->ib, solver_ctl_skip_factor(ctl) };
-    const OpRef Rto   = { P->d_ops, init ? &ctl->ib : &ctl->ia, init ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
-    switch(segment)
+    const Step2Args a = step2_args(P);
+    if(segment == 0)
     {
-    case 0:
-        if(init) return true;
-        // (the trial was started by the previous step's last kernel)
-        HIP_TRY(launch_factor_local(P->nd, P->br, Rfrom, P->F, 0.0, ctl, P->is_leader, P->stream), return false);
-        HIP_TRY(launch_shard_prepare_schur(P->nd, ctl, P->F, P->stream), return false);
-        return true;
-    case 1:
-        if(init) return true;
-        HIP_TRY(launch_solve_backsub(P->nd, P->br, Rfrom, P->F, NULL, false, P->stream), return false);
-        HIP_TRY(launch_shard_pack_gn(P->nd, P->br, P->d_ops, ctl, P->comm_gn(), P->stream), return false);
-        return true;
-    case 2:
-        if(!init)
+        if(init)
         {
-            // (the summed frame/point part of the Gauss-Newton step is read from the buffer)
-            HIP_TRY(launch_step_choose(P->nd, P->d_ops, ctl, P->F, P->d_step, P->stream, true, 3,
-                                       P->nd.NE > 0 ? P->comm_gn() : NULL), return false);
+            const OpRef R = { P->d_ops, &ctl->ib, NULL };
+            if(!problem_evaluate_ref(P, R, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
         }
-        if(!problem_evaluate_ref(P, Rto, true, true)) return false;
-        HIP_TRY(launch_shard_pack_point(P->nd, P->d_ops, ctl, init, P->comm_point(), P->stream), return false);
+        else
+        {
+            const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
+            HIP_TRY(launch_step2_choose(a, P->stream), return false);
+            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
+        }
+        HIP_TRY(launch_step2_assemble(a, init, P->stream), return false);
+        HIP_TRY(launch_step2_reduce(a, P->stream), return false);
         return true;
-    case 3:
-        HIP_TRY(launch_shard_point_sums(P->nd, P->d_ops, ctl, init, P->comm_point(), P->comm_gng(), P->stream), return false);
-        return true;
-    case 4:
-        // Cauchy step of the new point, accept/reject, and the start of the next trial: one launch
-        HIP_TRY(launch_shard_step_finish(P->nd, P->d_ops, ctl, P->F.status, init, P->comm_gng(), P->stream), return false);
+    }
+    if(segment == 1)
+    {
+        HIP_TRY(launch_step2_factor(a, init, P->stream), return false);
         return true;
     }
     set_error("mrcal_amd_problem_sharded_enqueue(): segment %d", segment);
     return false;
 }
 
-// the buffer to all-reduce (sum) after segment 0..3; Nelements may be 0
-void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* P, int segment, int64_t* Nelements)
+// the buffer to sum over the shards after segment 0 / 1
+void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* P, int which, int64_t* Nelements)
 {
     if(!problem_prepare_solver(P)) return NULL;
-    const NormalDims& nd = P->nd;
     void* p = NULL; int64_t n = 0;
-    switch(segment)
+    switch(which)
     {
-    case 0: p = P->F.S;          n = (int64_t)nd.Nc*nd.Nc + nd.Nc; break;
-    case 1: p = P->comm_gn();    n = nd.NE;         break;
-    case 2: p = P->comm_point(); n = nd.Nstate + 2; break;
-    case 3: p = P->comm_gng();   n = 1;             break;
-    default: set_error("mrcal_amd_problem_sharded_comm_buffer(): segment %d", segment);
+    case 0: p = P->F.S;    n = step2_comm1_doubles(P->nd); break;
+    case 1: p = P->d_comm; n = 4; break;
+    default: set_error("mrcal_amd_problem_sharded_comm_buffer(): %d", which);
     }
     if(Nelements) *Nelements = n;
     return p;

@@ -866,7 +866,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
 // order in which workgroups finish
 #define SRED_SPLIT 4      // threads sharing one output element (adjacent lanes)
 __device__ __forceinline__
-void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int is_leader,
+void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int add_g /* r starts from g_S (else from 0) */,
                        int nslots, const double* __restrict__ Spart,
                        double* __restrict__ S, double* __restrict__ r, int block)
 {
@@ -910,7 +910,7 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
     {
         const int i = idx - nS;
         if(i < nd.Nc)
-            r[i] = (is_leader ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0) - acc;
+            r[i] = (add_g ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0) - acc;
     }
 }
 __global__ __launch_bounds__(256)
@@ -1127,7 +1127,7 @@ struct SolverCtlFlags;
 struct Step2Dev
 {
     NormalDims nd; const OpDev* ops; SolverCtl* ctl; SolverCtlFlags* fl;
-    int initial; const double* qf_part; int qf_n;
+    int initial; const double* comm1_tail;       // [g_S (Nc) | |x|^2 | status] behind S and r
 };
 __device__ bool step2_finish(const Step2Dev& sd, int* chol_status);        // one workgroup; true: factor
 __device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite);   // one thread
@@ -1979,7 +1979,7 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
 #define QF_ROWS_PER_WAVE 8
 // this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
 __device__ __forceinline__
-double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block)
+double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nrows = nd.Nc + nd.NE;
@@ -2034,7 +2034,7 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
         }
         t_vNv = total;
         t_gv  = O.g[is]*vr;
-        t_vv  = vr*vr;
+        t_vv  = (vv_E_only && row < nd.Nc) ? 0.0 : vr*vr;
     }
     for(int off=4; off>0; off>>=1)
     {
@@ -2168,225 +2168,6 @@ struct SolverCtlFlags { int skip_factor, skip_eval;
                         int elim_mode, elim_sel, skip_elim, skip_asm, skip_chol, skip_backsub; };
 static_assert(sizeof(SolverCtlFlags) == 32, "");
 
-// start of a trial step (one thread): does this trial factor, does it evaluate
-__device__ __forceinline__ void ctl_begin(const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl, int* chol_status)
-{
-    ctl->abort_step = 0;
-    *chol_status = 0;
-    {
-        double* sc = ops[ctl->ib].scalars;
-        sc[SC_STEP_SNS] = sc[SC_STEP_GS] = sc[SC_STEP_SS] = 0.0;
-        if(!ctl->gn_valid[ctl->ib]) sc[SC_GN_LENSQ] = sc[SC_GN_DOT_CAUCHY] = 0.0;
-    }
-    if(!ctl->done && ctl->check_termination && ctl->Nsteps_accepted >= ctl->max_iterations)
-        ctl->done = 1;
-    if(ctl->done) { fl->skip_factor = 1; fl->skip_eval = 1; ctl->need_gn = 0; return; }
-    const int ib = ctl->ib;
-    const double tr = ctl->trustregion;
-    // the Cauchy step reaches the edge of the trust region: no need for Gauss-Newton
-    const bool cauchy_only = ctl->cauchy_lensq[ib] >= tr*tr;
-    ctl->need_gn = (!cauchy_only && !ctl->gn_valid[ib]) ? 1 : 0;
-    if(ctl->need_gn) ctl->Nfactorizations++;
-    fl->skip_factor = ctl->need_gn ? 0 : 1;
-    fl->skip_eval   = 0;
-}
-
-// |step_gn|^2 -> scalars[SC_GN_LENSQ], step_cauchy . step_gn -> scalars[SC_GN_DOT_CAUCHY] of the point ctl->ib
-__global__ __launch_bounds__(256)
-void gn_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                    const SolverCtlFlags* __restrict__ fl)
-{
-    if(fl->skip_factor) return;
-    const OpDev& O = ops[ctl->ib];
-    double a = 0.0, b = 0.0;
-    for(int i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += gridDim.x*blockDim.x)
-    {
-        const double gn = O.step_gn[i];
-        a += gn*gn;
-        b += gn*O.step_cauchy[i];
-    }
-    for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    __shared__ double part[4][2];
-    if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
-    __syncthreads();
-    if(threadIdx.x == 0) atomicAdd(&O.scalars[SC_GN_LENSQ], part[0][0]+part[1][0]+part[2][0]+part[3][0]);
-    if(threadIdx.x == 1) atomicAdd(&O.scalars[SC_GN_DOT_CAUCHY], part[0][1]+part[1][1]+part[2][1]+part[3][1]);
-}
-
-// Chooses the dog-leg step from the point ctl->ib for the current trust
-// region, writes step and the trial state b[ia] = b[ib] + step. Every
-// workgroup derives the same coefficients from the control block; workgroup 0
-// records them. Fields written here are not read by the other workgroups of
-// this launch
-__global__ __launch_bounds__(256)
-void step_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                        const int* __restrict__ chol_status, double* __restrict__ step, int compute_dots,
-                        const double* __restrict__ gn_E)
-{
-    if(ctl->done) return;
-    const int  ib = ctl->ib, ia = ctl->ia;
-    const OpDev& from = ops[ib];
-    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
-    const bool fresh_gn = ctl->need_gn != 0;
-    // sharded: the frame/point part of a fresh Gauss-Newton step arrives summed
-    // over the shards in a communication buffer (every shard back-substituted
-    // its own blocks); it is stored into the point on the way
-    const bool from_comm = (gn_E != NULL) && !fl->skip_factor;
-    auto gn_at = [&](int i) -> double
-    {
-        return (from_comm && i >= nd.Nie && i < nd.Nie + nd.NE) ? gn_E[i - nd.Nie] : from.step_gn[i];
-    };
-
-    // |step_gn|^2 and step_gn . step_cauchy of a fresh Gauss-Newton step: every
-    // workgroup sums the whole vectors itself, in the same fixed order (so all
-    // of them, on every rank, get the same bits), instead of a reduction kernel
-    // of its own in front of this one
-    __shared__ double dots[3];
-    if(fresh_gn && compute_dots)
-    {
-        // (all of a batch's loads in flight together: each thread walks 24 elements
-        //  of three vectors at NS, and one L2 round trip per element is most of
-        //  this kernel's time)
-        double a = 0.0, b = 0.0, c = 0.0;
-        constexpr int UB = 6;
-        for(int i0 = threadIdx.x; i0 < nd.Nstate; i0 += UB*blockDim.x)
-        {
-            double vg[UB], vc[UB], vx[UB];
-#pragma unroll
-            for(int u = 0; u < UB; u++)
-            {
-                const int  i  = i0 + u*blockDim.x;
-                const bool ok = i < nd.Nstate;
-                const int  ic = ok ? i : 0;
-                vg[u] = ok ? gn_at(ic) : 0.0;
-                vc[u] = from.step_cauchy[ic];
-                vx[u] = from.g[ic];
-            }
-#pragma unroll
-            for(int u = 0; u < UB; u++)
-            {
-                a += vg[u]*vg[u];
-                b += vg[u]*vc[u];
-                c += vg[u]*vx[u];
-            }
-        }
-        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
-        __shared__ double part[4][3];
-        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
-        __syncthreads();
-        if(threadIdx.x < 3)
-            dots[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        __syncthreads();
-        if(leader) { from.scalars[SC_GN_LENSQ] = dots[0]; from.scalars[SC_GN_DOT_CAUCHY] = dots[1]; }
-    }
-    const double gn_lensq_now = (fresh_gn && compute_dots) ? dots[0] : from.scalars[SC_GN_LENSQ];
-    const double gn_dot_now   = (fresh_gn && compute_dots) ? dots[1] : from.scalars[SC_GN_DOT_CAUCHY];
-
-    if(fresh_gn)
-    {
-        const double lensq = gn_lensq_now;
-        if(*chol_status != 0 || !(lensq == lensq))
-        {
-            // JtJ is singular: regularize, like libdogleg does, and void this trial
-            if(leader)
-            {
-                double lam = ctl->lambda;
-                lam = (lam == 0.0) ? 1e-10 : lam*10.0;
-                ctl->lambda = lam;
-                if(!(lam < 1e30)) { ctl->error = 1; ctl->done = 1; }
-                ctl->abort_step = 1;
-                fl->skip_eval   = 1;
-            }
-            return;
-        }
-    }
-
-    const double tr = ctl->trustregion, dsq = tr*tr;
-    const double norm2a = ctl->cauchy_lensq[ib];
-    double kc, kg, len_sq;
-    int edge;
-    double norm2b = 0.0, ab = 0.0;
-    if(norm2a >= dsq)
-    {
-        kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
-    }
-    else
-    {
-        // Gauss-Newton step: fresh from this trial's factorization, or kept
-        // from an earlier, rejected trial from the same point
-        norm2b = fresh_gn ? gn_lensq_now : ctl->gn_lensq[ib];
-        ab     = gn_dot_now;
-        if(norm2b <= dsq)
-        {
-            kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
-        }
-        else
-        {
-            // point on the Cauchy->GN segment at the trust-region edge:
-            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
-            const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
-            const double neg_c = norm2a - ab;                // a.(a-b)
-            double disc = neg_c*neg_c - l2*(norm2a - dsq);
-            if(disc < 0.0) disc = 0.0;
-            const double k = (neg_c + sqrt(disc))/l2;
-            kc = 1.0 - k; kg = k;
-            len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
-            edge = 1;
-        }
-    }
-
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i < nd.Nstate)
-    {
-        const double gni = gn_at(i);
-        // (the other workgroups read these entries from the buffer, not from here)
-        if(from_comm && fresh_gn && i >= nd.Nie && i < nd.Nie + nd.NE) from.step_gn[i] = gni;
-        double s = kc*from.step_cauchy[i];
-        if(kg != 0.0) s += kg*gni;
-        step[i] = s;
-        ops[ia].b[i] = from.b[i] + s;
-    }
-
-    if(leader)
-    {
-        if(fresh_gn)
-        {
-            ctl->gn_lensq[ib] = norm2b; ctl->gn_valid[ib] = 1;
-            ctl->gn_dot_g[ib]  = compute_dots ? dots[2] : 0.0;
-            ctl->gn_lambda[ib] = ctl->lambda;
-        }
-        // The expected improvement |x|^2 - |x + J s|^2 = -2 g.s - s^T N s WITHOUT a
-        // pass over N: the step is kc s_c + kg s_gn with s_c = k g and
-        // (N + lambda I) s_gn = -g, so every term is a dot product already at hand:
-        //   s_c^T N s_c   = k^2 g^T N g
-        //   s_c^T N s_gn  = -k g.g - lambda s_c.s_gn
-        //   s_gn^T N s_gn = -g.s_gn - lambda |s_gn|^2
-        {
-            const double gNg = from.scalars[SC_G_GNG], gg = from.scalars[SC_G_GG];
-            const double k   = (gNg > 0.0) ? -gg/gNg : 0.0;
-            double sNs = kc*kc*k*k*gNg, gs = kc*k*gg;
-            if(kg != 0.0)
-            {
-                const double a = ctl->gn_dot_g[ib], lam = ctl->gn_lambda[ib];
-                sNs += 2.0*kc*kg*(-k*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
-                gs  += kg*a;
-            }
-            from.scalars[SC_STEP_SNS] = sNs;
-            from.scalars[SC_STEP_GS]  = gs;
-            from.scalars[SC_STEP_SS]  = len_sq;
-        }
-        ctl->k_cauchy = kc; ctl->k_gn = kg;
-        ctl->step_len_sq = len_sq;
-        ctl->did_step_to_edge[ib] = edge;
-        ctl->Ntrials++;
-        if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
-        {
-            ctl->done = 1;
-            fl->skip_eval = 1;
-        }
-    }
-}
-
 // rho test, trust-region update, accept/reject (one thread)
 __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, SolverCtl* ctl)
 {
@@ -2416,56 +2197,35 @@ __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, Solver
             (tr < ctl->trustregion_threshold || tr == 0.0 || !(tr == tr)))
         ctl->done = 1;
 }
-// End of a trial step, in one launch of ONE workgroup: the Cauchy step
-// -(|g|^2/|Jg|^2) g of the point just evaluated and its bookkeeping, the rho
-// test with accept/reject (ctl_accept) and the start of the NEXT trial
-// (ctl_begin). One workgroup so that a barrier separates "everyone has read the
-// control state" from "thread 0 rewrites it"; the vector part is Nstate
-// elements. initial: the evaluation of the starting point (no accept).
-// gng_src (sharded): g^T N g summed over the shards, in its communication slot
-__global__ __launch_bounds__(1024)
-void step_finish_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                        int* chol_status, int initial, double* __restrict__ gng_src)
-{
-    const bool skip = !initial && fl->skip_eval;
-    const int  ip   = initial ? ctl->ib : ctl->ia;
-    const OpDev& O  = ops[ip];
-    // (sharded: g^T N g arrives summed over the shards in a communication buffer)
-    const double gNg = (gng_src != NULL) ? gng_src[0] : O.scalars[SC_G_GNG];
-    const double norm2_g = O.scalars[SC_G_GG], norm2_x = O.scalars[SC_NORM2_X];
-    const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
-    __syncthreads();
-    if(gng_src != NULL && threadIdx.x == 0) gng_src[0] = 0.0;       // the next point accumulates into it
-    if(!skip)
-        for(int i = threadIdx.x; i < nd.Nstate; i += blockDim.x) O.step_cauchy[i] = k*O.g[i];
-    if(threadIdx.x == 0)
-    {
-        if(!skip)
-        {
-            if(gng_src != NULL) O.scalars[SC_G_GNG] = gNg;
-            ctl->norm2_x[ip]      = norm2_x;
-            ctl->cauchy_lensq[ip] = k*k*norm2_g;
-            ctl->gn_valid[ip]     = 0;
-            ctl->did_step_to_edge[ip] = 0;
-            ctl->Nevaluations++;
-            if(!initial) ctl_accept(ops, ctl);
-        }
-        ctl_begin(ops, ctl, fl, chol_status);
-    }
-}
-
 ////////////////////////////////////////////////////////////////////////////////
-// the fused step (single GPU): choose | evaluate | assemble+eliminate | SYRK+finalize
-// | reduce+quadform | finish+Cholesky | backsub.  See solver_kernels.hpp
+// the fused step: choose | evaluate | assemble+eliminate | SYRK+finalize | reduce
+// | finish+Cholesky | backsub+quadform.  See solver_kernels.hpp
 ////////////////////////////////////////////////////////////////////////////////
-// The Gauss-Newton step is computed EAGERLY: a point that is accepted (and whose
-// Cauchy step does not already leave the trust region) is factored in the launch
-// that accepts it, from the elimination that rode along in its assembly.
-// libdogleg computes it lazily at the start of the next trial; the step taken is
-// the same. ctl->refactor: the current point must be eliminated (again) before a
-// step can be chosen from it - lambda was raised after a failed factorization
-// (libdogleg: "singular JtJ: adding lambda I from now on"), or its Gauss-Newton
-// step is needed after all and was never computed.
+// The Gauss-Newton step is computed EAGERLY: a point that is accepted is
+// factored in the launch that accepts it, from the elimination that rode along
+// in its assembly. libdogleg computes it lazily at the start of the next trial;
+// the step taken is the same. ctl->refactor: the current point must be
+// eliminated (again) before a step can be chosen from it - lambda was raised
+// after a failed factorization (libdogleg: "singular JtJ: adding lambda I from now
+// on"), or its Gauss-Newton step was never computed.
+//
+// The SAME step runs sharded over several GPUs (frames partitioned over the
+// ranks; mrcal_amd/parallel.py, solver.cpp). What a rank computes from its own
+// frames only is summed over the ranks in TWO collectives per trial:
+//   comm1 (after the reduce):    [ S | r | g_S | |x|^2 | status ]        Nc^2 + 2 Nc + 2 doubles
+//   comm2 (after the backsub):   [ g^T N g | |g_E|^2 | |gn_E|^2 | gn_E . g_E ]      4 doubles
+// Everything else is either rank-local (the frame part of the state, of g, of the
+// steps) or REPLICATED: the camera block of the state, and the control block,
+// which every rank advances with the same kernels on the same sums, so that all
+// ranks take the same decisions without talking about them. For that the sums a
+// rank forms by itself from replicated data must be bit-identical on all ranks:
+// fixed-order reductions everywhere, no atomics.
+//   comm1 == F.S (S, r and the tail are contiguous); comm2 given to the kernels:
+//   sharded. NULL: single GPU, the partial sums are read where they were left.
+#define COMM2_GNG    0
+#define COMM2_GGE    1
+#define COMM2_GNE2   2
+#define COMM2_GNE_GE 3
 
 __device__ __forceinline__ void ctl_raise_lambda(SolverCtl* ctl)
 {
@@ -2475,14 +2235,57 @@ __device__ __forceinline__ void ctl_raise_lambda(SolverCtl* ctl)
     if(!(lam < 1e30)) { ctl->error = 1; ctl->done = 1; }
 }
 
+// sum of n values v(i), by the whole workgroup (256 threads), in an order that
+// depends on n alone; the result in every thread. NOUT values at once
+template<int NOUT, class F>
+__device__ __forceinline__ void block_sum_fixed(int n, F&& v, double (&out)[NOUT], double* __restrict__ scratch /* [4][NOUT] + [NOUT] */)
+{
+    double acc[NOUT];
+#pragma unroll
+    for(int k = 0; k < NOUT; k++) acc[k] = 0.0;
+    for(int i = threadIdx.x; i < n; i += blockDim.x)
+    {
+        double t[NOUT];
+        v(i, t);
+#pragma unroll
+        for(int k = 0; k < NOUT; k++) acc[k] += t[k];
+    }
+#pragma unroll
+    for(int k = 0; k < NOUT; k++)
+        for(int off=32; off>0; off>>=1) acc[k] += __shfl_down(acc[k], off);
+    __syncthreads();            // scratch is free
+    if((threadIdx.x & 63) == 0)
+#pragma unroll
+        for(int k = 0; k < NOUT; k++) scratch[(threadIdx.x >> 6)*NOUT + k] = acc[k];
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    if(threadIdx.x < NOUT)
+    {
+        double t = 0.0;
+        for(int w = 0; w < nw; w++) t += scratch[w*NOUT + threadIdx.x];
+        scratch[16*NOUT + threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for(int k = 0; k < NOUT; k++) out[k] = scratch[16*NOUT + k];
+}
+
 // Chooses the dog-leg step from the point ctl->ib for the current trust region,
 // writes step and the trial state b[ia] = b[ib] + step; sets the flags of this
-// trial. As step_choose_kernel: every workgroup derives the same coefficients;
-// workgroup 0 records them; fields written here are not read by the other
-// workgroups of this launch
+// trial. Every workgroup derives the same numbers from the same data in the same
+// order; workgroup 0 records them; fields written here are not read by the other
+// workgroups of this launch.
+// The first trial from a new current point (ctl->derive) also finishes that
+// point: g^T N g (partials of the quadratic-form workgroups, or comm2), |g|^2, the
+// Cauchy step -(|g|^2/|Jg|^2) g. A fresh Gauss-Newton step (ctl->gn_fresh) gets
+// its dot products here: the camera-block part from the vectors, the frame/point
+// part from the back-substitution's per-block partials (or comm2)
 __global__ __launch_bounds__(256)
 void step2_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                         int* __restrict__ chol_status, double* __restrict__ step)
+                         int* __restrict__ chol_status, double* __restrict__ step,
+                         const double* __restrict__ qf_part, int qf_n,
+                         const double* __restrict__ dots_part, int dots_n,
+                         const double* __restrict__ comm2)
 {
     const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
     if(ctl->done)
@@ -2490,10 +2293,37 @@ void step2_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl
         if(leader) { fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1; }
         return;
     }
+    __shared__ double scratch[16*4 + 4];
     const int  ib = ctl->ib, ia = ctl->ia;
     const OpDev& from = ops[ib];
+    const bool derive = ctl->derive != 0;
+    auto s_to_state = [&](int i) -> int { return (i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie); };
+
+    // the point's own numbers
+    double gNg, gg, kcau, norm2a;
+    if(derive)
+    {
+        double o[1];
+        block_sum_fixed<1>(nd.Nc, [&](int i, double (&t)[1]) { const double v = from.g[s_to_state(i)]; t[0] = v*v; }, o, scratch);
+        double q, ggE;
+        if(comm2 != NULL) { q = comm2[COMM2_GNG]; ggE = comm2[COMM2_GGE]; }
+        else
+        {
+            double o2[2];
+            block_sum_fixed<2>(qf_n, [&](int i, double (&t)[2]) { t[0] = qf_part[4*i]; t[1] = qf_part[4*i + 2]; }, o2, scratch);
+            q = o2[0]; ggE = o2[1];
+        }
+        gNg = q; gg = o[0] + ggE;
+        kcau = (gNg > 0.0) ? -gg/gNg : 0.0;
+        norm2a = kcau*kcau*gg;
+    }
+    else
+    {
+        gNg = from.scalars[SC_G_GNG]; gg = from.scalars[SC_G_GG];
+        kcau = (gNg > 0.0) ? -gg/gNg : 0.0;
+        norm2a = ctl->cauchy_lensq[ib];
+    }
     const double tr = ctl->trustregion, dsq = tr*tr;
-    const double norm2a = ctl->cauchy_lensq[ib];
     const bool cauchy_only = norm2a >= dsq;
     if(ctl->refactor || (!cauchy_only && !ctl->gn_valid[ib]))
     {
@@ -2504,168 +2334,169 @@ void step2_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl
             *chol_status = 0;
             fl->skip_eval = 1; fl->elim_mode = 2; fl->elim_sel = ib; fl->skip_elim = 0; fl->skip_asm = 1;
         }
-        return;
+        // (the Cauchy step of a new point is still recorded below)
     }
-    const bool fresh_gn = !cauchy_only && ctl->gn_fresh != 0;
+    const bool voided = ctl->refactor || (!cauchy_only && !ctl->gn_valid[ib]);
+    const bool fresh_gn = !voided && !cauchy_only && ctl->gn_fresh != 0;
 
-    // |step_gn|^2, step_gn . step_cauchy, step_gn . g of a fresh Gauss-Newton step:
-    // every workgroup sums the whole vectors itself, in the same fixed order
-    __shared__ double dots[3];
+    double gn_lensq = ctl->gn_lensq[ib], gn_dot_g = ctl->gn_dot_g[ib];
     if(fresh_gn)
     {
-        double a = 0.0, b = 0.0, c = 0.0;
-        constexpr int UB = 6;
-        for(int i0 = threadIdx.x; i0 < nd.Nstate; i0 += UB*blockDim.x)
+        double o[2];
+        block_sum_fixed<2>(nd.Nc, [&](int i, double (&t)[2])
+                           { const int is = s_to_state(i); const double gn = from.step_gn[is]; t[0] = gn*gn; t[1] = gn*from.g[is]; },
+                           o, scratch);
+        double e2, eg;
+        if(comm2 != NULL) { e2 = comm2[COMM2_GNE2]; eg = comm2[COMM2_GNE_GE]; }
+        else
         {
-            double vg[UB], vc[UB], vx[UB];
-#pragma unroll
-            for(int u = 0; u < UB; u++)
-            {
-                const int  i  = i0 + u*blockDim.x;
-                const bool ok = i < nd.Nstate;
-                const int  ic = ok ? i : 0;
-                vg[u] = ok ? from.step_gn[ic] : 0.0;
-                vc[u] = from.step_cauchy[ic];
-                vx[u] = from.g[ic];
-            }
-#pragma unroll
-            for(int u = 0; u < UB; u++)
-            {
-                a += vg[u]*vg[u];
-                b += vg[u]*vc[u];
-                c += vg[u]*vx[u];
-            }
+            double o2[2];
+            block_sum_fixed<2>(dots_n, [&](int i, double (&t)[2]) { t[0] = dots_part[2*i]; t[1] = dots_part[2*i + 1]; }, o2, scratch);
+            e2 = o2[0]; eg = o2[1];
         }
-        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); c += __shfl_down(c, off); }
-        __shared__ double part[4][3];
-        if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; part[threadIdx.x >> 6][2] = c; }
-        __syncthreads();
-        if(threadIdx.x < 3)
-            dots[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-        __syncthreads();
-        if(leader) { from.scalars[SC_GN_LENSQ] = dots[0]; from.scalars[SC_GN_DOT_CAUCHY] = dots[1]; }
-        if(!(dots[0] == dots[0]))
-        {
-            // a Gauss-Newton step that is not a number: treat the factorization as failed
-            if(leader)
-            {
-                ctl_raise_lambda(ctl);
-                ctl->refactor = 1; ctl->abort_step = 1; ctl->gn_valid[ib] = 0;
-                *chol_status = 0;
-                fl->skip_eval = 1; fl->elim_mode = ctl->done ? 0 : 2; fl->elim_sel = ib;
-                fl->skip_elim = ctl->done ? 1 : 0; fl->skip_asm = 1;
-            }
-            return;
-        }
+        gn_lensq = o[0] + e2; gn_dot_g = o[1] + eg;
     }
-    const double gn_lensq_now = fresh_gn ? dots[0] : ctl->gn_lensq[ib];
-    const double gn_dot_now   = fresh_gn ? dots[1] : from.scalars[SC_GN_DOT_CAUCHY];
+    bool gn_nan = fresh_gn && !(gn_lensq == gn_lensq);
 
-    double kc, kg, len_sq;
-    int edge;
+    double kc = 0.0, kg = 0.0, len_sq = 0.0;
+    int edge = 0;
     double norm2b = 0.0, ab = 0.0;
-    if(cauchy_only)
+    if(!voided && !gn_nan)
     {
-        kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
-    }
-    else
-    {
-        norm2b = gn_lensq_now;
-        ab     = gn_dot_now;
-        if(norm2b <= dsq)
+        if(cauchy_only)
         {
-            kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
+            kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
         }
         else
         {
-            // point on the Cauchy->GN segment at the trust-region edge:
-            // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
-            const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
-            const double neg_c = norm2a - ab;                // a.(a-b)
-            double disc = neg_c*neg_c - l2*(norm2a - dsq);
-            if(disc < 0.0) disc = 0.0;
-            const double k = (neg_c + sqrt(disc))/l2;
-            kc = 1.0 - k; kg = k;
-            len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
-            edge = 1;
+            norm2b = gn_lensq;
+            ab     = kcau*gn_dot_g;            // step_gn . step_cauchy
+            if(norm2b <= dsq)
+            {
+                kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
+            }
+            else
+            {
+                // point on the Cauchy->GN segment at the trust-region edge:
+                // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
+                const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
+                const double neg_c = norm2a - ab;                // a.(a-b)
+                double disc = neg_c*neg_c - l2*(norm2a - dsq);
+                if(disc < 0.0) disc = 0.0;
+                const double k = (neg_c + sqrt(disc))/l2;
+                kc = 1.0 - k; kg = k;
+                len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
+                edge = 1;
+            }
         }
     }
 
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if(i < nd.Nstate)
     {
-        double sv = kc*from.step_cauchy[i];
-        if(kg != 0.0) sv += kg*from.step_gn[i];
-        step[i] = sv;
-        ops[ia].b[i] = from.b[i] + sv;
+        const double ci = derive ? kcau*from.g[i] : from.step_cauchy[i];
+        if(derive) from.step_cauchy[i] = ci;
+        if(!voided && !gn_nan)
+        {
+            double sv = kc*ci;
+            if(kg != 0.0) sv = fma(kg, from.step_gn[i], sv);
+            step[i] = sv;
+            ops[ia].b[i] = from.b[i] + sv;
+        }
     }
 
-    if(leader)
+    if(!leader) return;
+    if(derive)
     {
-        if(fresh_gn)
-        {
-            ctl->gn_lensq[ib] = norm2b;
-            ctl->gn_dot_g[ib] = dots[2];
-        }
-        // the expected improvement -2 g.s - s^T N s from dot products (step_choose_kernel explains)
-        {
-            const double gNg = from.scalars[SC_G_GNG], gg = from.scalars[SC_G_GG];
-            const double k   = (gNg > 0.0) ? -gg/gNg : 0.0;
-            double sNs = kc*kc*k*k*gNg, gs = kc*k*gg;
-            if(kg != 0.0)
-            {
-                const double a = fresh_gn ? dots[2] : ctl->gn_dot_g[ib], lam = ctl->gn_lambda[ib];
-                sNs += 2.0*kc*kg*(-k*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
-                gs  += kg*a;
-            }
-            from.scalars[SC_STEP_SNS] = sNs;
-            from.scalars[SC_STEP_GS]  = gs;
-            from.scalars[SC_STEP_SS]  = len_sq;
-        }
-        ctl->k_cauchy = kc; ctl->k_gn = kg;
-        ctl->step_len_sq = len_sq;
-        ctl->did_step_to_edge[ib] = edge;
-        ctl->abort_step = 0;
-        ctl->Ntrials++;
+        from.scalars[SC_G_GNG] = gNg; from.scalars[SC_G_GG] = gg; from.scalars[SC_G_GG2] = gg;
+        ctl->cauchy_lensq[ib] = norm2a;
+    }
+    if(voided) return;
+    if(gn_nan)
+    {
+        // a Gauss-Newton step that is not a number: treat the factorization as failed
+        ctl_raise_lambda(ctl);
+        ctl->refactor = 1; ctl->abort_step = 1; ctl->gn_valid[ib] = 0;
         *chol_status = 0;
-        if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
+        fl->skip_eval = 1; fl->elim_mode = ctl->done ? 0 : 2; fl->elim_sel = ib;
+        fl->skip_elim = ctl->done ? 1 : 0; fl->skip_asm = 1;
+        return;
+    }
+    if(fresh_gn)
+    {
+        ctl->gn_lensq[ib] = gn_lensq;
+        ctl->gn_dot_g[ib] = gn_dot_g;
+        from.scalars[SC_GN_LENSQ] = gn_lensq; from.scalars[SC_GN_DOT_CAUCHY] = ab;
+    }
+    // The expected improvement |x|^2 - |x + J s|^2 = -2 g.s - s^T N s WITHOUT a
+    // pass over N: the step is kc s_c + kg s_gn with s_c = k g and
+    // (N + lambda I) s_gn = -g, so every term is a dot product already at hand:
+    //   s_c^T N s_c   = k^2 g^T N g
+    //   s_c^T N s_gn  = -k g.g - lambda s_c.s_gn
+    //   s_gn^T N s_gn = -g.s_gn - lambda |s_gn|^2
+    {
+        double sNs = kc*kc*kcau*kcau*gNg, gs = kc*kcau*gg;
+        if(kg != 0.0)
         {
-            ctl->done = 1;
-            fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1;
+            const double a = gn_dot_g, lam = ctl->gn_lambda[ib];
+            sNs += 2.0*kc*kg*(-kcau*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
+            gs  += kg*a;
         }
-        else
-        {
-            fl->skip_eval = 0; fl->elim_mode = 1; fl->elim_sel = ia; fl->skip_elim = 0; fl->skip_asm = 0;
-        }
+        from.scalars[SC_STEP_SNS] = sNs;
+        from.scalars[SC_STEP_GS]  = gs;
+        from.scalars[SC_STEP_SS]  = len_sq;
+    }
+    ctl->k_cauchy = kc; ctl->k_gn = kg;
+    ctl->step_len_sq = len_sq;
+    ctl->did_step_to_edge[ib] = edge;
+    ctl->abort_step = 0;
+    ctl->Ntrials++;
+    *chol_status = 0;
+    if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
+    {
+        ctl->done = 1;
+        fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1;
+    }
+    else
+    {
+        fl->skip_eval = 0; fl->elim_mode = 1; fl->elim_sel = ia; fl->skip_elim = 0; fl->skip_asm = 0;
     }
 }
 
-// S, r of the point being eliminated (reduction of the SYRK's slots) and, side by
-// side in the same launch, the quadratic form g^T N g of the point just evaluated
-// (per-workgroup partials into qf_part: no atomics)
+// S, r of the point being eliminated (reduction of the SYRK's slots: this rank's
+// summand) and, behind them, what else the end of the trial needs from all
+// ranks: g_S, |x|^2 and whether a frame block failed to factor. S | r | tail are
+// contiguous: ONE all-reduce when sharded
 __global__ __launch_bounds__(256)
-void step2_reduce_quadform_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                                  const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
-                                  int nslots, const double* __restrict__ Spart,
-                                  double* __restrict__ S, double* __restrict__ r, double* __restrict__ qf_part)
+void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
+                         const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
+                         int nslots, const double* __restrict__ Spart,
+                         double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status)
 {
     if(fl->skip_elim) return;
     const OpDev& O = ops[fl->elim_sel];
     if((int)blockIdx.x < nred)
     {
-        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, is_leader, nslots, Spart, S, r, blockIdx.x);
+        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, 1, nslots, Spart, S, r, blockIdx.x);
         return;
     }
-    if(fl->skip_asm) return;
-    const int qb = blockIdx.x - nred;
-    const double mine = quadform_body(nd, O, O.g, qb);
-    if(threadIdx.x < 3) qf_part[4*qb + threadIdx.x] = mine;
+    double* __restrict__ tail = r + nd.Nc;
+    for(int i = threadIdx.x; i < nd.Nc + 2; i += blockDim.x)
+    {
+        double v;
+        if(i < nd.Nc)       v = O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)];
+        else if(i == nd.Nc) v = O.scalars[SC_NORM2_X];
+        else                v = (*status != 0) ? 1.0 : 0.0;
+        tail[i] = v;
+    }
 }
 
-// End of a trial, in ONE workgroup, in front of the factorization: the Cauchy
-// step -(|g|^2/|Jg|^2) g of the point just evaluated, the rho test with
-// accept/reject (ctl_accept), the termination tests; then: does the (possibly new)
-// current point need its Gauss-Newton step now? Returns that, to every thread
+// End of a trial, in ONE workgroup, in front of the factorization: the rho test
+// with accept/reject (ctl_accept), the termination tests; then: does the
+// (possibly new) current point get its Gauss-Newton step now? Returns that, to
+// every thread. comm1 = [S | r | g_S | |x|^2 | status] is complete (summed over
+// the ranks when sharded): the camera-block part of the new point's gradient is
+// taken from it
 __device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
 {
     const NormalDims& nd = sd.nd;
@@ -2673,55 +2504,36 @@ __device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
     SolverCtlFlags* fl = sd.fl;
     const int t = threadIdx.x, nt = blockDim.x;
     const int mode = fl->elim_mode;
-    __shared__ double s_part[16][2];
-    __shared__ double s_tot[2];
-    __shared__ int    s_go;
+    __shared__ int s_go, s_unpack;
     const int ip = sd.initial ? ctl->ib : ctl->ia;        // the point that was evaluated (mode 1)
-    if(mode == 1)
+    const double* __restrict__ tail = sd.comm1_tail;
+    const double norm2_x = tail[nd.Nc];
+    const bool   eblock_failed = tail[nd.Nc + 1] != 0.0;
+    __syncthreads();                      // everyone has read the control state
+    if(t == 0)
     {
-        const OpDev& O = sd.ops[ip];
-        double a = 0.0, b = 0.0;
-        for(int i = t; i < sd.qf_n; i += nt) { a += sd.qf_part[4*i]; b += sd.qf_part[4*i + 1]; }
-        for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-        if((t & 63) == 0) { s_part[t >> 6][0] = a; s_part[t >> 6][1] = b; }
-        __syncthreads();
-        if(t < 2)
+        if(mode == 1)
         {
-            double v = 0.0;
-            for(int k = 0; k < (nt >> 6); k++) v += s_part[k][t];
-            s_tot[t] = v;
-        }
-        __syncthreads();
-        const double gNg = s_tot[0], norm2_g = s_tot[1];
-        const double norm2_x = O.scalars[SC_NORM2_X];
-        const double k = (gNg > 0.0) ? -norm2_g/gNg : 0.0;
-        for(int i = t; i < nd.Nstate; i += nt) O.step_cauchy[i] = k*O.g[i];
-        __syncthreads();                  // everyone has read the control state
-        if(t == 0)
-        {
-            O.scalars[SC_G_GNG] = gNg; O.scalars[SC_G_GG] = norm2_g; O.scalars[SC_G_GG2] = norm2_g;
-            ctl->norm2_x[ip]      = norm2_x;
-            ctl->cauchy_lensq[ip] = k*k*norm2_g;
-            ctl->gn_valid[ip]     = 0;
+            sd.ops[ip].scalars[SC_NORM2_X] = norm2_x;
+            ctl->norm2_x[ip]  = norm2_x;
+            ctl->gn_valid[ip] = 0;
             ctl->did_step_to_edge[ip] = 0;
             ctl->Nevaluations++;
             if(!sd.initial) ctl_accept(sd.ops, ctl);
         }
-    }
-    if(t == 0)
-    {
-        int go = 0;
+        int go = 0, unpack = 0;
         ctl->gn_fresh = 0;
+        ctl->derive   = 0;
         if(!ctl->done && ctl->check_termination && ctl->Nsteps_accepted >= ctl->max_iterations)
             ctl->done = 1;
+        const int ib = ctl->ib;
+        if(mode == 1 && ib == ip) { unpack = 1; ctl->derive = 1; }       // a new current point
         if(!ctl->done)
         {
-            const int ib = ctl->ib;
-            const double tr = ctl->trustregion;
             if(mode == 2)      go = 1;
-            else if(mode == 1) go = (ib == ip) && !ctl->gn_valid[ib] && !(ctl->cauchy_lensq[ib] >= tr*tr);
+            else if(mode == 1) go = (ib == ip);
         }
-        if(go && *chol_status != 0)
+        if(go && eblock_failed)
         {
             // a 6x6 (3x3) block was not positive definite: regularize, like libdogleg does
             ctl_raise_lambda(ctl);
@@ -2731,9 +2543,15 @@ __device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
         if(go) ctl->Nfactorizations++;
         fl->skip_backsub = 1;             // until the factorization has succeeded
         fl->skip_chol    = go ? 0 : 1;
-        s_go = go;
+        s_go = go; s_unpack = unpack;
+        (void)chol_status;
     }
     __syncthreads();
+    if(s_unpack)
+    {
+        const OpDev& O = sd.ops[ip];
+        for(int i = t; i < nd.Nc; i += nt) O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = tail[i];
+    }
     return s_go != 0;
 }
 __device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite)
@@ -2767,99 +2585,106 @@ void step2_post_kernel(Step2Dev sd, const int* __restrict__ chol_status)
     if(threadIdx.x == 0 && !sd.fl->skip_chol) step2_chol_done(sd, *chol_status != 0);
 }
 
-////////////////////////////////////////////////////////////////////////////////
-// the sharded step: staging of what is summed over the shards
-////////////////////////////////////////////////////////////////////////////////
-// The trust-region logic runs replicated: every rank executes the same control
-// kernels on the same (all-reduced) numbers and so takes the same decisions.
-// The collectives are unconditional (a rank cannot know on the host whether
-// this trial factors or evaluates); a skipped phase contributes zeros.
-
-// [S | r] before its all-reduce. A shard whose 6x6/3x3 block factorization
-// failed poisons the first pivot, so that EVERY rank's Cholesky of the sum
-// fails and every rank voids the trial
+// After the factorization, side by side in one launch (256 threads):
+//   workgroups [0, nbs)   back-substitution d_e = -L^-T (y_e + Wt_e d_s), one WAVE per E block; each block
+//                         leaves (|d_e|^2, d_e . g_e) in dots_part[block]
+//   workgroup  nbs        d_s into the state-ordered step
+//   the rest              the quadratic form g^T N g of a new current point (ctl->derive): per-workgroup
+//                         partials into qf_part[.][0], and the frame/point part of |g|^2 into qf_part[.][2]
 __global__ __launch_bounds__(256)
-void shard_prepare_schur_kernel(int n, const SolverCtlFlags* __restrict__ fl, const int* __restrict__ status,
-                                double* __restrict__ Sr)
+void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* __restrict__ ops,
+                                   const SolverCtl* __restrict__ ctl, const SolverCtlFlags* __restrict__ fl,
+                                   const double* __restrict__ Wt, const double* __restrict__ LD,
+                                   const double* __restrict__ y, const double* __restrict__ ds,
+                                   double* __restrict__ dots_part, double* __restrict__ qf_part, int nbs)
 {
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(fl->skip_factor) { if(i < n) Sr[i] = 0.0; return; }
-    if(i == 0 && *status != 0) Sr[0] = __longlong_as_double(0x7ff8000000000000ll);
-}
-
-// the E part of the Gauss-Newton step: each shard has back-substituted its
-// own blocks [e0,e1) and [e2,e3)
-__global__ __launch_bounds__(256)
-void shard_pack_gn_kernel(NormalDims nd, int e0, int e1, int e2, int e3,
-                          const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                          const SolverCtlFlags* __restrict__ fl, double* __restrict__ comm)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i >= nd.NE) return;
-    const bool mine = (i >= e0 && i < e1) || (i >= e2 && i < e3);
-    comm[i] = (!fl->skip_factor && mine) ? ops[ctl->ib].step_gn[nd.Nie + i] : 0.0;
-}
-// [g | |x|^2 | s^T N s] of the point just evaluated (s^T N s belongs to the
-// point the step started from; it rides along)
-__global__ __launch_bounds__(256)
-void shard_pack_point_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                             const SolverCtlFlags* __restrict__ fl, int initial, double* __restrict__ comm)
-{
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i >= nd.Nstate + 2) return;
-    const bool skip = !initial && fl->skip_eval;
-    const OpDev& O = ops[initial ? ctl->ib : ctl->ia];
-    double v = 0.0;
-    if(!skip)
+    const OpDev& O = ops[ctl->ib];
+    const int b = blockIdx.x;
+    if(b > nbs)
     {
-        if(i < nd.Nstate)       v = O.g[i];
-        else if(i == nd.Nstate) v = O.scalars[SC_NORM2_X];
-        else                    v = 0.0;       // (spare slot)
+        if(!ctl->derive) return;
+        const int qb = b - nbs - 1;
+        const double mine = quadform_body(nd, O, O.g, qb, true);
+        if(threadIdx.x < 3) qf_part[4*qb + threadIdx.x] = mine;
+        return;
     }
-    comm[i] = v;
-}
-// The replicated control state must stay BIT-identical on all ranks (a rank
-// whose "done" differs would stop queueing collectives). What goes through an
-// all-reduce is identical by construction; the dot products every rank computes
-// for itself from replicated vectors must not depend on the order of atomics.
-// One workgroup, fixed reduction tree; overwrites what the atomic versions left.
-//   which 0: |step_gn|^2, step_gn.step_cauchy of ctl->ib
-//         1: g.step, |step|^2 of ctl->ib
-//         2: g.g of the point just evaluated
-//   unpack_g (which 2 only): the all-reduced [g | |x|^2]; it is copied into the
-//   point on the way (this launch replaces an unpack kernel in front of it)
-__global__ __launch_bounds__(1024)
-void shard_dots_kernel(int n, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
-                       const SolverCtlFlags* __restrict__ fl, const double* __restrict__ step, int which, int initial,
-                       const double* __restrict__ unpack_g)
-{
-    if(which == 0 && fl->skip_factor) return;
-    if(which == 1 && fl->skip_eval)   return;
-    if(which == 2 && !initial && fl->skip_eval) return;
-    const OpDev& O = ops[(which == 2 && !initial) ? ctl->ia : ctl->ib];
-    const bool unpack = (which == 2 && unpack_g != NULL);
-    const double* __restrict__ u = (which == 0) ? O.step_gn : (which == 1) ? step : (unpack ? unpack_g : O.g);
-    const double* __restrict__ w = (which == 0) ? O.step_cauchy : (unpack ? unpack_g : O.g);
-    double a = 0.0, b = 0.0;
-    for(int i = threadIdx.x; i < n; i += 1024)
+    if(fl->skip_backsub) return;
+    double* __restrict__ step = O.step_gn;
+    if(b == nbs)
     {
-        const double ui = u[i];
-        a += ui*ui;
-        b += ui*w[i];
-        if(unpack) O.g[i] = ui;
+        for(int i = threadIdx.x; i < nd.Nc; i += blockDim.x)
+            step[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = ds[i];
+        return;
     }
-    if(unpack && threadIdx.x == 0) O.scalars[SC_NORM2_X] = unpack_g[n];
-    for(int off=32; off>0; off>>=1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    __shared__ double part[16][2];
-    if((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = a; part[threadIdx.x >> 6][1] = b; }
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ibk = 4*b + wave;
+    if(ibk >= br.count()) return;
+    const int blk = br.block(ibk);
+    const int de  = (blk < nd.Nfb) ? 6 : 3;
+    const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
+    // all the loads first: L, y, g_e and this lane's columns of Wt_e against d_s
+    const double Lv = (lane < 36) ? LD[(size_t)blk*36 + lane] : 0.0;
+    const double yv = (lane < de) ? y[e0 + lane] : 0.0;
+    const double gv = (lane < de) ? O.g[nd.Nie + e0 + lane] : 0.0;
+    double part[6] = {0,0,0,0,0,0};
+    for(int c = lane; c < nd.Nc; c += 64)
+    {
+        const double d = ds[c];
+#pragma unroll
+        for(int i=0;i<6;i++) if(i < de) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
+    }
+#pragma unroll
+    for(int i=0;i<6;i++)
+        for(int off=32; off>0; off>>=1) part[i] += __shfl_down(part[i], off);
+    // lane 0 holds the sums; L, y, g come from the lanes that loaded them (no LDS, no barrier)
+    double v[6], Lr[6][6], ge[6];
+#pragma unroll
+    for(int i=0;i<6;i++)
+    {
+        v[i]  = __shfl(yv, i) + __shfl(part[i], 0);
+        ge[i] = __shfl(gv, i);
+#pragma unroll
+        for(int k=0;k<6;k++) Lr[i][k] = __shfl(Lv, i*6 + k);
+    }
+    if(lane == 0)
+    {
+        double d2 = 0.0, dg = 0.0;
+#pragma unroll
+        for(int i=5;i>=0;i--)
+        {
+            if(i >= de) continue;
+            double sacc = v[i];
+#pragma unroll
+            for(int k=i+1;k<6;k++) if(k < de) sacc -= Lr[k][i]*v[k];
+            v[i] = sacc/Lr[i][i];
+        }
+#pragma unroll
+        for(int i=0;i<6;i++)
+            if(i < de)
+            {
+                const double d = -v[i];
+                step[nd.Nie + e0 + i] = d;
+                d2 += d*d; dg += d*ge[i];
+            }
+        dots_part[2*ibk] = d2; dots_part[2*ibk + 1] = dg;
+    }
+}
+
+// sharded: this rank's summands of comm2, each summed in a fixed order. One workgroup
+__global__ __launch_bounds__(256)
+void step2_pack2_kernel(const SolverCtl* __restrict__ ctl, const SolverCtlFlags* __restrict__ fl,
+                        const double* __restrict__ qf_part, int qf_n,
+                        const double* __restrict__ dots_part, int dots_n, double* __restrict__ comm2)
+{
+    __shared__ double scratch[16*4 + 4];
+    double o[2] = {0.0, 0.0}, o2[2] = {0.0, 0.0};
+    if(ctl->derive)
+        block_sum_fixed<2>(qf_n, [&](int i, double (&t)[2]) { t[0] = qf_part[4*i]; t[1] = qf_part[4*i + 2]; }, o, scratch);
+    if(!fl->skip_backsub)
+        block_sum_fixed<2>(dots_n, [&](int i, double (&t)[2]) { t[0] = dots_part[2*i]; t[1] = dots_part[2*i + 1]; }, o2, scratch);
     if(threadIdx.x == 0)
     {
-        a = b = 0.0;
-        for(int k=0;k<16;k++) { a += part[k][0]; b += part[k][1]; }
-        if(which == 0)      { O.scalars[SC_GN_LENSQ] = a; O.scalars[SC_GN_DOT_CAUCHY] = b; }
-        else if(which == 1) { O.scalars[SC_STEP_SS]  = a; O.scalars[SC_STEP_GS] = b; }
-        else                { O.scalars[SC_G_GG]     = a; O.scalars[SC_G_GG2]   = a; }
+        comm2[COMM2_GNG] = o[0]; comm2[COMM2_GGE] = o[1]; comm2[COMM2_GNE2] = o2[0]; comm2[COMM2_GNE_GE] = o2[1];
     }
 }
 
@@ -3105,90 +2930,40 @@ void       solver_ctl_init_flags(void* ctl_image, int icur)
     fl->elim_mode = 1; fl->elim_sel = icur; fl->skip_chol = 1; fl->skip_backsub = 1;
 }
 
-// parts: 1 = the step (dot products, coefficients, b[ia] = b[ib] + step), 2 = its
-// quadratic form for the expected improvement
-hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream, bool deterministic, int parts, const double* gn_E)
+// what this shard does not own of a state vector, zeroed: the sum over the shards is then the state
+__global__ __launch_bounds__(256)
+void mask_state_kernel(NormalDims nd, BlockRanges br, int is_leader, double* __restrict__ b)
 {
-    if(parts & 1)
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i >= nd.Nstate) return;
+    bool mine;
+    if(i < nd.Nie || i >= nd.Nie + nd.NE) mine = is_leader != 0;        // the camera block
+    else
     {
-        // (the dot products of the Gauss-Newton step are formed inside, deterministically)
-        hipLaunchKernelGGL(step_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                           nd, ops, ctl, ctl_flags(ctl), F.status, step, 1, gn_E);
+        const int e = i - nd.Nie;
+        int lo, hi, lo2, hi2;
+        br.e_range(nd, 0, &lo, &hi);
+        br.e_range(nd, 1, &lo2, &hi2);
+        mine = (e >= lo && e < hi) || (e >= lo2 && e < hi2);
     }
-    // (parts & 2 used to be the quadratic form step^T N step: the expected
-    // improvement now comes out of step_choose_kernel itself)
-    (void)deterministic;
-    return hipGetLastError();
+    if(!mine) b[i] = 0.0;
 }
-// After the all-reduce of [g | |x|^2]: into the point, g.g in a fixed order, and this
-// shard's part of g^T N g accumulated straight into its communication slot
-// (cleared by the kernel that consumed it last: step_finish_kernel)
-hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                                   const double* comm_point, double* comm_gng, hipStream_t stream)
+hipError_t launch_mask_state(const NormalDims& nd, const BlockRanges& br, bool is_leader, double* b, hipStream_t stream)
 {
-    hipLaunchKernelGGL(shard_dots_kernel, dim3(1), dim3(1024), 0, stream, nd.Nstate, ops, ctl, ctl_flags(ctl),
-                       (const double*)NULL, 2, initial ? 1 : 0, comm_point);
-    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
-    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                       nd, Rp, comm_point, 0, comm_gng, 0, 1);
-    return hipGetLastError();
-}
-
-hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream)
-{
-    const int n = nd.Nc*nd.Nc + nd.Nc;
-    hipLaunchKernelGGL(shard_prepare_schur_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
-                       n, ctl_flags(ctl), F.status, F.S);
-    return hipGetLastError();
-}
-hipError_t launch_shard_pack_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
-                                double* comm, hipStream_t stream)
-{
-    if(nd.NE <= 0) return hipSuccess;
-    int e[4];
-    br.e_range(nd, 0, &e[0], &e[1]);
-    br.e_range(nd, 1, &e[2], &e[3]);
-    hipLaunchKernelGGL(shard_pack_gn_kernel, dim3((nd.NE + 255)/256), dim3(256), 0, stream,
-                       nd, e[0], e[1], e[2], e[3], ops, ctl, ctl_flags(ctl), comm);
-    return hipGetLastError();
-}
-hipError_t launch_shard_pack_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                                   double* comm, hipStream_t stream)
-{
-    const int n = nd.Nstate + 2;
-    hipLaunchKernelGGL(shard_pack_point_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), initial ? 1 : 0, comm);
-    return hipGetLastError();
-}
-// single-GPU end of a trial step: g^T N g, then step_finish_kernel (which also starts the next trial)
-hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
-                              hipStream_t stream)
-{
-    OpRef Rp = { ops, initial ? &ctl->ib : &ctl->ia, initial ? (const int*)NULL : solver_ctl_skip_eval(ctl) };
-    hipLaunchKernelGGL(quadform_kernel, dim3(quadform_blocks(nd)), dim3(256), 0, stream,
-                       nd, Rp, (const double*)NULL, 1, (double*)NULL, (int)SC_G_GNG, 3);
-    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, (double*)NULL);
-    return hipGetLastError();
-}
-// the sharded end of a trial step: the same kernel, g^T N g from the all-reduced buffer
-hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
-                                    double* gng, hipStream_t stream)
-{
-    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(1024), 0, stream,
-                       nd, ops, ctl, ctl_flags(ctl), chol_status, initial ? 1 : 0, gng);
+    hipLaunchKernelGGL(mask_state_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream, nd, br, is_leader ? 1 : 0, b);
     return hipGetLastError();
 }
 
 // ---- the fused step
+static int quadform_blocks(const NormalDims& nd);
 const int* solver_ctl_skip_eval2(const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
 
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream)
 {
     const NormalDims& nd = *a.nd;
     hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, ctl_flags(a.ctl), a.F->status, a.step);
+                       nd, a.ops, a.ctl, ctl_flags(a.ctl), a.F->status, a.step,
+                       a.plan->qf_part, quadform_blocks(nd), a.plan->dots_part, a.br->count(), a.comm2);
     return hipGetLastError();
 }
 
@@ -3229,8 +3004,8 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     return hipGetLastError();
 }
 
-// SYRK (+ finalize of A, g, |x|^2) | S, r + g^T N g | finish + Cholesky | back-substitution
-hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stream)
+// SYRK (+ finalize of A, g, |x|^2) | S, r and the tail of comm1. (Sharded: comm1 is all-reduced after this)
+hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
 {
     const DeviceProblem& P = *a.P;
     const NormalDims& nd = *a.nd;
@@ -3246,12 +3021,22 @@ hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stre
     const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream);
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nred = ((npairs*256 + nb*16)*SRED_SPLIT + 255)/256;
-    const int nqf  = quadform_blocks(nd);
-    hipLaunchKernelGGL(step2_reduce_quadform_kernel, dim3(nred + nqf), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, a.plan->qf_part);
+    hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status);
+    return hipGetLastError();
+}
+int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }
+
+// finish + Cholesky | back-substitution + quadratic form | (sharded) this rank's summands of comm2
+hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t stream)
+{
+    const NormalDims& nd = *a.nd;
+    const BlockRanges& br = *a.br;
+    const FactorBuffers& F = *a.F;
+    SolverCtlFlags* fl = ctl_flags(a.ctl);
     Step2Dev sd;
     sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0;
-    sd.qf_part = a.plan->qf_part; sd.qf_n = nqf;
+    sd.comm1_tail = F.r + nd.Nc;
     {
         const int n = nd.Nc;
         const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
@@ -3265,9 +3050,12 @@ hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stre
             hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
         }
     }
-    const OpRef Rcur = { a.ops, &a.ctl->ib, NULL };
-    hipLaunchKernelGGL(backsub_kernel, dim3(br.count()+1), dim3(64), 0, stream,
-                       nd, br, Rcur, &fl->skip_backsub, F.Wt, F.LD, F.y, F.r);
+    const int nbs = (br.count() + 3)/4, nqf = quadform_blocks(nd);
+    hipLaunchKernelGGL(step2_backsub_quadform_kernel, dim3(nbs + 1 + nqf), dim3(256), 0, stream,
+                       nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs);
+    if(a.comm2 != NULL)
+        hipLaunchKernelGGL(step2_pack2_kernel, dim3(1), dim3(256), 0, stream,
+                           a.ctl, fl, a.plan->qf_part, nqf, a.plan->dots_part, br.count(), (double*)a.comm2);
     return hipGetLastError();
 }
 

@@ -118,8 +118,9 @@ struct AssemblyPlan
     int     Ndest;
     double* row_part;         // [row_part_n] per-workgroup partial |x|^2 of the rows that do not come from board Grams
     int     row_part_n;
-    double* qf_part;          // [qf_part_n][4] per-workgroup partials of the quadratic form g^T N g (and g.g)
+    double* qf_part;          // [qf_part_n][4] per-workgroup partials of the quadratic form g^T N g (and of |g_E|^2)
     int     qf_part_n;
+    double* dots_part;        // [NEb][2] per-block (|d_e|^2, d_e . g_e) of the back-substitution
 };
 
 // state index -> S index (>=0) or -(1 + E index)
@@ -199,6 +200,8 @@ struct SolverCtl
     int    refactor;            // the current point must be (re-)eliminated before a step can be chosen:
                                 // lambda was just raised, or its Gauss-Newton step was never computed
     int    gn_fresh;            // step_gn of the current point was just computed: its dot products are not known yet
+    int    derive;              // the current point is new: g^T N g, |g|^2 and its Cauchy step are still to be derived
+    int    _pad;
 };
 
 hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t stream);
@@ -220,26 +223,6 @@ hipError_t launch_outlier_stats(int Npoints_board, double thresh_sq, const doubl
 hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const double* x, double* pool,
                                 int* counts, hipStream_t stream);
 
-// The device-controlled dog-leg step, in the order the kernels are queued:
-//   [factor_local, solve_backsub] -> choose -> [evaluate, assemble] -> finish (g^T N g, Cauchy step,
-//   accept/reject, start of the next trial)
-// gn_E (sharded): the frame/point part of the Gauss-Newton step summed over the shards
-hipError_t launch_step_choose(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, const FactorBuffers& F,
-                              double* step, hipStream_t stream,
-                              bool deterministic = false, int parts = 3, const double* gn_E = NULL);
-hipError_t launch_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
-                              hipStream_t stream);
-// the sharded step: staging around the collectives (see solver_kernels.hip)
-hipError_t launch_shard_prepare_schur(const NormalDims& nd, SolverCtl* ctl, const FactorBuffers& F, hipStream_t stream);
-hipError_t launch_shard_pack_gn(const NormalDims& nd, const BlockRanges& br, const OpDev* ops, SolverCtl* ctl,
-                                double* comm, hipStream_t stream);
-hipError_t launch_shard_pack_point(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                                   double* comm, hipStream_t stream);
-hipError_t launch_shard_point_sums(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, bool initial,
-                                   const double* comm_point, double* comm_gng, hipStream_t stream);
-hipError_t launch_shard_step_finish(const NormalDims& nd, const OpDev* ops, SolverCtl* ctl, int* chol_status, bool initial,
-                                    double* gng, hipStream_t stream);
-
 // solves against a kept factorization (F as left by launch_factor_local() +
 // launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order
 hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
@@ -250,27 +233,35 @@ hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& 
 hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
                                 const int32_t* Jp, const int32_t* Ji, hipStream_t stream);
 
-// ---- The fused trial step (single GPU; solver.cpp enqueue_trial_step()). Per trial, in this order:
-//   choose            the dog-leg step from the current point, b_trial                 (launch_step2_choose)
+// ---- The device-controlled dog-leg trial step (solver.cpp enqueue_trial_step()). Per trial, in this order:
+//   choose            the dog-leg step from the current point, b_trial; the first trial from a new point also
+//                     derives its Cauchy step                                          (launch_step2_choose)
 //   [prologue, board] x, J, Grams at the trial point                                   (launch_evaluate)
 //   assemble+factor   block normal equations of the trial point from the Grams, in a fixed order; the
 //                     frame blocks are eliminated on the spot (L, Wt, y): a Gauss-Newton solve of the
 //                     point, should it be accepted, is already under way                (launch_step2_assemble)
-//   syrk + finalize   Wt^T Wt partial tiles ; A, g_S, |x|^2 from the chunk partials
-//   reduce + quadform S, r ; g^T N g
-//   finish + Cholesky accept/reject, trust region, start of the next trial; Cholesky of S if the (new) current
-//                     point needs its Gauss-Newton step
-//   backsub           the frame/point part of the Gauss-Newton step
+//   syrk + finalize   Wt^T Wt partial tiles ; A, g_S, |x|^2 from the chunk partials     (launch_step2_reduce)
+//   reduce            S, r and the tail of comm1
+//                     -- sharded: all-reduce of comm1 --
+//   finish + Cholesky accept/reject, trust region; Cholesky of S if the point was accepted  (launch_step2_factor)
+//   backsub+quadform  the frame/point part of the Gauss-Newton step ; g^T N g of the new point
+//                     -- sharded: pack + all-reduce of comm2 (4 doubles) --
 // initial: the evaluation of the starting point (no choose, no accept)
 struct Step2Args
 {
     const DeviceProblem* P; const NormalDims* nd; const BlockRanges* br; const AssemblyPlan* plan;
     const OpDev* ops; SolverCtl* ctl; const FactorBuffers* F; const double* gram;
     const int32_t* Jp; const int32_t* Ji; double* step; bool is_leader;
+    const double* comm2;     // sharded: [4] g^T N g, |g_E|^2, |gn_E|^2, gn_E . g_E summed over the ranks; NULL: single GPU
 };
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
-hipError_t launch_step2_solve(const Step2Args& a, bool initial, hipStream_t stream);
+// ... comm1 = [S | r | g_S | |x|^2 | status] (F.S, step2_comm1_doubles()) is this rank's summand after _reduce;
+// _factor expects it summed over the ranks, and leaves this rank's summand of comm2 (if a.comm2 is given)
+hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream);
+hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t stream);
+int64_t    step2_comm1_doubles(const NormalDims& nd);
+hipError_t launch_mask_state(const NormalDims& nd, const BlockRanges& br, bool is_leader, double* b, hipStream_t stream);
 const int* solver_ctl_skip_eval2(const SolverCtl* ctl);
 // host-driven evaluation: deterministic block normal equations of the point R from the Grams (no elimination)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
