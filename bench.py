@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--cpu-baseline-iterations", type=int, default=3)
     ap.add_argument("--no-full-solve", action="store_true")
     ap.add_argument("--sharded", action="store_true",
-                    help="diagnostic: take the multi-GPU code path (frame shards + RCCL collectives) even with one rank")
+                    help="diagnostic: take the multi-GPU code path (frame shards + RCCL all-reduces from C++) even with one rank")
     return ap.parse_args()
 
 
@@ -102,10 +102,14 @@ def main():
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.sharded
     if sharded:
+        # torch.distributed is only the side channel of the start-up (the 128-byte
+        # RCCL id, the barriers, the max over ranks of the wall clock): gloo. The
+        # collectives of the solve are RCCL all-reduces issued by libmrcal_amd.so
+        # itself on the problem's HIP stream (mrcal_amd/csrc/comm.cpp)
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo")
 
     import mrcal_amd
     from mrcal_amd.synthetic import make_calibration_problem
@@ -118,7 +122,7 @@ def main():
 
     if sharded:
         from mrcal_amd.parallel import ShardedProblem
-        problem = ShardedProblem(_always_communicate=True, **oi)
+        problem = ShardedProblem(**oi)
         barrier = lambda: (dist.barrier(), torch.cuda.synchronize())
     else:
         from mrcal_amd.resident import Problem
@@ -153,7 +157,7 @@ def main():
     assert n == args.steps
 
     if sharded:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -191,7 +195,7 @@ def main():
         config  = dict(workload = workload,
                        Nstate = problem.Nstate_global, Nmeasurements = problem.Nmeas_global,
                        Nnz_J = problem.Nnz_global,
-                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), 4 all-reduces per step (reduced normal equations, frame steps, gradient, g^T JtJ g)"),
+                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), one process per GPU, 2 RCCL all-reduces per trial step: [S|r|g_S||x|^2] ({problem.problem.Nstate} state variables: Nc^2+2Nc+2 doubles) and 4 scalars"),
         roofline = dict(bound = "hbm",
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
@@ -200,7 +204,8 @@ def main():
                         algorithmic_bytes_per_launch = alg_bytes,
                         kernel_ms_avg = kernel_ms, kernel_ms_min = kmin_ms, kernel_ms_max = kmax_ms,
                         launches_timed = nlaunch),
-        solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"]),
+        solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"],
+                      **({"collectives": st["Ncollectives"]} if sharded else {})),
     )
 
     if rank == 0 and not args.no_full_solve and not sharded:

@@ -2477,7 +2477,11 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
     const OpDev& O = ops[fl->elim_sel];
     if((int)blockIdx.x < nred)
     {
-        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, 1, nslots, Spart, S, r, blockIdx.x);
+        // r starts from this rank's g_S: of a point just assembled that is its own summand
+        // (every rank adds its own); of a point re-eliminated later it is already the
+        // sum over the ranks (step2_finish unpacked it): the leader alone adds it
+        const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
+        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x);
         return;
     }
     double* __restrict__ tail = r + nd.Nc;

@@ -4,46 +4,44 @@ Why frames: every measurement row of a chessboard calibration touches exactly
 one frame pose, so a contiguous range of frames owns its rows of x and J, its
 6x6 diagonal blocks of JtJ and its couplings to the camera block outright. What
 all shards share is the small dense camera block (all intrinsics + extrinsics +
-the board warp: Nc = 140 variables at 8 cameras). Per dog-leg step each rank
+the board warp: Nc = 140 variables at 8 cameras).
 
-  seg 0  eliminates its frames locally (when the trust region asks for the
-         Gauss-Newton step) -> all-reduce of its summand of the Schur
-         complement [S | r]                   (Nc^2+Nc doubles: 158 KB at NS)
-  seg 1  factors the same Nc x Nc system redundantly, back-substitutes its own
-         frames -> all-reduce of the frame steps           (NE doubles: 48 KB)
-  seg 2  chooses the dog-leg step (the expected improvement comes from dot
-         products of replicated vectors: nothing to sum), evaluates x, J and its
-         blocks of JtJ at the trial point for ITS frames
-         -> all-reduce of [Jt x | |x|^2]       (Nstate+2 doubles: 49 KB at NS)
-  seg 3  -> all-reduce of g^T JtJ g                                 (1 double)
-  seg 4  Cauchy step of the new point, rho test, accept/reject
+The sharded trial step IS the single-GPU device-controlled step
+(csrc/solver.cpp enqueue_trial_step) with TWO sums over the ranks in it:
 
-i.e. four small collectives, all latency-bound (xGMI bandwidth is irrelevant
-at these sizes); the reference has no counterpart (it is single-threaded).
+  [choose the step | evaluate x, J, Grams at the trial point for MY frames |
+   block normal equations, my frames eliminated on the spot | my summand of the
+   Schur complement]
+        -> all-reduce  [ S | r | g_S | |x|^2 | status ]     Nc^2 + 2 Nc + 2 doubles (158 KB at NS)
+  [accept/reject, trust region (replicated: every rank decides the same from the
+   same sums) | Cholesky of S (replicated) | back-substitution of MY frames |
+   my part of g^T JtJ g]
+        -> all-reduce  [ g^T JtJ g | |g_E|^2 | |gn_E|^2 | gn_E . g_E ]              4 doubles
 
-NOTHING is read back between the segments: the trust-region state of
-libdogleg is a control block in device memory (csrc/solver_kernels.hip,
-"dog-leg control"), REPLICATED on every rank; every rank runs the same control
-kernels on the same all-reduced sums and so takes the same decisions. The
-collectives are therefore unconditional: a trial that needs no factorization
-(or a voided one) sums zeros. The host queues trial steps, and looks at a
-pinned snapshot of the control block a few steps behind to learn that the
-device has declared the solve finished; all ranks look at the same snapshot
-index, so they queue the same number of steps and the collectives match up.
+Rank-local: the frame poses of the shard's frames (state, gradient, steps) and
+its rows of x and J. Replicated: the camera block of the state and the
+trust-region control block. Both collectives are latency-bound (xGMI bandwidth
+is irrelevant at these sizes); the reference has no counterpart (it is
+single-threaded).
 
-The driver is written against a small "shard" interface so that the whole N>1
-flow (partition, segment/collective sequence, termination, outlier rejection)
-also runs on CPU under gloo with a numpy shard (tests/test_parallel_cpu.py).
-On the GPU the shard is GpuShard: the sharded-step API of libmrcal_amd.so
-(include/mrcal_amd.h), with torch only aliasing its HBM buffers for RCCL.
+Product path (ShardedProblem): the collectives are RCCL all-reduces issued from
+C++ on the problem's HIP stream (csrc/comm.cpp); Python only carries the
+128-byte communicator id between the ranks at start-up and calls
+solve()/run_steps() like a single-GPU caller.
+
+Protocol reference (ShardedDogleg + a "shard" object): the same two-collective
+protocol driven from Python through torch.distributed, so that the whole N>1
+flow (partition, what is summed, termination, outlier rejection, the final
+gather) runs on CPU under gloo with a numpy shard (tests/test_parallel_cpu.py)
+and on one GPU with two ranks sharing the device (tests/test_parallel_gpu.py:
+RCCL refuses two ranks per device, gloo does not).
 """
 import ctypes as C
 import math
 import numpy as np
 
-NSEGMENTS = 5       # segments of a trial step; a collective follows each of the first 4
-RING      = 8       # control-block snapshots in flight
-LAG       = 3       # how many trial steps the host may run ahead of what it has seen
+RING = 8       # control-block snapshots in flight
+LAG  = 3       # how many trial steps the host may run ahead of what it has seen
 
 
 def partition_frames(indices_frame_camintrinsics_camextrinsics, Nframes, world):
@@ -64,26 +62,22 @@ def partition_frames(indices_frame_camintrinsics_camextrinsics, Nframes, world):
     return [(bounds[r], bounds[r+1]) for r in range(world)]
 
 
+# ---------------------------------------------------------------------------
+# the protocol reference
+
 class Communicator:
-    """sum/max all-reduce over torch.distributed; no-ops for a single process
-    (unless always=True: a world of one still goes through the backend, which is
-    how the RCCL plumbing is exercised on a one-GPU box)"""
-    def __init__(self, group=None, always=False):
+    """sum all-reduce over torch.distributed; a no-op for a single process"""
+    def __init__(self, group=None):
         import torch.distributed as dist
         self.dist  = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = group
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self.rank  = self.dist.get_rank(group)       if self.dist else 0
-        self.active = self.dist is not None and (self.world > 1 or always)
         self.Ncollectives = 0
     def sum(self, t):
-        if self.active:
+        if self.dist is not None and self.world > 1:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            self.Ncollectives += 1
-    def max(self, t):
-        if self.active:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-            self.Ncollectives += 1
+        self.Ncollectives += 1
 
 
 class DoglegParameters:
@@ -99,19 +93,21 @@ class DoglegParameters:
 
 
 class ShardedDogleg:
-    """The dog-leg loop over a shard + a communicator.
+    """The dog-leg loop over a shard + a communicator, collectives from Python.
 
     The shard provides (see GpuShard):
       Nmeas_global, Ncorners_global, do_outlier_rejection
       reset(check_termination, max_iterations, trustregion0)   restart the device-side dog-leg
-      enqueue(initial, segment)      queue segment 0..4 of a trial step (initial: of the
-                                     evaluation of the starting point, segments 2..4)
-      comm_buffer(segment)           tensor to sum over the shards after segment 0..3 (or None)
+      enqueue(initial, segment)      queue segment 0 / 1 of a trial step (initial: of the
+                                     evaluation of the starting point)
+      comm_buffer(which)             tensor to sum over the shards after segment 0 / 1
       snapshot(slot) / wait(slot)    control-block snapshot; wait -> dict(done, error, ...)
       finish()                       drain; -> dict(Nsteps_accepted, Nevaluations,
                                      Nfactorizations, Ntrials, error, trustregion, norm2_x, lambda_)
       outlier_stats(thresh_sq) -> tensor [n_outliers, n_beyond, sum_x2] (local, current point)
       mark_outliers(thresh_sq) -> tensor [n_marked] (local)
+      masked_state() -> tensor: the state with what this shard does not own zeroed;
+      set_state(tensor)
       context()  -> context manager making the shard's stream current
     """
     def __init__(self, shard, comm, parameters=None):
@@ -120,15 +116,13 @@ class ShardedDogleg:
         self.prm   = parameters or DoglegParameters()
         self.started = False
         self.stats = dict(Niterations=0, Nevaluations=0, Nfactorizations=0, Noutlier_passes=0)
+        self.Ntrials_total = 0
 
     def _queue(self, initial):
         s = self.s
-        for seg in range(2 if initial else 0, NSEGMENTS):
+        for seg in (0, 1):
             s.enqueue(initial, seg)
-            if seg < NSEGMENTS-1:
-                buf = s.comm_buffer(seg)
-                if buf is not None and buf.numel() > 0:
-                    self.comm.sum(buf)
+            self.comm.sum(s.comm_buffer(seg))
 
     def run(self, max_steps=None, check_termination=True, trustregion=None):
         """Queues trial steps until the device declares the solve finished
@@ -154,6 +148,7 @@ class ShardedDogleg:
                     # every rank waits for the SAME snapshot: same decision everywhere
                     done = bool(s.wait((n - LAG) % RING)["done"])
             c = s.finish()
+        self.Ntrials_total += n + 1
         if c["error"]:
             raise RuntimeError("could not make JtJ positive definite")
         if check_termination:
@@ -188,6 +183,12 @@ class ShardedDogleg:
             self.comm.sum(nm)
             return True, int(nout) + int(nm[0].item())
 
+    def gather_state(self):
+        with self.s.context():
+            b = self.s.masked_state()
+            self.comm.sum(b)
+            self.s.set_state(b)
+
     def solve(self):
         Noutliers = 0
         while True:
@@ -205,6 +206,7 @@ class ShardedDogleg:
                 break
             self.stats["Noutlier_passes"] += 1
         self.started = False
+        self.gather_state()
         rms = math.sqrt(self.stats["norm2_x"]/self.s.Nmeas_global)
         return dict(self.stats, rms_reproj_error__pixels=rms, Noutliers_board=Noutliers)
 
@@ -216,39 +218,51 @@ class _DeviceArray:
                                              data=(int(ptr), False), version=2)
 
 
+def _declare_sharded(L):
+    if getattr(L, "_mrcal_amd_sharded_declared", False):
+        return
+    vp = C.c_void_p
+    L.mrcal_amd_problem_shard_info.restype  = None
+    L.mrcal_amd_problem_shard_info.argtypes = [vp, C.POINTER(C.c_int)]
+    L.mrcal_amd_problem_sharded_reset.restype  = C.c_bool
+    L.mrcal_amd_problem_sharded_reset.argtypes = [vp, C.c_int, C.c_int, C.c_double]
+    L.mrcal_amd_problem_sharded_enqueue.restype  = C.c_bool
+    L.mrcal_amd_problem_sharded_enqueue.argtypes = [vp, C.c_int, C.c_int]
+    L.mrcal_amd_problem_sharded_comm_buffer.restype  = vp
+    L.mrcal_amd_problem_sharded_comm_buffer.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.mrcal_amd_problem_sharded_snapshot.restype  = C.c_bool
+    L.mrcal_amd_problem_sharded_snapshot.argtypes = [vp, C.c_int]
+    L.mrcal_amd_problem_sharded_wait.restype  = C.c_bool
+    L.mrcal_amd_problem_sharded_wait.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.mrcal_amd_problem_sharded_finish.restype  = C.c_bool
+    L.mrcal_amd_problem_sharded_finish.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.mrcal_amd_problem_current.restype, L.mrcal_amd_problem_current.argtypes = C.c_int, [vp]
+    for name, args in (("outlier_stats", [vp, C.c_int, C.c_double, vp, vp]),
+                       ("mark_outliers", [vp, C.c_int, C.c_double, vp])):
+        f = getattr(L, f"mrcal_amd_problem_phase_{name}")
+        f.restype, f.argtypes = C.c_bool, args
+    L.mrcal_amd_comm_unique_id.restype,  L.mrcal_amd_comm_unique_id.argtypes  = C.c_bool, [vp]
+    L.mrcal_amd_comm_create.restype,     L.mrcal_amd_comm_create.argtypes     = vp, [vp, C.c_int, C.c_int]
+    L.mrcal_amd_comm_destroy.restype,    L.mrcal_amd_comm_destroy.argtypes    = None, [vp]
+    L.mrcal_amd_comm_Ncollectives.restype, L.mrcal_amd_comm_Ncollectives.argtypes = C.c_long, [vp]
+    L.mrcal_amd_problem_attach_comm.restype,  L.mrcal_amd_problem_attach_comm.argtypes  = C.c_bool, [vp, vp]
+    L.mrcal_amd_problem_gather_state.restype, L.mrcal_amd_problem_gather_state.argtypes = C.c_bool, [vp]
+    L._mrcal_amd_sharded_declared = True
+
+
 class GpuShard:
-    """The shard interface over libmrcal_amd.so's sharded-step API"""
+    """The shard interface over libmrcal_amd.so's sharded-step API, for a driver
+    that does the collectives itself (ShardedDogleg)"""
     def __init__(self, problem, Nmeas_global, Ncorners_global, do_outlier_rejection):
         import torch
         self.torch = torch
         self.p     = problem
-        L = problem._lib
-        vp = C.c_void_p
-        if not getattr(L, "_mrcal_amd_sharded_declared", False):
-            L.mrcal_amd_problem_shard_info.restype  = None
-            L.mrcal_amd_problem_shard_info.argtypes = [vp, C.POINTER(C.c_int)]
-            L.mrcal_amd_problem_sharded_reset.restype  = C.c_bool
-            L.mrcal_amd_problem_sharded_reset.argtypes = [vp, C.c_int, C.c_int, C.c_double]
-            L.mrcal_amd_problem_sharded_enqueue.restype  = C.c_bool
-            L.mrcal_amd_problem_sharded_enqueue.argtypes = [vp, C.c_int, C.c_int]
-            L.mrcal_amd_problem_sharded_comm_buffer.restype  = vp
-            L.mrcal_amd_problem_sharded_comm_buffer.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
-            L.mrcal_amd_problem_sharded_snapshot.restype  = C.c_bool
-            L.mrcal_amd_problem_sharded_snapshot.argtypes = [vp, C.c_int]
-            L.mrcal_amd_problem_sharded_wait.restype  = C.c_bool
-            L.mrcal_amd_problem_sharded_wait.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
-            L.mrcal_amd_problem_sharded_finish.restype  = C.c_bool
-            L.mrcal_amd_problem_sharded_finish.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
-            L.mrcal_amd_problem_current.restype, L.mrcal_amd_problem_current.argtypes = C.c_int, [vp]
-            for name, args in (("outlier_stats", [vp, C.c_int, C.c_double, vp, vp]),
-                               ("mark_outliers", [vp, C.c_int, C.c_double, vp])):
-                f = getattr(L, f"mrcal_amd_problem_phase_{name}")
-                f.restype, f.argtypes = C.c_bool, args
-            L._mrcal_amd_sharded_declared = True
-        self.L = L
+        self.L = L = problem._lib
+        _declare_sharded(L)
         info = (C.c_int*8)()
         L.mrcal_amd_problem_shard_info(problem.handle, info)
         self.Nstate, self.Nie, self.NE, self.Nc = info[0], info[1], info[2], info[3]
+        self.frame_lo, self.frame_hi = info[4], info[5]
         self.is_leader = bool(info[6])
         self.Nmeas_global = Nmeas_global
         self.Ncorners_global = Ncorners_global
@@ -272,15 +286,14 @@ class GpuShard:
                                                         int(max_iterations), float(trustregion0)), "sharded_reset")
     def enqueue(self, initial, segment):
         self._ok(self.L.mrcal_amd_problem_sharded_enqueue(self.p.handle, int(bool(initial)), segment), "sharded_enqueue")
-    def comm_buffer(self, segment):
-        if segment not in self._comm:
+    def comm_buffer(self, which):
+        if which not in self._comm:
             n = C.c_int64(0)
-            ptr = self.L.mrcal_amd_problem_sharded_comm_buffer(self.p.handle, segment, C.byref(n))
+            ptr = self.L.mrcal_amd_problem_sharded_comm_buffer(self.p.handle, which, C.byref(n))
             if not ptr:
                 raise RuntimeError("mrcal_amd_problem_sharded_comm_buffer() failed" + self.p._api._last_error())
-            self._comm[segment] = (self.torch.as_tensor(_DeviceArray(ptr, n.value, "<f8"), device="cuda")
-                                   if n.value > 0 else None)
-        return self._comm[segment]
+            self._comm[which] = self.torch.as_tensor(_DeviceArray(ptr, n.value, "<f8"), device="cuda")
+        return self._comm[which]
     def snapshot(self, slot):
         self._ok(self.L.mrcal_amd_problem_sharded_snapshot(self.p.handle, slot), "sharded_snapshot")
     def wait(self, slot):
@@ -307,44 +320,102 @@ class GpuShard:
                                                                self._counts.data_ptr()), "phase_mark_outliers")
         return self._counts[:1].to(self.torch.float64)
 
+    def masked_state(self):
+        b = self.p.b_packed()
+        mine = np.zeros(self.Nstate, dtype=bool)
+        if self.is_leader:
+            mine[:self.Nie] = True
+            mine[self.Nie + self.NE:] = True
+        mine[self.Nie + 6*self.frame_lo : self.Nie + 6*self.frame_hi] = True
+        b[~mine] = 0.0
+        return self.torch.from_numpy(b).to("cuda")
+    def set_state(self, t):
+        self.p.set_b_packed(t.cpu().numpy())
+
 
 class ShardedProblem:
     """A calibration problem sharded by frame over the ranks of the default
-    torch.distributed process group (backend nccl = RCCL). Every rank passes
-    the SAME optimization_inputs. API-compatible with resident.Problem where
-    the benchmark needs it"""
-    def __init__(self, group=None, _always_communicate=False, **optimization_inputs):
+    torch.distributed process group. Every rank passes the SAME
+    optimization_inputs. API-compatible with resident.Problem where the
+    benchmark needs it.
+
+    The product path: the two collectives per trial step are RCCL all-reduces
+    issued from C++ on the problem's stream; torch.distributed (any backend:
+    gloo is enough) only carries the 128-byte communicator id at start-up.
+    _driver="python": the protocol reference instead (collectives through
+    torch.distributed from Python): for two ranks on ONE device, which RCCL refuses"""
+    def __init__(self, group=None, _driver="rccl", **optimization_inputs):
+        import torch
+        import torch.distributed as dist
         from . import _api
         from .resident import Problem
-        self.comm = Communicator(group, always=_always_communicate)
+        have_dist = dist.is_available() and dist.is_initialized()
+        self.rank  = dist.get_rank(group)       if have_dist else 0
+        self.world = dist.get_world_size(group) if have_dist else 1
         p = _api._ingest(optimization_inputs, callback=False)
         if len(p.c_tri) > 0:
             # the outlier logic of triangulated pairs is sequential over the pairs
             # (mrcal.c:3978-4402) and lives with the single-GPU solve
             raise NotImplementedError("ShardedProblem: triangulated points are solved on one GPU (mrcal_amd.optimize())")
-        ranges = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.comm.world)
-        self.frame_range = ranges[self.comm.rank]
-        self.problem = Problem(_shard=self.frame_range, _leader=(self.comm.rank == 0),
-                               **optimization_inputs)
+        ranges = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.world)
+        self.frame_range = ranges[self.rank]
+        self.problem = Problem(_shard=self.frame_range, _leader=(self.rank == 0), **optimization_inputs)
         self.Nstate_global, self.Nmeas_global = _api._sizes(p)
         self.Nstate = self.Nstate_global
         self.Nnz_global = self.problem.Nnz
-        if self.comm.active:
-            import torch
-            t = torch.tensor([float(self.problem.Nnz)], dtype=torch.float64, device="cuda")
-            self.comm.sum(t)
+        if have_dist and self.world > 1:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor([float(self.problem.Nnz)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=group)
             self.Nnz_global = int(t.item())
-        Ncorners = p.Nobservations_board*max(p.width_n,0)*max(p.height_n,0)
-        self.shard = GpuShard(self.problem, self.Nmeas_global, Ncorners,
-                              bool(p.sel.as_dict()["do_apply_outlier_rejection"]))
-        self.dogleg = ShardedDogleg(self.shard, self.comm)
+        self._lib = L = self.problem._lib
+        _declare_sharded(L)
+        self._comm_handle = None
+        self.dogleg = None
+        self.Ncorners = p.Nobservations_board*max(p.width_n,0)*max(p.height_n,0)
+        self.do_outlier_rejection = bool(p.sel.as_dict()["do_apply_outlier_rejection"])
+        if _driver == "python":
+            self.comm  = Communicator(group)
+            self.shard = GpuShard(self.problem, self.Nmeas_global, self.Ncorners, self.do_outlier_rejection)
+            self.dogleg = ShardedDogleg(self.shard, self.comm)
+            return
+        # the communicator id, made by rank 0, to everybody
+        idbuf = (C.c_char*128)()
+        if self.rank == 0:
+            if not L.mrcal_amd_comm_unique_id(idbuf):
+                raise RuntimeError("mrcal_amd_comm_unique_id() failed:" + _api._last_error())
+        if have_dist and self.world > 1:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, src=0, group=group)
+            idbuf = (C.c_char*128).from_buffer_copy(bytes(t.cpu().tolist()))
+        self._comm_handle = L.mrcal_amd_comm_create(idbuf, self.rank, self.world)
+        if not self._comm_handle:
+            raise RuntimeError("mrcal_amd_comm_create() failed:" + _api._last_error())
+        if not L.mrcal_amd_problem_attach_comm(self.problem.handle, self._comm_handle):
+            raise RuntimeError("mrcal_amd_problem_attach_comm() failed:" + _api._last_error())
+
+    @property
+    def Ncollectives(self):
+        if self.dogleg is not None:
+            return self.comm.Ncollectives
+        return int(self._lib.mrcal_amd_comm_Ncollectives(self._comm_handle))
 
     def run_steps(self, Nsteps, trustregion=None):
-        return self.dogleg.run(max_steps=Nsteps, check_termination=False, trustregion=trustregion)
+        if self.dogleg is not None:
+            return self.dogleg.run(max_steps=Nsteps, check_termination=False, trustregion=trustregion)
+        return self.problem.run_steps(Nsteps, trustregion)
     def solve(self):
-        return self.dogleg.solve()
+        if self.dogleg is not None:
+            return self.dogleg.solve()
+        st = self.problem.solve()
+        # (rms and counters are those of the whole problem: they come out of the replicated control block)
+        st["rms_reproj_error__pixels"] = math.sqrt(st["norm2_x"]/self.Nmeas_global)
+        return st
     def solver_stats(self):
-        return dict(self.dogleg.stats, Ncollectives=self.comm.Ncollectives)
+        if self.dogleg is not None:
+            return dict(self.dogleg.stats, Ncollectives=self.Ncollectives)
+        return dict(self.problem.solver_stats(), Ncollectives=self.Ncollectives)
     def b_packed(self):
         return self.problem.b_packed()
     def synchronize(self):
@@ -357,3 +428,6 @@ class ShardedProblem:
         return self.problem.jacobian_algorithmic_bytes()
     def close(self):
         self.problem.close()
+        if self._comm_handle:
+            self._lib.mrcal_amd_comm_destroy(self._comm_handle)
+            self._comm_handle = None
