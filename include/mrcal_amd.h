@@ -499,8 +499,9 @@ void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* problem, int wh
 bool  mrcal_amd_problem_sharded_snapshot   (mrcal_amd_problem_t* problem, int slot);
 bool  mrcal_amd_problem_sharded_wait       (mrcal_amd_problem_t* problem, int slot, int* out);
 bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* out_i, double* out_d);
-/* info[8] = { Nstate, Nie, NE, Nc, frame_lo, frame_hi, is_leader, Ncorners_local }.
-   State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames+points, then the warp */
+/* info[10] = { Nstate, Nie, NE, Nc, frame_lo, frame_hi, is_leader, Ncorners_local, Nframe_blocks, Npoint_blocks }.
+   State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames (6 each) then points (3 each), then the warp.
+   The leader owns the camera block and the points */
 void  mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info);
 /* outlier statistics / marking on the local board observations (mrcal.c:3978-4402);
    counts (device int[4]) and sums (device double[1]) are accumulated into */

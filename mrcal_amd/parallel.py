@@ -259,10 +259,11 @@ class GpuShard:
         self.p     = problem
         self.L = L = problem._lib
         _declare_sharded(L)
-        info = (C.c_int*8)()
+        info = (C.c_int*10)()
         L.mrcal_amd_problem_shard_info(problem.handle, info)
         self.Nstate, self.Nie, self.NE, self.Nc = info[0], info[1], info[2], info[3]
         self.frame_lo, self.frame_hi = info[4], info[5]
+        self.Nfb = info[8]
         self.is_leader = bool(info[6])
         self.Nmeas_global = Nmeas_global
         self.Ncorners_global = Ncorners_global
@@ -325,7 +326,7 @@ class GpuShard:
         mine = np.zeros(self.Nstate, dtype=bool)
         if self.is_leader:
             mine[:self.Nie] = True
-            mine[self.Nie + self.NE:] = True
+            mine[self.Nie + 6*self.Nfb:] = True          # the points, the warp
         mine[self.Nie + 6*self.frame_lo : self.Nie + 6*self.frame_hi] = True
         b[~mine] = 0.0
         return self.torch.from_numpy(b).to("cuda")

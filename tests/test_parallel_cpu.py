@@ -1,5 +1,6 @@
-"""The N>1 flow (mrcal_amd/parallel.py) on CPU: world_size 2 and 3 over gloo,
-with a numpy shard standing in for the GPU's sharded-step kernels. The numpy shard
+"""The N>1 flow (mrcal_amd/parallel.py, the protocol reference driver) on CPU:
+world_size 2 and 3 over gloo, with a numpy shard standing in for the GPU's
+sharded-step kernels: TWO sums over the shards per trial step. The numpy shard
 gets its x and J from the CPU checker (the reference's own optimizer_callback,
 oracle/_ref), keeps only the rows of ITS frames, and does the block algebra
 densely. Checked:
@@ -38,9 +39,11 @@ def test_partition_frames():
 
 
 class NumpyShard:
-    """CPU stand-in for GpuShard (same interface), for ONE rank: the segments
-    of the sharded trial step in numpy, the device-side control kernels
-    (csrc/solver_kernels.hip, "dog-leg control") restated in Python"""
+    """CPU stand-in for GpuShard (same interface), for ONE rank: the two
+    segments of the sharded trial step in numpy, the device-side control logic
+    (csrc/solver_kernels.hip, "the fused step": step2_choose_kernel,
+    step2_finish, step2_chol_done) restated in Python. x and J come from the
+    CPU checker; the block algebra is dense"""
     def __init__(self, ref_api, oi, frame_range, is_leader):
         import torch
         self.torch, self.api, self.oi = torch, ref_api, oi
@@ -57,6 +60,7 @@ class NumpyShard:
         self.iwarp = ref_api.state_index_calobject_warp(**oi)
         self.Nc  = self.Nie + 2
         self.sidx = np.concatenate((np.arange(self.Nie), self.iwarp + np.arange(2)))
+        self.eidx_local = self.Nie + np.arange(6*self.f0, 6*self.f1)
         H, W = oi["observations_board"].shape[1:3]
         self.HW = H*W
         self.Ncorners_global = oi["observations_board"].shape[0]*H*W
@@ -70,17 +74,14 @@ class NumpyShard:
         self.rows = rows
         z = lambda n: np.zeros(n)
         self.op = [dict(b=z(self.Nstate), g=z(self.Nstate), N=None, x=None, norm2_x=0.0, gNg=0.0, gg=0.0,
-                        step_cauchy=z(self.Nstate), step_gn=z(self.Nstate),
-                        gn_lensq=0.0, gn_dot_cauchy=0.0, sNs=0.0, gs=0.0) for _ in range(2)]
-        self.comm = [torch.zeros(self.Nc*self.Nc + self.Nc, dtype=torch.float64),
-                     torch.zeros(self.NE, dtype=torch.float64),
-                     torch.zeros(self.Nstate + 2, dtype=torch.float64),
-                     torch.zeros(1, dtype=torch.float64)]
+                        step_cauchy=z(self.Nstate), step_gn=z(self.Nstate), sNs=0.0, gs=0.0) for _ in range(2)]
+        Nc = self.Nc
+        self.comm = [torch.zeros(Nc*Nc + 2*Nc + 2, dtype=torch.float64),       # [S | r | g_S | |x|^2 | status]
+                     torch.zeros(4, dtype=torch.float64)]                     # [gNg | ggE | gnE2 | gnE.gE]
         self.step = z(self.Nstate)
         self.current = 0
         self.lam = 0.0
         self.ring = [None]*8
-        self.Nsegments_run = 0
         # the seed
         self.op[0]["b"][:] = ref_api.optimizer_callback(no_jacobian=True, no_factorization=True, **oi)[0]
 
@@ -91,15 +92,18 @@ class NumpyShard:
 
     # ---- the interface ---------------------------------------------------
     def reset(self, check_termination, max_iterations, trustregion0):
+        self.lam = 0.0                # a new run starts unregularized
         self.ctl = dict(done=0, error=0, check=int(bool(check_termination)), maxit=max_iterations,
                         tr=float(trustregion0), lam=self.lam, ib=self.current, ia=1-self.current,
                         Nsteps_accepted=0, Ntrials=0, Nfactorizations=0, Nevaluations=0,
                         norm2_x=[0.0,0.0], cauchy_lensq=[0.0,0.0], gn_valid=[0,0], gn_lensq=[0.0,0.0],
-                        edge=[0,0], need_gn=0, step_len_sq=0.0)
-        self.skip_factor = self.skip_eval = 0
+                        gn_dot_g=[0.0,0.0], gn_lambda=[0.0,0.0], edge=[0,0],
+                        refactor=0, gn_fresh=0, derive=0, step_len_sq=0.0)
+        # the first thing that happens is the assembly + elimination of the starting point
+        self.fl = dict(skip_eval=0, elim_mode=1, elim_sel=self.current, skip_backsub=1)
         self.status = 0
-    def comm_buffer(self, segment):
-        return self.comm[segment] if self.comm[segment].numel() else None
+    def comm_buffer(self, which):
+        return self.comm[which]
     def snapshot(self, slot):
         self.ring[slot] = dict(self.ctl)
     def wait(self, slot):
@@ -112,119 +116,118 @@ class NumpyShard:
                     Nfactorizations=c["Nfactorizations"], Ntrials=c["Ntrials"], error=c["error"],
                     trustregion=c["tr"], norm2_x=c["norm2_x"][c["ib"]], lambda_=c["lam"])
     def enqueue(self, initial, seg):
-        self.Nsegments_run += 1
         getattr(self, f"_seg{seg}")(bool(initial))
+    def masked_state(self):
+        b = self.op[self.current]["b"].copy()
+        mine = np.zeros(self.Nstate, dtype=bool)
+        if self.is_leader:
+            mine[self.sidx] = True
+        mine[self.eidx_local] = True
+        b[~mine] = 0.0
+        return self.torch.from_numpy(b)
+    def set_state(self, t):
+        self.op[self.current]["b"][:] = t.numpy()
 
-    # ---- segments ---------------------------------------------------------
+    # ---- segment 0: choose | evaluate | assemble + eliminate | my summand of [S | r | g_S | |x|^2 | status]
     def _seg0(self, initial):
-        if initial: return
-        c = self.ctl
-        # ctl_begin (solver_kernels.hip)
+        c, fl = self.ctl, self.fl
+        if not initial:
+            self._choose()
+        out = self.comm[0].numpy()
+        mode = fl["elim_mode"]
+        if mode == 0:
+            return                              # (the kernels leave the buffer alone; nobody reads it)
+        O = self.op[fl["elim_sel"]]
+        if mode == 1:
+            self._evaluate(fl["elim_sel"])
+        Nc = self.Nc
         self.status = 0
-        O = self.op[c["ib"]]
-        O["sNs"] = O["gs"] = 0.0
+        S, r = self._eliminate(O, c["lam"], add_g=(mode == 1) or self.is_leader)
+        out[:Nc*Nc]             = S.ravel()
+        out[Nc*Nc:Nc*Nc+Nc]     = r
+        out[Nc*Nc+Nc:Nc*Nc+2*Nc] = O["g"][self.sidx]
+        out[Nc*Nc+2*Nc]         = O["norm2_x"]
+        out[Nc*Nc+2*Nc+1]       = float(self.status)
+
+    # ---- segment 1: accept/reject | Cholesky | back-substitution | my summand of the four scalars
+    def _seg1(self, initial):
+        c, fl = self.ctl, self.fl
+        Nc = self.Nc
+        v = self.comm[0].numpy()
+        mode = fl["elim_mode"]
+        ip = c["ib"] if initial else c["ia"]
+        norm2_x = float(v[Nc*Nc+2*Nc]); eblock_failed = v[Nc*Nc+2*Nc+1] != 0.0
+        # step2_finish
+        if mode == 1:
+            P = self.op[ip]
+            P["norm2_x_global"] = norm2_x
+            c["norm2_x"][ip]  = norm2_x
+            c["gn_valid"][ip] = 0
+            c["edge"][ip]     = 0
+            c["Nevaluations"] += 1
+            if not initial: self._accept()
+        go = unpack = 0
+        c["gn_fresh"] = 0; c["derive"] = 0
         if not c["done"] and c["check"] and c["Nsteps_accepted"] >= c["maxit"]:
             c["done"] = 1
-        if c["done"]:
-            self.skip_factor = self.skip_eval = 1
-            c["need_gn"] = 0
-        else:
-            cauchy_only = c["cauchy_lensq"][c["ib"]] >= c["tr"]**2
-            c["need_gn"] = int(not cauchy_only and not c["gn_valid"][c["ib"]])
-            if c["need_gn"]: c["Nfactorizations"] += 1
-            self.skip_factor = 0 if c["need_gn"] else 1
-            self.skip_eval   = 0
-        Sr = self.comm[0].numpy()
-        if self.skip_factor:
-            Sr[:] = 0.0
-            return
-        self._factor_local(c["ib"], c["lam"], Sr)
-        if self.status: Sr[0] = np.nan
-
-    def _seg1(self, initial):
-        if initial: return
+        ib = c["ib"]
+        if mode == 1 and ib == ip:
+            unpack = 1; c["derive"] = 1
+        if not c["done"]:
+            if mode == 2:   go = 1
+            elif mode == 1: go = int(ib == ip)
+        if go and eblock_failed:
+            self._raise_lambda(); c["refactor"] = 1; go = 0
+        if go: c["Nfactorizations"] += 1
+        fl["skip_backsub"] = 1
+        if unpack:
+            self.op[ip]["g"][self.sidx] = v[Nc*Nc+Nc:Nc*Nc+2*Nc]
+        O = self.op[c["ib"]]
         out = self.comm[1].numpy()
         out[:] = 0.0
-        if self.skip_factor: return
-        c  = self.ctl
-        O  = self.op[c["ib"]]
-        Sr = self.comm[0].numpy()
-        S  = Sr[:self.Nc*self.Nc].reshape(self.Nc, self.Nc)
-        r  = Sr[self.Nc*self.Nc:]
-        ok = np.all(np.isfinite(S))
-        if ok:
-            try:    np.linalg.cholesky(S)
-            except np.linalg.LinAlgError: ok = False
-        if not ok:
-            self.status = 1
-            ds = np.full(self.Nc, np.nan)
-        else:
-            ds = -np.linalg.solve(S, r)
-        O["step_gn"][self.sidx] = ds
-        for e, B, Dinv in self.fact:
-            v = -Dinv @ (O["g"][e] + B.T @ ds)
-            O["step_gn"][e] = v
-            out[e - self.Nie] = v
+        if go:
+            S = v[:Nc*Nc].reshape(Nc, Nc)
+            S = np.tril(S) + np.tril(S, -1).T          # (only the lower triangle is meaningful)
+            r = v[Nc*Nc:Nc*Nc+Nc]
+            ok = np.all(np.isfinite(S))
+            if ok:
+                try:    np.linalg.cholesky(S)
+                except np.linalg.LinAlgError: ok = False
+            if not ok:
+                self._raise_lambda(); c["refactor"] = 1
+            else:
+                c["refactor"] = 0
+                c["gn_valid"][ib]  = 1
+                c["gn_lambda"][ib] = c["lam"]
+                c["gn_fresh"]      = 1
+                fl["skip_backsub"] = 0
+                ds = -np.linalg.solve(S, r)
+                O["step_gn"][self.sidx] = ds
+                for e, B, Dinv in self.fact:
+                    O["step_gn"][e] = -Dinv @ (O["g"][e] + B.T @ ds)
+                d = O["step_gn"][self.eidx_local]
+                out[2] = float(d @ d)
+                out[3] = float(d @ O["g"][self.eidx_local])
+        if c["derive"]:
+            g = O["g"]
+            out[0] = float(g @ O["N"] @ g)                              # my rows' part of g^T JtJ g
+            out[1] = float(g[self.eidx_local] @ g[self.eidx_local])
 
-    def _seg2(self, initial):
+    # ---- the control logic ------------------------------------------------
+    def _raise_lambda(self):
         c = self.ctl
-        if not initial:
-            ib, ia = c["ib"], c["ia"]
-            O = self.op[ib]
-            if not self.skip_factor:
-                O["step_gn"][self.Nie:self.Nie+self.NE] = self.comm[1].numpy()
-                O["gn_lensq"]      = float(O["step_gn"] @ O["step_gn"])
-                O["gn_dot_cauchy"] = float(O["step_gn"] @ O["step_cauchy"])
-            self._step_choose()
-            if not self.skip_eval:
-                O["sNs"] = float(self.step @ O["N"] @ self.step)     # local part
-                O["gs"]  = float(O["g"] @ self.step)
-        ip = c["ib"] if initial else c["ia"]
-        out = self.comm[2].numpy()
-        if not initial and self.skip_eval:
-            out[:] = 0.0
-            return
-        self._evaluate(ip)
-        P = self.op[ip]
-        out[:self.Nstate]  = P["g"]
-        out[self.Nstate]   = P["norm2_x"]
-        out[self.Nstate+1] = 0.0 if initial else self.op[c["ib"]]["sNs"]
+        c["lam"] = 1e-10 if c["lam"] == 0.0 else c["lam"]*10.0
+        if not c["lam"] < 1e30:
+            c["error"] = c["done"] = 1
 
-    def _seg3(self, initial):
-        c = self.ctl
-        out = self.comm[3].numpy()
-        if not initial and self.skip_eval:
-            out[0] = 0.0
-            return
-        P  = self.op[c["ib"] if initial else c["ia"]]
-        v  = self.comm[2].numpy()
-        P["g"][:]    = v[:self.Nstate]
-        P["norm2_x"] = float(v[self.Nstate])
-        if not initial: self.op[c["ib"]]["sNs"] = float(v[self.Nstate+1])
-        P["gNg"] = float(P["g"] @ P["N"] @ P["g"])                   # local part
-        P["gg"]  = float(P["g"] @ P["g"])
-        out[0] = P["gNg"]
-
-    def _seg4(self, initial):
-        c = self.ctl
-        if not initial and self.skip_eval: return
-        ip = c["ib"] if initial else c["ia"]
-        P  = self.op[ip]
-        P["gNg"] = float(self.comm[3][0])
-        # step_finish_kernel: the Cauchy step
-        k = -P["gg"]/P["gNg"] if P["gNg"] > 0.0 else 0.0
-        P["step_cauchy"][:] = k*P["g"]
-        c["norm2_x"][ip]      = P["norm2_x"]
-        c["cauchy_lensq"][ip] = k*k*P["gg"]
-        c["gn_valid"][ip]     = 0
-        c["edge"][ip]         = 0
-        c["Nevaluations"]    += 1
-        if initial: return
+    def _accept(self):
         # ctl_accept (solver_kernels.hip)
+        c = self.ctl
         ib, ia = c["ib"], c["ia"]
         expected = -2.0*self.op[ib]["gs"] - self.op[ib]["sNs"]
         rho = (c["norm2_x"][ib] - c["norm2_x"][ia])/expected
-        if rho < 0.25:                  c["tr"] *= 0.1
+        if not (rho == rho) or not (c["norm2_x"][ia] == c["norm2_x"][ia]): rho = -1.0
+        if rho < 0.25:                     c["tr"] *= 0.1
         elif rho > 0.75 and c["edge"][ib]: c["tr"] *= 2.0
         if rho > 0.0:
             c["ib"], c["ia"] = ia, ib
@@ -232,27 +235,50 @@ class NumpyShard:
         elif c["check"] and (c["tr"] < 0.0 or c["tr"] == 0.0 or c["tr"] != c["tr"]):
             c["done"] = 1
 
-    # ---- pieces -----------------------------------------------------------
-    def _step_choose(self):
-        c = self.ctl
-        if c["done"]: return
+    def _choose(self):
+        # step2_choose_kernel
+        c, fl = self.ctl, self.fl
+        if c["done"]:
+            fl.update(skip_eval=1, elim_mode=0)
+            return
         ib, ia = c["ib"], c["ia"]
         O = self.op[ib]
-        fresh = bool(c["need_gn"])
-        if fresh and (self.status != 0 or not np.isfinite(O["gn_lensq"])):
-            lam = 1e-10 if c["lam"] == 0.0 else c["lam"]*10.0
-            c["lam"] = lam
-            if not lam < 1e30:
-                c["error"] = c["done"] = 1
-            self.skip_eval = 1
-            return
+        v2 = self.comm[1].numpy()
+        if c["derive"]:
+            ggS = float(O["g"][self.sidx] @ O["g"][self.sidx])
+            gNg, gg = float(v2[0]), ggS + float(v2[1])
+            kcau = -gg/gNg if gNg > 0.0 else 0.0
+            norm2a = kcau*kcau*gg
+            O["step_cauchy"][:] = kcau*O["g"]
+            O["gNg"], O["gg"] = gNg, gg
+            c["cauchy_lensq"][ib] = norm2a
+        else:
+            gNg, gg = O["gNg"], O["gg"]
+            kcau = -gg/gNg if gNg > 0.0 else 0.0
+            norm2a = c["cauchy_lensq"][ib]
         tr, dsq = c["tr"], c["tr"]**2
-        norm2a = c["cauchy_lensq"][ib]
-        if norm2a >= dsq:
+        cauchy_only = norm2a >= dsq
+        if c["refactor"] or (not cauchy_only and not c["gn_valid"][ib]):
+            c["refactor"] = 1
+            self.status = 0
+            fl.update(skip_eval=1, elim_mode=2, elim_sel=ib)
+            return
+        fresh = (not cauchy_only) and c["gn_fresh"]
+        gn_lensq, gn_dot_g = c["gn_lensq"][ib], c["gn_dot_g"][ib]
+        if fresh:
+            gnS = O["step_gn"][self.sidx]
+            gn_lensq = float(gnS @ gnS) + float(v2[2])
+            gn_dot_g = float(gnS @ O["g"][self.sidx]) + float(v2[3])
+            if not gn_lensq == gn_lensq:
+                self._raise_lambda()
+                c["refactor"] = 1; c["gn_valid"][ib] = 0
+                fl.update(skip_eval=1, elim_mode=(0 if c["done"] else 2), elim_sel=ib)
+                return
+        norm2b = ab = 0.0
+        if cauchy_only:
             kc, kg, len_sq, edge = tr/math.sqrt(norm2a), 0.0, dsq, 1
         else:
-            norm2b = O["gn_lensq"] if fresh else c["gn_lensq"][ib]
-            ab     = O["gn_dot_cauchy"]
+            norm2b, ab = gn_lensq, kcau*gn_dot_g
             if norm2b <= dsq:
                 kc, kg, len_sq, edge = 0.0, 1.0, norm2b, 0
             else:
@@ -263,18 +289,28 @@ class NumpyShard:
                 kc, kg = 1.0-k, k
                 len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b
                 edge = 1
-            if fresh:
-                c["gn_lensq"][ib] = norm2b
-                c["gn_valid"][ib] = 1
         self.step[:] = kc*O["step_cauchy"] + (kg*O["step_gn"] if kg != 0.0 else 0.0)
         self.op[ia]["b"][:] = O["b"] + self.step
+        if fresh:
+            c["gn_lensq"][ib], c["gn_dot_g"][ib] = gn_lensq, gn_dot_g
+        # the expected improvement from dot products (no pass over JtJ)
+        sNs, gs = kc*kc*kcau*kcau*gNg, kc*kcau*gg
+        if kg != 0.0:
+            a, lam = gn_dot_g, c["gn_lambda"][ib]
+            sNs += 2.0*kc*kg*(-kcau*gg - lam*ab) + kg*kg*(-a - lam*norm2b)
+            gs  += kg*a
+        O["sNs"], O["gs"] = sNs, gs
         c["step_len_sq"] = len_sq
         c["edge"][ib] = edge
         c["Ntrials"] += 1
+        self.status = 0
         if c["check"] and len_sq < 1e-7**2:
             c["done"] = 1
-            self.skip_eval = 1
+            fl.update(skip_eval=1, elim_mode=0)
+        else:
+            fl.update(skip_eval=0, elim_mode=1, elim_sel=ia)
 
+    # ---- pieces -----------------------------------------------------------
     def inputs_at(self, b):
         """optimization_inputs with the state b (all variables optimized)"""
         oi = dict(self.oi)
@@ -289,6 +325,7 @@ class NumpyShard:
 
     def _evaluate(self, iop):
         O = self.op[iop]
+        # (the frame poses of the other shards' frames in MY state are stale: my rows do not depend on them)
         _, x, J, _ = self.api.optimizer_callback(no_factorization=True, **self.inputs_at(O["b"]))
         Jl = J[self.rows].toarray()
         xl = x[self.rows]
@@ -297,13 +334,12 @@ class NumpyShard:
         O["g"][:] = Jl.T @ xl
         O["norm2_x"] = float(xl @ xl)
 
-    def _factor_local(self, iop, lam, Sr):
-        N, g = self.op[iop]["N"], self.op[iop]["g"]
+    def _eliminate(self, O, lam, add_g):
+        N, g = O["N"], O["g"]
         S = N[np.ix_(self.sidx, self.sidx)].copy()
         r = np.zeros(self.Nc)
-        if self.is_leader:
-            S += lam*np.eye(self.Nc)
-            r += g[self.sidx]
+        if self.is_leader: S += lam*np.eye(self.Nc)
+        if add_g:          r += g[self.sidx]
         self.fact = []
         for f in range(self.f0, self.f1):
             e = self.Nie + 6*f + np.arange(6)
@@ -318,8 +354,7 @@ class NumpyShard:
             S -= B @ Dinv @ B.T
             r -= B @ Dinv @ g[e]
             self.fact.append((e, B, Dinv))
-        Sr[:self.Nc*self.Nc] = S.ravel()
-        Sr[self.Nc*self.Nc:] = r
+        return S, r
 
     def _local_corners(self):
         x = self.op[self.current]["x"]
@@ -376,7 +411,7 @@ def _worker(rank, world, port, seed, out_path):
     if rank == 0:
         np.savez(out_path, b=b, weights=weights, rms=stats["rms_reproj_error__pixels"],
                  Noutliers=stats["Noutliers_board"], Nevaluations=stats["Nevaluations"],
-                 Ncollectives=dl.comm.Ncollectives)
+                 Ncollectives=dl.comm.Ncollectives, Ntrials=dl.Ntrials_total, Npasses=stats["Noutlier_passes"])
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -406,7 +441,9 @@ def test_sharded_solve_matches_unsharded_and_reference(tmp_path, ref_api):
         assert abs(r["rms"] - r1["rms"]) < 1e-8
         assert int(r["Noutliers"]) == int(r1["Noutliers"])
         assert np.array_equal(r["weights"] < 0, r1["weights"] < 0)
-        assert int(r["Ncollectives"]) > 0
+        # TWO sums over the shards per trial step (the starting point of a pass counts as
+        # one), a few per outlier pass, one for the final gather of the state
+        assert 0 < int(r["Ncollectives"]) <= 2*int(r["Ntrials"]) + 4*(int(r["Npasses"]) + 1) + 1
 
     # and against the reference's own mrcal_optimize() (+ restated libdogleg)
     oi, _ = make_calibration_problem(ref_api, Ncameras=2, Nframes=9, lensmodel="LENSMODEL_OPENCV4",

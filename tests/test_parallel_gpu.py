@@ -173,3 +173,43 @@ def test_rccl_world1_is_the_single_gpu_solve(amd, tmp_path):
     Ntrials_max = int(r["Nevaluations"]) + 8*(int(r["Npasses"]) + 1)
     assert 20 < int(r["Ncollectives"]) <= 2*Ntrials_max + 5*(int(r["Npasses"]) + 1) + 1
     assert int(r["Ncollectives_5steps"]) == 2*(5 + 1)
+
+
+def _points_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mrcal_amd
+    from mrcal_amd.parallel import ShardedProblem
+    from test_callback_parity import points_only_problem
+    oi = points_only_problem(mrcal_amd._api)
+    sp = ShardedProblem(_driver="python", **oi)
+    st = sp.solve()
+    if rank == 0:
+        np.savez(out_path, b=sp.b_packed(), rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"])
+    sp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_points_only(amd, tmp_path):
+    """no frames at all: every rank gets the empty frame range, and only the
+    leader may own the points and the regularization rows - or the sums over
+    the ranks count them twice (|x|^2 would come out doubled)"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    from test_callback_parity import points_only_problem
+    oi = points_only_problem(amd._api)
+    with Problem(**oi) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "w2p.npz")
+    port = 29300 + (os.getpid() % 250)
+    mp.spawn(_points_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
+    assert abs(float(r["rms"]) - s1["rms_reproj_error__pixels"]) < 1e-9
+    assert np.abs(r["b"] - b1).max() < 1e-6
