@@ -111,13 +111,18 @@ typedef struct
 /* The slice of SuiteSparse's cholmod_sparse that the reference's callback
    touches (mrcal.c:4461-4463: p, i, x only). Field order as in CHOLMOD so
    that a caller holding a real cholmod_sparse can pass it as is. Jt is
-   (Nstate x Nmeasurements) compressed-column, i.e. J in CSR */
+   (Nstate x Nmeasurements) compressed-column, i.e. J in CSR.
+   A translation unit that also includes SuiteSparse's <cholmod.h> (or
+   libdogleg's <dogleg.h>, which does) defines MRCAL_AMD_HAVE_CHOLMOD_SPARSE
+   first and gets the real type */
+#ifndef MRCAL_AMD_HAVE_CHOLMOD_SPARSE
 struct cholmod_sparse_struct
 {
     size_t nrow, ncol, nzmax;
     void *p, *i, *nz, *x, *z;
     int stype, itype, xtype, dtype, sorted, packed;
 };
+#endif
 
 /* ------------------------------------------------------------------------ */
 /* DROP-IN TIER                                                              */
