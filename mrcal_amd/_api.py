@@ -409,12 +409,17 @@ class Api:
         """mrcal.optimize(): solve; updates intrinsics, rt_cam_ref, rt_ref_frame,
         points, calobject_warp and the outlier marks in observations_board IN
         PLACE; returns the stats dict (mrcal-pywrap.c:1809-1888)"""
+        # (the reference's Python wrapper always passes check_gradient=false,
+        #  mrcal-pywrap.c:1842; the C entry point has it, and so the tests reach it)
+        kwargs = dict(kwargs)
+        check_gradient = bool(kwargs.pop("_check_gradient", False))
         p = self._ingest(kwargs, callback=False)
         Nstate, Nmeas = self._sizes(p)
         b_packed = np.empty((Nstate,), dtype=np.float64)
         x        = np.empty((Nmeas,),  dtype=np.float64)
-        stats = self.clib.mrcal_optimize(_ptr(b_packed), Nstate*8, _ptr(x), Nmeas*8,
-                                         *self._common_args(p), False)
+        stats = self.clib.mrcal_optimize(None if check_gradient else _ptr(b_packed), Nstate*8,
+                                         None if check_gradient else _ptr(x), Nmeas*8,
+                                         *self._common_args(p), check_gradient)
         if stats.rms_reproj_error__pixels < 0.0:
             raise RuntimeError("mrcal.optimize() failed!" + self._last_error())
         return dict(rms_reproj_error__pixels     = stats.rms_reproj_error__pixels,

@@ -83,6 +83,7 @@ struct mrcal_amd_problem
     double*                    d_comm   = NULL;   // comm2 of the sharded step (4 doubles) + scratch for host-side sums
     struct mrcal_amd_comm*     comm     = NULL;   // attached communicator (not owned): solve/run_steps run sharded
     bool                       sharded_external = false;   // sharded step, the CALLER does the collectives
+    bool                       verbose = false;            // mrcal_optimize(verbose): the iteration trace on stderr
     int*                       d_counts = NULL;   // [4]
     double*                    d_outlier_part = NULL;   // [outlier_partial_doubles()]
     double*                    h_scalars = NULL;  // pinned [64]

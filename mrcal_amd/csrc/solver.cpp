@@ -16,6 +16,7 @@
 // increase 2 above rho 0.75 (only if the step reached the trust-region edge).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <chrono>
 #include <vector>
@@ -236,7 +237,9 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     if(!enqueue_initial_point(P)) return false;
 
     const int LAG = 3;      // how many steps the host may run ahead of what it has seen
-    static const bool debug = (getenv("MRCAL_AMD_DEBUG_SOLVER") != NULL);
+    // verbose (mrcal.c:6291 turns on libdogleg's per-iteration report with it), or the environment
+    static const bool debug_env = (getenv("MRCAL_AMD_DEBUG_SOLVER") != NULL);
+    const bool debug = debug_env || P->verbose;
     int  nqueued = 0;
     bool done = false;
     const int max_trials = 100*prm.max_iterations + 1000;   // runaway guard
@@ -459,6 +462,68 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
         HIP_TRY(hipMemcpy(P->d_tri_outlier, out.data(), (size_t)(out.size()-1)*sizeof(int), hipMemcpyHostToDevice), return false);
     *found = true;
     return true;
+}
+
+// mrcal_optimize(check_gradient): libdogleg's dogleg_testGradient() (as restated in
+// oracle/dogleg_restated.c, same columns) for every state variable, from the
+// device's J and x. Small problems only: Nstate*Nmeasurements lines
+bool test_gradients(mrcal_amd_problem* P)
+{
+    const int Nstate = P->L.Nstate, Nmeas = P->L.Nmeas;
+    const double delta = 1e-6;
+    std::vector<double>  b0(Nstate > 0 ? Nstate : 1), b(Nstate > 0 ? Nstate : 1), x0(Nmeas > 0 ? Nmeas : 1), x1(Nmeas > 0 ? Nmeas : 1);
+    std::vector<int32_t> Jp((size_t)Nmeas + 1), Ji(P->Nnz > 0 ? P->Nnz : 1);
+    std::vector<double>  Jx(P->Nnz > 0 ? P->Nnz : 1);
+    if(!mrcal_amd_problem_get_b_packed(P, b0.data())) return false;
+    if(!mrcal_amd_problem_evaluate(P, true, true)) return false;
+    if(!mrcal_amd_problem_get_J(P, Jp.data(), Ji.data(), Jx.data())) return false;
+    for(int var = 0; var < Nstate; var++)
+    {
+        b = b0; b[var] -= delta/2.0;
+        if(!mrcal_amd_problem_set_b_packed(P, b.data()) || !mrcal_amd_problem_evaluate(P, false, true) ||
+           !mrcal_amd_problem_get_x(P, x0.data())) return false;
+        b[var] += delta;
+        if(!mrcal_amd_problem_set_b_packed(P, b.data()) || !mrcal_amd_problem_evaluate(P, false, true) ||
+           !mrcal_amd_problem_get_x(P, x1.data())) return false;
+        if(var == 0)
+            printf("# ivar imeasurement gradient_reported gradient_observed error error_relative\n");
+        for(int j = 0; j < Nmeas; j++)
+        {
+            double g_rep = 0.0;
+            for(int e = Jp[j]; e < Jp[j+1]; e++)
+                if(Ji[e] == var) g_rep += Jx[e];
+            const double g_obs = (x1[j] - x0[j]) / delta;
+            const double err   = g_rep - g_obs;
+            const double den   = (fabs(g_rep) + fabs(g_obs)) / 2.0;
+            printf("%d %d %.6g %.6g %.6g %.6g\n", var, j, g_rep, g_obs, err, den > 0.0 ? fabs(err)/den : 0.0);
+        }
+    }
+    fflush(stdout);
+    return mrcal_amd_problem_set_b_packed(P, b0.data());
+}
+
+// mrcal_optimize(verbose): the regularization report of mrcal.c:6503-6598
+void report_regularization(mrcal_amd_problem* P, const mrcal_problem_selections_t& sel)
+{
+    const Layout& L = P->L;
+    if(L.Nmeas_regularization <= 0) return;
+    std::vector<double> xreg(L.Nmeas_regularization);
+    if(hipMemcpy(xreg.data(), P->op[P->icur].x + L.i_meas_regularization, xreg.size()*sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    const double norm2_error = P->stats.norm2_x;
+    const int Ncore = L.Ncore;
+    const int Ndist_reg  = sel.do_optimize_intrinsics_distortions ? L.dims.Ncameras_intrinsics*(L.Nintrinsics - Ncore) : 0;
+    const int Ncenter    = sel.do_optimize_intrinsics_core ? L.dims.Ncameras_intrinsics*2 : 0;
+    double n2d = 0.0, n2c = 0.0;
+    int i = 0;
+    for(int k = 0; k < Ndist_reg && i < (int)xreg.size(); k++, i++) n2d += xreg[i]*xreg[i];
+    for(int k = 0; k < Ncenter   && i < (int)xreg.size(); k++, i++) n2c += xreg[i]*xreg[i];
+    const double rd = n2d/norm2_error, rc = n2c/norm2_error;
+    if(rd > 0.01) fprintf(stderr, "mrcal_amd: WARNING: regularization ratio for lens distortion exceeds 1%%. Is the scale factor too high? Ratio = %.3g/%.3g = %.3g\n", n2d, norm2_error, rd);
+    if(rc > 0.01) fprintf(stderr, "mrcal_amd: WARNING: regularization ratio for the projection centerpixel exceeds 1%%. Is the scale factor too high? Ratio = %.3g/%.3g = %.3g\n", n2c, norm2_error, rc);
+    fprintf(stderr, "mrcal_amd: reg err ratio (distortion,centerpixel): %.3g %.3g\n", rd, rc);
+    if(L.has_unity_cam01 && i < (int)xreg.size())
+        fprintf(stderr, "mrcal_amd: reg err ratio (unity_cam01): %.3g\n", xreg[i]*xreg[i]/norm2_error);
 }
 
 } // namespace
@@ -762,15 +827,9 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 bool verbose,
                 bool check_gradient)
 {
-    (void)problem_constants; (void)verbose;
+    (void)problem_constants;
     last_error_string().clear();
     const mrcal_stats_t failed = { -1.0, 0, 0 };
-
-    if(check_gradient)
-    {
-        set_error("mrcal_optimize(check_gradient=true) is not available in the GPU build");
-        return failed;
-    }
     if(Nobservations_board > 0 && problem_selections.do_optimize_calobject_warp && calobject_warp == NULL)
     {
         set_error("ERROR: We're optimizing the calibration object warp, so a buffer with a seed MUST be passed in.");
@@ -827,6 +886,20 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
         fprintf(stderr, "mrcal_amd: WARNING: problem isn't overdetermined: Nmeasurements=%d, Nstate=%d. Solver may not converge, and if it does, the results aren't reliable\n",
                 Nmeas, Nstate);
 
+    P->verbose = verbose;
+    if(check_gradient)
+    {
+        // mrcal.c:6600-6605: no solve; libdogleg's dogleg_testGradient() for every
+        // state variable: the reported gradient (a column of J) beside a central
+        // difference of x, one line per measurement, vnlog on stdout. The
+        // reference then returns sqrt(-1/Nmeasurements) for the rms: not a number
+        if(!test_gradients(P)) goto done;
+        stats.rms_reproj_error__pixels     = sqrt(-1.0);
+        stats.Noutliers_board              = 0;
+        stats.Noutliers_triangulated_point = 0;
+        goto done;
+    }
+
     // input outliers count even if nothing new is found (mrcal.c:6418-6421)
     for(int i=0; i<P->L.Nmeas_boards/2; i++)
         if(observations_board_pool[i].z < 0.0) Noutliers++;
@@ -849,6 +922,7 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
     stats.rms_reproj_error__pixels     = rms;
     stats.Noutliers_board              = Noutliers;
     stats.Noutliers_triangulated_point = P->stats.Noutliers_triangulated;
+    if(verbose) report_regularization(P, sel);
 
  done:
     mrcal_amd_problem_destroy(P);
