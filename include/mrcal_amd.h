@@ -570,6 +570,25 @@ void   mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f);
 int    mrcal_amd_factorization_Nstate (const mrcal_amd_factorization_t* f);
 /* xt[i,:] = (JtJ)^-1 bt[i,:]; host, C-contiguous (Nrhs,Nstate) */
 bool   mrcal_amd_factorization_solve  (mrcal_amd_factorization_t* f, const double* bt, int Nrhs, double* xt);
+/* The other systems of cholmod_solve2() (mrcal-pywrap.c:467-493), sys = CHOLMOD's codes:
+   0 A, 1 LDLt, 2 LD, 3 DLt, 4 L, 5 Lt, 6 D, 7 P, 8 Pt. The factorization kept here is
+       L L^T = P (JtJ) P^T      (an LL^T factorization: D = I, so LD == L, DLt == Lt)
+   with P the ordering [ frame blocks | point blocks | intrinsics, extrinsics | warp ]: the
+   eliminated blocks first. As with CHOLMOD, the vectors of the L/D systems are in the
+   order of P; "P" takes a vector there (x = P b), "Pt" back. mrcal's projection
+   uncertainty does  A1 = solve(b,'P'); A2 = solve(A1,'L'); A3 = solve(A2,'D');
+   Var = A2 A3^T  (mrcal/model_analysis.py:837-843): the same three calls work here */
+bool   mrcal_amd_factorization_solve_sys(mrcal_amd_factorization_t* f, int sys, const double* bt, int Nrhs, double* xt);
+/* The consumers of J that go with it (mrcal-genpywrap.py:477-731), on the J the
+   factorization was made from, which is resident on the device:
+   y (Nstate) = Jt x (Nmeas) ; out (Nx*Nx) = A Jt J At over the leading rows of J, A (Nx*Nstate), Nx <= 8 */
+bool   mrcal_amd_factorization_Jt_x     (mrcal_amd_factorization_t* f, const double* x, double* y);
+bool   mrcal_amd_factorization_A_Jt_J_At(mrcal_amd_factorization_t* f, const double* A, int Nx, int Nleading_rows_J, double* out);
+/* the same for a CSR matrix in host memory (the reference's signatures: mrcal._mrcal_npsp._Jt_x, _A_Jt_J_At) */
+bool   mrcal_amd_csr_Jt_x     (int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                               const double* x, double* y);
+bool   mrcal_amd_csr_A_Jt_J_At(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                               const double* A, int Nx, int Nleading_rows_J, double* out);
 /* (min diag L / max diag L)^2, like cholmod_rcond() */
 double mrcal_amd_factorization_rcond  (mrcal_amd_factorization_t* f);
 

@@ -68,7 +68,7 @@ lensmodel_num_params                  = _api.lensmodel_num_params
 project                               = _api.project
 unproject                             = _api.unproject
 
-from ._factorization import CHOLMOD_factorization
+from ._factorization import CHOLMOD_factorization, _Jt_x, _A_Jt_J_At, _A_Jt_J_At__2
 
 
 def gpu_available():

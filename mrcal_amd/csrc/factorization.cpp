@@ -45,6 +45,7 @@ struct mrcal_amd_factorization
     double*       d_rhs = NULL;
     double*       d_sol = NULL;
     double*       d_mm  = NULL;   // [2] min, max of the factor's diagonal
+    int           Nmeas = 0;
     hipStream_t   stream = NULL;
     std::vector<void*> allocs;
 
@@ -90,6 +91,7 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     }
     const int64_t Nnz = rowptr[Nmeas];
     mrcal_amd_factorization* f = new mrcal_amd_factorization();
+    f->Nmeas = Nmeas;
     NormalDims& nd = f->nd;
     nd.Nstate = Nstate; nd.Nie = Nstate_shared_leading; nd.Nwarp = Nwarp;
     nd.i_state_warp = Nstate - Nwarp; nd.Nc = nd.Nie + nd.Nwarp;
@@ -193,6 +195,129 @@ bool mrcal_amd_factorization_solve(mrcal_amd_factorization_t* f, const double* b
     }
     HIP_TRY(hipStreamSynchronize(f->stream), return false);
     return true;
+}
+
+// The other systems of cholmod_solve2() (mrcal-pywrap.c:467-493; sys = CHOLMOD's
+// codes: 0 A, 1 LDLt, 2 LD, 3 DLt, 4 L, 5 Lt, 6 D, 7 P, 8 Pt) against this
+// factorization: L L^T = P (JtJ) P^T with the frame/point blocks first and D = I
+// (solver_kernels.hip, "factor order"). Vectors of the L/D systems live in that
+// order, as CHOLMOD's live in its own
+bool mrcal_amd_factorization_solve_sys(mrcal_amd_factorization_t* f, int sys, const double* bt, int Nrhs, double* xt)
+{
+    last_error_string().clear();
+    if(sys < 0 || sys > FSOLVE_Pt) { set_error("unknown system %d", sys); return false; }
+    const size_t n = (size_t)f->nd.Nstate;
+    for(int i = 0; i < Nrhs; i++)
+    {
+        HIP_TRY(hipMemcpyAsync(f->d_rhs, bt + (size_t)i*n, n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
+        HIP_TRY(launch_fsolve_sys(f->nd, f->F, sys, f->d_rhs, f->d_sol, f->stream), return false);
+        HIP_TRY(hipMemcpyAsync(xt + (size_t)i*n, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
+    }
+    HIP_TRY(hipStreamSynchronize(f->stream), return false);
+    return true;
+}
+
+// y = Jt x with the J this factorization was made from (it is resident): mrcal-genpywrap.py:658-731 _Jt_x
+bool mrcal_amd_factorization_Jt_x(mrcal_amd_factorization_t* f, const double* x, double* y)
+{
+    last_error_string().clear();
+    const size_t n = (size_t)f->nd.Nstate;
+    HIP_TRY(hipMemcpyAsync(f->op.x, x, (size_t)f->Nmeas*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
+    HIP_TRY(hipMemsetAsync(f->d_sol, 0, n*sizeof(double), f->stream), return false);
+    HIP_TRY(launch_csr_Jt_x(f->Nmeas, f->d_Jp, f->d_Ji, f->op.Jv, f->op.x, f->d_sol, f->stream), return false);
+    HIP_TRY(hipMemcpyAsync(y, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
+    HIP_TRY(hipStreamSynchronize(f->stream), return false);
+    return true;
+}
+
+// out (Nx x Nx) = A Jt J At over the Nleading_rows_J leading rows of J, A (Nx x Nstate) row-major, host:
+// mrcal-genpywrap.py:477-657 _A_Jt_J_At. Nx <= 8
+bool mrcal_amd_factorization_A_Jt_J_At(mrcal_amd_factorization_t* f, const double* A, int Nx, int Nleading_rows_J, double* out)
+{
+    last_error_string().clear();
+    if(Nx < 1 || Nx > 8) { set_error("_A_Jt_J_At: A must have 1..8 rows, not %d", Nx); return false; }
+    if(Nleading_rows_J <= 0 || Nleading_rows_J > f->Nmeas)
+    {
+        set_error("Nleading_rows_J must be passed, and must be > 0 (and at most the %d rows of J)", f->Nmeas);
+        return false;
+    }
+    const size_t n = (size_t)f->nd.Nstate;
+    double *dA = NULL, *dout = NULL;
+    bool ok = true;
+    HIP_TRY(hipMalloc((void**)&dA, (size_t)Nx*n*sizeof(double)), return false);
+    HIP_TRY(hipMalloc((void**)&dout, 64*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(hipMemcpyAsync(dA, A, (size_t)Nx*n*sizeof(double), hipMemcpyHostToDevice, f->stream), ok = false);
+    if(ok) HIP_TRY(hipMemsetAsync(dout, 0, 64*sizeof(double), f->stream), ok = false);
+    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, (int)n, f->d_Jp, f->d_Ji, f->op.Jv, dA, dout, f->stream), ok = false);
+    if(ok) HIP_TRY(hipMemcpyAsync(out, dout, (size_t)Nx*Nx*sizeof(double), hipMemcpyDeviceToHost, f->stream), ok = false);
+    if(ok) HIP_TRY(hipStreamSynchronize(f->stream), ok = false);
+    hipFree(dA); hipFree(dout);
+    return ok;
+}
+
+// The same two for a CSR matrix that is on the host (the reference's signatures take the
+// p, i, x arrays: mrcal._mrcal_npsp._Jt_x, _A_Jt_J_At): upload, compute, free
+namespace {
+struct CsrOnDevice
+{
+    int32_t *Jp = NULL, *Ji = NULL; double *Jx = NULL; bool ok = false;
+    CsrOnDevice(int Nrows, const int32_t* p, const int32_t* i, const double* x)
+    {
+        const size_t nnz = (size_t)p[Nrows];
+        if(hipMalloc((void**)&Jp, ((size_t)Nrows+1)*sizeof(int32_t)) != hipSuccess) return;
+        if(hipMalloc((void**)&Ji, (nnz ? nnz : 1)*sizeof(int32_t)) != hipSuccess) return;
+        if(hipMalloc((void**)&Jx, (nnz ? nnz : 1)*sizeof(double)) != hipSuccess) return;
+        if(hipMemcpy(Jp, p, ((size_t)Nrows+1)*sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return;
+        if(nnz && hipMemcpy(Ji, i, nnz*sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return;
+        if(nnz && hipMemcpy(Jx, x, nnz*sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return;
+        ok = true;
+    }
+    ~CsrOnDevice() { hipFree(Jp); hipFree(Ji); hipFree(Jx); }
+};
+}
+bool mrcal_amd_csr_Jt_x(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                        const double* x, double* y)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0) { set_error("no HIP device is visible: libmrcal_amd has no CPU fallback"); return false; }
+    CsrOnDevice J(Nrows, Jp, Ji, Jx);
+    if(!J.ok) { set_error("could not put J on the device"); return false; }
+    double *dx = NULL, *dy = NULL;
+    bool ok = true;
+    HIP_TRY(hipMalloc((void**)&dx, (size_t)(Nrows > 0 ? Nrows : 1)*sizeof(double)), return false);
+    HIP_TRY(hipMalloc((void**)&dy, (size_t)(Ncols > 0 ? Ncols : 1)*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(dx, x, (size_t)Nrows*sizeof(double), hipMemcpyHostToDevice), ok = false);
+    if(ok) HIP_TRY(hipMemset(dy, 0, (size_t)Ncols*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(hipDeviceSynchronize(), ok = false);
+    if(ok) HIP_TRY(launch_csr_Jt_x(Nrows, J.Jp, J.Ji, J.Jx, dx, dy, NULL), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(y, dy, (size_t)Ncols*sizeof(double), hipMemcpyDeviceToHost), ok = false);
+    hipFree(dx); hipFree(dy);
+    return ok;
+}
+bool mrcal_amd_csr_A_Jt_J_At(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                             const double* A, int Nx, int Nleading_rows_J, double* out)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0) { set_error("no HIP device is visible: libmrcal_amd has no CPU fallback"); return false; }
+    if(Nx < 1 || Nx > 8) { set_error("_A_Jt_J_At: A must have 1..8 rows, not %d", Nx); return false; }
+    if(Nleading_rows_J <= 0 || Nleading_rows_J > Nrows)
+    {
+        set_error("Nleading_rows_J must be passed, and must be > 0 (and at most the %d rows of J)", Nrows);
+        return false;
+    }
+    CsrOnDevice J(Nrows, Jp, Ji, Jx);
+    if(!J.ok) { set_error("could not put J on the device"); return false; }
+    double *dA = NULL, *dout = NULL;
+    bool ok = true;
+    HIP_TRY(hipMalloc((void**)&dA, (size_t)Nx*Ncols*sizeof(double)), return false);
+    HIP_TRY(hipMalloc((void**)&dout, 64*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(dA, A, (size_t)Nx*Ncols*sizeof(double), hipMemcpyHostToDevice), ok = false);
+    if(ok) HIP_TRY(hipMemset(dout, 0, 64*sizeof(double)), ok = false);
+    if(ok) HIP_TRY(hipDeviceSynchronize(), ok = false);
+    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, Ncols, J.Jp, J.Ji, J.Jx, dA, dout, NULL), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(out, dout, (size_t)Nx*Nx*sizeof(double), hipMemcpyDeviceToHost), ok = false);
+    hipFree(dA); hipFree(dout);
+    return ok;
 }
 
 // like cholmod_rcond() for an LL' factorization: (min diag / max diag)^2

@@ -3074,10 +3074,23 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
 ////////////////////////////////////////////////////////////////////////////////
 namespace mrcal_amd {
 
-// y_e = L_e^-1 b_e, one thread per E block. b, y indexed by state / E index
+// The factorization kept by launch_factor_local() + the Cholesky of S is an LL^T
+// factorization of the PERMUTED matrix: with the eliminated blocks first,
+//     P (JtJ) P^T = [ D  Bt ]  =  L L^T ,   L = [ L_E   0  ]      L_E = blockdiag(chol(D_e))   (F.LD)
+//                   [ B  A  ]                   [ Wt^T  L_S ]     Wt  = L_E^-1 Bt              (F.Wt)
+//                                                                 L_S = chol(S)               (F.S, lower)
+// "factor order" = the order of P: [ E (frames, then points) | S (intrinsics, extrinsics, warp) ].
+// order 0: vectors in state order; 1: in factor order.
+__device__ __forceinline__ int fs_index_E(const NormalDims& nd, int order, int e) { return order ? e : nd.Nie + e; }
+__device__ __forceinline__ int fs_index_S(const NormalDims& nd, int order, int c)
+{
+    return order ? nd.NE + c : ((c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie));
+}
+
+// y_e = L_e^-1 b_e, one thread per E block
 __global__ __launch_bounds__(64)
 void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
-                           const double* __restrict__ b, double* __restrict__ y)
+                           const double* __restrict__ b, double* __restrict__ y, int order)
 {
     const int blk = blockIdx.x*blockDim.x + threadIdx.x;
     if(blk >= nd.NEb) return;
@@ -3087,7 +3100,7 @@ void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
     double w[6];
     for(int i=0;i<de;i++)
     {
-        double v = b[nd.Nie + e0 + i];
+        double v = b[fs_index_E(nd, order, e0 + i)];
         for(int k=0;k<i;k++) v -= L[i*6+k]*w[k];
         w[i] = v / L[i*6+i];
         y[e0+i] = w[i];
@@ -3096,20 +3109,21 @@ void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
 // r[c] = b_S[c] - sum_e Wt[e][c] y[e], one thread per S column
 __global__ __launch_bounds__(256)
 void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ y,
-                          const double* __restrict__ b, double* __restrict__ r)
+                          const double* __restrict__ b, double* __restrict__ r, int order)
 {
     const int c = blockIdx.x*blockDim.x + threadIdx.x;
     if(c >= nd.Nc) return;
-    double acc = b[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
+    double acc = b[fs_index_S(nd, order, c)];
     for(int e = 0; e < nd.NE; e++) acc -= Wt[(size_t)e*nd.Nc + c]*y[e];
     r[c] = acc;
 }
-// r <- (L L^T)^-1 r with L the lower triangle of S (row-major n x n), one workgroup
+// r <- L^-1 r (parts & 1), then r <- L^-T r (parts & 2), L the lower triangle of S (row-major n x n), one workgroup
 __global__ __launch_bounds__(1024)
-void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict__ r)
+void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
 {
     const int t = threadIdx.x, nt = blockDim.x;
     __shared__ double piv;
+    if(parts & 1)
     for(int j=0;j<n;j++)
     {
         if(t == 0) { piv = r[j]/S[(size_t)j*n + j]; r[j] = piv; }
@@ -3118,6 +3132,7 @@ void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict
         for(int i=j+1+t;i<n;i+=nt) r[i] -= S[(size_t)i*n + j]*pj;
         __syncthreads();
     }
+    if(parts & 2)
     for(int j=n-1;j>=0;j--)
     {
         if(t == 0) { piv = r[j]/S[(size_t)j*n + j]; r[j] = piv; }
@@ -3131,13 +3146,12 @@ void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict
 __global__ __launch_bounds__(64)
 void fsolve_backsub_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ LD,
                            const double* __restrict__ y, const double* __restrict__ xs,
-                           double* __restrict__ x)
+                           double* __restrict__ x, int order)
 {
     const int t = threadIdx.x;
     if((int)blockIdx.x == nd.NEb)
     {
-        for(int i=t;i<nd.Nc;i+=blockDim.x)
-            x[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = xs[i];
+        for(int i=t;i<nd.Nc;i+=blockDim.x) x[fs_index_S(nd, order, i)] = xs[i];
         return;
     }
     const int blk = blockIdx.x;
@@ -3168,7 +3182,7 @@ void fsolve_backsub_kernel(NormalDims nd, const double* __restrict__ Wt, const d
             for(int k=i+1;k<de;k++) s -= L[k*6+i]*v[k];
             v[i] = s/L[i*6+i];
         }
-        for(int i=0;i<de;i++) x[nd.Nie + e0 + i] = v[i];
+        for(int i=0;i<de;i++) x[fs_index_E(nd, order, e0 + i)] = v[i];
     }
 }
 // min and max over the diagonal of the whole factor: out[0] = min, out[1] = max
@@ -3199,14 +3213,133 @@ void fsolve_diag_minmax_kernel(NormalDims nd, const double* __restrict__ S, cons
     }
 }
 
+// y = b_E, r = b_S  /  x = [y ; r]
+__global__ __launch_bounds__(256)
+void fsolve_split_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ y, double* __restrict__ r, int order)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i < nd.NE) y[i] = b[fs_index_E(nd, order, i)];
+    else if(i < nd.NE + nd.Nc) r[i - nd.NE] = b[fs_index_S(nd, order, i - nd.NE)];
+}
+__global__ __launch_bounds__(256)
+void fsolve_join_kernel(NormalDims nd, const double* __restrict__ y, const double* __restrict__ r, double* __restrict__ x, int order)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if(i < nd.NE) x[fs_index_E(nd, order, i)] = y[i];
+    else if(i < nd.NE + nd.Nc) x[fs_index_S(nd, order, i - nd.NE)] = r[i - nd.NE];
+}
+// to_factor: x (factor order) = P b (state order); else x (state order) = P^T b (factor order)
+__global__ __launch_bounds__(256)
+void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ x, int to_factor)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;      // index in factor order
+    if(i >= nd.NE + nd.Nc) return;
+    const int is = (i < nd.NE) ? fs_index_E(nd, 0, i) : fs_index_S(nd, 0, i - nd.NE);
+    if(to_factor) x[i] = b[is]; else x[is] = b[i];
+}
+
+// ---- the consumers of J that mrcal's projection uncertainty uses (mrcal-genpywrap.py:477-731), on the
+// device-resident CSR J of a factorization
+// y = Jt x: one thread per row, atomics into y (zeroed by the caller)
+__global__ __launch_bounds__(256)
+void csr_Jt_x_kernel(int Nrows, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, const double* __restrict__ Jx,
+                     const double* __restrict__ x, double* __restrict__ y)
+{
+    const int r = blockIdx.x*blockDim.x + threadIdx.x;
+    if(r >= Nrows) return;
+    const double xr = x[r];
+    if(xr == 0.0) return;
+    for(int32_t p = Jp[r]; p < Jp[r+1]; p++) atomicAdd(&y[Ji[p]], Jx[p]*xr);
+}
+// out (NX x NX) += sum over the leading rows of outer(A j, A j), A (NX x Nstate) row-major
+template<int NX>
+__global__ __launch_bounds__(256)
+void csr_A_Jt_J_At_kernel(int Nrows, int Nstate, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                          const double* __restrict__ Jx, const double* __restrict__ A, double* __restrict__ out)
+{
+    const int r = blockIdx.x*blockDim.x + threadIdx.x;
+    double jta[NX];
+#pragma unroll
+    for(int i=0;i<NX;i++) jta[i] = 0.0;
+    if(r < Nrows)
+        for(int32_t p = Jp[r]; p < Jp[r+1]; p++)
+        {
+            const int32_t c = Ji[p];
+            const double  v = Jx[p];
+#pragma unroll
+            for(int i=0;i<NX;i++) jta[i] += A[(size_t)i*Nstate + c]*v;
+        }
+    __shared__ double part[4][NX*NX];
+#pragma unroll
+    for(int i=0;i<NX;i++)
+#pragma unroll
+        for(int j=0;j<NX;j++)
+        {
+            double v = jta[i]*jta[j];
+            for(int off=32; off>0; off>>=1) v += __shfl_down(v, off);
+            if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][i*NX + j] = v;
+        }
+    __syncthreads();
+    if(threadIdx.x < NX*NX)
+        atomicAdd(&out[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream)
+{
+    if(Nrows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(csr_Jt_x_kernel, dim3((Nrows + 255)/256), dim3(256), 0, stream, Nrows, Jp, Ji, Jx, x, y);
+    return hipGetLastError();
+}
+hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                                const double* A, double* out, hipStream_t stream)
+{
+    if(Nrows <= 0) return hipSuccess;
+    const dim3 g((Nrows + 255)/256), b(256);
+    switch(NX)
+    {
+#define CASE(n) case n: hipLaunchKernelGGL(csr_A_Jt_J_At_kernel<n>, g, b, 0, stream, Nrows, Nstate, Jp, Ji, Jx, A, out); break;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
                          const double* b, double* x, hipStream_t stream)
 {
-    if(nd.NEb > 0)
-        hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64), dim3(64), 0, stream, nd, F.LD, b, F.y);
-    hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Wt, F.y, b, F.r);
-    hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r);
-    hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1), dim3(64), 0, stream, nd, F.Wt, F.LD, F.y, F.r, x);
+    return launch_fsolve_sys(nd, F, FSOLVE_A, b, x, stream);
+}
+// The systems of cholmod_solve2() (same codes) against the kept factorization:
+// A x = b in state order; the others in factor order [E | S]: L x = b, L^T x = b,
+// L L^T x = b (D is the identity: this is an LL^T factorization, so LD == L,
+// DLt == Lt, and D copies); P, Pt permute between state and factor order
+hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int sys,
+                             const double* b, double* x, hipStream_t stream)
+{
+    const int n = nd.Nstate;
+    if(sys == FSOLVE_D) return hipMemcpyAsync(x, b, (size_t)n*sizeof(double), hipMemcpyDeviceToDevice, stream);
+    if(sys == FSOLVE_P || sys == FSOLVE_Pt)
+    {
+        hipLaunchKernelGGL(fsolve_permute_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, x, sys == FSOLVE_P ? 1 : 0);
+        return hipGetLastError();
+    }
+    const int  order   = (sys == FSOLVE_A) ? 0 : 1;
+    const bool forward = (sys == FSOLVE_A || sys == FSOLVE_LDLt || sys == FSOLVE_L  || sys == FSOLVE_LD);
+    const bool backwrd = (sys == FSOLVE_A || sys == FSOLVE_LDLt || sys == FSOLVE_Lt || sys == FSOLVE_DLt);
+    if(forward)
+    {
+        if(nd.NEb > 0)
+            hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64), dim3(64), 0, stream, nd, F.LD, b, F.y, order);
+        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Wt, F.y, b, F.r, order);
+    }
+    else
+        // y = b_E, r = b_S as they are
+        hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, F.y, F.r, order);
+    hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+    if(backwrd)
+        hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1), dim3(64), 0, stream, nd, F.Wt, F.LD, F.y, F.r, x, order);
+    else
+        hipLaunchKernelGGL(fsolve_join_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, F.y, F.r, x, order);
     return hipGetLastError();
 }
 hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream)

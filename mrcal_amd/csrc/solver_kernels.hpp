@@ -227,6 +227,14 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
 // launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order
 hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
                          const double* b, double* x, hipStream_t stream);
+// the systems of cholmod_solve2(), same codes (solver_kernels.hip explains the factor and its order)
+enum { FSOLVE_A = 0, FSOLVE_LDLt, FSOLVE_LD, FSOLVE_DLt, FSOLVE_L, FSOLVE_Lt, FSOLVE_D, FSOLVE_P, FSOLVE_Pt };
+hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int sys,
+                             const double* b, double* x, hipStream_t stream);
+// y += Jt x ; out (NX x NX) += A Jt J At over the leading rows (mrcal-genpywrap.py:477-731), CSR J on the device
+hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream);
+hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,
+                                const double* A, double* out, hipStream_t stream);
 // out2[0] = min, out2[1] = max of the factor's diagonal; preset to (+big, 0)
 hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream);
 // the normal equations of a bare CSR matrix into the blocks of R's operating point

@@ -34,10 +34,12 @@ def test_reference_known_answer(amd):
     assert relative_error(F.solve_xt_JtJ_bt(bt[0]), xt_ref[0]).max() < 1e-6
     bt3 = np.ascontiguousarray(np.stack((bt, 2*bt)))
     assert relative_error(F.solve_xt_JtJ_bt(bt3), np.stack((xt_ref, 2*xt_ref))).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        F.solve_xt_JtJ_bt(bt, sys="P")
+    with pytest.raises(RuntimeError, match="Unknown sys"):
+        F.solve_xt_JtJ_bt(bt, sys="Q")
     with pytest.raises(RuntimeError):
         F.solve_xt_JtJ_bt(bt.astype(np.float32))
+    # degenerate input: returned as it is (mrcal-pywrap.c:524-530)
+    assert F.solve_xt_JtJ_bt(np.zeros((0,3))).shape == (0,3)
 
 
 def test_singular_is_an_error_and_None_from_callback(amd):
@@ -133,3 +135,87 @@ def test_project_splined_matches_reference(amd, ref_api):
     assert relative_error(q, qr).max() < 1e-6
     assert relative_error(g, gr).max() < 1e-6
     assert relative_error(gi, gir).max() < 1e-6
+
+
+def _factor_dense(F, N):
+    """L (dense, lower) and the permutation matrix P out of the sys= interface:
+    column i of L^-1 is solve(e_i, 'L'); P from solve(I, 'P')"""
+    I  = np.eye(N)
+    Pm = F.solve_xt_JtJ_bt(I, sys="P").T           # rows of the result are P e_i: columns of P
+    Linv = F.solve_xt_JtJ_bt(I, sys="L").T
+    return np.linalg.inv(Linv), Pm
+
+
+@pytest.mark.parametrize("lensmodel,Ncam,Nf,with_points", (("LENSMODEL_OPENCV4", 2, 5, False),
+                                                            ("LENSMODEL_OPENCV8", 3, 10, True)))
+def test_sys_variants(amd, ref_api, lensmodel, Ncam, Nf, with_points):
+    """the sys= surface of CHOLMOD_factorization.solve_xt_JtJ_bt
+    (mrcal-pywrap.c:467-493) on the factorization optimizer_callback() returns:
+    L L^T == P JtJ P^T densely, every system against dense numpy, and the
+    sequence mrcal's projection uncertainty runs (model_analysis.py:837-843)"""
+    from test_callback_parity import _with_points
+    rng = np.random.RandomState(3)
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
+                                     object_width_n=7, object_height_n=6, seed=8)
+    if with_points: oi = _with_points(oi, rng)
+    _, x, J, F = amd.optimizer_callback(**oi)
+    assert F is not None
+    N = J.shape[1]
+    JtJ = (J.T @ J).toarray()
+    L, Pm = _factor_dense(F, N)
+    assert np.allclose(np.triu(L, 1), 0, atol=1e-9*np.abs(L).max())                 # lower triangular
+    assert np.array_equal(np.sort(Pm @ np.arange(N)), np.arange(N))                # a permutation
+    assert np.abs(L @ L.T - Pm @ JtJ @ Pm.T).max() < 1e-9*np.abs(JtJ).max()
+    B = rng.normal(size=(3, N))
+    # every system through its residual (JtJ of a problem with a few discrete points is
+    # badly conditioned: the solutions of two correct solvers differ, their residuals do not)
+    ops = {"A": JtJ, "L": L, "LD": L, "Lt": L.T, "DLt": L.T, "LDLt": L @ L.T, "D": np.eye(N), "P": Pm.T, "Pt": Pm}
+    for sys, M in ops.items():
+        got = F.solve_xt_JtJ_bt(B, sys=sys)
+        res = (M @ got.T).T - B
+        assert np.abs(res).max() <= 1e-9*np.abs(M).max()*np.abs(got).max()/max(1.0, np.abs(B).max()) + 1e-9, sys
+        assert np.abs(F.solve_xt_JtJ_bt(B, sys="CHOLMOD_" + sys) - got).max() == 0
+    # the projection-uncertainty sequence
+    A1 = F.solve_xt_JtJ_bt(B,  sys="P")
+    A2 = F.solve_xt_JtJ_bt(A1, sys="L")
+    A3 = F.solve_xt_JtJ_bt(A2, sys="D")
+    Var = A2 @ A3.T
+    Var_ref = B @ F.solve_xt_JtJ_bt(B).T
+    assert np.abs(Var - Var_ref).max() < 1e-9*np.abs(Var_ref).max()
+
+
+def test_Jt_x_and_A_Jt_J_At(amd):
+    """mrcal._mrcal_npsp._Jt_x / _A_Jt_J_At / _A_Jt_J_At__2 (mrcal-genpywrap.py:477-731):
+    from the p, i, x arrays like the reference's, and on the J resident with a factorization"""
+    rng = np.random.RandomState(4)
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6, lensmodel="LENSMODEL_OPENCV4",
+                                     object_width_n=5, object_height_n=4, seed=9)
+    _, x, J, F = amd.optimizer_callback(**oi)
+    Nmeas, Nstate = J.shape
+    out = np.zeros((Nstate,))
+    amd._Jt_x(J.indptr, J.indices, J.data, x, out=out)
+    ref = J.T @ x
+    assert np.abs(out - ref).max() < 1e-12*np.abs(ref).max()
+    assert np.abs(F._Jt_x(x) - ref).max() < 1e-12*np.abs(ref).max()
+    with pytest.raises(RuntimeError, match="must match the number of rows"):
+        amd._Jt_x(J.indptr, J.indices, J.data, x[:-1], out=out)
+    Nlead = amd.num_measurements_boards(**oi)
+    Jl = J[:Nlead].toarray()
+    for Nx in (2, 3):
+        A = rng.normal(size=(Nx, Nstate))
+        ref = A @ Jl.T @ Jl @ A.T
+        got = amd._A_Jt_J_At(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead)
+        assert np.abs(got - ref).max() < 1e-12*np.abs(ref).max()
+        assert np.abs(F._A_Jt_J_At(A, Nleading_rows_J=Nlead) - ref).max() < 1e-12*np.abs(ref).max()
+    A = rng.normal(size=(2, Nstate))
+    assert np.array_equal(amd._A_Jt_J_At__2(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead),
+                          amd._A_Jt_J_At(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead))
+    with pytest.raises(RuntimeError, match="Nleading_rows_J must be passed"):
+        amd._A_Jt_J_At(A, J.indptr, J.indices, J.data)
+    # what mrcal's projection uncertainty does with them (model_analysis.py:755-766): regularization present
+    dF = rng.normal(size=(2, Nstate))
+    Ax = F.solve_xt_JtJ_bt(dF)
+    Var = amd._A_Jt_J_At__2(Ax, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead)
+    JtJ = (J.T @ J).toarray()
+    Ad = np.linalg.solve(JtJ, dF.T).T
+    assert np.abs(Var - Ad @ Jl.T @ Jl @ Ad.T).max() < 1e-7*np.abs(Var).max()
