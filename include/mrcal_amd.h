@@ -199,6 +199,17 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
    mrcal_observation_point_triangulated_t carries (mrcal-pywrap.c:1388-1395) */
 bool mrcal_unproject(mrcal_point3_t* out, const mrcal_point2_t* q, int N,
                      const mrcal_lensmodel_t* lensmodel, const double* intrinsics);
+/* The batch form ON THE GPU, with the gradients that mrcal.unproject(get_gradients=True)
+   reports (mrcal/projections.py:112-395, which derives them from project()'s at the
+   solution): dv_dq (N,3,2), dv_dintrinsics (N,3,Nintrinsics), either may be NULL
+   (dv_dintrinsics needs dv_dq). Without gradients v is what mrcal_unproject() gives;
+   with them it is, like the reference's, the stereographic representative of the
+   same direction for the models inverted iteratively. normalize: unit vectors, and
+   the gradients of the unit vectors */
+bool mrcal_amd_unproject(mrcal_point3_t* v, double* dv_dq, double* dv_dintrinsics,
+                         const mrcal_point2_t* q, int N,
+                         const mrcal_lensmodel_t* lensmodel, const double* intrinsics, bool normalize);
+
 
 /* Stand-alone projection of N camera-frame points (reference: mrcal.h:165-174,
    mrcal.c:2867-3069). Host pointers. dq_dp (N,2,3) and dq_dintrinsics

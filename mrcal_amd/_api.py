@@ -484,59 +484,120 @@ class Api:
             # (mrcal-pywrap.c:1981-1988)
             return None
 
-    def project(self, v, lensmodel, intrinsics_data, get_gradients=False):
-        """q = project(v): N camera-frame points (...,3) through a lens model
-        (mrcal.project(), mrcal-genpywrap.py:134-470, here without the
-        broadcasting over models). With get_gradients: (q, dq_dv (...,2,3),
-        dq_dintrinsics (...,2,Nintrinsics))"""
+    @staticmethod
+    def _broadcast_models(pts, npt, intr, Ni, what):
+        """mrcal.project()/unproject() broadcast over the points AND over the
+        intrinsics (numpysane prototypes (3,),(Nintrinsics,) / (2,),(Nintrinsics,)):
+        -> points (B,npt), intrinsics (B,Ni) flattened to the common leading
+        shape, and that shape"""
+        pts  = np.asarray(pts,  dtype=np.float64)
+        intr = np.asarray(intr, dtype=np.float64)
+        if pts.shape[-1] != npt:
+            raise RuntimeError(f"{what} must have shape (...,{npt})")
+        if intr.ndim < 1 or intr.shape[-1] != Ni:
+            raise RuntimeError(f"intrinsics_data must have shape (...,{Ni})")
+        lead = np.broadcast_shapes(pts.shape[:-1], intr.shape[:-1])
+        pts_b  = np.ascontiguousarray(np.broadcast_to(pts,  lead + (npt,))).reshape(-1, npt)
+        if intr.ndim == 1:
+            return pts_b, intr.reshape(1, Ni), None, lead
+        intr_b = np.ascontiguousarray(np.broadcast_to(intr, lead + (Ni,))).reshape(-1, Ni)
+        # the distinct models, and which points go through each
+        uniq, inverse = np.unique(intr_b, axis=0, return_inverse=True)
+        return pts_b, uniq, inverse.reshape(-1), lead
+
+    def project(self, v, lensmodel, intrinsics_data, get_gradients=False, out=None):
+        """q = project(v): camera-frame points (...,3) through a lens model, on
+        the GPU (mrcal.project(), mrcal/projections.py:14-110 over
+        mrcal_project(), mrcal.h:374-391). Broadcasts over v and over
+        intrinsics_data (...,Nintrinsics) like the reference. With get_gradients:
+        (q, dq_dv (...,2,3), dq_dintrinsics (...,2,Nintrinsics))"""
         m = self.lib.lensmodel(lensmodel)
-        v = np.ascontiguousarray(v, dtype=np.float64)
-        if v.shape[-1] != 3:
-            raise RuntimeError("v must have shape (...,3)")
-        intr = np.ascontiguousarray(intrinsics_data, dtype=np.float64)
         Ni = self.clib.mrcal_lensmodel_num_params(C.byref(m))
-        if intr.shape != (Ni,):
-            raise RuntimeError(f"intrinsics_data must have shape ({Ni},) for {lensmodel}")
-        N = v.size // 3
-        q = np.empty(v.shape[:-1] + (2,))
-        dq_dv = np.empty(v.shape[:-1] + (2,3)) if get_gradients else None
-        dq_di = np.empty(v.shape[:-1] + (2,Ni)) if get_gradients else None
+        vb, models, which, lead = self._broadcast_models(v, 3, intrinsics_data, Ni, "v")
+        N = vb.shape[0]
+        q     = np.empty((N,2))
+        dq_dv = np.empty((N,2,3))  if get_gradients else None
+        dq_di = np.empty((N,2,Ni)) if get_gradients else None
         f = self.clib.mrcal_project
         f.restype  = C.c_bool
         f.argtypes = [C.c_void_p]*4 + [C.c_int, C.c_void_p, C.c_void_p]
-        ok = f(_ptr(q), _ptr(dq_dv) if get_gradients else None, _ptr(dq_di) if get_gradients else None,
-               _ptr(v), N, C.byref(m), _ptr(intr))
-        if not ok:
-            raise RuntimeError("mrcal_project() failed!" + self._last_error())
-        return (q, dq_dv, dq_di) if get_gradients else q
+        for im in range(models.shape[0]):
+            sel = slice(None) if which is None else np.nonzero(which == im)[0]
+            vi = np.ascontiguousarray(vb[sel]); n = vi.shape[0]
+            if n == 0: continue
+            qi = np.empty((n,2)); gv = np.empty((n,2,3)) if get_gradients else None
+            gi = np.empty((n,2,Ni)) if get_gradients else None
+            intr = np.ascontiguousarray(models[im])
+            if not f(_ptr(qi), _ptr(gv) if get_gradients else None, _ptr(gi) if get_gradients else None,
+                     _ptr(vi), n, C.byref(m), _ptr(intr)):
+                raise RuntimeError("mrcal_project() failed!" + self._last_error())
+            q[sel] = qi
+            if get_gradients: dq_dv[sel] = gv; dq_di[sel] = gi
+        q = q.reshape(lead + (2,))
+        if not get_gradients:
+            if out is not None: out[...] = q; return out
+            return q
+        res = (q, dq_dv.reshape(lead + (2,3)), dq_di.reshape(lead + (2,Ni)))
+        if out is not None:
+            for o, r in zip(out, res): o[...] = r
+            return out
+        return res
 
-    def unproject(self, q, lensmodel, intrinsics_data, normalize=False, get_gradients=False):
+    def unproject(self, q, lensmodel, intrinsics_data, normalize=False, get_gradients=False, out=None):
         """v = unproject(q): pixel coordinates (...,2) to observation vectors
-        (...,3) in camera coordinates (mrcal.unproject(), mrcal/projections.py:112,
-        over mrcal_unproject(), mrcal.h:401-411; here without the broadcasting
-        over models). Not normalized unless asked: like the reference, the
-        parametric models return (x/z, y/z, 1)-style vectors. The gradients of
-        the reference's Python routine (obtained there by differentiating
-        project() at the solution) are not provided"""
-        if get_gradients:
-            raise NotImplementedError("unproject(get_gradients=True) is not available")
+        (...,3) in camera coordinates, on the GPU (mrcal.unproject(),
+        mrcal/projections.py:112-395, over mrcal_unproject(), mrcal.h:401-411).
+        Broadcasts over q and over intrinsics_data (...,Nintrinsics). Not
+        normalized unless asked. With get_gradients: (v, dv_dq (...,3,2),
+        dv_dintrinsics (...,3,Nintrinsics)), derived from the gradients of
+        project() at the solution as the reference does; like the reference's,
+        the length of v then differs from the no-gradients call unless
+        normalize=True"""
         m = self.lib.lensmodel(lensmodel)
-        q = np.ascontiguousarray(q, dtype=np.float64)
-        if q.shape[-1] != 2:
-            raise RuntimeError("q must have shape (...,2)")
-        intr = np.ascontiguousarray(intrinsics_data, dtype=np.float64)
         Ni = self.clib.mrcal_lensmodel_num_params(C.byref(m))
-        if intr.shape != (Ni,):
-            raise RuntimeError(f"intrinsics_data must have shape ({Ni},) for {lensmodel}")
-        v = np.empty(q.shape[:-1] + (3,))
-        f = self.clib.mrcal_unproject
+        if not self.lib.has_symbol("mrcal_amd_unproject"):
+            # a library with the reference's entry points only (the tests' checker): its mrcal_unproject()
+            if get_gradients:
+                raise RuntimeError("this library has no unproject() gradients")
+            qq = np.ascontiguousarray(q, dtype=np.float64)
+            intr = np.ascontiguousarray(intrinsics_data, dtype=np.float64)
+            vv = np.empty(qq.shape[:-1] + (3,))
+            g = self.clib.mrcal_unproject
+            g.restype  = C.c_bool
+            g.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+            if not g(_ptr(vv), _ptr(qq), qq.size // 2, C.byref(m), _ptr(intr)):
+                raise RuntimeError("mrcal_unproject() failed!" + self._last_error())
+            if normalize: vv /= np.linalg.norm(vv, axis=-1, keepdims=True)
+            return vv
+        qb, models, which, lead = self._broadcast_models(q, 2, intrinsics_data, Ni, "q")
+        N = qb.shape[0]
+        v     = np.empty((N,3))
+        dv_dq = np.empty((N,3,2))  if get_gradients else None
+        dv_di = np.empty((N,3,Ni)) if get_gradients else None
+        f = self.clib.mrcal_amd_unproject
         f.restype  = C.c_bool
-        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        if not f(_ptr(v), _ptr(q), q.size // 2, C.byref(m), _ptr(intr)):
-            raise RuntimeError("mrcal_unproject() failed!" + self._last_error())
-        if normalize:
-            v /= np.linalg.norm(v, axis=-1, keepdims=True)
-        return v
+        f.argtypes = [C.c_void_p]*4 + [C.c_int, C.c_void_p, C.c_void_p, C.c_bool]
+        for im in range(models.shape[0]):
+            sel = slice(None) if which is None else np.nonzero(which == im)[0]
+            qi = np.ascontiguousarray(qb[sel]); n = qi.shape[0]
+            if n == 0: continue
+            vi = np.empty((n,3)); gq = np.empty((n,3,2)) if get_gradients else None
+            gi = np.empty((n,3,Ni)) if get_gradients else None
+            intr = np.ascontiguousarray(models[im])
+            if not f(_ptr(vi), _ptr(gq) if get_gradients else None, _ptr(gi) if get_gradients else None,
+                     _ptr(qi), n, C.byref(m), _ptr(intr), bool(normalize)):
+                raise RuntimeError("mrcal_unproject() failed!" + self._last_error())
+            v[sel] = vi
+            if get_gradients: dv_dq[sel] = gq; dv_di[sel] = gi
+        v = v.reshape(lead + (3,))
+        if not get_gradients:
+            if out is not None: out[...] = v; return out
+            return v
+        res = (v, dv_dq.reshape(lead + (3,2)), dv_di.reshape(lead + (3,Ni)))
+        if out is not None:
+            for o, r in zip(out, res): o[...] = r
+            return out
+        return res
 
     def _last_error(self):
         if self.lib.has_symbol("mrcal_amd_last_error"):

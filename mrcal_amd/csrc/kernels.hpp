@@ -77,4 +77,12 @@ hipError_t launch_project_points(int lens_type, const LensConfig& cfg, int N, in
                                  const double* p, const double* intrinsics,
                                  double* q, double* dq_dp, double* dq_dintrinsics, hipStream_t stream);
 
+// N pixels back to observation vectors, device pointers; dv_dq (N,3,2) / dv_di (N,3,Nintrinsics) may be NULL (dv_di
+// needs dv_dq). scratch: q (2N), dq_dv (6N), dq_di (2 N Nintrinsics) for the models inverted iteratively
+hipError_t launch_unproject_points(int lens_type, const LensConfig& cfg, int N, int Nintrinsics,
+                                   const double* q, const double* intr,
+                                   double* v, double* dv_dq, double* dv_di,
+                                   double* scratch_q, double* scratch_dq_dv, double* scratch_dq_di,
+                                   bool normalize, hipStream_t stream);
+
 } // namespace mrcal_amd

@@ -13,9 +13,11 @@
 // from the pinhole unprojection; the reference runs libdogleg's dense solver on
 // this 2x2 problem, here it is a plain Newton iteration on the same residual
 // q(u) - q with the same acceptance test (|q(u)-q|^2/2 <= 1e-4, else NaN).
+#include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
 #include "layout.hpp"
+#include "kernels.hpp"
 #include "host_state.hpp"
 #include "lens_models.hpp"
 #include "../../include/mrcal_amd.h"
@@ -160,4 +162,80 @@ bool mrcal_unproject(mrcal_point3_t* out, const mrcal_point2_t* q, int N,
         }
     }
     return true;
+}
+
+
+// The batch form on the GPU, with the gradients mrcal.unproject(get_gradients=True)
+// reports (mrcal/projections.py:112-395): host buffers in and out.
+//   v (N,3); dv_dq (N,3,2) and dv_dintrinsics (N,3,Nintrinsics) may be NULL.
+// Without gradients the vectors are what mrcal_unproject() returns; with them,
+// like the reference's, the stereographic representative of the same direction
+// (the gradients are those of THAT vector); normalize: unit vectors and the
+// gradients of the unit vectors
+extern "C"
+bool mrcal_amd_unproject(mrcal_point3_t* v, double* dv_dq, double* dv_dintrinsics,
+                         const mrcal_point2_t* q, int N,
+                         const mrcal_lensmodel_t* lensmodel, const double* intrinsics, bool normalize)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0)
+    {
+        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
+        return false;
+    }
+    if(N <= 0) return true;
+    if(dv_dintrinsics != NULL && dv_dq == NULL)
+    {
+        set_error("mrcal_amd_unproject(): dv_dintrinsics needs dv_dq");
+        return false;
+    }
+    const mrcal_lensmodel_type_t t = lensmodel->type;
+    if(!lens_supported((int)t)) { set_error("mrcal_amd_unproject(): lens model %d is not supported", (int)t); return false; }
+    const int Ni = lensmodel_num_params(*lensmodel);
+    LensConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    if(t == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+    {
+        cfg.spline_order = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.order;
+        cfg.spline_Nx    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Nx;
+        cfg.spline_Ny    = lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.Ny;
+        cfg.spline_segments_per_u =
+            spline_segments_per_u(cfg.spline_order, cfg.spline_Nx,
+                                  (double)lensmodel->LENSMODEL_SPLINED_STEREOGRAPHIC__config.fov_x_deg);
+    }
+    else if(t == MRCAL_LENSMODEL_CAHVORE)
+    {
+        cfg.cahvore_linearity = lensmodel->LENSMODEL_CAHVORE__config.linearity;
+        for(int i=9;i<12;i++)
+            if(intrinsics[i] != 0.)
+            {
+                set_error("unproject() currently only works with a central projection. So I cannot unproject(CAHVORE,E!=0). Please set E=0 to centralize this model");
+                return false;
+            }
+    }
+    const bool closed = t == MRCAL_LENSMODEL_PINHOLE || t == MRCAL_LENSMODEL_STEREOGRAPHIC ||
+                        t == MRCAL_LENSMODEL_LONLAT  || t == MRCAL_LENSMODEL_LATLON;
+    const bool grads  = dv_dq != NULL;
+    double *d_q = NULL, *d_i = NULL, *d_v = NULL, *d_gq = NULL, *d_gi = NULL, *s_q = NULL, *s_gv = NULL, *s_gi = NULL;
+    bool ok = true;
+#define TRY(expr) do { if(ok && (expr) != hipSuccess) { set_error("mrcal_amd_unproject(): %s failed", #expr); ok = false; } } while(0)
+    TRY(hipMalloc((void**)&d_q, (size_t)2*N*sizeof(double)));
+    TRY(hipMalloc((void**)&d_i, (size_t)Ni*sizeof(double)));
+    TRY(hipMalloc((void**)&d_v, (size_t)3*N*sizeof(double)));
+    if(grads)                  TRY(hipMalloc((void**)&d_gq, (size_t)6*N*sizeof(double)));
+    if(dv_dintrinsics != NULL) TRY(hipMalloc((void**)&d_gi, (size_t)3*N*Ni*sizeof(double)));
+    if(grads && !closed)
+    {
+        TRY(hipMalloc((void**)&s_q,  (size_t)2*N*sizeof(double)));
+        TRY(hipMalloc((void**)&s_gv, (size_t)6*N*sizeof(double)));
+        if(dv_dintrinsics != NULL) TRY(hipMalloc((void**)&s_gi, (size_t)2*N*Ni*sizeof(double)));
+    }
+    TRY(hipMemcpy(d_q, q, (size_t)2*N*sizeof(double), hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_i, intrinsics, (size_t)Ni*sizeof(double), hipMemcpyHostToDevice));
+    TRY(launch_unproject_points((int)t, cfg, N, Ni, d_q, d_i, d_v, d_gq, d_gi, s_q, s_gv, s_gi, normalize, NULL));
+    TRY(hipMemcpy(v, d_v, (size_t)3*N*sizeof(double), hipMemcpyDeviceToHost));
+    if(grads)                  TRY(hipMemcpy(dv_dq, d_gq, (size_t)6*N*sizeof(double), hipMemcpyDeviceToHost));
+    if(dv_dintrinsics != NULL) TRY(hipMemcpy(dv_dintrinsics, d_gi, (size_t)3*N*Ni*sizeof(double), hipMemcpyDeviceToHost));
+#undef TRY
+    hipFree(d_q); hipFree(d_i); hipFree(d_v); hipFree(d_gq); hipFree(d_gi); hipFree(s_q); hipFree(s_gv); hipFree(s_gi);
+    return ok;
 }

@@ -106,21 +106,36 @@ def test_unproject_matches_reference(amd, ref_api, lensmodel, intrinsics):
     assert np.abs(out[0] - out[1]).max() < 1e-8
 
 
-@pytest.mark.parametrize("lensmodel,intrinsics", UNPROJECT_MODELS[:6], ids=[m[0] for m in UNPROJECT_MODELS[:6]])
+SPLINED_MODEL = "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120"
+
+
+def _unproject_cases():
+    cases = list(UNPROJECT_MODELS)
+    rng = np.random.RandomState(12)
+    cases.append((SPLINED_MODEL, tuple(np.r_[1100., 1100., 500., 333., rng.uniform(-0.02, 0.02, 2*11*8)])))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lensmodel,intrinsics", _unproject_cases(), ids=[m[0][:30] for m in _unproject_cases()])
 def test_python_unproject(amd_api, ref_api, lensmodel, intrinsics):
-    """mrcal_amd.unproject(): shapes, normalize, against the reference's C
-    function, and project(unproject(q)) == q through the reference's project"""
+    """mrcal_amd.unproject() (GPU): shapes, normalize, against the reference's C
+    function, project(unproject(q)) == q, and the gradients
+    (mrcal/projections.py:112-395) against central differences and against the
+    identities they are derived from"""
     rng  = np.random.RandomState(4)
     intr = np.array(intrinsics, dtype=float)
-    q    = np.array((1512., 1112.)) + rng.uniform(-400, 400, size=(5, 7, 2))
+    Ni   = len(intr)
+    q    = intr[2:4] + rng.uniform(-400, 400, size=(5, 7, 2))
     v    = amd_api.unproject(q, lensmodel, intr)
     assert v.shape == (5, 7, 3)
-    assert np.allclose(v, ref_api.unproject(q, lensmodel, intr), rtol=0, atol=1e-9)
     vn = amd_api.unproject(q, lensmodel, intr, normalize=True)
     assert np.allclose(np.linalg.norm(vn, axis=-1), 1.0)
     assert np.allclose(np.cross(vn, v), 0, atol=1e-9)
+    # the reference's mrcal_unproject(): the same direction
+    vr = ref_api.unproject(q, lensmodel, intr, normalize=True)
+    assert np.abs(vn - vr).max() < 1e-8
     # the reference's mrcal_project() brings them back to the pixels
-    from mrcal_amd._cabi import Lensmodel
     m = ref_api.lib.lensmodel(lensmodel)
     f = ref_api.clib.mrcal_project
     f.restype  = C.c_bool
@@ -129,8 +144,62 @@ def test_python_unproject(amd_api, ref_api, lensmodel, intrinsics):
     vv = np.ascontiguousarray(v.reshape(-1, 3))
     assert f(q2.ctypes.data, None, None, vv.ctypes.data, 35, C.byref(m), intr.ctypes.data)
     assert np.abs(q2 - q.reshape(-1, 2)).max() < 1e-6
-    with pytest.raises(NotImplementedError):
-        amd_api.unproject(q, lensmodel, intr, get_gradients=True)
+
+    # ---- gradients
+    for normalize in (False, True):
+        vg, dv_dq, dv_di = amd_api.unproject(q, lensmodel, intr, normalize=normalize, get_gradients=True)
+        assert vg.shape == (5,7,3) and dv_dq.shape == (5,7,3,2) and dv_di.shape == (5,7,3,Ni)
+        # the same direction as without gradients; with normalize the same vector
+        assert np.allclose(np.cross(vg, vn), 0, atol=1e-9)
+        if normalize:
+            assert np.abs(vg - vn).max() < 1e-12
+            # gradients of a unit vector are orthogonal to it
+            assert np.abs(np.einsum("...k,...kj->...j", vg, dv_dq)).max() < 1e-9*np.abs(dv_dq).max()
+        # project(v(q,i), i) == q identically:  dq/dv dv/dq = I,  dq/dv dv/di + dq/di = 0
+        _, dq_dv, dq_di = amd_api.project(vg, lensmodel, intr, get_gradients=True)
+        assert np.abs(np.einsum("...ak,...kb->...ab", dq_dv, dv_dq) - np.eye(2)).max() < 1e-8
+        # (CAHVORE's E moves the entrance pupil: dq/dE depends on the LENGTH of v, so that part of the
+        #  identity holds at the vector the gradients were taken at - the un-normalized one - only)
+        ncheck = Ni - 3 if (lensmodel.startswith("LENSMODEL_CAHVORE") and normalize) else Ni
+        assert np.abs((np.einsum("...ak,...kj->...aj", dq_dv, dv_di) + dq_di)[...,:ncheck]).max() < \
+            1e-7*max(1.0, np.abs(dq_di).max())
+        # central differences of the routine itself (normalized: the length convention does not enter)
+        if normalize:
+            dq = 1e-3
+            for b in range(2):
+                e = np.zeros(2); e[b] = dq
+                fd = (amd_api.unproject(q + e, lensmodel, intr, normalize=True) -
+                      amd_api.unproject(q - e, lensmodel, intr, normalize=True))/(2*dq)
+                assert np.abs(fd - dv_dq[...,b]).max() < 1e-6*max(1e-3, np.abs(dv_dq).max())
+            # (CAHVORE: unproject() refuses E != 0, so E cannot be perturbed)
+            jlast = Ni-4 if lensmodel.startswith("LENSMODEL_CAHVORE") else Ni-1
+            for j in list(range(min(Ni, 6))) + ([jlast] if Ni > 6 else []):
+                di = 1e-6*max(1.0, abs(intr[j]))
+                e = np.zeros(Ni); e[j] = di
+                fd = (amd_api.unproject(q, lensmodel, intr + e, normalize=True) -
+                      amd_api.unproject(q, lensmodel, intr - e, normalize=True))/(2*di)
+                assert np.abs(fd - dv_di[...,j]).max() < 1e-5*max(1e-6, np.abs(dv_di[...,j]).max()) + 1e-9, j
+
+
+@pytest.mark.gpu
+def test_project_unproject_broadcast_over_models(amd_api):
+    """mrcal.project()/unproject() broadcast over the intrinsics too (numpysane
+    prototypes ((3,),(Nintrinsics,)) / ((2,),(Nintrinsics,)))"""
+    rng = np.random.RandomState(5)
+    lensmodel, base = UNPROJECT_MODELS[4][0], np.array(UNPROJECT_MODELS[4][1])
+    intr = base + rng.uniform(-1, 1, size=(3, 1, len(base)))*np.r_[5., 5., 5., 5., 1e-3*np.ones(len(base)-4)]
+    v = rng.uniform(-0.3, 0.3, size=(4, 3)); v[:,2] = 1.0
+    q = amd_api.project(v, lensmodel, intr)
+    assert q.shape == (3, 4, 2)
+    for i in range(3):
+        assert np.array_equal(q[i], amd_api.project(v, lensmodel, intr[i,0]))
+    vb = amd_api.unproject(q, lensmodel, intr)
+    assert vb.shape == (3, 4, 3)
+    assert np.abs(vb/vb[...,2:] - v).max() < 1e-9
+    vg, dv_dq, dv_di = amd_api.unproject(q, lensmodel, intr, get_gradients=True, normalize=True)
+    assert dv_dq.shape == (3, 4, 3, 2) and dv_di.shape == (3, 4, 3, len(base))
+    g1 = amd_api.unproject(q[1], lensmodel, intr[1,0], get_gradients=True, normalize=True)
+    assert np.array_equal(vg[1], g1[0]) and np.array_equal(dv_dq[1], g1[1]) and np.array_equal(dv_di[1], g1[2])
 
 
 def test_pair_residual_matches_reference_cpu(ref_api):
