@@ -31,6 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix = FP64 vector peak (vendor figure); measured ceiling
+                               # of v_mfma_f64_4x4x4 on this chip: 26 flop/clk/SIMD = 63.9 TFLOP/s (tools/exp/launch_floor.hip)
 
 
 def parse_args():
@@ -179,6 +181,30 @@ def main():
         except Exception:
             traffic = None
 
+    # MFMA utilisation of the dense blocks (north_star): the Gram of the board kernel live (its
+    # v_mfma_f64_4x4x4 flops over the same event-timed launches), the matrix-pipe busy share of the
+    # board kernel and of the Schur SYRK from the committed PMC pass (profiles/)
+    mfma = None
+    try:
+        NM = 8                                   # accumulators of the OPENCV8 tile (7 column blocks: problem.hpp)
+        mfma_per_obs = NM*((2*10*10 + 3)//4)
+        flops = 512.0*mfma_per_obs*args.cameras*args.frames/max(world, 1)
+        mfma = dict(kernel = "board_kernel Gram, v_mfma_f64_4x4x4 (4 blocks x 4x4x4 x 2 flop = 512 flop each, "
+                             f"{mfma_per_obs} per observation)",
+                    flops_per_launch = flops,
+                    achieved = flops/1e12/(kernel_ms*1e-3) if kernel_ms > 0 else 0.0,
+                    peak = FP64_MFMA_PEAK_TFLOPS, unit = "TFLOP/s")
+        mfma["frac"] = mfma["achieved"]/FP64_MFMA_PEAK_TFLOPS
+        mpath = os.path.join(ROOT, "profiles", "r02_mfma_utilisation.json")
+        if os.path.exists(mpath):
+            mj = json.load(open(mpath))
+            if mj.get("workload_cameras") == args.cameras and mj.get("workload_frames") == args.frames:
+                mfma["pmc_matrix_pipe_busy_frac"] = {k: v["mfma_busy_frac"] for k, v in mj["ns"].items()}
+                mfma["pmc_matrix_pipe_busy_frac_config2_splined"] = {k: v["mfma_busy_frac"] for k, v in mj["config2"].items()}
+                mfma["pmc_source"] = "profiles/r02_mfma_utilisation.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"
+    except Exception:
+        mfma = None
+
     result = dict(
         metric  = "LM (dog-leg) iterations/sec, 8-cam x 1000-frame OPENCV8 calibration",
         value   = args.steps/dt,
@@ -203,7 +229,8 @@ def main():
                         traffic = traffic,
                         algorithmic_bytes_per_launch = alg_bytes,
                         kernel_ms_avg = kernel_ms, kernel_ms_min = kmin_ms, kernel_ms_max = kmax_ms,
-                        launches_timed = nlaunch),
+                        launches_timed = nlaunch,
+                        mfma = mfma),
         solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"],
                       **({"collectives": st["Ncollectives"]} if sharded else {})),
     )
