@@ -1390,7 +1390,14 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
 #ifdef CHOL_TS
             if(p == 0 && lane == 0) sts[wave][1] = clock64();
 #endif
-            if(wave == 0 && p + 1 < npanels) factor_diag(p + 1);
+            // (wave 0 shares its SIMD with three of the updating waves: the dependent chain of the
+            //  diagonal block gets the issue slots first)
+            if(wave == 0 && p + 1 < npanels)
+            {
+                __builtin_amdgcn_s_setprio(3);
+                factor_diag(p + 1);
+                __builtin_amdgcn_s_setprio(0);
+            }
 #ifdef CHOL_TS
             if(p == 0 && lane == 0) sts[wave][2] = clock64();
 #endif
