@@ -14,7 +14,7 @@ independent numerics. CPU only.
   - the reference's mrcal_optimize() through the restated solver reaches the
     stationary point scipy finds for the same cost function on the reference's
     callback (a small calibration)
-  - dogleg_testGradient prints what test/test-gradients.py parses
+  - the default parameters are libdogleg's (the ones mrcal.c:6296-6299 overrides on top of)
 """
 import ctypes as C
 import os
