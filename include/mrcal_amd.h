@@ -361,6 +361,35 @@ int _mrcal_num_j_nonzero(int Nobservations_board,
                          mrcal_problem_selections_t problem_selections,
                          const mrcal_lensmodel_t* lensmodel);
 
+/* .cameramodel files at the C level: the on-disk form of one camera (lens
+   model, intrinsics, imager size, pose), a python dict literal. Host code.
+   reference: types.h:347-376 (the struct: the intrinsics follow the header, as
+   many as mrcal_lensmodel_num_params() says), mrcal.h:858-890 (the functions),
+   cameramodel-parser.re:356-790, mrcal.c:6626-6680. Only lensmodel, intrinsics,
+   imagersize and extrinsics/rt_cam_ref are read; other keys are skipped. The
+   writer prints %.17g (the reference prints %f). */
+typedef struct
+{
+    double            rt_cam_ref[6];
+    unsigned int      imagersize[2];
+    mrcal_lensmodel_t lensmodel;
+    double            intrinsics[0];
+} mrcal_cameramodel_VOID_t;
+#define mrcal_cameramodel_t mrcal_cameramodel_VOID_t
+/* these allocate; release with mrcal_free_cameramodel(). NULL on error. len > 0:
+   the string need not be 0-terminated; len <= 0: it is */
+mrcal_cameramodel_VOID_t* mrcal_read_cameramodel_string(const char* string, const int len);
+mrcal_cameramodel_VOID_t* mrcal_read_cameramodel_file  (const char* filename);
+void                      mrcal_free_cameramodel(mrcal_cameramodel_VOID_t** cameramodel);
+/* these read into a caller's buffer with room for *Nintrinsics_max intrinsics.
+   false on failure; if the buffer was too small, *Nintrinsics_max says what is
+   needed, otherwise it comes back <= 0 */
+bool mrcal_read_cameramodel_string_into(mrcal_cameramodel_VOID_t* model, int* Nintrinsics_max,
+                                        const char* string, const int len);
+bool mrcal_read_cameramodel_file_into  (mrcal_cameramodel_VOID_t* model, int* Nintrinsics_max,
+                                        const char* filename);
+bool mrcal_write_cameramodel_file(const char* filename, const mrcal_cameramodel_VOID_t* cameramodel);
+
 /* ------------------------------------------------------------------------ */
 /* RESIDENT TIER                                                             */
 /* ------------------------------------------------------------------------ */
