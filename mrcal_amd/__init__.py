@@ -71,12 +71,14 @@ unproject                             = _api.unproject
 from ._factorization import CHOLMOD_factorization, _Jt_x, _A_Jt_J_At, _A_Jt_J_At__2
 
 # the callers either side of the path: the on-disk format of
-# a calibration, host-side pose arithmetic. As in the reference, the class
+# a calibration, host-side pose arithmetic, the seeding. As in the reference, the class
 # takes the name of its module
 from .poseutils import (identity_R, identity_r, identity_Rt, identity_rt, R_from_r, r_from_R, Rt_from_rt, rt_from_Rt,
                         invert_R, invert_Rt, invert_rt, compose_Rt, compose_rt, compose_r,
                         rotate_point_R, rotate_point_r, transform_point_Rt, transform_point_rt, close_contour)
 from .cameramodel import cameramodel, CameramodelParseException
+from .calibration import (ref_calibration_object, align_procrustes_points_Rt01, traverse_sensor_links,
+                          estimate_monocular_calobject_poses_Rt_tocam, estimate_joint_frame_poses, seed_stereographic)
 
 
 def gpu_available():

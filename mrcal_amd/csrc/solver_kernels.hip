@@ -2786,6 +2786,8 @@ static int syrk_grid_x(const NormalDims& nd)
 }
 static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_per_slice)
 {
+    // no camera variables at all (a solve for the frames alone): no Schur complement, no slices
+    if(nd.Nc == 0) { *nslices = 0; *e_per_slice = 4*SYRK_UNROLL; return; }
     int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
     if(ns < 1) ns = 1;
     int per = (nrows + ns - 1)/ns;
@@ -2797,6 +2799,7 @@ static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_p
 size_t schur_partial_doubles(const NormalDims& nd)
 {
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    if(nd.Nc == 0) return 64;
     int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
     if(ns < 1) ns = 1;
     const size_t nslots = 2*(size_t)ns;

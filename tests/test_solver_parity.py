@@ -178,6 +178,24 @@ def test_optimize_matches_checker(amd, ref_api, lensmodel, Ncam, Nf, btol):
     assert abs(np.linalg.norm(sa["x"]) - np.linalg.norm(sr["x"])) < 1e-7*np.linalg.norm(sr["x"])
 
 
+# the partial solves every calibration starts with (mrcal-calibrate-cameras:412-460: the geometry alone, then
+# geometry + core): camera blocks of 0, 6 and 4 variables
+@pytest.mark.parametrize("Ncam,sel", ((1, dict(do_optimize_intrinsics_core=False, do_optimize_intrinsics_distortions=False)),
+                                      (2, dict(do_optimize_intrinsics_core=False, do_optimize_intrinsics_distortions=False)),
+                                      (1, dict(do_optimize_intrinsics_core=True,  do_optimize_intrinsics_distortions=False)),
+                                      (2, dict(do_optimize_frames=False))))
+def test_optimize_partial_selections(amd, ref_api, Ncam, sel):
+    oi, truth = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=9, lensmodel="LENSMODEL_OPENCV4",
+                                         object_width_n=10, object_height_n=10, seed=12, make_outliers=False)
+    oi.update(sel)
+    oi.update(do_optimize_calobject_warp=False, do_apply_regularization=False, do_apply_outlier_rejection=False,
+              calobject_warp=None)
+    oa, sa, orr, sr = _solve_both(amd, ref_api, oi)
+    assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+    assert np.abs(sa["b_packed"] - sr["b_packed"]).max() < 2e-5
+    assert np.abs(sa["x"] - sr["x"]).max() < 1e-5
+
+
 def test_optimize_recovers_truth(amd):
     """noise-free observations -> the solve must land on |x| ~ 0
     (test-basic-calibration.py:366-385 asserts |x|<1e-8 for perfect data)"""
