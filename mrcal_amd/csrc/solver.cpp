@@ -191,11 +191,12 @@ bool capture_segment(mrcal_amd_problem* P, int segment, hipGraphExec_t* exec)
 // event | kernel | event | graph. Graphs are captured on first use
 bool queue_trial_step(mrcal_amd_problem* P)
 {
-    // Measured (8 cameras x 1000 frames): the ~21 launches of a step queued
-    // eagerly take 277 us, replayed as one graph 279 us, as graph|kernel|graph
-    // (when the board kernel is timed with events) 297 us. Eager is the default;
+    // Measured (8 cameras x 1000 frames, when a step was 17 launches): queued
+    // eagerly 277 us, replayed as one graph 279 us, as graph|kernel|graph (when
+    // the board kernel is timed with events) 297 us. Eager is the default;
     // MRCAL_AMD_GRAPH=1 selects the graph, which does not depend on the host
-    // keeping up with the queue
+    // keeping up with the queue. (Single GPU only: the all-reduces of the sharded
+    // step are not captured)
     static const bool use_graph = (getenv("MRCAL_AMD_GRAPH") != NULL);
     if(!use_graph || P->comm != NULL) return enqueue_trial_step(P, 0);
     if(!P->ev_pool_enabled)
