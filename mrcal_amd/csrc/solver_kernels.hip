@@ -1119,6 +1119,7 @@ __device__ __forceinline__ double row_share_f64(double v)   // lane N of each 16
     return u.d;
 }
 typedef double chol_double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double readlane_f64(double v, int lane);
 
 // The fused step (see "dog-leg control" below) puts the end of a trial - accept
 // or reject, the trust region, does the current point need its Gauss-Newton
@@ -1131,6 +1132,16 @@ struct Step2Dev
 };
 __device__ bool step2_finish(const Step2Dev& sd, int* chol_status);        // one workgroup; true: factor
 __device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite);   // one thread
+
+// LDS of the kernel: the packed triangle (n+1 rows), the inverse diagonal blocks, factor_diag's scratch
+#define CHOL_XLD 17              // row stride of an inverse diagonal block: odd, so that 16 lanes reading a column hit 16 banks
+__host__ __device__ inline int    chol_tri_doubles(int n) { return ((((n+1)*(n+2)) >> 1) + 1) & ~1; }
+__host__ __device__ inline size_t chol_lds_bytes(int n)
+{
+    const int npanels = (n + CHOL_PB - 1)/CHOL_PB;
+    return ((size_t)chol_tri_doubles(n) + (size_t)npanels*CHOL_PB*CHOL_XLD + 3*64)*sizeof(double);
+}
+static inline bool chol_fits_lds(int n) { return n <= 200 && chol_lds_bytes(n) <= 160*1024 - 4096; }
 
 template<bool FINISH>
 __global__ __launch_bounds__(1024)
@@ -1145,17 +1156,17 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     const int nt   = blockDim.x;
     const int lane = t & 63, wave = t >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // the same, known to be wave-uniform
-    const int l16  = t & 15;                  // lane within its DPP row
     const int npanels = (n + CHOL_PB - 1)/CHOL_PB;
+    const int r16 = lane & 15, kq = lane >> 4;
 
     // element (i,j), j <= i <= n, packed. Row n is the right-hand side
     auto rowptr = [&](int i) -> double* { return Mp + ((i*(i+1)) >> 1); };
+    double* __restrict__ Xs   = Mp + chol_tri_doubles(n);               // [npanels][16][CHOL_XLD]: L_pp^-T of every panel
+    double* __restrict__ cbuf = Xs + npanels*CHOL_PB*CHOL_XLD;          // [3][64]: factor_diag's column exchange + a sink
 
-    __shared__ int    notpd;
-    __shared__ double rdiag_all[16*CHOL_PB];     // 1/L[j][j], every panel's (n <= 256)
+    __shared__ int notpd;
     if(t == 0) notpd = 0;
 #ifdef CHOL_TS
-    __shared__ long long sts[16][3];
     long long cts[64]; int ncts = 0;
 #define CTS() do { if(t == 0 && ncts < 64) cts[ncts++] = clock64(); } while(0)
 #else
@@ -1163,125 +1174,139 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
 #endif
     CTS();
 
-    // the lower triangle into LDS. Wave w takes rows w, w+16, ..., 64 columns
-    // per lane pass; 12 loads in flight per thread, no divisions
-    for(int i0 = wave; i0 < n; i0 += 16*4)
+    // The lower triangle into LDS. Wave w takes rows w, w+16, ..., 64 columns per
+    // lane pass, and asks for ALL of it before it stores anything: S was written
+    // by other CUs a launch ago and every load is a trip across the chip (three
+    // batches of 12 loads were three such trips: 3.9 us of the kernel's 48)
     {
-        double v[4][3];
+        double v[13][4];
 #pragma unroll
-        for(int a = 0; a < 4; a++)
+        for(int a = 0; a < 13; a++)
 #pragma unroll
-            for(int b = 0; b < 3; b++)
-            {
-                const int i = i0 + 16*a, j = lane + 64*b;
-                v[a][b] = (i < n && j <= i) ? S[(size_t)i*n + j] : 0.0;
-            }
+            for(int b = 0; b < 4; b++)
+                if(b <= a/4)
+                {
+                    const int  i = wave_u + 16*a, j = lane + 64*b;
+                    const bool ok = (i < n && j <= i);
+                    v[a][b] = S[ok ? (size_t)i*n + j : 0];          // always a valid address: no branch around the load
+                }
 #pragma unroll
-        for(int a = 0; a < 4; a++)
+        for(int a = 0; a < 13; a++)
 #pragma unroll
-            for(int b = 0; b < 3; b++)
-            {
-                const int i = i0 + 16*a, j = lane + 64*b;
-                if(i < n && j <= i) rowptr(i)[j] = v[a][b];
-            }
-        // rows longer than 192 (n > 192): the rest, plainly
-        for(int a = 0; a < 4; a++)
-        {
-            const int i = i0 + 16*a;
-            if(i < n) for(int j = lane + 192; j <= i; j += 64) rowptr(i)[j] = S[(size_t)i*n + j];
-        }
+            for(int b = 0; b < 4; b++)
+                if(b <= a/4)
+                {
+                    const int i = wave_u + 16*a, j = lane + 64*b;
+                    if(i < n && j <= i) rowptr(i)[j] = v[a][b];
+                }
     }
     for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     __syncthreads();
 
-    // (a) diagonal block of panel p: wave 0, lanes 0..15 hold rows j0..j0+15
+    // (a) diagonal block of panel p, wave 0. Lanes 0..15 hold the rows of the
+    // block (beyond the end of the matrix: rows of the identity), lanes 16..31 the
+    // rows of an identity matrix appended below it. What the column operations of
+    // the factorization do to appended rows is to multiply them by L^-T from the
+    // right: lanes 16..31 leave with the rows of X = L_pp^-T, which turns the panel
+    // solve below into a matrix product and the backward solve of the block into
+    // a matrix-vector product. Per column j:
+    //   pivot: one v_readlane pair (the value is wave-uniform)
+    //   1/sqrt: hardware estimate (2^-24) + ONE Newton step = 4e-15 relative
+    //     (tools/exp/rsq_probe.hip): a backward error of the size the factorization's
+    //     own rounding has at this n. (Not positive: flagged; the factor is left to
+    //     turn into NaNs and is thrown away - no select in the dependent chain)
+    //   multipliers L[c][j], c > j: the next column's by readlane, at once (the next
+    //     pivot waits for nothing else); the others through LDS - each block lane
+    //     stores its entry, every lane reads the column back as broadcasts - and are
+    //     applied inside the NEXT column's pivot chain. The previous version moved
+    //     every multiplier with two DPP instructions: 50 VALU instructions per column,
+    //     issue-bound; this one has 27
     auto factor_diag = [&](int p) __attribute__((always_inline))
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
+        const bool isblk = lane < 16, isid = (lane >= 16 && lane < 32);
+        const bool mine  = isblk && r16 < jb;
+        double row[CHOL_PB];
         {
-            double row[CHOL_PB];
-            {
-                // unconditional loads (reading past the end of a packed row stays
-                // inside the buffer), then select: no branches
-                const bool mine = (lane < jb);
-                const double* __restrict__ src = rowptr(j0 + (mine ? lane : 0)) + j0;
-                double tmp[CHOL_PB];
+            // unconditional loads (reading past the end of a packed row stays
+            // inside the buffer), then select: no branches
+            const double* __restrict__ src = rowptr(j0 + (mine ? r16 : 0)) + j0;
+            double tmp[CHOL_PB];
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
+            for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) row[c] = (mine && c <= lane) ? tmp[c] : 0.0;
-            }
-            // No predication anywhere: the entries above the diagonal (row[c]
-            // of lane i < c) are simply never read for anything that matters.
-            //
-            // The pivot chain (broadcast, 1/sqrt with two Newton steps, scaling)
-            // is a string of dependent FP64 instructions; the rank-1 update of
-            // the columns to the right is independent work. Column j's update
-            // touches column j+1 first (the next pivot needs only that), the
-            // rest of it is deferred and issued in between the instructions
-            // of column j+1's pivot chain, where it fills their latency
-            double myrd = 1.0;
-            bool   bad  = false;
-            // row[c] -= L[i][j] L[c][j] for c in [C0,C1], c > j; L[c][j] = lane c's row[j]
-            auto upd = [&](auto J, auto C0, auto C1)
-            {
-                constexpr int j = decltype(J)::value, c0 = decltype(C0)::value, c1 = decltype(C1)::value;
-#define CHOL_UPD(c) if(j >= 0 && (c) > j && (c) >= c0 && (c) <= c1 && j < jb) row[(c) & 15] -= row[j & 15]*row_share_f64<(c) & 15>(row[j & 15]);
-                CHOL_UPD(1)  CHOL_UPD(2)  CHOL_UPD(3)  CHOL_UPD(4)  CHOL_UPD(5)
-                CHOL_UPD(6)  CHOL_UPD(7)  CHOL_UPD(8)  CHOL_UPD(9)  CHOL_UPD(10)
-                CHOL_UPD(11) CHOL_UPD(12) CHOL_UPD(13) CHOL_UPD(14) CHOL_UPD(15)
-#undef CHOL_UPD
-            };
+            for(int c = 0; c < CHOL_PB; c++)
+                row[c] = mine ? ((c <= r16) ? tmp[c] : 0.0) : ((lane < 32 && c == r16) ? 1.0 : 0.0);
+        }
+        bool   bad = false;
+        // Column j's multipliers reach the other lanes through LDS, and LDS answers after
+        // ~100 cycles, while a wave issues in order: a wait for them stops the pivot chain
+        // too. So they are asked for as soon as column j is scaled and applied at the END
+        // of column j+1 (a column of the chain, ~40 instructions, in between): two register
+        // sets, alternating. Only the next pivot's own multiplier goes by readlane, at once
+        double lp[2] = {0.0, 0.0};       // this lane's scaled entry of columns j-1, j-2 (by parity)
+        double Lc[2][CHOL_PB];           // those columns of the block: L[c][j-1], L[c][j-2]
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c++) Lc[0][c] = Lc[1][c] = 0.0;
+        double* __restrict__ mycb = cbuf + lane;
 #define IC(v) std::integral_constant<int,(v)>{}
-            auto column = [&](auto J)
+        auto column = [&](auto J)
+        {
+            constexpr int j = decltype(J)::value;
+            const double piv = readlane_f64(row[j], j);
+            bad = bad || !(piv > 0.0);
+            const double rd0 = __builtin_amdgcn_rsq(piv);
+            const double hp  = -0.5*piv;
+            const double sq  = rd0*rd0;
+            const double lr  = row[j]*rd0;          // beside the chain
+            const double u   = fma(hp, sq, 1.5);
+            const double l   = lr*u;                 // block lane j: piv/sqrt(piv)
+            row[j] = l;
+            if constexpr(j + 2 < CHOL_PB)
             {
-                constexpr int j = decltype(J)::value;
-                if(j >= jb) return;
-                // pending: the update from column j-1 of the columns j+1..15, in slices
-                double piv = row_share_f64<j>(row[j]);
-                upd(IC(j-1), IC(j+1), IC(j+2));
-                bad = bad || !(piv > 0.0);
-                piv = (piv > 0.0) ? piv : 1.0;
-                // 1/sqrt(piv): hardware estimate + 2 Newton steps rd <- rd (1.5 - 0.5 piv rd^2)
-                double rd = __builtin_amdgcn_rsq(piv);
-                const double hp = -0.5*piv;
-                upd(IC(j-1), IC(j+3), IC(j+4));
-                double sq = rd*rd;
-                upd(IC(j-1), IC(j+5), IC(j+6));
-                double u  = fma(hp, sq, 1.5);
-                upd(IC(j-1), IC(j+7), IC(j+8));
-                rd = rd*u;
-                upd(IC(j-1), IC(j+9), IC(j+10));
-                sq = rd*rd;
-                upd(IC(j-1), IC(j+11), IC(j+12));
-                u  = fma(hp, sq, 1.5);
-                upd(IC(j-1), IC(j+13), IC(15));
-                rd = rd*u;
-                myrd = (lane == j) ? rd : myrd;
-                row[j] *= rd;      // lane j: piv*rd = sqrt(piv)
-                upd(IC(j), IC(j+1), IC(j+1));       // the next pivot's column first
-            };
+                // (every lane stores: no exec juggling; lanes 0..15 are the block)
+                mycb[64*(j & 1)] = l;
+                const double* __restrict__ cb = cbuf + 64*(j & 1);
+#pragma unroll
+                for(int c = j + 2; c < CHOL_PB; c++) Lc[j & 1][c] = cb[c];
+                lp[j & 1] = l;
+            }
+            // the next pivot's column first
+            if constexpr(j + 1 < CHOL_PB) row[j+1] = fma(-l, readlane_f64(l, j+1), row[j+1]);
+            // what column j-1 does to the columns right of j+... (asked for a column ago): row[c] -= L[i][j-1] L[c][j-1]
+            if constexpr(j >= 1)
+            {
+#pragma unroll
+                for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-lp[(j-1) & 1], Lc[(j-1) & 1][c], row[c]);
+            }
+        };
 #define CHOL_COL(j) column(IC(j));
-            CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
-            CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
+        CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
+        CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
 #undef CHOL_COL
 #undef IC
-            if(lane < jb)
-            {
-                double* __restrict__ dst = rowptr(j0 + lane) + j0;
+        // L back into the triangle (lanes 0..15, entries up to the diagonal), X into its
+        // block (lanes 16..31); everything else into this lane's sink: one store per
+        // column for the whole wave, no divergence
+        {
+            double* __restrict__ sink = cbuf + 128 + lane;
+            double* __restrict__ dstL = rowptr(j0 + (mine ? r16 : 0)) + j0;
+            double* __restrict__ dstX = Xs + p*CHOL_PB*CHOL_XLD + r16*CHOL_XLD;
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) if(c <= lane) dst[c] = row[c];
-                rdiag_all[p*CHOL_PB + lane] = myrd;
+            for(int c = 0; c < CHOL_PB; c++)
+            {
+                double* dst = isid ? dstX + c : (mine && c <= r16) ? dstL + c : sink;
+                *dst = row[c];
             }
-            if(bad && lane == 0) notpd = 1;
         }
+        if(bad && lane == 0) notpd = 1;
     };
 
     // Look-ahead: the diagonal block of panel p+1 is final as soon as ONE tile of
     // panel p's trailing update is done. Wave 0 does that tile first and factors
-    // the block (a long dependent chain, 16 lanes) while waves 1..15 do the rest
-    // of the update: the chain is off the critical path of everything but itself
+    // the block (a long dependent chain) while waves 1..15 do the rest of the
+    // update: the chain is off the critical path of everything but itself
     // (p = -1: nothing but the factorization of the first diagonal block, so
     // that there is ONE copy of that long inlined code, not a cold one for the
     // first block and another for the rest)
@@ -1292,42 +1317,37 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         const int jb = min(CHOL_PB, n - j0);
         const int m0 = j0 + jb;
 
-        // (b) rows below (and the rhs row): L[i][j0..] <- A[i][j0..] L11^-T. 16 lanes per row
+        // (b) rows below (and the rhs row): L[i][j0..] <- A[i][j0..] X, X = L_pp^-T, on the
+        // matrix cores: a tile of 16 rows per wave, 4 x v_mfma_f64_16x16x4 (A lane = A[i=l%16][k=l/16],
+        // B lane = B[k=l/16][j=l%16], D register v of lane l = D[l/16 + 4v][l%16]). In place: a wave
+        // has read its tile before it writes it. (As a forward substitution, 16 lanes per row with
+        // a 16-step DPP chain each, this phase was 3.3k cycles of every panel's ~11k)
         if(p >= 0)
         {
-            double lrow[CHOL_PB];      // row l16 of the diagonal block
+            const double* __restrict__ X = Xs + p*CHOL_PB*CHOL_XLD;
+            const int ntile_b = (n + 1 - m0 + 15) >> 4;
+            for(int ti = wave_u; ti < ntile_b; ti += 16)
             {
-                const double* __restrict__ src = rowptr(j0 + ((l16 < jb) ? l16 : 0)) + j0;
-                double tmp[CHOL_PB];
+                const int  ia = m0 + 16*ti + r16;
+                const bool va = ia <= n;
+                const double* __restrict__ pa = rowptr(va ? ia : n) + j0;
+                chol_double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
-#pragma unroll
-                for(int c = 0; c < CHOL_PB; c++) lrow[c] = (l16 < jb && c < l16) ? tmp[c] : 0.0;
-            }
-            const double myrd = (l16 < jb) ? rdiag_all[p*CHOL_PB + l16] : 0.0;
-            // Lane c carries the SCALED entry a' = a/L[c][c], which is what the other
-            // lanes need from it and what is stored in the end; its multipliers are
-            // pre-scaled accordingly. A step of the dependent chain is then one
-            // broadcast and one FMA, not multiply + broadcast + FMA
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++) lrow[c] *= myrd;
-            // the 16 lanes of a DPP row work on the same matrix row: they leave the loop together
-            for(int i = m0 + (t >> 4); i <= n; i += (nt >> 4))
-            {
-                const bool ok = (l16 < jb);
-                double a = rowptr(i)[j0 + ((l16 < jb) ? l16 : 0)];
-                a = ok ? a*myrd : 0.0;
-                // lane c's value is final once the steps k < c are done (lrow[k] = 0 for k >= c)
-                auto step = [&](auto C)
+                for(int s4 = 0; s4 < 4; s4++)
                 {
-                    constexpr int c = decltype(C)::value;
-                    a -= row_share_f64<c>(a)*lrow[c];
-                };
-#define CHOL_STEP(c) step(std::integral_constant<int,(c)>{});
-                CHOL_STEP(0)  CHOL_STEP(1)  CHOL_STEP(2)  CHOL_STEP(3)  CHOL_STEP(4)  CHOL_STEP(5)  CHOL_STEP(6)  CHOL_STEP(7)
-                CHOL_STEP(8)  CHOL_STEP(9)  CHOL_STEP(10) CHOL_STEP(11) CHOL_STEP(12) CHOL_STEP(13) CHOL_STEP(14) CHOL_STEP(15)
-#undef CHOL_STEP
-                if(ok) rowptr(i)[j0 + l16] = a;
+                    const int  k  = 4*s4 + kq;
+                    const bool vk = k < jb;
+                    const double al = pa[vk ? k : 0];
+                    const double av = (va && vk) ? al : 0.0;
+                    const double bv = X[k*CHOL_XLD + r16];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for(int v = 0; v < 4; v++)
+                {
+                    const int ri = m0 + 16*ti + kq + 4*v;
+                    if(ri <= n && r16 < jb) rowptr(ri)[j0 + r16] = acc[v];
+                }
             }
         }
         if(p >= 0) __syncthreads();
@@ -1335,17 +1355,10 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
 
         // (c) trailing update with MFMA: C[i][c] -= sum_k L[i][k] L[c][k], k in the
         //     panel; rows m0..n (incl. the rhs row), columns m0..n-1, c <= i.
-        //     16x16 tiles (ta,tb), tb <= ta, dealt round-robin to the 16 waves.
-        //     Operand layout of v_mfma_f64_16x16x4_f64 (measured,
-        //     tools/mfma_f64_layout_probe.hip): A lane = A[i=l%16][k=l/16],
-        //     B lane = B[k=l/16][j=l%16], D register v of lane l = D[l/16 + 4v][l%16]
+        //     16x16 tiles (ta,tb), tb <= ta, dealt round-robin to the 16 waves
         {
-#ifdef CHOL_TS
-            if(p == 0 && lane == 0) sts[wave][0] = clock64();
-#endif
             const int nrows = n + 1 - m0, ncols = n - m0;
             const int ntr = (p < 0) ? 0 : (nrows + 15) >> 4, ntc = (ncols + 15) >> 4;     // p = -1: no tiles
-            const int r16 = lane & 15, kq = lane >> 4;
             // tile (0,0) = the next diagonal block: wave 0; tiles 1.. : waves 1..15
             // round-robin. Wave-uniform (scalar) bookkeeping: no wave walks
             // through the other waves' tiles
@@ -1387,9 +1400,6 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                     for(int v = 0; v < 4; v++) if(cv[v]) *cp[v] = acc[v];
                 }
             }
-#ifdef CHOL_TS
-            if(p == 0 && lane == 0) sts[wave][1] = clock64();
-#endif
             // (wave 0 shares its SIMD with three of the updating waves: the dependent chain of the
             //  diagonal block gets the issue slots first)
             if(wave == 0 && p + 1 < npanels)
@@ -1398,9 +1408,6 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
                 factor_diag(p + 1);
                 __builtin_amdgcn_s_setprio(0);
             }
-#ifdef CHOL_TS
-            if(p == 0 && lane == 0) sts[wave][2] = clock64();
-#endif
         }
         __syncthreads();
         CTS();
@@ -1410,38 +1417,26 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
 
     // row n now holds z = L^-1 r. Solve L^T d = z backwards, panel by panel.
     // The same look-ahead as in the factorization: once panel p is solved, wave 0
-    // updates the 16 entries of panel p-1 and solves that panel (a 16-step
-    // dependent chain) while waves 1..15 update everything above it
+    // updates the 16 entries of panel p-1 and solves that panel while waves 1..15
+    // update everything above it. The block's own solve is d_p = X w, X = L_pp^-T
+    // (upper triangular): a product, not a 16-step substitution
     double* __restrict__ z = rowptr(n);
     auto back_diag = [&](int p) __attribute__((always_inline))
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
-        // lane c holds z[c] and column c of the diagonal block
-        double col[CHOL_PB];
+        const double* __restrict__ X = Xs + p*CHOL_PB*CHOL_XLD + ((lane < CHOL_PB) ? lane : 0)*CHOL_XLD;
+        double xv[CHOL_PB], wv[CHOL_PB];
+#pragma unroll
+        for(int k = 0; k < CHOL_PB; k++) { xv[k] = X[k]; wv[k] = z[j0 + ((k < jb) ? k : 0)]; }
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for(int k = 0; k < CHOL_PB; k += 2)
         {
-            double tmp[CHOL_PB];
-#pragma unroll
-            for(int k = 0; k < CHOL_PB; k++) tmp[k] = rowptr(j0 + ((k < jb) ? k : 0))[j0 + ((lane <= k) ? lane : 0)];
-#pragma unroll
-            for(int k = 0; k < CHOL_PB; k++) col[k] = (lane < jb && k < jb && k > lane) ? tmp[k] : 0.0;
+            acc0 += (k   < jb && k   >= lane) ? xv[k]  *wv[k]   : 0.0;
+            acc1 += (k+1 < jb && k+1 >= lane) ? xv[k+1]*wv[k+1] : 0.0;
         }
-        const double myrd = (lane < jb) ? rdiag_all[p*CHOL_PB + lane] : 0.0;
-        // the same scaling trick as in the panel solve: lane c carries d_c-to-be
-        // = z_c/L[c][c] and pre-scaled multipliers; one broadcast + one FMA per step
-        double zc = (lane < jb) ? z[j0 + lane]*myrd : 0.0;
-#pragma unroll
-        for(int k = 0; k < CHOL_PB; k++) col[k] *= myrd;
-        auto step = [&](auto K)
-        {
-            constexpr int k = decltype(K)::value;
-            zc -= col[k]*row_share_f64<k>(zc);           // col[k] = 0 for k <= lane
-        };
-#define CHOL_STEP(k) step(std::integral_constant<int,(k)>{});
-        CHOL_STEP(15) CHOL_STEP(14) CHOL_STEP(13) CHOL_STEP(12) CHOL_STEP(11) CHOL_STEP(10) CHOL_STEP(9) CHOL_STEP(8)
-        CHOL_STEP(7)  CHOL_STEP(6)  CHOL_STEP(5)  CHOL_STEP(4)  CHOL_STEP(3)  CHOL_STEP(2)  CHOL_STEP(1) CHOL_STEP(0)
-#undef CHOL_STEP
-        if(lane < jb) z[j0 + lane] = zc;
+        if(lane < jb) z[j0 + lane] = acc0 + acc1;
     };
     // z[i] -= sum_c L[j0+c][i] d[c]
     auto back_update = [&](int i, int j0, int jb) __attribute__((always_inline))
@@ -1469,7 +1464,6 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     };
     CTS();
     if(wave == 0) back_diag(npanels-1);
-    CTS();
     __syncthreads();
     CTS();
     for(int p = npanels-1; p >= 1; p--)
@@ -1479,16 +1473,13 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         if(wave == 0)
         {
             if(lane < CHOL_PB) back_update(j0 - CHOL_PB + lane, j0, jb);     // panel p-1 is full
-            CTS();
             back_diag(p - 1);
-            CTS();
         }
         else
             for(int i = t - 64; i < j0 - CHOL_PB; i += nt - 64) back_update(i, j0, jb);
         __syncthreads();
         CTS();
     }
-    CTS();
     // r <- -d ; keep the factor for later solves (uncertainty, solve_xt_JtJ_bt)
     for(int i = t; i < n; i += nt) r[i] = -z[i];
     if(keep_factor)
@@ -1920,8 +1911,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
 }
 size_t cholesky_large_workspace_doubles(int n)
 {
-    const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
-    if(lds <= 160*1024 - 4096 && n <= 256) return 1;       // the LDS kernel serves
+    if(chol_fits_lds(n)) return 1;       // the LDS kernel serves
     return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB*LCH_NB;
 }
 
@@ -2868,11 +2858,10 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
 {
     {
         const int n = nd.Nc;
-        const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
-        if(lds <= 160*1024 - 4096 && n <= 256)
+        if(chol_fits_lds(n))
         {
             Step2Dev none; memset(&none, 0, sizeof(none));
-            hipLaunchKernelGGL(schur_cholesky_solve_kernel<false>, dim3(1), dim3(1024), lds, stream,
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel<false>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
                                n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status, none);
         }
         else if(F.Linv != NULL)
@@ -3053,9 +3042,8 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
     sd.comm1_tail = F.r + nd.Nc;
     {
         const int n = nd.Nc;
-        const size_t lds = ((size_t)(n+1)*(n+2)/2)*sizeof(double);
-        if(lds <= 160*1024 - 4096 && n <= 256)
-            hipLaunchKernelGGL(schur_cholesky_solve_kernel<true>, dim3(1), dim3(1024), lds, stream,
+        if(chol_fits_lds(n))
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel<true>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
                                n, (const int*)NULL, 0, F.S, F.r, F.status, sd);
         else
         {
