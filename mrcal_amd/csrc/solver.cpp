@@ -261,6 +261,20 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
                     nqueued, s.Nsteps_accepted, s.trustregion, s.norm2_x[s.ib], s.lambda, s.refactor, s.abort_step, st,
                     sqrt(s.step_len_sq), s.expected_improvement, s.k_cauchy, s.k_gn, s.done);
         }
+        // Sharded: every queued step carries two collectives, so every rank must queue
+        // the SAME number of steps. The control block is replicated bit for bit, but
+        // which snapshots have arrived when the host looks is a matter of timing: only
+        // the snapshot exactly LAG steps back counts, and it is waited for
+        if(P->comm != NULL)
+        {
+            if(nqueued >= LAG)
+            {
+                const int sj = (nqueued - LAG) % CTL_RING;
+                HIP_TRY(hipEventSynchronize(P->ctl_events[sj]), return false);
+                if(P->h_ctl_ring[sj].done) done = true;
+            }
+            continue;
+        }
         // look at the newest snapshot that is at least LAG steps old, or any
         // newer one that happens to be complete
         for(int back = 1; back <= CTL_RING-1 && back <= nqueued; back++)
