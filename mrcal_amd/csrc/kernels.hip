@@ -369,8 +369,13 @@ void copy_out_full(const double* __restrict__ tile, gdouble* __restrict__ out,
             const int rb = it*2*R + u*R;
             if(it >= NIT || rb >= 64) continue;
             gdouble* __restrict__ o = out + rb*K;       // wave-uniform
-            if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v[q];
-            else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v[q];
+            // (nontemporal: the 300 MB of Jacobian values are not read again by anything in the step. As
+            //  ordinary stores they went through the L2 as dirty lines and pushed the pixels and joint
+            //  records - read again by every launch - out of the caches: 82 -> 76 us for the kernel,
+            //  and the kernels after it find more of their inputs still cached. The Gram, which the
+            //  assembly reads next, stays an ordinary store: no difference either way)
+            if(rb + R - 1 < 64)      __builtin_nontemporal_store(v[q], reinterpret_cast<gdouble2*>(&o[gofs]));
+            else if(rsub < 64 - rb)  __builtin_nontemporal_store(v[q], reinterpret_cast<gdouble2*>(&o[gofs]));
         }
     }
 }
@@ -484,10 +489,10 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
         gdouble* __restrict__ o = out + rb*K;       // wave-uniform
         if(FULL)
         {
-            if(rb + R - 1 < 64)      *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
-            else if(rsub < 64 - rb)  *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+            if(rb + R - 1 < 64)      __builtin_nontemporal_store(v, reinterpret_cast<gdouble2*>(&o[gofs]));
+            else if(rsub < 64 - rb)  __builtin_nontemporal_store(v, reinterpret_cast<gdouble2*>(&o[gofs]));
         }
-        else if(rb + rsub < nrows)   *reinterpret_cast<gdouble2*>(&o[gofs]) = v;
+        else if(rb + rsub < nrows)   __builtin_nontemporal_store(v, reinterpret_cast<gdouble2*>(&o[gofs]));
     }
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
@@ -790,7 +795,7 @@ void board_kernel(DeviceProblem P,
             double2 err;
             err.x = inlier ? (q[0] - qx_obs)*w : 0.0;
             err.y = inlier ? (q[1] - qy_obs)*w : 0.0;
-            if(valid) { d2_t e2; e2.x = err.x; e2.y = err.y; *reinterpret_cast<gdouble2*>(&x[m.i_meas0 + 2*pt]) = e2; }
+            if(valid) { d2_t e2; e2.x = err.x; e2.y = err.y; __builtin_nontemporal_store(e2, reinterpret_cast<gdouble2*>(&x[m.i_meas0 + 2*pt])); }
 
             // outliers keep their columns and get all-zero values: everything
             // below is skipped for them and the rows stay 0
@@ -944,7 +949,7 @@ void board_kernel(DeviceProblem P,
                             d2_t v;
                             v.x = tile[r*KS + (isy ? co_ty0 : co_tx0)];
                             v.y = tile[r*KS + (isy ? co_ty1 : co_tx1)];
-                            *reinterpret_cast<gdouble2*>(&out[r*k + co_c0]) = v;
+                            __builtin_nontemporal_store(v, reinterpret_cast<gdouble2*>(&out[r*k + co_c0]));
                         }
                 }
                 else
@@ -958,7 +963,7 @@ void board_kernel(DeviceProblem P,
                         d2_t v;
                         v.x = tile[r0*KS + board_csr_to_tile_col(P, has_ext, c0, r0 & 1)];
                         v.y = tile[r1*KS + board_csr_to_tile_col(P, has_ext, c1, r1 & 1)];
-                        *reinterpret_cast<gdouble2*>(&out[e]) = v;
+                        __builtin_nontemporal_store(v, reinterpret_cast<gdouble2*>(&out[e]));
                     }
                 }
             }
