@@ -91,6 +91,7 @@ struct mrcal_amd_problem
     // of pinned host copies the host polls without stalling the queue
     mrcal_amd::SolverCtl*      d_ctl = NULL;
     mrcal_amd::SolverCtl*      h_ctl_ring = NULL;
+    mrcal_amd::SolverCtl*      snap_target = NULL;      // where the step being queued leaves its control-block snapshot
     std::vector<hipEvent_t>    ctl_events;
     bool                       ctl_initialized = false;
     // one trial step captured as a graph: whole [0], or split around the board

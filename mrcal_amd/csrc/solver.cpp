@@ -109,6 +109,7 @@ Step2Args step2_args(mrcal_amd_problem* P)
     a.ops = P->d_ops; a.ctl = P->d_ctl; a.F = &P->F; a.gram = P->d_gram;
     a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
     a.comm2 = (P->comm != NULL || P->sharded_external) ? P->d_comm : NULL;
+    a.snap  = P->capturing ? NULL : P->snap_target;
     return a;
 }
 
@@ -246,9 +247,17 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     const int max_trials = 100*prm.max_iterations + 1000;   // runaway guard
     while(!done && nqueued < max_trials)
     {
-        if(!queue_trial_step(P)) return false;
         const int slot = nqueued % CTL_RING;
-        HIP_TRY(hipMemcpyAsync(&P->h_ctl_ring[slot], P->d_ctl, sizeof(SolverCtl), hipMemcpyDeviceToHost, P->stream), return false);
+        // the step's last kernel leaves the snapshot in the pinned ring itself (eager queueing; a captured
+        // graph has its arguments baked in and is followed by a copy instead)
+        static const bool use_graph = (getenv("MRCAL_AMD_GRAPH") != NULL);
+        const bool by_kernel = !use_graph || P->comm != NULL;
+        P->snap_target = by_kernel ? &P->h_ctl_ring[slot] : NULL;
+        const bool queued = queue_trial_step(P);
+        P->snap_target = NULL;
+        if(!queued) return false;
+        if(!by_kernel)
+            HIP_TRY(hipMemcpyAsync(&P->h_ctl_ring[slot], P->d_ctl, sizeof(SolverCtl), hipMemcpyDeviceToHost, P->stream), return false);
         HIP_TRY(hipEventRecord(P->ctl_events[slot], P->stream), return false);
         nqueued++;
         if(debug)

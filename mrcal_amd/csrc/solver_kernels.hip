@@ -2597,10 +2597,16 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
                                    const SolverCtl* __restrict__ ctl, const SolverCtlFlags* __restrict__ fl,
                                    const double* __restrict__ Wt, const double* __restrict__ LD,
                                    const double* __restrict__ y, const double* __restrict__ ds,
-                                   double* __restrict__ dots_part, double* __restrict__ qf_part, int nbs)
+                                   double* __restrict__ dots_part, double* __restrict__ qf_part, int nbs,
+                                   SolverCtl* __restrict__ snap)
 {
     const OpDev& O = ops[ctl->ib];
     const int b = blockIdx.x;
+    // The control block is final for this step (its last writer is the launch before this one): the
+    // host's snapshot of it is written straight into pinned memory. As a hipMemcpyAsync it was a copy
+    // kernel of its own behind every step, 4-6 us on the stream
+    if(snap != NULL && b == 0 && threadIdx.x < (int)(sizeof(SolverCtl)/sizeof(int)))
+        ((int*)snap)[threadIdx.x] = ((const int*)ctl)[threadIdx.x];
     if(b > nbs)
     {
         if(!ctl->derive) return;
@@ -3054,7 +3060,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
     }
     const int nbs = (br.count() + 3)/4, nqf = quadform_blocks(nd);
     hipLaunchKernelGGL(step2_backsub_quadform_kernel, dim3(nbs + 1 + nqf), dim3(256), 0, stream,
-                       nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs);
+                       nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs, a.snap);
     if(a.comm2 != NULL)
         hipLaunchKernelGGL(step2_pack2_kernel, dim3(1), dim3(256), 0, stream,
                            a.ctl, fl, a.plan->qf_part, nqf, a.plan->dots_part, br.count(), (double*)a.comm2);

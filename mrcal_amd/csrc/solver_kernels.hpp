@@ -261,6 +261,7 @@ struct Step2Args
     const OpDev* ops; SolverCtl* ctl; const FactorBuffers* F; const double* gram;
     const int32_t* Jp; const int32_t* Ji; double* step; bool is_leader;
     const double* comm2;     // sharded: [4] g^T N g, |g_E|^2, |gn_E|^2, gn_E . g_E summed over the ranks; NULL: single GPU
+    SolverCtl* snap;         // host-visible (pinned) copy of the control block to leave behind at the end of the step; NULL: none
 };
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
