@@ -1143,6 +1143,101 @@ __host__ __device__ inline size_t chol_lds_bytes(int n)
 }
 static inline bool chol_fits_lds(int n) { return n <= 200 && chol_lds_bytes(n) <= 160*1024 - 4096; }
 
+// The 16x16 diagonal block of a Cholesky panel, one wave, in registers. Lanes 0..15
+// hold the rows of the block (lanes jb..15, beyond the end of the matrix: rows of the
+// identity), lanes 16..31 the rows of an identity matrix appended below it, which
+// leave as X = L^-T (what the column operations do to appended rows is to multiply
+// them by L^-T from the right).
+//   rowL: lane r < jb: its row of the block in LDS, 16 entries readable (the others: any readable row)
+//   X:    [16][CHOL_XLD] in LDS;  cbuf: [2][64] doubles of LDS scratch
+//   dstL(c): where lane r < 16 stores entry c of its row of L (a sink for what must not be stored)
+// Returns true if a pivot was not positive (the factor is then garbage: NaNs).
+// Per column j:
+//   pivot: one v_readlane pair (the value is wave-uniform)
+//   1/sqrt: hardware estimate (2^-24) + ONE Newton step = 4e-15 relative
+//     (tools/exp/rsq_probe.hip): a backward error of the size the factorization's
+//     own rounding has at n ~ 100. (Not positive: flagged; no select in the chain)
+//   multipliers L[c][j], c > j: the next column's by readlane, at once (the next
+//     pivot waits for nothing else); the others through LDS - each block lane
+//     stores its entry, every lane reads the column back as broadcasts. LDS answers
+//     after ~100 cycles and a wave issues in order: a wait for them would stop the
+//     pivot chain too. So they are asked for as soon as column j is scaled and
+//     applied at the END of column j+1, from two alternating register sets. (The
+//     version before moved every multiplier with two DPP instructions: 50 VALU
+//     instructions per column, issue-bound; this one has 27)
+template<class DstL>
+__device__ __forceinline__
+bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__ rowL,
+                        double* __restrict__ X, double* __restrict__ cbuf, DstL dstL)
+{
+    const int  r16  = lane & 15;
+    const bool mine = lane < 16 && r16 < jb;
+    double row[CHOL_PB];
+    {
+        // unconditional loads, then select: no branches
+        double tmp[CHOL_PB];
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c++) tmp[c] = rowL[c];
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c++)
+            row[c] = mine ? ((c <= r16) ? tmp[c] : 0.0) : ((lane < 32 && c == r16) ? 1.0 : 0.0);
+    }
+    bool   bad = false;
+    double lp[2] = {0.0, 0.0};       // this lane's scaled entry of columns j-1, j-2 (by parity)
+    double Lc[2][CHOL_PB];           // those columns of the block: L[c][j-1], L[c][j-2]
+#pragma unroll
+    for(int c = 0; c < CHOL_PB; c++) Lc[0][c] = Lc[1][c] = 0.0;
+    double* __restrict__ mycb = cbuf + lane;
+#define IC(v) std::integral_constant<int,(v)>{}
+    auto column = [&](auto J)
+    {
+        constexpr int j = decltype(J)::value;
+        const double piv = readlane_f64(row[j], j);
+        bad = bad || !(piv > 0.0);
+        const double rd0 = __builtin_amdgcn_rsq(piv);
+        const double hp  = -0.5*piv;
+        const double sq  = rd0*rd0;
+        const double lr  = row[j]*rd0;          // beside the chain
+        const double u   = fma(hp, sq, 1.5);
+        const double l   = lr*u;                 // block lane j: piv/sqrt(piv)
+        row[j] = l;
+        if constexpr(j + 2 < CHOL_PB)
+        {
+            // (every lane stores: no exec juggling; lanes 0..15 are the block)
+            mycb[64*(j & 1)] = l;
+            const double* __restrict__ cb = cbuf + 64*(j & 1);
+#pragma unroll
+            for(int c = j + 2; c < CHOL_PB; c++) Lc[j & 1][c] = cb[c];
+            lp[j & 1] = l;
+        }
+        // the next pivot's column first
+        if constexpr(j + 1 < CHOL_PB) row[j+1] = fma(-l, readlane_f64(l, j+1), row[j+1]);
+        // what column j-1 does to the columns right of j (asked for a column ago): row[c] -= L[i][j-1] L[c][j-1]
+        if constexpr(j >= 1)
+        {
+#pragma unroll
+            for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-lp[(j-1) & 1], Lc[(j-1) & 1][c], row[c]);
+        }
+    };
+#define CHOL_COL(j) column(IC(j));
+    CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
+    CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
+#undef CHOL_COL
+#undef IC
+    // L through dstL (lanes 0..15), X into its block (lanes 16..31): one store per column for the whole wave
+    {
+        const bool isid = (lane >= 16 && lane < 32);
+        double* __restrict__ dstX = X + r16*CHOL_XLD;
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c++)
+        {
+            double* dst = isid ? dstX + c : dstL(c);
+            *dst = row[c];
+        }
+    }
+    return bad;
+}
+
 template<bool FINISH>
 __global__ __launch_bounds__(1024)
 void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_factor,
@@ -1203,103 +1298,17 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     __syncthreads();
 
-    // (a) diagonal block of panel p, wave 0. Lanes 0..15 hold the rows of the
-    // block (beyond the end of the matrix: rows of the identity), lanes 16..31 the
-    // rows of an identity matrix appended below it. What the column operations of
-    // the factorization do to appended rows is to multiply them by L^-T from the
-    // right: lanes 16..31 leave with the rows of X = L_pp^-T, which turns the panel
-    // solve below into a matrix product and the backward solve of the block into
-    // a matrix-vector product. Per column j:
-    //   pivot: one v_readlane pair (the value is wave-uniform)
-    //   1/sqrt: hardware estimate (2^-24) + ONE Newton step = 4e-15 relative
-    //     (tools/exp/rsq_probe.hip): a backward error of the size the factorization's
-    //     own rounding has at this n. (Not positive: flagged; the factor is left to
-    //     turn into NaNs and is thrown away - no select in the dependent chain)
-    //   multipliers L[c][j], c > j: the next column's by readlane, at once (the next
-    //     pivot waits for nothing else); the others through LDS - each block lane
-    //     stores its entry, every lane reads the column back as broadcasts - and are
-    //     applied inside the NEXT column's pivot chain. The previous version moved
-    //     every multiplier with two DPP instructions: 50 VALU instructions per column,
-    //     issue-bound; this one has 27
+    // (a) diagonal block of panel p, wave 0: chol_factor_diag16() above. L back into the triangle
+    // (entries up to the diagonal; the rest into a per-lane sink), X = L_pp^-T into its block
     auto factor_diag = [&](int p) __attribute__((always_inline))
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
-        const bool isblk = lane < 16, isid = (lane >= 16 && lane < 32);
-        const bool mine  = isblk && r16 < jb;
-        double row[CHOL_PB];
-        {
-            // unconditional loads (reading past the end of a packed row stays
-            // inside the buffer), then select: no branches
-            const double* __restrict__ src = rowptr(j0 + (mine ? r16 : 0)) + j0;
-            double tmp[CHOL_PB];
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++) tmp[c] = src[c];
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++)
-                row[c] = mine ? ((c <= r16) ? tmp[c] : 0.0) : ((lane < 32 && c == r16) ? 1.0 : 0.0);
-        }
-        bool   bad = false;
-        // Column j's multipliers reach the other lanes through LDS, and LDS answers after
-        // ~100 cycles, while a wave issues in order: a wait for them stops the pivot chain
-        // too. So they are asked for as soon as column j is scaled and applied at the END
-        // of column j+1 (a column of the chain, ~40 instructions, in between): two register
-        // sets, alternating. Only the next pivot's own multiplier goes by readlane, at once
-        double lp[2] = {0.0, 0.0};       // this lane's scaled entry of columns j-1, j-2 (by parity)
-        double Lc[2][CHOL_PB];           // those columns of the block: L[c][j-1], L[c][j-2]
-#pragma unroll
-        for(int c = 0; c < CHOL_PB; c++) Lc[0][c] = Lc[1][c] = 0.0;
-        double* __restrict__ mycb = cbuf + lane;
-#define IC(v) std::integral_constant<int,(v)>{}
-        auto column = [&](auto J)
-        {
-            constexpr int j = decltype(J)::value;
-            const double piv = readlane_f64(row[j], j);
-            bad = bad || !(piv > 0.0);
-            const double rd0 = __builtin_amdgcn_rsq(piv);
-            const double hp  = -0.5*piv;
-            const double sq  = rd0*rd0;
-            const double lr  = row[j]*rd0;          // beside the chain
-            const double u   = fma(hp, sq, 1.5);
-            const double l   = lr*u;                 // block lane j: piv/sqrt(piv)
-            row[j] = l;
-            if constexpr(j + 2 < CHOL_PB)
-            {
-                // (every lane stores: no exec juggling; lanes 0..15 are the block)
-                mycb[64*(j & 1)] = l;
-                const double* __restrict__ cb = cbuf + 64*(j & 1);
-#pragma unroll
-                for(int c = j + 2; c < CHOL_PB; c++) Lc[j & 1][c] = cb[c];
-                lp[j & 1] = l;
-            }
-            // the next pivot's column first
-            if constexpr(j + 1 < CHOL_PB) row[j+1] = fma(-l, readlane_f64(l, j+1), row[j+1]);
-            // what column j-1 does to the columns right of j+... (asked for a column ago): row[c] -= L[i][j-1] L[c][j-1]
-            if constexpr(j >= 1)
-            {
-#pragma unroll
-                for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-lp[(j-1) & 1], Lc[(j-1) & 1][c], row[c]);
-            }
-        };
-#define CHOL_COL(j) column(IC(j));
-        CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
-        CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
-#undef CHOL_COL
-#undef IC
-        // L back into the triangle (lanes 0..15, entries up to the diagonal), X into its
-        // block (lanes 16..31); everything else into this lane's sink: one store per
-        // column for the whole wave, no divergence
-        {
-            double* __restrict__ sink = cbuf + 128 + lane;
-            double* __restrict__ dstL = rowptr(j0 + (mine ? r16 : 0)) + j0;
-            double* __restrict__ dstX = Xs + p*CHOL_PB*CHOL_XLD + r16*CHOL_XLD;
-#pragma unroll
-            for(int c = 0; c < CHOL_PB; c++)
-            {
-                double* dst = isid ? dstX + c : (mine && c <= r16) ? dstL + c : sink;
-                *dst = row[c];
-            }
-        }
+        const bool mine = lane < 16 && r16 < jb;
+        double* __restrict__ rowL = rowptr(j0 + (mine ? r16 : 0)) + j0;
+        double* __restrict__ sink = cbuf + 128 + lane;
+        const bool bad = chol_factor_diag16(lane, jb, rowL, Xs + p*CHOL_PB*CHOL_XLD, cbuf,
+                                            [&](int c) -> double* { return (mine && c <= r16) ? rowL + c : sink; });
         if(bad && lane == 0) notpd = 1;
     };
 
@@ -1598,17 +1607,19 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // One workgroup of 1024 factors the 128x64 matrix [M11; I] by columns, blocked
 // by 16: what the factorization does to rows appended below the matrix is to
 // multiply them by L^-T from the right (the way schur_cholesky_solve_kernel gets
-// L^-1 r out of its rhs row), so the identity comes out as L^-T = X^T. Per panel
-// of 16 columns:
-//   (a) wave 0 factors the 16x16 diagonal block in registers: lane i = row i,
-//       pivots and multipliers by v_readlane
-//   (b) one thread per row below: its 16 entries times L_pp^-T (forward
-//       substitution against the block, read as LDS broadcasts)
-//   (c) every thread: rank-16 update of the columns to the right
-// 3 barriers per panel, 4 panels. (Measured history of this kernel: 256 threads
-// with a barrier per column 160 us; one wave with the whole block in registers,
-// unrolled, 65 us - instruction fetch; one wave blocked by 16 with dynamic loops
-// 53 us - latency, no second wave to hide it. This: 25 us)
+// L^-1 r out of its rhs row), so the identity comes out as L^-T = X^T. The same
+// three phases per 16 columns as in schur_cholesky_solve_kernel, on a square
+// LDS array:
+//   (a) wave 0: chol_factor_diag16() - the 16x16 block in registers, and its own
+//       inverse transpose X_pp from the identity lanes
+//   (b) the rows below (to row 127): A[i][panel] <- A[i][panel] X_pp, a 16-row tile
+//       per wave on v_mfma_f64_16x16x4
+//   (c) rank-16 update of the columns to the right with the same MFMA; wave 0 takes
+//       the next diagonal tile first and factors it while the others finish
+// (Measured history of this kernel: 256 threads with a barrier per column 160 us;
+// one wave with the whole block in registers 65 us; one wave blocked by 16 53 us;
+// 1024 threads with a readlane factorization of the 16x16 block, a substitution
+// chain per row for (b) and scalar FMAs for (c): 20-39 us. This: see DESIGN.md)
 #define LCH_PB 16
 __global__ __launch_bounds__(1024)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
@@ -1616,10 +1627,14 @@ void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__
 {
     if(skip != NULL && *skip) return;
     constexpr int NB = LCH_NB, NR = 2*LCH_NB, LD = LCH_NB + 1;
+    static_assert(LCH_PB == CHOL_PB, "chol_factor_diag16() is the block factorization");
     __shared__ double A[NR*LD];                 // rows 0..63: the block; rows 64..127: the identity -> L^-T
-    __shared__ double rdiag[LCH_PB];            // 1/L[j][j] of the current panel
+    __shared__ __attribute__((aligned(16))) double Xb[CHOL_PB*CHOL_XLD];      // L_pp^-T of the current 16 columns
+    __shared__ __attribute__((aligned(16))) double cb[3*64];                  // chol_factor_diag16's exchange + a sink
     __shared__ int    notpd;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r16 = lane & 15, kq = lane >> 4;
     const int nb = min(NB, n - j0);
     if(t == 0) notpd = 0;
     // the block, padded with the identity (so that a short last panel factors too)
@@ -1631,77 +1646,62 @@ void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__
     }
     __syncthreads();
 
+    auto diag = [&](int base) __attribute__((always_inline))
+    {
+        double* __restrict__ rowL = &A[(base + r16)*LD + base];
+        double* __restrict__ sink = cb + 128 + lane;
+        // (the entries right of the diagonal are stored too, as zeros: nothing reads them)
+        const bool bad = chol_factor_diag16(lane, CHOL_PB, rowL, Xb, cb,
+                                            [&](int c) -> double* { return (lane < 16) ? rowL + c : sink; });
+        if(bad && lane == 0) notpd = 1;
+    };
+    if(wave == 0) diag(0);
+    __syncthreads();
+
 #pragma unroll 1
     for(int base = 0; base < NB; base += LCH_PB)
     {
-        // (a)
-        if(wave == 0)
+        const int m0 = base + LCH_PB;
+        // (b) rows m0 .. 127
+        for(int ti = wave_u; ti < (NR - m0)/16; ti += 16)
         {
-            const int  r   = (lane < LCH_PB) ? lane : 0;
-            double pr[LCH_PB];
+            double* __restrict__ pa = &A[(m0 + 16*ti + r16)*LD + base];
+            chol_double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for(int c = 0; c < LCH_PB; c++) pr[c] = A[(base + r)*LD + base + c];
-            bool   bad  = false;
-            double myrd = 1.0;
-            static_for<0,LCH_PB>([&](auto J)
+            for(int s4 = 0; s4 < 4; s4++)
             {
-                constexpr int j = decltype(J)::value;
-                double piv = readlane_f64(pr[j], j);
-                bad = bad || !(piv > 0.0);
-                piv = (piv > 0.0) ? piv : 1.0;
-                double rd = __builtin_amdgcn_rsq(piv);
-                rd = rd*(1.5 - 0.5*piv*rd*rd);
-                rd = rd*(1.5 - 0.5*piv*rd*rd);
-                pr[j] *= rd;
-                myrd = (lane == j) ? rd : myrd;
-                static_for<j+1,LCH_PB>([&](auto Cc)
-                {
-                    constexpr int c = decltype(Cc)::value;
-                    pr[c] -= pr[j]*readlane_f64(pr[j], c);
-                });
-            });
-            if(lane < LCH_PB)
-            {
-#pragma unroll
-                for(int c = 0; c < LCH_PB; c++) A[(base + lane)*LD + base + c] = (c <= lane) ? pr[c] : 0.0;
-                rdiag[lane] = myrd;
+                const int k = 4*s4 + kq;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k], Xb[k*CHOL_XLD + r16], acc, 0, 0, 0);
             }
-            if(bad && lane == 0) notpd = 1;
+#pragma unroll
+            for(int v = 0; v < 4; v++) A[(m0 + 16*ti + kq + 4*v)*LD + base + r16] = acc[v];
         }
         __syncthreads();
-        // (b) rows base+16 .. 127:  x_c = (a_c - sum_{k<c} x_k L[c][k]) / L[c][c]
+        // (c) tiles (ta, tb), tb <= ta, of rows m0.. x columns m0..63; (0,0) = the next diagonal block: wave 0
         {
-            const int i = base + LCH_PB + t;
-            if(i < NR)
+            const int ntr = (NR - m0)/16, ntc = (NB - m0)/16;
+            int ntiles = 0;
+            for(int ta = 0; ta < ntr; ta++) ntiles += min(ta + 1, ntc);
+            for(int tix = wave_u; tix < ntiles; tix += (wave_u == 0 ? ntiles : 15))
             {
-                double xr[LCH_PB];
+                int ta = 0, tb = tix;
+                for(;;) { const int ntb = min(ta + 1, ntc); if(tb < ntb) break; tb -= ntb; ta++; }
+                const double* __restrict__ pa = &A[(m0 + 16*ta + r16)*LD + base];
+                const double* __restrict__ pb = &A[(m0 + 16*tb + r16)*LD + base];
+                double* __restrict__ pc = &A[(m0 + 16*ta + kq)*LD + m0 + 16*tb + r16];
+                chol_double4_t acc;
 #pragma unroll
-                for(int c = 0; c < LCH_PB; c++) xr[c] = A[i*LD + base + c];
+                for(int v = 0; v < 4; v++) acc[v] = pc[4*v*LD];
 #pragma unroll
-                for(int c = 0; c < LCH_PB; c++)
+                for(int s4 = 0; s4 < 4; s4++)
                 {
-                    double a = xr[c];
-#pragma unroll
-                    for(int k = 0; k < c; k++) a -= xr[k]*A[(base + c)*LD + base + k];
-                    xr[c] = a*rdiag[c];
+                    const int k = 4*s4 + kq;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[k], pb[k], acc, 0, 0, 0);
                 }
 #pragma unroll
-                for(int c = 0; c < LCH_PB; c++) A[i*LD + base + c] = xr[c];
+                for(int v = 0; v < 4; v++) pc[4*v*LD] = acc[v];
             }
-        }
-        __syncthreads();
-        // (c) A[i][c] -= sum_k L[i][base+k] L[c][base+k]   for c in the columns to the right, i >= c
-        {
-            const int c0 = base + LCH_PB, ncol = NB - c0, nrow = NR - c0;
-            for(int e = t; e < nrow*ncol; e += 1024)
-            {
-                const int i = c0 + e / ncol, c = c0 + e % ncol;
-                if(c > i) continue;             // (above the diagonal of the block: never read)
-                double acc = 0.0;
-#pragma unroll
-                for(int k = 0; k < LCH_PB; k++) acc += A[i*LD + base + k]*A[c*LD + base + k];
-                A[i*LD + c] -= acc;
-            }
+            if(wave == 0 && m0 < NB) diag(m0);
         }
         __syncthreads();
     }
