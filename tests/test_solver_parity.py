@@ -121,7 +121,14 @@ def test_normal_equations_match_JtJ(amd, case):
 # camera blocks of 30 (one LDS-resident Cholesky), 212 (past the LDS kernel: the
 # panel-by-panel Cholesky in HBM, three full 64-column panels and a partial one)
 # and 780 variables (splined: 13 panels)
+# ... and the panel edges of the LDS kernel (panels of 16): camera blocks of exactly 16 and 32
+# variables, one past (18), one short of three panels (46), the biggest that still fits the LDS (170 of <= 178)
 @pytest.mark.parametrize("lensmodel,Ncam,Nf,W,H", (("LENSMODEL_OPENCV4", 2, 8, 8, 7),
+                                                   ("LENSMODEL_PINHOLE", 2, 8, 8, 7),
+                                                   ("LENSMODEL_OPENCV8", 2, 8, 8, 7),
+                                                   ("LENSMODEL_OPENCV12", 1, 8, 8, 7),
+                                                   ("LENSMODEL_PINHOLE", 5, 8, 8, 7),
+                                                   ("LENSMODEL_OPENCV12", 8, 6, 10, 10),
                                                    ("LENSMODEL_OPENCV8", 12, 6, 10, 10),
                                                    ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", 2, 40, 10, 10)))
 def test_gauss_newton_step_matches_dense_solve(amd, lensmodel, Ncam, Nf, W, H):
