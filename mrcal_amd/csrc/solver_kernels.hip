@@ -1089,25 +1089,22 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
 // one workgroup of 1024 (16 waves). On output r holds d and, if keep_factor,
 // the lower triangle of S holds L.
 //
-// Blocked, panels of 16 columns, 3 workgroup barriers per panel instead of 3
-// per column:
-//   (a) wave 0 factors the 16x16 diagonal block IN REGISTERS: lane i of a
-//       16-lane DPP row holds matrix row i; pivots and multipliers travel by
-//       DPP row_share (one VALU move per 32 bits, no LDS or SGPR round trip)
-//   (b) the rows below the panel: forward substitution with 16 lanes per
-//       matrix row (lane c holds column c; the 16 steps again by row_share):
-//       64 rows per pass instead of one row per thread with a 136-long
-//       dependent chain
-//   (c) rank-16 update of the trailing matrix with v_mfma_f64_16x16x4_f64, one
-//       16x16 tile at a time per wave: 16 LDS accesses feed 4096 FMAs, where a
-//       VALU register tile gets 16 FMAs out of 8 LDS reads (the LDS pipe was the
-//       limit of that variant: 5 us for the first panel)
+// Blocked, panels of 16 columns, 2 workgroup barriers per panel:
+//   (a) wave 0 factors the 16x16 diagonal block IN REGISTERS, one matrix row per
+//       lane, with 16 identity rows appended (lanes 16..31) that come out as
+//       X = L_pp^-T: chol_factor_diag16()
+//   (b) the rows below the panel: L21 = A21 X, a 16-row tile per wave on
+//       v_mfma_f64_16x16x4 (it was a forward substitution, 16 lanes per row with a
+//       16-step DPP chain each: 3.3k cycles per panel, now 1.2-1.8k)
+//   (c) rank-16 update of the trailing matrix with the same MFMA, one 16x16 tile
+//       at a time per wave. Wave 0 takes the next diagonal tile first and factors
+//       it while the others finish (look-ahead)
 // The right-hand side rides along as an extra matrix row n, so L z = r is
 // solved by the factorization itself; L^T d = z then goes panel by panel,
-// backwards, the 16x16 triangle again by row_share in wave 0.
+// backwards, the block's own solve being the product d_p = X w.
 //
-// Storage: packed lower triangle in LDS, (n+1)(n+2)/2 doubles: n <= 200.
-// Larger camera blocks use launch_cholesky_large() below
+// Storage: packed lower triangle in LDS, (n+1)(n+2)/2 doubles, + the X blocks:
+// n <= 178 (chol_fits_lds). Larger camera blocks use launch_cholesky_large() below
 #define CHOL_PB 16
 template<int N>
 __device__ __forceinline__ double row_share_f64(double v)   // lane N of each 16-lane row, to the row
