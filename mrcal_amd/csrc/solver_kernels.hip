@@ -934,6 +934,22 @@ void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const Solve
 // holds D[l/16 + 4 v][l%16]
 typedef double syrk_d4 __attribute__((ext_vector_type(4)));
 #define SYRK_UNROLL 16
+// Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
+// L2. In the natural order every XCD ends up reading ALL of Wt (each tile pair needs its two column
+// strips over all rows): 8 x |Wt| from the Infinity Cache into the L2s. Here the slices (row ranges
+// of Wt) are dealt to the XCDs instead: XCD k takes slices k, k+8, ... of every tile pair and reads
+// an eighth of the rows. (nslices is a multiple of 8: syrk_slicing)
+__device__ __forceinline__ void syrk_xcd_map(int nslices, int* px, int* sy)
+{
+    *px = blockIdx.x; *sy = blockIdx.y;
+    if((nslices & 7) == 0)
+    {
+        const int L = blockIdx.x + gridDim.x*blockIdx.y;
+        const int j = L >> 3;
+        *sy = (L & 7) + 8*(j / (int)gridDim.x);
+        *px = j % (int)gridDim.x;
+    }
+}
 __global__ __launch_bounds__(64)
 void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
                             int slot0, int nslots_total,
@@ -944,10 +960,12 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
     if(skip != NULL && *skip) return;
     // tile pair p -> (bi <= bj)
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
-    int bi = 0, p = blockIdx.x;
+    int px, sy;
+    syrk_xcd_map(nslices, &px, &sy);
+    int bi = 0, p = px;
     while(p >= nb - bi) { p -= nb - bi; bi++; }
     const int bj = bi + p;
-    const int e_begin = e_lo + blockIdx.y*e_per_slice;
+    const int e_begin = e_lo + sy*e_per_slice;
     const int e_end   = min(e_hi, e_begin + e_per_slice);   // may be empty: the slot is then written as zeros
 
     const int lane = threadIdx.x;
@@ -983,8 +1001,8 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
             if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
         }
     }
-    const int slot = slot0 + blockIdx.y;
-    double* __restrict__ o = Spart + ((size_t)slot*npairs + blockIdx.x)*256;
+    const int slot = slot0 + sy;
+    double* __restrict__ o = Spart + ((size_t)slot*npairs + px)*256;
 #pragma unroll
     for(int v=0;v<4;v++) o[64*v + lane] = acc[v];
     if(diag && cc == 0)
@@ -1013,12 +1031,14 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
     if(skip != NULL && *skip) return;
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // strip -> (bi, first bj)
-    int bi = 0, sidx = blockIdx.x;
+    int px, sy;
+    syrk_xcd_map(nslices, &px, &sy);
+    int bi = 0, sidx = px;
     for(;;) { const int ng = (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP; if(sidx < ng) break; sidx -= ng; bi++; }
     const int bj0 = bi + SYRK_STRIP*sidx;
     const int ntile = min(SYRK_STRIP, nb - bj0);
     const int pair0 = bi*nb - (bi*(bi-1))/2 + (bj0 - bi);          // pair index of (bi, bj0); the strip's follow
-    const int e_begin = e_lo + blockIdx.y*e_per_slice;
+    const int e_begin = e_lo + sy*e_per_slice;
     const int e_end   = min(e_hi, e_begin + e_per_slice);
 
     const int lane = threadIdx.x;
@@ -1068,7 +1088,7 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
             if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
         }
     }
-    const int slot = slot0 + blockIdx.y;
+    const int slot = slot0 + sy;
 #pragma unroll
     for(int q = 0; q < SYRK_STRIP; q++)
     {
@@ -2767,35 +2787,45 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
 // SYRK slicing: ~SYRK_TARGET_WAVES one-wave workgroups per part, slices a
 // multiple of the unrolled k-loop. Both parts (frame blocks, point blocks) get
 // the same number of slots whether or not they are populated
+#ifndef SYRK_TARGET_WAVES
 #define SYRK_TARGET_WAVES 2048
+#endif
+#ifndef SYRK_STRIP_FROM
+#define SYRK_STRIP_FROM 256      // camera blocks wider than this: the strip kernel (one A operand for four B operands)
+#endif
 // workgroups along x of the SYRK launch: tile pairs, or strips of up to SYRK_STRIP of them (big camera blocks)
 static int syrk_grid_x(const NormalDims& nd)
 {
     const int nb = (nd.Nc + 15)/16;
-    if(nd.Nc <= 256) return nb*(nb+1)/2;
+    if(nd.Nc <= SYRK_STRIP_FROM) return nb*(nb+1)/2;
     int nstrips = 0;
     for(int bi = 0; bi < nb; bi++) nstrips += (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP;
     return nstrips;
+}
+// slices per part at most: a multiple of 8
+static int syrk_max_slices(const NormalDims& nd)
+{
+    int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
+    if(ns < 1) ns = 1;
+    return (ns + 7) & ~7;
 }
 static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_per_slice)
 {
     // no camera variables at all (a solve for the frames alone): no Schur complement, no slices
     if(nd.Nc == 0) { *nslices = 0; *e_per_slice = 4*SYRK_UNROLL; return; }
-    int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
-    if(ns < 1) ns = 1;
+    int ns = syrk_max_slices(nd);
     int per = (nrows + ns - 1)/ns;
     per = ((per + 4*SYRK_UNROLL - 1)/(4*SYRK_UNROLL))*(4*SYRK_UNROLL);
     if(per < 4*SYRK_UNROLL) per = 4*SYRK_UNROLL;
     ns = (nrows + per - 1)/per;
+    ns = (ns + 7) & ~7;         // a multiple of 8, for the slice -> XCD dealing (syrk_xcd_map); the last ones may be empty
     *nslices = ns; *e_per_slice = per;
 }
 size_t schur_partial_doubles(const NormalDims& nd)
 {
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     if(nd.Nc == 0) return 64;
-    int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
-    if(ns < 1) ns = 1;
-    const size_t nslots = 2*(size_t)ns;
+    const size_t nslots = 2*(size_t)syrk_max_slices(nd);
     return nslots*npairs*256 + nslots*nb*16 + 64;
 }
 
@@ -2819,11 +2849,11 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
         {
             const bool with_ride = (ride != NULL && !rode);
             FinalizeRide fr = with_ride ? *ride : none;
-            const int gx = (nd.Nc > 256) ? syrk_grid_x(nd) : npairs;
+            const int gx = (nd.Nc > SYRK_STRIP_FROM) ? syrk_grid_x(nd) : npairs;
             const int extra = with_ride ? (ride->plan.Ndest*FIN_LANES + gx*64 - 1)/(gx*64) : 0;
             fr.row0 = ns[part];
             rode = rode || with_ride;
-            if(nd.Nc > 256)
+            if(nd.Nc > SYRK_STRIP_FROM)
                 hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
                                    nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
             else
