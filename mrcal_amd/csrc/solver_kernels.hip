@@ -1171,9 +1171,9 @@ static inline bool chol_fits_lds(int n) { return n <= 200 && chol_lds_bytes(n) <
 // Returns true if a pivot was not positive (the factor is then garbage: NaNs).
 // Per column j:
 //   pivot: one v_readlane pair (the value is wave-uniform)
-//   1/sqrt: hardware estimate (2^-24) + ONE Newton step = 4e-15 relative
-//     (tools/exp/rsq_probe.hip): a backward error of the size the factorization's
-//     own rounding has at n ~ 100. (Not positive: flagged; no select in the chain)
+//   1/sqrt: hardware estimate (2^-24) + two Newton steps = 2.6e-16 relative
+//     (tools/exp/rsq_f64_probe.hip; one step is 4e-15 and measures no faster here).
+//     (Not positive: flagged; no select in the chain)
 //   multipliers L[c][j], c > j: the next column's by readlane, at once (the next
 //     pivot waits for nothing else); the others through LDS - each block lane
 //     stores its entry, every lane reads the column back as broadcasts. LDS answers
@@ -1216,7 +1216,9 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
         const double sq  = rd0*rd0;
         const double lr  = row[j]*rd0;          // beside the chain
         const double u   = fma(hp, sq, 1.5);
-        const double l   = lr*u;                 // block lane j: piv/sqrt(piv)
+        const double rd1 = rd0*u;
+        const double u2  = fma(hp, rd1*rd1, 1.5);
+        const double l   = (lr*u)*u2;            // block lane j: piv/sqrt(piv)
         row[j] = l;
         if constexpr(j + 2 < CHOL_PB)
         {
