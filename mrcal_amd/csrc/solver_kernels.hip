@@ -555,12 +555,89 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     }
 }
 
+// sum over the 32 lanes of this lane's half of the wave, to all of them
+__device__ __forceinline__ double half_wave_sum_f64(double v)
+{
+#pragma unroll
+    for(int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+// 64 consecutive rows per wave. The rows of a CSR Jacobian come in runs with the SAME
+// columns: of a board observation's 2 W H rows, the x rows share one column set and the y
+// rows another (fx, cx against fy, cy). Lanes 0..31 take the even rows, lanes 32..63 the
+// odd ones. In each half, the rows with the columns of the half's first pending row form a
+// group: their products are summed across the half and ONE lane adds them; then the next
+// group (the rows past an observation boundary), until no row is pending. A run of 32 rows
+// costs the atomics of one. (A bare CSR Jacobian handed to CHOLMOD_factorization(J) has no
+// Grams to assemble from: at 1.6 M rows x 24 entries one lane per row is 922 M atomics, 97 ms)
+__device__ __forceinline__
+void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int row1,
+                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    const int lane = threadIdx.x & 63, half = lane >> 5, first = half << 5;
+    const int r = r_first + 2*(lane & 31) + half;
+    const bool valid = r < row1;
+    const int p0 = valid ? Jp[r] : 0, p1 = valid ? Jp[r+1] : 0;
+    const int len = p1 - p0;
+    const double* __restrict__ Jv = O.Jv;
+    const double xr = valid ? O.x[r] : 0.0;
+    bool todo = valid;
+    while(__any(todo))
+    {
+        const unsigned long long pending = __ballot(todo);
+        const unsigned mine = (unsigned)(pending >> first);             // this half's 32 lanes
+        const bool active = mine != 0u;
+        const int  leader = first + (active ? __ffs(mine) - 1 : 0);
+        const int  lp0 = __shfl(p0, leader), llen = active ? __shfl(len, leader) : 0;
+        const int  lenmax = max(__shfl(llen, 0), __shfl(llen, 32));
+        const int32_t* __restrict__ cols = Ji + lp0;                     // the group's columns
+        bool member = todo && len == llen;
+        for(int k = 0; k < lenmax; k++)
+            if(member && k < llen) member = Ji[p0 + k] == cols[k];
+        const bool adder = active && lane == leader;
+
+        const double n2 = half_wave_sum_f64(member ? xr*xr : 0.0);
+        if(adder) atomicAdd(&O.scalars[SC_NORM2_X], n2);
+        for(int p = 0; p < lenmax; p++)
+        {
+            const bool inp = member && p < llen;
+            const double vi = inp ? Jv[p0 + p] : 0.0;
+            const double gs = half_wave_sum_f64(vi*xr);
+            const bool addp = adder && p < llen;
+            const int  ci = addp ? cols[p] : 0;
+            const int  si = state_to_SE(nd, ci);
+            if(addp) atomicAdd(&O.g[ci], gs);
+            for(int q = p; q < lenmax; q++)
+            {
+                const double v = half_wave_sum_f64((inp && q < llen) ? vi*Jv[p0 + q] : 0.0);
+                if(!addp || q >= llen) continue;
+                const int cj = cols[q];
+                const int sj = state_to_SE(nd, cj);
+                // both orientations of the pair, as the row-by-row loop over (p,q) and (q,p) adds them
+                for(int o = 0; o < ((p == q) ? 1 : 2); o++)
+                {
+                    const int s0 = o ? sj : si, s1 = o ? si : sj;
+                    if(s0 >= 0 && s1 >= 0)      atomicAdd(&O.A[(size_t)s0*nd.Nc + s1], v);
+                    else if(s0 < 0 && s1 >= 0)  atomicAdd(&O.Bt[(size_t)(-s0-1)*nd.Nc + s1], v);
+                    else if(s0 < 0 && s1 < 0)
+                    {
+                        int bi, ai, di, e0i, bj, aj, dj, e0j;
+                        E_to_block(nd, -s0-1, &bi, &ai, &di, &e0i);
+                        E_to_block(nd, -s1-1, &bj, &aj, &dj, &e0j);
+                        if(bi == bj) atomicAdd(&O.D[(size_t)bi*36 + ai*6 + aj], v);
+                    }
+                }
+            }
+        }
+        todo = todo && !member;
+    }
+}
 __global__ __launch_bounds__(64)
 void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
                          const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
     if(opref_skip(R)) return;
-    rows_generic_row(nd, opref_get(R), row0 + blockIdx.x*blockDim.x + threadIdx.x, row1, Jp, Ji);
+    rows_generic_wave(nd, opref_get(R), row0 + blockIdx.x*blockDim.x, row1, Jp, Ji);
 }
 
 // The same for problems made of such rows (structure from motion: tens of
