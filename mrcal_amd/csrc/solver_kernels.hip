@@ -357,11 +357,13 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
     {
         const int    ci = Ji[p];
         const double vi = Jv[p];
+        if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
         atomicAdd(&g[ci], vi*xr);
         const int si = state_to_SE(nd, ci);
         for(int q = p0; q < p1; q++)
         {
             const int    cj = Ji[q];
+            if((unsigned)cj >= (unsigned)nd.Nstate) continue;
             const double v  = vi*Jv[q];
             const int    sj = state_to_SE(nd, cj);
             if(si >= 0 && sj >= 0)
@@ -374,7 +376,7 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
                 E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
                 E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
                 if(bi == bj) atomicAdd(&D[(size_t)bi*36 + ai*6 + aj], v);
-                // bi != bj cannot happen: no row touches two E blocks
+                else         O.scalars[SC_BAD_STRUCTURE] = 1.0;      // no row may touch two E blocks
             }
         }
     }
@@ -603,8 +605,9 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
             const bool inp = member && p < llen;
             const double vi = inp ? Jv[p0 + p] : 0.0;
             const double gs = half_wave_sum_f64(vi*xr);
-            const bool addp = adder && p < llen;
-            const int  ci = addp ? cols[p] : 0;
+            bool addp = adder && p < llen;
+            int  ci = addp ? cols[p] : 0;
+            if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; addp = false; ci = 0; }
             const int  si = state_to_SE(nd, ci);
             if(addp) atomicAdd(&O.g[ci], gs);
             for(int q = p; q < lenmax; q++)
@@ -612,6 +615,7 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
                 const double v = half_wave_sum_f64((inp && q < llen) ? vi*Jv[p0 + q] : 0.0);
                 if(!addp || q >= llen) continue;
                 const int cj = cols[q];
+                if((unsigned)cj >= (unsigned)nd.Nstate) continue;       // (flagged when it comes up as p)
                 const int sj = state_to_SE(nd, cj);
                 // both orientations of the pair, as the row-by-row loop over (p,q) and (q,p) adds them
                 for(int o = 0; o < ((p == q) ? 1 : 2); o++)
@@ -625,6 +629,7 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
                         E_to_block(nd, -s0-1, &bi, &ai, &di, &e0i);
                         E_to_block(nd, -s1-1, &bj, &aj, &dj, &e0j);
                         if(bi == bj) atomicAdd(&O.D[(size_t)bi*36 + ai*6 + aj], v);
+                        else         O.scalars[SC_BAD_STRUCTURE] = 1.0;
                     }
                 }
             }

@@ -57,6 +57,7 @@ enum
     SC_STEP_GS,            // g . step
     SC_STEP_SS,            // |step|^2
     SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3,   // host-driven paths
+    SC_BAD_STRUCTURE,      // > 0: a row handed to the generic assembly couples two eliminated blocks, or has a column out of range
     NSCALARS = 16
 };
 

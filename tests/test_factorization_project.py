@@ -48,6 +48,30 @@ def test_singular_is_an_error_and_None_from_callback(amd):
         amd.CHOLMOD_factorization(J)
 
 
+def test_wrong_structure_is_an_error(amd):
+    """the partition that optimizer_callback() declares must be the matrix's: a row that touches two frame blocks, or a
+    column beyond the state, is reported (by the assembly kernel itself), not factored"""
+    import scipy.sparse
+    from mrcal_amd._factorization import CHOLMOD_factorization
+    rng = np.random.default_rng(0)
+    Nc, Nfb = 5, 4                                  # 5 shared variables, 4 frame blocks of 6
+    Nstate = Nc + 6*Nfb
+    rows = []
+    for f in range(Nfb):
+        for _ in range(40):
+            r = np.zeros(Nstate); r[:Nc] = rng.normal(size=Nc); r[Nc + 6*f: Nc + 6*f + 6] = rng.normal(size=6)
+            rows.append(r)
+    J = scipy.sparse.csr_matrix(np.array(rows))
+    f = CHOLMOD_factorization(J, _partition=(Nc, Nfb, 0, 0))        # fine
+    assert f.solve_xt_JtJ_bt(np.ones((1, Nstate))).shape == (1, Nstate)
+    bad = np.array(rows); bad[7, Nc + 6*2] = 1.0                     # row 7 (frame 0) now touches frame 2 as well
+    with pytest.raises(RuntimeError, match="structure"):
+        CHOLMOD_factorization(scipy.sparse.csr_matrix(bad), _partition=(Nc, Nfb, 0, 0))
+    Jb = scipy.sparse.csr_matrix(np.array(rows)); Jb.indices = Jb.indices.copy(); Jb.indices[3] = Nstate + 5
+    with pytest.raises(RuntimeError, match="structure"):
+        CHOLMOD_factorization(Jb, _partition=(Nc, Nfb, 0, 0))
+
+
 @pytest.mark.parametrize("lensmodel,Ncam,Nf,with_points", (("LENSMODEL_OPENCV4", 2, 5, False),
                                                             ("LENSMODEL_OPENCV8", 3, 6, True),
                                                             ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120", 1, 8, False)))
