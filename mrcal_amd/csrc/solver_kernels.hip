@@ -3221,15 +3221,34 @@ void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
         y[e0+i] = w[i];
     }
 }
-// r[c] = b_S[c] - sum_e Wt[e][c] y[e], one thread per S column
+// r[c] = b_S[c] - sum_e Wt[e][c] y[e]. (One thread per S column walking all of Wt: 1.36 ms at 6000 x 140.)
+// In two launches: a workgroup sums a slab of rows for 256 columns (coalesced across the columns) into
+// part[slab][c]; then one thread per column adds the slabs IN ORDER: no atomics, the same bits every time
 __global__ __launch_bounds__(256)
-void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ y,
+void fsolve_reduce_partial_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ y,
+                                  double* __restrict__ part, int rows_per_slab)
+{
+    const int c = blockIdx.x*blockDim.x + threadIdx.x;
+    const int e0 = blockIdx.y*rows_per_slab, e1 = min(nd.NE, e0 + rows_per_slab);
+    if(c >= nd.Nc) return;
+    double acc0 = 0.0, acc1 = 0.0;
+    int e = e0;
+    for(; e + 1 < e1; e += 2)
+    {
+        acc0 += Wt[(size_t)e*nd.Nc + c]*y[e];
+        acc1 += Wt[(size_t)(e+1)*nd.Nc + c]*y[e+1];
+    }
+    if(e < e1) acc0 += Wt[(size_t)e*nd.Nc + c]*y[e];
+    part[(size_t)blockIdx.y*nd.Nc + c] = acc0 + acc1;
+}
+__global__ __launch_bounds__(256)
+void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ part, int nslabs,
                           const double* __restrict__ b, double* __restrict__ r, int order)
 {
     const int c = blockIdx.x*blockDim.x + threadIdx.x;
     if(c >= nd.Nc) return;
     double acc = b[fs_index_S(nd, order, c)];
-    for(int e = 0; e < nd.NE; e++) acc -= Wt[(size_t)e*nd.Nc + c]*y[e];
+    for(int s = 0; s < nslabs; s++) acc -= part[(size_t)s*nd.Nc + c];
     r[c] = acc;
 }
 // r <- L^-1 r (parts & 1), then r <- L^-T r (parts & 2), L the lower triangle of S (row-major n x n), one workgroup
@@ -3256,6 +3275,81 @@ void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict
         for(int i=t;i<j;i+=nt) r[i] -= S[(size_t)j*n + i]*pj;
         __syncthreads();
     }
+}
+// The same with the factor in LDS (n <= 178, the sizes schur_cholesky_solve_kernel keeps there): the whole
+// workgroup loads the packed triangle, then ONE wave runs the two sweeps with r in registers (lane l holds
+// entries l, l+64, l+128) - a step is a cross-lane read of the pivot entry and one multiply-add per slot, its
+// multipliers (a column of L going forward, a row going back) requested a step ahead. The global-memory
+// version above pays two workgroup barriers and a memory round trip per column: 98 us at n = 140, this 12
+__global__ __launch_bounds__(1024)
+void fsolve_dense_lds_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
+{
+    extern __shared__ __attribute__((aligned(16))) double Lp[];      // packed lower triangle
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto rowptr = [&](int i) -> double* { return Lp + ((i*(i+1)) >> 1); };
+    for(int i = wave; i < n; i += 16)
+        for(int j = lane; j <= i; j += 64) rowptr(i)[j] = S[(size_t)i*n + j];
+    __syncthreads();
+    if(wave != 0) return;
+    // slot k of lane l = entry l + 64 k
+    double z[3], rd[3];
+#pragma unroll
+    for(int k = 0; k < 3; k++)
+    {
+        const int i = lane + 64*k;
+        z[k]  = (i < n) ? r[i] : 0.0;
+        rd[k] = (i < n) ? 1.0/rowptr(i)[i] : 0.0;
+    }
+    auto entry = [&](const double (&v)[3], int j) -> double       // entry j, to every lane
+    {
+        const int k = j >> 6;
+        const double mine = (k == 0) ? v[0] : (k == 1) ? v[1] : v[2];
+        return __shfl(mine, j & 63);
+    };
+    if(parts & 1)
+    {
+        // L w = r, right-looking: w_j = z_j / L_jj ; z_i -= L[i][j] w_j for i > j
+        double col[3];
+#pragma unroll
+        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; col[k] = (i < n && i > 0) ? rowptr(i)[0] : 0.0; }
+        for(int j = 0; j < n; j++)
+        {
+            const double wj = entry(z, j)*entry(rd, j);
+            double nxt[3];
+#pragma unroll
+            for(int k = 0; k < 3; k++) { const int i = lane + 64*k; nxt[k] = (j + 1 < n && i < n && i > j + 1) ? rowptr(i)[j+1] : 0.0; }
+#pragma unroll
+            for(int k = 0; k < 3; k++)
+            {
+                const int i = lane + 64*k;
+                z[k] = (i == j) ? wj : (i > j) ? fma(-col[k], wj, z[k]) : z[k];
+                col[k] = nxt[k];
+            }
+        }
+    }
+    if(parts & 2)
+    {
+        // L^T x = w, right-looking from the end: x_j = z_j / L_jj ; z_i -= L[j][i] x_j for i < j
+        double row[3];
+#pragma unroll
+        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; row[k] = (i < n - 1) ? rowptr(n-1)[i] : 0.0; }
+        for(int j = n - 1; j >= 0; j--)
+        {
+            const double xj = entry(z, j)*entry(rd, j);
+            double nxt[3];
+#pragma unroll
+            for(int k = 0; k < 3; k++) { const int i = lane + 64*k; nxt[k] = (j >= 1 && i < j - 1) ? rowptr(j-1)[i] : 0.0; }
+#pragma unroll
+            for(int k = 0; k < 3; k++)
+            {
+                const int i = lane + 64*k;
+                z[k] = (i == j) ? xj : (i < j) ? fma(-row[k], xj, z[k]) : z[k];
+                row[k] = nxt[k];
+            }
+        }
+    }
+#pragma unroll
+    for(int k = 0; k < 3; k++) { const int i = lane + 64*k; if(i < n) r[i] = z[k]; }
 }
 // x_e = L_e^-T (y_e - Wt_e x_S), one workgroup per E block; the extra block copies x_S
 __global__ __launch_bounds__(64)
@@ -3445,12 +3539,26 @@ hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int s
     {
         if(nd.NEb > 0)
             hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64), dim3(64), 0, stream, nd, F.LD, b, F.y, order);
-        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Wt, F.y, b, F.r, order);
+        // slabs of rows of Wt summed side by side into F.Spart (free between factorizations), then added in order
+        const size_t room = schur_partial_doubles(nd);
+        int rows_per_slab = 64;
+        int nslabs = (nd.NE + rows_per_slab - 1)/rows_per_slab;
+        const int max_slabs = (nd.Nc > 0) ? (int)std::min<size_t>(room/(size_t)nd.Nc, 4096) : 1;
+        if(nslabs > max_slabs) { nslabs = max_slabs > 0 ? max_slabs : 1; rows_per_slab = (nd.NE + nslabs - 1)/nslabs; nslabs = (nd.NE + rows_per_slab - 1)/rows_per_slab; }
+        if(nd.NE > 0 && nd.Nc > 0)
+            hipLaunchKernelGGL(fsolve_reduce_partial_kernel, dim3((nd.Nc + 255)/256, nslabs), dim3(256), 0, stream,
+                               nd, F.Wt, F.y, F.Spart, rows_per_slab);
+        else nslabs = 0;
+        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Spart, nslabs, b, F.r, order);
     }
     else
         // y = b_E, r = b_S as they are
         hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, F.y, F.r, order);
-    hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+    if(nd.Nc > 0 && nd.Nc <= 178)
+        hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(1), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2)*sizeof(double), stream,
+                           nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+    else
+        hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
     if(backwrd)
         hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1), dim3(64), 0, stream, nd, F.Wt, F.LD, F.y, F.r, x, order);
     else
