@@ -3449,16 +3449,40 @@ void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* 
 
 // ---- the consumers of J that mrcal's projection uncertainty uses (mrcal-genpywrap.py:477-731), on the
 // device-resident CSR J of a factorization
-// y = Jt x: one thread per row, atomics into y (zeroed by the caller)
-__global__ __launch_bounds__(256)
+// y = Jt x, atomics into y (zeroed by the caller). 64 rows per wave, grouped as in rows_generic_wave(): the
+// rows of a half-wave that have the columns of its first pending row are summed across the half, and one
+// lane adds the sums. (One lane per row: 37 M atomics on 6140 addresses, 200 000 of them on each intrinsic: 41 ms)
+__global__ __launch_bounds__(64)
 void csr_Jt_x_kernel(int Nrows, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, const double* __restrict__ Jx,
                      const double* __restrict__ x, double* __restrict__ y)
 {
-    const int r = blockIdx.x*blockDim.x + threadIdx.x;
-    if(r >= Nrows) return;
-    const double xr = x[r];
-    if(xr == 0.0) return;
-    for(int32_t p = Jp[r]; p < Jp[r+1]; p++) atomicAdd(&y[Ji[p]], Jx[p]*xr);
+    const int lane = threadIdx.x & 63, half = lane >> 5, first = half << 5;
+    const int r = blockIdx.x*64 + 2*(lane & 31) + half;
+    const bool valid = r < Nrows;
+    const int p0 = valid ? Jp[r] : 0, p1 = valid ? Jp[r+1] : 0;
+    const int len = p1 - p0;
+    const double xr = valid ? x[r] : 0.0;
+    bool todo = valid && xr != 0.0;
+    while(__any(todo))
+    {
+        const unsigned long long pending = __ballot(todo);
+        const unsigned mine = (unsigned)(pending >> first);
+        const bool active = mine != 0u;
+        const int  leader = first + (active ? __ffs(mine) - 1 : 0);
+        const int  lp0 = __shfl(p0, leader), llen = active ? __shfl(len, leader) : 0;
+        const int  lenmax = max(__shfl(llen, 0), __shfl(llen, 32));
+        const int32_t* __restrict__ cols = Ji + lp0;
+        bool member = todo && len == llen;
+        for(int k = 0; k < lenmax; k++)
+            if(member && k < llen) member = Ji[p0 + k] == cols[k];
+        const bool adder = active && lane == leader;
+        for(int k = 0; k < lenmax; k++)
+        {
+            const double sk = half_wave_sum_f64((member && k < llen) ? Jx[p0 + k]*xr : 0.0);
+            if(adder && k < llen) atomicAdd(&y[cols[k]], sk);
+        }
+        todo = todo && !member;
+    }
 }
 // out (NX x NX) += sum over the leading rows of outer(A j, A j), A (NX x Nstate) row-major
 template<int NX>
@@ -3495,7 +3519,7 @@ void csr_A_Jt_J_At_kernel(int Nrows, int Nstate, const int32_t* __restrict__ Jp,
 hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream)
 {
     if(Nrows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(csr_Jt_x_kernel, dim3((Nrows + 255)/256), dim3(256), 0, stream, Nrows, Jp, Ji, Jx, x, y);
+    hipLaunchKernelGGL(csr_Jt_x_kernel, dim3((Nrows + 63)/64), dim3(64), 0, stream, Nrows, Jp, Ji, Jx, x, y);
     return hipGetLastError();
 }
 hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,
