@@ -483,11 +483,17 @@ void* mrcal_amd_problem_stream(mrcal_amd_problem_t* problem);
    Returns milliseconds, <0 if unavailable */
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* problem);
 
-/* Records a HIP event pair around EVERY Jacobian-kernel launch from now on
-   (up to `capacity` launches), on the problem's stream; _end() stops, waits and
-   reports the number of launches and their total/min/max duration (ms). This
-   is how the benchmark measures the dominant kernel over its timed region */
+/* Records a HIP event pair around every `stride`-th Jacobian-kernel launch from
+   now on (up to `capacity` pairs), on the problem's stream; _end() stops, waits
+   and reports the number of launches timed and their total/min/max duration
+   (ms). This is how the benchmark measures the dominant kernel over its timed
+   region. An event pair costs the stream ~11 us (5.6 on each side of the
+   kernel), which is why the solver's steps carry none unless asked, and why the
+   benchmark asks for a stride. _begin(p, n) == _begin_strided(p, n, 1).
+   (mrcal_amd_problem_last_jacobian_kernel_ms() refers to host-driven
+   mrcal_amd_problem_evaluate() calls.) */
 bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int capacity);
+bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* problem, int capacity, int stride);
 bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
                                            double* total_ms, double* min_ms, double* max_ms);
 

@@ -45,6 +45,7 @@ struct mrcal_amd_problem
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region
     std::vector<hipEvent_t> ev_pool;
     int         ev_pool_used = 0;
+    int         ev_pool_seen = 0, ev_pool_stride = 1;      // launches since _begin(); every stride-th one is timed
     bool        ev_pool_enabled = false;
 
     // inputs

@@ -421,8 +421,8 @@ class ShardedProblem:
         return self.problem.b_packed()
     def synchronize(self):
         self.problem.synchronize()
-    def jacobian_timing_begin(self, capacity):
-        self.problem.jacobian_timing_begin(capacity)
+    def jacobian_timing_begin(self, capacity, stride=1):
+        self.problem.jacobian_timing_begin(capacity, stride)
     def jacobian_timing_end(self):
         return self.problem.jacobian_timing_end()
     def jacobian_algorithmic_bytes(self):

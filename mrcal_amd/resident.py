@@ -82,6 +82,7 @@ class Problem:
         L.mrcal_amd_problem_gauss_newton_step.restype, L.mrcal_amd_problem_gauss_newton_step.argtypes = C.c_bool, [vp, vp]
         L.mrcal_amd_problem_get_board_pool.restype,    L.mrcal_amd_problem_get_board_pool.argtypes    = C.c_bool, [vp, vp]
         L.mrcal_amd_problem_jacobian_timing_begin.restype,  L.mrcal_amd_problem_jacobian_timing_begin.argtypes = C.c_bool, [vp, C.c_int]
+        L.mrcal_amd_problem_jacobian_timing_begin_strided.restype,  L.mrcal_amd_problem_jacobian_timing_begin_strided.argtypes = C.c_bool, [vp, C.c_int, C.c_int]
         L.mrcal_amd_problem_jacobian_timing_end.restype  = C.c_bool
         L.mrcal_amd_problem_jacobian_timing_end.argtypes = [vp, ip, dpp, dpp, dpp]
         L._mrcal_amd_resident_declared = True
@@ -112,8 +113,8 @@ class Problem:
     def jacobian_algorithmic_bytes(self):
         return int(self._lib.mrcal_amd_problem_jacobian_algorithmic_bytes(self.handle))
 
-    def jacobian_timing_begin(self, capacity):
-        self._check(self._lib.mrcal_amd_problem_jacobian_timing_begin(self.handle, int(capacity)), "jacobian_timing_begin")
+    def jacobian_timing_begin(self, capacity, stride=1):
+        self._check(self._lib.mrcal_amd_problem_jacobian_timing_begin_strided(self.handle, int(capacity), int(stride)), "jacobian_timing_begin")
 
     def jacobian_timing_end(self):
         """(Nlaunches, total_ms, min_ms, max_ms) of the Jacobian kernel since _begin()"""
