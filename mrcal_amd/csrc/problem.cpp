@@ -66,7 +66,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -104,6 +104,9 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     }
     ok = ok && dev_alloc(&P->F.Spart, schur_partial_doubles(nd));
     ok = ok && dev_alloc(&P->F.Linv,  cholesky_large_workspace_doubles(nd.Nc));
+    // the tile occupancy of Wt: only where the couplings are sparse (the splined models) and the strip SYRK runs
+    if(L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && nd.Nc > 256 && nd.Nc <= 4096)
+        ok = ok && dev_alloc(&P->F.occ, (size_t)(nd.NEb > 0 ? nd.NEb : 1)*occ_words(nd));
     {
         char* ctl = NULL;
         ok = ok && dev_alloc(&ctl, solver_ctl_bytes());

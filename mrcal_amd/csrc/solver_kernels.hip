@@ -597,6 +597,12 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
         for(int k = 0; k < lenmax; k++)
             if(member && k < llen) member = Ji[p0 + k] == cols[k];
         const bool adder = active && lane == leader;
+        // no runs here (regularization rows: every row its own columns): the rows still pending go one lane per row
+        if(__popcll(__ballot(member)) < 8)
+        {
+            if(todo) rows_generic_row(nd, O, r, row1, Jp, Ji);
+            return;
+        }
 
         const double n2 = half_wave_sum_f64(member ? xr*xr : 0.0);
         if(adder) atomicAdd(&O.scalars[SC_NORM2_X], n2);
@@ -814,7 +820,7 @@ void zero_normal_kernel(NormalDims nd, OpRef R)
 __global__ __launch_bounds__(64)
 void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
-                          int* __restrict__ status)
+                          int* __restrict__ status, unsigned* __restrict__ occ, int nocc)
 {
     if(opref_skip(R)) return;
     const OpDev& O = opref_get(R);
@@ -825,6 +831,8 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
 
     __shared__ double L[36];
     __shared__ double rinv[6];
+    __shared__ unsigned occ_s[8];           // which 16-column tiles of this block's Wt rows are not all zero (Nc <= 4096)
+    if(threadIdx.x < 8) occ_s[threadIdx.x] = 0u;
     const int blk = br.block(first + blockIdx.x);
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
@@ -921,6 +929,16 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
         }
         if(c < nd.Nc) { for(int i=0;i<de;i++) Wt[(size_t)(e0+i)*nd.Nc + c] = w[i]; }
         else          { for(int i=0;i<de;i++) y[e0+i] = w[i]; }
+        if(occ != NULL)
+        {
+            // columns 64 cc .. 64 cc + 63 = tiles 4 cc .. 4 cc + 3
+            bool nz = false;
+            for(int i=0;i<de;i++) nz = nz || (w[i] != 0.0);
+            const unsigned long long m = __ballot(nz && c < nd.Nc);
+            const unsigned bits = ((m & 0xffffull) ? 1u : 0u) | (((m >> 16) & 0xffffull) ? 2u : 0u) |
+                                  (((m >> 32) & 0xffffull) ? 4u : 0u) | ((m >> 48) ? 8u : 0u);
+            if(t == 0 && bits) occ_s[(4*cc) >> 5] |= bits << ((4*cc) & 31);
+        }
     }
     // wider camera blocks: the remaining columns, plainly
     for(int c = t + 64*MAXC; c <= nd.Nc; c += blockDim.x)
@@ -934,6 +952,17 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
         }
         if(c < nd.Nc) for(int i=0;i<de;i++) Wt[(size_t)(e0+i)*nd.Nc + c] = w[i];
         else          for(int i=0;i<de;i++) y[e0+i] = w[i];
+        if(occ != NULL)
+        {
+            bool nz = false;
+            for(int i=0;i<de;i++) nz = nz || (w[i] != 0.0);
+            if(nz && c < nd.Nc) atomicOr(&occ_s[(c >> 4) >> 5], 1u << ((c >> 4) & 31));
+        }
+    }
+    if(occ != NULL)
+    {
+        __syncthreads();
+        if(t < nocc) occ[(size_t)blk*nocc + t] = occ_s[t];
     }
 }
 
@@ -1168,6 +1197,121 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
             for(int q = 0; q < SYRK_STRIP; q++)
                 acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[q][u], acc[q], 0, 0, 0);
             if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
+        }
+    }
+    const int slot = slot0 + sy;
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++)
+    {
+        if(q >= ntile) break;
+        double* __restrict__ o = Spart + ((size_t)slot*npairs + pair0 + q)*256;
+#pragma unroll
+        for(int v=0;v<4;v++) o[64*v + lane] = acc[q][v];
+    }
+    if(diag && cc == 0)
+    {
+        double* __restrict__ rpart = Spart + (size_t)nslots_total*npairs*256 + (size_t)slot*nb*16 + 16*bi;
+#pragma unroll
+        for(int v=0;v<4;v++) rpart[kk + 4*v] = accr[v];
+    }
+}
+
+// The same where Wt is SPARSE by tiles (the splined models: a frame's rows of Wt are nonzero only under the
+// knots its board covers, about a third of the 76 column tiles, so about a ninth of the tile pairs).
+// eblock_factor_kernel leaves a bit per (block, 16-column tile); here a wave walks the BLOCKS of its slice:
+// a block that does not touch tile bi is skipped (scalar test), of the others the A operand is loaded and
+// only the B tiles the block touches are. A block's 6 (3) rows are two (one) k-steps of 4, the missing
+// rows zero: a third more matrix instructions per processed block, for an eighth of the blocks x tiles.
+// Slices cut blocks wherever they fall: each side takes its rows
+__global__ __launch_bounds__(64)
+void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
+                              int slot0, int nslots_total,
+                              const double* __restrict__ Wt, const double* __restrict__ y,
+                              double* __restrict__ Spart, int nslices, FinalizeRide fr,
+                              const unsigned* __restrict__ occ, int nocc)
+{
+    if((int)blockIdx.y >= nslices) { finalize_ride(fr, nd); return; }
+    if(skip != NULL && *skip) return;
+    const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
+    int px, sy;
+    syrk_xcd_map(nslices, &px, &sy);
+    int bi = 0, sidx = px;
+    for(;;) { const int ng = (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP; if(sidx < ng) break; sidx -= ng; bi++; }
+    const int bj0 = bi + SYRK_STRIP*sidx;
+    const int ntile = min(SYRK_STRIP, nb - bj0);
+    const int pair0 = bi*nb - (bi*(bi-1))/2 + (bj0 - bi);
+    const int e_begin = e_lo + sy*e_per_slice;
+    const int e_end   = min(e_hi, e_begin + e_per_slice);
+
+    const int lane = threadIdx.x;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int ci = 16*bi + cc;
+    const bool oki = ci < nd.Nc;
+    const double* __restrict__ pi = Wt + (oki ? ci : 0);
+    const double* __restrict__ pj[SYRK_STRIP];
+    bool okj[SYRK_STRIP];
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++)
+    {
+        const int cj = 16*(bj0 + q) + cc;
+        okj[q] = (q < ntile) && cj < nd.Nc;
+        pj[q]  = Wt + (okj[q] ? cj : 0);
+    }
+    const bool diag = (bj0 == bi);
+
+    syrk_d4 acc[SYRK_STRIP];
+#pragma unroll
+    for(int q = 0; q < SYRK_STRIP; q++) acc[q] = syrk_d4{0.0, 0.0, 0.0, 0.0};
+    syrk_d4 accr = {0.0, 0.0, 0.0, 0.0};
+    if(e_begin < e_end)
+    {
+        auto block_of   = [&](int e) { return (e < 6*nd.Nfb) ? e/6 : nd.Nfb + (e - 6*nd.Nfb)/3; };
+        auto block_row0 = [&](int b) { return (b < nd.Nfb) ? 6*b : 6*nd.Nfb + 3*(b - nd.Nfb); };
+        const int b_first = block_of(e_begin), b_last = block_of(e_end - 1);
+        const unsigned wi = bi >> 5, mi = 1u << (bi & 31);
+        for(int b = b_first; b <= b_last; b++)
+        {
+            const unsigned* __restrict__ ob = occ + (size_t)b*nocc;
+            if(!(ob[wi] & mi)) continue;
+            bool lj[SYRK_STRIP]; bool any = diag;
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+            {
+                lj[q] = (q < ntile) && ((ob[(bj0 + q) >> 5] >> ((bj0 + q) & 31)) & 1u);
+                any = any || lj[q];
+            }
+            if(!any) continue;
+            const int br0 = block_row0(b);
+            const int r0 = max(br0, e_begin), r1 = min(br0 + ((b < nd.Nfb) ? 6 : 3), e_end);
+            const bool two = (r1 - r0) > 4;
+            const int  ea = r0 + kk, eb = r0 + 4 + kk;
+            const bool oka = ea < r1, okb = eb < r1;
+            const size_t rowa = (size_t)(oka ? ea : r0)*nd.Nc, rowb = (size_t)(okb ? eb : r0)*nd.Nc;
+            double a0 = pi[rowa], a1 = two ? pi[rowb] : 0.0;
+            if(!oka || !oki) a0 = 0.0;
+            if(!okb || !oki) a1 = 0.0;
+            double b0[SYRK_STRIP], b1[SYRK_STRIP];
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+                if(lj[q])
+                {
+                    b0[q] = pj[q][rowa]; b1[q] = two ? pj[q][rowb] : 0.0;
+                    if(!oka || !okj[q]) b0[q] = 0.0;
+                    if(!okb || !okj[q]) b1[q] = 0.0;
+                }
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+                if(lj[q])
+                {
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[q], acc[q], 0, 0, 0);
+                    if(two) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q], acc[q], 0, 0, 0);
+                }
+            if(diag)
+            {
+                const double y0 = (cc == 0 && oka) ? y[ea] : 0.0, y1 = (cc == 0 && okb) ? y[eb] : 0.0;
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y0, accr, 0, 0, 0);
+                if(two) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y1, accr, 0, 0, 0);
+            }
         }
     }
     const int slot = slot0 + sy;
@@ -2937,7 +3081,11 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
             const int extra = with_ride ? (ride->plan.Ndest*FIN_LANES + gx*64 - 1)/(gx*64) : 0;
             fr.row0 = ns[part];
             rode = rode || with_ride;
-            if(nd.Nc > SYRK_STRIP_FROM)
+            if(nd.Nc > SYRK_STRIP_FROM && F.occ != NULL)
+                hipLaunchKernelGGL(schur_syrk_sparse_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
+                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr,
+                                   F.occ, occ_words(nd));
+            else if(nd.Nc > SYRK_STRIP_FROM)
                 hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
                                    nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
             else
@@ -2956,7 +3104,7 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
 {
     if(br.count() > 0)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
-                           nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status);
+                           nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status, F.occ, occ_words(nd));
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nslots = launch_syrk(nd, br, R.skip, F, NULL, stream);
     {
@@ -3118,8 +3266,11 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     if(nrest > 0)
     {
         const OpRef R = { a.ops, &fl->elim_sel, &fl->skip_elim };
+        // (the occupancy of Wt's tiles is tracked only when EVERY block comes through here: F.occ is only
+        //  allocated for the splined models, whose blocks all do)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(nrest), dim3(64), 0, stream,
-                           nd, br, nframes_fused, R, 0.0, a.ctl, a.F->Wt, a.F->LD, a.F->y, a.F->status);
+                           nd, br, nframes_fused, R, 0.0, a.ctl, a.F->Wt, a.F->LD, a.F->y, a.F->status,
+                           (nframes_fused == 0) ? a.F->occ : (unsigned*)NULL, occ_words(nd));
     }
     return hipGetLastError();
 }
@@ -3476,6 +3627,12 @@ void csr_Jt_x_kernel(int Nrows, const int32_t* __restrict__ Jp, const int32_t* _
         for(int k = 0; k < lenmax; k++)
             if(member && k < llen) member = Ji[p0 + k] == cols[k];
         const bool adder = active && lane == leader;
+        if(__popcll(__ballot(member)) < 8)
+        {
+            // no runs: one lane per row for what is pending
+            if(todo) for(int p = p0; p < p1; p++) atomicAdd(&y[Ji[p]], Jx[p]*xr);
+            return;
+        }
         for(int k = 0; k < lenmax; k++)
         {
             const double sk = half_wave_sum_f64((member && k < llen) ? Jx[p0 + k]*xr : 0.0);

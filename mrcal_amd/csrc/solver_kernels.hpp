@@ -72,7 +72,10 @@ struct FactorBuffers
     double* Spart;    // [schur_partial_doubles(nd)] per-slice partial products of the SYRK, summed by schur_reduce_kernel
     double* Linv;     // [cholesky_large_workspace_doubles(Nc)] inverses of the 64x64 diagonal blocks (large Nc only)
     int*    status;   // [1] nonzero: not positive definite
+    unsigned* occ;    // [NEb][occ_words(nd)] bit per 16-column tile of the camera block: does the block's Wt hold a nonzero there?
+                      // Written by eblock_factor_kernel, read by the sparse SYRK (the splined models). NULL: not tracked
 };
+inline int occ_words(const NormalDims& nd) { return (((nd.Nc + 15) >> 4) + 31) >> 5; }
 
 // size of FactorBuffers::Linv: the multi-launch Cholesky of camera blocks that do not fit the LDS
 size_t cholesky_large_workspace_doubles(int n);
