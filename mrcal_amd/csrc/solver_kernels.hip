@@ -817,7 +817,7 @@ void zero_normal_kernel(NormalDims nd, OpRef R)
 
 // One workgroup per E block: L L^T = D_e + lambda I;  Wt_e = L^-1 Bt_e;  y_e = L^-1 g_e.
 // status[0] is set to 1 if any block is not positive definite
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(256)
 void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
                           int* __restrict__ status, unsigned* __restrict__ occ, int nocc)
@@ -842,12 +842,15 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
     // lane's columns of Bt_e (column Nc is g_e). The 6x6 factorization below
     // then runs under the latency of the big loads
     const double dval = (t < 36) ? D[(size_t)blk*36 + t] : 0.0;
-    constexpr int MAXC = 4;                // columns per lane held in registers: Nc <= 255
+    // (one wave for camera blocks up to 255 columns, four for wider ones: the splined models' 1206 columns
+    //  by one wave per block were 800 waves on the whole chip, 67 us of latency)
+    constexpr int MAXC = 4;                // columns per lane held in registers
+    const int nth = blockDim.x;
     double bt[MAXC][6];
 #pragma unroll
     for(int cc = 0; cc < MAXC; cc++)
     {
-        const int c = t + 64*cc;
+        const int c = t + nth*cc;
 #pragma unroll
         for(int i=0;i<6;i++)
             bt[cc][i] = (i < de && c <= nd.Nc) ? ((c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.Nie + e0 + i]) : 0.0;
@@ -916,7 +919,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
 #pragma unroll
     for(int cc = 0; cc < MAXC; cc++)
     {
-        const int c = t + 64*cc;
+        const int c = t + nth*cc;
         if(c > nd.Nc) break;
         double w[6];
 #pragma unroll
@@ -931,17 +934,18 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
         else          { for(int i=0;i<de;i++) y[e0+i] = w[i]; }
         if(occ != NULL)
         {
-            // columns 64 cc .. 64 cc + 63 = tiles 4 cc .. 4 cc + 3
+            // this wave's 64 columns = 4 tiles, starting at a multiple of 64
             bool nz = false;
             for(int i=0;i<de;i++) nz = nz || (w[i] != 0.0);
             const unsigned long long m = __ballot(nz && c < nd.Nc);
             const unsigned bits = ((m & 0xffffull) ? 1u : 0u) | (((m >> 16) & 0xffffull) ? 2u : 0u) |
                                   (((m >> 32) & 0xffffull) ? 4u : 0u) | ((m >> 48) ? 8u : 0u);
-            if(t == 0 && bits) occ_s[(4*cc) >> 5] |= bits << ((4*cc) & 31);
+            const int tile0 = (c - (t & 63)) >> 4;
+            if((t & 63) == 0 && bits) atomicOr(&occ_s[tile0 >> 5], bits << (tile0 & 31));
         }
     }
     // wider camera blocks: the remaining columns, plainly
-    for(int c = t + 64*MAXC; c <= nd.Nc; c += blockDim.x)
+    for(int c = t + nth*MAXC; c <= nd.Nc; c += nth)
     {
         double w[6];
         for(int i=0;i<de;i++)
@@ -3103,7 +3107,7 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
                                double lambda, const SolverCtl* ctl, bool is_leader, hipStream_t stream)
 {
     if(br.count() > 0)
-        hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(64), 0, stream,
+        hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(nd.Nc > 255 ? 256 : 64), 0, stream,
                            nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status, F.occ, occ_words(nd));
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nslots = launch_syrk(nd, br, R.skip, F, NULL, stream);
@@ -3268,7 +3272,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
         const OpRef R = { a.ops, &fl->elim_sel, &fl->skip_elim };
         // (the occupancy of Wt's tiles is tracked only when EVERY block comes through here: F.occ is only
         //  allocated for the splined models, whose blocks all do)
-        hipLaunchKernelGGL(eblock_factor_kernel, dim3(nrest), dim3(64), 0, stream,
+        hipLaunchKernelGGL(eblock_factor_kernel, dim3(nrest), dim3(nd.Nc > 255 ? 256 : 64), 0, stream,
                            nd, br, nframes_fused, R, 0.0, a.ctl, a.F->Wt, a.F->LD, a.F->y, a.F->status,
                            (nframes_fused == 0) ? a.F->occ : (unsigned*)NULL, occ_words(nd));
     }
