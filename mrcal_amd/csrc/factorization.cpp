@@ -14,6 +14,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 #include "layout.hpp"
 #include "host_state.hpp"
 #include "problem.hpp"
@@ -45,6 +46,8 @@ struct mrcal_amd_factorization
     double*       d_rhs = NULL;
     double*       d_sol = NULL;
     double*       d_mm  = NULL;   // [2] min, max of the factor's diagonal
+    double*       d_rhs_batch = NULL, *d_sol_batch = NULL;   // [batch_capacity][Nstate]: right-hand sides / solutions of a solve call
+    int           batch_capacity = 0;
     int           Nmeas = 0;
     hipStream_t   stream = NULL;
     std::vector<void*> allocs;
@@ -172,18 +175,34 @@ void mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f) { delete f; }
 int  mrcal_amd_factorization_Nstate(const mrcal_amd_factorization_t* f) { return f->nd.Nstate; }
 
 // xt[i,:] = (JtJ)^-1 bt[i,:], i in [0,Nrhs). Host pointers, C-contiguous (Nrhs,Nstate)
-bool mrcal_amd_factorization_solve(mrcal_amd_factorization_t* f, const double* bt, int Nrhs, double* xt)
+// The right-hand sides go up in batches and the solutions come down in batches: a copy to or from pageable
+// host memory per right-hand side is a synchronization each, more than the six kernels of a solve take
+static bool solve_batched(mrcal_amd_factorization_t* f, int sys, const double* bt, int Nrhs, double* xt)
 {
-    last_error_string().clear();
     const size_t n = (size_t)f->nd.Nstate;
-    for(int i = 0; i < Nrhs; i++)
+    if(Nrhs <= 0) return true;
+    const int BATCH = (int)std::max<size_t>(1, std::min<size_t>((size_t)Nrhs, ((size_t)32 << 20)/(n*sizeof(double) + 1)));      // <= 32 MB each way
+    if(f->batch_capacity < BATCH)
     {
-        HIP_TRY(hipMemcpyAsync(f->d_rhs, bt + (size_t)i*n, n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
-        HIP_TRY(launch_fsolve(f->nd, f->F, f->d_rhs, f->d_sol, f->stream), return false);
-        HIP_TRY(hipMemcpyAsync(xt + (size_t)i*n, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
+        double *rb = NULL, *sb = NULL;
+        if(!f->alloc(&rb, (size_t)BATCH*n) || !f->alloc(&sb, (size_t)BATCH*n)) return false;
+        f->d_rhs_batch = rb; f->d_sol_batch = sb; f->batch_capacity = BATCH;      // (the smaller ones are freed with the object)
+    }
+    for(int i0 = 0; i0 < Nrhs; i0 += BATCH)
+    {
+        const int nb = std::min(BATCH, Nrhs - i0);
+        HIP_TRY(hipMemcpyAsync(f->d_rhs_batch, bt + (size_t)i0*n, (size_t)nb*n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
+        for(int i = 0; i < nb; i++)
+            HIP_TRY(launch_fsolve_sys(f->nd, f->F, sys, f->d_rhs_batch + (size_t)i*n, f->d_sol_batch + (size_t)i*n, f->stream), return false);
+        HIP_TRY(hipMemcpyAsync(xt + (size_t)i0*n, f->d_sol_batch, (size_t)nb*n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
     }
     HIP_TRY(hipStreamSynchronize(f->stream), return false);
     return true;
+}
+bool mrcal_amd_factorization_solve(mrcal_amd_factorization_t* f, const double* bt, int Nrhs, double* xt)
+{
+    last_error_string().clear();
+    return solve_batched(f, FSOLVE_A, bt, Nrhs, xt);
 }
 
 // The other systems of cholmod_solve2() (mrcal-pywrap.c:467-493; sys = CHOLMOD's
@@ -195,15 +214,7 @@ bool mrcal_amd_factorization_solve_sys(mrcal_amd_factorization_t* f, int sys, co
 {
     last_error_string().clear();
     if(sys < 0 || sys > FSOLVE_Pt) { set_error("unknown system %d", sys); return false; }
-    const size_t n = (size_t)f->nd.Nstate;
-    for(int i = 0; i < Nrhs; i++)
-    {
-        HIP_TRY(hipMemcpyAsync(f->d_rhs, bt + (size_t)i*n, n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
-        HIP_TRY(launch_fsolve_sys(f->nd, f->F, sys, f->d_rhs, f->d_sol, f->stream), return false);
-        HIP_TRY(hipMemcpyAsync(xt + (size_t)i*n, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
-    }
-    HIP_TRY(hipStreamSynchronize(f->stream), return false);
-    return true;
+    return solve_batched(f, sys, bt, Nrhs, xt);
 }
 
 // y = Jt x with the J this factorization was made from (it is resident): mrcal-genpywrap.py:658-731 _Jt_x

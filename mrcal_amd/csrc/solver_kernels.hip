@@ -3396,15 +3396,19 @@ void fsolve_reduce_partial_kernel(NormalDims nd, const double* __restrict__ Wt, 
     if(e < e1) acc0 += Wt[(size_t)e*nd.Nc + c]*y[e];
     part[(size_t)blockIdx.y*nd.Nc + c] = acc0 + acc1;
 }
+// (16 lanes per column: lane k adds the slabs k, k+16, ... in order, then the 16 sums are added in lane order)
 __global__ __launch_bounds__(256)
 void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ part, int nslabs,
                           const double* __restrict__ b, double* __restrict__ r, int order)
 {
-    const int c = blockIdx.x*blockDim.x + threadIdx.x;
-    if(c >= nd.Nc) return;
-    double acc = b[fs_index_S(nd, order, c)];
-    for(int s = 0; s < nslabs; s++) acc -= part[(size_t)s*nd.Nc + c];
-    r[c] = acc;
+    const int gid = blockIdx.x*blockDim.x + threadIdx.x;
+    const int c = gid >> 4, k = gid & 15;
+    const bool ok = c < nd.Nc;
+    double acc = 0.0;
+    if(ok) for(int s = k; s < nslabs; s += 16) acc += part[(size_t)s*nd.Nc + c];
+    // fixed order: ((0+1)+(2+3))+... over the 16 lanes of the column
+    for(int off = 1; off < 16; off <<= 1) acc += __shfl_xor(acc, off);
+    if(ok && k == 0) r[c] = b[fs_index_S(nd, order, c)] - acc;
 }
 // r <- L^-1 r (parts & 1), then r <- L^-T r (parts & 2), L the lower triangle of S (row-major n x n), one workgroup
 __global__ __launch_bounds__(1024)
@@ -3439,69 +3443,123 @@ void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict
 __global__ __launch_bounds__(1024)
 void fsolve_dense_lds_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
 {
-    extern __shared__ __attribute__((aligned(16))) double Lp[];      // packed lower triangle
+    extern __shared__ __attribute__((aligned(16))) double Lp[];      // packed lower triangle, then 1/diagonal
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto rowptr = [&](int i) -> double* { return Lp + ((i*(i+1)) >> 1); };
-    for(int i = wave; i < n; i += 16)
-        for(int j = lane; j <= i; j += 64) rowptr(i)[j] = S[(size_t)i*n + j];
+    double* __restrict__ rds = Lp + (((n*(n+1)) >> 1) + 1);
+    {
+        // everything asked for before anything is stored (as in schur_cholesky_solve_kernel)
+        double v[12][3];
+#pragma unroll
+        for(int a = 0; a < 12; a++)
+#pragma unroll
+            for(int b = 0; b < 3; b++)
+                if(b <= a/4)
+                {
+                    const int  i = wave_u + 16*a, j = lane + 64*b;
+                    const bool ok = (i < n && j <= i);
+                    v[a][b] = S[ok ? (size_t)i*n + j : 0];
+                }
+#pragma unroll
+        for(int a = 0; a < 12; a++)
+#pragma unroll
+            for(int b = 0; b < 3; b++)
+                if(b <= a/4)
+                {
+                    const int i = wave_u + 16*a, j = lane + 64*b;
+                    if(i < n && j <= i) { rowptr(i)[j] = v[a][b]; if(j == i) rds[i] = 1.0/v[a][b]; }
+                }
+    }
     __syncthreads();
     if(wave != 0) return;
-    // slot k of lane l = entry l + 64 k
-    double z[3], rd[3];
+    // slot k of lane l = entry l + 64 k. Every LDS read below is UNCONDITIONAL (index clamped into the
+    // triangle, value selected afterwards): a load under a condition becomes a branch with a wait of its own,
+    // and a step of the sweeps was 800 cycles of those
+    double z[3];
+    int    tri[3];                      // start of row i of the packed triangle (row n-1 for the lanes past the end)
 #pragma unroll
     for(int k = 0; k < 3; k++)
     {
-        const int i = lane + 64*k;
-        z[k]  = (i < n) ? r[i] : 0.0;
-        rd[k] = (i < n) ? 1.0/rowptr(i)[i] : 0.0;
+        const int i = lane + 64*k, ic = min(i, n - 1);
+        z[k]   = r[ic];
+        z[k]   = (i < n) ? z[k] : 0.0;
+        tri[k] = (ic*(ic+1)) >> 1;
     }
-    auto entry = [&](const double (&v)[3], int j) -> double       // entry j, to every lane
-    {
-        const int k = j >> 6;
-        const double mine = (k == 0) ? v[0] : (k == 1) ? v[1] : v[2];
-        return __shfl(mine, j & 63);
-    };
+    // (the slot that holds entry j is a compile-time constant inside each of the three j ranges below: indexing
+    //  z[] with a run-time slot number would put the array into scratch memory)
     if(parts & 1)
     {
         // L w = r, right-looking: w_j = z_j / L_jj ; z_i -= L[i][j] w_j for i > j
         double col[3];
 #pragma unroll
-        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; col[k] = (i < n && i > 0) ? rowptr(i)[0] : 0.0; }
-        for(int j = 0; j < n; j++)
+        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; const double v = Lp[tri[k]]; col[k] = (i < n && i > 0) ? v : 0.0; }
+        double rdj = rds[0];
+        auto sweep = [&](auto KS)
         {
-            const double wj = entry(z, j)*entry(rd, j);
-            double nxt[3];
-#pragma unroll
-            for(int k = 0; k < 3; k++) { const int i = lane + 64*k; nxt[k] = (j + 1 < n && i < n && i > j + 1) ? rowptr(i)[j+1] : 0.0; }
-#pragma unroll
-            for(int k = 0; k < 3; k++)
+            constexpr int ks = decltype(KS)::value;
+            for(int j = 64*ks; j < min(n, 64*ks + 64); j++)
             {
-                const int i = lane + 64*k;
-                z[k] = (i == j) ? wj : (i > j) ? fma(-col[k], wj, z[k]) : z[k];
-                col[k] = nxt[k];
+                const double wj = readlane_f64(z[ks], j & 63)*rdj;
+                double nxt[3];
+#pragma unroll
+                for(int k = 0; k < 3; k++)
+                {
+                    // (column j+1 of row i; rows i <= j+1 read their own diagonal instead: inside the row)
+                    const int i = lane + 64*k, ic = min(i, n - 1);
+                    const double v = Lp[tri[k] + min(j + 1, ic)];
+                    nxt[k] = (i < n && i > j + 1) ? v : 0.0;
+                }
+                const double rdn = rds[min(j + 1, n - 1)];
+#pragma unroll
+                for(int k = 0; k < 3; k++)
+                {
+                    const int i = lane + 64*k;
+                    const double upd = fma(-col[k], wj, z[k]);
+                    z[k] = (i == j) ? wj : (i > j) ? upd : z[k];
+                    col[k] = nxt[k];
+                }
+                rdj = rdn;
             }
-        }
+        };
+        sweep(std::integral_constant<int,0>{}); sweep(std::integral_constant<int,1>{}); sweep(std::integral_constant<int,2>{});
     }
     if(parts & 2)
     {
         // L^T x = w, right-looking from the end: x_j = z_j / L_jj ; z_i -= L[j][i] x_j for i < j
         double row[3];
+        const int last = ((n-1)*n) >> 1;
 #pragma unroll
-        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; row[k] = (i < n - 1) ? rowptr(n-1)[i] : 0.0; }
-        for(int j = n - 1; j >= 0; j--)
+        for(int k = 0; k < 3; k++) { const int i = lane + 64*k; const double v = Lp[last + min(i, n - 1)]; row[k] = (i < n - 1) ? v : 0.0; }
+        double rdj = rds[n-1];
+        auto sweep = [&](auto KS)
         {
-            const double xj = entry(z, j)*entry(rd, j);
-            double nxt[3];
-#pragma unroll
-            for(int k = 0; k < 3; k++) { const int i = lane + 64*k; nxt[k] = (j >= 1 && i < j - 1) ? rowptr(j-1)[i] : 0.0; }
-#pragma unroll
-            for(int k = 0; k < 3; k++)
+            constexpr int ks = decltype(KS)::value;
+            for(int j = min(n, 64*ks + 64) - 1; j >= 64*ks; j--)
             {
-                const int i = lane + 64*k;
-                z[k] = (i == j) ? xj : (i < j) ? fma(-row[k], xj, z[k]) : z[k];
-                row[k] = nxt[k];
+                const double xj = readlane_f64(z[ks], j & 63)*rdj;
+                double nxt[3];
+                const int jm = max(j - 1, 0), rowm = (jm*(jm+1)) >> 1;
+#pragma unroll
+                for(int k = 0; k < 3; k++)
+                {
+                    const int i = lane + 64*k;
+                    const double v = Lp[rowm + min(i, jm)];
+                    nxt[k] = (j >= 1 && i < j - 1) ? v : 0.0;
+                }
+                const double rdn = rds[jm];
+#pragma unroll
+                for(int k = 0; k < 3; k++)
+                {
+                    const int i = lane + 64*k;
+                    const double upd = fma(-row[k], xj, z[k]);
+                    z[k] = (i == j) ? xj : (i < j) ? upd : z[k];
+                    row[k] = nxt[k];
+                }
+                rdj = rdn;
             }
-        }
+        };
+        sweep(std::integral_constant<int,2>{}); sweep(std::integral_constant<int,1>{}); sweep(std::integral_constant<int,0>{});
     }
 #pragma unroll
     for(int k = 0; k < 3; k++) { const int i = lane + 64*k; if(i < n) r[i] = z[k]; }
@@ -3734,13 +3792,13 @@ hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int s
             hipLaunchKernelGGL(fsolve_reduce_partial_kernel, dim3((nd.Nc + 255)/256, nslabs), dim3(256), 0, stream,
                                nd, F.Wt, F.y, F.Spart, rows_per_slab);
         else nslabs = 0;
-        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Spart, nslabs, b, F.r, order);
+        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((16*nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Spart, nslabs, b, F.r, order);
     }
     else
         // y = b_E, r = b_S as they are
         hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, F.y, F.r, order);
     if(nd.Nc > 0 && nd.Nc <= 178)
-        hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(1), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2)*sizeof(double), stream,
+        hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(1), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2 + nd.Nc)*sizeof(double), stream,
                            nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
     else
         hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
