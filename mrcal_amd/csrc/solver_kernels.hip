@@ -3564,6 +3564,119 @@ void fsolve_dense_lds_kernel(int n, const double* __restrict__ S, double* __rest
 #pragma unroll
     for(int k = 0; k < 3; k++) { const int i = lane + 64*k; if(i < n) r[i] = z[k]; }
 }
+// The same for a big camera block (splined models: n = 1206), by blocks of 64 columns, r in LDS. A block is
+// (a) its 64 x 64 diagonal triangle into LDS (row stride 65: a column read is conflict-free), (b) one wave
+// solving it with r in registers as above, (c) the whole workgroup subtracting the block's part from the rows
+// (forward) / columns (backward) that remain - reads of S that are row segments either way: going forward 16
+// lanes share a row's 64 entries, going back a thread owns a column and half of the block's rows.
+// fsolve_dense_kernel pays two barriers and a memory round trip per COLUMN: 1870 us at n = 1206
+#define FSB_LD 65
+__global__ __launch_bounds__(1024)
+void fsolve_dense_blocked_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
+{
+    extern __shared__ __attribute__((aligned(16))) double fsb_lds[];
+    const int npad = (n + 63) & ~63, nblocks = npad >> 6;
+    double* __restrict__ rs   = fsb_lds;                 // npad
+    double* __restrict__ Ld   = rs + npad;               // 64 x 65
+    double* __restrict__ zs   = Ld + 64*FSB_LD;          // 64
+    double* __restrict__ part = zs + 64;                 // 1024
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for(int i = t; i < npad; i += 1024) rs[i] = (i < n) ? r[i] : 0.0;
+    // rows past n are rows of the identity: their entries of r are zero and stay zero
+    auto load_diag = [&](int j0)
+    {
+#pragma unroll
+        for(int e = t; e < 64*64; e += 1024)
+        {
+            const int i = e >> 6, k = e & 63;
+            const bool ok = (j0 + i < n) && (k <= i);
+            const double v = S[ok ? (size_t)(j0 + i)*n + j0 + k : 0];
+            Ld[i*FSB_LD + k] = ok ? v : (i == k ? 1.0 : 0.0);
+        }
+    };
+    if(parts & 1)
+    for(int b = 0; b < nblocks; b++)
+    {
+        const int j0 = b << 6;
+        load_diag(j0);
+        __syncthreads();
+        if(wave == 0)
+        {
+            double z = rs[j0 + lane];
+            const double inv = 1.0/Ld[lane*FSB_LD + lane];
+            double m = Ld[lane*FSB_LD];
+            for(int k = 0; k < 64; k++)
+            {
+                const double mnext = Ld[lane*FSB_LD + ((k + 1) & 63)];
+                const double zk = readlane_f64(z, k)*readlane_f64(inv, k);
+                z = (lane == k) ? zk : ((lane > k) ? fma(-m, zk, z) : z);
+                m = mnext;
+            }
+            rs[j0 + lane] = z; zs[lane] = z;
+        }
+        __syncthreads();
+        {
+            const int sub = t & 15;
+            const double z0 = zs[4*sub], z1 = zs[4*sub+1], z2 = zs[4*sub+2], z3 = zs[4*sub+3];
+#pragma unroll 4
+            for(int i = j0 + 64 + (t >> 4); i < n; i += 64)
+            {
+                const double* __restrict__ p = S + (size_t)i*n + j0 + 4*sub;
+                double a = (p[0]*z0 + p[1]*z1) + (p[2]*z2 + p[3]*z3);
+                a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+                if(sub == 0) rs[i] -= a;
+            }
+        }
+        __syncthreads();
+    }
+    if(parts & 2)
+    for(int b = nblocks - 1; b >= 0; b--)
+    {
+        const int j0 = b << 6;
+        load_diag(j0);
+        __syncthreads();
+        if(wave == 0)
+        {
+            double z = rs[j0 + lane];
+            const double inv = 1.0/Ld[lane*FSB_LD + lane];
+            double m = Ld[63*FSB_LD + lane];
+            for(int k = 63; k >= 0; k--)
+            {
+                const double mnext = Ld[((k - 1) & 63)*FSB_LD + lane];
+                const double zk = readlane_f64(z, k)*readlane_f64(inv, k);
+                z = (lane == k) ? zk : ((lane < k) ? fma(-m, zk, z) : z);
+                m = mnext;
+            }
+            rs[j0 + lane] = z; zs[lane] = z;
+        }
+        __syncthreads();
+        // columns i < j0: two threads per column, 32 of the block's rows each
+        const int kmax = min(64, n - j0);
+        const int g = t >> 9, w = t & 511;
+        for(int i0 = 0; i0 < j0; i0 += 512)
+        {
+            const int i = i0 + w;
+            double a0 = 0.0, a1 = 0.0;
+            if(i < j0)
+            {
+                const double* __restrict__ p = S + (size_t)(j0 + 32*g)*n + i;
+#pragma unroll
+                for(int k = 0; k < 32; k += 2)
+                {
+                    const int k0 = 32*g + k;
+                    if(k0     < kmax) a0 = fma(p[(size_t)k*n],       zs[k0],     a0);
+                    if(k0 + 1 < kmax) a1 = fma(p[(size_t)(k + 1)*n], zs[k0 + 1], a1);
+                }
+            }
+            part[t] = a0 + a1;
+            __syncthreads();
+            if(g == 0 && i < j0) rs[i] -= part[w] + part[512 + w];
+            __syncthreads();
+        }
+    }
+    for(int i = t; i < n; i += 1024) r[i] = rs[i];
+}
+static inline size_t fsolve_blocked_lds_bytes(int n) { return (size_t)(((n + 63) & ~63) + 64*FSB_LD + 64 + 1024)*sizeof(double); }
 // x_e = L_e^-T (y_e - Wt_e x_S), one workgroup per E block; the extra block copies x_S
 __global__ __launch_bounds__(64)
 void fsolve_backsub_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ LD,
@@ -3799,6 +3912,9 @@ hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int s
         hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, F.y, F.r, order);
     if(nd.Nc > 0 && nd.Nc <= 178)
         hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(1), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2 + nd.Nc)*sizeof(double), stream,
+                           nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+    else if(nd.Nc > 0 && fsolve_blocked_lds_bytes(nd.Nc) <= 156*1024)
+        hipLaunchKernelGGL(fsolve_dense_blocked_kernel, dim3(1), dim3(1024), fsolve_blocked_lds_bytes(nd.Nc), stream,
                            nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
     else
         hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));

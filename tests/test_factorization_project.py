@@ -74,7 +74,11 @@ def test_wrong_structure_is_an_error(amd):
 
 @pytest.mark.parametrize("lensmodel,Ncam,Nf,with_points", (("LENSMODEL_OPENCV4", 2, 5, False),
                                                             ("LENSMODEL_OPENCV8", 3, 6, True),
-                                                            ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120", 1, 8, False)))
+                                                            ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120", 1, 8, False),
+                                                            # a camera block past what the LDS triangular solve holds
+                                                            # (234, and 2*160 + 6 = 326: the blocked one)
+                                                            ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=13_Ny=9_fov_x_deg=120", 1, 8, False),
+                                                            ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=10_Ny=8_fov_x_deg=120", 2, 8, False)))
 def test_callback_factorization_solves(amd, lensmodel, Ncam, Nf, with_points):
     oi, _ = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
                                      object_width_n=8, object_height_n=7, seed=21)
@@ -171,7 +175,8 @@ def _factor_dense(F, N):
 
 
 @pytest.mark.parametrize("lensmodel,Ncam,Nf,with_points", (("LENSMODEL_OPENCV4", 2, 5, False),
-                                                            ("LENSMODEL_OPENCV8", 3, 10, True)))
+                                                            ("LENSMODEL_OPENCV8", 3, 10, True),
+                                                            ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=13_Ny=9_fov_x_deg=120", 1, 8, False)))
 def test_sys_variants(amd, ref_api, lensmodel, Ncam, Nf, with_points):
     """the sys= surface of CHOLMOD_factorization.solve_xt_JtJ_bt
     (mrcal-pywrap.c:467-493) on the factorization optimizer_callback() returns:
@@ -182,6 +187,7 @@ def test_sys_variants(amd, ref_api, lensmodel, Ncam, Nf, with_points):
     oi, _ = make_calibration_problem(amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lensmodel,
                                      object_width_n=7, object_height_n=6, seed=8)
     if with_points: oi = _with_points(oi, rng)
+    if "SPLINED" in lensmodel: oi["do_optimize_intrinsics_core"] = False
     _, x, J, F = amd.optimizer_callback(**oi)
     assert F is not None
     N = J.shape[1]
