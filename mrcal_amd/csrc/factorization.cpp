@@ -47,6 +47,7 @@ struct mrcal_amd_factorization
     double*       d_sol = NULL;
     double*       d_mm  = NULL;   // [2] min, max of the factor's diagonal
     double*       d_rhs_batch = NULL, *d_sol_batch = NULL;   // [batch_capacity][Nstate]: right-hand sides / solutions of a solve call
+    double*       d_batch_scratch = NULL;                    // y, r, partial sums of the batch (launch_fsolve_sys_batch)
     int           batch_capacity = 0;
     int           Nmeas = 0;
     hipStream_t   stream = NULL;
@@ -63,6 +64,12 @@ struct mrcal_amd_factorization
         }
         allocs.push_back((void*)*p);
         return true;
+    }
+    void release(void* p)
+    {
+        if(!p) return;
+        for(size_t i = 0; i < allocs.size(); i++)
+            if(allocs[i] == p) { hipStreamSynchronize(stream); hipFree(p); allocs.erase(allocs.begin() + i); return; }
     }
     ~mrcal_amd_factorization()
     {
@@ -181,19 +188,27 @@ static bool solve_batched(mrcal_amd_factorization_t* f, int sys, const double* b
 {
     const size_t n = (size_t)f->nd.Nstate;
     if(Nrhs <= 0) return true;
-    const int BATCH = (int)std::max<size_t>(1, std::min<size_t>((size_t)Nrhs, ((size_t)32 << 20)/(n*sizeof(double) + 1)));      // <= 32 MB each way
+    // <= 32 MB of right-hand sides each way, <= 256 MB of scratch (y, r and the partial sums of every right-hand side)
+    const size_t per_rhs = fsolve_batch_scratch_doubles(f->nd, 1);
+    const size_t part_per_rhs = per_rhs - (size_t)f->nd.NE - (size_t)f->nd.Nc;
+    size_t cap = std::min<size_t>((size_t)Nrhs, ((size_t)32 << 20)/(n*sizeof(double) + 1));
+    cap = std::min<size_t>(cap, ((size_t)256 << 20)/(per_rhs*sizeof(double) + 1));
+    const int BATCH = (int)std::max<size_t>(1, std::min<size_t>(cap, 16384));
     if(f->batch_capacity < BATCH)
     {
-        double *rb = NULL, *sb = NULL;
-        if(!f->alloc(&rb, (size_t)BATCH*n) || !f->alloc(&sb, (size_t)BATCH*n)) return false;
-        f->d_rhs_batch = rb; f->d_sol_batch = sb; f->batch_capacity = BATCH;      // (the smaller ones are freed with the object)
+        double *rb = NULL, *sb = NULL, *sc = NULL;
+        if(!f->alloc(&rb, (size_t)BATCH*n) || !f->alloc(&sb, (size_t)BATCH*n) || !f->alloc(&sc, (size_t)BATCH*per_rhs)) return false;
+        f->release(f->d_rhs_batch); f->release(f->d_sol_batch); f->release(f->d_batch_scratch);
+        f->d_rhs_batch = rb; f->d_sol_batch = sb; f->d_batch_scratch = sc; f->batch_capacity = BATCH;
     }
     for(int i0 = 0; i0 < Nrhs; i0 += BATCH)
     {
         const int nb = std::min(BATCH, Nrhs - i0);
+        double* y    = f->d_batch_scratch;
+        double* r    = y + (size_t)BATCH*f->nd.NE;
+        double* part = r + (size_t)BATCH*f->nd.Nc;
         HIP_TRY(hipMemcpyAsync(f->d_rhs_batch, bt + (size_t)i0*n, (size_t)nb*n*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
-        for(int i = 0; i < nb; i++)
-            HIP_TRY(launch_fsolve_sys(f->nd, f->F, sys, f->d_rhs_batch + (size_t)i*n, f->d_sol_batch + (size_t)i*n, f->stream), return false);
+        HIP_TRY(launch_fsolve_sys_batch(f->nd, f->F, sys, f->d_rhs_batch, f->d_sol_batch, nb, y, r, part, part_per_rhs, f->stream), return false);
         HIP_TRY(hipMemcpyAsync(xt + (size_t)i0*n, f->d_sol_batch, (size_t)nb*n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
     }
     HIP_TRY(hipStreamSynchronize(f->stream), return false);

@@ -3360,8 +3360,11 @@ __device__ __forceinline__ int fs_index_S(const NormalDims& nd, int order, int c
 // y_e = L_e^-1 b_e, one thread per E block
 __global__ __launch_bounds__(64)
 void fsolve_forward_kernel(NormalDims nd, const double* __restrict__ LD,
-                           const double* __restrict__ b, double* __restrict__ y, int order)
+                           const double* __restrict__ b, double* __restrict__ y, int order, size_t sb)
 {
+    // (blockIdx.z in every fsolve kernel: the right-hand side of a batch; sb its stride in b and x.
+    //  y, r and the partial sums of a batch lie one right-hand side after the other)
+    b += blockIdx.z*sb; y += (size_t)blockIdx.z*nd.NE;
     const int blk = blockIdx.x*blockDim.x + threadIdx.x;
     if(blk >= nd.NEb) return;
     const int de = (blk < nd.Nfb) ? 6 : 3;
@@ -3383,6 +3386,7 @@ __global__ __launch_bounds__(256)
 void fsolve_reduce_partial_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ y,
                                   double* __restrict__ part, int rows_per_slab)
 {
+    y += (size_t)blockIdx.z*nd.NE; part += (size_t)blockIdx.z*gridDim.y*nd.Nc;
     const int c = blockIdx.x*blockDim.x + threadIdx.x;
     const int e0 = blockIdx.y*rows_per_slab, e1 = min(nd.NE, e0 + rows_per_slab);
     if(c >= nd.Nc) return;
@@ -3399,8 +3403,9 @@ void fsolve_reduce_partial_kernel(NormalDims nd, const double* __restrict__ Wt, 
 // (16 lanes per column: lane k adds the slabs k, k+16, ... in order, then the 16 sums are added in lane order)
 __global__ __launch_bounds__(256)
 void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ part, int nslabs,
-                          const double* __restrict__ b, double* __restrict__ r, int order)
+                          const double* __restrict__ b, double* __restrict__ r, int order, size_t sb)
 {
+    b += blockIdx.z*sb; r += (size_t)blockIdx.z*nd.Nc; part += (size_t)blockIdx.z*nslabs*nd.Nc;
     const int gid = blockIdx.x*blockDim.x + threadIdx.x;
     const int c = gid >> 4, k = gid & 15;
     const bool ok = c < nd.Nc;
@@ -3414,6 +3419,7 @@ void fsolve_reduce_kernel(NormalDims nd, const double* __restrict__ part, int ns
 __global__ __launch_bounds__(1024)
 void fsolve_dense_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
 {
+    r += (size_t)blockIdx.x*n;
     const int t = threadIdx.x, nt = blockDim.x;
     __shared__ double piv;
     if(parts & 1)
@@ -3444,6 +3450,7 @@ __global__ __launch_bounds__(1024)
 void fsolve_dense_lds_kernel(int n, const double* __restrict__ S, double* __restrict__ r, int parts)
 {
     extern __shared__ __attribute__((aligned(16))) double Lp[];      // packed lower triangle, then 1/diagonal
+    r += (size_t)blockIdx.x*n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto rowptr = [&](int i) -> double* { return Lp + ((i*(i+1)) >> 1); };
@@ -3580,6 +3587,7 @@ void fsolve_dense_blocked_kernel(int n, const double* __restrict__ S, double* __
     double* __restrict__ Ld   = rs + npad;               // 64 x 65
     double* __restrict__ zs   = Ld + 64*FSB_LD;          // 64
     double* __restrict__ part = zs + 64;                 // 1024
+    r += (size_t)blockIdx.x*n;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for(int i = t; i < npad; i += 1024) rs[i] = (i < n) ? r[i] : 0.0;
     // rows past n are rows of the identity: their entries of r are zero and stay zero
@@ -3681,8 +3689,9 @@ static inline size_t fsolve_blocked_lds_bytes(int n) { return (size_t)(((n + 63)
 __global__ __launch_bounds__(64)
 void fsolve_backsub_kernel(NormalDims nd, const double* __restrict__ Wt, const double* __restrict__ LD,
                            const double* __restrict__ y, const double* __restrict__ xs,
-                           double* __restrict__ x, int order)
+                           double* __restrict__ x, int order, size_t sb)
 {
+    y += (size_t)blockIdx.z*nd.NE; xs += (size_t)blockIdx.z*nd.Nc; x += blockIdx.z*sb;
     const int t = threadIdx.x;
     if((int)blockIdx.x == nd.NEb)
     {
@@ -3750,23 +3759,26 @@ void fsolve_diag_minmax_kernel(NormalDims nd, const double* __restrict__ S, cons
 
 // y = b_E, r = b_S  /  x = [y ; r]
 __global__ __launch_bounds__(256)
-void fsolve_split_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ y, double* __restrict__ r, int order)
+void fsolve_split_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ y, double* __restrict__ r, int order, size_t sb)
 {
+    b += blockIdx.z*sb; y += (size_t)blockIdx.z*nd.NE; r += (size_t)blockIdx.z*nd.Nc;
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if(i < nd.NE) y[i] = b[fs_index_E(nd, order, i)];
     else if(i < nd.NE + nd.Nc) r[i - nd.NE] = b[fs_index_S(nd, order, i - nd.NE)];
 }
 __global__ __launch_bounds__(256)
-void fsolve_join_kernel(NormalDims nd, const double* __restrict__ y, const double* __restrict__ r, double* __restrict__ x, int order)
+void fsolve_join_kernel(NormalDims nd, const double* __restrict__ y, const double* __restrict__ r, double* __restrict__ x, int order, size_t sb)
 {
+    x += blockIdx.z*sb; y += (size_t)blockIdx.z*nd.NE; r += (size_t)blockIdx.z*nd.Nc;
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if(i < nd.NE) x[fs_index_E(nd, order, i)] = y[i];
     else if(i < nd.NE + nd.Nc) x[fs_index_S(nd, order, i - nd.NE)] = r[i - nd.NE];
 }
 // to_factor: x (factor order) = P b (state order); else x (state order) = P^T b (factor order)
 __global__ __launch_bounds__(256)
-void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ x, int to_factor)
+void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* __restrict__ x, int to_factor, size_t sb)
 {
+    b += blockIdx.z*sb; x += blockIdx.z*sb;
     const int i = blockIdx.x*blockDim.x + threadIdx.x;      // index in factor order
     if(i >= nd.NE + nd.Nc) return;
     const int is = (i < nd.NE) ? fs_index_E(nd, 0, i) : fs_index_S(nd, 0, i - nd.NE);
@@ -3881,11 +3893,42 @@ hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
 hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int sys,
                              const double* b, double* x, hipStream_t stream)
 {
+    // slabs of rows of Wt are summed side by side into F.Spart (free between factorizations)
+    return launch_fsolve_sys_batch(nd, F, sys, b, x, 1, F.y, F.r, F.Spart, schur_partial_doubles(nd), stream);
+}
+// rows of Wt a slab of the r = b_S - Wt^T y sum takes when nrhs right-hand sides are solved side by side
+static void fsolve_slabs(const NormalDims& nd, int nrhs, size_t room_per_rhs, int* rows_per_slab, int* nslabs)
+{
+    // 64 rows whatever the batch: a right-hand side gets the same bits alone and in company
+    (void)nrhs;
+    int rps = 64;
+    int ns  = (nd.NE + rps - 1)/rps;
+    const int max_slabs = (nd.Nc > 0) ? (int)std::min<size_t>(room_per_rhs/(size_t)nd.Nc, 4096) : 1;
+    if(ns > max_slabs) { ns = max_slabs > 0 ? max_slabs : 1; rps = (nd.NE + ns - 1)/ns; ns = (nd.NE + rps - 1)/rps; }
+    *rows_per_slab = rps; *nslabs = ns;
+}
+size_t fsolve_batch_scratch_doubles(const NormalDims& nd, int nrhs)
+{
+    int rps, ns;
+    fsolve_slabs(nd, nrhs, (size_t)1 << 40, &rps, &ns);
+    return (size_t)nd.NE + (size_t)nd.Nc + (size_t)std::max(ns, 1)*(size_t)nd.Nc;
+}
+// nrhs systems at once: b, x are [nrhs][Nstate]; y [nrhs][NE], r [nrhs][Nc], part [nrhs][part_per_rhs] scratch.
+// A right-hand side is its own set of workgroups of every kernel (blockIdx.z; blockIdx.x of the one-workgroup
+// triangular solve), so a batch costs about what one costs until the chip is full
+hipError_t launch_fsolve_sys_batch(const NormalDims& nd, const FactorBuffers& F, int sys,
+                                   const double* b, double* x, int nrhs,
+                                   double* y, double* r, double* part, size_t part_per_rhs, hipStream_t stream)
+{
     const int n = nd.Nstate;
-    if(sys == FSOLVE_D) return hipMemcpyAsync(x, b, (size_t)n*sizeof(double), hipMemcpyDeviceToDevice, stream);
+    if(nrhs <= 0) return hipSuccess;
+    if(nrhs > 65535) return hipErrorInvalidValue;
+    const unsigned Z = (unsigned)nrhs;
+    const size_t sb = (size_t)n;
+    if(sys == FSOLVE_D) return hipMemcpyAsync(x, b, (size_t)nrhs*n*sizeof(double), hipMemcpyDeviceToDevice, stream);
     if(sys == FSOLVE_P || sys == FSOLVE_Pt)
     {
-        hipLaunchKernelGGL(fsolve_permute_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, x, sys == FSOLVE_P ? 1 : 0);
+        hipLaunchKernelGGL(fsolve_permute_kernel, dim3((n + 255)/256, 1, Z), dim3(256), 0, stream, nd, b, x, sys == FSOLVE_P ? 1 : 0, sb);
         return hipGetLastError();
     }
     const int  order   = (sys == FSOLVE_A) ? 0 : 1;
@@ -3894,34 +3937,31 @@ hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int s
     if(forward)
     {
         if(nd.NEb > 0)
-            hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64), dim3(64), 0, stream, nd, F.LD, b, F.y, order);
-        // slabs of rows of Wt summed side by side into F.Spart (free between factorizations), then added in order
-        const size_t room = schur_partial_doubles(nd);
-        int rows_per_slab = 64;
-        int nslabs = (nd.NE + rows_per_slab - 1)/rows_per_slab;
-        const int max_slabs = (nd.Nc > 0) ? (int)std::min<size_t>(room/(size_t)nd.Nc, 4096) : 1;
-        if(nslabs > max_slabs) { nslabs = max_slabs > 0 ? max_slabs : 1; rows_per_slab = (nd.NE + nslabs - 1)/nslabs; nslabs = (nd.NE + rows_per_slab - 1)/rows_per_slab; }
+            hipLaunchKernelGGL(fsolve_forward_kernel, dim3((nd.NEb + 63)/64, 1, Z), dim3(64), 0, stream, nd, F.LD, b, y, order, sb);
+        int rows_per_slab, nslabs;
+        fsolve_slabs(nd, nrhs, part_per_rhs, &rows_per_slab, &nslabs);
         if(nd.NE > 0 && nd.Nc > 0)
-            hipLaunchKernelGGL(fsolve_reduce_partial_kernel, dim3((nd.Nc + 255)/256, nslabs), dim3(256), 0, stream,
-                               nd, F.Wt, F.y, F.Spart, rows_per_slab);
+            hipLaunchKernelGGL(fsolve_reduce_partial_kernel, dim3((nd.Nc + 255)/256, nslabs, Z), dim3(256), 0, stream,
+                               nd, F.Wt, y, part, rows_per_slab);
         else nslabs = 0;
-        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((16*nd.Nc + 255)/256), dim3(256), 0, stream, nd, F.Spart, nslabs, b, F.r, order);
+        hipLaunchKernelGGL(fsolve_reduce_kernel, dim3((16*nd.Nc + 255)/256, 1, Z), dim3(256), 0, stream, nd, part, nslabs, b, r, order, sb);
     }
     else
         // y = b_E, r = b_S as they are
-        hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, b, F.y, F.r, order);
+        hipLaunchKernelGGL(fsolve_split_kernel, dim3((n + 255)/256, 1, Z), dim3(256), 0, stream, nd, b, y, r, order, sb);
+    const int parts = (forward ? 1 : 0) | (backwrd ? 2 : 0);
     if(nd.Nc > 0 && nd.Nc <= 178)
-        hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(1), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2 + nd.Nc)*sizeof(double), stream,
-                           nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+        hipLaunchKernelGGL(fsolve_dense_lds_kernel, dim3(Z), dim3(1024), (size_t)(((nd.Nc*(nd.Nc+1)) >> 1) + 2 + nd.Nc)*sizeof(double), stream,
+                           nd.Nc, F.S, r, parts);
     else if(nd.Nc > 0 && fsolve_blocked_lds_bytes(nd.Nc) <= 156*1024)
-        hipLaunchKernelGGL(fsolve_dense_blocked_kernel, dim3(1), dim3(1024), fsolve_blocked_lds_bytes(nd.Nc), stream,
-                           nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+        hipLaunchKernelGGL(fsolve_dense_blocked_kernel, dim3(Z), dim3(1024), fsolve_blocked_lds_bytes(nd.Nc), stream,
+                           nd.Nc, F.S, r, parts);
     else
-        hipLaunchKernelGGL(fsolve_dense_kernel, dim3(1), dim3(1024), 0, stream, nd.Nc, F.S, F.r, (forward ? 1 : 0) | (backwrd ? 2 : 0));
+        hipLaunchKernelGGL(fsolve_dense_kernel, dim3(Z), dim3(1024), 0, stream, nd.Nc, F.S, r, parts);
     if(backwrd)
-        hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1), dim3(64), 0, stream, nd, F.Wt, F.LD, F.y, F.r, x, order);
+        hipLaunchKernelGGL(fsolve_backsub_kernel, dim3(nd.NEb + 1, 1, Z), dim3(64), 0, stream, nd, F.Wt, F.LD, y, r, x, order, sb);
     else
-        hipLaunchKernelGGL(fsolve_join_kernel, dim3((n + 255)/256), dim3(256), 0, stream, nd, F.y, F.r, x, order);
+        hipLaunchKernelGGL(fsolve_join_kernel, dim3((n + 255)/256, 1, Z), dim3(256), 0, stream, nd, y, r, x, order, sb);
     return hipGetLastError();
 }
 hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream)

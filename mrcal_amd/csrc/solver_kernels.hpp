@@ -235,6 +235,12 @@ hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
 enum { FSOLVE_A = 0, FSOLVE_LDLt, FSOLVE_LD, FSOLVE_DLt, FSOLVE_L, FSOLVE_Lt, FSOLVE_D, FSOLVE_P, FSOLVE_Pt };
 hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int sys,
                              const double* b, double* x, hipStream_t stream);
+// nrhs of them side by side: b, x [nrhs][Nstate]; scratch y [nrhs][NE], r [nrhs][Nc], part [nrhs][part_per_rhs]
+// (fsolve_batch_scratch_doubles(nd, nrhs) = NE + Nc + part_per_rhs for a batch of that size)
+size_t     fsolve_batch_scratch_doubles(const NormalDims& nd, int nrhs);
+hipError_t launch_fsolve_sys_batch(const NormalDims& nd, const FactorBuffers& F, int sys,
+                                   const double* b, double* x, int nrhs,
+                                   double* y, double* r, double* part, size_t part_per_rhs, hipStream_t stream);
 // y += Jt x ; out (NX x NX) += A Jt J At over the leading rows (mrcal-genpywrap.py:477-731), CSR J on the device
 hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream);
 hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,

@@ -214,6 +214,26 @@ def test_sys_variants(amd, ref_api, lensmodel, Ncam, Nf, with_points):
     assert np.abs(Var - Var_ref).max() < 1e-9*np.abs(Var_ref).max()
 
 
+def test_solve_batch_is_row_independent(amd):
+    """solve_xt_JtJ_bt takes any number of right-hand sides (mrcal's uncertainty grids pass thousands:
+    model_analysis.py:837-843); here they are solved side by side on the device. A row's answer has the
+    same bits alone, in a small batch and in a big one"""
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=12, lensmodel="LENSMODEL_OPENCV8",
+                                     object_width_n=7, object_height_n=6, seed=5)
+    _, x, J, F = amd.optimizer_callback(**oi)
+    N = J.shape[1]
+    B = np.random.RandomState(0).normal(size=(300, N))
+    for sys in ("A", "L", "Lt", "P"):
+        big = F.solve_xt_JtJ_bt(B, sys=sys)
+        assert big.shape == B.shape
+        for i in (0, 1, 150, 299):
+            assert np.array_equal(F.solve_xt_JtJ_bt(B[i], sys=sys), big[i]), (sys, i)
+        assert np.array_equal(F.solve_xt_JtJ_bt(B[10:17], sys=sys), big[10:17]), sys
+    JtJ = (J.T @ J).toarray()
+    Xs = F.solve_xt_JtJ_bt(B)
+    assert np.abs(Xs @ JtJ - B).max() < 1e-9*np.abs(JtJ).max()*np.abs(Xs).max()
+
+
 def test_Jt_x_and_A_Jt_J_At(amd):
     """mrcal._mrcal_npsp._Jt_x / _A_Jt_J_At / _A_Jt_J_At__2 (mrcal-genpywrap.py:477-731):
     from the p, i, x arrays like the reference's, and on the J resident with a factorization"""

@@ -11,10 +11,11 @@ for _ in range(2):
     t0 = time.perf_counter(); b, x, J, f = mrcal_amd.optimizer_callback(**copy_inputs(oi))
     print("callback+factorization", time.perf_counter() - t0)
 N = J.shape[1]
-bt = np.random.default_rng(0).normal(size=(8, N))
-f.solve_xt_JtJ_bt(bt)
-t0 = time.perf_counter(); xt = f.solve_xt_JtJ_bt(bt); dt = time.perf_counter() - t0
-print(f"splined solve_xt_JtJ_bt: {dt/8*1e6:.0f} us per rhs")
+for nrhs in (1, 8, 512, 4800):
+    bt = np.random.default_rng(0).normal(size=(nrhs, N))
+    f.solve_xt_JtJ_bt(bt)
+    t0 = time.perf_counter(); xt = f.solve_xt_JtJ_bt(bt); dt = time.perf_counter() - t0
+    print(f"splined solve_xt_JtJ_bt, {nrhs} right-hand sides: {dt*1e3:.2f} ms, {dt/nrhs*1e6:.1f} us each")
 JtJ = (J.T @ J)
 res = (JtJ @ xt.T).T - bt
 print("residual", np.abs(res).max(), "scale", np.abs(bt).max())
