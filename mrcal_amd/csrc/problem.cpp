@@ -66,6 +66,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
+    hipFree(plan.spl_hdr); hipFree(plan.spl_part);
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -292,7 +293,17 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         ok = ok && dev_upload(&P->plan.dest_begin,       dest_begin.data(),       dest_begin.size());
         ok = ok && dev_upload(&P->plan.dest_src,         dest_src.data(),         dest_src.size());
         ok = ok && dev_upload(&P->plan.pair_chunk_begin, pair_chunk_begin.data(), pair_chunk_begin.size());
-        ok = ok && dev_alloc (&P->plan.chunk_part, with_grams ? (size_t)(P->plan.Nchunks > 0 ? P->plan.Nchunks : 1)*npos : (size_t)1);
+        if(with_grams || Nobs == 0)
+            ok = ok && dev_alloc(&P->plan.chunk_part, with_grams ? (size_t)(P->plan.Nchunks > 0 ? P->plan.Nchunks : 1)*npos : (size_t)1);
+        else
+        {
+            // splined models: the staged Grams of assemble_splined_kernel (two passes per observation), the knot
+            // boxes, and the parts of the rows of the camera block that are not knots (+ the x row)
+            const int nknotrows = P->D.Nintr_state > 0 ? P->D.Ncameras_intrinsics*(P->D.Nintr_state - P->D.Ncore_state) : 0;
+            ok = ok && dev_alloc(&P->plan.chunk_part, (size_t)2*Nobs*SPL_TRI);
+            ok = ok && dev_alloc(&P->plan.spl_hdr,    (size_t)Nobs);
+            ok = ok && dev_alloc(&P->plan.spl_part,   (size_t)(nd.Nc + 1 - nknotrows)*SPLG_E*(nd.Nc + 1));
+        }
         {
             const int row0 = 2*P->D.W*P->D.H*Nobs;
             P->plan.row_part_n = (Nobs > 0 && L.Nmeas > row0) ? (L.Nmeas - row0 + 255)/256 : 0;

@@ -651,6 +651,10 @@ bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* P,
     if(g)  HIP_TRY(hipMemcpyAsync(g,  N.g,  (size_t)nd.Nstate*sizeof(double),   hipMemcpyDeviceToHost, P->stream), return false);
     if(norm2_x) HIP_TRY(hipMemcpyAsync(norm2_x, &N.scalars[SC_NORM2_X], sizeof(double), hipMemcpyDeviceToHost, P->stream), return false);
     HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    // (the device keeps A's lower triangle: the upper one is written by some assemblies and not by others)
+    if(A)
+        for(int i = 0; i < nd.Nc; i++)
+            for(int j = i + 1; j < nd.Nc; j++) A[(size_t)i*nd.Nc + j] = A[(size_t)j*nd.Nc + i];
     if(dims) { dims[0]=nd.Nc; dims[1]=nd.NE; dims[2]=nd.NEb; dims[3]=nd.Nfb; dims[4]=nd.Nie; dims[5]=nd.Nwarp; }
     return true;
 }

@@ -391,18 +391,84 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
 //     board, K = (order+1 + span)^2 of them per surface;
 //   - an x row touches the x surface only, a y row the y surface only
 //     (board_splined_kernel: column col0 + .. + xy), and all rows are equally long
-// One workgroup per frame, two passes per observation (x rows, y rows). A pass
-// writes its rows DENSELY over the local columns
-//     [ K knots | 4 core | 6 extrinsics | 2 warp | 6 frame | x ]
-// into LDS and the 256 threads form that matrix's Gram product in 8x8 register
-// tiles: no LDS atomics, and the one product yields the A, Bt, D_f, g and |x|^2
-// contributions at once. Nonzero tile entries are flushed with global atomics,
-// ~8000 per observation instead of ~135 000. An observation covering more than
-// SPL_TW-19 knots goes the generic way, row by row.
-#define SPL_TW      128         // local columns, 16 tiles of 8
+// Two kernels, no atomics, the same bits every time:
+//   assemble_splined_kernel: one workgroup per frame, two passes per observation
+//     (x rows, y rows). A pass writes its rows DENSELY over the local columns
+//         [ K knots | 4 core | 6 extrinsics | 2 warp | 6 frame | x ]
+//     into LDS and the 256 threads form the lower triangle of that matrix's Gram
+//     product in registers: one product yields the A, Bt, D_f, g and |x|^2
+//     contributions at once. What belongs to the frame (Bt, D_f, g_f: nobody else
+//     writes them) is added in place; the camera-block rows and the x row are
+//     STAGED, a packed lower triangle per pass, with the knot box in a header.
+//   assemble_splined_gather_kernel: one workgroup per ROW of the camera block
+//     (+ one for the x row: g and |x|^2). It walks the passes in order, and where
+//     the pass holds its row adds the row's staged entries into an LDS copy of
+//     the row of A; the copy is added to A at the end. A knot's row is in ~1 pass
+//     in 10; the rows every pass holds (core, extrinsics, warp, x) are split over
+//     SPLG_E workgroups each, summed in order by assemble_splined_combine_kernel.
+// (The one-kernel version flushed each pass's tile sums with global atomics, 8000 of them
+//  per observation; two thirds of a workgroup's time was that flush: 340 us at 30 x 20 knots,
+//  800 frames.) An observation covering more than SPL_TW-19 knots goes the generic way,
+// row by row, with atomics; its header says so. Only the lower triangle of A is written
+#define SPL_TW      128         // local columns
 #define SPL_NDENSE  12
 #define SPL_NEXTRA  (SPL_NDENSE + 6 + 1)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+// Thread (ty, tx) of the 16 x 16 owns the local rows ty + 16 a and columns tx + 16 b, a, b < 8: whatever the
+// number of columns in use, every thread has the same share of them, and of the lower triangle (a >= b). A row
+// of J in LDS has the 8 columns of a thread side by side
+__device__ __forceinline__ int spl_pos(int c) { return ((c & 15) << 3) + (c >> 4); }
+__device__ __forceinline__ int spl_tri(int r) { return (r*(r + 1)) >> 1; }
+
+// += the Gram of nr rows, the slots a >= b of the first NS slots
+template<int NS> __device__ __forceinline__
+void spl_gram_rows(const double* __restrict__ Jd, int nr, int ty, int tx, double (&acc)[36])
+{
+    for(int i = 0; i < nr; i++)
+    {
+        const double2* __restrict__ ra = (const double2*)(Jd + i*SPL_TW + 8*ty);
+        const double2* __restrict__ rb = (const double2*)(Jd + i*SPL_TW + 8*tx);
+        double va[8], vb[8];
+#pragma unroll
+        for(int u = 0; u < (NS + 1)/2; u++)
+        {
+            const double2 a2 = ra[u], b2 = rb[u];
+            va[2*u] = a2.x; va[2*u+1] = a2.y; vb[2*u] = b2.x; vb[2*u+1] = b2.y;
+        }
+#pragma unroll
+        for(int a = 0; a < NS; a++)
+#pragma unroll
+            for(int b = 0; b <= a; b++) acc[((a*(a+1)) >> 1) + b] += va[a]*vb[b];
+    }
+}
+// state index of local column c of a pass, -1: not a camera-block variable of this pass (a frame column, x,
+// or a variable that is not being optimized)
+__device__ __forceinline__
+int spl_col_state(const DeviceProblem& P, const NormalDims& nd, int c, int K, int ix0, int iy0, int wx, int xy,
+                  int i_state_intrinsics, int i_state_extrinsics)
+{
+    if(c < K)
+        return (i_state_intrinsics >= 0)
+            ? i_state_intrinsics + P.Ncore_state + 2*((iy0 + c / wx)*P.cfg.spline_Nx + ix0 + c % wx) + xy : -1;
+    const int d = c - K;
+    if(d < 4)           return (i_state_intrinsics >= 0 && d < P.Ncore_state) ? i_state_intrinsics + d : -1;
+    if(d < 10)          return (i_state_extrinsics >= 0) ? i_state_extrinsics + (d - 4) : -1;
+    if(d < SPL_NDENSE)  return nd.Nwarp ? nd.i_state_warp + (d - 10) : -1;
+    return -1;
+}
+// (not inlined: what it needs in registers should not count against the kernel's usual path)
+__device__ __noinline__
+void spl_rows_fallback(const NormalDims& nd, const OpDev& O, int r_first, int r1,
+                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    for(int r = r_first; r < r1; r += blockDim.x) rows_generic_row(nd, O, r, r1, Jp, Ji);
+}
+#ifndef SPL_WAVES_PER_EU
+#define SPL_WAVES_PER_EU 2
+#endif
+#ifndef SPL_ROWS_CAP
+#define SPL_ROWS_CAP 64
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU)))
 void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
                              const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int rows_cap)
 {
@@ -418,12 +484,21 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
     const int NPTS = P.W*P.H, Nx = P.cfg.spline_Nx, order1 = P.cfg.spline_order + 1;
     const int Ncs = P.Ncore_state;
+    // (-DSPL_TS: cycles per phase, printed by three of the workgroups)
+#ifdef SPL_TS
+    long long ts_bbox = 0, ts_zero = 0, ts_scatter = 0, ts_gram = 0, ts_out = 0, ts0 = clock64(), ts1;
+#define SPL_TICK(what) { ts1 = clock64(); what += ts1 - ts0; ts0 = ts1; }
+#else
+#define SPL_TICK(what)
+#endif
 
     for(int o = o0; o < o1; o++)
     {
         const BoardObsMeta m = P.board_meta[o];
         const int r0 = m.i_meas0, r1 = m.i_meas0 + 2*NPTS;
-        const int L  = Jp[r0+1] - Jp[r0];               // entries per row, the same for all rows of the observation
+        // (rowptr[i_meas0 + r] = i_nnz0 + r*nnz_per_row: board_splined_kernel. From the record: two loads fewer in line)
+        const int p00 = (int)m.i_nnz0;
+        const int L   = m.nnz_per_row;                  // entries per row, the same for all rows of the observation
         // bounding box of the knots under this observation: from the first spline column of every x row
         if(t < 4) bbox[t] = (t & 1) ? -1 : 0x7fffffff;
         __syncthreads();
@@ -432,7 +507,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             {
                 // (outliers have x == 0 and all-zero rows: whatever columns they carry do not matter)
                 if(x[r0 + 2*c] == 0.0 && x[r0 + 2*c + 1] == 0.0) continue;
-                const int rel  = Ji[Jp[r0 + 2*c] + (Ncs ? 2 : 0)] - (m.i_state_intrinsics + Ncs);
+                const int rel  = Ji[p00 + 2*c*L + (Ncs ? 2 : 0)] - (m.i_state_intrinsics + Ncs);
                 const int knot = rel >> 1, ix = knot % Nx, iy = knot / Nx;
                 atomicMin(&bbox[0], ix); atomicMax(&bbox[1], ix + order1 - 1);
                 atomicMin(&bbox[2], iy); atomicMax(&bbox[3], iy + order1 - 1);
@@ -443,13 +518,17 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int wx = any ? bbox[1] - bbox[0] + 1 : 0, wy = any ? bbox[3] - bbox[2] + 1 : 0;
         const int K  = wx*wy;
         __syncthreads();            // bbox is reused by the next observation
+        SPL_TICK(ts_bbox)
         if(K + SPL_NEXTRA > SPL_TW)
         {
-            for(int r = r0 + t; r < r1; r += blockDim.x) rows_generic_row(nd, O, r, r1, Jp, Ji);
+            if(t == 0) plan.spl_hdr[o] = SplHdr{ 0, 0, -1, -1 };
+            spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
             continue;
         }
+        if(t == 0) plan.spl_hdr[o] = SplHdr{ ix0, iy0, wx, wy };
         const int NC = K + SPL_NEXTRA;                  // local columns in use
-        const bool tile_live = (8*ty < NC) && (8*tx < NC);
+        const int NS = (NC + 15) >> 4;                  // slots of a thread in use
+        const int lx = K + SPL_NDENSE + 6;              // the x column
 
         for(int xy = 0; xy < 2; xy++)
         {
@@ -468,92 +547,277 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     return K + 4 + (col - m.i_state_extrinsics);
                 return K + 10 + (col - P.i_state_warp);
             };
-            double acc[8][8];
+            double acc[36];
 #pragma unroll
-            for(int i = 0; i < 8; i++)
-#pragma unroll
-                for(int j = 0; j < 8; j++) acc[i][j] = 0.0;
+            for(int i = 0; i < 36; i++) acc[i] = 0.0;
 
             for(int c0 = 0; c0 < NPTS; c0 += rows_cap)
             {
                 const int nr = min(rows_cap, NPTS - c0);
                 for(int i = t; i < nr*(SPL_TW/2); i += blockDim.x) ((double2*)Jd)[i] = make_double2(0.0, 0.0);
                 __syncthreads();
-                const int pbase = Jp[r0] + (2*c0 + xy)*L;
-                for(int e = t; e < nr*L; e += blockDim.x)
+                SPL_TICK(ts_zero)
+                const int pbase = p00 + (2*c0 + xy)*L;
+                // (four entries per thread asked for together: one entry at a time, its column only when the
+                //  value is not zero, is two memory round trips per entry: 10 000 cycles per 64 rows)
+                for(int e0 = 0; e0 < nr*L; e0 += 4*256)
                 {
-                    const int i = e / L, k = e - i*L;
-                    const int p = pbase + 2*i*L + k;
-                    const double v = Jv[p];
-                    if(v != 0.0) Jd[i*SPL_TW + local_of(Ji[p])] = v;
-                }
-                for(int i = t; i < nr; i += blockDim.x) Jd[i*SPL_TW + K + SPL_NDENSE + 6] = x[r0 + 2*(c0 + i) + xy];
-                __syncthreads();
-                if(tile_live)
-                    for(int i = 0; i < nr; i++)
+                    double v[4]; int ci[4], ii[4];
+#pragma unroll
+                    for(int u = 0; u < 4; u++)
                     {
-                        const double2* __restrict__ ra = (const double2*)(Jd + i*SPL_TW + 8*ty);
-                        const double2* __restrict__ rb = (const double2*)(Jd + i*SPL_TW + 8*tx);
-                        double va[8], vb[8];
-#pragma unroll
-                        for(int u = 0; u < 4; u++)
-                        {
-                            const double2 a2 = ra[u], b2 = rb[u];
-                            va[2*u] = a2.x; va[2*u+1] = a2.y; vb[2*u] = b2.x; vb[2*u+1] = b2.y;
-                        }
-#pragma unroll
-                        for(int a = 0; a < 8; a++)
-#pragma unroll
-                            for(int b = 0; b < 8; b++) acc[a][b] += va[a]*vb[b];
+                        const int e = e0 + 256*u + t;
+                        const bool ok = e < nr*L;
+                        const int i = ok ? e / L : 0, k = ok ? e - i*L : 0;
+                        const int p = pbase + 2*i*L + k;
+                        ii[u] = i;
+                        v[u]  = ok ? Jv[p] : 0.0;
+                        ci[u] = Ji[p];
                     }
+#pragma unroll
+                    for(int u = 0; u < 4; u++)
+                        if(v[u] != 0.0) Jd[ii[u]*SPL_TW + spl_pos(local_of(ci[u]))] = v[u];
+                }
+                for(int i = t; i < nr; i += blockDim.x) Jd[i*SPL_TW + spl_pos(lx)] = x[r0 + 2*(c0 + i) + xy];
                 __syncthreads();
+                SPL_TICK(ts_scatter)
+                switch(NS)
+                {
+                case 2: spl_gram_rows<2>(Jd, nr, ty, tx, acc); break;
+                case 3: spl_gram_rows<3>(Jd, nr, ty, tx, acc); break;
+                case 4: spl_gram_rows<4>(Jd, nr, ty, tx, acc); break;
+                case 5: spl_gram_rows<5>(Jd, nr, ty, tx, acc); break;
+                case 6: spl_gram_rows<6>(Jd, nr, ty, tx, acc); break;
+                case 7: spl_gram_rows<7>(Jd, nr, ty, tx, acc); break;
+                default:spl_gram_rows<8>(Jd, nr, ty, tx, acc); break;
+                }
+                __syncthreads();
+                SPL_TICK(ts_gram)
             }
 
-            // flush. local column -> what it is
-            //   kind 0: camera-block variable, idx = state index;  1: frame variable 0..5;  2: x;  3: nothing
-            auto what = [&](int c, int* idx) -> int
+            // out: the whole lower triangle is staged - the camera-block rows and the x row for the gather, the
+            // six frame rows for the second half of this (the unrolled stores stay simple: with the frame rows'
+            // three destinations in each of the 36 the kernel spilled registers)
+            double* __restrict__ G = plan.chunk_part + ((size_t)2*o + xy)*SPL_TRI;
+#pragma unroll
+            for(int a = 0; a < 8; a++)
             {
-                if(c < K)
+                const int row = ty + 16*a;
+                if(row >= NC) continue;
+                double* __restrict__ Grow = G + spl_tri(row) + tx;
+#pragma unroll
+                for(int b = 0; b <= a; b++)
+                    if(tx + 16*b <= row) Grow[16*b] = acc[((a*(a+1)) >> 1) + b];
+            }
+            __syncthreads();
+            // what belongs to the frame, added in place: rows K+12 .. K+17 against the camera-block columns (Bt)
+            // and against each other (D_f); the x row against the frame columns (g_f)
+            if(P.do_optimize_frames)
+                for(int e = t; e < 7*SPL_TW; e += blockDim.x)
                 {
-                    *idx = m.i_state_intrinsics + Ncs + 2*((iy0 + c / wx)*Nx + ix0 + c % wx) + xy;
-                    return 0;
-                }
-                const int d = c - K;
-                if(d < 4)           { *idx = m.i_state_intrinsics + d;       return (Ncs && m.i_state_intrinsics >= 0) ? 0 : 3; }
-                if(d < 10)          { *idx = m.i_state_extrinsics + (d - 4); return (m.i_state_extrinsics >= 0) ? 0 : 3; }
-                if(d < SPL_NDENSE)  { *idx = P.i_state_warp + (d - 10);      return 0; }
-                if(d < SPL_NDENSE+6){ *idx = d - SPL_NDENSE;                 return 1; }
-                *idx = 0;
-                return (d == SPL_NDENSE+6) ? 2 : 3;
-            };
-            if(tile_live)
-            {
-                int kb[8], ib[8];
-#pragma unroll
-                for(int b = 0; b < 8; b++) kb[b] = what(8*tx + b, &ib[b]);
-#pragma unroll
-                for(int a = 0; a < 8; a++)
-                {
-                    int ia;
-                    const int ka = what(8*ty + a, &ia);
-                    if(ka == 3) continue;
-#pragma unroll
-                    for(int b = 0; b < 8; b++)
+                    const int ia = e >> 7, col = e & (SPL_TW - 1);      // ia 6: the x row
+                    const int row = K + SPL_NDENSE + ia;
+                    const int ib = col - (K + SPL_NDENSE);
+                    if(col > row || (ia == 6 && (ib < 0 || ib >= 6))) continue;
+                    const double v = G[spl_tri(row) + col];
+                    if(v == 0.0) continue;
+                    if(ia == 6) O.g[nd.Nie + 6*f + ib] += v;
+                    else if(ib >= 0)
                     {
-                        const double v = acc[a][b];
-                        if(v == 0.0) continue;
-                        if(ka == 0 && kb[b] == 0)
-                            atomicAdd(&O.A[(size_t)state_to_SE(nd, ia)*nd.Nc + state_to_SE(nd, ib[b])], v);
-                        else if(ka == 0 && kb[b] == 2) atomicAdd(&O.g[ia], v);
-                        else if(ka == 1 && kb[b] == 0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, ib[b])], v);
-                        else if(ka == 1 && kb[b] == 1) atomicAdd(&O.D[(size_t)f*36 + ia*6 + ib[b]], v);
-                        else if(ka == 1 && kb[b] == 2) atomicAdd(&O.g[nd.Nie + 6*f + ia], v);
-                        else if(ka == 2 && kb[b] == 2) atomicAdd(&O.scalars[SC_NORM2_X], v);
-                        // (the other combinations are the mirrors of these)
+                        O.D[(size_t)f*36 + ia*6 + ib] += v;
+                        if(ib != ia) O.D[(size_t)f*36 + ib*6 + ia] += v;
+                    }
+                    else
+                    {
+                        const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m.i_state_intrinsics, m.i_state_extrinsics);
+                        if(cs < 0) continue;
+                        // a knot's column is written by this pass of this observation and by nobody else
+                        double* __restrict__ dst = &O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)];
+                        if(col < K) *dst = v; else *dst += v;
+                    }
+                }
+            // (the next pass, or observation, may add to the same entries of Bt, D, g from other threads)
+            __syncthreads();
+            SPL_TICK(ts_out)
+        }
+    }
+#ifdef SPL_TS
+    if((f == 0 || f == 400 || f == 799) && (t == 0 || t == 255))
+        printf("splined assembly f %d t %d: bbox %lld zero %lld scatter %lld gram %lld out %lld cycles\n", f, t, ts_bbox, ts_zero, ts_scatter, ts_gram, ts_out);
+#endif
+}
+
+#define SPLG_WAVES 8
+#define SPLG_BATCH 4      // passes whose loads are in flight together
+// rows of the camera block that are knots (a workgroup each), and the others + the x row (SPLG_E workgroups each)
+__host__ __device__ inline int splg_nknotrows(const DeviceProblem& P) { return P.Nintr_state > 0 ? P.Ncameras_intrinsics*(P.Nintr_state - P.Ncore_state) : 0; }
+__host__ __device__ inline int splg_ndense(const DeviceProblem& P, const NormalDims& nd) { return nd.Nc + 1 - splg_nknotrows(P); }
+__global__ __launch_bounds__(64*SPLG_WAVES)
+void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nwaves)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double accs[];        // [nwaves][Nc+1]
+    const OpDev& O = opref_get(R);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int stride = nd.Nc + 1;
+    const int Nx = P.cfg.spline_Nx, Ncs = P.Ncore_state;
+    const int nknot = splg_nknotrows(P), nintr = P.Nintr_state > 0 ? P.Ncameras_intrinsics*P.Nintr_state : 0;
+    // the row, and the observations this workgroup walks
+    int r, obs0, obs1, dense = -1, chunk = 0;
+    if((int)blockIdx.x < nknot)
+    {
+        const int per = P.Nintr_state - Ncs, ic = blockIdx.x / per;
+        r = ic*P.Nintr_state + Ncs + (blockIdx.x - ic*per);
+        obs0 = 0; obs1 = P.Nobs_board;
+    }
+    else
+    {
+        dense = (blockIdx.x - nknot) / SPLG_E; chunk = (blockIdx.x - nknot) % SPLG_E;
+        const int ncore = P.Nintr_state > 0 ? P.Ncameras_intrinsics*Ncs : 0;
+        r = (dense < ncore) ? (dense / Ncs)*P.Nintr_state + dense % Ncs : nintr + (dense - ncore);
+        const int per = (P.Nobs_board + SPLG_E - 1)/SPLG_E;
+        obs0 = min(P.Nobs_board, chunk*per); obs1 = min(P.Nobs_board, obs0 + per);
+    }
+    for(int i = t; i < nwaves*stride; i += blockDim.x) accs[i] = 0.0;
+    __syncthreads();
+    const bool xrow = (r == nd.Nc);
+    const int  sr   = xrow ? -1 : ((r < nd.Nie) ? r : nd.i_state_warp + (r - nd.Nie));     // state index of the row
+    if(wave < nwaves)
+    {
+        double* __restrict__ acc = accs + wave*stride;
+        const int per = (obs1 - obs0 + nwaves - 1)/nwaves;
+        const int w0 = min(obs1, obs0 + wave*per), w1 = min(obs1, w0 + per);
+        for(int ob = w0; ob < w1; ob += 64)
+        {
+            // lane l: does observation ob + l hold the row, and where (local row of the x pass, of the y pass)
+            const int o = ob + lane;
+            int lr0 = -1, lr1 = -1, kind = 2;       // kind 0: a knot's row, 1: a core row, 2: the others
+            SplHdr h = { 0, 0, -1, -1 };
+            int isi = -1, ise = -1;
+            if(o < w1)
+            {
+                h = plan.spl_hdr[o];
+                isi = P.board_meta[o].i_state_intrinsics; ise = P.board_meta[o].i_state_extrinsics;
+                if(h.wx >= 0)
+                {
+                    const int K = h.wx*h.wy;
+                    if(xrow) lr0 = lr1 = K + SPL_NDENSE + 6;
+                    else if(r >= nd.Nie) lr0 = lr1 = K + 10 + (r - nd.Nie);
+                    else if(ise >= 0 && sr >= ise && sr < ise + 6) lr0 = lr1 = K + 4 + (sr - ise);
+                    else if(isi >= 0 && sr >= isi && sr < isi + P.Nintr_state)
+                    {
+                        const int rel = sr - isi;
+                        if(rel < Ncs) { lr0 = lr1 = K + rel; kind = 1; }
+                        else
+                        {
+                            const int knot = (rel - Ncs) >> 1;
+                            const int ax = knot % Nx - h.ix0, ay = knot / Nx - h.iy0;
+                            kind = 0;
+                            if(ax >= 0 && ax < h.wx && ay >= 0 && ay < h.wy)
+                            {
+                                if((rel - Ncs) & 1) lr1 = ay*h.wx + ax; else lr0 = ay*h.wx + ax;
+                            }
+                        }
                     }
                 }
             }
+            unsigned long long mm = __ballot(lr0 >= 0 || lr1 >= 0);
+            while(mm)
+            {
+                // up to SPLG_BATCH observations: every load first, then the sums in order
+                double v[SPLG_BATCH][2][2], vc[SPLG_BATCH][2];
+                int    cs[SPLG_BATCH][2], csc[SPLG_BATCH], Kk[SPLG_BATCH];
+                bool   on[SPLG_BATCH][2];
+#pragma unroll
+                for(int k = 0; k < SPLG_BATCH; k++)
+                {
+                    const bool have = mm != 0ull;
+                    const int src = have ? __ffsll((long long)mm) - 1 : 0;
+                    if(have) mm &= mm - 1;
+                    const int oo  = ob + src;
+                    const int ix0 = __shfl(h.ix0, src), iy0 = __shfl(h.iy0, src), wx = __shfl(h.wx, src), wy = __shfl(h.wy, src);
+                    const int si  = __shfl(isi, src), se = __shfl(ise, src), kd = __shfl(kind, src);
+                    const int l0  = __shfl(lr0, src), l1 = __shfl(lr1, src);
+                    const int K   = wx*wy;
+                    Kk[k]  = K;
+                    csc[k] = (have && kd == 0 && lane < Ncs && si >= 0) ? si + lane : -1;
+#pragma unroll
+                    for(int it = 0; it < 2; it++)
+                    {
+                        const int lc = lane + 64*it;
+                        // the column's variable: the same in both passes but for the surface of a knot
+                        int c = spl_col_state(P, nd, lc, K, ix0, iy0, wx > 0 ? wx : 1, 0, si, se);
+                        if(kd == 1 && lc < K) c = -1;                      // a core row: the knots are above the diagonal
+                        if(xrow && lc == K + SPL_NDENSE + 6) c = -2;        // |x|^2
+                        cs[k][it] = have ? c : -1;
+                    }
+#pragma unroll
+                    for(int xy = 0; xy < 2; xy++)
+                    {
+                        const int lr = xy ? l1 : l0;
+                        on[k][xy] = have && lr >= 0;
+                        const double* __restrict__ Gp = plan.chunk_part + ((size_t)2*oo + xy)*SPL_TRI;
+#pragma unroll
+                        for(int it = 0; it < 2; it++)
+                        {
+                            const int lc = lane + 64*it;
+                            v[k][xy][it] = (on[k][xy] && lc <= lr && cs[k][it] != -1) ? Gp[spl_tri(lr) + lc] : 0.0;
+                        }
+                        // a knot's row against the core: below it in local order
+                        vc[k][xy] = (on[k][xy] && csc[k] >= 0) ? Gp[spl_tri(K + lane) + lr] : 0.0;
+                    }
+                }
+#pragma unroll
+                for(int k = 0; k < SPLG_BATCH; k++)
+#pragma unroll
+                    for(int xy = 0; xy < 2; xy++)
+                    {
+                        if(!on[k][xy]) continue;
+#pragma unroll
+                        for(int it = 0; it < 2; it++)
+                        {
+                            const int c = cs[k][it];
+                            const double vv = v[k][xy][it];
+                            if(c == -1 || vv == 0.0) continue;
+                            if(c == -2) acc[nd.Nc] += vv;
+                            else        acc[state_to_SE(nd, c + ((lane + 64*it < Kk[k]) ? xy : 0))] += vv;
+                        }
+                        if(csc[k] >= 0 && vc[k][xy] != 0.0) acc[state_to_SE(nd, csc[k])] += vc[k][xy];
+                    }
+            }
         }
+    }
+    __syncthreads();
+    // the waves' copies, in wave order
+    for(int c = t; c < stride; c += blockDim.x)
+    {
+        double s = 0.0;
+        for(int w = 0; w < nwaves; w++) s += accs[w*stride + c];
+        if(dense >= 0) { plan.spl_part[((size_t)dense*SPLG_E + chunk)*stride + c] = s; continue; }
+        if(s != 0.0 && c <= r) O.A[(size_t)r*nd.Nc + c] += s;
+    }
+}
+// the SPLG_E parts of a row every pass holds, in order
+__global__ __launch_bounds__(256)
+void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const int dense = blockIdx.x, stride = nd.Nc + 1;
+    const int nintr = P.Nintr_state > 0 ? P.Ncameras_intrinsics*P.Nintr_state : 0;
+    const int ncore = P.Nintr_state > 0 ? P.Ncameras_intrinsics*P.Ncore_state : 0;
+    const int r = (dense < ncore) ? (dense / P.Ncore_state)*P.Nintr_state + dense % P.Ncore_state : nintr + (dense - ncore);
+    for(int c = threadIdx.x; c < stride; c += blockDim.x)
+    {
+        double s = 0.0;
+        for(int e = 0; e < SPLG_E; e++) s += plan.spl_part[((size_t)dense*SPLG_E + e)*stride + c];
+        if(s == 0.0) continue;
+        if(r == nd.Nc)
+        {
+            if(c == nd.Nc) O.scalars[SC_NORM2_X] += s;
+            else           O.g[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)] += s;
+        }
+        else if(c <= r) O.A[(size_t)r*nd.Nc + c] += s;
     }
 }
 
@@ -2243,11 +2507,19 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
     double acc[QF_ROWS_PER_WAVE];
 #pragma unroll
     for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] = 0.0;
+    // (of A only the lower triangle: the splined assembly writes no other. An entry below the diagonal counts twice)
+    int rowc[QF_ROWS_PER_WAVE];
+#pragma unroll
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) rowc[rr] = min(row0 + rr, Nrows - 1);
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double vs = v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
 #pragma unroll
-        for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] += M[rr][c]*vs;
+        for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
+        {
+            const double wgt = (rowc[rr] >= nd.Nc) ? 1.0 : (c < rowc[rr]) ? 2.0 : (c == rowc[rr]) ? 1.0 : 0.0;
+            if(wgt != 0.0) acc[rr] += wgt*(M[rr][c]*vs);
+        }
     }
 #pragma unroll
     for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
@@ -2989,10 +3261,18 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         int rows_from = row0;
         if(by_rows && P.Nobs_board > 0 && P.Nframes > 0)
         {
-            const int rows_cap = std::min(P.W*P.H, 64);          // 64 KB of LDS: two workgroups per CU
+            const int rows_cap = std::min(P.W*P.H, SPL_ROWS_CAP);          // 64 KB of LDS: two workgroups per CU
             const size_t lds = (size_t)rows_cap*SPL_TW*sizeof(double);
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), lds, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji, rows_cap);
+            // a copy of the row per wave, as many waves as the LDS holds copies
+            const size_t row_bytes = (size_t)(nd.Nc + 1)*sizeof(double);
+            const int nwaves = (int)std::min<size_t>(SPLG_WAVES, (size_t)(150*1024)/row_bytes);
+            if(nwaves < 1) return hipErrorInvalidValue;
+            const int ndense = splg_ndense(P, nd);
+            hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(splg_nknotrows(P) + ndense*SPLG_E), dim3(64*SPLG_WAVES),
+                               nwaves*row_bytes, stream, P, nd, B.R, plan, nwaves);
+            hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(ndense), dim3(256), 0, stream, P, nd, B.R, plan);
             rows_from = 2*P.W*P.H*P.Nobs_board;
         }
         if(P.Nmeas > rows_from)

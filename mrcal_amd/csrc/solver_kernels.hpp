@@ -95,6 +95,10 @@ enum { PAIROP_NONE = 0,
 struct PairOp { int op, aux; };
 
 #define REDUCE_CHUNK 64     // observations of one pair summed by one workgroup (reduce_pair_chunk), in batches of 16 loads
+// splined models: the packed lower triangle of a pass's local Gram (128 local columns), and the knots it spans
+#define SPL_TRI (128*129/2)
+#define SPLG_E  8         // workgroups sharing a row of the camera block that every pass holds (assemble_splined_gather_kernel)
+struct SplHdr { int ix0, iy0, wx, wy; };      // wx < 0: the observation went row by row, nothing is staged
 struct AssemblyPlan
 {
     int* frame_obs_begin;  // [Nframes+1]
@@ -125,6 +129,9 @@ struct AssemblyPlan
     double* qf_part;          // [qf_part_n][4] per-workgroup partials of the quadratic form g^T N g (and of |g_E|^2)
     int     qf_part_n;
     double* dots_part;        // [NEb][2] per-block (|d_e|^2, d_e . g_e) of the back-substitution
+    // splined models (assemble_splined_kernel): chunk_part holds the staged Grams, [2 Nobs_board][SPL_TRI]
+    SplHdr* spl_hdr;          // [Nobs_board] the knot box of each observation
+    double* spl_part;         // [rows every pass holds][SPLG_E][Nc+1]
 };
 
 // state index -> S index (>=0) or -(1 + E index)
