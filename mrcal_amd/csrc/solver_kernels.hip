@@ -797,9 +797,53 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
         if(s != 0.0 && c <= r) O.A[(size_t)r*nd.Nc + c] += s;
     }
 }
-// the SPLG_E parts of a row every pass holds, in order
+// The regularization rows of a splined model (regularization_splined_kernel in kernels.hip): per knot a radial
+// and a tangential row on the knot's two variables, then one row per centre-pixel variable, then unity_cam01.
+// Rows 2 i and 2 i + 1 share their columns; no two PAIRS do. One lane per pair, the pair's rows one after the
+// other, plain adds: the same bits every time. (Row by row with atomics, the two rows of a knot race.) |x|^2 of a
+// workgroup's rows goes to row_part[blockIdx.x]; the combine kernel adds those in order. Lower triangle of A only
 __global__ __launch_bounds__(256)
-void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan)
+void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
+                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, double* __restrict__ row_part)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Jv = O.Jv;
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    double n2 = 0.0;
+    for(int k = 0; k < 2; k++)
+    {
+        const int r = row0 + 2*i + k;
+        if(r >= row1) break;
+        const double xr = O.x[r];
+        n2 += xr*xr;
+        const int p0 = Jp[r], p1 = Jp[r+1];
+        for(int p = p0; p < p1; p++)
+        {
+            const int ci = Ji[p];
+            const double vi = Jv[p];
+            if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
+            const int si = state_to_SE(nd, ci);
+            if(si < 0) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }       // a regularization row has camera-block variables only
+            O.g[ci] += vi*xr;
+            for(int q = p0; q < p1; q++)
+            {
+                const int cj = Ji[q];
+                if((unsigned)cj >= (unsigned)nd.Nstate) continue;
+                const int sj = state_to_SE(nd, cj);
+                if(sj >= 0 && sj <= si) O.A[(size_t)si*nd.Nc + sj] += vi*Jv[q];
+            }
+        }
+    }
+    for(int off = 32; off > 0; off >>= 1) n2 += __shfl_down(n2, off);
+    __shared__ double part[4];
+    if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if(threadIdx.x == 0) row_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// the SPLG_E parts of a row every pass holds, in order; and |x|^2 of the regularization rows
+__global__ __launch_bounds__(256)
+void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nrow_parts)
 {
     if(opref_skip(R)) return;
     const OpDev& O = opref_get(R);
@@ -811,6 +855,8 @@ void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, As
     {
         double s = 0.0;
         for(int e = 0; e < SPLG_E; e++) s += plan.spl_part[((size_t)dense*SPLG_E + e)*stride + c];
+        if(r == nd.Nc && c == nd.Nc)
+            for(int b = 0; b < nrow_parts; b++) s += plan.row_part[b];
         if(s == 0.0) continue;
         if(r == nd.Nc)
         {
@@ -3258,8 +3304,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
     {
         // splined models: the board rows observation by observation (local Grams in
         // LDS), everything else row by row
-        int rows_from = row0;
-        if(by_rows && P.Nobs_board > 0 && P.Nframes > 0)
+        int rows_from = row0, rows_to = P.Nmeas;
+        const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
+        if(splined_boards)
         {
             const int rows_cap = std::min(P.W*P.H, SPL_ROWS_CAP);          // 64 KB of LDS: two workgroups per CU
             const size_t lds = (size_t)rows_cap*SPL_TW*sizeof(double);
@@ -3272,19 +3319,27 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             const int ndense = splg_ndense(P, nd);
             hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(splg_nknotrows(P) + ndense*SPLG_E), dim3(64*SPLG_WAVES),
                                nwaves*row_bytes, stream, P, nd, B.R, plan, nwaves);
-            hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(ndense), dim3(256), 0, stream, P, nd, B.R, plan);
             rows_from = 2*P.W*P.H*P.Nobs_board;
+            // the regularization rows: in pairs (rows_pairs_kernel), after whatever other rows there are
+            if(P.i_meas_regularization >= rows_from && P.i_meas_regularization < P.Nmeas) rows_to = P.i_meas_regularization;
         }
-        if(P.Nmeas > rows_from)
+        if(rows_to > rows_from)
         {
             // many rows on a small camera block: sum in LDS first (rows_generic_lds_kernel)
-            if(nd.Nc <= ROWS_LDS_NC && P.Nmeas - rows_from >= 4096)
-                hipLaunchKernelGGL(rows_generic_lds_kernel, dim3((P.Nmeas - rows_from + 255)/256), dim3(256),
+            if(nd.Nc <= ROWS_LDS_NC && rows_to - rows_from >= 4096)
+                hipLaunchKernelGGL(rows_generic_lds_kernel, dim3((rows_to - rows_from + 255)/256), dim3(256),
                                    4*(size_t)(nd.Nc*nd.Nc + nd.Nc)*sizeof(double), stream,
-                                   nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+                                   nd, B.R, rows_from, rows_to, B.Jp, B.Ji);
             else
-                hipLaunchKernelGGL(rows_generic_kernel, dim3((P.Nmeas - rows_from + 63)/64), dim3(64), 0, stream,
-                                   nd, B.R, rows_from, P.Nmeas, B.Jp, B.Ji);
+                hipLaunchKernelGGL(rows_generic_kernel, dim3((rows_to - rows_from + 63)/64), dim3(64), 0, stream,
+                                   nd, B.R, rows_from, rows_to, B.Jp, B.Ji);
+        }
+        if(splined_boards)
+        {
+            const int nrp = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
+            if(nrp > 0)
+                hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp), dim3(256), 0, stream, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
+            hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(splg_ndense(P, nd)), dim3(256), 0, stream, P, nd, B.R, plan, nrp);
         }
     }
     return hipGetLastError();

@@ -305,15 +305,21 @@ def test_sfm_configuration_full_size(amd, ref_api):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("Ncameras,Nframes", ((3, 60), (8, 1000)))
-def test_solve_is_bit_reproducible(amd, Ncameras, Nframes):
+@pytest.mark.parametrize("Ncameras,Nframes,lensmodel,extra", (
+    (3, 60,   "LENSMODEL_OPENCV8", {}),
+    (8, 1000, "LENSMODEL_OPENCV8", {}),
+    # the splined assembly (staged local Grams, gathered in order; regularization rows in pairs): two cameras
+    # with the core, and BASELINE configuration 2
+    (2, 40,   "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", {}),
+    (1, 800,  "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120", {"do_optimize_intrinsics_core": False})))
+def test_solve_is_bit_reproducible(amd, Ncameras, Nframes, lensmodel, extra):
     """The block normal equations are summed in a fixed order (no floating-point
     atomics between the Grams and the Cholesky: DESIGN.md section 5): the same
     problem solved again takes the same steps and ends on the same bits. The
     metric's configuration, outlier rejection included, three times"""
     from mrcal_amd.resident import Problem
-    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel="LENSMODEL_OPENCV8",
-                                     object_width_n=10, object_height_n=10, seed=0)
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel=lensmodel,
+                                     object_width_n=10, object_height_n=10, seed=0, **extra)
     runs = []
     for i in range(3):
         with Problem(**copy_inputs(oi)) as p:
