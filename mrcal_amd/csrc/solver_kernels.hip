@@ -2180,16 +2180,37 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // 1024 threads with a readlane factorization of the 16x16 block, a substitution
 // chain per row for (b) and scalar FMAs for (c): 20-39 us. This: see DESIGN.md)
 #define LCH_PB 16
-__global__ __launch_bounds__(1024)
-void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
-                       double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status)
+// 16 x 16 tile (wi, wc) of A X^T, A and X 64 x 64 in LDS with row stride 65. Register v of lane l: row 16 wi +
+// l/16 + 4 v, column 16 wc + l%16. (X lower triangular: the products beyond its diagonal add zeros)
+__device__ __forceinline__
+syrk_d4 lch_tile_ABt(const double* __restrict__ A, const double* __restrict__ B, int wi, int wc, int r16, int kq, bool negate)
 {
-    if(skip != NULL && *skip) return;
+    syrk_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
+    {
+        const double av = A[(16*wi + r16)*(LCH_NB+1) + k0 + kq];
+        const double bv = B[(16*wc + r16)*(LCH_NB+1) + k0 + kq];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -av : av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+// With Xprev: the block is first brought up to date with the PREVIOUS panel (columns jprev .. jprev+63), whose
+// trailing update runs beside this workgroup in the same launch (lchol_update_kernel, which leaves this block
+// alone):  Lb = M[block rows][previous panel] Xprev^T,  block -= Lb Lb^T.  (Lb is not stored: the tile workgroups
+// of this launch read the same rows of the previous panel as they are. lchol_trsm of the next launch stores it)
+#define LCH_LDS_DOUBLES (2*LCH_NB*(LCH_NB+1) + CHOL_PB*CHOL_XLD + 3*64 + LCH_NB*(LCH_NB+1))
+__device__ __forceinline__
+void lchol_diag_block(int n, double* __restrict__ M, int j0,
+                      double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status,
+                      const double* __restrict__ Xprev, int jprev, double* __restrict__ lds /* LCH_LDS_DOUBLES, 16-byte aligned */)
+{
     constexpr int NB = LCH_NB, NR = 2*LCH_NB, LD = LCH_NB + 1;
     static_assert(LCH_PB == CHOL_PB, "chol_factor_diag16() is the block factorization");
-    __shared__ double A[NR*LD];                 // rows 0..63: the block; rows 64..127: the identity -> L^-T
-    __shared__ __attribute__((aligned(16))) double Xb[CHOL_PB*CHOL_XLD];      // L_pp^-T of the current 16 columns
-    __shared__ __attribute__((aligned(16))) double cb[3*64];                  // chol_factor_diag16's exchange + a sink
+    double* __restrict__ A  = lds;                       // rows 0..63: the block; rows 64..127: the identity -> L^-T
+    double* __restrict__ Xb = A + NR*LD;                 // [CHOL_PB][CHOL_XLD] L_pp^-T of the current 16 columns
+    double* __restrict__ cb = Xb + CHOL_PB*CHOL_XLD;     // [3*64] chol_factor_diag16's exchange + a sink
+    double* __restrict__ Pm = cb + 3*64;                 // [NB][LD] this block's rows of the previous panel
     __shared__ int    notpd;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -2202,6 +2223,36 @@ void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__
         const int i = idx / NB, j = idx - i*NB;
         A[i*LD + j]        = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
         A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    if(Xprev != NULL)
+    {
+        // (rows 64.. of A are free until the factorization starts: the identity is written again below)
+        double* __restrict__ Xp = A + NB*LD;
+        for(int idx = t; idx < NB*NB; idx += 1024)
+        {
+            const int i = idx / NB, k = idx - i*NB;
+            Pm[i*LD + k] = (i < nb) ? M[(size_t)(j0+i)*n + jprev + k] : 0.0;
+            Xp[i*LD + k] = Xprev[idx];
+        }
+        __syncthreads();
+        const int wi = wave_u >> 2, wc = wave_u & 3;
+        const syrk_d4 lb = lch_tile_ABt(Pm, Xp, wi, wc, r16, kq, false);
+        __syncthreads();
+#pragma unroll
+        for(int v = 0; v < 4; v++) Pm[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lb[v];
+        __syncthreads();
+        if(wc <= wi)
+        {
+            const syrk_d4 d = lch_tile_ABt(Pm, Pm, wi, wc, r16, kq, true);
+#pragma unroll
+            for(int v = 0; v < 4; v++) A[(16*wi + kq + 4*v)*LD + 16*wc + r16] += d[v];
+        }
+        __syncthreads();
+        for(int idx = t; idx < NB*NB; idx += 1024)
+        {
+            const int i = idx / NB, j = idx - i*NB;
+            A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
+        }
     }
     __syncthreads();
 
@@ -2273,99 +2324,131 @@ void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__
     }
     if(t == 0 && notpd) atomicExch(status, 1);
 }
-
-// rows m0 + 64 b .. of the panel (incl. the rhs row n):  L21 = M21 L11^-T,
-// i.e. out[i][j] = sum_{k<=j} M21[i][k] Linv[j][k]
-__global__ __launch_bounds__(256)
-void lchol_trsm_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
-                       const double* __restrict__ Linv)
+__global__ __launch_bounds__(1024)
+void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
+                       double* __restrict__ Linv, int* __restrict__ status)
 {
     if(skip != NULL && *skip) return;
-    __shared__ double A[LCH_NB][LCH_NB+1];
-    __shared__ double X[LCH_NB][LCH_NB+1];
-    const int t  = threadIdx.x;
-    const int nb = min(LCH_NB, n - j0);
-    const int m0 = j0 + nb;
-    const int r0 = m0 + blockIdx.x*LCH_NB;          // first row of this chunk; rows up to n (inclusive)
-    for(int idx = t; idx < LCH_NB*LCH_NB; idx += 256)
-    {
-        const int i = idx / LCH_NB, j = idx - i*LCH_NB;
-        X[i][j] = Linv[idx];
-        A[i][j] = (r0 + i <= n && j < nb) ? M[(size_t)(r0+i)*n + j0 + j] : 0.0;
-    }
-    __syncthreads();
-    // out = A X^T (X is lower triangular, zero above the diagonal: no special
-    // casing). Wave w: rows 16w.., the four 16-column tiles, k in steps of 4
-    const int wave = t >> 6, lane = t & 63;
-    const int r16 = lane & 15, kq = lane >> 4;
-    syrk_d4 acc[4];
-#pragma unroll
-    for(int c = 0; c < 4; c++) acc[c] = syrk_d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
-    {
-        // A operand: lane (i = l%16, k = l/16); B operand B[k][j] = X[j][k]: lane (j = l%16, k = l/16)
-        const double av = A[16*wave + r16][k0 + kq];
-#pragma unroll
-        for(int c = 0; c < 4; c++)
-            if(k0 < 16*(c+1))           // X[j][k] = 0 for k > j: tile c has nothing beyond k = 16c+15
-                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, X[16*c + r16][k0 + kq], acc[c], 0, 0, 0);
-    }
-    // D register v of lane l = D[l/16 + 4 v][l%16]
-#pragma unroll
-    for(int c = 0; c < 4; c++)
-#pragma unroll
-        for(int v = 0; v < 4; v++)
-        {
-            const int i = 16*wave + kq + 4*v, j = 16*c + r16;
-            if(r0 + i <= n && j < nb) M[(size_t)(r0+i)*n + j0 + j] = acc[c][v];
-        }
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    lchol_diag_block(n, M, j0, Linv, status, NULL, 0, lds);
 }
 
-// trailing update, 32 x 32 tiles (ti >= tj) of the rows/columns from m0 on:
-//   M[i][c] -= sum_k L[i][j0+k] L[c][j0+k]        i in [m0, n], c in [m0, n), c <= i
-// 4 waves, one 16x16 MFMA tile each; operands staged in LDS
-__global__ __launch_bounds__(256)
-void lchol_syrk_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0, int ntile)
+// One launch per panel (lchol_panel_kernel), three kinds of workgroup side by side:
+//   [0]  lchol_diag_kernel's work for the NEXT panel: its diagonal block, updated with this panel, factored
+//   [1 .. ntiles]  the trailing update of THIS panel by 64 x 64 tiles - each tile workgroup makes the rows of
+//        L21 = M21 X^T it needs itself (two 64 x 64 x 64 products on the MFMA, a few hundred ns) instead of
+//        waiting for a panel-solve launch;  M21 is left as it is while they read it
+//   [.. + ntrsm]  the panel solve of the PREVIOUS panel, in place: nobody reads those columns any more
+// The chain per panel was diagonal block -> panel solve -> trailing update, three dependent launches of 13 + 9 +
+// 8 us and the gaps between them; it is one launch as long as the longest of the three kinds
+// rows of the trailing matrix come in blocks of 64; the rhs row n is a block of its own (the last)
+__device__ __forceinline__
+void lch_tile_of(int q, int nbt, int* bi, int* bj)
 {
-    if(skip != NULL && *skip) return;
-    // tile pair from the linear index: ti >= tj
-    int ti = 0, p = blockIdx.x;
-    while(p > ti) { p -= ti + 1; ti++; }
-    const int tj = p;
-    (void)ntile;
-    const int nb = min(LCH_NB, n - j0);
-    const int m0 = j0 + nb;
-    const int i0 = m0 + 32*ti, c0 = m0 + 32*tj;
-    __shared__ double Li[32][LCH_NB+1];
-    __shared__ double Lc[32][LCH_NB+1];
-    const int t = threadIdx.x;
-    for(int idx = t; idx < 32*LCH_NB; idx += 256)
-    {
-        const int i = idx / LCH_NB, k = idx - i*LCH_NB;
-        Li[i][k] = (i0 + i <= n && k < nb) ? M[(size_t)(i0+i)*n + j0 + k] : 0.0;
-        Lc[i][k] = (c0 + i <  n && k < nb) ? M[(size_t)(c0+i)*n + j0 + k] : 0.0;
-    }
-    __syncthreads();
-    const int wave = t >> 6, lane = t & 63;
-    const int wi = wave >> 1, wc = wave & 1;            // this wave's 16x16 sub-tile
-    const int r16 = lane & 15, kq = lane >> 4;
-    syrk_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
-    {
-        // A[i][k] = L[i][k] (lane: i = l%16, k = l/16); B[k][j] = L[c][k] (lane: j = l%16, k = l/16)
-        const double av = Li[16*wi + r16][k0 + kq];
-        const double bv = Lc[16*wc + r16][k0 + kq];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-    // D register v of lane l = D[l/16 + 4 v][l%16]
+    // q = 0 ..: the pairs (bi, bj), bj <= bi < nbt, but (0, 0) [the diagonal workgroup's]; then (nbt, bj), bj < nbt
+    const int ntri = nbt*(nbt + 1)/2 - 1;
+    if(q >= ntri) { *bi = nbt; *bj = q - ntri; return; }
+    int i = 0, p = q + 1;
+    while(p > i) { p -= i + 1; i++; }
+    *bi = i; *bj = p;
+}
+__device__ __forceinline__
+void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __restrict__ X, int q,
+                       double* __restrict__ MI, double* __restrict__ MC, double* __restrict__ Xs)
+{
+    constexpr int NB = LCH_NB, LD = LCH_NB + 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r16 = lane & 15, kq = lane >> 4, wi = wave_u >> 2, wc = wave_u & 3;
+    const int m0 = j0 + NB;
+    const int nbt = (n - m0 + NB - 1)/NB;
+    int bi, bj;
+    lch_tile_of(q, nbt, &bi, &bj);
+    const bool rhs  = (bi == nbt), diag = (bi == bj);
+    const int  i0   = rhs ? n : m0 + NB*bi, c0 = m0 + NB*bj;
+    const int  ni   = rhs ? 1 : min(NB, n - i0), nc = min(NB, n - c0);     // rows of M in the two blocks
+    // the tile itself, asked for first
+    double tile[4];
 #pragma unroll
     for(int v = 0; v < 4; v++)
     {
-        const int i = i0 + 16*wi + kq + 4*v, c = c0 + 16*wc + r16;
-        if(i <= n && c < n && c <= i) M[(size_t)i*n + c] -= acc[v];
+        const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
+        const bool ok = i < ni && c < nc && (!diag || c <= i);
+        tile[v] = ok ? M[(size_t)(i0 + i)*n + c0 + c] : 0.0;
     }
+    for(int idx = t; idx < NB*NB; idx += 1024)
+    {
+        const int i = idx / NB, k = idx - i*NB;
+        MI[i*LD + k] = (i < ni) ? M[(size_t)(i0 + i)*n + j0 + k] : 0.0;
+        if(!diag) MC[i*LD + k] = (i < nc) ? M[(size_t)(c0 + i)*n + j0 + k] : 0.0;
+        Xs[i*LD + k] = X[idx];
+    }
+    __syncthreads();
+    const syrk_d4 li = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false);
+    syrk_d4 lc = li;
+    if(!diag) lc = lch_tile_ABt(MC, Xs, wi, wc, r16, kq, false);
+    __syncthreads();
+#pragma unroll
+    for(int v = 0; v < 4; v++)
+    {
+        MI[(16*wi + kq + 4*v)*LD + 16*wc + r16] = li[v];
+        if(!diag) MC[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lc[v];
+    }
+    __syncthreads();
+    const syrk_d4 d = lch_tile_ABt(MI, diag ? MI : MC, wi, wc, r16, kq, true);
+#pragma unroll
+    for(int v = 0; v < 4; v++)
+    {
+        const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
+        if(i < ni && c < nc && (!diag || c <= i)) M[(size_t)(i0 + i)*n + c0 + c] = tile[v] + d[v];
+    }
+}
+// rows r0 .. r0+63 (up to the rhs row n) of a panel:  L21 = M21 L11^-T, in place
+__device__ __forceinline__
+void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __restrict__ X, int b,
+                      double* __restrict__ MI, double* __restrict__ Xs)
+{
+    constexpr int NB = LCH_NB, LD = LCH_NB + 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r16 = lane & 15, kq = lane >> 4, wi = wave_u >> 2, wc = wave_u & 3;
+    const int nb = min(NB, n - j0);
+    const int r0 = j0 + nb + b*NB;
+    for(int idx = t; idx < NB*NB; idx += 1024)
+    {
+        const int i = idx / NB, k = idx - i*NB;
+        MI[i*LD + k] = (r0 + i <= n && k < nb) ? M[(size_t)(r0 + i)*n + j0 + k] : 0.0;
+        Xs[i*LD + k] = X[idx];
+    }
+    __syncthreads();
+    const syrk_d4 l = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false);
+#pragma unroll
+    for(int v = 0; v < 4; v++)
+    {
+        const int i = 16*wi + kq + 4*v, j = 16*wc + r16;
+        if(r0 + i <= n && j < nb) M[(size_t)(r0 + i)*n + j0 + j] = l[v];
+    }
+}
+// block 0: the next panel's diagonal block (if there is a next panel); then the tiles; then the previous panel's solve
+__global__ __launch_bounds__(1024)
+void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
+                        int j0, const double* __restrict__ X, int ntiles,
+                        double* __restrict__ Xnext, int* __restrict__ status,
+                        int jprev, const double* __restrict__ Xprev, int ntrsm)
+{
+    if(skip != NULL && *skip) return;
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    static_assert(LCH_LDS_DOUBLES >= 3*LCH_NB*(LCH_NB+1), "the tile workgroups take three 64 x 65 arrays");
+    double* __restrict__ MI = lds;
+    double* __restrict__ MC = MI + LCH_NB*(LCH_NB+1);
+    double* __restrict__ Xs = MC + LCH_NB*(LCH_NB+1);
+    const int b = (int)blockIdx.x - 1;
+    if(b < 0)
+    {
+        if(Xnext != NULL) lchol_diag_block(n, M, j0 + LCH_NB, Xnext, status, X, j0, lds);
+    }
+    else if(b < ntiles) lchol_update_tile(n, M, j0, X, b, MI, MC, Xs);
+    else if(b < ntiles + ntrsm) lchol_trsm_block(n, M, jprev, Xprev, b - ntiles, MI, Xs);
 }
 
 // L^T d = z, panel by panel from the last: one workgroup. z is row n of M; on
@@ -2450,21 +2533,28 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    auto Xof = [&](int p) { return Linv + (size_t)p*LCH_NB*LCH_NB; };
+    // rows below a panel, the rhs row included, in blocks of 64 (the panel solve's)
+    auto ntrsm_of = [&](int p) { const int m0 = std::min(n, (p + 1)*LCH_NB); return (n + 1 - m0 + LCH_NB - 1)/LCH_NB; };
+    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, 0, Xof(0), status);
     for(int p = 0; p < npanels; p++)
     {
         const int j0 = p*LCH_NB;
-        const int nb = (n - j0 < LCH_NB) ? n - j0 : LCH_NB;
-        const int m0 = j0 + nb;
-        double* Lp = Linv + (size_t)p*LCH_NB*LCH_NB;
-        hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, j0, Lp, status);
-        const int nrows = n + 1 - m0;       // rows below, incl. the rhs row
-        hipLaunchKernelGGL(lchol_trsm_kernel, dim3((nrows + LCH_NB - 1)/LCH_NB), dim3(256), 0, stream, n, skip, M, j0, Lp);
-        if(m0 < n)
-        {
-            const int ntile = (nrows + 31)/32;
-            hipLaunchKernelGGL(lchol_syrk_kernel, dim3(ntile*(ntile+1)/2), dim3(256), 0, stream, n, skip, M, j0, ntile);
-        }
+        const int m0 = std::min(n, j0 + LCH_NB);
+        const bool has_next = (p + 1 < npanels);
+        // tiles: the 64-row blocks of the trailing matrix by pairs, without the next diagonal block, and the rhs row against each
+        const int nbt = (n - m0 + LCH_NB - 1)/LCH_NB;
+        const int ntiles = has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
+        const int ntrsm  = (p > 0) ? ntrsm_of(p - 1) : 0;
+        if(!has_next && ntrsm == 0) continue;
+        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm), dim3(1024), 0, stream,
+                           n, skip, M, j0, (const double*)Xof(p), ntiles, has_next ? Xof(p + 1) : (double*)NULL, status,
+                           (p > 0) ? j0 - LCH_NB : 0, (const double*)((p > 0) ? Xof(p - 1) : Xof(0)), ntrsm);
     }
+    // the last panel's solve: the rhs row alone
+    hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1)), dim3(1024), 0, stream,
+                       n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
+                       (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1));
     hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), (size_t)n*sizeof(double), stream, n, skip, M, Linv);
     return hipGetLastError();
 }
