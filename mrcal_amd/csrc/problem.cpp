@@ -76,6 +76,9 @@ mrcal_amd_problem::~mrcal_amd_problem()
     for(hipEvent_t e : ev_pool) hipEventDestroy(e);
     if(ev_j0)  hipEventDestroy(ev_j0);
     if(ev_j1)  hipEventDestroy(ev_j1);
+    if(ev_fork) hipEventDestroy(ev_fork);
+    if(ev_join) hipEventDestroy(ev_join);
+    if(side_stream) hipStreamDestroy(side_stream);
     if(stream) hipStreamDestroy(stream);
 }
 
@@ -633,6 +636,9 @@ mrcal_amd_problem_create(const double*                 intrinsics,
 
     bool ok = true;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking), ok = false);
+    HIP_TRY(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking), ok = false);
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), ok = false);
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j0), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j1), ok = false);
 

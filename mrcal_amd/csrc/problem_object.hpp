@@ -40,6 +40,10 @@ struct mrcal_amd_problem
 
     hipStream_t stream = NULL;
     hipEvent_t  ev_j0  = NULL, ev_j1 = NULL;
+    // a second stream for work of a step that nothing on the first one waits for at once (the gather of the
+    // splined assembly runs beside the block elimination and the SYRK): fork / join events
+    hipStream_t side_stream = NULL;
+    hipEvent_t  ev_fork = NULL, ev_join = NULL;
     bool        have_jacobian_timing = false;
     bool        capturing = false;      // a hipGraph capture is in progress on the stream
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region

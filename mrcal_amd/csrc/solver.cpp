@@ -110,6 +110,7 @@ Step2Args step2_args(mrcal_amd_problem* P)
     a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
     a.comm2 = (P->comm != NULL || P->sharded_external) ? P->d_comm : NULL;
     a.snap  = P->capturing ? NULL : P->snap_target;
+    a.side = P->side_stream; a.ev_fork = P->ev_fork; a.ev_join = P->ev_join;
     return a;
 }
 

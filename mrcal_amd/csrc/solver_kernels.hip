@@ -2216,6 +2216,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r16 = lane & 15, kq = lane >> 4;
     const int nb = min(NB, n - j0);
+#ifdef LCH_TS
+    long long ts[6]; ts[0] = clock64();
+#endif
     if(t == 0) notpd = 0;
     // the block, padded with the identity (so that a short last panel factors too)
     for(int idx = t; idx < NB*NB; idx += 1024)
@@ -2224,6 +2227,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
         A[i*LD + j]        = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
         A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
     }
+#ifdef LCH_TS
+    ts[1] = clock64();
+#endif
     if(Xprev != NULL)
     {
         // (rows 64.. of A are free until the factorization starts: the identity is written again below)
@@ -2256,6 +2262,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     }
     __syncthreads();
 
+#ifdef LCH_TS
+    ts[2] = clock64();
+#endif
     auto diag = [&](int base) __attribute__((always_inline))
     {
         double* __restrict__ rowL = &A[(base + r16)*LD + base];
@@ -2315,6 +2324,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
         }
         __syncthreads();
     }
+#ifdef LCH_TS
+    ts[3] = clock64();
+#endif
     // L back into the matrix; X[i][k] = (L^-T)[k][i] = row 64+k, column i
     for(int idx = t; idx < NB*NB; idx += 1024)
     {
@@ -2323,6 +2335,10 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
         Linv[idx] = (j <= i) ? A[(NB + j)*LD + i] : 0.0;
     }
     if(t == 0 && notpd) atomicExch(status, 1);
+#ifdef LCH_TS
+    ts[4] = clock64();
+    if(t == 0 && (j0 == 128 || j0 == 640)) printf("lchol diag j0 %d: issue loads %lld, pre-update %lld, factor %lld, store %lld cycles\n", j0, ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], ts[4]-ts[3]);
+#endif
 }
 __global__ __launch_bounds__(1024)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
@@ -2364,6 +2380,9 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
     const int nbt = (n - m0 + NB - 1)/NB;
     int bi, bj;
     lch_tile_of(q, nbt, &bi, &bj);
+#ifdef LCH_TS
+    const long long tt0 = clock64();
+#endif
     const bool rhs  = (bi == nbt), diag = (bi == bj);
     const int  i0   = rhs ? n : m0 + NB*bi, c0 = m0 + NB*bj;
     const int  ni   = rhs ? 1 : min(NB, n - i0), nc = min(NB, n - c0);     // rows of M in the two blocks
@@ -2402,6 +2421,9 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
         const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
         if(i < ni && c < nc && (!diag || c <= i)) M[(size_t)(i0 + i)*n + c0 + c] = tile[v] + d[v];
     }
+#ifdef LCH_TS
+    if(t == 0 && (j0 == 64 || j0 == 576) && (q == 0 || q == 40)) printf("lchol tile j0 %d q %d: %lld cycles\n", j0, q, clock64() - tt0);
+#endif
 }
 // rows r0 .. r0+63 (up to the rhs row n) of a panel:  L21 = M21 L11^-T, in place
 __device__ __forceinline__
@@ -2647,6 +2669,7 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
     int rowc[QF_ROWS_PER_WAVE];
 #pragma unroll
     for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) rowc[rr] = min(row0 + rr, Nrows - 1);
+#pragma unroll 2
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double vs = v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
@@ -3291,6 +3314,8 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     const double yv = (lane < de) ? y[e0 + lane] : 0.0;
     const double gv = (lane < de) ? O.g[nd.Nie + e0 + lane] : 0.0;
     double part[6] = {0,0,0,0,0,0};
+    // (four column groups asked for together: with a 1206-variable camera block the loop is 19 round trips otherwise)
+#pragma unroll 4
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double d = ds[c];
@@ -3374,8 +3399,10 @@ static int    assemble_row_blocks(const DeviceProblem& P)
 //   board problems with Grams: assemble_factor_kernel (frames | pair chunks | generic rows), then
 //   assemble_finalize (here: its own launch; in the fused step it rides along in the SYRK launch)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
-                           const EvalBuffers& B, hipStream_t stream)
+                           const EvalBuffers& B, hipStream_t stream,
+                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool* forked)
 {
+    if(forked) *forked = false;
     // splined models: no per-observation Gram; every row goes through the generic path
     const bool by_rows = (P.lens_type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
     const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
@@ -3395,6 +3422,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         // splined models: the board rows observation by observation (local Grams in
         // LDS), everything else row by row
         int rows_from = row0, rows_to = P.Nmeas;
+        hipStream_t gstream = stream;
         const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
         if(splined_boards)
         {
@@ -3407,11 +3435,21 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             const int nwaves = (int)std::min<size_t>(SPLG_WAVES, (size_t)(150*1024)/row_bytes);
             if(nwaves < 1) return hipErrorInvalidValue;
             const int ndense = splg_ndense(P, nd);
-            hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(splg_nknotrows(P) + ndense*SPLG_E), dim3(64*SPLG_WAVES),
-                               nwaves*row_bytes, stream, P, nd, B.R, plan, nwaves);
             rows_from = 2*P.W*P.H*P.Nobs_board;
-            // the regularization rows: in pairs (rows_pairs_kernel), after whatever other rows there are
             if(P.i_meas_regularization >= rows_from && P.i_meas_regularization < P.Nmeas) rows_to = P.i_meas_regularization;
+            // What follows the workgroups above writes the camera block's A and g, and |x|^2: nothing the block
+            // elimination or the SYRK read. With a side stream it runs beside them (unless there are other rows
+            // - discrete points - that add to A with atomics at the same time)
+            if(side != NULL && forked != NULL && rows_to == rows_from)
+            {
+                hipError_t e = hipEventRecord(ev_fork, stream);           if(e != hipSuccess) return e;
+                e = hipStreamWaitEvent(side, ev_fork, 0);                 if(e != hipSuccess) return e;
+                *forked = true;
+                gstream = side;
+            }
+            hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(splg_nknotrows(P) + ndense*SPLG_E), dim3(64*SPLG_WAVES),
+                               nwaves*row_bytes, gstream, P, nd, B.R, plan, nwaves);
+            // (the regularization rows: in pairs, rows_pairs_kernel, after whatever other rows there are)
         }
         if(rows_to > rows_from)
         {
@@ -3428,8 +3466,13 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         {
             const int nrp = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
             if(nrp > 0)
-                hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp), dim3(256), 0, stream, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
-            hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(splg_ndense(P, nd)), dim3(256), 0, stream, P, nd, B.R, plan, nrp);
+                hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp), dim3(256), 0, gstream, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
+            hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(splg_ndense(P, nd)), dim3(256), 0, gstream, P, nd, B.R, plan, nrp);
+            if(gstream != stream)
+            {
+                const hipError_t e = hipEventRecord(ev_join, gstream);
+                if(e != hipSuccess) return e;
+            }
         }
     }
     return hipGetLastError();
@@ -3664,9 +3707,12 @@ hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream)
     return hipGetLastError();
 }
 
+// (launch_step2_assemble left work on the side stream: launch_step2_reduce, which always follows it, joins)
+static thread_local bool step2_side_pending = false;
 // the block normal equations of the point the flags name, and the elimination of its frame/point blocks
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream)
 {
+    step2_side_pending = false;
     const DeviceProblem& P = *a.P;
     const NormalDims& nd = *a.nd;
     const BlockRanges& br = *a.br;
@@ -3687,7 +3733,10 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
         // no Grams (splined models, problems without boards): the atomic row-by-row assembly of the evaluated point
         EvalBuffers B; memset(&B, 0, sizeof(B));
         B.R = OpRef{ a.ops, sel_eval, &fl->skip_asm }; B.Jp = (int32_t*)a.Jp; B.Ji = (int32_t*)a.Ji;
-        launch_assemble(P, nd, br, *a.plan, B, stream);
+        bool forked = false;
+        const hipError_t e = launch_assemble(P, nd, br, *a.plan, B, stream, a.side, a.ev_fork, a.ev_join, &forked);
+        if(e != hipSuccess) return e;
+        step2_side_pending = forked;
     }
     // the blocks the fused kernel did not eliminate: all of them on the row-by-row
     // path; the point blocks otherwise (their rows are accumulated in the same launch)
@@ -3719,6 +3768,13 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
         ride.npos = gram_stride(P.Ndist); ride.ops = a.ops; ride.sel = &fl->elim_sel; ride.skip = &fl->skip_asm; ride.plan = *a.plan;
     }
     const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream);
+    // A, g of the camera block and |x|^2 may still be on their way on the side stream
+    if(step2_side_pending)
+    {
+        const hipError_t e = hipStreamWaitEvent(stream, a.ev_join, 0);
+        if(e != hipSuccess) return e;
+        step2_side_pending = false;
+    }
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nred = ((npairs*256 + nb*16)*SRED_SPLIT + 255)/256;
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,

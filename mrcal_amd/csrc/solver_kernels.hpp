@@ -279,6 +279,8 @@ struct Step2Args
     const int32_t* Jp; const int32_t* Ji; double* step; bool is_leader;
     const double* comm2;     // sharded: [4] g^T N g, |g_E|^2, |gn_E|^2, gn_E . g_E summed over the ranks; NULL: single GPU
     SolverCtl* snap;         // host-visible (pinned) copy of the control block to leave behind at the end of the step; NULL: none
+    // a side stream with its fork and join events (NULL: none): _assemble may leave work there that _reduce waits for
+    hipStream_t side; hipEvent_t ev_fork, ev_join;
 };
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
@@ -290,8 +292,11 @@ int64_t    step2_comm1_doubles(const NormalDims& nd);
 hipError_t launch_mask_state(const NormalDims& nd, const BlockRanges& br, bool is_leader, double* b, hipStream_t stream);
 const int* solver_ctl_skip_eval2(const SolverCtl* ctl);
 // host-driven evaluation: deterministic block normal equations of the point R from the Grams (no elimination)
+// (with side and the two events: what only A, g of the camera block and |x|^2 wait for goes to the side stream,
+//  forked after the kernels Bt, D come from; *forked tells the caller to wait for ev_join before it reads those)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
-                           const EvalBuffers& B, hipStream_t stream);
+                           const EvalBuffers& B, hipStream_t stream,
+                           hipStream_t side = NULL, hipEvent_t ev_fork = NULL, hipEvent_t ev_join = NULL, bool* forked = NULL);
 
 // the control block is followed in memory by its derived flags
 size_t     solver_ctl_bytes();
