@@ -2180,21 +2180,28 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
 // 1024 threads with a readlane factorization of the 16x16 block, a substitution
 // chain per row for (b) and scalar FMAs for (c): 20-39 us. This: see DESIGN.md)
 #define LCH_PB 16
-// 16 x 16 tile (wi, wc) of A X^T, A and X 64 x 64 in LDS with row stride 65. Register v of lane l: row 16 wi +
-// l/16 + 4 v, column 16 wc + l%16. (X lower triangular: the products beyond its diagonal add zeros)
+// 16 x 16 tile (wi, wc) of A B^T over k < kmax (a multiple of 16), A and B 64 x 64 in LDS with row stride 65.
+// Register v of lane l: row 16 wi + l/16 + 4 v, column 16 wc + l%16.
+// B = X, lower triangular: tile column wc has nothing beyond k = 16 wc + 15. A v_mfma_f64_16x16x4 is ~110 cycles
+// and the four waves of a SIMD take turns: a workgroup's 64^3 product is 7000 cycles of ONE CU. So the callers
+// deal the tiles so that every SIMD (wave % 4) gets every tile column: 4+8+12+16 instructions instead of 4 x 16
 __device__ __forceinline__
-syrk_d4 lch_tile_ABt(const double* __restrict__ A, const double* __restrict__ B, int wi, int wc, int r16, int kq, bool negate)
+syrk_d4 lch_tile_ABt(const double* __restrict__ A, const double* __restrict__ B, int wi, int wc, int r16, int kq, bool negate,
+                     int kmax = LCH_NB)
 {
     syrk_d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for(int k1 = 0; k1 < kmax; k1 += 16)
 #pragma unroll
-    for(int k0 = 0; k0 < LCH_NB; k0 += 4)
-    {
-        const double av = A[(16*wi + r16)*(LCH_NB+1) + k0 + kq];
-        const double bv = B[(16*wc + r16)*(LCH_NB+1) + k0 + kq];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -av : av, bv, acc, 0, 0, 0);
-    }
+        for(int k0 = k1; k0 < k1 + 16; k0 += 4)
+        {
+            const double av = A[(16*wi + r16)*(LCH_NB+1) + k0 + kq];
+            const double bv = B[(16*wc + r16)*(LCH_NB+1) + k0 + kq];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(negate ? -av : av, bv, acc, 0, 0, 0);
+        }
     return acc;
 }
+// tile (wi, wc) of a wave for a product with X: the SIMD is wave % 4 = wi, so each SIMD has one tile of every column
+__device__ __forceinline__ void lch_tile_for_X(int wave, int* wi, int* wc) { *wi = wave & 3; *wc = wave >> 2; }
 // With Xprev: the block is first brought up to date with the PREVIOUS panel (columns jprev .. jprev+63), whose
 // trailing update runs beside this workgroup in the same launch (lchol_update_kernel, which leaves this block
 // alone):  Lb = M[block rows][previous panel] Xprev^T,  block -= Lb Lb^T.  (Lb is not stored: the tile workgroups
@@ -2241,17 +2248,21 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
             Xp[i*LD + k] = Xprev[idx];
         }
         __syncthreads();
-        const int wi = wave_u >> 2, wc = wave_u & 3;
-        const syrk_d4 lb = lch_tile_ABt(Pm, Xp, wi, wc, r16, kq, false);
+        int wi, wc;
+        lch_tile_for_X(wave_u, &wi, &wc);
+        const syrk_d4 lb = lch_tile_ABt(Pm, Xp, wi, wc, r16, kq, false, 16*(wc + 1));
         __syncthreads();
 #pragma unroll
         for(int v = 0; v < 4; v++) Pm[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lb[v];
         __syncthreads();
-        if(wc <= wi)
+        // the ten tiles of the lower triangle on waves 0..9: three, three, two and two to a SIMD
+        if(wave_u < 10)
         {
-            const syrk_d4 d = lch_tile_ABt(Pm, Pm, wi, wc, r16, kq, true);
+            int ti = 0, tj = wave_u;
+            while(tj > ti) { tj -= ti + 1; ti++; }
+            const syrk_d4 d = lch_tile_ABt(Pm, Pm, ti, tj, r16, kq, true);
 #pragma unroll
-            for(int v = 0; v < 4; v++) A[(16*wi + kq + 4*v)*LD + 16*wc + r16] += d[v];
+            for(int v = 0; v < 4; v++) A[(16*ti + kq + 4*v)*LD + 16*tj + r16] += d[v];
         }
         __syncthreads();
         for(int idx = t; idx < NB*NB; idx += 1024)
@@ -2274,8 +2285,16 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
                                             [&](int c) -> double* { return (lane < 16) ? rowL + c : sink; });
         if(bad && lane == 0) notpd = 1;
     };
+#ifdef LCH_TS
+    long long tsd = 0, tsb = 0, tsc = 0, tsy = 0, tq = clock64(), tq1;
+#define LCH_TICK(w) { tq1 = clock64(); w += tq1 - tq; tq = tq1; }
+#else
+#define LCH_TICK(w)
+#endif
     if(wave == 0) diag(0);
+    LCH_TICK(tsd)
     __syncthreads();
+    LCH_TICK(tsy)
 
 #pragma unroll 1
     for(int base = 0; base < NB; base += LCH_PB)
@@ -2295,7 +2314,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
 #pragma unroll
             for(int v = 0; v < 4; v++) A[(m0 + 16*ti + kq + 4*v)*LD + base + r16] = acc[v];
         }
+        LCH_TICK(tsb)
         __syncthreads();
+        LCH_TICK(tsy)
         // (c) tiles (ta, tb), tb <= ta, of rows m0.. x columns m0..63; (0,0) = the next diagonal block: wave 0
         {
             const int ntr = (NR - m0)/16, ntc = (NB - m0)/16;
@@ -2320,9 +2341,12 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
 #pragma unroll
                 for(int v = 0; v < 4; v++) pc[4*v*LD] = acc[v];
             }
+            LCH_TICK(tsc)
             if(wave == 0 && m0 < NB) diag(m0);
+            LCH_TICK(tsd)
         }
         __syncthreads();
+        LCH_TICK(tsy)
     }
 #ifdef LCH_TS
     ts[3] = clock64();
@@ -2337,7 +2361,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     if(t == 0 && notpd) atomicExch(status, 1);
 #ifdef LCH_TS
     ts[4] = clock64();
-    if(t == 0 && (j0 == 128 || j0 == 640)) printf("lchol diag j0 %d: issue loads %lld, pre-update %lld, factor %lld, store %lld cycles\n", j0, ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], ts[4]-ts[3]);
+    if((t == 0 || t == 64*5) && (j0 == 128 || j0 == 640)) printf("lchol diag j0 %d t %d: issue loads %lld, pre-update %lld, factor %lld (diag16 %lld, b %lld, c %lld, barriers %lld), store %lld cycles\n", j0, t, ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], tsd, tsb, tsc, tsy, ts[4]-ts[3]);
 #endif
 }
 __global__ __launch_bounds__(1024)
@@ -2376,6 +2400,8 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
     const int t = threadIdx.x, lane = t & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r16 = lane & 15, kq = lane >> 4, wi = wave_u >> 2, wc = wave_u & 3;
+    int xi, xc;
+    lch_tile_for_X(wave_u, &xi, &xc);
     const int m0 = j0 + NB;
     const int nbt = (n - m0 + NB - 1)/NB;
     int bi, bj;
@@ -2403,15 +2429,15 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
         Xs[i*LD + k] = X[idx];
     }
     __syncthreads();
-    const syrk_d4 li = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false);
+    const syrk_d4 li = lch_tile_ABt(MI, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
     syrk_d4 lc = li;
-    if(!diag) lc = lch_tile_ABt(MC, Xs, wi, wc, r16, kq, false);
+    if(!diag) lc = lch_tile_ABt(MC, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
     __syncthreads();
 #pragma unroll
     for(int v = 0; v < 4; v++)
     {
-        MI[(16*wi + kq + 4*v)*LD + 16*wc + r16] = li[v];
-        if(!diag) MC[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lc[v];
+        MI[(16*xi + kq + 4*v)*LD + 16*xc + r16] = li[v];
+        if(!diag) MC[(16*xi + kq + 4*v)*LD + 16*xc + r16] = lc[v];
     }
     __syncthreads();
     const syrk_d4 d = lch_tile_ABt(MI, diag ? MI : MC, wi, wc, r16, kq, true);
@@ -2433,7 +2459,9 @@ void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __res
     constexpr int NB = LCH_NB, LD = LCH_NB + 1;
     const int t = threadIdx.x, lane = t & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r16 = lane & 15, kq = lane >> 4, wi = wave_u >> 2, wc = wave_u & 3;
+    const int r16 = lane & 15, kq = lane >> 4;
+    int wi, wc;
+    lch_tile_for_X(wave_u, &wi, &wc);
     const int nb = min(NB, n - j0);
     const int r0 = j0 + nb + b*NB;
     for(int idx = t; idx < NB*NB; idx += 1024)
@@ -2443,7 +2471,7 @@ void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __res
         Xs[i*LD + k] = X[idx];
     }
     __syncthreads();
-    const syrk_d4 l = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false);
+    const syrk_d4 l = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false, 16*(wc + 1));
 #pragma unroll
     for(int v = 0; v < 4; v++)
     {
@@ -2468,8 +2496,14 @@ void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict_
     if(b < 0)
     {
         if(Xnext != NULL) lchol_diag_block(n, M, j0 + LCH_NB, Xnext, status, X, j0, lds);
+        return;
     }
-    else if(b < ntiles) lchol_update_tile(n, M, j0, X, b, MI, MC, Xs);
+    // The diagonal workgroup is the long one (24 us against 9), and it starts with a cold read of 96 KB. With
+    // two hundred workgroups asking for theirs at the same moment that read took 6 us; the others wait 3 first
+#ifndef LCH_NO_SLEEP
+    if(Xnext != NULL) __builtin_amdgcn_s_sleep(127);
+#endif
+    if(b < ntiles) lchol_update_tile(n, M, j0, X, b, MI, MC, Xs);
     else if(b < ntiles + ntrsm) lchol_trsm_block(n, M, jprev, Xprev, b - ntiles, MI, Xs);
 }
 
