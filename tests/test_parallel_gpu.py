@@ -18,10 +18,14 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _problem(amd_api):
+SPLINED = "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120"
+
+
+def _problem(amd_api, lensmodel="LENSMODEL_OPENCV8"):
     from mrcal_amd.synthetic import make_calibration_problem
-    return make_calibration_problem(amd_api, Ncameras=3, Nframes=11, lensmodel="LENSMODEL_OPENCV8",
-                                    object_width_n=10, object_height_n=10, seed=5)[0]
+    extra = {"do_optimize_intrinsics_core": False} if "SPLINED" in lensmodel else {}
+    return make_calibration_problem(amd_api, Ncameras=3, Nframes=11, lensmodel=lensmodel,
+                                    object_width_n=10, object_height_n=10, seed=5, **extra)[0]
 
 
 def test_world1_python_driver_matches_cpp_solver(amd):
@@ -46,7 +50,7 @@ def test_world1_python_driver_matches_cpp_solver(amd):
     assert Ncoll <= 2*Ntrials + 4*(s_py["Noutlier_passes"] + 1) + 1
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, lensmodel):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
@@ -56,7 +60,7 @@ def _worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import mrcal_amd
     from mrcal_amd.parallel import ShardedProblem
-    oi = _problem(mrcal_amd._api)
+    oi = _problem(mrcal_amd._api, lensmodel)
     sp = ShardedProblem(_driver="python", **oi)
     st = sp.solve()
     b  = sp.b_packed()
@@ -76,17 +80,19 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_world2_sharded_on_one_device_matches_single(amd, tmp_path):
+# (the splined models: the staged assembly and its gather, a shard's frames only)
+@pytest.mark.parametrize("lensmodel", ("LENSMODEL_OPENCV8", SPLINED))
+def test_world2_sharded_on_one_device_matches_single(amd, tmp_path, lensmodel):
     import torch.multiprocessing as mp
     from mrcal_amd.resident import Problem
-    oi = _problem(amd._api)
+    oi = _problem(amd._api, lensmodel)
     with Problem(**oi) as p:
         s1 = p.solve()
         b1 = p.b_packed()
     out = str(tmp_path / "w2.npz")
     port = 29600 + (os.getpid() % 300)
     try:
-        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, out, lensmodel), nprocs=2, join=True)
     except Exception as e:
         if "gloo" in str(e).lower() and "cuda" in str(e).lower():
             pytest.skip(f"gloo cannot move device tensors in this build: {e}")
@@ -95,7 +101,9 @@ def test_world2_sharded_on_one_device_matches_single(amd, tmp_path):
     assert 0 < r["frames"][1] < 11            # the frames really were split
     assert int(r["Noutliers"]) == s1["Noutliers_board"]
     assert abs(float(r["rms"]) - s1["rms_reproj_error__pixels"]) < 1e-8
-    assert np.abs(r["b"] - b1).max() < 2e-5
+    # (a splined surface has knots the boards barely reach: the optimum is flat along them and the two runs, whose
+    #  sums are ordered differently, stop 1e-4 apart there in packed units; the cost and the outliers agree)
+    assert np.abs(r["b"] - b1).max() < (1e-3 if "SPLINED" in lensmodel else 2e-5)
     assert 0 < int(r["Ncollectives"]) <= 2*int(r["Ntrials"]) + 4*(int(r["Npasses"]) + 1) + 1
 
 
