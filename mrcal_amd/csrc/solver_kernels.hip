@@ -2508,23 +2508,29 @@ void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict_
 }
 
 // L^T d = z, panel by panel from the last: one workgroup. z is row n of M; on
-// return r (= that row) holds -d
+// return r (= that row) holds -d.
+// One workgroup pulls ~50 GB/s, and the factor of a 1206-variable block is 5.8 MB: 115-155 us. So the panels are
+// taken in a few GROUPS, last group first: this kernel solves a group's panels [p_lo, p_hi) against the group's
+// own rows (rows below the group are solved already and have been applied), then lchol_backward_apply_kernel - as
+// many workgroups as there are 64-column blocks left of the group - subtracts the group's rows times its d from
+// every earlier entry of z. The one-workgroup kernels stream the groups' diagonal triangles only (1/16 of the
+// factor each with four groups). The last one (p_lo == 0) negates
 __global__ __launch_bounds__(1024)
 void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
-                           const double* __restrict__ Linv_all)
+                           const double* __restrict__ Linv_all, int p_lo, int p_hi)
 {
     if(skip != NULL && *skip) return;
     extern __shared__ double zs[];                      // z, n doubles: read by every thread in every panel
     double* __restrict__ z = M + (size_t)n*n;
+    const int row_hi = min(n, p_hi*LCH_NB);             // rows of this group: [p_lo*64, row_hi)
     __shared__ double part[16][LCH_NB];
     __shared__ double w[LCH_NB];
     __shared__ double Xs[LCH_NB*LCH_NB];
     const int t = threadIdx.x;
     const int c = t & (LCH_NB-1), slice = t >> 6;       // 16 slices of rows for each of the 64 columns
-    const int npanels = (n + LCH_NB - 1)/LCH_NB;
     for(int i = t; i < n; i += blockDim.x) zs[i] = z[i];
     __syncthreads();
-    for(int p = npanels-1; p >= 0; p--)
+    for(int p = p_hi-1; p >= p_lo; p--)
     {
         const int j0 = p*LCH_NB;
         const int nb = min(LCH_NB, n - j0);
@@ -2545,7 +2551,7 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
             const double* __restrict__ col = M + j0 + c;
             int i = m0 + slice;
             constexpr int UB = 24;
-            for(; i + 16*(UB-1) < n; i += 16*UB)
+            for(; i + 16*(UB-1) < row_hi; i += 16*UB)
             {
                 double v[UB];
 #pragma unroll
@@ -2555,7 +2561,7 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
                 for(int u = 0; u < UB; u += 2) { a0 += v[u]*zs[i + 16*u]; a1 += v[u+1]*zs[i + 16*(u+1)]; }
                 acc += a0 + a1;
             }
-            for(; i + 16*3 < n; i += 16*4)
+            for(; i + 16*3 < row_hi; i += 16*4)
             {
                 double v[4];
 #pragma unroll
@@ -2563,7 +2569,7 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
 #pragma unroll
                 for(int u = 0; u < 4; u++) acc += v[u]*zs[i + 16*u];
             }
-            for(; i < n; i += 16) acc += col[(size_t)i*n]*zs[i];
+            for(; i < row_hi; i += 16) acc += col[(size_t)i*n]*zs[i];
         }
         part[slice][c] = acc;
         __syncthreads();
@@ -2583,7 +2589,37 @@ void lchol_backward_kernel(int n, const int* __restrict__ skip, double* __restri
         }
         __syncthreads();
     }
-    for(int i = t; i < n; i += blockDim.x) z[i] = -zs[i];
+    if(p_lo == 0) { for(int i = t; i < n; i += blockDim.x) z[i] = -zs[i]; }
+    else          { for(int i = p_lo*LCH_NB + t; i < row_hi; i += blockDim.x) z[i] = zs[i]; }
+}
+// z[c] -= sum over the rows i in [row_lo, row_hi) of L[i][c] d[i] (d = z there), c < row_lo: 64 columns per workgroup,
+// four slices of the rows, added in order
+__global__ __launch_bounds__(256)
+void lchol_backward_apply_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int row_lo, int row_hi)
+{
+    if(skip != NULL && *skip) return;
+    double* __restrict__ z = M + (size_t)n*n;
+    __shared__ double part[4][LCH_NB];
+    const int t = threadIdx.x, c = blockIdx.x*LCH_NB + (t & (LCH_NB-1)), slice = t >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    if(c < row_lo)
+    {
+        const double* __restrict__ col = M + c;
+        int i = row_lo + slice;
+        constexpr int UB = 16;
+        for(; i + 4*(UB-1) < row_hi; i += 4*UB)
+        {
+            double v[UB], d[UB];
+#pragma unroll
+            for(int u = 0; u < UB; u++) { v[u] = col[(size_t)(i + 4*u)*n]; d[u] = z[i + 4*u]; }
+#pragma unroll
+            for(int u = 0; u < UB; u += 2) { a0 = fma(v[u], d[u], a0); a1 = fma(v[u+1], d[u+1], a1); }
+        }
+        for(; i < row_hi; i += 4) a0 = fma(col[(size_t)i*n], z[i], a0);
+    }
+    part[slice][t & (LCH_NB-1)] = a0 + a1;
+    __syncthreads();
+    if(t < LCH_NB && c < row_lo) z[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
@@ -2611,7 +2647,16 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1)), dim3(1024), 0, stream,
                        n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
                        (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1));
-    hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), (size_t)n*sizeof(double), stream, n, skip, M, Linv);
+    // the backward sweep, in groups of panels (see lchol_backward_kernel)
+    const int ngroups = (npanels >= 12) ? 4 : (npanels >= 6) ? 2 : 1;
+    for(int g = ngroups - 1; g >= 0; g--)
+    {
+        const int p_lo = (int)((long long)npanels*g/ngroups), p_hi = (int)((long long)npanels*(g + 1)/ngroups);
+        hipLaunchKernelGGL(lchol_backward_kernel, dim3(1), dim3(1024), (size_t)n*sizeof(double), stream, n, skip, M, Linv, p_lo, p_hi);
+        if(p_lo > 0)
+            hipLaunchKernelGGL(lchol_backward_apply_kernel, dim3(p_lo), dim3(256), 0, stream,
+                               n, skip, M, p_lo*LCH_NB, std::min(n, p_hi*LCH_NB));
+    }
     return hipGetLastError();
 }
 size_t cholesky_large_workspace_doubles(int n)
