@@ -130,6 +130,9 @@ def test_normal_equations_match_JtJ(amd, case):
                                                    ("LENSMODEL_PINHOLE", 5, 8, 8, 7),
                                                    ("LENSMODEL_OPENCV12", 8, 6, 10, 10),
                                                    ("LENSMODEL_OPENCV8", 12, 6, 10, 10),
+                                                   # whole panels of the launch-per-panel Cholesky: 192 = 3 x 64, 256 = 4 x 64
+                                                   ("LENSMODEL_OPENCV4", 14, 6, 8, 7),
+                                                   ("LENSMODEL_PINHOLE", 26, 5, 8, 7),
                                                    ("LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", 2, 40, 10, 10)))
 def test_gauss_newton_step_matches_dense_solve(amd, lensmodel, Ncam, Nf, W, H):
     from mrcal_amd.resident import Problem
