@@ -1778,11 +1778,23 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
             for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-lp[(j-1) & 1], Lc[(j-1) & 1][c], row[c]);
         }
     };
+#ifdef DIAG16_TS
+    long long dts[17];
+#define CHOL_COL(j) dts[j] = clock64(); __builtin_amdgcn_sched_barrier(0); column(IC(j));
+#else
 #define CHOL_COL(j) column(IC(j));
+#endif
     CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
     CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
 #undef CHOL_COL
 #undef IC
+#ifdef DIAG16_TS
+    dts[16] = clock64();
+    if(lane == 0 && blockIdx.x == 0 && rowL != NULL && dts[0] % 997 == 0)
+        printf("diag16 per column: %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n",
+               dts[1]-dts[0], dts[2]-dts[1], dts[3]-dts[2], dts[4]-dts[3], dts[5]-dts[4], dts[6]-dts[5], dts[7]-dts[6], dts[8]-dts[7],
+               dts[9]-dts[8], dts[10]-dts[9], dts[11]-dts[10], dts[12]-dts[11], dts[13]-dts[12], dts[14]-dts[13], dts[15]-dts[14], dts[16]-dts[15]);
+#endif
     // L through dstL (lanes 0..15), X into its block (lanes 16..31): one store per column for the whole wave
     {
         const bool isid = (lane >= 16 && lane < 32);
