@@ -1729,6 +1729,9 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
 {
     const int  r16  = lane & 15;
     const bool mine = lane < 16 && r16 < jb;
+#ifdef DIAG16_TS
+    const long long dts_in = clock64();
+#endif
     double row[CHOL_PB];
     {
         // unconditional loads, then select: no branches
@@ -1782,7 +1785,14 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
     long long dts[17];
 #define CHOL_COL(j) dts[j] = clock64(); __builtin_amdgcn_sched_barrier(0); column(IC(j));
 #else
+    // A scheduling barrier between the columns: left alone, the compiler's scheduler treats the sixteen unrolled
+    // columns as one block and interleaves them (sinking LDS reads to their uses, hoisting multiply-adds): 6160
+    // cycles per call. With the columns kept apart, in the order written: see tools/exp/diag16_bench.hip
+#ifndef CHOL_NO_COLUMN_BARRIER
+#define CHOL_COL(j) __builtin_amdgcn_sched_barrier(0); column(IC(j));
+#else
 #define CHOL_COL(j) column(IC(j));
+#endif
 #endif
     CHOL_COL(0)  CHOL_COL(1)  CHOL_COL(2)  CHOL_COL(3)  CHOL_COL(4)  CHOL_COL(5)  CHOL_COL(6)  CHOL_COL(7)
     CHOL_COL(8)  CHOL_COL(9)  CHOL_COL(10) CHOL_COL(11) CHOL_COL(12) CHOL_COL(13) CHOL_COL(14) CHOL_COL(15)
@@ -1791,8 +1801,8 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
 #ifdef DIAG16_TS
     dts[16] = clock64();
     if(lane == 0 && blockIdx.x == 0 && rowL != NULL && dts[0] % 997 == 0)
-        printf("diag16 per column: %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n",
-               dts[1]-dts[0], dts[2]-dts[1], dts[3]-dts[2], dts[4]-dts[3], dts[5]-dts[4], dts[6]-dts[5], dts[7]-dts[6], dts[8]-dts[7],
+        printf("diag16 entry to column 0: %lld; per column: %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n",
+               dts[0]-dts_in, dts[1]-dts[0], dts[2]-dts[1], dts[3]-dts[2], dts[4]-dts[3], dts[5]-dts[4], dts[6]-dts[5], dts[7]-dts[6], dts[8]-dts[7],
                dts[9]-dts[8], dts[10]-dts[9], dts[11]-dts[10], dts[12]-dts[11], dts[13]-dts[12], dts[14]-dts[13], dts[15]-dts[14], dts[16]-dts[15]);
 #endif
     // L through dstL (lanes 0..15), X into its block (lanes 16..31): one store per column for the whole wave
@@ -1806,6 +1816,9 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
             *dst = row[c];
         }
     }
+#ifdef DIAG16_TS
+    { const long long dts_out = clock64(); if(lane == 0 && blockIdx.x == 0 && dts_in % 997 == 0) printf("diag16 whole call %lld cycles\n", dts_out - dts_in); }
+#endif
     return bad;
 }
 
@@ -2219,6 +2232,13 @@ __device__ __forceinline__ void lch_tile_for_X(int wave, int* wi, int* wc) { *wi
 // alone):  Lb = M[block rows][previous panel] Xprev^T,  block -= Lb Lb^T.  (Lb is not stored: the tile workgroups
 // of this launch read the same rows of the previous panel as they are. lchol_trsm of the next launch stores it)
 #define LCH_LDS_DOUBLES (2*LCH_NB*(LCH_NB+1) + CHOL_PB*CHOL_XLD + 3*64 + LCH_NB*(LCH_NB+1))
+// threads of the panel kernels' workgroups. What they do is bound by ONE CU's matrix pipes and by wave 0's pivot
+// chain, not by the number of waves; with 1024 threads a wave has 128 registers and chol_factor_diag16() spills
+#ifndef LCH_THREADS
+#define LCH_THREADS 512
+#endif
+#define LCH_NW  (LCH_THREADS/64)     // waves
+#define LCH_TPW (16/LCH_NW)          // 16 x 16 tiles of a 64 x 64 block per wave
 __device__ __forceinline__
 void lchol_diag_block(int n, double* __restrict__ M, int j0,
                       double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status,
@@ -2240,7 +2260,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
 #endif
     if(t == 0) notpd = 0;
     // the block, padded with the identity (so that a short last panel factors too)
-    for(int idx = t; idx < NB*NB; idx += 1024)
+    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
     {
         const int i = idx / NB, j = idx - i*NB;
         A[i*LD + j]        = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
@@ -2253,31 +2273,42 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     {
         // (rows 64.. of A are free until the factorization starts: the identity is written again below)
         double* __restrict__ Xp = A + NB*LD;
-        for(int idx = t; idx < NB*NB; idx += 1024)
+        for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
         {
             const int i = idx / NB, k = idx - i*NB;
             Pm[i*LD + k] = (i < nb) ? M[(size_t)(j0+i)*n + jprev + k] : 0.0;
             Xp[i*LD + k] = Xprev[idx];
         }
         __syncthreads();
-        int wi, wc;
-        lch_tile_for_X(wave_u, &wi, &wc);
-        const syrk_d4 lb = lch_tile_ABt(Pm, Xp, wi, wc, r16, kq, false, 16*(wc + 1));
+        syrk_d4 lb[LCH_TPW];
+#pragma unroll
+        for(int u = 0; u < LCH_TPW; u++)
+        {
+            int wi, wc;
+            lch_tile_for_X(wave_u + LCH_NW*u, &wi, &wc);
+            lb[u] = lch_tile_ABt(Pm, Xp, wi, wc, r16, kq, false, 16*(wc + 1));
+        }
         __syncthreads();
 #pragma unroll
-        for(int v = 0; v < 4; v++) Pm[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lb[v];
-        __syncthreads();
-        // the ten tiles of the lower triangle on waves 0..9: three, three, two and two to a SIMD
-        if(wave_u < 10)
+        for(int u = 0; u < LCH_TPW; u++)
         {
-            int ti = 0, tj = wave_u;
+            int wi, wc;
+            lch_tile_for_X(wave_u + LCH_NW*u, &wi, &wc);
+#pragma unroll
+            for(int v = 0; v < 4; v++) Pm[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lb[u][v];
+        }
+        __syncthreads();
+        // the ten tiles of the lower triangle, dealt to the waves (and so to the SIMDs) in turn
+        for(int tix = wave_u; tix < 10; tix += LCH_NW)
+        {
+            int ti = 0, tj = tix;
             while(tj > ti) { tj -= ti + 1; ti++; }
             const syrk_d4 d = lch_tile_ABt(Pm, Pm, ti, tj, r16, kq, true);
 #pragma unroll
             for(int v = 0; v < 4; v++) A[(16*ti + kq + 4*v)*LD + 16*tj + r16] += d[v];
         }
         __syncthreads();
-        for(int idx = t; idx < NB*NB; idx += 1024)
+        for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
         {
             const int i = idx / NB, j = idx - i*NB;
             A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
@@ -2313,7 +2344,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     {
         const int m0 = base + LCH_PB;
         // (b) rows m0 .. 127
-        for(int ti = wave_u; ti < (NR - m0)/16; ti += 16)
+        for(int ti = wave_u; ti < (NR - m0)/16; ti += LCH_NW)
         {
             double* __restrict__ pa = &A[(m0 + 16*ti + r16)*LD + base];
             chol_double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -2334,7 +2365,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
             const int ntr = (NR - m0)/16, ntc = (NB - m0)/16;
             int ntiles = 0;
             for(int ta = 0; ta < ntr; ta++) ntiles += min(ta + 1, ntc);
-            for(int tix = wave_u; tix < ntiles; tix += (wave_u == 0 ? ntiles : 15))
+            for(int tix = wave_u; tix < ntiles; tix += (wave_u == 0 ? ntiles : LCH_NW - 1))
             {
                 int ta = 0, tb = tix;
                 for(;;) { const int ntb = min(ta + 1, ntc); if(tb < ntb) break; tb -= ntb; ta++; }
@@ -2364,7 +2395,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     ts[3] = clock64();
 #endif
     // L back into the matrix; X[i][k] = (L^-T)[k][i] = row 64+k, column i
-    for(int idx = t; idx < NB*NB; idx += 1024)
+    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
     {
         const int i = idx / NB, j = idx - i*NB;
         if(i < nb && j < nb && j <= i) M[(size_t)(j0+i)*n + j0 + j] = A[i*LD + j];
@@ -2376,7 +2407,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     if((t == 0 || t == 64*5) && (j0 == 128 || j0 == 640)) printf("lchol diag j0 %d t %d: issue loads %lld, pre-update %lld, factor %lld (diag16 %lld, b %lld, c %lld, barriers %lld), store %lld cycles\n", j0, t, ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], tsd, tsb, tsc, tsy, ts[4]-ts[3]);
 #endif
 }
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(LCH_THREADS)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
                        double* __restrict__ Linv, int* __restrict__ status)
 {
@@ -2411,9 +2442,9 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
     constexpr int NB = LCH_NB, LD = LCH_NB + 1;
     const int t = threadIdx.x, lane = t & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r16 = lane & 15, kq = lane >> 4, wi = wave_u >> 2, wc = wave_u & 3;
-    int xi, xc;
-    lch_tile_for_X(wave_u, &xi, &xc);
+    const int r16 = lane & 15, kq = lane >> 4;
+    // the wave's tiles u = 0 .. LCH_TPW-1: (wi, wc) of the 64 x 64 tile
+    auto tile_of = [&](int u, int* wi, int* wc) { const int w = wave_u + LCH_NW*u; *wi = w >> 2; *wc = w & 3; };
     const int m0 = j0 + NB;
     const int nbt = (n - m0 + NB - 1)/NB;
     int bi, bj;
@@ -2425,15 +2456,20 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
     const int  i0   = rhs ? n : m0 + NB*bi, c0 = m0 + NB*bj;
     const int  ni   = rhs ? 1 : min(NB, n - i0), nc = min(NB, n - c0);     // rows of M in the two blocks
     // the tile itself, asked for first
-    double tile[4];
+    double tile[LCH_TPW][4];
 #pragma unroll
-    for(int v = 0; v < 4; v++)
+    for(int u = 0; u < LCH_TPW; u++)
     {
-        const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
-        const bool ok = i < ni && c < nc && (!diag || c <= i);
-        tile[v] = ok ? M[(size_t)(i0 + i)*n + c0 + c] : 0.0;
+        int wi, wc; tile_of(u, &wi, &wc);
+#pragma unroll
+        for(int v = 0; v < 4; v++)
+        {
+            const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
+            const bool ok = i < ni && c < nc && (!diag || c <= i);
+            tile[u][v] = ok ? M[(size_t)(i0 + i)*n + c0 + c] : 0.0;
+        }
     }
-    for(int idx = t; idx < NB*NB; idx += 1024)
+    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
     {
         const int i = idx / NB, k = idx - i*NB;
         MI[i*LD + k] = (i < ni) ? M[(size_t)(i0 + i)*n + j0 + k] : 0.0;
@@ -2441,23 +2477,41 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
         Xs[i*LD + k] = X[idx];
     }
     __syncthreads();
-    const syrk_d4 li = lch_tile_ABt(MI, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
-    syrk_d4 lc = li;
-    if(!diag) lc = lch_tile_ABt(MC, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
-    __syncthreads();
+    syrk_d4 li[LCH_TPW], lc[LCH_TPW];
 #pragma unroll
-    for(int v = 0; v < 4; v++)
+    for(int u = 0; u < LCH_TPW; u++)
     {
-        MI[(16*xi + kq + 4*v)*LD + 16*xc + r16] = li[v];
-        if(!diag) MC[(16*xi + kq + 4*v)*LD + 16*xc + r16] = lc[v];
+        int xi, xc;
+        lch_tile_for_X(wave_u + LCH_NW*u, &xi, &xc);
+        li[u] = lch_tile_ABt(MI, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
+        lc[u] = li[u];
+        if(!diag) lc[u] = lch_tile_ABt(MC, Xs, xi, xc, r16, kq, false, 16*(xc + 1));
     }
     __syncthreads();
-    const syrk_d4 d = lch_tile_ABt(MI, diag ? MI : MC, wi, wc, r16, kq, true);
 #pragma unroll
-    for(int v = 0; v < 4; v++)
+    for(int u = 0; u < LCH_TPW; u++)
     {
-        const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
-        if(i < ni && c < nc && (!diag || c <= i)) M[(size_t)(i0 + i)*n + c0 + c] = tile[v] + d[v];
+        int xi, xc;
+        lch_tile_for_X(wave_u + LCH_NW*u, &xi, &xc);
+#pragma unroll
+        for(int v = 0; v < 4; v++)
+        {
+            MI[(16*xi + kq + 4*v)*LD + 16*xc + r16] = li[u][v];
+            if(!diag) MC[(16*xi + kq + 4*v)*LD + 16*xc + r16] = lc[u][v];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for(int u = 0; u < LCH_TPW; u++)
+    {
+        int wi, wc; tile_of(u, &wi, &wc);
+        const syrk_d4 d = lch_tile_ABt(MI, diag ? MI : MC, wi, wc, r16, kq, true);
+#pragma unroll
+        for(int v = 0; v < 4; v++)
+        {
+            const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
+            if(i < ni && c < nc && (!diag || c <= i)) M[(size_t)(i0 + i)*n + c0 + c] = tile[u][v] + d[v];
+        }
     }
 #ifdef LCH_TS
     if(t == 0 && (j0 == 64 || j0 == 576) && (q == 0 || q == 40)) printf("lchol tile j0 %d q %d: %lld cycles\n", j0, q, clock64() - tt0);
@@ -2472,27 +2526,31 @@ void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __res
     const int t = threadIdx.x, lane = t & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    int wi, wc;
-    lch_tile_for_X(wave_u, &wi, &wc);
     const int nb = min(NB, n - j0);
     const int r0 = j0 + nb + b*NB;
-    for(int idx = t; idx < NB*NB; idx += 1024)
+    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
     {
         const int i = idx / NB, k = idx - i*NB;
         MI[i*LD + k] = (r0 + i <= n && k < nb) ? M[(size_t)(r0 + i)*n + j0 + k] : 0.0;
         Xs[i*LD + k] = X[idx];
     }
     __syncthreads();
-    const syrk_d4 l = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false, 16*(wc + 1));
 #pragma unroll
-    for(int v = 0; v < 4; v++)
+    for(int u = 0; u < LCH_TPW; u++)
     {
-        const int i = 16*wi + kq + 4*v, j = 16*wc + r16;
-        if(r0 + i <= n && j < nb) M[(size_t)(r0 + i)*n + j0 + j] = l[v];
+        int wi, wc;
+        lch_tile_for_X(wave_u + LCH_NW*u, &wi, &wc);
+        const syrk_d4 l = lch_tile_ABt(MI, Xs, wi, wc, r16, kq, false, 16*(wc + 1));
+#pragma unroll
+        for(int v = 0; v < 4; v++)
+        {
+            const int i = 16*wi + kq + 4*v, j = 16*wc + r16;
+            if(r0 + i <= n && j < nb) M[(size_t)(r0 + i)*n + j0 + j] = l[v];
+        }
     }
 }
 // block 0: the next panel's diagonal block (if there is a next panel); then the tiles; then the previous panel's solve
-__global__ __launch_bounds__(1024)
+__global__ __launch_bounds__(LCH_THREADS)
 void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
                         int j0, const double* __restrict__ X, int ntiles,
                         double* __restrict__ Xnext, int* __restrict__ status,
@@ -2640,7 +2698,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     auto Xof = [&](int p) { return Linv + (size_t)p*LCH_NB*LCH_NB; };
     // rows below a panel, the rhs row included, in blocks of 64 (the panel solve's)
     auto ntrsm_of = [&](int p) { const int m0 = std::min(n, (p + 1)*LCH_NB); return (n + 1 - m0 + LCH_NB - 1)/LCH_NB; };
-    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(1024), 0, stream, n, skip, M, 0, Xof(0), status);
+    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n, skip, M, 0, Xof(0), status);
     for(int p = 0; p < npanels; p++)
     {
         const int j0 = p*LCH_NB;
@@ -2651,12 +2709,12 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         const int ntiles = has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
         const int ntrsm  = (p > 0) ? ntrsm_of(p - 1) : 0;
         if(!has_next && ntrsm == 0) continue;
-        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm), dim3(1024), 0, stream,
+        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm), dim3(LCH_THREADS), 0, stream,
                            n, skip, M, j0, (const double*)Xof(p), ntiles, has_next ? Xof(p + 1) : (double*)NULL, status,
                            (p > 0) ? j0 - LCH_NB : 0, (const double*)((p > 0) ? Xof(p - 1) : Xof(0)), ntrsm);
     }
     // the last panel's solve: the rhs row alone
-    hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1)), dim3(1024), 0, stream,
+    hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1)), dim3(LCH_THREADS), 0, stream,
                        n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
                        (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1));
     // the backward sweep, in groups of panels (see lchol_backward_kernel)
