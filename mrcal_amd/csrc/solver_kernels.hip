@@ -2259,26 +2259,44 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     long long ts[6]; ts[0] = clock64();
 #endif
     if(t == 0) notpd = 0;
-    // the block, padded with the identity (so that a short last panel factors too)
-    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
+    // the block, padded with the identity (so that a short last panel factors too); with Xprev, this block's rows
+    // of the previous panel and Xprev too (rows 64.. of A are free until the factorization starts: the identity is
+    // written there afterwards). EVERY load first, from addresses that are always valid, then the selects and the
+    // stores: loads under a condition compile to branches with a wait each, three memory round trips instead of one
     {
-        const int i = idx / NB, j = idx - i*NB;
-        A[i*LD + j]        = (i < nb && j < nb && j <= i) ? M[(size_t)(j0+i)*n + j0 + j] : ((i == j) ? 1.0 : 0.0);
-        A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
+        constexpr int NIT = NB*NB/LCH_THREADS;
+        double va[NIT], vp[NIT], vx[NIT];
+        double* __restrict__ Xp = A + NB*LD;
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, j = idx - i*NB;
+            const bool ina = (i < nb && j < nb && j <= i);
+            va[u] = M[ina ? (size_t)(j0+i)*n + j0 + j : (size_t)0];
+            if(Xprev != NULL)
+            {
+                vp[u] = M[(i < nb) ? (size_t)(j0+i)*n + jprev + j : (size_t)0];
+                vx[u] = Xprev[idx];
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, j = idx - i*NB;
+            const bool ina = (i < nb && j < nb && j <= i);
+            A[i*LD + j] = ina ? va[u] : ((i == j) ? 1.0 : 0.0);
+            if(Xprev != NULL) { Pm[i*LD + j] = (i < nb) ? vp[u] : 0.0; Xp[i*LD + j] = vx[u]; }
+            else              A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
+        }
     }
 #ifdef LCH_TS
     ts[1] = clock64();
 #endif
     if(Xprev != NULL)
     {
-        // (rows 64.. of A are free until the factorization starts: the identity is written again below)
         double* __restrict__ Xp = A + NB*LD;
-        for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
-        {
-            const int i = idx / NB, k = idx - i*NB;
-            Pm[i*LD + k] = (i < nb) ? M[(size_t)(j0+i)*n + jprev + k] : 0.0;
-            Xp[i*LD + k] = Xprev[idx];
-        }
         __syncthreads();
         syrk_d4 lb[LCH_TPW];
 #pragma unroll
@@ -2469,12 +2487,28 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
             tile[u][v] = ok ? M[(size_t)(i0 + i)*n + c0 + c] : 0.0;
         }
     }
-    for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
     {
-        const int i = idx / NB, k = idx - i*NB;
-        MI[i*LD + k] = (i < ni) ? M[(size_t)(i0 + i)*n + j0 + k] : 0.0;
-        if(!diag) MC[i*LD + k] = (i < nc) ? M[(size_t)(c0 + i)*n + j0 + k] : 0.0;
-        Xs[i*LD + k] = X[idx];
+        // (all loads, from addresses that are always valid; then the stores: see lchol_diag_block)
+        constexpr int NIT = NB*NB/LCH_THREADS;
+        double vi[NIT], vc[NIT], vx[NIT];
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, k = idx - i*NB;
+            vi[u] = M[(size_t)(i0 + (i < ni ? i : 0))*n + j0 + k];
+            vc[u] = diag ? 0.0 : M[(size_t)(c0 + (i < nc ? i : 0))*n + j0 + k];
+            vx[u] = X[idx];
+        }
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, k = idx - i*NB;
+            MI[i*LD + k] = (i < ni) ? vi[u] : 0.0;
+            if(!diag) MC[i*LD + k] = (i < nc) ? vc[u] : 0.0;
+            Xs[i*LD + k] = vx[u];
+        }
     }
     __syncthreads();
     syrk_d4 li[LCH_TPW], lc[LCH_TPW];
