@@ -311,7 +311,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             const int row0 = 2*P->D.W*P->D.H*Nobs;
             P->plan.row_part_n = (Nobs > 0 && L.Nmeas > row0) ? (L.Nmeas - row0 + 255)/256 : 0;
             ok = ok && dev_alloc(&P->plan.row_part, (size_t)(P->plan.row_part_n > 0 ? P->plan.row_part_n : 1));
-            P->plan.qf_part_n = (nd.Nc + nd.NE + 31)/32;
+            P->plan.qf_part_n = (nd.Nc + nd.NE + 4*QF_ROWS_PER_WAVE - 1)/(4*QF_ROWS_PER_WAVE);
             ok = ok && dev_alloc(&P->plan.qf_part, (size_t)4*(P->plan.qf_part_n > 0 ? P->plan.qf_part_n : 1));
             ok = ok && dev_alloc(&P->plan.dots_part, (size_t)2*(nd.NEb > 0 ? nd.NEb : 1));
         }

@@ -2827,7 +2827,8 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
 // out[0] += v^T N v, and if nout == 3: out[1] += g . v,  out[2] += v . v   with N = [A B; Bt D]
 // of the operating point: v^T N v = v_S^T A v_S + 2 v_E^T (Bt v_S) + v_E^T D v_E.
 // One wave per group of rows of [A ; Bt]; one atomic triple per workgroup
-#define QF_ROWS_PER_WAVE 8
+// (QF_ROWS_PER_WAVE: solver_kernels.hpp. With 8 rows a wave, a 1206-variable camera block had 188 workgroups
+//  walking 46 MB of Bt: 1.4 TB/s)
 // this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
 __device__ __forceinline__
 double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false)
@@ -2852,7 +2853,7 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
     int rowc[QF_ROWS_PER_WAVE];
 #pragma unroll
     for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) rowc[rr] = min(row0 + rr, Nrows - 1);
-#pragma unroll 2
+#pragma unroll 4
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double vs = v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];

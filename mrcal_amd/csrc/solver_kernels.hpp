@@ -99,6 +99,9 @@ struct PairOp { int op, aux; };
 #define SPL_TRI (128*129/2)
 #define SPLG_E  8         // workgroups sharing a row of the camera block that every pass holds (assemble_splined_gather_kernel)
 struct SplHdr { int ix0, iy0, wx, wy; };      // wx < 0: the observation went row by row, nothing is staged
+#ifndef QF_ROWS_PER_WAVE
+#define QF_ROWS_PER_WAVE 2    // rows of [A ; Bt] a wave of the quadratic-form workgroups takes
+#endif
 struct AssemblyPlan
 {
     int* frame_obs_begin;  // [Nframes+1]
@@ -127,7 +130,7 @@ struct AssemblyPlan
     double* row_part;         // [row_part_n] per-workgroup partial |x|^2 of the rows that do not come from board Grams
     int     row_part_n;
     double* qf_part;          // [qf_part_n][4] per-workgroup partials of the quadratic form g^T N g (and of |g_E|^2)
-    int     qf_part_n;
+    int     qf_part_n;        // = quadform workgroups: (Nc + NE) rows, 4 waves x QF_ROWS_PER_WAVE rows each
     double* dots_part;        // [NEb][2] per-block (|d_e|^2, d_e . g_e) of the back-substitution
     // splined models (assemble_splined_kernel): chunk_part holds the staged Grams, [2 Nobs_board][SPL_TRI]
     SplHdr* spl_hdr;          // [Nobs_board] the knot box of each observation
