@@ -571,7 +571,8 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                         const int i = ok ? e / L : 0, k = ok ? e - i*L : 0;
                         const int p = pbase + 2*i*L + k;
                         ii[u] = i;
-                        v[u]  = ok ? Jv[p] : 0.0;
+                        const double jv = Jv[p];        // (p is a valid entry either way)
+                        v[u]  = ok ? jv : 0.0;
                         ci[u] = Ji[p];
                     }
 #pragma unroll
@@ -761,10 +762,17 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                         for(int it = 0; it < 2; it++)
                         {
                             const int lc = lane + 64*it;
-                            v[k][xy][it] = (on[k][xy] && lc <= lr && cs[k][it] != -1) ? Gp[spl_tri(lr) + lc] : 0.0;
+                            // (always a load, from an address that is always valid: a load under a condition is a branch and a wait)
+                            const bool want = on[k][xy] && lc <= lr && cs[k][it] != -1;
+                            const double g = Gp[want ? spl_tri(lr) + lc : 0];
+                            v[k][xy][it] = want ? g : 0.0;
                         }
                         // a knot's row against the core: below it in local order
-                        vc[k][xy] = (on[k][xy] && csc[k] >= 0) ? Gp[spl_tri(K + lane) + lr] : 0.0;
+                        {
+                            const bool want = on[k][xy] && csc[k] >= 0;
+                            const double g = Gp[want ? spl_tri(K + lane) + lr : 0];
+                            vc[k][xy] = want ? g : 0.0;
+                        }
                     }
                 }
 #pragma unroll
@@ -1151,7 +1159,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
     // everything this workgroup reads is requested up front: the block, and this
     // lane's columns of Bt_e (column Nc is g_e). The 6x6 factorization below
     // then runs under the latency of the big loads
-    const double dval = (t < 36) ? D[(size_t)blk*36 + t] : 0.0;
+    const double dval = D[(size_t)blk*36 + min(t, 35)];
     // (one wave for camera blocks up to 255 columns, four for wider ones: the splined models' 1206 columns
     //  by one wave per block were 800 waves on the whole chip, 67 us of latency)
     constexpr int MAXC = 4;                // columns per lane held in registers
@@ -2484,7 +2492,8 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
         {
             const int i = 16*wi + kq + 4*v, c = 16*wc + r16;
             const bool ok = i < ni && c < nc && (!diag || c <= i);
-            tile[u][v] = ok ? M[(size_t)(i0 + i)*n + c0 + c] : 0.0;
+            const double mv = M[ok ? (size_t)(i0 + i)*n + c0 + c : (size_t)0];
+            tile[u][v] = ok ? mv : 0.0;
         }
     }
     {
@@ -3494,9 +3503,10 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     const int de  = (blk < nd.Nfb) ? 6 : 3;
     const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
     // all the loads first: L, y, g_e and this lane's columns of Wt_e against d_s
-    const double Lv = (lane < 36) ? LD[(size_t)blk*36 + lane] : 0.0;
-    const double yv = (lane < de) ? y[e0 + lane] : 0.0;
-    const double gv = (lane < de) ? O.g[nd.Nie + e0 + lane] : 0.0;
+    // (unconditional, clamped: three loads under conditions were three branches with a wait each)
+    const double Lv = LD[(size_t)blk*36 + min(lane, 35)];
+    const double yv = y[e0 + min(lane, de - 1)];
+    const double gv = O.g[nd.Nie + e0 + min(lane, de - 1)];
     double part[6] = {0,0,0,0,0,0};
     // (four column groups asked for together: with a 1206-variable camera block the loop is 19 round trips otherwise)
 #pragma unroll 4
