@@ -1591,50 +1591,88 @@ void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e
         auto block_row0 = [&](int b) { return (b < nd.Nfb) ? 6*b : 6*nd.Nfb + 3*(b - nd.Nfb); };
         const int b_first = block_of(e_begin), b_last = block_of(e_end - 1);
         const unsigned wi = bi >> 5, mi = 1u << (bi & 31);
-        for(int b = b_first; b <= b_last; b++)
+        // The occupancy bits of 64 blocks at a time, one block per lane: ONE round trip for the lot, then the
+        // wave goes through the blocks that touch its tiles. (Read block by block - a dependent load in front
+        // of every block, skipped or not - the walk over a slice's 100 blocks was most of the kernel's 104 us.)
+        // And the operands of the NEXT block that counts are asked for before the products of the current one
+        struct Operands { double a0, a1, b0[SYRK_STRIP], b1[SYRK_STRIP], y0, y1; unsigned mb; bool two; };
+        auto fetch = [&](int b, unsigned mb, Operands& o)
         {
-            const unsigned* __restrict__ ob = occ + (size_t)b*nocc;
-            if(!(ob[wi] & mi)) continue;
-            bool lj[SYRK_STRIP]; bool any = diag;
-#pragma unroll
-            for(int q = 0; q < SYRK_STRIP; q++)
-            {
-                lj[q] = (q < ntile) && ((ob[(bj0 + q) >> 5] >> ((bj0 + q) & 31)) & 1u);
-                any = any || lj[q];
-            }
-            if(!any) continue;
             const int br0 = block_row0(b);
             const int r0 = max(br0, e_begin), r1 = min(br0 + ((b < nd.Nfb) ? 6 : 3), e_end);
-            const bool two = (r1 - r0) > 4;
+            o.two = (r1 - r0) > 4; o.mb = mb;
             const int  ea = r0 + kk, eb = r0 + 4 + kk;
             const bool oka = ea < r1, okb = eb < r1;
             const size_t rowa = (size_t)(oka ? ea : r0)*nd.Nc, rowb = (size_t)(okb ? eb : r0)*nd.Nc;
-            double a0 = pi[rowa], a1 = two ? pi[rowb] : 0.0;
-            if(!oka || !oki) a0 = 0.0;
-            if(!okb || !oki) a1 = 0.0;
-            double b0[SYRK_STRIP], b1[SYRK_STRIP];
+            o.a0 = pi[rowa]; o.a1 = o.two ? pi[rowb] : 0.0;
+            if(!oka || !oki) o.a0 = 0.0;
+            if(!okb || !oki) o.a1 = 0.0;
 #pragma unroll
             for(int q = 0; q < SYRK_STRIP; q++)
-                if(lj[q])
+            {
+                o.b0[q] = 0.0; o.b1[q] = 0.0;
+                if((mb >> q) & 1u)
                 {
-                    b0[q] = pj[q][rowa]; b1[q] = two ? pj[q][rowb] : 0.0;
-                    if(!oka || !okj[q]) b0[q] = 0.0;
-                    if(!okb || !okj[q]) b1[q] = 0.0;
+                    o.b0[q] = pj[q][rowa]; o.b1[q] = o.two ? pj[q][rowb] : 0.0;
+                    if(!oka || !okj[q]) o.b0[q] = 0.0;
+                    if(!okb || !okj[q]) o.b1[q] = 0.0;
                 }
+            }
+            o.y0 = 0.0; o.y1 = 0.0;
+            if(diag)
+            {
+                const double u0 = y[oka ? ea : r0], u1 = y[okb ? eb : r0];
+                o.y0 = (cc == 0 && oka) ? u0 : 0.0; o.y1 = (cc == 0 && okb) ? u1 : 0.0;
+            }
+        };
+        auto apply = [&](const Operands& o)
+        {
 #pragma unroll
             for(int q = 0; q < SYRK_STRIP; q++)
-                if(lj[q])
+                if((o.mb >> q) & 1u)
                 {
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[q], acc[q], 0, 0, 0);
-                    if(two) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[q], acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.b0[q], acc[q], 0, 0, 0);
+                    if(o.two) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.b1[q], acc[q], 0, 0, 0);
                 }
             if(diag)
             {
-                const double y0 = (cc == 0 && oka) ? y[ea] : 0.0, y1 = (cc == 0 && okb) ? y[eb] : 0.0;
-                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, y0, accr, 0, 0, 0);
-                if(two) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, y1, accr, 0, 0, 0);
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.y0, accr, 0, 0, 0);
+                if(o.two) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.y1, accr, 0, 0, 0);
+            }
+        };
+        Operands cur, nxt;
+        bool have = false;
+        const int nblk = b_last - b_first + 1;
+        for(int base = 0; base < nblk; base += 64)
+        {
+            unsigned m = 0;         // bits 0..3: the block touches B tile q of the strip; bit 4: it touches the A tile
+            if(base + lane < nblk)
+            {
+                const unsigned* __restrict__ ob = occ + (size_t)(b_first + base + lane)*nocc;
+                const unsigned wa = ob[wi];
+                const int w0i = bj0 >> 5, w1i = min((bj0 + SYRK_STRIP - 1) >> 5, nocc - 1);
+                const unsigned w0 = ob[w0i], w1 = ob[w1i];
+#pragma unroll
+                for(int q = 0; q < SYRK_STRIP; q++)
+                {
+                    const int tile = bj0 + q;
+                    const unsigned w = ((tile >> 5) == w0i) ? w0 : w1;
+                    if(q < ntile && ((w >> (tile & 31)) & 1u)) m |= 1u << q;
+                }
+                if(wa & mi) m |= 16u;
+            }
+            unsigned long long live = __ballot((m & 16u) && (diag || (m & 15u)));
+            while(live)
+            {
+                const int bit = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                const unsigned mb = (unsigned)__builtin_amdgcn_readlane((int)m, bit);
+                fetch(b_first + base + bit, mb, nxt);
+                if(have) apply(cur);
+                cur = nxt; have = true;
             }
         }
+        if(have) apply(cur);
     }
     const int slot = slot0 + sy;
 #pragma unroll
