@@ -45,11 +45,13 @@ def r_from_R(R):
         s = 0.5*np.linalg.norm(v)
         c = 0.5*(np.trace(M) - 1.0)
         th = np.arctan2(s, c)
-        if s > 1e-6:
-            out[i] = v*(th/(2.0*s))
-        elif c > 0:
+        if c > 0 and s <= 1e-6:
             out[i] = 0.5*v                      # th ~ sin(th)
+        elif c > 0 or s > 0.1:
+            out[i] = v*(th/(2.0*s))
         else:
+            # towards pi v = 2 sin(th) axis shrinks and its rounding error (1e-16, absolute) does not:
+            # at pi - 1e-5 the axis from v is good to 1e-11 only
             # near pi: the axis from the symmetric part, sym(R) - cos(th) I = (1 - cos(th)) a a^T
             B = 0.5*(M + M.T) - c*np.eye(3)
             a = B[int(np.argmax(np.diag(B)))]
