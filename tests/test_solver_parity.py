@@ -94,6 +94,29 @@ def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
     assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
+def test_normal_equations_splined_with_points(amd):
+    """a splined model with discrete points beside the boards: the points' rows add to the camera block with
+    atomics (the generic rows), so the gather of the staged board Grams stays on the main stream, in front of them"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6,
+                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120",
+                                     object_width_n=10, object_height_n=10, seed=29)
+    oi["do_optimize_intrinsics_core"] = False
+    oi = _with_points(oi, np.random.RandomState(3))
+    # (points where this lens model sees them)
+    oi["observations_point"][:,:2] = np.random.RandomState(4).uniform(700, 1300, size=oi["observations_point"][:,:2].shape)
+    with Problem(**oi) as p:
+        ne = p.normal_equations()
+        J, x = p.J(), p.x()
+        d = p.gauss_newton_step()
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    assert np.abs(N_gpu - N).max() < 1e-10*np.abs(N).max()
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    assert np.abs(N @ d + g).max() < 1e-6*max(np.abs(g).max(), 1.0)
+
+
 @pytest.mark.parametrize("case", ("boards", "boards+points", "no-extrinsics-opt", "monocular"))
 def test_normal_equations_match_JtJ(amd, case):
     from mrcal_amd.resident import Problem
