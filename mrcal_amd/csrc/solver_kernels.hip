@@ -2362,8 +2362,9 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
             for(int v = 0; v < 4; v++) Pm[(16*wi + kq + 4*v)*LD + 16*wc + r16] = lb[u][v];
         }
         __syncthreads();
-        // the ten tiles of the lower triangle, dealt to the waves (and so to the SIMDs) in turn
-        for(int tix = wave_u; tix < 10; tix += LCH_NW)
+        // the ten tiles of the lower triangle: wave 0 takes the first alone - it is all the first 16 x 16 block
+        // factorization needs, which then starts without waiting for the others, who share the other nine
+        for(int tix = wave_u; tix < (wave_u == 0 ? 1 : 10); tix += LCH_NW - 1)
         {
             int ti = 0, tj = tix;
             while(tj > ti) { tj -= ti + 1; ti++; }
@@ -2371,14 +2372,14 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
 #pragma unroll
             for(int v = 0; v < 4; v++) A[(16*ti + kq + 4*v)*LD + 16*tj + r16] += d[v];
         }
-        __syncthreads();
+        // (rows 64.. held Xprev, read for the last time two barriers ago; nobody reads them before the next one)
         for(int idx = t; idx < NB*NB; idx += LCH_THREADS)
         {
             const int i = idx / NB, j = idx - i*NB;
             A[(NB + i)*LD + j] = (i == j) ? 1.0 : 0.0;
         }
     }
-    __syncthreads();
+    else __syncthreads();
 
 #ifdef LCH_TS
     ts[2] = clock64();
