@@ -3,9 +3,10 @@
 First the parity proper: x, J (CSR rowptr/colidx bit-exact, values within 1e-6
 by the reference's relative-error measure) and b_packed (bit-exact) against the
 reference's own callback (oracle/_ref/libmrcal_ref.so: 0.04 - 0.9 s of CPU per
-configuration). Only the reference's SOLVE through the
-restated Cholesky is slow at these sizes, so the solve is checked through
-properties. Then properties that need no oracle:
+configuration). The reference's SOLVE (mrcal_optimize() over the restated
+libdogleg) is compared at configurations 0 and 1 (test_solve_matches_reference_at_baseline_size;
+the metric's size with MRCAL_AMD_SLOW=1: 3 minutes of CPU); the bigger ones are
+checked through properties. Then properties that need no oracle:
 
   sizes         Nstate, Nmeasurements, Nnz == the (bit-exact) layout functions
   structure     CSR rowptr monotone and ending at Nnz, columns sorted and
@@ -119,7 +120,10 @@ def _check_shards_add_up(oi, ne, Nframes, nshards=3):
     assert abs(acc["norm2_x"] - ne["norm2_x"]) < 1e-10*ne["norm2_x"]
 
 
-def _check_solve(amd, oi, check_state=True):
+def _check_solve(amd, oi):
+    """properties of the solve that need no oracle, with the same bounds at every size (the round-1 "damped
+    crawl" that loosened them for the big configurations was the synthetic problem's definition, DESIGN.md
+    section 5: lambda stays 0 through every solve of every configuration now)"""
     from mrcal_amd.resident import Problem
     oi = copy_inputs(oi)
     with Problem(**oi) as p0:
@@ -135,24 +139,15 @@ def _check_solve(amd, oi, check_state=True):
         x, J = p.x(), p.J()
     g = J.T @ x
     Jnorm = np.sqrt((J.data**2).sum())
-    # (the biggest configuration may stop in the damped crawl, at the iteration
-    # limit, a few 1e-4 of the rms short of the optimum: looser bounds there)
-    tight = check_state
-    assert np.linalg.norm(g) < (1e-5 if tight else 1e-3)*Jnorm*np.linalg.norm(x), np.linalg.norm(g)/(Jnorm*np.linalg.norm(x))
+    assert np.linalg.norm(g) < 1e-5*Jnorm*np.linalg.norm(x), np.linalg.norm(g)/(Jnorm*np.linalg.norm(x))
     # idempotence: solving again from the solution stays there
     b1 = s["b_packed"].copy()
     oi["do_apply_outlier_rejection"] = False
     s2 = amd.optimize(**oi)
-    # (the big problems end in the damped crawl described in DESIGN.md section 3,
-    # like the reference's libdogleg does once JtJ has been found singular: a
-    # second solve may still take up to the 4th digit off the rms; it must not go up)
     rms1 = np.sqrt(float(x @ x)/Nmeas)
     assert s2["rms_reproj_error__pixels"] <= rms1 + 1e-9
-    assert rms1 - s2["rms_reproj_error__pixels"] < (1e-3 if tight else 1e-2)*rms1
-    # the state itself is only pinned where the problem is well conditioned: the
-    # biggest configuration has a nearly flat direction along which the crawl moves
-    if check_state:
-        assert np.abs(s2["b_packed"] - b1).max() < 5e-3
+    assert rms1 - s2["rms_reproj_error__pixels"] < 1e-6*rms1
+    assert np.abs(s2["b_packed"] - b1).max() < 5e-3
     return s
 
 
@@ -193,10 +188,67 @@ def test_board_configurations_full_size(amd, ref_api, name):
     if cfg["Nframes"] <= 1000:
         _check_shards_add_up(oi, ne, cfg["Nframes"])
     del J
-    s = _check_solve(amd, oi, check_state=(cfg["Nframes"] <= 1000))
+    s = _check_solve(amd, oi)
     # the data were generated with 1.5 pixel noise and ~1% outliers
     assert 1.0 < s["rms_reproj_error__pixels"] < 2.0
     assert s["Noutliers_board"] > 0
+
+
+def _compare_solves(sa, oa, sr, orr, btol=2e-5, xtol=1e-5):
+    """what tests/test_solver_parity.py::test_optimize_matches_checker asserts at toy size"""
+    assert sa["Noutliers_board"] == sr["Noutliers_board"]
+    assert np.array_equal(oa["observations_board"][...,2] < 0, orr["observations_board"][...,2] < 0), \
+        "the two solves marked different outliers"
+    assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+    # the cost itself: equal to 1e-12 relative (observed 1e-15), and ours no higher than that
+    ca, cr = float(sa["x"] @ sa["x"]), float(sr["x"] @ sr["x"])
+    assert ca <= cr*(1. + 1e-12), (ca, cr)
+    db = np.abs(sa["b_packed"] - sr["b_packed"])
+    print(f"returned states differ by {db.max():.3g} (packed units) at {db.argmax()}, x by {np.abs(sa['x'] - sr['x']).max():.3g}, "
+          f"cost {ca!r} vs {cr!r}")
+    assert db.max() < btol, f"packed state differs by {db.max()} at {db.argmax()}"
+    assert np.abs(sa["x"] - sr["x"]).max() < xtol
+    assert abs(np.linalg.norm(sa["x"]) - np.linalg.norm(sr["x"])) < 1e-7*np.linalg.norm(sr["x"])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ("config0: 1 camera x 40 frames OPENCV4", "config1: 4 cameras x 400 frames OPENCV8"))
+def test_solve_matches_reference_at_baseline_size(amd, ref_api, name):
+    """The SOLVE, not only the callback, against the reference's mrcal_optimize() (mrcal.c:6179-6624: pack, the
+    outlier loop, unpack, stats; libdogleg restated underneath, oracle/dogleg_restated.c) at BASELINE.json's
+    configurations 0 and 1: same outlier mask, Noutliers, rms to 1e-6, cost to 1e-12; the returned state to 2e-5
+    and x to 1e-5 at configuration 0 (at configuration 1 see below).
+    (Configuration 1 is ~25 s of the CPU checker; the metric's 8 x 1000 is 3 minutes of it:
+    tools/ns_solve_vs_reference.py -> profiles/r03_ns_solve_vs_reference.json, test below when MRCAL_AMD_SLOW=1)"""
+    oi, _ = make_calibration_problem(amd._api, object_width_n=10, object_height_n=10, seed=2, **BOARD_CONFIGS[name])
+    oa, orr = copy_inputs(oi), copy_inputs(oi)
+    sa = amd.optimize(**oa)
+    sr = ref_api.optimize(**orr)
+    # Configuration 1 is noise-limited, in BOTH solvers: Gauss-Newton on 1.5-pixel residuals converges linearly
+    # along OPENCV8's flattest directions (eigenvalues of JtJ from 0.13 to 4.9e10), and from the reference's
+    # own returned state exact GN steps still move one high-order distortion coefficient by 1.7e-4 each while
+    # the cost changes in its 15th digit (tools/diag_config1_valley.py: CPU only, reproducible without a GPU).
+    # Any dog-leg loop stops there, wherever its rounding leaves it: the returned states are held to 1e-3
+    # packed units and 1e-3 pixels (observed 3.1e-4, 1.6e-4), the cost to 1e-12 relative (observed 1e-15),
+    # outliers exactly. Configuration 0: 2e-5 and 1e-5 like the toy sizes
+    weak = name.startswith("config1")
+    _compare_solves(sa, oa, sr, orr, btol=(1e-3 if weak else 2e-5), xtol=(1e-3 if weak else 1e-5))
+    for k in ("intrinsics", "rt_cam_ref", "rt_ref_frame", "calobject_warp"):
+        if oa[k] is not None and oa[k].size:
+            from conftest import relative_error
+            assert relative_error(oa[k], orr[k], eps=1e-3).max() < 1e-3, k
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(__import__("os").environ.get("MRCAL_AMD_SLOW", "0") != "1",
+                    reason="3 minutes of the CPU checker: MRCAL_AMD_SLOW=1 (tools/ns_solve_vs_reference.py keeps the record)")
+def test_solve_matches_reference_at_metric_size(amd, ref_api):
+    oi, _ = make_calibration_problem(amd._api, object_width_n=10, object_height_n=10, seed=2,
+                                     **BOARD_CONFIGS["metric: 8 cameras x 1000 frames OPENCV8"])
+    oa, orr = copy_inputs(oi), copy_inputs(oi)
+    sa = amd.optimize(**oa)
+    sr = ref_api.optimize(**orr)
+    _compare_solves(sa, oa, sr, orr, btol=1e-3, xtol=1e-3)
 
 
 @pytest.mark.timeout(900)

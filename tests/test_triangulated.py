@@ -28,7 +28,11 @@ def R_from_r(r):
     return np.eye(3) + np.sin(th)*K + (1-np.cos(th))*(K@K)
 
 
-def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise=0.5, Nboard_frames=0):
+def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise=0.5, Nboard_frames=0,
+                board_wh=(10,10), board_spacing=0.1):
+    """Nboard_frames > 0: chessboard frames beside the triangulated points, every camera seeing every board
+    (BASELINE.json's configuration 5: "4 cameras + 20k triangulated points + board frames"; allowed by
+    mrcal.c:6043-6051 with the intrinsics locked). The frame poses are then optimized too"""
     rng = np.random.RandomState(seed)
     W, H = 4000, 2200
     core = np.array((600., 600., (W-1)/2., (H-1)/2.))
@@ -43,19 +47,24 @@ def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise
     for i in range(1, Ncam):
         rt_cam_ref[i-1,:3] = rng.uniform(-0.05, 0.05, 3)
         rt_cam_ref[i-1,3:] = (-1.0*i, rng.uniform(-0.1,0.1), rng.uniform(-0.1,0.1))
+
+    def pixel(ic, pref):
+        """perfect pixel of a point given in the reference frame, seen by camera ic"""
+        p = pref if ic == 0 else R_from_r(rt_cam_ref[ic-1,:3]) @ pref + rt_cam_ref[ic-1,3:]
+        x, y = p[0]/p[2], p[1]/p[2]
+        if lensmodel == "LENSMODEL_OPENCV4":
+            k = intr[ic,4:]
+            r2 = x*x + y*y
+            cd = 1 + k[0]*r2 + k[1]*r2*r2
+            x, y = x*cd + 2*k[2]*x*y + k[3]*(r2+2*x*x), y*cd + k[2]*(r2+2*y*y) + 2*k[3]*x*y
+        return core[:2]*np.array((x,y)) + core[2:]
+
     pts = np.column_stack((rng.uniform(-3, 5, Npoints), rng.uniform(-2, 2, Npoints), rng.uniform(8, 30, Npoints)))
     obs, idx = [], []
     for ip in range(Npoints):
         cams = np.sort(rng.choice(Ncam, size=rng.randint(2, Ncam+1), replace=False))
         for ic in cams:
-            p = pts[ip] if ic == 0 else R_from_r(rt_cam_ref[ic-1,:3]) @ pts[ip] + rt_cam_ref[ic-1,3:]
-            x, y = p[0]/p[2], p[1]/p[2]
-            if lensmodel == "LENSMODEL_OPENCV4":
-                k = intr[ic,4:]
-                r2 = x*x + y*y
-                cd = 1 + k[0]*r2 + k[1]*r2*r2
-                x, y = x*cd + 2*k[2]*x*y + k[3]*(r2+2*x*x), y*cd + k[2]*(r2+2*y*y) + 2*k[3]*x*y
-            q = core[:2]*np.array((x,y)) + core[2:] + rng.normal(0, noise, 2)
+            q = pixel(ic, pts[ip]) + rng.normal(0, noise, 2)
             obs.append((q[0], q[1], 1.0))
             idx.append((ip, ic, ic-1))
     obs = np.array(obs); idx = np.array(idx, dtype=np.int32)
@@ -71,7 +80,33 @@ def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise
               do_optimize_extrinsics = True, do_optimize_frames = False, do_optimize_calobject_warp = False,
               do_apply_regularization = True, do_apply_regularization_unity_cam01 = True,
               do_apply_outlier_rejection = False, verbose = False)
-    return oi, dict(rt_cam_ref=rt_cam_ref, points=pts)
+    truth = dict(rt_cam_ref=rt_cam_ref, points=pts)
+    if Nboard_frames:
+        Wb, Hb = board_wh
+        rb = np.random.RandomState(seed + 77771)     # (its own stream: the points above do not depend on the boards)
+        rt_ref_frame = np.column_stack((rb.uniform(-0.3, 0.3, (Nboard_frames,3)),
+                                        rb.uniform(-2.5, 0.5, Nboard_frames), rb.uniform(-1, 0.5, Nboard_frames),
+                                        rb.uniform(4, 8, Nboard_frames)))
+        gx, gy = np.meshgrid(np.arange(Wb)*board_spacing, np.arange(Hb)*board_spacing)
+        corners = np.stack((gx, gy, np.zeros_like(gx)), axis=-1)          # (Hb,Wb,3): y-major then x (mrcal.c:2794)
+        ob = np.zeros((Nboard_frames*Ncam, Hb, Wb, 3))
+        ib = np.zeros((Nboard_frames*Ncam, 3), dtype=np.int32)
+        for f in range(Nboard_frames):
+            pref = corners @ R_from_r(rt_ref_frame[f,:3]).T + rt_ref_frame[f,3:]
+            for ic in range(Ncam):
+                o = f*Ncam + ic
+                ib[o] = (f, ic, ic-1)
+                for iy in range(Hb):
+                    for ix in range(Wb):
+                        ob[o,iy,ix,:2] = pixel(ic, pref[iy,ix])
+        ob[...,:2] += rb.normal(0, noise, ob[...,:2].shape)
+        ob[...,2]   = rb.uniform(0.5, 1.0, ob.shape[:3])
+        ob[1,2,3,2] = -1.      # an outlier on input
+        oi.update(rt_ref_frame = np.ascontiguousarray(rt_ref_frame + rb.normal(0, 1, rt_ref_frame.shape)*np.array((5e-3,)*3 + (2e-2,)*3)),
+                  observations_board = ob, indices_frame_camintrinsics_camextrinsics = ib,
+                  calibration_object_spacing = board_spacing, do_optimize_frames = True)
+        truth["rt_ref_frame"] = rt_ref_frame
+    return oi, truth
 
 
 # ------------------------------------------------------------------ CPU ---
@@ -380,3 +415,77 @@ def test_solve_matches_checker_and_truth(amd, ref_api):
     # geometry comes out close to the truth
     assert abs(np.linalg.norm(oa["rt_cam_ref"][0,3:]) - 1.0) < 1e-3
     assert np.abs(oa["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 0.01
+
+
+def compare_callbacks_with_pairs(res_amd, res_ref, m0, m1, what=""):
+    """compare_callbacks() (bit-exact b_packed and CSR structure, x and J to 1e-6 by the reference's relative
+    error) with the bar of the triangulated rows [m0,m1) widened by the rounding envelope of their formula and
+    by nothing else: the residual is 2 sqrt(2 - 2 cos th)-like (triangulation.cc:767-805) and ANY double
+    evaluation of it is off by ~K eps/|x| in x and ~K eps/x^2 relative in its gradient (mp_triangulated.py;
+    test_pair_residual_rounding_envelope_cpu holds the reference's rows and ours to K = 16 against a
+    60-digit evaluation). Two implementations may differ by twice that"""
+    import mp_triangulated as M
+    b_a, x_a, J_a, _ = res_amd
+    b_r, x_r, J_r, _ = res_ref
+    assert np.array_equal(b_a, b_r), f"{what}: b_packed differs"
+    assert np.array_equal(J_a.indptr,  J_r.indptr),  f"{what}: CSR rowptr differs"
+    assert np.array_equal(J_a.indices, J_r.indices), f"{what}: CSR colidx differs"
+    tri = np.zeros(x_r.shape, dtype=bool); tri[m0:m1] = True
+    assert relative_error(x_a[~tri], x_r[~tri]).max() < REL_TOL, what
+    assert np.all(np.abs(x_a - x_r)[tri] <= np.maximum(REL_TOL*np.abs(x_r[tri]), 2*M.noise_envelope_x(x_r[tri], K_ENVELOPE))), what
+    row_of = np.repeat(np.arange(len(x_r)), np.diff(J_r.indptr))
+    maxJ_row = np.maximum.reduceat(np.abs(J_r.data), J_r.indptr[:-1])
+    tolJ = np.where(tri, np.maximum(REL_TOL, 2*M.noise_envelope_J_rel(x_r, K_ENVELOPE)), 0.0)*maxJ_row
+    excess = np.abs(J_a.data - J_r.data) - np.maximum(tolJ[row_of], REL_TOL*(np.abs(J_a.data) + np.abs(J_r.data))/2. + REL_TOL*1e-6)
+    assert excess.max() <= 0, f"{what}: J differs beyond the bar in row {row_of[np.argmax(excess)]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("lensmodel,Npoints,Nboard_frames", (("LENSMODEL_PINHOLE", 60,   5),
+                                                             ("LENSMODEL_OPENCV4", 2500, 300)))
+def test_boards_and_triangulated_in_one_problem(amd, ref_api, lensmodel, Npoints, Nboard_frames):
+    """BASELINE.json's configuration 5 shape: board frames AND triangulated points in one problem (intrinsics
+    locked, extrinsics + frames optimized: mrcal.c:6043-6051). The triangulated rows sit BEHIND the board rows
+    in the measurement vector (mrcal.c:5180-5653 after :4603-4898), they touch only the extrinsics columns
+    while the board rows couple extrinsics and frames: the Schur elimination of the frames and the
+    extrinsics-only generic rows in one solve. Callback against the reference, then the solve against the
+    checker"""
+    from test_callback_parity import compare_callbacks
+    oi, truth = sfm_problem(lensmodel=lensmodel, Ncam=4, Npoints=Npoints, seed=9, noise=0.3, Nboard_frames=Nboard_frames)
+    Nobs_board = 4*Nboard_frames
+    for unity in (True, False):
+        oi["do_apply_regularization_unity_cam01"] = unity
+        ra = amd.optimizer_callback(no_factorization=True, **oi)
+        rr = ref_api.optimizer_callback(no_factorization=True, **oi)
+        m0 = amd.measurement_index_points_triangulated(**oi)
+        compare_callbacks_with_pairs(ra, rr, m0, m0 + amd.num_measurements_points_triangulated(**oi),
+                                     f"boards+triangulated {lensmodel} unity={unity}")
+    # the layout: board rows first, the pairs behind them, then the regularization
+    assert amd.num_states(**oi) == ref_api.num_states(**oi) == 6*3 + 6*Nboard_frames
+    assert amd.measurement_index_points_triangulated(**oi) == ref_api.measurement_index_points_triangulated(**oi) \
+        == Nobs_board*100*2
+    assert amd.num_measurements_points_triangulated(**oi) == ref_api.num_measurements_points_triangulated(**oi) >= Npoints
+    assert amd.measurement_index_regularization(**oi) == ref_api.measurement_index_regularization(**oi)
+    J = ra[2]
+    m0 = Nobs_board*200
+    # a pair's row holds extrinsics columns only; a board row of a non-reference camera holds both
+    assert J.indices[J.indptr[m0]:J.indptr[m0 + amd.num_measurements_points_triangulated(**oi)]].max() < 18
+    assert J.indices[J.indptr[200]:J.indptr[201]].max() >= 18
+
+    # the solve, outlier rejection on (boards AND divergent/k-sigma pairs)
+    oi["do_apply_regularization_unity_cam01"] = True
+    oi["do_apply_outlier_rejection"] = True
+    oa, orr = copy_inputs(oi), copy_inputs(oi)
+    sa = amd.optimize(**oa)
+    sr = ref_api.optimize(**orr)
+    assert sa["Noutliers_board"] == sr["Noutliers_board"]
+    assert sa["Noutliers_triangulated_point"] == sr["Noutliers_triangulated_point"]
+    assert np.array_equal(oa["observations_board"][...,2] < 0, orr["observations_board"][...,2] < 0)
+    assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
+    assert np.abs(sa["b_packed"] - sr["b_packed"]).max() < 2e-5
+    assert np.abs(oa["rt_cam_ref"] - orr["rt_cam_ref"]).max() < 1e-5
+    assert np.abs(oa["rt_ref_frame"] - orr["rt_ref_frame"]).max() < 1e-4
+    # and the geometry is the truth's up to the noise (the boards fix the scale)
+    assert np.abs(oa["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 5e-3
+    assert np.abs(oa["rt_cam_ref"][:,3:] - truth["rt_cam_ref"][:,3:]).max() < (5e-2 if Nboard_frames < 50 else 5e-3)
