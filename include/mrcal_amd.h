@@ -249,6 +249,26 @@ bool mrcal_optimizer_callback(double* b_packed, int buffer_size_b_packed,
                               int calibration_object_height_n,
                               bool verbose);
 
+/* reference: mrcal.h:613-669, uncertainty.c:798-1541 (Python: mrcal.drt_cross_reprojection__dbpacked(),
+   mrcal-pywrap.c:2012-2110). K_packed = drt_ref_refperturbed/db_packed (icam_intrinsics < 0: "rrp") or
+   drt_cam_camperturbed/db_packed for that camera ("ccp"), from the packed Jacobian Jt as
+   mrcal_optimizer_callback() fills it and the packed state it was evaluated at. Each Kpacked* is (6, N of that
+   block), rows stored densely (stride1 == sizeof(double); strides in bytes, <= 0: contiguous); NULL where the
+   block is not in the state. The sums over the rows of J run on the GPU (csrc/uncertainty.hip) */
+bool _mrcal_drt_cross_reprojection__dbpacked(double* Kpackede,  int Kpackede_stride0,  int Kpackede_stride1,
+                                             double* Kpackedf,  int Kpackedf_stride0,  int Kpackedf_stride1,
+                                             double* Kpackedp,  int Kpackedp_stride0,  int Kpackedp_stride1,
+                                             double* Kpackedcw, int Kpackedcw_stride0, int Kpackedcw_stride1,
+                                             const int icam_intrinsics,
+                                             const double* b_packed, int buffer_size_b_packed,
+                                             struct cholmod_sparse_struct* Jt,
+                                             int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                                             int Npoints, int Npoints_fixed,
+                                             int Nobservations_board, int Nobservations_point,
+                                             const mrcal_lensmodel_t* lensmodel,
+                                             mrcal_problem_selections_t problem_selections,
+                                             int calibration_object_width_n, int calibration_object_height_n);
+
 /* reference: mrcal.h:713-853 (layout of the measurement and state vectors),
    mrcal.c:337-735, 3737-3880 */
 int mrcal_measurement_index_boards(int i_observation_board,
@@ -583,6 +603,11 @@ int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* problem, int Nsteps, double
 void mrcal_amd_problem_solver_stats(mrcal_amd_problem_t* problem,
                                     int* Niterations, int* Nevaluations, int* Nfactorizations,
                                     int* Noutlier_passes, double* norm2_x, double* lambda, double* seconds);
+
+/* K (6, Nstate) row-major of _mrcal_drt_cross_reprojection__dbpacked() from the Jacobian the problem holds
+   (evaluated here at its current state; nothing crosses PCIe but K and one small record per observation).
+   Zero outside the extrinsics / frames / points / calobject_warp blocks, like the reference's wrapper leaves it */
+bool mrcal_amd_problem_drt_cross_reprojection(mrcal_amd_problem_t* problem, int icam_intrinsics, double* K);
 
 /* Test/diagnostic access. Evaluates at the resident state and copies out the
    normal equations N = JtJ in the solver's block form (see

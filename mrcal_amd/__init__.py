@@ -39,6 +39,7 @@ _api = _Api(_lib)
 
 optimize                              = _api.optimize
 optimizer_callback                    = _api.optimizer_callback
+drt_cross_reprojection__dbpacked      = _api.drt_cross_reprojection__dbpacked
 state_index_intrinsics                = _api.state_index_intrinsics
 state_index_extrinsics                = _api.state_index_extrinsics
 state_index_frames                    = _api.state_index_frames

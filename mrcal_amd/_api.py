@@ -464,6 +464,43 @@ class Api:
                 factorization = self._factorization(J, p)
         return b_packed, x, J, factorization
 
+    def drt_cross_reprojection__dbpacked(self, icam_intrinsics=-1, **kwargs):
+        """mrcal.drt_cross_reprojection__dbpacked() (mrcal-pywrap.c:2012-2110, 2156-2161): K (6,Nstate) =
+        drt_ref_refperturbed/db_packed (icam_intrinsics < 0 or None: the "rrp" form) or
+        drt_cam_camperturbed/db_packed of that camera ("ccp"), zero outside the extrinsics / frames / points /
+        calobject_warp columns: the cross-reprojection uncertainty's link between a perturbation of the solve
+        and the transform that compensates for it (mrcal/model_analysis.py:1379, 1441). One evaluation of the
+        Jacobian at the given state, then _mrcal_drt_cross_reprojection__dbpacked() (uncertainty.c:798)"""
+        icam = -1 if icam_intrinsics is None else int(icam_intrinsics)
+        kwargs = dict(kwargs, no_jacobian=False, no_factorization=True)
+        p = self._ingest(kwargs, callback=True)
+        if icam >= p.Ncameras_intrinsics:
+            raise RuntimeError(f"icam_intrinsics MUST be <0 (if unused) or in [0,Ncameras_intrinsics-1]. "
+                               f"got {icam} NOT in [0,{p.Ncameras_intrinsics-1}]")
+        b_packed, x, J, _ = self.optimizer_callback(**kwargs)
+        Nstate, Nmeas = J.shape[1], J.shape[0]
+        Jt = CholmodSparse(nrow=Nstate, ncol=Nmeas, nzmax=J.nnz,
+                           p=J.indptr.ctypes.data, i=J.indices.ctypes.data, x=J.data.ctypes.data,
+                           stype=0, itype=0, xtype=1, dtype=0, sorted=1, packed=1)
+        s = (p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
+             p.Nobservations_board, p.sel, C.byref(p.lensmodel))
+        K = np.zeros((6, Nstate), dtype=np.float64)
+        def block(i0):
+            return (K.ctypes.data + 8*i0 if i0 >= 0 else None), K.strides[0], K.strides[1]
+        i_e  = self.clib.mrcal_state_index_extrinsics(0, *s)
+        i_f  = self.clib.mrcal_state_index_frames(0, *s)
+        i_p  = self.clib.mrcal_state_index_points(0, *s)
+        i_cw = self.clib.mrcal_state_index_calobject_warp(*s)
+        ok = self.clib._mrcal_drt_cross_reprojection__dbpacked(
+            *block(i_e), *block(i_f), *block(i_p), *block(i_cw),
+            icam, _ptr(b_packed), Nstate*8, C.byref(Jt),
+            p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
+            p.Nobservations_board, p.Nobservations_point,
+            C.byref(p.lensmodel), p.sel, p.width_n, p.height_n)
+        if not ok:
+            raise RuntimeError("_mrcal_drt_cross_reprojection__dbpacked() failed" + self._last_error())
+        return K
+
     def _factorization(self, J, p):
         """the factorization of JtJ that optimizer_callback() returns; with the
         product library the structured GPU solver, told how the state splits"""

@@ -182,6 +182,11 @@ class MrcalLib:
         sig("mrcal_optimize", Stats,
             [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + common + [C.c_bool])
 
+        if hasattr(L, "_mrcal_drt_cross_reprojection__dbpacked"):
+            sig("_mrcal_drt_cross_reprojection__dbpacked", C.c_bool,
+                [C.c_void_p, C.c_int, C.c_int]*4 + [C.c_int, C.c_void_p, C.c_int, C.POINTER(CholmodSparse)] +
+                [C.c_int]*7 + [C.POINTER(Lensmodel), ProblemSelections, C.c_int, C.c_int])
+
     def has_symbol(self, name):
         return hasattr(self.lib, name)
 

@@ -188,6 +188,15 @@ class Problem:
                     "get_normal_equations")
         return dict(A=A, Bt=Bt, D=D, g=g, norm2_x=n2[0], Nc=Nc, NE=NE, NEb=NEb, Nfb=Nfb, Nie=Nie, Nwarp=Nwarp)
 
+    def drt_cross_reprojection__dbpacked(self, icam_intrinsics=-1):
+        """K (6,Nstate) of mrcal.drt_cross_reprojection__dbpacked() from the RESIDENT Jacobian at the current
+        state: J never leaves the device"""
+        f = self._lib.mrcal_amd_problem_drt_cross_reprojection
+        f.restype, f.argtypes = C.c_bool, [C.c_void_p, C.c_int, C.c_void_p]
+        K = np.zeros((6, self.Nstate))
+        self._check(f(self.handle, -1 if icam_intrinsics is None else int(icam_intrinsics), _ptr(K)), "drt_cross_reprojection")
+        return K
+
     def gauss_newton_step(self):
         d = np.zeros((self.Nstate,))
         self._check(self._lib.mrcal_amd_problem_gauss_newton_step(self.handle, _ptr(d)), "gauss_newton_step")
