@@ -94,14 +94,35 @@ def cpu_baseline(oi, Niterations):
                        "the reference with the real CHOLMOD is [value, value_upper_bound_callback_only]")
 
 
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, the way
+    the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
+    does, and pass rank 0's JSON line through. Returns the exit code"""
+    import socket
+    import subprocess
+    import torch
+    if torch.cuda.device_count() < ngpus:
+        print(f"bench.py: --gpus {ngpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     rank       = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world      = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: taking the launcher's", file=sys.stderr)
         args.gpus = world
 
     import numpy as np
@@ -237,6 +258,9 @@ def main():
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
                         frac = achieved/HBM_PEAK_GBS,
                         traffic = traffic,
+                        traffic_source = None if traffic is None else
+                            "committed constant: profiles/board_kernel_hbm_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
+                            "not re-measured in this run)",
                         algorithmic_bytes_per_launch = alg_bytes,
                         kernel_ms_avg = kernel_ms, kernel_ms_min = kmin_ms, kernel_ms_max = kmax_ms,
                         launches_timed = nlaunch, timed_every = TIMED_EVERY,

@@ -393,18 +393,14 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
         HIP_TRY(hipStreamSynchronize(P->stream), return false);
         return true;
     };
+    // Sharded: every rank issues the SAME collectives whether or not its shard holds any board corners or
+    // pairs (partition_frames() may leave a rank without observations): a rank that skipped one would sit in
+    // gather_state()'s all-reduce while the others are still in here. Decisions are taken from the summed
+    // numbers only, so they are the same everywhere.
     int counts[4]; double sum_board;
     if(!board_stats(-1.0, counts, &sum_board)) return false;
-    double Npts_all = (double)Npts;
-    {
-        double v[3] = { (double)counts[0], sum_board, Npts_all };
-        if(!over_ranks(v, 3)) return false;
-        counts[0] = (int)v[0]; sum_board = v[1]; Npts_all = v[2];
-    }
-    int Nout_board = counts[0];
-    const int Nin_board = (int)Npts_all - Nout_board;
 
-    // triangulated pairs: divergent ones are thrown out right away
+    // triangulated pairs (this rank's points): divergent ones are thrown out right away
     std::vector<double> x_tri(Npairs > 0 ? Npairs : 1), b(P->L.Nstate > 0 ? P->L.Nstate : 1);
     std::vector<int>&   out = P->tri_outlier_host;
     double sum_tri = 0.0;
@@ -437,6 +433,15 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
             else { sum_tri += x_tri[ip]*x_tri[ip]; Nin_tri++; }
         }
     }
+    double Npts_all = (double)Npts;
+    {
+        double v[7] = { (double)counts[0], sum_board, Npts_all, sum_tri, (double)Nin_tri, (double)Nout_tri, marked_tri ? 1.0 : 0.0 };
+        if(!over_ranks(v, 7)) return false;
+        counts[0] = (int)v[0]; sum_board = v[1]; Npts_all = v[2];
+        sum_tri = v[3]; Nin_tri = (int)v[4]; Nout_tri = (int)v[5]; marked_tri = v[6] > 0.0;
+    }
+    int Nout_board = counts[0];
+    const int Nin_board = (int)Npts_all - Nout_board;
     *Noutliers_board = Nout_board;
     *Noutliers_tri   = Nout_tri;
     bool any = marked_tri;
@@ -444,22 +449,22 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
     if(Ndenom > 0)
     {
         const double var = (sum_board + sum_tri)/(double)Ndenom;
-        if(!any && Npts > 0)
+        if(!any)
         {
             double dummy;
             if(!board_stats(k1*k1*var, counts, &dummy)) return false;
             double v[1] = { (double)counts[1] };
+            for(int ip = 0; ip < Npairs && v[0] == 0.0; ip++)
+            {
+                const TriPairMeta& m = P->tri_meta_host[ip];
+                if(!out[m.i0] && !out[m.i1] && x_tri[ip]*x_tri[ip] > k1*k1*var) v[0] = 1.0;
+            }
             if(!over_ranks(v, 1)) return false;
             if(v[0] > 0) any = true;
         }
-        if(!any)
-            for(int ip = 0; ip < Npairs; ip++)
-            {
-                const TriPairMeta& m = P->tri_meta_host[ip];
-                if(!out[m.i0] && !out[m.i1] && x_tri[ip]*x_tri[ip] > k1*k1*var) { any = true; break; }
-            }
         if(any)
         {
+            double v[2] = { 0.0, 0.0 };
             if(Npts > 0)
             {
                 HIP_TRY(hipMemsetAsync(P->d_counts, 0, 4*sizeof(int), P->stream), return false);
@@ -467,9 +472,7 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
                 HIP_TRY(hipMemcpyAsync(P->h_scalars + 32, P->d_counts, 4*sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
                 HIP_TRY(hipStreamSynchronize(P->stream), return false);
                 memcpy(counts, P->h_scalars + 32, 4*sizeof(int));
-                double v[1] = { (double)counts[0] };
-                if(!over_ranks(v, 1)) return false;
-                *Noutliers_board = Nout_board + (int)v[0];
+                v[0] = (double)counts[0];
             }
             for(int ip = 0; ip < Npairs; ip++)
             {
@@ -477,9 +480,12 @@ bool mark_outliers(mrcal_amd_problem* P, int* Noutliers_board, int* Noutliers_tr
                 if(!out[m.i0] && !out[m.i1] && x_tri[ip]*x_tri[ip] > k0*k0*var)
                 {
                     out[m.i0] = out[m.i1] = 1;
-                    (*Noutliers_tri)++;
+                    v[1] += 1.0;
                 }
             }
+            if(!over_ranks(v, 2)) return false;
+            *Noutliers_board = Nout_board + (int)v[0];
+            *Noutliers_tri   = Nout_tri   + (int)v[1];
         }
     }
     if(!any) return true;

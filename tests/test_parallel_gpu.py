@@ -221,3 +221,57 @@ def test_world2_points_only(amd, tmp_path):
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
     assert abs(float(r["rms"]) - s1["rms_reproj_error__pixels"]) < 1e-9
     assert np.abs(r["b"] - b1).max() < 1e-6
+
+
+def _rccl_world2_worker(rank, world, port, out_path):
+    """one rank of a REAL multi-GPU run: its own device, RCCL all-reduces issued from libmrcal_amd.so"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mrcal_amd
+    from mrcal_amd.parallel import ShardedProblem
+    oi = _problem(mrcal_amd._api)
+    sp = ShardedProblem(_driver="rccl", **oi)
+    st = sp.solve()
+    b = sp.b_packed()
+    # every rank ends with the same replicated state
+    t = torch.from_numpy(b.copy())
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"],
+                 Noutliers=st["Noutliers_board"], replicated=bool(torch.equal(lo, hi)),
+                 Ncollectives=sp.Ncollectives, Nevaluations=st["Nevaluations"])
+    sp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_world2_on_two_devices(amd, tmp_path):
+    """The product path with MORE THAN ONE RANK: two processes, two GPUs, ShardedProblem(_driver="rccl") - the
+    collectives are ncclAllReduce calls issued by libmrcal_amd.so between its own kernel launches. Skips itself
+    on a one-GPU box (the boxes of this pool); runs the first time it finds two devices. Same optimum, outliers
+    and cost as the single-GPU solve (the sums over two shards differ from the unsharded ones in the last bits,
+    so the trajectories may differ by rounding: compared to the solve's own tolerance, not bit for bit)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs, this box has {torch.cuda.device_count()}")
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    oi = _problem(amd._api)
+    with Problem(**oi) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "rccl2.npz")
+    port = 29500 + (os.getpid() % 250)
+    mp.spawn(_rccl_world2_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    assert bool(r["replicated"])
+    assert int(r["Noutliers"]) == s1["Noutliers_board"]
+    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
+    assert np.abs(r["b"] - b1).max() < 2e-5
+    assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
