@@ -147,6 +147,14 @@ def _check_region(region):
         raise Exception("The valid-intrinsics region must be a closed contour: first point == last point")
 
 
+class _Solve:
+    """where a model came from: the serialized optimization_inputs (bytes, or None) and which of that solve's
+    cameras this is"""
+    __slots__ = ("blob", "icam_i", "icam_e")
+    def __init__(self, blob=None, icam_i=None, icam_e=None):
+        self.blob, self.icam_i, self.icam_e = blob, icam_i, icam_e
+
+
 class cameramodel:
     """one camera: lens model + intrinsics, imager size, pose relative to the
     reference frame, optionally the solve that produced it"""
@@ -169,9 +177,7 @@ class cameramodel:
         from_inputs = optimization_inputs is not None or icam_intrinsics is not None or icam_extrinsics is not None
 
         self._valid_intrinsics_region = None
-        self._optimization_inputs_string = None
-        self._icam_intrinsics = None
-        self._icam_extrinsics = None
+        self._solve = _Solve()
 
         if file_or_model is not None:
             if discrete or from_inputs:
@@ -183,9 +189,7 @@ class cameramodel:
                 self._intrinsics = (str(o._intrinsics[0]), np.array(o._intrinsics[1], dtype=float))
                 if o._valid_intrinsics_region is not None:
                     self._valid_intrinsics_region = np.array(o._valid_intrinsics_region, dtype=float)
-                self._optimization_inputs_string = o._optimization_inputs_string
-                self._icam_intrinsics = o._icam_intrinsics
-                self._icam_extrinsics = o._icam_extrinsics
+                self._solve = _Solve(o._solve.blob, o._solve.icam_i, o._solve.icam_e)
             elif isinstance(file_or_model, str):
                 if file_or_model == "-":
                     import sys
@@ -217,12 +221,12 @@ class cameramodel:
                             imagersize=optimization_inputs["imagersizes"][icam_intrinsics],
                             optimization_inputs=optimization_inputs,
                             icam_intrinsics=icam_intrinsics, icam_extrinsics=icam_extrinsics)
-            if self._icam_extrinsics < 0:
+            if self._solve.icam_e < 0:
                 self.rt_cam_ref(np.zeros(6))
             else:
                 rt = optimization_inputs.get("rt_cam_ref")
                 if rt is None or _is_poison(rt): rt = optimization_inputs["extrinsics_rt_fromref"]
-                self.rt_cam_ref(rt[self._icam_extrinsics])
+                self.rt_cam_ref(rt[self._solve.icam_e])
         else:
             raise Exception("Need a filename or a cameramodel object or discrete arrays or optimization_inputs")
 
@@ -290,42 +294,52 @@ class cameramodel:
             icam_e = model.get("icam_extrinsics")
             if icam_e is not None and not isinstance(icam_e, int):
                 raise CameramodelParseException("'icam_extrinsics' is given, but it's not an int")
-            self._optimization_inputs_string = model["optimization_inputs"]
-            self._icam_intrinsics = icam
-            self._icam_extrinsics = icam_e
+            self._solve.blob = model["optimization_inputs"]
+            self._solve.icam_i = icam
+            self._solve.icam_e = icam_e
         else:
             if "icam_intrinsics" in model or "icam_extrinsics" in model:
                 raise CameramodelParseException("'optimization_inputs' is NOT given, but icam_intrinsics or icam_extrinsics ARE")
-            self._optimization_inputs_string = None
-            self._icam_intrinsics = None
-            self._icam_extrinsics = None
+            self._solve.blob = None
+            self._solve.icam_i = None
+            self._solve.icam_e = None
+
+    def _entries(self):
+        """the file as data: (key, python literal text, comment lines above it, trailing comment, blank line after).
+        The byte layout is the format's (mrcal/cameramodel.py:503-558 writes the same bytes; files are compared
+        byte for byte in tests/test_cameramodel.py)"""
+        def row(v): return "[" + "".join(f" {x:.10g}," for x in v) + "]"
+        lens, data = self._intrinsics
+        out = [("lensmodel", f" '{lens}'", (), None, True),
+               ("intrinsics", " " + row(data), ("intrinsics are fx,fy,cx,cy,distortion0,distortion1,....",), None, True)]
+        if self._valid_intrinsics_region is not None:
+            body = "".join(f"    [ {q[0]:.10g}, {q[1]:.10g} ],\n" for q in self._valid_intrinsics_region)
+            out.append(("valid_intrinsics_region", " [\n" + body + "]", (), None, True))
+        out.append(("rt_cam_ref", " " + row(self._rt_cam_ref), (), None, False))
+        out.append(("extrinsics", " " + row(self._rt_cam_ref), (), "for compatibility with mrcal < 2.5", True))
+        out.append(("imagersize", f" [ {int(self._imagersize[0])}, {int(self._imagersize[1])},]", (), None, True))
+        for key, v in (("icam_intrinsics", self._solve.icam_i), ("icam_extrinsics", self._solve.icam_e)):
+            if v is not None: out.append((key, f" {v:d}", (), None, False))
+        out.append((None, None, (), None, True))
+        if self._solve.blob is not None:
+            out.append(("optimization_inputs", f" {self._solve.blob}",
+                        ("Everything the solve that produced this model was given (ALL the observations of",
+                         "ALL its cameras), at its optimum: numpy .npz, compressed, base-85. Needed for",
+                         "projection uncertainties and for re-running the solve. Editing the intrinsics",
+                         "invalidates it; moving the camera (the extrinsics) does not"), None, True))
+        return out
 
     def _write(self, f, note=None):
-        def numbers_(v): return "".join(f" {x:.10g}," for x in v)
-        if note is not None:
-            for line in note.splitlines(): f.write("# " + line + "\n")
-        f.write("{\n")
-        f.write(f"    'lensmodel':  '{self._intrinsics[0]}',\n\n")
-        f.write("    # intrinsics are fx,fy,cx,cy,distortion0,distortion1,....\n")
-        f.write(f"    'intrinsics': [{numbers_(self._intrinsics[1])}],\n\n")
-        if self._valid_intrinsics_region is not None:
-            f.write("    'valid_intrinsics_region': [\n")
-            for row in self._valid_intrinsics_region:
-                f.write(f"    [ {row[0]:.10g}, {row[1]:.10g} ],\n")
-            f.write("],\n\n")
-        f.write(f"    'rt_cam_ref': [{numbers_(self._rt_cam_ref)}],\n")
-        f.write(f"    'extrinsics': [{numbers_(self._rt_cam_ref)}], # for compatibility with mrcal < 2.5\n\n")
-        f.write(f"    'imagersize': [ {int(self._imagersize[0])}, {int(self._imagersize[1])},],\n\n")
-        if self._icam_intrinsics is not None: f.write(f"    'icam_intrinsics': {self._icam_intrinsics:d},\n")
-        if self._icam_extrinsics is not None: f.write(f"    'icam_extrinsics': {self._icam_extrinsics:d},\n")
-        f.write("\n")
-        if self._optimization_inputs_string is not None:
-            f.write("    # Everything the solve that produced this model was given (ALL the observations of\n"
-                    "    # ALL its cameras), at its optimum: numpy .npz, compressed, base-85. Needed for\n"
-                    "    # projection uncertainties and for re-running the solve. Editing the intrinsics\n"
-                    "    # invalidates it; moving the camera (the extrinsics) does not\n")
-            f.write(f"    'optimization_inputs': {self._optimization_inputs_string},\n\n")
-        f.write("}\n")
+        text = ["# " + line + "\n" for line in (note.splitlines() if note is not None else ())]
+        text.append("{\n")
+        pad = {"lensmodel": " "}       # (the format aligns this one value with the next)
+        for key, literal, above, trailing, blank in self._entries():
+            text.extend(f"    # {c}\n" for c in above)
+            if key is not None:
+                text.append(f"    '{key}':{pad.get(key, '')}{literal},{' # ' + trailing if trailing else ''}\n")
+            if blank: text.append("\n")
+        text.append("}\n")
+        f.write("".join(text))
 
     def write(self, f, *, note=None, cahvor=False, opencv=False):
         """to a file name or an open text file"""
@@ -365,8 +379,8 @@ class cameramodel:
         self._imagersize = np.array(imagersize, dtype=np.int32)
         self._intrinsics = (str(intrinsics[0]), np.array(intrinsics[1], dtype=float))
         if optimization_inputs is not None:
-            self._optimization_inputs_string = _serialize_optimization_inputs(optimization_inputs)
-            self._icam_intrinsics = int(icam_intrinsics)
+            self._solve.blob = _serialize_optimization_inputs(optimization_inputs)
+            self._solve.icam_i = int(icam_intrinsics)
             if icam_extrinsics is None:
                 from . import corresponding_icam_extrinsics
                 clean = {k: v for k, v in optimization_inputs.items() if not _is_poison(v)}
@@ -375,11 +389,11 @@ class cameramodel:
                 except Exception as e:
                     raise Exception("optimization_inputs given, but icam_extrinsics not given, and it cannot be "
                                     f"inferred; are the cameras moving? Error: {e}")
-            self._icam_extrinsics = int(icam_extrinsics)
+            self._solve.icam_e = int(icam_extrinsics)
         else:
-            self._optimization_inputs_string = None
-            self._icam_intrinsics = None
-            self._icam_extrinsics = None
+            self._solve.blob = None
+            self._solve.icam_i = None
+            self._solve.icam_e = None
         self._valid_intrinsics_region = None
 
     def _pose(self, value, to_stored, from_stored):
@@ -422,30 +436,30 @@ class cameramodel:
     def optimization_inputs(self):
         """the kwargs of optimize()/optimizer_callback() at the optimum this model
         came from, or None"""
-        if self._optimization_inputs_string is None: return None
-        d = _deserialize_optimization_inputs(self._optimization_inputs_string)
+        if self._solve.blob is None: return None
+        d = _deserialize_optimization_inputs(self._solve.blob)
         d["verbose"] = False
         return d
 
     def optimization_inputs_reset(self):
-        self._optimization_inputs_string = None
+        self._solve.blob = None
 
     def icam_intrinsics(self):
-        return self._icam_intrinsics
+        return self._solve.icam_i
 
     def icam_extrinsics(self):
         """which camera pose of the solve this is (<0: the reference), or None
         without optimization_inputs. Files older than the key: inferred from the
         stored solve, which works for stationary cameras"""
-        if self._icam_intrinsics is None: return None
-        if self._icam_extrinsics is None:
+        if self._solve.icam_i is None: return None
+        if self._solve.icam_e is None:
             from . import corresponding_icam_extrinsics
             d = {k: v for k, v in self.optimization_inputs().items() if not _is_poison(v)}
-            self._icam_extrinsics = int(corresponding_icam_extrinsics(self._icam_intrinsics, **d))
-        return self._icam_extrinsics
+            self._solve.icam_e = int(corresponding_icam_extrinsics(self._solve.icam_i, **d))
+        return self._solve.icam_e
 
     def _optimization_inputs_match(self, other):
-        return self._optimization_inputs_string == other._optimization_inputs_string
+        return self._solve.blob == other._solve.blob
 
     def _extrinsics_moved_since_calibration(self):
         icam = self.icam_extrinsics()

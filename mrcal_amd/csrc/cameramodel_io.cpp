@@ -19,9 +19,17 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <locale.h>
 
 namespace
 {
+// the "C" locale, whatever LC_NUMERIC the process runs under: numbers in a .cameramodel are Python literals
+locale_t c_locale()
+{
+    static locale_t loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    return loc;
+}
+
 using mrcal_amd::set_error;
 
 struct Scanner
@@ -69,9 +77,15 @@ struct Scanner
         skip();
         const char c = s[i];
         if(!(c == '-' || c == '+' || c == '.' || (c >= '0' && c <= '9'))) return false;
+        // decimal digits, a point, an exponent: what Python's literal_eval takes for a number and the reference's
+        // scanner (cameramodel-parser.re) accepts. strtod() would also read hex floats, "inf", "nan", and takes its
+        // decimal separator from LC_NUMERIC: the token is checked first and converted in the C locale
+        size_t j = i;
+        while((s[j] >= '0' && s[j] <= '9') || s[j] == '+' || s[j] == '-' || s[j] == '.' || s[j] == 'e' || s[j] == 'E') j++;
+        if(s[j] == 'x' || s[j] == 'X' || s[j] == 'p' || s[j] == 'P') return false;
         char* end = NULL;
-        const double v = strtod(s + i, &end);
-        if(end == s + i) return false;
+        const double v = strtod_l(s + i, &end, c_locale());
+        if(end == s + i || (size_t)(end - s) > j) return false;
         const char e = *end;
         if(!(e == '\0' || e == ' ' || e == '\t' || e == '\n' || e == '\r' || e == ',' || e == ']' || e == ')' || e == '}' || e == '#'))
             return false;
@@ -316,6 +330,9 @@ bool mrcal_write_cameramodel_file(const char* filename, const mrcal_cameramodel_
     if(N < 0) { set_error("cameramodel: lens model '%s' has no parameter count", name); return false; }
     FILE* fp = fopen(filename, "w");
     if(fp == NULL) { set_error("cameramodel: could not open '%s' for writing", filename); return false; }
+    // (printf takes its decimal separator from LC_NUMERIC: a comma there would split every number in two for
+    //  Python's literal_eval and for the reader above)
+    const locale_t previous = uselocale(c_locale());
     fprintf(fp, "{\n    'lensmodel':  '%s',\n\n    'intrinsics': [", name);
     for(int i = 0; i < N; i++) fprintf(fp, " %.17g,", cameramodel->intrinsics[i]);
     fprintf(fp, "],\n\n");
@@ -326,6 +343,7 @@ bool mrcal_write_cameramodel_file(const char* filename, const mrcal_cameramodel_
         fprintf(fp, "],\n");
     }
     fprintf(fp, "\n    'imagersize': [ %u, %u ],\n}\n", cameramodel->imagersize[0], cameramodel->imagersize[1]);
+    uselocale(previous);
     const bool ok = !ferror(fp);
     if(fclose(fp) != 0 || !ok) { set_error("cameramodel: error writing '%s'", filename); return false; }
     return true;

@@ -290,11 +290,24 @@ struct CsrOnDevice
     ~CsrOnDevice() { hipFree(Jp); hipFree(Ji); hipFree(Jx); }
 };
 }
+// the caller's CSR is what the kernels index with: rowptr non-decreasing from 0, every column inside the matrix
+static bool csr_is_valid(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji)
+{
+    if(Nrows < 0 || Ncols < 0 || Jp == NULL || Jp[0] != 0) { set_error("malformed CSR matrix: rowptr must start at 0"); return false; }
+    for(int r = 0; r < Nrows; r++)
+        if(Jp[r+1] < Jp[r]) { set_error("malformed CSR matrix: rowptr decreases at row %d", r); return false; }
+    const int64_t nnz = Jp[Nrows];
+    unsigned bad = 0;
+    for(int64_t p = 0; p < nnz; p++) bad |= (unsigned)((unsigned)Ji[p] >= (unsigned)Ncols);
+    if(bad) { set_error("malformed CSR matrix: a column index is outside [0,%d)", Ncols); return false; }
+    return true;
+}
 bool mrcal_amd_csr_Jt_x(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx,
                         const double* x, double* y)
 {
     last_error_string().clear();
     if(mrcal_amd_device_count() <= 0) { set_error("no HIP device is visible: libmrcal_amd has no CPU fallback"); return false; }
+    if(!csr_is_valid(Nrows, Ncols, Jp, Ji)) return false;
     CsrOnDevice J(Nrows, Jp, Ji, Jx);
     if(!J.ok) { set_error("could not put J on the device"); return false; }
     double *dx = NULL, *dy = NULL;
@@ -320,6 +333,7 @@ bool mrcal_amd_csr_A_Jt_J_At(int Nrows, int Ncols, const int32_t* Jp, const int3
         set_error("Nleading_rows_J must be passed, and must be > 0 (and at most the %d rows of J)", Nrows);
         return false;
     }
+    if(!csr_is_valid(Nrows, Ncols, Jp, Ji)) return false;
     CsrOnDevice J(Nrows, Jp, Ji, Jx);
     if(!J.ok) { set_error("could not put J on the device"); return false; }
     double *dA = NULL, *dout = NULL;

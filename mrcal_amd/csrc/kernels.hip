@@ -1986,7 +1986,8 @@ hipError_t launch_unproject_points(int lens_type, const LensConfig& cfg, int N, 
         hipLaunchKernelGGL(unproject_closed_form_kernel, grid, block, 0, stream, lens_type, N, q, intr, v, dv_dq, dv_di);
     else
     {
-        const int behind_ok = (lens_type == MRCAL_LENSMODEL_CAHVORE) ? 1 : 0;
+        // can_project_behind_camera (mrcal.c:255-288): none of the parametric models that come this way can: a solution with z < 0 is flipped, mrcal.c:3274
+        const int behind_ok = 0;       // (the splined model, which can, has its own kernel below)
 #define MRCAL_AMD_UNPROJECT(PROJ, ND) hipLaunchKernelGGL((unproject_points_kernel<PROJ,ND>), grid, block, 0, stream, cfg, N, q, intr, behind_ok, v)
         switch(lens_type)
         {

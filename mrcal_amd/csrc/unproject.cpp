@@ -54,9 +54,10 @@ bool project_any(const mrcal_lensmodel_t& m, const LensConfig& cfg,
 }
 bool projects_behind_camera(mrcal_lensmodel_type_t t)
 {
+    // mrcal_lensmodel_metadata().can_project_behind_camera, mrcal.c:255-288 (CAHVORE: false; its solutions with
+    // z < 0 are flipped like the other models', mrcal.c:3274)
     return t == MRCAL_LENSMODEL_STEREOGRAPHIC || t == MRCAL_LENSMODEL_LONLAT ||
-           t == MRCAL_LENSMODEL_LATLON        || t == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC ||
-           t == MRCAL_LENSMODEL_CAHVORE;
+           t == MRCAL_LENSMODEL_LATLON        || t == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC;
 }
 
 } // namespace

@@ -345,3 +345,39 @@ def test_real_calibration_resolves_to_the_stored_optimum(amd, ref_api):
     assert abs(sg["rms_reproj_error__pixels"] - rms0) < 1e-5
     assert np.abs(pg["intrinsics"][0, :4] - oi["intrinsics"][0, :4]).max() < 0.05       # pixels
     assert np.abs(pg["intrinsics"] - pr["intrinsics"]).max() < 1e-3
+
+
+def test_c_reader_and_writer_ignore_the_numeric_locale(amd, tmp_path):
+    """numbers in a .cameramodel are Python literals whatever LC_NUMERIC says (a comma as the decimal separator
+    would split every number for literal_eval), and only decimal literals are numbers (strtod would also take hex
+    floats and 'inf')"""
+    import locale, ctypes as C
+    L = amd._lib.lib
+    L.mrcal_read_cameramodel_string.restype = C.c_void_p
+    L.mrcal_read_cameramodel_string.argtypes = [C.c_char_p, C.c_int]
+    L.mrcal_free_cameramodel.argtypes = [C.POINTER(C.c_void_p)]
+    L.mrcal_write_cameramodel_file.restype = C.c_bool
+    L.mrcal_write_cameramodel_file.argtypes = [C.c_char_p, C.c_void_p]
+    text = b"{'lensmodel': 'LENSMODEL_PINHOLE', 'intrinsics': [1000.5, 1001.25, 320.5, 240.75], " \
+           b"'rt_cam_ref': [0.5, 0.25, 0.125, 1.5, 2.5, 3.5], 'imagersize': [640, 480]}"
+    have = None
+    for name in ("de_DE.UTF-8", "fr_FR.UTF-8", "de_DE", "fr_FR"):
+        try:
+            locale.setlocale(locale.LC_NUMERIC, name); have = name; break
+        except locale.Error:
+            pass
+    try:
+        m = C.c_void_p(L.mrcal_read_cameramodel_string(text, len(text)))
+        assert m.value
+        out = str(tmp_path / "m.cameramodel")
+        assert L.mrcal_write_cameramodel_file(out.encode(), m)
+        L.mrcal_free_cameramodel(C.byref(m))
+    finally:
+        locale.setlocale(locale.LC_NUMERIC, "C")
+    back = amd.cameramodel(out)
+    assert np.array_equal(back.intrinsics()[1], (1000.5, 1001.25, 320.5, 240.75))
+    assert np.array_equal(back.rt_cam_ref(), (0.5, 0.25, 0.125, 1.5, 2.5, 3.5))
+    # (without such a locale installed the test still holds the C-locale path)
+    for bad in (b"0x1p3", b"inf", b"-inf", b"nan", b"1_000"):
+        t = text.replace(b"1000.5", bad)
+        assert not L.mrcal_read_cameramodel_string(t, len(t)), bad

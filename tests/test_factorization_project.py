@@ -262,6 +262,15 @@ def test_Jt_x_and_A_Jt_J_At(amd):
                           amd._A_Jt_J_At(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead))
     with pytest.raises(RuntimeError, match="Nleading_rows_J must be passed"):
         amd._A_Jt_J_At(A, J.indptr, J.indices, J.data)
+    # a malformed CSR is an error, not an out-of-bounds write on the device
+    bad = J.indices.copy(); bad[7] = Nstate + 3
+    with pytest.raises(RuntimeError, match="column index"):
+        amd._Jt_x(J.indptr, bad, J.data, x, out=out)
+    with pytest.raises(RuntimeError, match="column index"):
+        amd._A_Jt_J_At(A, J.indptr, bad, J.data, Nleading_rows_J=Nlead)
+    badp = J.indptr.copy(); badp[5] = badp[6] + 1
+    with pytest.raises(RuntimeError, match="rowptr"):
+        amd._Jt_x(badp, J.indices, J.data, x, out=out)
     # what mrcal's projection uncertainty does with them (model_analysis.py:755-766): regularization present
     dF = rng.normal(size=(2, Nstate))
     Ax = F.solve_xt_JtJ_bt(dF)
