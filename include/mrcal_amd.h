@@ -458,6 +458,38 @@ mrcal_amd_problem_create(const double*                 intrinsics,
                          int calibration_object_height_n,
                          int shard_begin_frame, int shard_end_frame,
                          bool is_shard_leader);
+/* The same with the discrete points and the triangulated points sharded as well: the shard owns
+   the points [shard_begin_point, shard_end_point) - their 3x3 blocks, and their observations wherever those sit
+   in the caller's array - and the triangulated point SETS [shard_begin_tripoint, shard_end_tripoint) (a set = the
+   consecutive observations of one point up to last_in_set; its pairs are its own rows). An end < 0: all of that
+   kind with the leader, as mrcal_amd_problem_create() does. The camera block of the state and the regularization
+   rows stay with the leader */
+mrcal_amd_problem_t*
+mrcal_amd_problem_create_sharded(const double*                 intrinsics,
+                         const mrcal_pose_t*           rt_cam_ref,
+                         const mrcal_pose_t*           rt_ref_frame,
+                         const mrcal_point3_t*         points,
+                         const mrcal_calobject_warp_t* calobject_warp,
+                         int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                         int Npoints, int Npoints_fixed,
+                         const mrcal_observation_board_t* observations_board,
+                         const mrcal_observation_point_t* observations_point,
+                         int Nobservations_board,
+                         int Nobservations_point,
+                         const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                         int Nobservations_point_triangulated,
+                         const mrcal_point3_t* observations_board_pool,
+                         const mrcal_point3_t* observations_point_pool,
+                         const mrcal_lensmodel_t* lensmodel,
+                         const int* imagersizes,
+                         mrcal_problem_selections_t problem_selections,
+                         double calibration_object_spacing,
+                         int calibration_object_width_n,
+                         int calibration_object_height_n,
+                         int shard_begin_frame, int shard_end_frame,
+                         int shard_begin_point, int shard_end_point,
+                         int shard_begin_tripoint, int shard_end_tripoint,
+                         bool is_shard_leader);
 void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem);
 
 /* sizes of the LOCAL (this shard's) problem */

@@ -407,7 +407,7 @@ int mrcal_amd_device_count(void)
 }
 
 mrcal_amd_problem_t*
-mrcal_amd_problem_create(const double*                 intrinsics,
+mrcal_amd_problem_create_sharded(const double*                 intrinsics,
                          const mrcal_pose_t*           rt_cam_ref,
                          const mrcal_pose_t*           rt_ref_frame,
                          const mrcal_point3_t*         points,
@@ -429,6 +429,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
                          int calibration_object_width_n,
                          int calibration_object_height_n,
                          int shard_begin_frame, int shard_end_frame,
+                         int shard_begin_point, int shard_end_point,
+                         int shard_begin_tripoint, int shard_end_tripoint,
                          bool is_shard_leader)
 {
     last_error_string().clear();
@@ -494,15 +496,43 @@ mrcal_amd_problem_create(const double*                 intrinsics,
             board_sel.push_back(i);
     }
     const int Nboard_local = (int)board_sel.size();
-    const int Npoint_local = is_shard_leader ? Nobservations_point : 0;
+    // discrete points: the shard owns the points [shard_begin_point, shard_end_point) (their 3x3 blocks of JtJ,
+    // their rows of x and J) wherever their observations sit in the caller's array (the API does
+    // not promise point-sorted observations). shard_end_point < 0: all of them on the leader, none elsewhere
+    if(!sharded || shard_end_point < 0) { shard_begin_point = 0; shard_end_point = (!sharded || is_shard_leader) ? Npoints : 0; }
+    std::vector<int> point_sel;
+    for(int i=0; i<Nobservations_point; i++)
+    {
+        const int ip = observations_point[i].i_point;
+        if(ip >= shard_begin_point && ip < shard_end_point) point_sel.push_back(i);
+    }
+    const int Npoint_local = (int)point_sel.size();
+    // triangulated points: a point's observations are consecutive (last_in_set ends the set) and its pairs are its
+    // own, so the shard takes the point SETS [shard_begin_tripoint, shard_end_tripoint): one contiguous range of
+    // observations [tri_o0, tri_o1). < 0: all with the leader
+    int tri_o0 = 0, tri_o1 = 0;
+    {
+        if(!sharded || shard_end_tripoint < 0) { shard_begin_tripoint = 0; shard_end_tripoint = (!sharded || is_shard_leader) ? 0x7fffffff : 0; }
+        int iset = 0;
+        bool in_range = false;
+        for(int i=0; i<Nobservations_point_triangulated; i++)
+        {
+            const bool mine = iset >= shard_begin_tripoint && iset < shard_end_tripoint;
+            if(mine && !in_range) { tri_o0 = i; in_range = true; }
+            if(mine) tri_o1 = i + 1;
+            if(observations_point_triangulated[i].last_in_set) iset++;
+        }
+        if(!in_range) tri_o0 = tri_o1 = 0;
+    }
+    const int Ntri_local = tri_o1 - tri_o0;
+    const mrcal_observation_point_triangulated_t* tri_local = (Ntri_local > 0) ? observations_point_triangulated + tri_o0 : NULL;
 
     Layout L = Lg;
     L.dims.Nobservations_board = Nboard_local;   // NOTE: has_warp etc. stay global
     L.dims.Nobservations_point = Npoint_local;
     L.Nmeas_boards         = Nboard_local * calibration_object_width_n*calibration_object_height_n * 2;
     L.Nmeas_points         = Npoint_local * 2;
-    // the triangulated points stay whole, with the shard leader
-    L.Nmeas_triangulated   = is_shard_leader ? Lg.Nmeas_triangulated : 0;
+    L.Nmeas_triangulated   = num_measurements_triangulated_initial(tri_local, Ntri_local, -1);
     if(!is_shard_leader) { L.Nmeas_regularization = 0; L.has_unity_cam01 = false; L.Nreg_percamera = 0; }
     L.i_meas_boards         = 0;
     L.i_meas_points         = L.Nmeas_boards;
@@ -541,7 +571,7 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     std::vector<PointObsMeta> pmeta(Npoint_local);
     for(int j=0; j<Npoint_local; j++)
     {
-        const mrcal_observation_point_t& o = observations_point[j];
+        const mrcal_observation_point_t& o = observations_point[point_sel[j]];
         PointObsMeta& m = pmeta[j];
         memset(&m, 0, sizeof(m));
         const bool variable = sel.do_optimize_frames && o.i_point < Npoints - Npoints_fixed;
@@ -561,11 +591,11 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     std::vector<TriPairMeta> tmeta;
     if(L.Nmeas_triangulated > 0)
     {
-        const mrcal_observation_point_triangulated_t* ot = observations_point_triangulated;
-        for(int i0 = 0; i0 < Nobservations_point_triangulated; i0++)
+        const mrcal_observation_point_triangulated_t* ot = tri_local;      // (indices local to the shard's range)
+        for(int i0 = 0; i0 < Ntri_local; i0++)
         {
             if(ot[i0].last_in_set) continue;
-            for(int i1 = i0+1; i1 < Nobservations_point_triangulated; i1++)
+            for(int i1 = i0+1; i1 < Ntri_local; i1++)
             {
                 TriPairMeta m;
                 memset(&m, 0, sizeof(m));
@@ -633,6 +663,8 @@ mrcal_amd_problem_create(const double*                 intrinsics,
         pool_src = pool_local.data();
     }
     P->board_sel = board_sel;
+    std::vector<mrcal_point3_t> point_pool_local((size_t)(Npoint_local > 0 ? Npoint_local : 1));
+    for(int j=0; j<Npoint_local; j++) point_pool_local[j] = observations_point_pool[point_sel[j]];
 
     bool ok = true;
     HIP_TRY(hipStreamCreateWithFlags(&P->stream, hipStreamNonBlocking), ok = false);
@@ -649,17 +681,18 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     ok = ok && dev_upload(&P->d_board_meta,        bmeta.data(),                (size_t)Nboard_local);
     ok = ok && dev_upload(&P->d_board_pool,        (const double*)pool_src,     (size_t)Nboard_local*NPTS*3);
     ok = ok && dev_upload(&P->d_point_meta,        pmeta.data(),                (size_t)Npoint_local);
-    ok = ok && dev_upload(&P->d_point_pool,        (const double*)observations_point_pool, (size_t)Npoint_local*3);
+    ok = ok && dev_upload(&P->d_point_pool,        (const double*)point_pool_local.data(), (size_t)Npoint_local*3);
     ok = ok && dev_upload(&P->d_imagersizes,       imagersizes,                 (size_t)Ncameras_intrinsics*2);
     {
-        const int Nt = Nobservations_point_triangulated;
+        const int Nt = Ntri_local;
+        P->tri_obs0 = tri_o0;
         P->tri_meta_host = tmeta;
         P->tri_px_host.resize((size_t)3*Nt + 1);
         P->tri_outlier_host.resize((size_t)Nt + 1);
         for(int i=0;i<Nt;i++)
         {
-            for(int j=0;j<3;j++) P->tri_px_host[3*i+j] = observations_point_triangulated[i].px.xyz[j];
-            P->tri_outlier_host[i] = observations_point_triangulated[i].outlier ? 1 : 0;
+            for(int j=0;j<3;j++) P->tri_px_host[3*i+j] = tri_local[i].px.xyz[j];
+            P->tri_outlier_host[i] = tri_local[i].outlier ? 1 : 0;
         }
         ok = ok && dev_upload(&P->d_tri_meta,    tmeta.data(),                tmeta.size());
         ok = ok && dev_upload(&P->d_tri_px,      P->tri_px_host.data(),       (size_t)3*Nt);
@@ -693,8 +726,13 @@ mrcal_amd_problem_create(const double*                 intrinsics,
             P->br.frame_lo = shard_begin_frame < 0 ? 0 : shard_begin_frame;
             P->br.frame_hi = (shard_end_frame < 0 || shard_end_frame > Nframes) ? Nframes : shard_end_frame;
         }
-        P->br.point_lo  = nd.Nfb;
-        P->br.point_hi  = is_shard_leader ? nd.NEb : nd.Nfb;
+        // the point blocks (the variable points only) of the shard's point range
+        {
+            auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+            P->br.point_lo = nd.Nfb + clampi(shard_begin_point, 0, nd.Npb);
+            P->br.point_hi = nd.Nfb + clampi(shard_end_point,   0, nd.Npb);
+            if(P->br.point_hi < P->br.point_lo) P->br.point_hi = P->br.point_lo;
+        }
     }
 
     DeviceProblem& D = P->D;
@@ -768,6 +806,42 @@ mrcal_amd_problem_create(const double*                 intrinsics,
     }
     HIP_TRY(hipStreamSynchronize(P->stream), { delete P; return NULL; });
     return P;
+}
+
+mrcal_amd_problem_t*
+mrcal_amd_problem_create(const double*                 intrinsics,
+                         const mrcal_pose_t*           rt_cam_ref,
+                         const mrcal_pose_t*           rt_ref_frame,
+                         const mrcal_point3_t*         points,
+                         const mrcal_calobject_warp_t* calobject_warp,
+                         int Ncameras_intrinsics, int Ncameras_extrinsics, int Nframes,
+                         int Npoints, int Npoints_fixed,
+                         const mrcal_observation_board_t* observations_board,
+                         const mrcal_observation_point_t* observations_point,
+                         int Nobservations_board,
+                         int Nobservations_point,
+                         const mrcal_observation_point_triangulated_t* observations_point_triangulated,
+                         int Nobservations_point_triangulated,
+                         const mrcal_point3_t* observations_board_pool,
+                         const mrcal_point3_t* observations_point_pool,
+                         const mrcal_lensmodel_t* lensmodel,
+                         const int* imagersizes,
+                         mrcal_problem_selections_t problem_selections,
+                         double calibration_object_spacing,
+                         int calibration_object_width_n,
+                         int calibration_object_height_n,
+                         int shard_begin_frame, int shard_end_frame,
+                         bool is_shard_leader)
+{
+    // the shard leader owns every discrete and triangulated point
+    return mrcal_amd_problem_create_sharded(intrinsics, rt_cam_ref, rt_ref_frame, points, calobject_warp,
+                                            Ncameras_intrinsics, Ncameras_extrinsics, Nframes, Npoints, Npoints_fixed,
+                                            observations_board, observations_point, Nobservations_board, Nobservations_point,
+                                            observations_point_triangulated, Nobservations_point_triangulated,
+                                            observations_board_pool, observations_point_pool, lensmodel, imagersizes,
+                                            problem_selections, calibration_object_spacing,
+                                            calibration_object_width_n, calibration_object_height_n,
+                                            shard_begin_frame, shard_end_frame, 0, -1, 0, -1, is_shard_leader);
 }
 
 void mrcal_amd_problem_destroy(mrcal_amd_problem_t* problem)

@@ -69,6 +69,7 @@ struct mrcal_amd_problem
     std::vector<mrcal_amd::TriPairMeta> tri_meta_host;
     std::vector<double>      tri_px_host;
     std::vector<int>         tri_outlier_host;
+    int                      tri_obs0 = 0;      // the shard's first triangulated observation in the caller's array
 
     // shared between the operating points
     double*  d_joint = NULL;

@@ -709,6 +709,7 @@ void mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info)
     info[4] = P->br.frame_lo; info[5] = P->br.frame_hi; info[6] = P->is_leader ? 1 : 0;
     info[7] = P->D.Nobs_board * P->D.W * P->D.H;
     info[8] = P->nd.Nfb; info[9] = P->nd.Npb;
+    info[10] = P->br.point_lo; info[11] = P->br.point_hi;      // point BLOCKS (indices >= Nfb) this shard owns
 }
 // outlier statistics / marking on the local board observations
 // (mrcal.c:3978-4402). counts (device int[4]) and sums (device double[1]) are

@@ -1,4 +1,5 @@
-"""Multi-GPU solve: one process per GPU, board observations sharded by FRAME.
+"""Multi-GPU solve: one process per GPU, board observations sharded by FRAME, discrete points by POINT,
+triangulated points by point SET.
 
 Why frames: every measurement row of a chessboard calibration touches exactly
 one frame pose, so a contiguous range of frames owns its rows of x and J, its
@@ -60,6 +61,44 @@ def partition_frames(indices_frame_camintrinsics_camextrinsics, Nframes, world):
         bounds.append(f)
     bounds.append(Nframes)
     return [(bounds[r], bounds[r+1]) for r in range(world)]
+
+
+def partition_counts(counts, world):
+    """Contiguous index ranges [(i0,i1)]*world over len(counts) items with ~equal sums of counts: every item in
+    exactly one range; ranges may be empty"""
+    counts = np.asarray(counts, dtype=np.int64)
+    N      = len(counts)
+    total  = int(counts.sum())
+    csum   = np.concatenate(((0,), np.cumsum(counts)))
+    bounds = [0]
+    for r in range(1, world):
+        i = int(np.searchsorted(csum, total*r/world, side="left"))
+        bounds.append(min(max(i, bounds[-1]), N))
+    bounds.append(N)
+    return [(bounds[r], bounds[r+1]) for r in range(world)]
+
+
+def partition_points(indices_point_camintrinsics_camextrinsics, Npoints, world):
+    """Discrete points sharded BY POINT: contiguous ranges of i_point with ~equal observation
+    counts. A point's 3x3 block of JtJ and all of its observations (in whatever order the caller listed them) go
+    to one rank"""
+    idx = np.asarray(indices_point_camintrinsics_camextrinsics).reshape(-1, 3)
+    counts = np.bincount(idx[:,0], minlength=Npoints) if Npoints > 0 else np.zeros((0,), np.int64)
+    return partition_counts(counts, world)
+
+
+def partition_triangulated(last_in_set, world):
+    """Triangulated points sharded by point SET (the consecutive observations of one point, closed by
+    last_in_set): contiguous ranges of set indices with ~equal numbers of PAIRS (a set of n observations is
+    n(n-1)/2 measurement rows)"""
+    last = np.asarray(last_in_set, dtype=bool)
+    if last.size == 0:
+        return [(0, 0)]*world
+    ends = np.nonzero(last)[0]
+    if ends.size == 0 or ends[-1] != last.size - 1:
+        ends = np.concatenate((ends, (last.size - 1,)))
+    n = np.diff(np.concatenate(((-1,), ends)))
+    return partition_counts(n*(n-1)//2, world)
 
 
 # ---------------------------------------------------------------------------
@@ -259,11 +298,12 @@ class GpuShard:
         self.p     = problem
         self.L = L = problem._lib
         _declare_sharded(L)
-        info = (C.c_int*10)()
+        info = (C.c_int*12)()
         L.mrcal_amd_problem_shard_info(problem.handle, info)
         self.Nstate, self.Nie, self.NE, self.Nc = info[0], info[1], info[2], info[3]
         self.frame_lo, self.frame_hi = info[4], info[5]
         self.Nfb = info[8]
+        self.point_lo, self.point_hi = info[10] - info[8], info[11] - info[8]      # variable points owned
         self.is_leader = bool(info[6])
         self.Nmeas_global = Nmeas_global
         self.Ncorners_global = Ncorners_global
@@ -326,8 +366,9 @@ class GpuShard:
         mine = np.zeros(self.Nstate, dtype=bool)
         if self.is_leader:
             mine[:self.Nie] = True
-            mine[self.Nie + 6*self.Nfb:] = True          # the points, the warp
+            mine[self.Nie + self.NE:] = True             # the warp
         mine[self.Nie + 6*self.frame_lo : self.Nie + 6*self.frame_hi] = True
+        mine[self.Nie + 6*self.Nfb + 3*self.point_lo : self.Nie + 6*self.Nfb + 3*self.point_hi] = True
         b[~mine] = 0.0
         return self.torch.from_numpy(b).to("cuda")
     def set_state(self, t):
@@ -354,13 +395,20 @@ class ShardedProblem:
         self.rank  = dist.get_rank(group)       if have_dist else 0
         self.world = dist.get_world_size(group) if have_dist else 1
         p = _api._ingest(optimization_inputs, callback=False)
-        if len(p.c_tri) > 0:
-            # the outlier logic of triangulated pairs is sequential over the pairs
-            # (mrcal.c:3978-4402) and lives with the single-GPU solve
-            raise NotImplementedError("ShardedProblem: triangulated points are solved on one GPU (mrcal_amd.optimize())")
-        ranges = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.world)
-        self.frame_range = ranges[self.rank]
-        self.problem = Problem(_shard=self.frame_range, _leader=(self.rank == 0), **optimization_inputs)
+        self.do_outlier_rejection = bool(p.sel.as_dict()["do_apply_outlier_rejection"])
+        if len(p.c_tri) > 0 and _driver == "python" and self.do_outlier_rejection:
+            # (the protocol reference's mark_outliers() knows boards only; the product path - the C++ one - does
+            #  the pairs' divergence and k-sigma logic per shard, with the variance summed over the ranks)
+            raise NotImplementedError("the Python protocol driver rejects board outliers only; use the RCCL driver")
+        # boards by frame, discrete points by point, triangulated points by point set: the rows of x and J and the
+        # eliminated blocks of each are then local to one rank
+        self.frame_range = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, self.world)[self.rank]
+        self.point_range = partition_points(np.column_stack((p.c_point["i_point"],)*3), p.Npoints, self.world)[self.rank] \
+                           if len(p.c_point) > 0 else (0, 0)
+        self.tripoint_range = partition_triangulated(p.c_tri["flags"] & 1, self.world)[self.rank]
+        self.problem = Problem(_shard=self.frame_range, _leader=(self.rank == 0),
+                               _shard_points=self.point_range, _shard_tripoints=self.tripoint_range,
+                               **optimization_inputs)
         self.Nstate_global, self.Nmeas_global = _api._sizes(p)
         self.Nstate = self.Nstate_global
         self.Nnz_global = self.problem.Nnz
@@ -374,7 +422,6 @@ class ShardedProblem:
         self._comm_handle = None
         self.dogleg = None
         self.Ncorners = p.Nobservations_board*max(p.width_n,0)*max(p.height_n,0)
-        self.do_outlier_rejection = bool(p.sel.as_dict()["do_apply_outlier_rejection"])
         if _driver == "python":
             self.comm  = Communicator(group)
             self.shard = GpuShard(self.problem, self.Nmeas_global, self.Ncorners, self.do_outlier_rejection)

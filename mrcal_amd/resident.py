@@ -18,7 +18,7 @@ class Problem:
         x = p.x()                    # host copies on demand
     """
 
-    def __init__(self, _shard=(0,-1), _leader=True, **optimization_inputs):
+    def __init__(self, _shard=(0,-1), _leader=True, _shard_points=(0,-1), _shard_tripoints=(0,-1), **optimization_inputs):
         from . import _api, _lib
         self._api = _api
         self._lib = _lib.lib
@@ -27,9 +27,10 @@ class Problem:
         self._inputs = p   # keeps the numpy arrays alive
         a = _api._common_args(p)
         # common args: ..., lensmodel, imagersizes, sel, problem_constants, spacing, W, H, verbose
-        self.handle = self._lib.mrcal_amd_problem_create(
+        self.handle = self._lib.mrcal_amd_problem_create_sharded(
             *a[:18], a[18], a[19], a[20], a[22], a[23], a[24],
-            int(_shard[0]), int(_shard[1]), bool(_leader))
+            int(_shard[0]), int(_shard[1]), int(_shard_points[0]), int(_shard_points[1]),
+            int(_shard_tripoints[0]), int(_shard_tripoints[1]), bool(_leader))
         if not self.handle:
             raise RuntimeError("mrcal_amd_problem_create() failed:" + _api._last_error())
         self.Nstate = self._lib.mrcal_amd_problem_Nstate(self.handle)
@@ -42,8 +43,8 @@ class Problem:
         if getattr(L, "_mrcal_amd_resident_declared", False):
             return
         vp = C.c_void_p
-        L.mrcal_amd_problem_create.restype  = vp
-        L.mrcal_amd_problem_create.argtypes = [
+        L.mrcal_amd_problem_create_sharded.restype  = vp
+        L.mrcal_amd_problem_create_sharded.argtypes = [
             vp, vp, vp, vp, vp,
             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
             vp, vp, C.c_int, C.c_int,
@@ -51,7 +52,7 @@ class Problem:
             vp, vp,
             C.POINTER(Lensmodel), vp, ProblemSelections,
             C.c_double, C.c_int, C.c_int,
-            C.c_int, C.c_int, C.c_bool]
+            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_bool]
         L.mrcal_amd_problem_destroy.restype  = None
         L.mrcal_amd_problem_destroy.argtypes = [vp]
         for name in ("Nstate", "Nmeasurements"):

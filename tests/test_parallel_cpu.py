@@ -38,6 +38,21 @@ def test_partition_frames():
             assert max(counts) - min(counts) <= 2*ncam.max()
 
 
+def test_partitions_of_points_and_pairs():
+    from mrcal_amd.parallel import partition_points, partition_triangulated, partition_counts
+    idx = np.array(((0,0,-1),(2,1,0),(1,0,-1),(2,0,-1),(3,1,0),(3,0,-1),(3,2,1)), dtype=np.int32)     # unsorted by point
+    for world in (1, 2, 3, 8):
+        r = partition_points(idx, 5, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == 5
+        assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+    last = np.array((0,0,1, 0,1, 0,0,0,1, 0,1), dtype=bool)      # sets of 3, 2, 4, 2 observations: 3, 1, 6, 1 pairs
+    assert partition_triangulated(last, 1) == [(0,4)]
+    r = partition_triangulated(last, 2)
+    assert r[0][0] == 0 and r[-1][1] == 4 and r[0][1] == r[1][0]
+    assert partition_triangulated(np.zeros((0,), dtype=bool), 3) == [(0,0)]*3
+    assert partition_counts([5,5,5,5], 2) == [(0,2),(2,4)]
+
+
 class NumpyShard:
     """CPU stand-in for GpuShard (same interface), for ONE rank: the two
     segments of the sharded trial step in numpy, the device-side control logic

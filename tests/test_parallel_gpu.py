@@ -275,3 +275,128 @@ def test_rccl_world2_on_two_devices(amd, tmp_path):
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
     assert np.abs(r["b"] - b1).max() < 2e-5
     assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
+
+
+# ---- discrete points sharded by point, triangulated points by point set --------------------
+def _sfm_with_everything(api, seed=9):
+    """boards AND triangulated points AND discrete points (some fixed, listed out of point order) in one problem,
+    intrinsics locked; the discrete points sit where the truth geometry puts them, so that the optimum is well
+    determined"""
+    from test_triangulated import sfm_problem, R_from_r
+    oi, truth = sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=120, seed=seed, noise=0.3, Nboard_frames=9)
+    rng = np.random.RandomState(seed + 5)
+    Np, Nfixed = 11, 3
+    pts = np.column_stack((rng.uniform(-2, 1, Np), rng.uniform(-1, 1, Np), rng.uniform(5, 9, Np)))
+    # every point's first observation in point order (the wrapper wants the indices to extend the set one at a
+    # time, mrcal-pywrap.c:1159-1204), the others after them in random order: NOT sorted by point
+    cams = [np.sort(rng.choice(4, size=3, replace=False)) for _ in range(Np)]
+    pairs = [(ip, cams[ip][0]) for ip in range(Np)]
+    rest  = [(ip, c) for ip in range(Np) for c in cams[ip][1:]]
+    pairs += [rest[i] for i in rng.permutation(len(rest))]
+    idx, obs = [], []
+    for ip, ic in pairs:
+        rt = truth["rt_cam_ref"][ic-1] if ic > 0 else None
+        pc = pts[ip] if rt is None else R_from_r(rt[:3]) @ pts[ip] + rt[3:]
+        q = api.project(pc[None], oi["lensmodel"], oi["intrinsics"][ic])[0] + rng.normal(0, 0.3, 2)
+        idx.append((ip, ic, ic-1)); obs.append((q[0], q[1], rng.uniform(0.5, 1.5)))
+    idx = np.array(idx, dtype=np.int32); obs = np.array(obs)
+    obs[2,2] = -1.
+    oi.update(points = np.ascontiguousarray(pts + np.r_[rng.normal(0, 0.05, (Np-Nfixed,3)), np.zeros((Nfixed,3))]),
+              observations_point = np.ascontiguousarray(obs), indices_point_camintrinsics_camextrinsics = idx,
+              Npoints_fixed = Nfixed)
+    return oi
+
+
+@pytest.mark.parametrize("world", (2, 3))
+def test_shards_of_points_and_pairs_add_up(amd, world):
+    """what the all-reduce relies on, for every kind of row at once: the normal equations of the shards - boards
+    by frame, discrete points by point, triangulated points by point set, regularization with the leader - sum
+    to the unsharded ones, every measurement row is in exactly one shard, every eliminated block in exactly one"""
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.parallel import partition_frames, partition_points, partition_triangulated
+    from mrcal_amd.synthetic import copy_inputs
+    oi = _sfm_with_everything(amd._api)
+    p = amd._api._ingest(dict(oi), callback=False)
+    fr = partition_frames(p.c_board["iframe"].reshape(-1,1), p.Nframes, world)
+    pr = partition_points(np.column_stack((p.c_point["i_point"],)*3), p.Npoints, world)
+    tr = partition_triangulated(p.c_tri["flags"] & 1, world)
+    with Problem(**copy_inputs(oi)) as p0:
+        ne = p0.normal_equations()
+        Nmeas, Nnz = p0.Nmeas, p0.Nnz
+    acc, Nm, Nz = None, 0, 0
+    for r in range(world):
+        with Problem(_shard=fr[r], _leader=(r == 0), _shard_points=pr[r], _shard_tripoints=tr[r], **copy_inputs(oi)) as ps:
+            n = ps.normal_equations()
+            Nm += ps.Nmeas; Nz += ps.Nnz
+        if acc is None: acc = {k: np.array(n[k], dtype=float) for k in ("A", "Bt", "D", "g")}; acc["norm2_x"] = n["norm2_x"]
+        else:
+            for k in ("A", "Bt", "D", "g"): acc[k] += n[k]
+            acc["norm2_x"] += n["norm2_x"]
+    assert Nm == Nmeas and Nz == Nnz
+    for k in ("A", "Bt", "D", "g"):
+        assert np.abs(acc[k] - ne[k]).max() < 1e-10*np.abs(ne[k]).max(), k
+    assert abs(acc["norm2_x"] - ne["norm2_x"]) < 1e-10*ne["norm2_x"]
+
+
+def test_rccl_world1_solves_points_and_pairs(amd):
+    """ShardedProblem no longer refuses triangulated points: the product path (collectives from C++, outlier
+    logic of the pairs per shard with the variance summed over the ranks) with a world of one == the single-GPU
+    solve, outliers of both kinds included"""
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.parallel import ShardedProblem
+    from mrcal_amd.synthetic import copy_inputs
+    oi = _sfm_with_everything(amd._api)
+    oi["do_apply_outlier_rejection"] = True
+    oi["observations_board"][3,2,4,:2] += 40.       # something to throw out
+    with Problem(**copy_inputs(oi)) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    sp = ShardedProblem(_driver="rccl", **copy_inputs(oi))
+    s2 = sp.solve()
+    b2 = sp.b_packed()
+    sp.close()
+    assert s2["Noutliers_board"] == s1["Noutliers_board"] > 0
+    assert abs(s2["norm2_x"] - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
+    assert np.abs(b1 - b2).max() < 1e-6
+
+
+def _pairs_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mrcal_amd
+    from mrcal_amd.parallel import ShardedProblem
+    oi = _sfm_with_everything(mrcal_amd._api)
+    oi["do_apply_outlier_rejection"] = False
+    sp = ShardedProblem(_driver="python", **oi)
+    st = sp.solve()
+    if rank == 0:
+        np.savez(out_path, b=sp.b_packed(), rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"],
+                 ranges=np.array((sp.frame_range, sp.point_range, sp.tripoint_range)))
+    sp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_points_and_pairs(amd, tmp_path):
+    """two ranks (one device, protocol driver over gloo): boards, discrete points and triangulated points each
+    split between the ranks; the same optimum as the single-GPU solve"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.synthetic import copy_inputs
+    oi = _sfm_with_everything(amd._api)
+    oi["do_apply_outlier_rejection"] = False
+    with Problem(**copy_inputs(oi)) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "w2sfm.npz")
+    port = 29600 + (os.getpid() % 250)
+    mp.spawn(_pairs_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    # every kind really was split
+    assert all(0 < hi - lo for lo, hi in r["ranges"])
+    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
+    assert np.abs(r["b"] - b1).max() < 1e-6
