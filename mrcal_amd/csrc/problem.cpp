@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <map>
 #include <algorithm>
 #include "layout.hpp"
 #include "host_state.hpp"
@@ -67,6 +68,12 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
     hipFree(plan.spl_hdr); hipFree(plan.spl_part);
+    {
+        mrcal_amd::GenPlan& G = plan.gen;
+        hipFree(G.rows); hipFree(G.chunk_begin); hipFree(G.chunk_group); hipFree(G.group_k); hipFree(G.group_off); hipFree(G.spos);
+        hipFree(G.scol); hipFree(G.part); hipFree(G.dest_id); hipFree(G.dest_begin); hipFree(G.dest_src); hipFree(G.group_chunk_begin);
+        hipFree(G.eb_block); hipFree(G.eb_begin); hipFree(G.eb_rows); hipFree(G.eb_group); hipFree(G.eb_epos);
+    }
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -83,6 +90,159 @@ mrcal_amd_problem::~mrcal_amd_problem()
 }
 
 namespace mrcal_amd {
+
+// The fixed-order plan for the rows outside the Grams that share destinations: discrete points, triangulated
+// pairs (GenPlan, solver_kernels.hpp). From the CSR structure itself, which does not change between evaluations
+// (except the splined models' patch columns: no plan then, those rows keep the atomics)
+static bool build_gen_plan(mrcal_amd_problem* P)
+{
+    GenPlan& G = P->plan.gen;
+    memset(&G, 0, sizeof(G));
+    const Layout& L = P->L;
+    const NormalDims& nd = P->nd;
+    const int r0 = L.i_meas_points, r1 = L.i_meas_regularization;
+    G.row_first = r0; G.row_end = r1;
+    if(r1 <= r0) return true;
+    if(L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && L.Nmeas_points > 0 && L.Ndist_state > 0) return true;
+    std::vector<int32_t> Jp((size_t)(r1 - r0) + 1);
+    HIP_TRY(hipMemcpy(Jp.data(), P->d_Jp + r0, Jp.size()*sizeof(int32_t), hipMemcpyDeviceToHost), return false);
+    const int32_t p0 = Jp[0], p1 = Jp[r1 - r0];
+    std::vector<int32_t> Ji((size_t)(p1 - p0 > 0 ? p1 - p0 : 1));
+    if(p1 > p0) HIP_TRY(hipMemcpy(Ji.data(), P->d_Ji + p0, (size_t)(p1 - p0)*sizeof(int32_t), hipMemcpyDeviceToHost), return false);
+
+    struct RowInfo { int group, eblk, epos; };
+    std::vector<RowInfo> info((size_t)(r1 - r0));
+    std::map<std::vector<int>, int> groups;          // [k | spos.. | scol..] -> group
+    std::vector<std::vector<int>> group_sig;
+    int kmax = 0;
+    for(int r = r0; r < r1; r++)
+    {
+        const int a = Jp[r - r0] - p0, b = Jp[r - r0 + 1] - p0;
+        std::vector<int> spos, scol;
+        int eblk = -1, epos = -1, ecount = 0;
+        for(int p = a; p < b; p++)
+        {
+            const int c = Ji[p];
+            if(c < 0 || c >= nd.Nstate) return true;                 // (flagged at run time by the row-by-row path)
+            const int se = state_to_SE(nd, c);
+            if(se >= 0) { spos.push_back(p - a); scol.push_back(se); }
+            else
+            {
+                const int e = -se - 1;
+                const int blk = (e < 6*nd.Nfb) ? e/6 : nd.Nfb + (e - 6*nd.Nfb)/3;
+                const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
+                const int de  = (blk < nd.Nfb) ? 6 : 3;
+                // the block's columns must be all there, side by side, in order
+                if(ecount == 0) { if(e != e0) return true; eblk = blk; epos = p - a; }
+                else if(blk != eblk || e != e0 + ecount) return true;
+                ecount++;
+                if(ecount > de) return true;
+            }
+        }
+        if(eblk >= 0 && ecount != ((eblk < nd.Nfb) ? 6 : 3)) return true;
+        const int k = (int)spos.size();
+        if(k > GEN_KMAX) return true;
+        if(k > kmax) kmax = k;
+        std::vector<int> sig; sig.reserve(2*k + 1);
+        sig.push_back(k); sig.insert(sig.end(), spos.begin(), spos.end()); sig.insert(sig.end(), scol.begin(), scol.end());
+        auto it = groups.find(sig);
+        int g;
+        if(it == groups.end()) { g = (int)group_sig.size(); groups.emplace(sig, g); group_sig.push_back(sig); }
+        else g = it->second;
+        info[r - r0] = RowInfo{ g, eblk, epos };
+    }
+    const int Ngroups = (int)group_sig.size();
+    const int stride  = (kmax*(kmax+1))/2 + kmax + 1;
+    if(stride > 1023 || Ngroups >= (1 << 20)) return true;
+
+    // rows by (group, row); chunks
+    std::vector<int> rows((size_t)(r1 - r0));
+    for(int i = 0; i < r1 - r0; i++) rows[i] = r0 + i;
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return info[a - r0].group < info[b - r0].group; });
+    std::vector<int> chunk_begin, chunk_group, group_chunk_begin(Ngroups + 1, 0);
+    for(size_t i = 0; i < rows.size();)
+    {
+        const int g = info[rows[i] - r0].group;
+        size_t j = i;
+        while(j < rows.size() && j - i < GEN_CHUNK && info[rows[j] - r0].group == g) j++;
+        chunk_begin.push_back((int)i); chunk_group.push_back(g);
+        group_chunk_begin[g + 1]++;
+        i = j;
+    }
+    chunk_begin.push_back((int)rows.size());
+    for(int g = 0; g < Ngroups; g++) group_chunk_begin[g+1] += group_chunk_begin[g];
+    std::vector<int> group_k(Ngroups), group_off(Ngroups), spos_all, scol_all;
+    for(int g = 0; g < Ngroups; g++)
+    {
+        const std::vector<int>& sig = group_sig[g];
+        const int k = sig[0];
+        group_k[g] = k; group_off[g] = (int)spos_all.size();
+        spos_all.insert(spos_all.end(), sig.begin() + 1, sig.begin() + 1 + k);
+        scol_all.insert(scol_all.end(), sig.begin() + 1 + k, sig.end());
+    }
+    // destinations: entries of A (both orientations, as the row-by-row path adds them), of g (S part), |x|^2
+    const int nA = nd.Nc*nd.Nc;
+    std::map<int, std::vector<int>> src;
+    for(int g = 0; g < Ngroups; g++)
+    {
+        const int k = group_k[g];
+        const int* sc = scol_all.data() + group_off[g];
+        int pos = 0;
+        for(int p = 0; p < k; p++)
+            for(int q = p; q < k; q++, pos++)
+            {
+                const int code = (g << 10) | pos;
+                src[sc[p]*nd.Nc + sc[q]].push_back(code);
+                if(q != p) src[sc[q]*nd.Nc + sc[p]].push_back(code);
+            }
+        for(int p = 0; p < k; p++, pos++) src[nA + sc[p]].push_back((g << 10) | pos);
+        src[nA + nd.Nc].push_back((g << 10) | pos);
+    }
+    std::vector<int> dest_id, dest_begin(1, 0), dest_src;
+    for(auto& kv : src)
+    {
+        dest_id.push_back(kv.first);
+        dest_src.insert(dest_src.end(), kv.second.begin(), kv.second.end());
+        dest_begin.push_back((int)dest_src.size());
+    }
+    // the eliminated blocks: their rows, in row order
+    std::map<int, std::vector<int>> by_block;
+    for(int r = r0; r < r1; r++)
+        if(info[r - r0].eblk >= 0) by_block[info[r - r0].eblk].push_back(r);
+    std::vector<int> eb_block, eb_begin(1, 0), eb_rows, eb_group, eb_epos;
+    for(auto& kv : by_block)
+    {
+        eb_block.push_back(kv.first);
+        for(int r : kv.second) { eb_rows.push_back(r); eb_group.push_back(info[r - r0].group); eb_epos.push_back(info[r - r0].epos); }
+        eb_begin.push_back((int)eb_rows.size());
+    }
+    auto nonempty = [](std::vector<int>& v) { if(v.empty()) v.push_back(0); };
+    const int Nchunks = (int)chunk_group.size(), Neb = (int)eb_block.size(), Ndest = (int)dest_id.size();
+    nonempty(chunk_group); nonempty(spos_all); nonempty(scol_all); nonempty(dest_id); nonempty(dest_src);
+    nonempty(eb_block); nonempty(eb_rows); nonempty(eb_group); nonempty(eb_epos);
+    bool ok = true;
+    ok = ok && dev_upload(&G.rows,        rows.data(),        rows.size());
+    ok = ok && dev_upload(&G.chunk_begin, chunk_begin.data(), chunk_begin.size());
+    ok = ok && dev_upload(&G.chunk_group, chunk_group.data(), chunk_group.size());
+    ok = ok && dev_upload(&G.group_k,     group_k.data(),     group_k.size());
+    ok = ok && dev_upload(&G.group_off,   group_off.data(),   group_off.size());
+    ok = ok && dev_upload(&G.spos,        spos_all.data(),    spos_all.size());
+    ok = ok && dev_upload(&G.scol,        scol_all.data(),    scol_all.size());
+    ok = ok && dev_upload(&G.dest_id,     dest_id.data(),     dest_id.size());
+    ok = ok && dev_upload(&G.dest_begin,  dest_begin.data(),  dest_begin.size());
+    ok = ok && dev_upload(&G.dest_src,    dest_src.data(),    dest_src.size());
+    ok = ok && dev_upload(&G.group_chunk_begin, group_chunk_begin.data(), group_chunk_begin.size());
+    ok = ok && dev_upload(&G.eb_block,    eb_block.data(),    eb_block.size());
+    ok = ok && dev_upload(&G.eb_begin,    eb_begin.data(),    eb_begin.size());
+    ok = ok && dev_upload(&G.eb_rows,     eb_rows.data(),     eb_rows.size());
+    ok = ok && dev_upload(&G.eb_group,    eb_group.data(),    eb_group.size());
+    ok = ok && dev_upload(&G.eb_epos,     eb_epos.data(),     eb_epos.size());
+    ok = ok && dev_alloc (&G.part, (size_t)(Nchunks > 0 ? Nchunks : 1)*stride);
+    if(!ok) return false;
+    G.Nrows = r1 - r0; G.Nchunks = Nchunks; G.Ngroups = Ngroups; G.stride = stride; G.kmax = kmax;
+    G.Ndest = Ndest; G.Neblocks = Neb;
+    return true;
+}
 
 bool problem_prepare_solver(mrcal_amd_problem* P)
 {
@@ -307,8 +467,10 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             ok = ok && dev_alloc(&P->plan.spl_hdr,    (size_t)Nobs);
             ok = ok && dev_alloc(&P->plan.spl_part,   (size_t)(nd.Nc + 1 - nknotrows)*SPLG_E*(nd.Nc + 1));
         }
+        ok = ok && build_gen_plan(P);
         {
-            const int row0 = 2*P->D.W*P->D.H*Nobs;
+            // (with the plan above, the row-by-row workgroups of the assembly take the regularization rows only)
+            const int row0 = (P->plan.gen.Nrows > 0) ? L.i_meas_regularization : 2*P->D.W*P->D.H*Nobs;
             P->plan.row_part_n = (Nobs > 0 && L.Nmeas > row0) ? (L.Nmeas - row0 + 255)/256 : 0;
             ok = ok && dev_alloc(&P->plan.row_part, (size_t)(P->plan.row_part_n > 0 ? P->plan.row_part_n : 1));
             P->plan.qf_part_n = (nd.Nc + nd.NE + 4*QF_ROWS_PER_WAVE - 1)/(4*QF_ROWS_PER_WAVE);

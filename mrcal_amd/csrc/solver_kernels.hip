@@ -1044,6 +1044,119 @@ void rows_generic_lds_kernel(NormalDims nd, OpRef R, int row0, int row1,
     }
 }
 
+// ---- rows outside the Grams, in a fixed order (GenPlan, solver_kernels.hpp) ----
+// One workgroup per chunk of a group's rows. The chunk's camera-block values (and x) are staged in LDS,
+// then every output - a pair (p <= q), a sum s_p x, or sum x^2 - is summed over the rows in order by one thread
+__device__ __forceinline__
+void gen_chunk(const GenPlan& G, const OpDev& O, const int32_t* __restrict__ Jp, int ichunk, double* __restrict__ lds)
+{
+    const int g  = G.chunk_group[ichunk];
+    const int k  = G.group_k[g];
+    const int* __restrict__ spos = G.spos + G.group_off[g];
+    const int c0 = G.chunk_begin[ichunk], nrows = G.chunk_begin[ichunk+1] - c0;
+    const int ld = k + 1;
+    for(int i = threadIdx.x; i < nrows*ld; i += blockDim.x)
+    {
+        const int ir = i / ld, c = i - ir*ld;
+        const int r  = G.rows[c0 + ir];
+        lds[i] = (c < k) ? O.Jv[Jp[r] + spos[c]] : O.x[r];
+    }
+    __syncthreads();
+    const int npairs = (k*(k+1)) >> 1, nout = npairs + k + 1;
+    double* __restrict__ out = G.part + (size_t)ichunk*G.stride;
+    for(int o = threadIdx.x; o < nout; o += blockDim.x)
+    {
+        int p, q;
+        if(o < npairs)
+        {
+            // o -> (p,q), p <= q, row-major over the upper triangle
+            p = 0; int rem = o;
+            while(rem >= k - p) { rem -= k - p; p++; }
+            q = p + rem;
+        }
+        else if(o < npairs + k) { p = o - npairs; q = k; }
+        else                    { p = k; q = k; }
+        double acc = 0.0;
+        for(int ir = 0; ir < nrows; ir++) acc = fma(lds[ir*ld + p], lds[ir*ld + q], acc);
+        out[o] = acc;
+    }
+}
+// One wave per eliminated block that such rows touch: its rows of Bt, its D block and its part of g, the
+// rows applied one after the other. lds: [6][Nc] Bt rows, then [36] D, then [6] g
+__device__ __forceinline__
+void gen_eblock(const GenPlan& G, const NormalDims& nd, const OpDev& O, const int32_t* __restrict__ Jp, int ieb,
+                double* __restrict__ lds)
+{
+    const int blk = G.eb_block[ieb];
+    int de, e0;
+    if(blk < nd.Nfb) { de = 6; e0 = 6*blk; } else { de = 3; e0 = 6*nd.Nfb + 3*(blk - nd.Nfb); }
+    const int Nc = nd.Nc, nlds = 6*Nc + 42;
+    for(int i = threadIdx.x; i < nlds; i += blockDim.x) lds[i] = 0.0;
+    __syncthreads();
+    double* __restrict__ lD = lds + 6*Nc;
+    double* __restrict__ lg = lD + 36;
+    for(int ii = G.eb_begin[ieb]; ii < G.eb_begin[ieb+1]; ii++)
+    {
+        const int r = G.eb_rows[ii], g = G.eb_group[ii], k = G.group_k[g];
+        const int* __restrict__ spos = G.spos + G.group_off[g];
+        const int* __restrict__ scol = G.scol + G.group_off[g];
+        const double* __restrict__ jr = O.Jv + Jp[r];
+        const double* __restrict__ je = jr + G.eb_epos[ii];
+        const double xr = O.x[r];
+        // (within one row every entry below is touched by one thread: plain read-modify-writes)
+        for(int i = threadIdx.x; i < de*k; i += blockDim.x)
+        {
+            const int a = i / k, c = i - a*k;
+            lds[a*Nc + scol[c]] = fma(je[a], jr[spos[c]], lds[a*Nc + scol[c]]);
+        }
+        if((int)threadIdx.x < de*de)
+        {
+            const int a = threadIdx.x / de, b = threadIdx.x - a*de;
+            lD[a*6 + b] = fma(je[a], je[b], lD[a*6 + b]);
+        }
+        if((int)threadIdx.x < de) lg[threadIdx.x] = fma(je[threadIdx.x], xr, lg[threadIdx.x]);
+        __syncthreads();
+    }
+    for(int i = threadIdx.x; i < de*Nc; i += blockDim.x) O.Bt[(size_t)e0*Nc + i] = lds[i];
+    if((int)threadIdx.x < 36) O.D[(size_t)blk*36 + threadIdx.x] = lD[threadIdx.x];
+    if((int)threadIdx.x < de) O.g[nd.Nie + e0 + threadIdx.x] = lg[threadIdx.x];
+}
+static size_t gen_lds_bytes(const GenPlan& G, const NormalDims& nd)
+{
+    const size_t a = (size_t)GEN_CHUNK*(G.kmax + 1), b = (G.Neblocks > 0) ? (size_t)6*nd.Nc + 42 : 0;
+    return (a > b ? a : b)*sizeof(double);
+}
+// workgroups [0, Nchunks): chunks; then the eliminated blocks
+__global__ __launch_bounds__(256)
+void gen_rows_kernel(NormalDims nd, OpRef R, GenPlan G, const int32_t* __restrict__ Jp)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ double lds_g[];
+    const OpDev& O = opref_get(R);
+    if((int)blockIdx.x < G.Nchunks) gen_chunk(G, O, Jp, blockIdx.x, lds_g);
+    else                            gen_eblock(G, nd, O, Jp, blockIdx.x - G.Nchunks, lds_g);
+}
+// the regularization rows where there are no board Grams to ride with: every row has destinations of its own
+// (A and g through one add each into the cleared buffers); |x|^2 summed in a fixed order. One workgroup
+__global__ __launch_bounds__(256)
+void rows_single_kernel(NormalDims nd, OpRef R, int row0, int row1, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    double n2 = 0.0;
+    for(int r = row0 + threadIdx.x; r < row1; r += blockDim.x)
+    {
+        double v = 0.0;
+        rows_generic_row(nd, O, r, row1, Jp, Ji, &v);
+        n2 += v;
+    }
+    for(int off=32; off>0; off>>=1) n2 += __shfl_down(n2, off);
+    __shared__ double part[4];
+    if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n2;
+    __syncthreads();
+    if(threadIdx.x == 0) O.scalars[SC_NORM2_X] += (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 // The Gram assembly (+ elimination of the frame blocks) and the generic rows in
 // ONE launch (all three kinds of work are independent): workgroups
 // [0, nframe_blocks) take a frame each, the next Nchunks a pair chunk each, the
@@ -3621,10 +3734,36 @@ hipError_t launch_zero_normal(const NormalDims& nd, const OpRef& R, hipStream_t 
     return hipGetLastError();
 }
 static size_t assemble_lds_bytes(const NormalDims& nd) { return (size_t)(6*nd.Nc + 42 + 48)*sizeof(double); }
-static int    assemble_row_blocks(const DeviceProblem& P)
+// the first of the rows the assembly takes one lane each: with a plan for the rows that share destinations
+// (GenPlan) only the regularization rows are left, whose destinations are their own
+static int    assemble_row0(const DeviceProblem& P, const AssemblyPlan& plan)
 {
-    const int row0 = 2*P.W*P.H*P.Nobs_board;
+    return (plan.gen.Nrows > 0) ? P.i_meas_regularization : 2*P.W*P.H*P.Nobs_board;
+}
+static int    assemble_row_blocks(const DeviceProblem& P, const AssemblyPlan& plan)
+{
+    const int row0 = assemble_row0(P, plan);
     return (P.Nmeas > row0) ? (P.Nmeas - row0 + 255)/256 : 0;
+}
+// the planned rows: chunks and eliminated blocks in one launch; then, AFTER whatever else finalizes into A, g and
+// |x|^2 (launches on a stream are ordered: every destination is added to by one thread at a time), their sums
+static hipError_t launch_gen_rows(const NormalDims& nd, const AssemblyPlan& plan, const OpRef& R, const int32_t* Jp, hipStream_t stream)
+{
+    const GenPlan& G = plan.gen;
+    if(G.Nrows <= 0 || G.Nchunks + G.Neblocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_rows_kernel, dim3(G.Nchunks + G.Neblocks), dim3(256), gen_lds_bytes(G, nd), stream, nd, R, G, Jp);
+    return hipGetLastError();
+}
+static hipError_t launch_gen_finalize(const NormalDims& nd, const AssemblyPlan& plan, const OpRef& R, hipStream_t stream)
+{
+    const GenPlan& G = plan.gen;
+    if(G.Nrows <= 0 || G.Ndest <= 0) return hipSuccess;
+    AssemblyPlan gp = plan;
+    gp.Ndest = G.Ndest; gp.dest_id = G.dest_id; gp.dest_begin = G.dest_begin; gp.dest_src = G.dest_src;
+    gp.pair_chunk_begin = G.group_chunk_begin; gp.chunk_part = G.part; gp.row_part_n = 0;
+    hipLaunchKernelGGL(assemble_finalize_kernel, dim3((G.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,
+                       G.stride, nd, R.ops, R.sel, R.skip, gp);
+    return hipGetLastError();
 }
 // The block normal equations of a point that was just evaluated, from the Grams
 // (or row by row where there are none). The point's normal equations must have
@@ -3643,12 +3782,16 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
     {
         const int nframe_blocks = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
         FactorBuffers none; memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks + assemble_row_blocks(P)), dim3(256),
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks + assemble_row_blocks(P, plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
-                           (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, row0, P.Nmeas, B.Jp, B.Ji);
+                           (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, assemble_row0(P, plan), P.Nmeas, B.Jp, B.Ji);
+        hipError_t e = launch_gen_rows(nd, plan, B.R, B.Jp, stream);
+        if(e != hipSuccess) return e;
         if(plan.Ndest > 0)
             hipLaunchKernelGGL(assemble_finalize_kernel, dim3((plan.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,
                                gram_stride(P.Ndist), nd, B.R.ops, B.R.sel, B.R.skip, plan);
+        e = launch_gen_finalize(nd, plan, B.R, stream);
+        if(e != hipSuccess) return e;
     }
     else
     {
@@ -3684,7 +3827,20 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                                nwaves*row_bytes, gstream, P, nd, B.R, plan, nwaves);
             // (the regularization rows: in pairs, rows_pairs_kernel, after whatever other rows there are)
         }
-        if(rows_to > rows_from)
+        bool planned = false;
+        if(plan.gen.Nrows > 0 && rows_from <= plan.gen.row_first && plan.gen.row_end <= rows_to)
+        {
+            // the rows that share destinations in a fixed order (GenPlan); what is left of [rows_from, rows_to) is
+            // the regularization rows, with destinations of their own: one workgroup, |x|^2 summed in order
+            hipError_t e = launch_gen_rows(nd, plan, B.R, B.Jp, stream);
+            if(e != hipSuccess) return e;
+            e = launch_gen_finalize(nd, plan, B.R, stream);
+            if(e != hipSuccess) return e;
+            if(rows_to > plan.gen.row_end)
+                hipLaunchKernelGGL(rows_single_kernel, dim3(1), dim3(256), 0, stream, nd, B.R, plan.gen.row_end, rows_to, B.Jp, B.Ji);
+            planned = true;
+        }
+        if(rows_to > rows_from && !planned)
         {
             // many rows on a small camera block: sum in LDS first (rows_generic_lds_kernel)
             if(nd.Nc <= ROWS_LDS_NC && rows_to - rows_from >= 4096)
@@ -3957,9 +4113,14 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     {
         const int row0 = 2*P.W*P.H*P.Nobs_board;
         nframes_fused = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks + assemble_row_blocks(P)), dim3(256),
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks + assemble_row_blocks(P, *a.plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
-                           &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, row0, P.Nmeas, a.Jp, a.Ji);
+                           &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, assemble_row0(P, *a.plan), P.Nmeas, a.Jp, a.Ji);
+        // the planned rows of the evaluated point (their own launch: they ride on nothing; a trial without an
+        // evaluation skips them). Their sums are added after the Grams' (launch_step2_reduce)
+        (void)row0;
+        const hipError_t e = launch_gen_rows(nd, *a.plan, OpRef{ a.ops, sel_eval, &fl->skip_asm }, a.Jp, stream);
+        if(e != hipSuccess) return e;
     }
     else
     {
@@ -4001,6 +4162,12 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
         ride.npos = gram_stride(P.Ndist); ride.ops = a.ops; ride.sel = &fl->elim_sel; ride.skip = &fl->skip_asm; ride.plan = *a.plan;
     }
     const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream);
+    if(with_grams)
+    {
+        // (after the ride: one adder per destination at a time)
+        const hipError_t e = launch_gen_finalize(nd, *a.plan, OpRef{ a.ops, &fl->elim_sel, &fl->skip_asm }, stream);
+        if(e != hipSuccess) return e;
+    }
     // A, g of the camera block and |x|^2 may still be on their way on the side stream
     if(step2_side_pending)
     {

