@@ -32,14 +32,17 @@
 #include "lens_models.hpp"
 #include "triangulation.hpp"
 #include "kernels.hpp"
+#include "dogleg_choose.hpp"
 
 namespace mrcal_amd {
 
 ////////////////////////////////////////////////////////////////////////////////
 // state access: packed state b[] (if the block is being optimized) or seeds
 ////////////////////////////////////////////////////////////////////////////////
+// (the state: a pointer to the packed vector, or anything indexable like one - dogleg_choose.hpp's TrialState)
+template<class BV>
 __device__ __forceinline__
-double get_intrinsic(const DeviceProblem& P, const double* __restrict__ b, int icam, int i)
+double get_intrinsic(const DeviceProblem& P, const BV& b, int icam, int i)
 {
     if(i < P.Ncore)
     {
@@ -52,32 +55,35 @@ double get_intrinsic(const DeviceProblem& P, const double* __restrict__ b, int i
         return b[P.i_state_intrinsics + icam*P.Nintr_state + P.Ncore_state + (i - P.Ncore)] * SCALE_DISTORTION;
     return P.seed_intrinsics[icam*P.Nintrinsics + i];
 }
+template<class BV>
 __device__ __forceinline__
-void get_rt_cam_ref(double* rt, const DeviceProblem& P, const double* __restrict__ b, int icam_extrinsics)
+void get_rt_cam_ref(double* rt, const DeviceProblem& P, const BV& b, int icam_extrinsics)
 {
     if(P.do_optimize_extrinsics)
     {
-        const double* s = &b[P.i_state_extrinsics + 6*icam_extrinsics];
-        for(int i=0;i<3;i++) rt[i]   = s[i]   * SCALE_ROTATION_CAMERA;
-        for(int i=0;i<3;i++) rt[3+i] = s[3+i] * SCALE_TRANSLATION_CAMERA;
+        const int s = P.i_state_extrinsics + 6*icam_extrinsics;
+        for(int i=0;i<3;i++) rt[i]   = b[s + i]   * SCALE_ROTATION_CAMERA;
+        for(int i=0;i<3;i++) rt[3+i] = b[s + 3+i] * SCALE_TRANSLATION_CAMERA;
     }
     else
         for(int i=0;i<6;i++) rt[i] = P.seed_rt_cam_ref[6*icam_extrinsics + i];
 }
+template<class BV>
 __device__ __forceinline__
-void get_rt_ref_frame(double* rt, const DeviceProblem& P, const double* __restrict__ b, int iframe)
+void get_rt_ref_frame(double* rt, const DeviceProblem& P, const BV& b, int iframe)
 {
     if(P.do_optimize_frames)
     {
-        const double* s = &b[P.i_state_frames + 6*iframe];
-        for(int i=0;i<3;i++) rt[i]   = s[i]   * SCALE_ROTATION_FRAME;
-        for(int i=0;i<3;i++) rt[3+i] = s[3+i] * SCALE_TRANSLATION_FRAME;
+        const int s = P.i_state_frames + 6*iframe;
+        for(int i=0;i<3;i++) rt[i]   = b[s + i]   * SCALE_ROTATION_FRAME;
+        for(int i=0;i<3;i++) rt[3+i] = b[s + 3+i] * SCALE_TRANSLATION_FRAME;
     }
     else
         for(int i=0;i<6;i++) rt[i] = P.seed_rt_ref_frame[6*iframe + i];
 }
+template<class BV>
 __device__ __forceinline__
-void get_warp(double* w, const DeviceProblem& P, const double* __restrict__ b)
+void get_warp(double* w, const DeviceProblem& P, const BV& b)
 {
     if(P.has_warp_state)
     {
@@ -170,40 +176,52 @@ void joint_pose_record(double* __restrict__ out,
 // 2e-5 by the reference's relative-error measure. Parity first: the reference's
 // route is followed literally)
 
+template<bool WITH_J, bool WITH_STRUCTURE, class BV>
+__device__ __forceinline__
+void regularization_row_at(const DeviceProblem& P, const BV& b, double* __restrict__ x, double* __restrict__ Jv,
+                           int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i);
 template<bool WITH_J, bool WITH_STRUCTURE>
 __device__ __forceinline__
 void regularization_row(const DeviceProblem& P, const OpRef& R,
-                        int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i);
+                        int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i)
+{
+    const double* b = opref_get(R).b;
+    regularization_row_at<WITH_J,WITH_STRUCTURE>(P, b, opref_get(R).x, opref_get(R).Jv, rowptr, colidx, i);
+}
 
 #define PROLOGUE_ZERO_BLOCKS 1024
 // Workgroups, in order: [pose records, 64 observations each] [unpacking of the
 // intrinsics and the warp] [clearing of the normal equations, if asked for]
-// [regularization rows, 64 each: reg_mode 0 = x only, 1 = x and J, -1 = none].
+// [regularization rows, 64 each: reg_mode 0 = x only, 1 = x and J, -1 = none]
+// [CHOOSE: the dog-leg step, 64 state variables each].
 // Only the first kind is long; the others are independent of it and of each
-// other and ride along instead of costing launches of their own
-__global__ __launch_bounds__(64)
-void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode)
+// other and ride along instead of costing launches of their own.
+// CHOOSE (the solver's trial step): the launch also CHOOSES the trial point it evaluates (dogleg_choose.hpp) -
+// every workgroup derives the step's scalars for itself, the pose / unpack / regularization workgroups compute
+// the entries of the trial state they need from them (TrialState: the same instructions, hence the same bits,
+// as the workgroups at the end of the grid that write the step and the trial state out), and whether the trial
+// evaluates anything at all is taken from the derived numbers, not from the flag being written
+template<class BV>
+__device__ __forceinline__
+void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV& b, const OpDev& O,
+                         int nblocks_unpack, int nblocks_zero, int reg_mode)
 {
-    const OpRef R = B.R;
     double* __restrict__ joint = B.joint;
-    if(opref_skip(R)) return;
-    if((int)blockIdx.x >= (P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero)
+    const int nblocks_obs = (P.Nobs_board + 63)/64;
+    if((int)blockIdx.x >= nblocks_obs + nblocks_unpack + nblocks_zero)
     {
-        const int i = ((int)blockIdx.x - ((P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero))*64 + threadIdx.x;
-        if(reg_mode == 1)      regularization_row<true, false>(P, R, (int32_t*)NULL, (int32_t*)NULL, i);
-        else if(reg_mode == 0) regularization_row<false,false>(P, R, (int32_t*)NULL, (int32_t*)NULL, i);
+        const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*64 + threadIdx.x;
+        if(reg_mode == 1)      regularization_row_at<true, false>(P, b, O.x, O.Jv, (int32_t*)NULL, (int32_t*)NULL, i);
+        else if(reg_mode == 0) regularization_row_at<false,false>(P, b, O.x, O.Jv, (int32_t*)NULL, (int32_t*)NULL, i);
         return;
     }
-    const double* __restrict__ b = opref_get(R).b;
     // the blocks past the observations unpack the intrinsics of every camera
     // and the board warp from the packed state (or copy the seeds); the blocks
     // past those clear the point's normal equations (a bandwidth job that runs
     // next to the long dependent chains of the pose blocks instead of costing a
     // launch of its own)
-    const int nblocks_obs = (P.Nobs_board + 63)/64;
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
     {
-        const OpDev& O = opref_get(R);
         const long long nz = nblocks_zero;
         for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*64 + threadIdx.x; i < B.zero_total; i += nz*64)
         {
@@ -251,6 +269,34 @@ void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, i
         joint_pose_record(rec, NULL, rt_frame);
     double* out = joint + (size_t)iobs*JOINT_STRIDE;
     for(int i=0;i<JOINT_STRIDE;i++) out[i] = rec[i];
+}
+template<bool CHOOSE>
+__global__ __launch_bounds__(64)
+void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode,
+                           int nblocks_reg, ChooseArgs ca)
+{
+    const OpRef R = B.R;
+    if constexpr(CHOOSE)
+    {
+        __shared__ double scratch[17*7];
+        const ChooseOut c = dogleg_choose_scalars(ca, scratch);
+        const int first = (P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero + nblocks_reg;
+        if((int)blockIdx.x >= first)
+        {
+            dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*64 + threadIdx.x);
+            if((int)blockIdx.x == first && threadIdx.x == 0) dogleg_choose_record(ca, c);
+            return;
+        }
+        if(c.skip_eval) return;
+        // (ia: not touched by the choice)
+        board_prologue_body(P, B, dogleg_trial_state(ca, c), ca.ops[c.ia], nblocks_unpack, nblocks_zero, reg_mode);
+    }
+    else
+    {
+        if(opref_skip(R)) return;
+        const double* b = opref_get(R).b;
+        board_prologue_body(P, B, b, opref_get(R), nblocks_unpack, nblocks_zero, reg_mode);
+    }
 }
 
 ////////////////////////////////////////////////////////////////////////////////
@@ -1220,14 +1266,11 @@ void point_structure_kernel(DeviceProblem P, int32_t* __restrict__ rowptr, int32
 ////////////////////////////////////////////////////////////////////////////////
 // Rows, in order: [distortions of cam0..camN] [centre pixel x,y of cam0..camN]
 // [unity_cam01]. Reference: mrcal.c:5795-5954
-template<bool WITH_J, bool WITH_STRUCTURE>
+template<bool WITH_J, bool WITH_STRUCTURE, class BV>
 __device__ __forceinline__
-void regularization_row(const DeviceProblem& P, const OpRef& R,
-                        int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i)
+void regularization_row_at(const DeviceProblem& P, const BV& b, double* __restrict__ x, double* __restrict__ Jv,
+                           int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx, const int i)
 {
-    const double* __restrict__ b  = opref_get(R).b;
-    double*       __restrict__ x  = opref_get(R).x;
-    double*       __restrict__ Jv = opref_get(R).Jv;
     const int Ndist_rows   = P.do_apply_regularization ? P.Ncameras_intrinsics*P.Ndist_state : 0;
     const int Ncenter_rows = (P.do_apply_regularization && P.Ncore_state) ? P.Ncameras_intrinsics*2 : 0;
     const int Nrows        = Ndist_rows + Ncenter_rows + (P.has_unity_cam01 ? 1 : 0);
@@ -1631,6 +1674,22 @@ void regularization_splined_kernel(DeviceProblem P, OpRef R,
 }
 
 static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian, hipStream_t stream);
+// the prologue launch; with B.choose the trial step's choice rides in it (board_prologue_kernel<true>)
+static void launch_prologue(const DeviceProblem& P, const EvalBuffers& B, int nblocks_obs, int nblocks_unpack, int nblocks_zero,
+                            int nblocks_reg, bool with_jacobian, hipStream_t stream)
+{
+    const int reg_mode = nblocks_reg > 0 ? (with_jacobian ? 1 : 0) : -1;
+    const int n = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg;
+    if(B.choose != NULL)
+    {
+        const int nblocks_choose = (B.choose->nd.Nstate + 63)/64;
+        hipLaunchKernelGGL(board_prologue_kernel<true>, dim3(n + nblocks_choose), dim3(64), 0, stream,
+                           P, B, nblocks_unpack, nblocks_zero, reg_mode, nblocks_reg, *B.choose);
+    }
+    else
+        hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(n), dim3(64), 0, stream,
+                           P, B, nblocks_unpack, nblocks_zero, reg_mode, nblocks_reg, ChooseArgs());
+}
 static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                                 hipStream_t stream, hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
@@ -1641,8 +1700,7 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
         const int Nreg_rows      = 0;      // the splined regularization has its own kernel
         const int nblocks_reg    = (Nreg_rows + 63)/64;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg), dim3(64), 0, stream,
-                           P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? (with_jacobian ? 1 : 0) : -1);
+        launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
@@ -1662,7 +1720,7 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
             EvalBuffers Bu = B;
             Bu.zero_total = 0;
             const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
-            hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack, 0, -1);
+            hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack, 0, -1, 0, ChooseArgs());
         }
         if(with_jacobian)
             hipLaunchKernelGGL((point_splined_kernel<true>),  dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
@@ -2108,8 +2166,7 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
         const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
         const int nblocks_reg    = (Nreg_rows + 63)/64;
-        hipLaunchKernelGGL(board_prologue_kernel, dim3(nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg), dim3(64), 0, stream,
-                           P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? (with_jacobian ? 1 : 0) : -1);
+        launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
@@ -2159,6 +2216,10 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     }
 }
 
+bool prologue_takes_choose(const DeviceProblem& P)
+{
+    return P.Nobs_board > 0 && P.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC;
+}
 bool lens_supported(int lens_type)
 {
     switch(lens_type)

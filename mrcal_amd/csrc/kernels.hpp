@@ -40,6 +40,7 @@ struct OpRef
 __device__ __forceinline__ bool opref_skip(const OpRef& r) { return r.skip != NULL && *r.skip != 0; }
 __device__ __forceinline__ const OpDev& opref_get(const OpRef& r) { return r.ops[r.sel ? *r.sel : 0]; }
 
+struct ChooseArgs;      // dogleg_choose.hpp
 // what one evaluation reads and writes
 struct EvalBuffers
 {
@@ -52,7 +53,13 @@ struct EvalBuffers
     // equations: A[zero_n[0]], Bt[zero_n[1]], D[zero_n[2]], g[zero_n[3]], scalars[zero_n[4]]
     long long zero_n[5];
     long long zero_total;
+    // HOST pointer, read when the prologue is launched (never on the device). Given: the solver's trial step lets
+    // the prologue launch choose the trial point it evaluates (board_prologue_kernel<true>); R then only names the
+    // operating point for the kernels AFTER the prologue
+    const ChooseArgs* choose;
 };
+// can the evaluation's prologue launch carry the choice of the trial point (EvalBuffers::choose)?
+bool prologue_takes_choose(const DeviceProblem& P);
 
 bool lens_supported(int lens_type);
 

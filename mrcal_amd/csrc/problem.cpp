@@ -500,11 +500,17 @@ bool problem_sync_ops(mrcal_amd_problem* P)
 }
 
 bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobian, bool with_normal, int parts,
-                          hipStream_t stream)
+                          hipStream_t stream, const ChooseArgs* choose)
 {
     if(with_normal && !P->solver_ready) { set_error("solver buffers are not allocated"); return false; }
     if(stream == NULL) stream = P->stream;
     EvalBuffers B = P->eval_buffers(R, with_normal);
+    if(choose != NULL && !((parts & EVAL_PART_PROLOGUE) && prologue_takes_choose(P->D)))
+    {
+        set_error("internal error: this evaluation has no prologue launch to choose the trial point in");
+        return false;
+    }
+    B.choose = choose;
     if(with_normal && (parts & EVAL_PART_ZERO))
     {
         if((parts & EVAL_PART_PROLOGUE) && P->D.Nobs_board > 0)

@@ -117,6 +117,7 @@ struct mrcal_amd_problem
         B.R = R; B.joint = d_joint; B.Jp = d_Jp; B.Ji = d_Ji; B.gram = with_gram ? d_gram : NULL;
         for(int i=0;i<5;i++) B.zero_n[i] = 0;
         B.zero_total = 0;
+        B.choose = NULL;
         return B;
     }
     mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const { return eval_buffers(opref(i), with_gram); }
@@ -132,7 +133,8 @@ bool problem_prepare_solver(mrcal_amd_problem* P);
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal);
 // the same, with the operating point possibly resolved on the device
 bool problem_evaluate_ref(mrcal_amd_problem* P, const mrcal_amd::OpRef& R, bool with_jacobian, bool with_normal,
-                          int parts = mrcal_amd::EVAL_PART_ALL, hipStream_t stream = NULL /* default: the problem's */);
+                          int parts = mrcal_amd::EVAL_PART_ALL, hipStream_t stream = NULL /* default: the problem's */,
+                          const mrcal_amd::ChooseArgs* choose = NULL /* the prologue launch also chooses the trial point */);
 // uploads op[0..1] to d_ops
 bool problem_sync_ops(mrcal_amd_problem* P);
 }

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "host_state.hpp"
 #include "problem_object.hpp"
+#include "dogleg_choose.hpp"
 #include "triangulation.hpp"
 #include "../../include/mrcal_amd.h"
 
@@ -152,8 +153,17 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     {
         // the step from the current point (its Gauss-Newton step was computed when the
         // point was accepted); then the joint poses of the trial point
-        HIP_TRY(launch_step2_choose(a, P->stream), return false);
-        if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
+        if(prologue_takes_choose(P->D))
+        {
+            // ONE launch: the prologue's workgroups choose the trial point they evaluate (dogleg_choose.hpp)
+            const ChooseArgs ca = step2_choose_args(a);
+            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO, NULL, &ca)) return false;
+        }
+        else
+        {
+            HIP_TRY(launch_step2_choose(a, P->stream), return false);
+            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
+        }
     }
     if(segment == 0 || segment == 2)
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_BOARD)) return false;
@@ -759,8 +769,17 @@ bool mrcal_amd_problem_sharded_enqueue(mrcal_amd_problem_t* P, int initial, int 
         else
         {
             const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
-            HIP_TRY(launch_step2_choose(a, P->stream), return false);
-            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
+            const int parts = EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST;
+            if(prologue_takes_choose(P->D))
+            {
+                const ChooseArgs ca = step2_choose_args(a);
+                if(!problem_evaluate_ref(P, Rto, true, true, parts, NULL, &ca)) return false;
+            }
+            else
+            {
+                HIP_TRY(launch_step2_choose(a, P->stream), return false);
+                if(!problem_evaluate_ref(P, Rto, true, true, parts)) return false;
+            }
         }
         HIP_TRY(launch_step2_assemble(a, init, P->stream), return false);
         HIP_TRY(launch_step2_reduce(a, P->stream), return false);

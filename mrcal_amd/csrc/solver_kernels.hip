@@ -29,6 +29,7 @@
 #include <string.h>
 #include "problem.hpp"
 #include "solver_kernels.hpp"
+#include "dogleg_choose.hpp"
 #include <type_traits>
 
 namespace mrcal_amd {
@@ -2215,7 +2216,10 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
         }
     };
     CTS();
-    if(wave == 0) back_diag(npanels-1);
+    // (n = 0 - a solve without camera variables - has no panel: back_diag(-1) would read and WRITE 16 doubles in
+    //  front of the triangle, i.e. this kernel's own flags in LDS; found when a change of the LDS layout made
+    //  such solves report "not positive definite" at random)
+    if(wave == 0 && npanels > 0) back_diag(npanels-1);
     __syncthreads();
     CTS();
     for(int p = npanels-1; p >= 1; p--)
@@ -3180,16 +3184,6 @@ void outlier_stats_sum_kernel(int n, const double* __restrict__ part, double* __
 ////////////////////////////////////////////////////////////////////////////////
 // dog-leg control (libdogleg's trust-region logic, on the device)
 ////////////////////////////////////////////////////////////////////////////////
-// flags derived from the control state, for the kernels' skip pointers
-//   skip_factor: this trial does not need a factorization
-//   skip_eval:   this trial does not evaluate a new point
-//   (the fused step) elim_mode: 0 nothing to eliminate; 1 the trial point was evaluated: its blocks come from the
-//   Grams; 2 the current point is re-eliminated from its stored blocks. elim_sel: which operating point that is.
-//   skip_elim = (elim_mode == 0), skip_asm = (elim_mode != 1); skip_chol / skip_backsub: set by the finish logic
-struct SolverCtlFlags { int skip_factor, skip_eval;
-                        int elim_mode, elim_sel, skip_elim, skip_asm, skip_chol, skip_backsub; };
-static_assert(sizeof(SolverCtlFlags) == 32, "");
-
 // rho test, trust-region update, accept/reject (one thread)
 __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, SolverCtl* ctl)
 {
@@ -3244,245 +3238,15 @@ __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, Solver
 // fixed-order reductions everywhere, no atomics.
 //   comm1 == F.S (S, r and the tail are contiguous); comm2 given to the kernels:
 //   sharded. NULL: single GPU, the partial sums are read where they were left.
-#define COMM2_GNG    0
-#define COMM2_GGE    1
-#define COMM2_GNE2   2
-#define COMM2_GNE_GE 3
-
-__device__ __forceinline__ void ctl_raise_lambda(SolverCtl* ctl)
+// The dog-leg step from the current point: dogleg_choose.hpp. As a launch of its own where the evaluation that
+// follows has no prologue launch to carry it (problems without boards, the splined models, the protocol driver)
+__global__ __launch_bounds__(64)
+void step2_choose_kernel(ChooseArgs a)
 {
-    double lam = ctl->lambda;
-    lam = (lam == 0.0) ? 1e-10 : lam*10.0;
-    ctl->lambda = lam;
-    if(!(lam < 1e30)) { ctl->error = 1; ctl->done = 1; }
-}
-
-// sum of n values v(i), by the whole workgroup (256 threads), in an order that
-// depends on n alone; the result in every thread. NOUT values at once
-template<int NOUT, class F>
-__device__ __forceinline__ void block_sum_fixed(int n, F&& v, double (&out)[NOUT], double* __restrict__ scratch /* [4][NOUT] + [NOUT] */)
-{
-    double acc[NOUT];
-#pragma unroll
-    for(int k = 0; k < NOUT; k++) acc[k] = 0.0;
-    for(int i = threadIdx.x; i < n; i += blockDim.x)
-    {
-        double t[NOUT];
-        v(i, t);
-#pragma unroll
-        for(int k = 0; k < NOUT; k++) acc[k] += t[k];
-    }
-#pragma unroll
-    for(int k = 0; k < NOUT; k++)
-        for(int off=32; off>0; off>>=1) acc[k] += __shfl_down(acc[k], off);
-    __syncthreads();            // scratch is free
-    if((threadIdx.x & 63) == 0)
-#pragma unroll
-        for(int k = 0; k < NOUT; k++) scratch[(threadIdx.x >> 6)*NOUT + k] = acc[k];
-    __syncthreads();
-    const int nw = blockDim.x >> 6;
-    if(threadIdx.x < NOUT)
-    {
-        double t = 0.0;
-        for(int w = 0; w < nw; w++) t += scratch[w*NOUT + threadIdx.x];
-        scratch[16*NOUT + threadIdx.x] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for(int k = 0; k < NOUT; k++) out[k] = scratch[16*NOUT + k];
-}
-
-// Chooses the dog-leg step from the point ctl->ib for the current trust region,
-// writes step and the trial state b[ia] = b[ib] + step; sets the flags of this
-// trial. Every workgroup derives the same numbers from the same data in the same
-// order; workgroup 0 records them; fields written here are not read by the other
-// workgroups of this launch.
-// The first trial from a new current point (ctl->derive) also finishes that
-// point: g^T N g (partials of the quadratic-form workgroups, or comm2), |g|^2, the
-// Cauchy step -(|g|^2/|Jg|^2) g. A fresh Gauss-Newton step (ctl->gn_fresh) gets
-// its dot products here: the camera-block part from the vectors, the frame/point
-// part from the back-substitution's per-block partials (or comm2)
-__global__ __launch_bounds__(256)
-void step2_choose_kernel(NormalDims nd, const OpDev* __restrict__ ops, SolverCtl* ctl, SolverCtlFlags* fl,
-                         int* __restrict__ chol_status, double* __restrict__ step,
-                         const double* __restrict__ qf_part, int qf_n,
-                         const double* __restrict__ dots_part, int dots_n,
-                         const double* __restrict__ comm2)
-{
-    const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
-    if(ctl->done)
-    {
-        if(leader) { fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1; }
-        return;
-    }
-    __shared__ double scratch[16*4 + 4];
-    const int  ib = ctl->ib, ia = ctl->ia;
-    const OpDev& from = ops[ib];
-    const bool derive = ctl->derive != 0;
-    auto s_to_state = [&](int i) -> int { return (i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie); };
-
-    // the point's own numbers
-    double gNg, gg, kcau, norm2a;
-    if(derive)
-    {
-        double o[1];
-        block_sum_fixed<1>(nd.Nc, [&](int i, double (&t)[1]) { const double v = from.g[s_to_state(i)]; t[0] = v*v; }, o, scratch);
-        double q, ggE;
-        if(comm2 != NULL) { q = comm2[COMM2_GNG]; ggE = comm2[COMM2_GGE]; }
-        else
-        {
-            double o2[2];
-            block_sum_fixed<2>(qf_n, [&](int i, double (&t)[2]) { t[0] = qf_part[4*i]; t[1] = qf_part[4*i + 2]; }, o2, scratch);
-            q = o2[0]; ggE = o2[1];
-        }
-        gNg = q; gg = o[0] + ggE;
-        kcau = (gNg > 0.0) ? -gg/gNg : 0.0;
-        norm2a = kcau*kcau*gg;
-    }
-    else
-    {
-        gNg = from.scalars[SC_G_GNG]; gg = from.scalars[SC_G_GG];
-        kcau = (gNg > 0.0) ? -gg/gNg : 0.0;
-        norm2a = ctl->cauchy_lensq[ib];
-    }
-    const double tr = ctl->trustregion, dsq = tr*tr;
-    const bool cauchy_only = norm2a >= dsq;
-    if(ctl->refactor || (!cauchy_only && !ctl->gn_valid[ib]))
-    {
-        // no step can be chosen: this trial eliminates the current point (again)
-        if(leader)
-        {
-            ctl->refactor = 1; ctl->abort_step = 1;
-            *chol_status = 0;
-            fl->skip_eval = 1; fl->elim_mode = 2; fl->elim_sel = ib; fl->skip_elim = 0; fl->skip_asm = 1;
-        }
-        // (the Cauchy step of a new point is still recorded below)
-    }
-    const bool voided = ctl->refactor || (!cauchy_only && !ctl->gn_valid[ib]);
-    const bool fresh_gn = !voided && !cauchy_only && ctl->gn_fresh != 0;
-
-    double gn_lensq = ctl->gn_lensq[ib], gn_dot_g = ctl->gn_dot_g[ib];
-    if(fresh_gn)
-    {
-        double o[2];
-        block_sum_fixed<2>(nd.Nc, [&](int i, double (&t)[2])
-                           { const int is = s_to_state(i); const double gn = from.step_gn[is]; t[0] = gn*gn; t[1] = gn*from.g[is]; },
-                           o, scratch);
-        double e2, eg;
-        if(comm2 != NULL) { e2 = comm2[COMM2_GNE2]; eg = comm2[COMM2_GNE_GE]; }
-        else
-        {
-            double o2[2];
-            block_sum_fixed<2>(dots_n, [&](int i, double (&t)[2]) { t[0] = dots_part[2*i]; t[1] = dots_part[2*i + 1]; }, o2, scratch);
-            e2 = o2[0]; eg = o2[1];
-        }
-        gn_lensq = o[0] + e2; gn_dot_g = o[1] + eg;
-    }
-    bool gn_nan = fresh_gn && !(gn_lensq == gn_lensq);
-
-    double kc = 0.0, kg = 0.0, len_sq = 0.0;
-    int edge = 0;
-    double norm2b = 0.0, ab = 0.0;
-    if(!voided && !gn_nan)
-    {
-        if(cauchy_only)
-        {
-            kc = tr/sqrt(norm2a); kg = 0.0; len_sq = dsq; edge = 1;
-        }
-        else
-        {
-            norm2b = gn_lensq;
-            ab     = kcau*gn_dot_g;            // step_gn . step_cauchy
-            if(norm2b <= dsq)
-            {
-                kc = 0.0; kg = 1.0; len_sq = norm2b; edge = 0;
-            }
-            else
-            {
-                // point on the Cauchy->GN segment at the trust-region edge:
-                // |a + k(b-a)|^2 = dsq, a = Cauchy, b = GN
-                const double l2    = norm2a - 2.0*ab + norm2b;   // |a-b|^2
-                const double neg_c = norm2a - ab;                // a.(a-b)
-                double disc = neg_c*neg_c - l2*(norm2a - dsq);
-                if(disc < 0.0) disc = 0.0;
-                const double k = (neg_c + sqrt(disc))/l2;
-                kc = 1.0 - k; kg = k;
-                len_sq = kc*kc*norm2a + 2.0*kg*kc*ab + kg*kg*norm2b;
-                edge = 1;
-            }
-        }
-    }
-
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
-    if(i < nd.Nstate)
-    {
-        const double ci = derive ? kcau*from.g[i] : from.step_cauchy[i];
-        if(derive) from.step_cauchy[i] = ci;
-        if(!voided && !gn_nan)
-        {
-            double sv = kc*ci;
-            if(kg != 0.0) sv = fma(kg, from.step_gn[i], sv);
-            step[i] = sv;
-            ops[ia].b[i] = from.b[i] + sv;
-        }
-    }
-
-    if(!leader) return;
-    if(derive)
-    {
-        from.scalars[SC_G_GNG] = gNg; from.scalars[SC_G_GG] = gg; from.scalars[SC_G_GG2] = gg;
-        ctl->cauchy_lensq[ib] = norm2a;
-    }
-    if(voided) return;
-    if(gn_nan)
-    {
-        // a Gauss-Newton step that is not a number: treat the factorization as failed
-        ctl_raise_lambda(ctl);
-        ctl->refactor = 1; ctl->abort_step = 1; ctl->gn_valid[ib] = 0;
-        *chol_status = 0;
-        fl->skip_eval = 1; fl->elim_mode = ctl->done ? 0 : 2; fl->elim_sel = ib;
-        fl->skip_elim = ctl->done ? 1 : 0; fl->skip_asm = 1;
-        return;
-    }
-    if(fresh_gn)
-    {
-        ctl->gn_lensq[ib] = gn_lensq;
-        ctl->gn_dot_g[ib] = gn_dot_g;
-        from.scalars[SC_GN_LENSQ] = gn_lensq; from.scalars[SC_GN_DOT_CAUCHY] = ab;
-    }
-    // The expected improvement |x|^2 - |x + J s|^2 = -2 g.s - s^T N s WITHOUT a
-    // pass over N: the step is kc s_c + kg s_gn with s_c = k g and
-    // (N + lambda I) s_gn = -g, so every term is a dot product already at hand:
-    //   s_c^T N s_c   = k^2 g^T N g
-    //   s_c^T N s_gn  = -k g.g - lambda s_c.s_gn
-    //   s_gn^T N s_gn = -g.s_gn - lambda |s_gn|^2
-    {
-        double sNs = kc*kc*kcau*kcau*gNg, gs = kc*kcau*gg;
-        if(kg != 0.0)
-        {
-            const double a = gn_dot_g, lam = ctl->gn_lambda[ib];
-            sNs += 2.0*kc*kg*(-kcau*gg - lam*ab) + kg*kg*(-a - lam*norm2b);
-            gs  += kg*a;
-        }
-        from.scalars[SC_STEP_SNS] = sNs;
-        from.scalars[SC_STEP_GS]  = gs;
-        from.scalars[SC_STEP_SS]  = len_sq;
-    }
-    ctl->k_cauchy = kc; ctl->k_gn = kg;
-    ctl->step_len_sq = len_sq;
-    ctl->did_step_to_edge[ib] = edge;
-    ctl->abort_step = 0;
-    ctl->Ntrials++;
-    *chol_status = 0;
-    if(ctl->check_termination && len_sq < ctl->update_threshold*ctl->update_threshold)
-    {
-        ctl->done = 1;
-        fl->skip_eval = 1; fl->elim_mode = 0; fl->skip_elim = 1; fl->skip_asm = 1;
-    }
-    else
-    {
-        fl->skip_eval = 0; fl->elim_mode = 1; fl->elim_sel = ia; fl->skip_elim = 0; fl->skip_asm = 0;
-    }
+    __shared__ double scratch[17*7];
+    const ChooseOut c = dogleg_choose_scalars(a, scratch);
+    dogleg_choose_elementwise(a, c, blockIdx.x*blockDim.x + threadIdx.x);
+    if(blockIdx.x == 0 && threadIdx.x == 0) dogleg_choose_record(a, c);
 }
 
 // S, r of the point being eliminated (reduction of the SYRK's slots: this rank's
@@ -3711,7 +3475,7 @@ void step2_pack2_kernel(const SolverCtl* __restrict__ ctl, const SolverCtlFlags*
                         const double* __restrict__ qf_part, int qf_n,
                         const double* __restrict__ dots_part, int dots_n, double* __restrict__ comm2)
 {
-    __shared__ double scratch[16*4 + 4];
+    __shared__ double scratch[17*7];
     double o[2] = {0.0, 0.0}, o2[2] = {0.0, 0.0};
     if(ctl->derive)
         block_sum_fixed<2>(qf_n, [&](int i, double (&t)[2]) { t[0] = qf_part[4*i]; t[1] = qf_part[4*i + 2]; }, o, scratch);
@@ -4087,12 +3851,20 @@ hipError_t launch_mask_state(const NormalDims& nd, const BlockRanges& br, bool i
 static int quadform_blocks(const NormalDims& nd);
 const int* solver_ctl_skip_eval2(const SolverCtl* ctl) { return &((const SolverCtlFlags*)(ctl + 1))->skip_eval; }
 
+ChooseArgs step2_choose_args(const Step2Args& a)
+{
+    ChooseArgs c;
+    c.nd = *a.nd; c.ops = a.ops; c.ctl = a.ctl; c.fl = ctl_flags(a.ctl); c.chol_status = a.F->status; c.step = a.step;
+    c.qf_part = a.plan->qf_part; c.qf_n = quadform_blocks(*a.nd); c.dots_part = a.plan->dots_part; c.dots_n = a.br->count();
+    c.comm2 = a.comm2;
+    return c;
+}
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream)
 {
     const NormalDims& nd = *a.nd;
-    hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + 255)/256), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, ctl_flags(a.ctl), a.F->status, a.step,
-                       a.plan->qf_part, quadform_blocks(nd), a.plan->dots_part, a.br->count(), a.comm2);
+    // (workgroups of 64, like the prologue's when the choice rides there: the fixed-order sums depend on the
+    //  workgroup size, and the ranks of a sharded solve - with or without boards in their shard - must get the same bits)
+    hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + 63)/64), dim3(64), 0, stream, step2_choose_args(a));
     return hipGetLastError();
 }
 

@@ -326,6 +326,9 @@ struct Step2Args
     hipStream_t side; hipEvent_t ev_fork, ev_join;
 };
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
+// the same as arguments, for an evaluation whose prologue launch carries the choice (EvalBuffers::choose)
+struct ChooseArgs;
+ChooseArgs step2_choose_args(const Step2Args& a);
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
 // ... comm1 = [S | r | g_S | |x|^2 | status] (F.S, step2_comm1_doubles()) is this rank's summand after _reduce;
 // _factor expects it summed over the ranks, and leaves this rank's summand of comm2 (if a.comm2 is given)
