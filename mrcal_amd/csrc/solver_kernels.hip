@@ -2218,7 +2218,9 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     CTS();
     // (n = 0 - a solve without camera variables - has no panel: back_diag(-1) would read and WRITE 16 doubles in
     //  front of the triangle, i.e. this kernel's own flags in LDS; found when a change of the LDS layout made
-    //  such solves report "not positive definite" at random)
+    //  such solves report "not positive definite" at random.
+    //  Measured and dropped: the whole sweep by wave 0 alone, no barriers - 40.3 us against 39.0: what a panel of
+    //  the sweep costs is its chain of LDS round trips, not the barrier)
     if(wave == 0 && npanels > 0) back_diag(npanels-1);
     __syncthreads();
     CTS();

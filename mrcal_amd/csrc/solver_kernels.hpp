@@ -94,7 +94,10 @@ enum { PAIROP_NONE = 0,
        PAIROP_MIRROR = 0x100 };
 struct PairOp { int op, aux; };
 
-#define REDUCE_CHUNK 64     // observations of one pair summed by one workgroup (reduce_pair_chunk), in batches of 16 loads
+#ifndef REDUCE_CHUNK
+#define REDUCE_CHUNK 64
+#endif
+// (REDUCE_CHUNK)    // observations of one pair summed by one workgroup (reduce_pair_chunk), in batches of 16 loads
 // splined models: the packed lower triangle of a pass's local Gram (128 local columns), and the knots it spans
 #define SPL_TRI (128*129/2)
 #define SPLG_E  8         // workgroups sharing a row of the camera block that every pass holds (assemble_splined_gather_kernel)

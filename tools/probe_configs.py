@@ -15,6 +15,9 @@ def board(**kw):
 def sfm():
     from test_triangulated import sfm_problem
     return sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=6, noise=0.3)[0]
+def sfm_boards():
+    from test_triangulated import sfm_problem
+    return sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=6, noise=0.3, Nboard_frames=400)[0]
 CONFIGS = (("0: 1 cam x 40 frames OPENCV4",            lambda: board(Ncameras=1,  Nframes=40,   lensmodel="LENSMODEL_OPENCV4")),
            ("1: 4 cams x 400 frames OPENCV8",          lambda: board(Ncameras=4,  Nframes=400,  lensmodel="LENSMODEL_OPENCV8")),
            ("metric: 8 cams x 1000 frames OPENCV8",    lambda: board(Ncameras=8,  Nframes=1000, lensmodel="LENSMODEL_OPENCV8")),
@@ -22,7 +25,8 @@ CONFIGS = (("0: 1 cam x 40 frames OPENCV4",            lambda: board(Ncameras=1,
                                                                       lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
                                                                       do_optimize_intrinsics_core=False)),     # the core is redundant with the surface (mrcal's own recipe locks it)
            ("3: 16 cams x 2000 frames OPENCV8",        lambda: board(Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8")),
-           ("4: SfM, 4 cams, 20k triangulated points", sfm))
+           ("4: SfM, 4 cams, 20k triangulated points", sfm),
+           ("5: SfM + boards, 4 cams, 20k triangulated points, 400 board frames", sfm_boards))
 print("| configuration | Nstate | Nmeas | Nnz(J) | trial step | full solve (iterations, outlier passes) |")
 print("|---|---|---|---|---|---|")
 only = [a for a in sys.argv[1:]]          # e.g. "3": just that configuration (for rocprofv3)
