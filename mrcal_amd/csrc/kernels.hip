@@ -2218,7 +2218,8 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
 
 bool prologue_takes_choose(const DeviceProblem& P)
 {
-    return P.Nobs_board > 0 && P.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC;
+    // (every evaluation of a problem with boards starts with the prologue launch, the splined models' too)
+    return P.Nobs_board > 0;
 }
 bool lens_supported(int lens_type)
 {
