@@ -226,13 +226,17 @@ def main():
                     achieved = flops/1e12/(kernel_ms*1e-3) if kernel_ms > 0 else 0.0,
                     peak = FP64_MFMA_PEAK_TFLOPS, unit = "TFLOP/s")
         mfma["frac"] = mfma["achieved"]/FP64_MFMA_PEAK_TFLOPS
-        mpath = os.path.join(ROOT, "profiles", "r02_mfma_utilisation.json")
-        if os.path.exists(mpath):
+        for mname in ("r03_mfma_utilisation.json", "r02_mfma_utilisation.json"):
+            mpath = os.path.join(ROOT, "profiles", mname)
+            if not os.path.exists(mpath):
+                continue
             mj = json.load(open(mpath))
             if mj.get("workload_cameras") == args.cameras and mj.get("workload_frames") == args.frames:
-                mfma["pmc_matrix_pipe_busy_frac"] = {k: v["mfma_busy_frac"] for k, v in mj["ns"].items()}
-                mfma["pmc_matrix_pipe_busy_frac_config2_splined"] = {k: v["mfma_busy_frac"] for k, v in mj["config2"].items()}
-                mfma["pmc_source"] = "profiles/r02_mfma_utilisation.json (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs))"
+                mfma["pmc_matrix_pipe_busy_frac"] = {k: v["mfma_busy_frac"] for k, v in mj["ns"].items() if "mfma_busy_frac" in v}
+                mfma["pmc_matrix_pipe_busy_frac_config2_splined"] = {k: v["mfma_busy_frac"] for k, v in mj["config2"].items() if "mfma_busy_frac" in v}
+                mfma["pmc_source"] = f"committed constant: profiles/{mname} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs), " \
+                                     "a rocprofv3 --pmc pass of its own; not re-measured in this run)"
+            break
     except Exception:
         mfma = None
 
