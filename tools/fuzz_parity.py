@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Randomized parity sweep (dev tool, GPU box): random small calibration problems - lens model, cameras, frames,
+board size, which blocks are optimized, discrete points, outliers on input - through mrcal_amd and through the
+reference's own code (oracle/_ref): callback (b_packed and CSR structure bit-exact, x and J to 1e-6), then the solve
+(same outliers, rms to 1e-5 relative; where they differ, both solutions are solved again by BOTH solvers: the same
+numbers from the same starting point mean the first solves differed by their path, not by the implementation).
+Prints one line per case and a summary; exit code 1 on any mismatch.
+
+    python tools/fuzz_parity.py [Ncases] [seed]
+"""
+import os, sys, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mrcal_amd
+from mrcal_amd._cabi import MrcalLib
+from mrcal_amd._api import Api
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+from test_callback_parity import compare_callbacks, _with_points
+
+N    = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ref  = Api(MrcalLib(os.path.join(ROOT, "oracle", "_ref", "libmrcal_ref.so")))
+rng  = np.random.RandomState(seed)
+MODELS = ("LENSMODEL_PINHOLE", "LENSMODEL_STEREOGRAPHIC", "LENSMODEL_OPENCV4", "LENSMODEL_OPENCV5", "LENSMODEL_OPENCV8",
+          "LENSMODEL_OPENCV12", "LENSMODEL_CAHVOR", "LENSMODEL_CAHVORE_linearity=0.37",
+          "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=11_Ny=8_fov_x_deg=120")
+bad = 0; npath = 0; nsolved = 0
+for icase in range(N):
+    lens  = MODELS[rng.randint(len(MODELS))]
+    Ncam  = int(rng.randint(1, 5)); Nf = int(rng.randint(2, 13))
+    W, H  = int(rng.randint(3, 11)), int(rng.randint(3, 11))
+    oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=Ncam, Nframes=Nf, lensmodel=lens,
+                                     object_width_n=W, object_height_n=H, seed=int(rng.randint(1 << 30)))
+    splined = "SPLINED" in lens
+    sel = dict(do_optimize_intrinsics_core        = bool(rng.rand() < 0.7) and not splined,
+               do_optimize_intrinsics_distortions = bool(rng.rand() < 0.7) and oi["intrinsics"].shape[1] > 4,
+               do_optimize_extrinsics             = bool(rng.rand() < 0.8) and Ncam > 1,
+               do_optimize_frames                 = bool(rng.rand() < 0.85),
+               do_optimize_calobject_warp         = bool(rng.rand() < 0.6),
+               do_apply_regularization            = bool(rng.rand() < 0.7))
+    if not any(sel[k] for k in list(sel)[:5]): sel["do_optimize_frames"] = True
+    oi.update(sel)
+    if not sel["do_optimize_calobject_warp"] and rng.rand() < 0.5: oi["calobject_warp"] = None
+    with_points = rng.rand() < 0.35 and not splined
+    if with_points:
+        oi = _with_points(oi, rng, Npoints=int(rng.randint(3, 9)), Npoints_fixed=int(rng.randint(0, 3)))
+    if rng.rand() < 0.5:
+        oi["observations_board"][rng.randint(oi["observations_board"].shape[0]), rng.randint(H), rng.randint(W), 2] = -1.
+    what = f"case {icase}: {lens.replace('LENSMODEL_','')[:22]} {Ncam} cam {Nf} fr {W}x{H} " + \
+           "".join(c for c, k in zip("cdefwr", sel) if sel[k]) + (" +points" if with_points else "")
+    try:
+        compare_callbacks(mrcal_amd.optimizer_callback(no_factorization=True, **copy_inputs(oi)),
+                          ref.optimizer_callback(no_factorization=True, **copy_inputs(oi)), what)
+        # the solve: only where the problem is well posed enough for two solvers to be expected at the same point:
+        # enough data per unknown, the distortions regularized, no discrete points at made-up pixels (a point seen once
+        # has no depth: a singular 3x3 block; seen twice at random pixels it sits wherever its rays happen to pass)
+        well_posed = (not with_points) and W*H >= 30 and Nf >= 5 and \
+                     (sel["do_apply_regularization"] or not sel["do_optimize_intrinsics_distortions"])
+        if not well_posed:
+            print(what, "ok (callback only)", flush=True)
+            continue
+        nsolved += 1
+        oa, orr = copy_inputs(oi), copy_inputs(oi)
+        sa, sr = mrcal_amd.optimize(**oa), ref.optimize(**orr)
+        ok = sa["Noutliers_board"] == sr["Noutliers_board"] and \
+             abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-5*sr["rms_reproj_error__pixels"]
+        msg = ""
+        if not ok:
+            # two solvers, two stopping points? Each solution is solved again by BOTH (no outlier rejection): a
+            # solution that either solver improves further was not a stationary point
+            def again(api, o):
+                o = copy_inputs(o); o["do_apply_outlier_rejection"] = False
+                return api.optimize(**o)["rms_reproj_error__pixels"]
+            r_aa, r_ra = again(mrcal_amd, oa), again(ref, oa)      # from OUR solution
+            r_ar, r_rr = again(mrcal_amd, orr), again(ref, orr)    # from the REFERENCE's solution
+            msg = (f"SOLVE DIFFERS: rms {sa['rms_reproj_error__pixels']:.9g} vs {sr['rms_reproj_error__pixels']:.9g}, "
+                   f"outliers {sa['Noutliers_board']} vs {sr['Noutliers_board']}; again from ours: ours {r_aa:.9g} ref {r_ra:.9g}; "
+                   f"again from the reference's: ours {r_ar:.9g} ref {r_rr:.9g}")
+            # the same behaviour from the same starting point = the first solves differed by their PATH (both stop at the
+            # iteration limit or where the gain ratio drowns in rounding on these small, often unregularized problems)
+            alike = abs(r_aa - r_ra) < 2e-3*r_ra and abs(r_ar - r_rr) < 2e-3*r_rr
+            msg = ("path-dependent, the two solvers alike from either solution: " if alike else "") + msg
+            ok = alike
+            npath += alike
+        print(what, "ok" if not msg else msg, flush=True)
+        bad += not ok
+    except Exception as e:
+        bad += 1
+        print(what, "FAILED:", str(e).splitlines()[0][:200], flush=True)
+print(f"{N - bad}/{N} cases agree: every callback; {nsolved} solves compared ({npath} of them: solves that end on different points of the same valley, both solvers alike when restarted))")
+sys.exit(1 if bad else 0)
