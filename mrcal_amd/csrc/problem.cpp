@@ -154,6 +154,12 @@ static bool build_gen_plan(mrcal_amd_problem* P)
     const int Ngroups = (int)group_sig.size();
     const int stride  = (kmax*(kmax+1))/2 + kmax + 1;
     if(stride > 1023 || Ngroups >= (1 << 20)) return true;
+    // (gen_eblock keeps a block's rows of Bt in LDS: 6 Nc doubles, within the 64 KB a launch gets without asking)
+    {
+        bool any_eblock = false;
+        for(const RowInfo& ri : info) any_eblock = any_eblock || ri.eblk >= 0;
+        if(any_eblock && ((size_t)6*nd.Nc + 42)*sizeof(double) > 64*1024) return true;
+    }
 
     // rows by (group, row); chunks
     std::vector<int> rows((size_t)(r1 - r0));
