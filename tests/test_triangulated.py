@@ -101,7 +101,7 @@ def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise
                         ob[o,iy,ix,:2] = pixel(ic, pref[iy,ix])
         ob[...,:2] += rb.normal(0, noise, ob[...,:2].shape)
         ob[...,2]   = rb.uniform(0.5, 1.0, ob.shape[:3])
-        ob[1,2,3,2] = -1.      # an outlier on input
+        ob[1, min(2, Hb-1), min(3, Wb-1), 2] = -1.      # an outlier on input
         oi.update(rt_ref_frame = np.ascontiguousarray(rt_ref_frame + rb.normal(0, 1, rt_ref_frame.shape)*np.array((5e-3,)*3 + (2e-2,)*3)),
                   observations_board = ob, indices_frame_camintrinsics_camextrinsics = ib,
                   calibration_object_spacing = board_spacing, do_optimize_frames = True)
@@ -431,7 +431,7 @@ def compare_callbacks_with_pairs(res_amd, res_ref, m0, m1, what=""):
     assert np.array_equal(J_a.indptr,  J_r.indptr),  f"{what}: CSR rowptr differs"
     assert np.array_equal(J_a.indices, J_r.indices), f"{what}: CSR colidx differs"
     tri = np.zeros(x_r.shape, dtype=bool); tri[m0:m1] = True
-    assert relative_error(x_a[~tri], x_r[~tri]).max() < REL_TOL, what
+    if (~tri).any(): assert relative_error(x_a[~tri], x_r[~tri]).max() < REL_TOL, what
     assert np.all(np.abs(x_a - x_r)[tri] <= np.maximum(REL_TOL*np.abs(x_r[tri]), 2*M.noise_envelope_x(x_r[tri], K_ENVELOPE))), what
     row_of = np.repeat(np.arange(len(x_r)), np.diff(J_r.indptr))
     maxJ_row = np.maximum.reduceat(np.abs(J_r.data), J_r.indptr[:-1])

@@ -88,5 +88,26 @@ for icase in range(N):
     except Exception as e:
         bad += 1
         print(what, "FAILED:", str(e).splitlines()[0][:200], flush=True)
+# structure-from-motion shapes: triangulated points (+ board frames), intrinsics locked (mrcal.c:6043-6051). The pairs'
+# rows are held to the rounding envelope of their formula (tests/test_triangulated.py compare_callbacks_with_pairs)
+from test_triangulated import sfm_problem, compare_callbacks_with_pairs
+Nsfm = max(N//5, 4)
+for icase in range(Nsfm):
+    lens = ("LENSMODEL_PINHOLE", "LENSMODEL_OPENCV4")[rng.randint(2)]
+    Ncam = int(rng.randint(2, 6)); Np = int(rng.randint(6, 80)); Nbf = int(rng.randint(0, 5))
+    oi, _ = sfm_problem(lens, Ncam=Ncam, Npoints=Np, seed=int(rng.randint(1 << 30)), noise=float(rng.uniform(0.1, 2.0)),
+                        Nboard_frames=Nbf, board_wh=(int(rng.randint(3, 8)), int(rng.randint(3, 8))))
+    oi["do_apply_regularization_unity_cam01"] = bool(rng.rand() < 0.6)
+    what = f"sfm case {icase}: {lens.replace('LENSMODEL_','')} {Ncam} cam {Np} points {Nbf} board frames unity={oi['do_apply_regularization_unity_cam01']}"
+    try:
+        m0 = mrcal_amd.measurement_index_points_triangulated(**oi)
+        compare_callbacks_with_pairs(mrcal_amd.optimizer_callback(no_factorization=True, **copy_inputs(oi)),
+                                     ref.optimizer_callback(no_factorization=True, **copy_inputs(oi)),
+                                     m0, m0 + mrcal_amd.num_measurements_points_triangulated(**oi), what)
+        print(what, "ok (callback only)", flush=True)
+    except Exception as e:
+        bad += 1
+        print(what, "FAILED:", str(e).splitlines()[0][:200], flush=True)
+N += Nsfm
 print(f"{N - bad}/{N} cases agree: every callback; {nsolved} solves compared ({npath} of them: solves that end on different points of the same valley, both solvers alike when restarted))")
 sys.exit(1 if bad else 0)
