@@ -569,6 +569,13 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nl
 typedef struct mrcal_amd_comm mrcal_amd_comm_t;
 bool              mrcal_amd_comm_unique_id(void* id128);
 mrcal_amd_comm_t* mrcal_amd_comm_create(const void* id128, int rank, int world);
+/* The same interface over a POSIX shared-memory segment, for the ranks of one
+   host: synchronous, staged through host memory, the sum taken in rank order.
+   For exercising the sharded solve where RCCL cannot run (two ranks on one
+   device); not a transport to measure. name: "/x", unused, the same on every
+   rank. A rank that does not arrive within MRCAL_AMD_HOST_COMM_TIMEOUT
+   seconds (default 120) makes the collective fail */
+mrcal_amd_comm_t* mrcal_amd_comm_create_host(const char* name, int rank, int world);
 void              mrcal_amd_comm_destroy(mrcal_amd_comm_t* comm);
 int               mrcal_amd_comm_rank (const mrcal_amd_comm_t* comm);
 int               mrcal_amd_comm_world(const mrcal_amd_comm_t* comm);

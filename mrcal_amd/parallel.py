@@ -282,6 +282,7 @@ def _declare_sharded(L):
         f.restype, f.argtypes = C.c_bool, args
     L.mrcal_amd_comm_unique_id.restype,  L.mrcal_amd_comm_unique_id.argtypes  = C.c_bool, [vp]
     L.mrcal_amd_comm_create.restype,     L.mrcal_amd_comm_create.argtypes     = vp, [vp, C.c_int, C.c_int]
+    L.mrcal_amd_comm_create_host.restype, L.mrcal_amd_comm_create_host.argtypes = vp, [C.c_char_p, C.c_int, C.c_int]
     L.mrcal_amd_comm_destroy.restype,    L.mrcal_amd_comm_destroy.argtypes    = None, [vp]
     L.mrcal_amd_comm_Ncollectives.restype, L.mrcal_amd_comm_Ncollectives.argtypes = C.c_long, [vp]
     L.mrcal_amd_problem_attach_comm.restype,  L.mrcal_amd_problem_attach_comm.argtypes  = C.c_bool, [vp, vp]
@@ -384,8 +385,11 @@ class ShardedProblem:
     The product path: the two collectives per trial step are RCCL all-reduces
     issued from C++ on the problem's stream; torch.distributed (any backend:
     gloo is enough) only carries the 128-byte communicator id at start-up.
-    _driver="python": the protocol reference instead (collectives through
-    torch.distributed from Python): for two ranks on ONE device, which RCCL refuses"""
+    _driver="host": the same C++ solve with its collectives staged through a
+    shared-memory segment of the host (csrc/comm.cpp): several ranks on ONE
+    device, which RCCL refuses - what the tests of the C++ path at world > 1 run.
+    _driver="python": the protocol reference (collectives through
+    torch.distributed from Python)"""
     def __init__(self, group=None, _driver="rccl", **optimization_inputs):
         import torch
         import torch.distributed as dist
@@ -427,6 +431,19 @@ class ShardedProblem:
             self.shard = GpuShard(self.problem, self.Nmeas_global, self.Ncorners, self.do_outlier_rejection)
             self.dogleg = ShardedDogleg(self.shard, self.comm)
             return
+        if _driver == "host":
+            import os, secrets
+            name = [("/mrcal_amd_%d_%s" % (os.getpid(), secrets.token_hex(4))) if self.rank == 0 else None]
+            if have_dist and self.world > 1:
+                dist.broadcast_object_list(name, src=0, group=group)
+            self._comm_handle = L.mrcal_amd_comm_create_host(name[0].encode(), self.rank, self.world)
+            if not self._comm_handle:
+                raise RuntimeError("mrcal_amd_comm_create_host() failed:" + _api._last_error())
+            if not L.mrcal_amd_problem_attach_comm(self.problem.handle, self._comm_handle):
+                raise RuntimeError("mrcal_amd_problem_attach_comm() failed:" + _api._last_error())
+            return
+        if _driver != "rccl":
+            raise ValueError("_driver: 'rccl', 'host' or 'python'")
         # the communicator id, made by rank 0, to everybody
         idbuf = (C.c_char*128)()
         if self.rank == 0:

@@ -7,6 +7,9 @@ far as one GPU allows:
     frame-sharded kernels + the two sums per trial step == the single-GPU solve,
     with bit-identical replicated state on both ranks (protocol reference driver)
   - run_steps() continues where the previous call stopped
+  - the C++ sharded solve at worlds 2 and 3 on ONE device, its collectives staged
+    through host shared memory (mrcal_amd_comm_create_host): boards, points,
+    pairs, outlier passes, a rank without boards
 """
 import os
 import sys
@@ -400,3 +403,90 @@ def test_world2_points_and_pairs(amd, tmp_path):
     assert all(0 < hi - lo for lo, hi in r["ranges"])
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
     assert np.abs(r["b"] - b1).max() < 1e-6
+
+
+# ---- the C++ sharded solve at world > 1 on one device: collectives staged through the host (csrc/comm.cpp) ----
+HOST_CASES = ("boards", "boards_splined", "everything", "fewer_frames_than_ranks")
+def _host_case(api, which):
+    from mrcal_amd.synthetic import make_calibration_problem
+    if which == "boards":         oi = _problem(api)
+    if which == "boards_splined": oi = _problem(api, SPLINED)
+    if which == "everything":
+        oi = _sfm_with_everything(api)
+        oi["do_apply_outlier_rejection"] = True
+        oi["observations_board"][3,2,4,:2] += 40.
+    if which == "fewer_frames_than_ranks":
+        # two frames for three ranks: one rank owns no board at all, and still takes part in every collective of
+        # the outlier pass
+        oi = make_calibration_problem(api, Ncameras=2, Nframes=2, lensmodel="LENSMODEL_OPENCV4",
+                                      object_width_n=10, object_height_n=10, seed=3)[0]
+        oi["do_optimize_intrinsics_distortions"] = False
+        oi["observations_board"][1,2,4,:2] += 40.
+    return oi
+
+
+def _host_worker(rank, world, port, out_path, which):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      MRCAL_AMD_HOST_COMM_TIMEOUT="60")
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mrcal_amd
+    from mrcal_amd.parallel import ShardedProblem
+    sp = ShardedProblem(_driver="host", **_host_case(mrcal_amd._api, which))
+    st = sp.solve()
+    b = sp.b_packed()
+    t = torch.from_numpy(b.copy())
+    lo, hi = t.clone(), t.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    counts = torch.tensor([st["Niterations"], st["Nevaluations"], st["Noutliers_board"], st["Noutlier_passes"]])
+    cl, ch = counts.clone(), counts.clone()
+    dist.all_reduce(cl, op=dist.ReduceOp.MIN); dist.all_reduce(ch, op=dist.ReduceOp.MAX)
+    ranges = torch.zeros(world, 6, dtype=torch.int64)
+    ranges[rank] = torch.tensor(sp.frame_range + sp.point_range + sp.tripoint_range)
+    dist.all_reduce(ranges)
+    if rank == 0:
+        np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"],
+                 Noutliers=st["Noutliers_board"],
+                 replicated=bool(torch.equal(lo, hi) and torch.equal(cl, ch)),
+                 Ncollectives=sp.Ncollectives, Nevaluations=st["Nevaluations"], ranges=ranges.numpy())
+    sp.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which,world", (("boards", 2), ("boards_splined", 2), ("everything", 2), ("everything", 3),
+                                         ("fewer_frames_than_ranks", 3)))
+def test_cpp_sharded_solve_over_the_host_transport(amd, tmp_path, which, world):
+    """The PRODUCT solver with more than one rank on a one-GPU box: ShardedProblem(_driver="host") is the C++
+    sharded solve - the device-controlled step with its two all-reduces, mark_outliers() with its three, the
+    final gather - with mrcal_amd_comm_allreduce_sum() staged through a shared-memory segment instead of RCCL
+    (which refuses two ranks on one device). Same outliers, cost and optimum as the single-GPU solve; every rank
+    ends with the same state and the same counters. The last case leaves a rank without a single board: its
+    collectives must still pair up with the others' (a mismatch is a timeout here, reported, not a hang)"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.synthetic import copy_inputs
+    oi = _host_case(amd._api, which)
+    with Problem(**copy_inputs(oi)) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "host.npz")
+    port = 29700 + (os.getpid() % 250)
+    mp.spawn(_host_worker, args=(world, port, out, which), nprocs=world, join=True)
+    r = np.load(out)
+    assert bool(r["replicated"])
+    fr = r["ranges"][:, 0:2]
+    if which == "fewer_frames_than_ranks":
+        assert (fr[:,1] - fr[:,0] == 0).any() and s1["Noutliers_board"] > 0
+    else:
+        assert (fr[:,1] - fr[:,0] > 0).all()
+    if which == "everything":
+        assert (r["ranges"][:,3] > r["ranges"][:,2]).all() and (r["ranges"][:,5] > r["ranges"][:,4]).all()
+        assert s1["Noutliers_board"] > 0
+    assert int(r["Noutliers"]) == s1["Noutliers_board"]
+    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
+    assert np.abs(r["b"] - b1).max() < (1e-3 if which == "boards_splined" else 2e-5)
+    assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
