@@ -64,7 +64,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     }
     hipFree(d_ops);
     hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
-    hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table);
+    hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table); hipFree(plan.frame_pos); hipFree(plan.obs_cols);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
     hipFree(plan.spl_hdr); hipFree(plan.spl_part);
@@ -261,6 +261,12 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->op[1].b,  (size_t)L.Nstate);
     ok = ok && dev_alloc(&P->op[1].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc(&P->op[1].Jv, (size_t)P->Nnz);
+    if(L.lensmodel.type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && (size_t)P->D.Nobs_board*gram_stride(L.Ndist) >= ((size_t)1 << 32))
+    {
+        // (reduce_pair_chunk() addresses the Grams with 32-bit element offsets; this is 34 GB of Grams)
+        set_error("too many board observations: %d Grams of %d doubles", P->D.Nobs_board, gram_stride(L.Ndist));
+        return false;
+    }
     ok = ok && dev_alloc(&P->d_gram,   (L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) ? (size_t)1 : (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
     for(int i=0;i<2 && ok;i++)
     {
@@ -409,6 +415,64 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         }
         ok = ok && dev_upload(&P->plan.pos_table,  tab.data(),        tab.size());
         ok = ok && dev_upload(&P->plan.pair_table, ptab.data(),       ptab.size());
+        {
+            // the frame part, per position and per observation (AssemblyPlan::frame_pos). Derived from the table
+            // above and checked against it: every pair's operation at every position must come back out
+            const int nintr = (P->D.Nintr_state > 0) ? P->D.Ncameras_intrinsics*P->D.Nintr_state : 0;
+            std::vector<int> fpos(npos, FRAMEPOS_NONE);
+            std::vector<int> pair_cols(2*(pair_rep.empty() ? 1 : pair_rep.size()), -1);
+            auto classify = [&](const PairOp& op, int* kind, int* a, int* k, int* base) -> void
+            {
+                *kind = FRAMEPOS_NONE; *a = 0; *k = 0; *base = -1;
+                const int b = op.aux >> 16;
+                switch(op.op & 0xff)
+                {
+                case PAIROP_D:  *kind = (op.op & PAIROP_MIRROR) ? FRAMEPOS_D_MIRROR : FRAMEPOS_D; *a = op.aux & 0xffff; *k = b; break;
+                case PAIROP_GF: *kind = FRAMEPOS_GF; *a = op.aux & 0xffff; break;
+                case PAIROP_BT:
+                    *a = op.aux & 0xffff;
+                    if(b < nintr)        { *kind = FRAMEPOS_BT_INTRINSICS; *base = (b/P->D.Nintr_state)*P->D.Nintr_state; *k = b - *base; }
+                    else if(b < nd.Nie)  { *kind = FRAMEPOS_BT_EXTRINSICS; *base = nintr + ((b - nintr)/6)*6;              *k = b - *base; }
+                    else                 { *kind = FRAMEPOS_BT_WARP; *k = b; }
+                    break;
+                default: break;
+                }
+            };
+            bool consistent = true;
+            for(size_t ip = 0; ip < pair_rep.size(); ip++)
+                for(int pos = 0; pos < npos; pos++)
+                {
+                    int kind, a, k, base;
+                    classify(ptab[ip*npos + pos], &kind, &a, &k, &base);
+                    if(kind == FRAMEPOS_NONE) continue;
+                    const int code = kind | (a << 3) | (k << 6);
+                    if(fpos[pos] == FRAMEPOS_NONE) fpos[pos] = code;
+                    else if(fpos[pos] != code) consistent = false;
+                    if(kind == FRAMEPOS_BT_INTRINSICS || kind == FRAMEPOS_BT_EXTRINSICS)
+                    {
+                        int& c = pair_cols[2*ip + (kind == FRAMEPOS_BT_EXTRINSICS ? 1 : 0)];
+                        if(c < 0) c = base; else if(c != base) consistent = false;
+                    }
+                }
+            // ... and back: a pair without a block (the camera at the reference has no extrinsics) has nothing
+            // at that block's positions, and every other position reads the same through both tables
+            for(size_t ip = 0; ip < pair_rep.size() && consistent; ip++)
+                for(int pos = 0; pos < npos; pos++)
+                {
+                    int kind, a, k, base;
+                    classify(ptab[ip*npos + pos], &kind, &a, &k, &base);
+                    const int fk = fpos[pos] & 7;
+                    const bool absent = (fk == FRAMEPOS_BT_INTRINSICS && pair_cols[2*ip] < 0) || (fk == FRAMEPOS_BT_EXTRINSICS && pair_cols[2*ip+1] < 0);
+                    if(kind == FRAMEPOS_NONE ? !(fk == FRAMEPOS_NONE || absent) : absent) consistent = false;
+                }
+            // (the splined models assemble from staged rows, not from Grams: no use for these tables)
+            const bool uses_grams = P->D.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC;
+            if(!consistent && uses_grams) { set_error("internal: the Gram positions of the frame part depend on the camera pair"); return false; }
+            std::vector<int> obs_cols(2*(Nobs > 0 ? Nobs : 1), -1);
+            for(int o = 0; o < Nobs; o++) { obs_cols[2*o] = pair_cols[2*obs_pair[o]]; obs_cols[2*o+1] = pair_cols[2*obs_pair[o]+1]; }
+            ok = ok && dev_upload(&P->plan.frame_pos, fpos.data(),     fpos.size());
+            ok = ok && dev_upload(&P->plan.obs_cols,  obs_cols.data(), obs_cols.size());
+        }
         ok = ok && dev_upload(&P->plan.obs_pair,   obs_pair.data(),   obs_pair.size());
         ok = ok && dev_upload(&P->plan.chunk_pair, chunk_pair.data(), chunk_pair.size());
 

@@ -77,7 +77,8 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
 // lds_f: Btf[6][Nc] | Df[36] | gf[6] | L[36] | rinv[6]
 __device__ __forceinline__
 void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, const AssemblyPlan& plan,
-                          const double* __restrict__ gram, int f, int mode, bool do_factor, double lambda,
+                          const double* __restrict__ gram, int f, int o0, int o1 /* the frame's observations (mode 1) */,
+                          int mode, bool do_factor, double lambda,
                           const FactorBuffers& F, double* __restrict__ lds_f)
 {
     double* __restrict__ Btf  = lds_f;
@@ -85,8 +86,14 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
     double* __restrict__ gf   = Df + 36;
     double* __restrict__ Ls   = gf + 6;
     double* __restrict__ rinv = Ls + 36;
-    __shared__ int pair_of[8];                 // the pairs of the 8 observations in flight
     const int t = threadIdx.x;
+#ifdef ASM_TS
+    long long ats[16]; int nats = 0;
+#define ATS() do { if(t == 0 && nats < 16) ats[nats++] = clock64(); } while(0)
+#else
+#define ATS()
+#endif
+    ATS();
     const int e0 = 6*f;   // frame blocks come first in E
     double* __restrict__ Bt = O.Bt;
     double* __restrict__ D  = O.D;
@@ -94,67 +101,83 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
 
     if(mode == 1)
     {
-        const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
         for(int i = t; i < 6*nd.Nc + 42; i += blockDim.x) lds_f[i] = 0.0;
+        __syncthreads();
         const int npos = gram_stride(P.Ndist);
         for(int ob = o0; ob < o1; ob += 8)
         {
-            __syncthreads();                       // pair_of is free again (and, the first time, the accumulators are zero)
-            if(t < 8) pair_of[t] = plan.obs_pair[(ob + t < o1) ? ob + t : o0];
-            __syncthreads();
-            // 8 Gram loads per position in flight, together with the position's flag and the pairs' operations
-            for(int base = 0; base < npos; base += 2*blockDim.x)        // (uniform trip count: barriers inside)
+            // where the cameras of the 8 observations in flight sit in the camera block (uniform loads, in flight
+            // together with the Gram loads below: nothing here waits for anything but the frame's range)
+            int col_i[8], col_e[8];
+#pragma unroll
+            for(int u = 0; u < 8; u++)
+            {
+                const int o = (ob + u < o1) ? ob + u : o0;
+                col_i[u] = plan.obs_cols[2*o]; col_e[u] = plan.obs_cols[2*o+1];
+            }
+            // 8 Gram loads per position in flight
+            for(int base = 0; base < npos; base += 2*blockDim.x)
             {
                 const int pos0 = base + t;
                 double vv[2][8];
-                PairOp op[2][8];
-                int    flag[2];
+                int    rec[2];
 #pragma unroll
                 for(int w = 0; w < 2; w++)
                 {
                     const int pos = pos0 + w*blockDim.x;
                     const int pc  = (pos < npos) ? pos : t;
-                    flag[w] = (pos < npos) ? plan.pos_table[pc] : 0;
+                    rec[w] = (pos < npos) ? plan.frame_pos[pc] : FRAMEPOS_NONE;
                     // (Masking the loads of the positions without a frame column - whole 64-byte
                     //  lines of a Gram are camera-block only - was measured: 28 us against 26.
                     //  The kernel is not bound by its traffic)
 #pragma unroll
-                    for(int u = 0; u < 8; u++)
-                    {
-                        const int o = (ob + u < o1) ? ob + u : o0;
-                        vv[w][u] = gram[(size_t)o*npos + pc];
-                        op[w][u] = plan.pair_table[(size_t)pair_of[u]*npos + pc];
-                    }
-                }
-                // one observation at a time: distinct positions of ONE observation never share a destination
-#pragma unroll
-                for(int u = 0; u < 8; u++)
-                {
-                    if(ob + u < o1)
+                    for(int u = 0; u < 8; u++) vv[w][u] = 0.0;
+                    if((rec[w] & 7) != FRAMEPOS_NONE)
                     {
 #pragma unroll
-                        for(int w = 0; w < 2; w++)
+                        for(int u = 0; u < 8; u++)
                         {
-                            if(!(flag[w] & 0x20000)) continue;          // no frame column in this position, for any pair
-                            const double v = vv[w][u];
-                            const int a = op[w][u].aux & 0xffff, b = op[w][u].aux >> 16;
-                            switch(op[w][u].op & 0xff)
-                            {
-                            case PAIROP_D:
-                                Df[a*6 + b] += v;
-                                if(op[w][u].op & PAIROP_MIRROR) Df[b*6 + a] += v;
-                                break;
-                            case PAIROP_BT: Btf[a*nd.Nc + b] += v; break;
-                            case PAIROP_GF: gf[a] += v; break;
-                            default: break;
-                            }
+                            const int o = (ob + u < o1) ? ob + u : o0;
+                            vv[w][u] = gram[(size_t)o*npos + pc];
                         }
                     }
-                    __syncthreads();
                 }
+                // The observations in order, NO barrier between them: a destination belongs to one position -
+                // position = (a camera-block tile column, a frame column), and whatever the camera the tile
+                // column lands in a state of its own kind (an intrinsic of some camera, an extrinsic of some
+                // camera, a warp term) - hence to one thread, which adds its observations one after the other
+#pragma unroll
+                for(int w = 0; w < 2; w++)
+                {
+                    const int kind = rec[w] & 7, a = (rec[w] >> 3) & 7, k = rec[w] >> 6;
+                    if(kind == FRAMEPOS_NONE) continue;
+                    if(kind == FRAMEPOS_BT_INTRINSICS || kind == FRAMEPOS_BT_EXTRINSICS)
+                    {
+                        double* __restrict__ row = Btf + a*nd.Nc + k;
+#pragma unroll
+                        for(int u = 0; u < 8; u++)
+                        {
+                            const int c = (kind == FRAMEPOS_BT_INTRINSICS) ? col_i[u] : col_e[u];
+                            if(ob + u < o1 && c >= 0) row[c] += vv[w][u];
+                        }
+                    }
+                    else
+                    {
+                        // the same entry for every observation: summed on top of what is there, in order
+                        double* __restrict__ dst = (kind == FRAMEPOS_GF)      ? gf + a :
+                                                   (kind == FRAMEPOS_BT_WARP) ? Btf + a*nd.Nc + k : Df + a*6 + k;
+                        double acc = *dst;
+#pragma unroll
+                        for(int u = 0; u < 8; u++) if(ob + u < o1) acc += vv[w][u];
+                        *dst = acc;
+                        if(kind == FRAMEPOS_D_MIRROR) Df[k*6 + a] = acc;
+                    }
+                }
+                ATS();
             }
         }
         __syncthreads();
+        ATS();
         for(int i = t; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] = Btf[i];
         if(t < 36)      D[(size_t)f*36 + t]     = Df[t];
         else if(t < 42) g[nd.Nie + e0 + (t-36)] = gf[t-36];
@@ -203,15 +226,17 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
             for(int j=0;j<6;j++) Ls[i*6+j] = (j <= i) ? M[i][j] : 0.0;
         if(!ok) atomicExch(F.status, 1);
     }
+    ATS();
     __syncthreads();
+    ATS();
     if(t < 36) F.LD[(size_t)f*36 + t] = Ls[t];
-    double Lr[6][6], ri[6];
+    double Lr[6][6], ri[6];             // (the strict lower triangle is all the substitution reads)
 #pragma unroll
     for(int i=0;i<6;i++)
     {
         ri[i] = rinv[i];
 #pragma unroll
-        for(int k=0;k<6;k++) Lr[i][k] = Ls[i*6+k];
+        for(int k=0;k<i;k++) Lr[i][k] = Ls[i*6+k];
     }
     // forward substitution, one column of [Bt_f | g_f] per thread and pass
     for(int c = t; c <= nd.Nc; c += blockDim.x)
@@ -228,6 +253,12 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
         if(c < nd.Nc) { for(int i=0;i<6;i++) F.Wt[(size_t)(e0+i)*nd.Nc + c] = w[i]; }
         else          { for(int i=0;i<6;i++) F.y[e0+i] = w[i]; }
     }
+    ATS();
+#ifdef ASM_TS
+    if(t == 0 && (f == 0 || f == 300 || f == 999))
+        printf("asm ts f=%d n=%d (zero | loads + adds | sync | bt-write+factor | sync | fsub): %lld %lld %lld %lld %lld %lld\n", f, nats,
+               ats[1]-ats[0], ats[2]-ats[1], ats[3]-ats[2], ats[4]-ats[3], ats[5]-ats[4], ats[6]-ats[5]);
+#endif
 }
 
 // S-S part: observations that see the same (intrinsics, extrinsics) pair add to
@@ -235,57 +266,51 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
 // each thread sums its Gram positions over the chunk, in order (coalesced reads,
 // 16 in flight), and leaves the sum in chunk_part[chunk][pos]. assemble_finalize()
 // adds the chunks up, again in a fixed order. No atomics
+// a pair chunk is reduced by one workgroup per 256 Gram positions
+__host__ __device__ __forceinline__ int assemble_chunk_slices(const DeviceProblem& P) { return (gram_stride(P.Ndist) + 255) >> 8; }
 __device__ __forceinline__
 void reduce_pair_chunk(const DeviceProblem& P, const AssemblyPlan& plan,
-                       const double* __restrict__ gram, int ichunk)
+                       const double* __restrict__ gram, int ichunk, int islice /* which 256 positions */)
 {
     const int c0 = plan.chunk_begin[ichunk], c1 = plan.chunk_begin[ichunk+1];
     const int npos = gram_stride(P.Ndist);
     const PairOp* __restrict__ ops = plan.pair_table + (size_t)plan.chunk_pair[ichunk]*npos;
     double* __restrict__ out = plan.chunk_part + (size_t)ichunk*npos;
     const int nobs = c1 - c0;
-    // two positions per thread and 16 observations of each in flight together
-    for(int base = 0; base < npos; base += 2*blockDim.x)
+#ifdef ASM_TS
+    const long long cts0 = clock64();
+#endif
+    // one position per thread (a workgroup per 256 positions of the chunk: two position per thread and half
+    // as many workgroups needed 112 registers, and at four waves per SIMD the launch no longer fit the chip
+    // at once), 16 observations of it in flight together
+    const int  pos  = islice*blockDim.x + threadIdx.x;
+    const int  kind = (pos < npos) ? (ops[pos].op & 0xff) : PAIROP_NONE;
+    const bool live = (kind == PAIROP_A || kind == PAIROP_G || kind == PAIROP_NORM);
+    double acc = 0.0;
+    for(int u0 = 0; u0 < nobs; u0 += 16)
     {
-        int  pos[2]; bool live[2];
+        double vv[16];
+        unsigned ob[16];                // (problem_prepare_solver() refuses Grams past 2^32 doubles)
 #pragma unroll
-        for(int w = 0; w < 2; w++)
+        for(int u = 0; u < 16; u++)
         {
-            pos[w] = base + w*blockDim.x + threadIdx.x;
-            const int kind = (pos[w] < npos) ? (ops[pos[w]].op & 0xff) : PAIROP_NONE;
-            live[w] = (kind == PAIROP_A || kind == PAIROP_G || kind == PAIROP_NORM);
-        }
-        double acc[2] = {0.0, 0.0};
-        for(int u0 = 0; u0 < nobs; u0 += 16)
-        {
-            double vv[2][16];
-            size_t ob[16];
-#pragma unroll
-            for(int u = 0; u < 16; u++)
-            {
-                const int k = (u0 + u < nobs) ? c0 + u0 + u : c0;
-                ob[u] = (size_t)plan.pair_obs[k]*npos;
-            }
-            // (per position ONE masked region holding its 16 loads: in flight together)
-#pragma unroll
-            for(int w = 0; w < 2; w++)
-            {
-#pragma unroll
-                for(int u = 0; u < 16; u++) vv[w][u] = 0.0;
-                if(live[w])
-                {
-#pragma unroll
-                    for(int u = 0; u < 16; u++) vv[w][u] = gram[ob[u] + pos[w]];
-                }
-            }
-#pragma unroll
-            for(int w = 0; w < 2; w++)
-#pragma unroll
-                for(int u = 0; u < 16; u++) acc[w] += (u0 + u < nobs) ? vv[w][u] : 0.0;
+            const int k = (u0 + u < nobs) ? c0 + u0 + u : c0;
+            ob[u] = (unsigned)plan.pair_obs[k]*(unsigned)npos;
         }
 #pragma unroll
-        for(int w = 0; w < 2; w++) if(pos[w] < npos) out[pos[w]] = acc[w];
+        for(int u = 0; u < 16; u++) vv[u] = 0.0;
+        if(live)
+        {
+#pragma unroll
+            for(int u = 0; u < 16; u++) vv[u] = gram[(size_t)ob[u] + pos];
+        }
+#pragma unroll
+        for(int u = 0; u < 16; u++) acc += (u0 + u < nobs) ? vv[u] : 0.0;
     }
+    if(pos < npos) out[pos] = acc;
+#ifdef ASM_TS
+    if(threadIdx.x == 0 && islice == 0 && (ichunk == 0 || ichunk == plan.Nchunks-1)) printf("asm ts chunk %d of %d (nobs %d) dur=%lld\n", ichunk, plan.Nchunks, nobs, clock64()-cts0);
+#endif
 }
 
 // Every destination of the camera-block part - an entry of A, of g (S part) or
@@ -1160,11 +1185,11 @@ void rows_single_kernel(NormalDims nd, OpRef R, int row0, int row1, const int32_
 
 // The Gram assembly (+ elimination of the frame blocks) and the generic rows in
 // ONE launch (all three kinds of work are independent): workgroups
-// [0, nframe_blocks) take a frame each, the next Nchunks a pair chunk each, the
+// [0, nframe_blocks) take a frame each, the next Nchunks*slices 256 positions of a pair chunk each, the
 // rest 256 generic rows each.
 //   mode (device flag, or mode_host): 0 nothing; 1 the point *sel_eval was just
 //   evaluated; 2 re-eliminate the point *sel_cur from its stored blocks
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
 void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRanges br, const OpDev* __restrict__ ops,
                             const int* __restrict__ sel_eval, const int* __restrict__ sel_cur,
                             const SolverCtl* __restrict__ ctl, const int* __restrict__ skip,
@@ -1174,22 +1199,35 @@ void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRanges br, cons
                             int nframe_blocks, int row0, int row1,
                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
-    if(skip != NULL && *skip) return;
-    const int mode = mode_ptr ? *mode_ptr : mode_host;
-    if(mode == 0) return;
-    extern __shared__ double lds_f[];
-    const OpDev& O = ops[(mode == 1) ? (sel_eval ? *sel_eval : 0) : (sel_cur ? *sel_cur : 0)];
-    const double lambda = ctl ? ctl->lambda : lambda_host;
+    // everything the workgroup needs to know before it can ask for data, asked for at once: one trip to memory.
+    // (The chunk workgroups last: their loads then fall into the frame workgroups' arithmetic. First: 17.4 us
+    //  against 16.5)
+    const int nslices = assemble_chunk_slices(P), nchunk_blocks = plan.Nchunks*nslices;
     const int b = blockIdx.x;
-    if(b < nframe_blocks)
-        assemble_frame_block(P, nd, O, plan, gram, br.frame_lo + b, mode, do_factor != 0, lambda, F, lds_f);
+    const bool frame_block = b < nframe_blocks;
+    const int skipv = skip     ? *skip     : 0;
+    const int mode  = mode_ptr ? *mode_ptr : mode_host;
+    const int ie    = sel_eval ? *sel_eval : 0;
+    const int ic    = sel_cur  ? *sel_cur  : 0;
+    const double lambda = ctl ? ctl->lambda : lambda_host;
+    const int o0 = frame_block ? plan.frame_obs_begin[br.frame_lo + b]     : 0;
+    const int o1 = frame_block ? plan.frame_obs_begin[br.frame_lo + b + 1] : 0;
+    if(skipv || mode == 0) return;
+    extern __shared__ double lds_f[];
+    const OpDev& O = ops[(mode == 1) ? ie : ic];
+    if(frame_block)
+        assemble_frame_block(P, nd, O, plan, gram, br.frame_lo + b, o0, o1, mode, do_factor != 0, lambda, F, lds_f);
     else if(mode != 1) return;
-    else if(b < nframe_blocks + plan.Nchunks) reduce_pair_chunk(P, plan, gram, b - nframe_blocks);
+    else if(b < nframe_blocks + nchunk_blocks)
+    {
+        const int cb = b - nframe_blocks;
+        reduce_pair_chunk(P, plan, gram, cb / nslices, cb - (cb / nslices)*nslices);
+    }
     else
     {
         // rows that do not come from board observations; |x|^2 of each workgroup's
         // rows goes to its slot of row_part, summed in order by assemble_finalize()
-        const int rb = b - nframe_blocks - plan.Nchunks;
+        const int rb = b - nframe_blocks - nchunk_blocks;
         double n2 = 0.0;
         rows_generic_row(nd, O, row0 + rb*256 + threadIdx.x, row1, Jp, Ji, &n2);
         for(int off=32; off>0; off>>=1) n2 += __shfl_down(n2, off);
@@ -1480,7 +1518,9 @@ void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const Solve
 // y give r. Result layout of the instruction (measured): register v of lane l
 // holds D[l/16 + 4 v][l%16]
 typedef double syrk_d4 __attribute__((ext_vector_type(4)));
+#ifndef SYRK_UNROLL
 #define SYRK_UNROLL 16
+#endif
 // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), and every XCD has its own
 // L2. In the natural order every XCD ends up reading ALL of Wt (each tile pair needs its two column
 // strips over all rows): 8 x |Wt| from the Infinity Cache into the L2s. Here the slices (row ranges
@@ -1525,6 +1565,9 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
 
     syrk_d4 acc  = {0.0, 0.0, 0.0, 0.0};
     syrk_d4 accr = {0.0, 0.0, 0.0, 0.0};
+#ifdef ASM_TS
+    const long long sts0 = clock64();
+#endif
     for(int e0 = e_begin; e0 < e_end; e0 += 4*SYRK_UNROLL)
     {
         double a[SYRK_UNROLL], b[SYRK_UNROLL], yy[SYRK_UNROLL];
@@ -1545,6 +1588,8 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
         for(int u=0;u<SYRK_UNROLL;u++)
         {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], diag ? a[u] : b[u], acc, 0, 0, 0);
+            // (Wt^T y as a matrix instruction for ONE useful column doubles the diagonal tiles' matrix work; on
+            //  the vector unit instead: measured, no change - the launch is as long as its loads' round trips)
             if(diag) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], yy[u], accr, 0, 0, 0);
         }
     }
@@ -1559,6 +1604,9 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
 #pragma unroll
         for(int v=0;v<4;v++) rpart[kk + 4*v] = accr[v];
     }
+#ifdef ASM_TS
+    if(lane == 0 && (px == 1 || px == 44) && (sy == 0 || sy == 40)) printf("syrk ts px=%d sy=%d block=(%d,%d) rows=%d dur=%lld\n", px, sy, blockIdx.x, blockIdx.y, e_end-e_begin, clock64()-sts0);
+#endif
 }
 
 // The same for big camera blocks (splined models: 76 x 76 tiles), where the
@@ -3548,7 +3596,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
     {
         const int nframe_blocks = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
         FactorBuffers none; memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks + assemble_row_blocks(P, plan)), dim3(256),
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
                            (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, assemble_row0(P, plan), P.Nmeas, B.Jp, B.Ji);
         hipError_t e = launch_gen_rows(nd, plan, B.R, B.Jp, stream);
@@ -3887,7 +3935,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     {
         const int row0 = 2*P.W*P.H*P.Nobs_board;
         nframes_fused = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks + assemble_row_blocks(P, *a.plan)), dim3(256),
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, *a.plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
                            &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, assemble_row0(P, *a.plan), P.Nmeas, a.Jp, a.Ji);
         // the planned rows of the evaluated point (their own launch: they ride on nothing; a trial without an

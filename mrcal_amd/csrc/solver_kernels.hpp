@@ -93,6 +93,7 @@ enum { PAIROP_NONE = 0,
        PAIROP_GF,     // g_f[a]
        PAIROP_MIRROR = 0x100 };
 struct PairOp { int op, aux; };
+enum { FRAMEPOS_NONE = 0, FRAMEPOS_D, FRAMEPOS_D_MIRROR, FRAMEPOS_GF, FRAMEPOS_BT_INTRINSICS, FRAMEPOS_BT_EXTRINSICS, FRAMEPOS_BT_WARP };
 
 #ifndef REDUCE_CHUNK
 #define REDUCE_CHUNK 64
@@ -157,6 +158,13 @@ struct AssemblyPlan
     // bit 31 valid, bit 17 "involves a frame column", bit 16 "in a diagonal block", bits 8..15 i, bits 0..7 j
     int*    pos_table;     // [gram_stride]
     PairOp* pair_table;    // [Npairs][gram_stride]
+    // The frame part of the same, without the trip through pair_table: what a position adds to depends on the
+    // pair only through WHERE the camera's intrinsics and extrinsics sit in the camera block.
+    //   frame_pos[pos]   FRAMEPOS_* kind | a << 3 | k << 6  (a: frame variable; k: second frame variable, or the
+    //                    offset within the camera's intrinsics / extrinsics, or the S index of a warp term)
+    //   obs_cols[o][2]   S index of the first intrinsic / first extrinsic of observation o's camera (-1: none)
+    int*    frame_pos;     // [gram_stride]
+    int*    obs_cols;      // [Nobs_board][2]
     // Fixed-order reduction of the camera-block part (no atomics: the sums do
     // not depend on scheduling). reduce_pair_chunk() leaves one partial sum per
     // (chunk, Gram position); assemble_finalize() then adds, for every
