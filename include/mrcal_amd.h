@@ -613,6 +613,14 @@ bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* o
    State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames (6 each) then points (3 each), then the warp.
    The leader owns the camera block and the points */
 void  mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info);
+/* Which part of the state the solver keeps as the dense block S and which it
+   eliminates block by block (E). The state vector is the reference's either way;
+     S index s -> state s (s < info[0]) or s + info[1];   E index e -> state info[2] + e
+   info[3]: 0 the frames and points are eliminated (stationary cameras), 1 the
+   extrinsics are (a moving camera: many rt_cam_ref, few frames; chosen at
+   creation, test_calibration_helpers.py:422-493 builds such problems). The
+   blocks of mrcal_amd_problem_get_normal_equations() are in these indices */
+void  mrcal_amd_problem_partition(mrcal_amd_problem_t* problem, int info[4]);
 /* outlier statistics / marking on the local board observations (mrcal.c:3978-4402);
    counts (device int[4]) and sums (device double[1]) are accumulated into */
 bool  mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* problem, int iop, double thresh_sq,

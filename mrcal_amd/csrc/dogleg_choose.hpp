@@ -144,7 +144,7 @@ ChooseOut dogleg_choose_scalars(const ChooseArgs& a, double* __restrict__ scratc
     const OpDev& from = a.ops[ib];
     const bool derive = ctl->derive != 0;
     c.derive = derive;
-    auto s_to_state = [&](int i) -> int { return (i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie); };
+    auto s_to_state = [&](int i) -> int { return S_to_state(nd, i); };
 
     // Every sum this choice may need, accumulated per thread first and reduced across the workgroup ONCE:
     //   [0] |g_S|^2  [1] g^T N g  [2] |g_E|^2                      (a new point: derive)

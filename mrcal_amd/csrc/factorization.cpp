@@ -103,8 +103,9 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     mrcal_amd_factorization* f = new mrcal_amd_factorization();
     f->Nmeas = Nmeas;
     NormalDims& nd = f->nd;
-    nd.Nstate = Nstate; nd.Nie = Nstate_shared_leading; nd.Nwarp = Nwarp;
-    nd.i_state_warp = Nstate - Nwarp; nd.Nc = nd.Nie + nd.Nwarp;
+    nd.Nstate = Nstate; nd.Nwarp = Nwarp;
+    nd.i_state_warp = Nstate - Nwarp; nd.Nc = Nstate_shared_leading + nd.Nwarp;
+    normal_dims_set_partition(nd, Nstate_shared_leading);
     nd.NE = NE; nd.Nfb = Nframe_blocks; nd.Npb = Npoint_blocks; nd.NEb = nd.Nfb + nd.Npb;
     f->br.frame_lo = 0; f->br.frame_hi = nd.Nfb; f->br.point_lo = nd.Nfb; f->br.point_hi = nd.NEb;
     if((double)nd.Nc*nd.Nc*8.0 > 64e9)

@@ -63,7 +63,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
     }
     hipFree(d_ops);
-    hipFree(plan.frame_obs_begin); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
+    hipFree(plan.frame_obs_begin); hipFree(plan.frame_obs); hipFree(plan.chunk_begin); hipFree(plan.pair_obs); hipFree(plan.pos_table);
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table); hipFree(plan.frame_pos); hipFree(plan.obs_cols);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
@@ -321,9 +321,18 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     std::vector<BoardObsMeta> meta(Nobs);
     if(Nobs > 0)
         HIP_TRY(hipMemcpy(meta.data(), P->d_board_meta, (size_t)Nobs*sizeof(BoardObsMeta), hipMemcpyDeviceToHost), return false);
-    std::vector<int> frame_begin(L.dims.Nframes+1, 0);
-    for(int o=0;o<Nobs;o++) frame_begin[meta[o].iframe+1]++;
-    for(int f=0;f<L.dims.Nframes;f++) frame_begin[f+1] += frame_begin[f];
+    // the eliminated pose of an observation (its frame; with elim_extrinsics its camera, which may be the
+    // reference: none then), and the one that stays in the camera block
+    const bool elimx = nd.elim_extrinsics != 0;
+    auto eblock_of = [&](const BoardObsMeta& m) -> int { return elimx ? m.icam_extrinsics : m.iframe; };
+    // (what a Gram position means is common to the observations with the same camera-block columns AND the same
+    //  columns present: the key of a "pair" carries whether there is an eliminated pose - a camera at the
+    //  reference has none)
+    auto spose_of  = [&](const BoardObsMeta& m) -> int { return 2*(elimx ? m.iframe : m.icam_extrinsics) + ((eblock_of(m) >= 0) ? 1 : 0); };
+    const int Neblocks_board = elimx ? P->D.Ncameras_extrinsics : L.dims.Nframes;
+    std::vector<int> frame_begin(Neblocks_board+1, 0);
+    for(int o=0;o<Nobs;o++) if(eblock_of(meta[o]) >= 0) frame_begin[eblock_of(meta[o])+1]++;
+    for(int f=0;f<Neblocks_board;f++) frame_begin[f+1] += frame_begin[f];
     // sanity: contiguity
     for(int o=1;o<Nobs;o++)
         if(meta[o].iframe < meta[o-1].iframe)
@@ -331,13 +340,21 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             set_error("board observations must be sorted by frame");
             return false;
         }
+    // (the observations of a frame are contiguous, those of a camera need not be: a list then)
+    std::vector<int> eblock_obs;
+    if(elimx)
+    {
+        std::vector<int> fill(frame_begin.begin(), frame_begin.end() - 1);
+        eblock_obs.assign(Nobs > 0 ? Nobs : 1, 0);
+        for(int o=0;o<Nobs;o++) if(eblock_of(meta[o]) >= 0) eblock_obs[fill[eblock_of(meta[o])]++] = o;
+    }
 
     std::vector<int> order(Nobs);
     for(int o=0;o<Nobs;o++) order[o] = o;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b)
                      {
                          if(meta[a].icam_intrinsics != meta[b].icam_intrinsics) return meta[a].icam_intrinsics < meta[b].icam_intrinsics;
-                         return meta[a].icam_extrinsics < meta[b].icam_extrinsics;
+                         return spose_of(meta[a]) < spose_of(meta[b]);
                      });
     const int CHUNK = REDUCE_CHUNK;
     std::vector<int> chunk_begin;
@@ -346,13 +363,14 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         int j = i;
         while(j < Nobs && j - i < CHUNK &&
               meta[order[j]].icam_intrinsics == meta[order[i]].icam_intrinsics &&
-              meta[order[j]].icam_extrinsics == meta[order[i]].icam_extrinsics) j++;
+              spose_of(meta[order[j]]) == spose_of(meta[order[i]])) j++;
         chunk_begin.push_back(i);
         i = j;
     }
     chunk_begin.push_back(Nobs);
     P->plan.Nchunks = (int)chunk_begin.size() - 1;
     ok = ok && dev_upload(&P->plan.frame_obs_begin, frame_begin.data(), frame_begin.size());
+    if(elimx) ok = ok && dev_upload(&P->plan.frame_obs, eblock_obs.data(), eblock_obs.size());
     ok = ok && dev_upload(&P->plan.chunk_begin,     chunk_begin.data(), chunk_begin.size());
     ok = ok && dev_upload(&P->plan.pair_obs,        order.data(),       order.size());
     {
@@ -362,7 +380,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         {
             const int o = order[k];
             if(k == 0 || meta[o].icam_intrinsics != meta[order[k-1]].icam_intrinsics ||
-                         meta[o].icam_extrinsics != meta[order[k-1]].icam_extrinsics)
+                         spose_of(meta[o]) != spose_of(meta[order[k-1]]))
                 pair_rep.push_back(o);
             obs_pair[o] = (int)pair_rep.size() - 1;
         }
@@ -432,7 +450,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
                 case PAIROP_BT:
                     *a = op.aux & 0xffff;
                     if(b < nintr)        { *kind = FRAMEPOS_BT_INTRINSICS; *base = (b/P->D.Nintr_state)*P->D.Nintr_state; *k = b - *base; }
-                    else if(b < nd.Nie)  { *kind = FRAMEPOS_BT_EXTRINSICS; *base = nintr + ((b - nintr)/6)*6;              *k = b - *base; }
+                    else if(b < nd.Nc - nd.Nwarp) { *kind = FRAMEPOS_BT_EXTRINSICS; *base = nintr + ((b - nintr)/6)*6;     *k = b - *base; }
                     else                 { *kind = FRAMEPOS_BT_WARP; *k = b; }
                     break;
                 default: break;
@@ -459,6 +477,9 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             for(size_t ip = 0; ip < pair_rep.size() && consistent; ip++)
                 for(int pos = 0; pos < npos; pos++)
                 {
+                    // (observations without an eliminated pose - a camera at the reference, with elim_extrinsics -
+                    //  are in no block's list: what the frame part's tables say about them is never looked at)
+                    if(eblock_of(meta[pair_rep[ip]]) < 0) break;
                     int kind, a, k, base;
                     classify(ptab[ip*npos + pos], &kind, &a, &k, &base);
                     const int fk = fpos[pos] & 7;
@@ -949,13 +970,41 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     {
         NormalDims& nd = P->nd;
         nd.Nstate       = L.Nstate;
-        nd.Nie          = L.Nstate_intrinsics + L.Nstate_extrinsics;
         nd.Nwarp        = L.Nstate_warp;
         nd.i_state_warp = L.i_state_warp;
-        nd.Nc           = nd.Nie + nd.Nwarp;
-        nd.NE           = L.Nstate_frames + L.Nstate_points;
-        nd.Nfb          = L.Nstate_frames/6;
-        nd.Npb          = L.Nstate_points/3;
+        // Which pose blocks are eliminated (NormalDims, solver_kernels.hpp): the frames and points, unless the
+        // extrinsics are the numerous ones - a moving camera against a stationary board, many rt_cam_ref and
+        // few frames (test_calibration_helpers.py:422-493 builds such problems) - and every row touches at most
+        // one of them, and only board rows touch them: a camera's block is then written whole by the workgroup
+        // that sums its observations' Grams, as a frame's is (no triangulated pairs, no discrete points, no
+        // unity_cam01 row). The splined models' assembly and the sharding know frames only.
+        // MRCAL_AMD_ELIMINATE=frames|extrinsics overrides the choice where both are possible (tests)
+        bool elimx = !sharded && lensmodel->type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && Ntri_local == 0 &&
+                     Npoint_local == 0 && !sel.do_apply_regularization_unity_cam01 && L.Nstate_extrinsics > 0;
+        if(elimx)
+        {
+            const char* env = getenv("MRCAL_AMD_ELIMINATE");
+            if(env && !strcmp(env, "frames"))          elimx = false;
+            else if(env && !strcmp(env, "extrinsics")) elimx = true;
+            else elimx = Ncameras_extrinsics >= 4 && L.Nstate_frames + L.Nstate_points < L.Nstate_extrinsics;
+        }
+        if(!elimx)
+        {
+            nd.Nc  = L.Nstate_intrinsics + L.Nstate_extrinsics + nd.Nwarp;
+            nd.NE  = L.Nstate_frames + L.Nstate_points;
+            nd.Nfb = L.Nstate_frames/6;
+            nd.Npb = L.Nstate_points/3;
+            normal_dims_set_partition(nd, L.Nstate_intrinsics + L.Nstate_extrinsics);
+        }
+        else
+        {
+            nd.NE  = L.Nstate_extrinsics;
+            nd.Nc  = L.Nstate - nd.NE;
+            nd.Nfb = L.Nstate_extrinsics/6;
+            nd.Npb = 0;
+            nd.S_split = L.Nstate_intrinsics; nd.S_shift = nd.NE; nd.E_state0 = L.Nstate_intrinsics;
+            nd.elim_extrinsics = 1;
+        }
         nd.NEb          = nd.Nfb + nd.Npb;
         P->is_leader    = is_shard_leader;
         P->br.frame_lo  = 0;  P->br.frame_hi = nd.Nfb;
@@ -987,6 +1036,7 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     D.Nstate = L.Nstate;  D.Nmeas = L.Nmeas;
     D.do_optimize_extrinsics = L.Nstate_extrinsics > 0;
     D.do_optimize_frames     = sel.do_optimize_frames;
+    D.elim_extrinsics        = P->nd.elim_extrinsics;
     D.has_warp_state         = L.has_warp;
     D.has_warp_seed          = (calobject_warp != NULL);
     D.Ncameras_intrinsics = Ncameras_intrinsics; D.Ncameras_extrinsics = Ncameras_extrinsics;

@@ -252,6 +252,7 @@ struct DeviceProblem
     int i_state_intrinsics, i_state_extrinsics, i_state_frames, i_state_points, i_state_warp;
     int Nstate, Nmeas;
     int do_optimize_extrinsics, do_optimize_frames;
+    int elim_extrinsics;       // the solver eliminates the extrinsics blocks, not the frames (NormalDims, solver_kernels.hpp)
     int has_warp_state;  // warp is a state variable
     int has_warp_seed;   // a warp was given (it is applied whether optimized or not)
     int Ncameras_intrinsics, Ncameras_extrinsics, Nframes, Npoints, Npoints_fixed;

@@ -672,7 +672,7 @@ bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* P,
     if(A)
         for(int i = 0; i < nd.Nc; i++)
             for(int j = i + 1; j < nd.Nc; j++) A[(size_t)i*nd.Nc + j] = A[(size_t)j*nd.Nc + i];
-    if(dims) { dims[0]=nd.Nc; dims[1]=nd.NE; dims[2]=nd.NEb; dims[3]=nd.Nfb; dims[4]=nd.Nie; dims[5]=nd.Nwarp; }
+    if(dims) { dims[0]=nd.Nc; dims[1]=nd.NE; dims[2]=nd.NEb; dims[3]=nd.Nfb; dims[4]=nd.S_split; dims[5]=nd.Nwarp; }
     return true;
 }
 
@@ -713,9 +713,13 @@ bool mrcal_amd_problem_gather_state(mrcal_amd_problem_t* P)
     HIP_TRY(hipStreamSynchronize(P->stream), return false);
     return true;
 }
+void mrcal_amd_problem_partition(mrcal_amd_problem_t* P, int* info)
+{
+    info[0] = P->nd.S_split; info[1] = P->nd.S_shift; info[2] = P->nd.E_state0; info[3] = P->nd.elim_extrinsics;
+}
 void mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info)
 {
-    info[0] = P->nd.Nstate; info[1] = P->nd.Nie; info[2] = P->nd.NE; info[3] = P->nd.Nc;
+    info[0] = P->nd.Nstate; info[1] = P->nd.S_split; info[2] = P->nd.NE; info[3] = P->nd.Nc;
     info[4] = P->br.frame_lo; info[5] = P->br.frame_hi; info[6] = P->is_leader ? 1 : 0;
     info[7] = P->D.Nobs_board * P->D.W * P->D.H;
     info[8] = P->nd.Nfb; info[9] = P->nd.Npb;

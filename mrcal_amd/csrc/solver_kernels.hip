@@ -109,12 +109,15 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
             // where the cameras of the 8 observations in flight sit in the camera block (uniform loads, in flight
             // together with the Gram loads below: nothing here waits for anything but the frame's range)
             int col_i[8], col_e[8];
+            int obs[8];
 #pragma unroll
             for(int u = 0; u < 8; u++)
             {
-                const int o = (ob + u < o1) ? ob + u : o0;
-                col_i[u] = plan.obs_cols[2*o]; col_e[u] = plan.obs_cols[2*o+1];
+                const int i = (ob + u < o1) ? ob + u : o0;
+                obs[u] = plan.frame_obs ? plan.frame_obs[i] : i;      // (a frame's observations are contiguous, a camera's a list)
             }
+#pragma unroll
+            for(int u = 0; u < 8; u++) { col_i[u] = plan.obs_cols[2*obs[u]]; col_e[u] = plan.obs_cols[2*obs[u]+1]; }
             // 8 Gram loads per position in flight
             for(int base = 0; base < npos; base += 2*blockDim.x)
             {
@@ -135,11 +138,7 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
                     if((rec[w] & 7) != FRAMEPOS_NONE)
                     {
 #pragma unroll
-                        for(int u = 0; u < 8; u++)
-                        {
-                            const int o = (ob + u < o1) ? ob + u : o0;
-                            vv[w][u] = gram[(size_t)o*npos + pc];
-                        }
+                        for(int u = 0; u < 8; u++) vv[w][u] = gram[(size_t)obs[u]*npos + pc];
                     }
                 }
                 // The observations in order, NO barrier between them: a destination belongs to one position -
@@ -180,13 +179,13 @@ void assemble_frame_block(const DeviceProblem& P, const NormalDims& nd, const Op
         ATS();
         for(int i = t; i < 6*nd.Nc; i += blockDim.x) Bt[(size_t)e0*nd.Nc + i] = Btf[i];
         if(t < 36)      D[(size_t)f*36 + t]     = Df[t];
-        else if(t < 42) g[nd.Nie + e0 + (t-36)] = gf[t-36];
+        else if(t < 42) g[nd.E_state0 + e0 + (t-36)] = gf[t-36];
     }
     else
     {
         for(int i = t; i < 6*nd.Nc; i += blockDim.x) Btf[i] = Bt[(size_t)e0*nd.Nc + i];
         if(t < 36)      Df[t]    = D[(size_t)f*36 + t];
-        else if(t < 42) gf[t-36] = g[nd.Nie + e0 + (t-36)];
+        else if(t < 42) gf[t-36] = g[nd.E_state0 + e0 + (t-36)];
         __syncthreads();
     }
     if(!do_factor) return;
@@ -353,7 +352,7 @@ void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const Ass
     if(!live || j != 0) return;
     const int nA = nd.Nc*nd.Nc;
     if(d < nA)              O.A[d] += acc;
-    else if(d < nA + nd.Nc) { const int sc = d - nA; O.g[(sc < nd.Nie) ? sc : nd.i_state_warp + (sc - nd.Nie)] += acc; }
+    else if(d < nA + nd.Nc) { const int sc = d - nA; O.g[S_to_state(nd, sc)] += acc; }
     else
     {
         for(int b = 0; b < plan.row_part_n; b++) acc += plan.row_part[b];
@@ -561,7 +560,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             // state index -> local column of this pass
             auto local_of = [&](int col) -> int
             {
-                if(P.do_optimize_frames && col >= nd.Nie && col < nd.Nie + nd.NE) return K + SPL_NDENSE + (col - (nd.Nie + 6*f));
+                if(P.do_optimize_frames && col >= nd.E_state0 && col < nd.E_state0 + nd.NE) return K + SPL_NDENSE + (col - (nd.E_state0 + 6*f));
                 if(m.i_state_intrinsics >= 0 && col >= m.i_state_intrinsics && col < m.i_state_intrinsics + P.Nintr_state)
                 {
                     const int rel = col - m.i_state_intrinsics;
@@ -648,7 +647,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     if(col > row || (ia == 6 && (ib < 0 || ib >= 6))) continue;
                     const double v = G[spl_tri(row) + col];
                     if(v == 0.0) continue;
-                    if(ia == 6) O.g[nd.Nie + 6*f + ib] += v;
+                    if(ia == 6) O.g[nd.E_state0 + 6*f + ib] += v;
                     else if(ib >= 0)
                     {
                         O.D[(size_t)f*36 + ia*6 + ib] += v;
@@ -708,7 +707,7 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
     for(int i = t; i < nwaves*stride; i += blockDim.x) accs[i] = 0.0;
     __syncthreads();
     const bool xrow = (r == nd.Nc);
-    const int  sr   = xrow ? -1 : ((r < nd.Nie) ? r : nd.i_state_warp + (r - nd.Nie));     // state index of the row
+    const int  sr   = xrow ? -1 : (S_to_state(nd, r));     // state index of the row
     if(wave < nwaves)
     {
         double* __restrict__ acc = accs + wave*stride;
@@ -729,7 +728,7 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                 {
                     const int K = h.wx*h.wy;
                     if(xrow) lr0 = lr1 = K + SPL_NDENSE + 6;
-                    else if(r >= nd.Nie) lr0 = lr1 = K + 10 + (r - nd.Nie);
+                    else if(r >= nd.S_split) lr0 = lr1 = K + 10 + (r - nd.S_split);       // (a warp term: the splined models keep the stationary partition)
                     else if(ise >= 0 && sr >= ise && sr < ise + 6) lr0 = lr1 = K + 4 + (sr - ise);
                     else if(isi >= 0 && sr >= isi && sr < isi + P.Nintr_state)
                     {
@@ -895,7 +894,7 @@ void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, As
         if(r == nd.Nc)
         {
             if(c == nd.Nc) O.scalars[SC_NORM2_X] += s;
-            else           O.g[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)] += s;
+            else           O.g[S_to_state(nd, c)] += s;
         }
         else if(c <= r) O.A[(size_t)r*nd.Nc + c] += s;
     }
@@ -1065,7 +1064,7 @@ void rows_generic_lds_kernel(NormalDims nd, OpRef R, int row0, int row1,
         else
         {
             const int sc = i - Nc*Nc;
-            atomicAdd(&O.g[(sc < nd.Nie) ? sc : nd.i_state_warp + (sc - nd.Nie)], v);
+            atomicAdd(&O.g[S_to_state(nd, sc)], v);
         }
     }
 }
@@ -1145,7 +1144,7 @@ void gen_eblock(const GenPlan& G, const NormalDims& nd, const OpDev& O, const in
     }
     for(int i = threadIdx.x; i < de*Nc; i += blockDim.x) O.Bt[(size_t)e0*Nc + i] = lds[i];
     if((int)threadIdx.x < 36) O.D[(size_t)blk*36 + threadIdx.x] = lD[threadIdx.x];
-    if((int)threadIdx.x < de) O.g[nd.Nie + e0 + threadIdx.x] = lg[threadIdx.x];
+    if((int)threadIdx.x < de) O.g[nd.E_state0 + e0 + threadIdx.x] = lg[threadIdx.x];
 }
 static size_t gen_lds_bytes(const GenPlan& G, const NormalDims& nd)
 {
@@ -1323,7 +1322,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
         const int c = t + nth*cc;
 #pragma unroll
         for(int i=0;i<6;i++)
-            bt[cc][i] = (i < de && c <= nd.Nc) ? ((c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.Nie + e0 + i]) : 0.0;
+            bt[cc][i] = (i < de && c <= nd.Nc) ? ((c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.E_state0 + e0 + i]) : 0.0;
     }
 
     if(t < 36) L[t] = dval + (((t/6) == (t%6)) ? lambda : 0.0);
@@ -1420,7 +1419,7 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
         double w[6];
         for(int i=0;i<de;i++)
         {
-            double v = (c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.Nie + e0 + i];
+            double v = (c < nd.Nc) ? Bt[(size_t)(e0+i)*nd.Nc + c] : g[nd.E_state0 + e0 + i];
             for(int k=0;k<i;k++) v -= L[i*6+k]*w[k];
             w[i] = v*rinv[i];
         }
@@ -1495,7 +1494,7 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
     {
         const int i = idx - nS;
         if(i < nd.Nc)
-            r[i] = (add_g ? O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] : 0.0) - acc;
+            r[i] = (add_g ? O.g[S_to_state(nd, i)] : 0.0) - acc;
     }
 }
 __global__ __launch_bounds__(256)
@@ -2998,7 +2997,7 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
     {
         // the extra block copies d_s
         for(int i=t;i<nd.Nc;i+=blockDim.x)
-            step[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = ds[i];
+            step[S_to_state(nd, i)] = ds[i];
         return;
     }
     const int blk = br.block(blockIdx.x);
@@ -3032,7 +3031,7 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
             for(int k=i+1;k<de;k++) s -= Ls[k*6+i]*v[k];
             v[i] = s/Ls[i*6+i];
         }
-        for(int i=0;i<de;i++) step[nd.Nie + e0 + i] = -v[i];
+        for(int i=0;i<de;i++) step[nd.E_state0 + e0 + i] = -v[i];
     }
 }
 
@@ -3071,7 +3070,7 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
 #pragma unroll 4
     for(int c = lane; c < nd.Nc; c += 64)
     {
-        const double vs = v[(c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie)];
+        const double vs = v[S_to_state(nd, c)];
 #pragma unroll
         for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
         {
@@ -3096,8 +3095,8 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
     {
         int    is;      // state index of this row's variable
         double wgt;
-        if(row < nd.Nc) { is = (row < nd.Nie) ? row : nd.i_state_warp + (row - nd.Nie); wgt = 1.0; }
-        else            { is = nd.Nie + (row - nd.Nc);                                  wgt = 2.0; }
+        if(row < nd.Nc) { is = S_to_state(nd, row); wgt = 1.0; }
+        else            { is = E_to_state(nd, row - nd.Nc);                              wgt = 2.0; }
         const double vr = v[is];
         double total = wgt*vr*mine;
         if(row >= nd.Nc)
@@ -3105,7 +3104,7 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
             int blk, a, de, e0;
             E_to_block(nd, row - nd.Nc, &blk, &a, &de, &e0);
             double s = 0.0;
-            for(int c=0;c<de;c++) s += O.D[(size_t)blk*36 + a*6 + c]*v[nd.Nie + e0 + c];
+            for(int c=0;c<de;c++) s += O.D[(size_t)blk*36 + a*6 + c]*v[nd.E_state0 + e0 + c];
             total += vr*s;
         }
         t_vNv = total;
@@ -3324,7 +3323,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
     for(int i = threadIdx.x; i < nd.Nc + 2; i += blockDim.x)
     {
         double v;
-        if(i < nd.Nc)       v = O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)];
+        if(i < nd.Nc)       v = O.g[S_to_state(nd, i)];
         else if(i == nd.Nc) v = O.scalars[SC_NORM2_X];
         else                v = (*status != 0) ? 1.0 : 0.0;
         tail[i] = v;
@@ -3390,7 +3389,7 @@ __device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
     if(s_unpack)
     {
         const OpDev& O = sd.ops[ip];
-        for(int i = t; i < nd.Nc; i += nt) O.g[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = tail[i];
+        for(int i = t; i < nd.Nc; i += nt) O.g[S_to_state(nd, i)] = tail[i];
     }
     return s_go != 0;
 }
@@ -3459,7 +3458,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     if(b == nbs)
     {
         for(int i = threadIdx.x; i < nd.Nc; i += blockDim.x)
-            step[(i < nd.Nie) ? i : nd.i_state_warp + (i - nd.Nie)] = ds[i];
+            step[S_to_state(nd, i)] = ds[i];
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3472,7 +3471,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     // (unconditional, clamped: three loads under conditions were three branches with a wait each)
     const double Lv = LD[(size_t)blk*36 + min(lane, 35)];
     const double yv = y[e0 + min(lane, de - 1)];
-    const double gv = O.g[nd.Nie + e0 + min(lane, de - 1)];
+    const double gv = O.g[nd.E_state0 + e0 + min(lane, de - 1)];
     double part[6] = {0,0,0,0,0,0};
     // (four column groups asked for together: with a 1206-variable camera block the loop is 19 round trips otherwise)
 #pragma unroll 4
@@ -3512,7 +3511,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
             if(i < de)
             {
                 const double d = -v[i];
-                step[nd.Nie + e0 + i] = d;
+                step[nd.E_state0 + e0 + i] = d;
                 d2 += d*d; dg += d*ge[i];
             }
         dots_part[2*ibk] = d2; dots_part[2*ibk + 1] = dg;
@@ -3594,7 +3593,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
     const int row0 = by_rows ? 0 : 2*P.W*P.H*P.Nobs_board;
     if(P.Nobs_board > 0 && !by_rows)
     {
-        const int nframe_blocks = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
+        const int nframe_blocks = br.frame_hi - br.frame_lo;        // (the 6x6 eliminated blocks: frames, or cameras)
         FactorBuffers none; memset(&none, 0, sizeof(none));
         hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
@@ -3880,10 +3879,11 @@ void mask_state_kernel(NormalDims nd, BlockRanges br, int is_leader, double* __r
     const int i = blockIdx.x*blockDim.x + threadIdx.x;
     if(i >= nd.Nstate) return;
     bool mine;
-    if(i < nd.Nie || i >= nd.Nie + nd.NE) mine = is_leader != 0;        // the camera block
+    const int se = state_to_SE(nd, i);
+    if(se >= 0) mine = is_leader != 0;        // the camera block
     else
     {
-        const int e = i - nd.Nie;
+        const int e = -se - 1;
         int lo, hi, lo2, hi2;
         br.e_range(nd, 0, &lo, &hi);
         br.e_range(nd, 1, &lo2, &hi2);
@@ -3934,7 +3934,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     if(P.Nobs_board > 0 && !by_rows)
     {
         const int row0 = 2*P.W*P.H*P.Nobs_board;
-        nframes_fused = P.do_optimize_frames ? (br.frame_hi - br.frame_lo) : 0;
+        nframes_fused = br.frame_hi - br.frame_lo;
         hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, *a.plan)), dim3(256),
                            assemble_lds_bytes(nd), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
                            &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, assemble_row0(P, *a.plan), P.Nmeas, a.Jp, a.Ji);
@@ -4054,10 +4054,10 @@ namespace mrcal_amd {
 //                                                                 L_S = chol(S)               (F.S, lower)
 // "factor order" = the order of P: [ E (frames, then points) | S (intrinsics, extrinsics, warp) ].
 // order 0: vectors in state order; 1: in factor order.
-__device__ __forceinline__ int fs_index_E(const NormalDims& nd, int order, int e) { return order ? e : nd.Nie + e; }
+__device__ __forceinline__ int fs_index_E(const NormalDims& nd, int order, int e) { return order ? e : E_to_state(nd, e); }
 __device__ __forceinline__ int fs_index_S(const NormalDims& nd, int order, int c)
 {
-    return order ? nd.NE + c : ((c < nd.Nie) ? c : nd.i_state_warp + (c - nd.Nie));
+    return order ? nd.NE + c : (S_to_state(nd, c));
 }
 
 // y_e = L_e^-1 b_e, one thread per E block

@@ -7,20 +7,40 @@
 
 namespace mrcal_amd {
 
-// partition of the state into the dense shared block S and the block-diagonal
-// eliminated set E (see solver_kernels.hip)
+// Partition of the state into the dense shared block S and the block-diagonal
+// eliminated set E (see solver_kernels.hip). Which blocks are eliminated is a
+// property of the problem: the numerous, mutually independent
+// ones. Stationary cameras and a moving board (or points): the frames and
+// points are eliminated, S = intrinsics + extrinsics + warp. A moving camera
+// and a stationary board (many rt_cam_ref, few frames): the extrinsics are
+// eliminated, S = intrinsics + frames + points + warp (elim_extrinsics). The
+// state vector keeps the reference's order either way:
+//   [intrinsics | extrinsics | frames | points | warp]
+// and S, E are index ranges of it:
+//   S index s  ->  state s            for s <  S_split
+//                  state s + S_shift  for s >= S_split
+//   E index e  ->  state E_state0 + e
 struct NormalDims
 {
     int Nstate;
-    int Nie;          // intrinsics + extrinsics state variables: S indices [0,Nie) == state indices
-    int Nwarp;        // 0 or 2: S indices [Nie, Nie+Nwarp)
+    int Nwarp;        // 0 or 2: the last S indices
     int i_state_warp;
-    int Nc;           // Nie + Nwarp
-    int NE;           // frame + point state variables; E index e == state index Nie + e
-    int Nfb;          // frame blocks (6x6)
-    int Npb;          // point blocks (3x3)
+    int Nc;           // size of S
+    int NE;           // size of E
+    int Nfb;          // 6x6 blocks of E (frames, or extrinsics), first in E
+    int Npb;          // 3x3 blocks of E (points), after them
     int NEb;          // Nfb + Npb
+    int S_split, S_shift, E_state0;
+    int elim_extrinsics;
 };
+__host__ __device__ inline int S_to_state(const NormalDims& nd, int s) { return (s < nd.S_split) ? s : s + nd.S_shift; }
+__host__ __device__ inline int E_to_state(const NormalDims& nd, int e) { return nd.E_state0 + e; }
+// the stationary-camera partition over a state [shared Nshared | E (NE) | warp (Nwarp)]
+__host__ __device__ inline void normal_dims_set_partition(NormalDims& nd, int Nshared_leading)
+{
+    nd.S_split = Nshared_leading; nd.S_shift = nd.i_state_warp - Nshared_leading; nd.E_state0 = Nshared_leading;
+    nd.elim_extrinsics = 0;
+}
 
 // The E blocks a shard owns: a contiguous range of frame blocks plus (on the
 // shard leader) all the point blocks
@@ -148,7 +168,8 @@ struct GenPlan
 struct AssemblyPlan
 {
     GenPlan gen;
-    int* frame_obs_begin;  // [Nframes+1]
+    int* frame_obs_begin;  // [blocks+1] the board observations of each 6x6 eliminated block (a frame: contiguous) ...
+    int* frame_obs;        // ... or, if not NULL, entries [begin, end) of this list (a camera's, with elim_extrinsics)
     int* chunk_begin;      // [Nchunks+1]
     int* pair_obs;         // [Nobs_board] observation indices grouped by (intrinsics, extrinsics) pair
     int* chunk_pair;       // [Nchunks] the pair of each chunk
@@ -162,7 +183,8 @@ struct AssemblyPlan
     // pair only through WHERE the camera's intrinsics and extrinsics sit in the camera block.
     //   frame_pos[pos]   FRAMEPOS_* kind | a << 3 | k << 6  (a: frame variable; k: second frame variable, or the
     //                    offset within the camera's intrinsics / extrinsics, or the S index of a warp term)
-    //   obs_cols[o][2]   S index of the first intrinsic / first extrinsic of observation o's camera (-1: none)
+    //   obs_cols[o][2]   S index of the first intrinsic of observation o's camera / of the first variable of its
+    //                    pose in the camera block (the camera's extrinsics; the frame with elim_extrinsics); -1: none
     int*    frame_pos;     // [gram_stride]
     int*    obs_cols;      // [Nobs_board][2]
     // Fixed-order reduction of the camera-block part (no atomics: the sums do
@@ -191,11 +213,11 @@ struct AssemblyPlan
 // state index -> S index (>=0) or -(1 + E index)
 __host__ __device__ inline int state_to_SE(const NormalDims& nd, int col)
 {
-    if(col < nd.Nie) return col;
-    if(nd.Nwarp && col >= nd.i_state_warp) return nd.Nie + (col - nd.i_state_warp);
-    return -(1 + (col - nd.Nie));
+    if(col >= nd.E_state0 && col < nd.E_state0 + nd.NE) return -(1 + (col - nd.E_state0));
+    return (col < nd.S_split) ? col : col - nd.S_shift;
 }
 // What a column of the board kernel's tile (problem.hpp) is, for one observation
+// (COL_FRAME: a variable of the observation's ELIMINATED pose - its frame, or with elim_extrinsics its camera)
 enum { COL_ABSENT = 0, COL_S, COL_FRAME, COL_X };
 struct TileColInfo { int kind; int idx; };   // COL_S: state index; COL_FRAME: 0..5
 __host__ __device__ inline
@@ -213,11 +235,19 @@ TileColInfo board_tile_col_info(const DeviceProblem& P, const BoardObsMeta& m, i
     }
     else if(col < tile_frame0(nd))
     {
-        if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0) { r.kind = COL_S; r.idx = m.i_state_extrinsics + (col - tile_ext0(nd)); }
+        if(P.do_optimize_extrinsics && m.icam_extrinsics >= 0)
+        {
+            if(P.elim_extrinsics) { r.kind = COL_FRAME; r.idx = col - tile_ext0(nd); }
+            else                  { r.kind = COL_S;     r.idx = m.i_state_extrinsics + (col - tile_ext0(nd)); }
+        }
     }
     else if(col < tile_warp0(nd))
     {
-        if(P.do_optimize_frames) { r.kind = COL_FRAME; r.idx = col - tile_frame0(nd); }
+        if(P.do_optimize_frames)
+        {
+            if(P.elim_extrinsics) { r.kind = COL_S;     r.idx = m.i_state_frame + (col - tile_frame0(nd)); }
+            else                  { r.kind = COL_FRAME; r.idx = col - tile_frame0(nd); }
+        }
     }
     else if(col < tile_xcol(nd))
     {

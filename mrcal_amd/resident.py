@@ -187,7 +187,16 @@ class Problem:
         n2 = np.zeros((1,))
         self._check(self._lib.mrcal_amd_problem_get_normal_equations(self.handle, _ptr(A), _ptr(Bt), _ptr(D), _ptr(g), _ptr(n2), dims),
                     "get_normal_equations")
-        return dict(A=A, Bt=Bt, D=D, g=g, norm2_x=n2[0], Nc=Nc, NE=NE, NEb=NEb, Nfb=Nfb, Nie=Nie, Nwarp=Nwarp)
+        return dict(A=A, Bt=Bt, D=D, g=g, norm2_x=n2[0], Nc=Nc, NE=NE, NEb=NEb, Nfb=Nfb, Nie=Nie, Nwarp=Nwarp, **self.partition())
+
+    def partition(self):
+        """dict(S_split, S_shift, E_state0, eliminates): S index s is state s (s < S_split) or s + S_shift, E index
+        e is state E_state0 + e; eliminates is 'frames' or 'extrinsics' (include/mrcal_amd.h)"""
+        info = (C.c_int*4)()
+        f = self._lib.mrcal_amd_problem_partition
+        f.restype, f.argtypes = None, [C.c_void_p, C.POINTER(C.c_int)]
+        f(self.handle, info)
+        return dict(S_split=info[0], S_shift=info[1], E_state0=info[2], eliminates="extrinsics" if info[3] else "frames")
 
     def drt_cross_reprojection__dbpacked(self, icam_intrinsics=-1):
         """K (6,Nstate) of mrcal.drt_cross_reprojection__dbpacked() from the RESIDENT Jacobian at the current

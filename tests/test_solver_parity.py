@@ -26,18 +26,21 @@ def dense_normal(J, x):
 
 
 def blocks_to_dense(ne, Nstate):
-    """reassembles the solver's block form into the dense (Nstate,Nstate) JtJ"""
-    Nie, Nc, NE, Nfb = ne["Nie"], ne["Nc"], ne["NE"], ne["Nfb"]
-    sidx = np.concatenate((np.arange(Nie), np.arange(Nie+NE, Nie+NE+ne["Nwarp"]))).astype(int)
+    """reassembles the solver's block form into the dense (Nstate,Nstate) JtJ: S index s is state s below
+    S_split and s + S_shift from there on, E index e is state E_state0 + e (Problem.partition())"""
+    Nc, NE, Nfb = ne["Nc"], ne["NE"], ne["Nfb"]
+    s = np.arange(Nc)
+    sidx = np.where(s < ne["S_split"], s, s + ne["S_shift"]).astype(int)
+    E0 = ne["E_state0"]
     N = np.zeros((Nstate, Nstate))
     N[np.ix_(sidx, sidx)] = ne["A"]
     for e in range(NE):
-        N[Nie+e, sidx] = ne["Bt"][e]
-        N[sidx, Nie+e] = ne["Bt"][e]
+        N[E0+e, sidx] = ne["Bt"][e]
+        N[sidx, E0+e] = ne["Bt"][e]
     for b in range(ne["NEb"]):
         if b < Nfb: e0, de = 6*b, 6
         else:       e0, de = 6*Nfb + 3*(b-Nfb), 3
-        N[Nie+e0:Nie+e0+de, Nie+e0:Nie+e0+de] = ne["D"][b,:de,:de]
+        N[E0+e0:E0+e0+de, E0+e0:E0+e0+de] = ne["D"][b,:de,:de]
     return N
 
 

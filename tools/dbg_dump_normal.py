@@ -7,6 +7,11 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, "tests")
 import mrcal_amd
 from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
 from mrcal_amd.resident import Problem
+_partition = Problem.partition
+def _tolerant(self):
+    try: return _partition(self)
+    except AttributeError: return {}          # (a build from before the partition query)
+Problem.partition = _tolerant
 out = {}
 for name, kw in (("c3", dict(Ncameras=3, Nframes=11, lensmodel="LENSMODEL_OPENCV8")), ("c1", dict(Ncameras=1, Nframes=30, lensmodel="LENSMODEL_OPENCV8")),
                  ("c4", dict(Ncameras=4, Nframes=200, lensmodel="LENSMODEL_OPENCV4"))):
