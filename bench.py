@@ -94,6 +94,13 @@ def cpu_baseline(oi, Niterations):
                        "the reference with the real CHOLMOD is [value, value_upper_bound_callback_only]")
 
 
+# MRCAL_AMD_BENCH_ONE_DEVICE=1: every rank on device 0, the solve's collectives staged through host shared memory
+# (mrcal_amd_comm_create_host) instead of RCCL, which refuses two ranks per device. For checking THIS SCRIPT's
+# multi-rank path - the launcher, the barriers, the max over ranks, rank 0's line - on a one-GPU box
+# (tests/test_parallel_gpu.py); the line it prints says so and is not a measurement
+ONE_DEVICE = os.environ.get("MRCAL_AMD_BENCH_ONE_DEVICE") == "1"
+
+
 def spawn_ranks(ngpus):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, the way
     the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`
@@ -101,7 +108,7 @@ def spawn_ranks(ngpus):
     import socket
     import subprocess
     import torch
-    if torch.cuda.device_count() < ngpus:
+    if torch.cuda.device_count() < ngpus and not ONE_DEVICE:
         print(f"bench.py: --gpus {ngpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -129,7 +136,7 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if ONE_DEVICE else local_rank)
     sharded = world > 1 or args.sharded
     if sharded:
         # torch.distributed is only the side channel of the start-up (the 128-byte
@@ -152,7 +159,7 @@ def main():
 
     if sharded:
         from mrcal_amd.parallel import ShardedProblem
-        problem = ShardedProblem(**oi)
+        problem = ShardedProblem(_driver="host" if ONE_DEVICE else "rccl", **oi)
         barrier = lambda: (dist.barrier(), torch.cuda.synchronize())
     else:
         from mrcal_amd.resident import Problem
@@ -256,7 +263,7 @@ def main():
         config  = dict(workload = workload,
                        Nstate = problem.Nstate_global, Nmeasurements = problem.Nmeas_global,
                        Nnz_J = problem.Nnz_global,
-                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), one process per GPU, 2 RCCL all-reduces per trial step: [S|r|g_S||x|^2] ({problem.problem.Nstate} state variables: Nc^2+2Nc+2 doubles) and 4 scalars"),
+                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), one process per GPU, 2 {"host-staged (validation)" if ONE_DEVICE else "RCCL"} all-reduces per trial step: [S|r|g_S||x|^2] ({problem.problem.Nstate} state variables: Nc^2+2Nc+2 doubles) and 4 scalars"),
         roofline = dict(bound = "hbm",
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
@@ -273,6 +280,8 @@ def main():
                       **({"collectives": st["Ncollectives"]} if sharded else {})),
     )
 
+    if ONE_DEVICE:
+        result["transport"] = "host shared memory, all ranks on ONE device (MRCAL_AMD_BENCH_ONE_DEVICE=1): a check of the multi-rank path, NOT a measurement"
     if rank == 0 and not args.no_full_solve and not sharded:
         # the second half of the metric: one full solve, seed to return,
         # outlier rejection included, on a fresh copy

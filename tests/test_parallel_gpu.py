@@ -490,3 +490,24 @@ def test_cpp_sharded_solve_over_the_host_transport(amd, tmp_path, which, world):
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
     assert np.abs(r["b"] - b1).max() < (1e-3 if which == "boards_splined" else 2e-5)
     assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
+
+
+@pytest.mark.parametrize("world", (2, 4))
+def test_bench_multi_rank_path_on_one_device(world):
+    """bench.py --gpus N end to end at N > 1 on a one-GPU box: it starts its own ranks (torch.distributed.run on
+    127.0.0.1), every rank builds its shard, the timed region is bracketed by the barriers, the wall clock is the
+    max over the ranks and rank 0 prints the one line - with MRCAL_AMD_BENCH_ONE_DEVICE=1, which puts the ranks on
+    device 0 and the solve's collectives on the host transport (the line says so; it is not a measurement)"""
+    import json, subprocess
+    env = dict(os.environ, MRCAL_AMD_BENCH_ONE_DEVICE="1", MRCAL_AMD_HOST_COMM_TIMEOUT="120")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"): env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+                        "--cameras", "3", "--frames", "40"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["steps"] == 6 and d["warmup"] == 2
+    assert d["value"] > 0 and abs(d["value"] - 1e3/d["ms_per_step"]) < 1e-6*d["value"]
+    assert d["scaling"] == "strong" and d["unit"] == "iterations/s" and "NOT a measurement" in d["transport"]
+    assert d["solver"]["collectives"] >= 2*d["solver"]["evaluations"]
+    assert d["roofline"]["launches_timed"] > 0 and d["cpu_baseline"] is None
