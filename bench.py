@@ -263,7 +263,7 @@ def main():
         config  = dict(workload = workload,
                        Nstate = problem.Nstate_global, Nmeasurements = problem.Nmeas_global,
                        Nnz_J = problem.Nnz_global,
-                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), one process per GPU, 2 {"host-staged (validation)" if ONE_DEVICE else "RCCL"} all-reduces per trial step: [S|r|g_S||x|^2] ({problem.problem.Nstate} state variables: Nc^2+2Nc+2 doubles) and 4 scalars"),
+                       parallelism = "single GPU" if not sharded else f"frames sharded over {world} GPU(s), one process per GPU, 2 {'host-staged (validation)' if ONE_DEVICE else 'RCCL'} all-reduces per trial step: [S|r|g_S||x|^2] ({problem.problem.Nstate} state variables: Nc^2+2Nc+2 doubles) and 4 scalars"),
         roofline = dict(bound = "hbm",
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
