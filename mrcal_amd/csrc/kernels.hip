@@ -189,11 +189,11 @@ void regularization_row(const DeviceProblem& P, const OpRef& R,
     regularization_row_at<WITH_J,WITH_STRUCTURE>(P, b, opref_get(R).x, opref_get(R).Jv, rowptr, colidx, i);
 }
 
-#define PROLOGUE_ZERO_BLOCKS 1024
-// Workgroups, in order: [pose records, 64 observations each] [unpacking of the
+#define PROLOGUE_ZERO_BLOCKS (1024*64/PRO_T)
+// Workgroups (PRO_T threads), in order: [pose records, an observation per thread] [unpacking of the
 // intrinsics and the warp] [clearing of the normal equations, if asked for]
-// [regularization rows, 64 each: reg_mode 0 = x only, 1 = x and J, -1 = none]
-// [CHOOSE: the dog-leg step, 64 state variables each].
+// [regularization rows, one per thread: reg_mode 0 = x only, 1 = x and J, -1 = none]
+// [CHOOSE: the dog-leg step, a state variable per thread].
 // Only the first kind is long; the others are independent of it and of each
 // other and ride along instead of costing launches of their own.
 // CHOOSE (the solver's trial step): the launch also CHOOSES the trial point it evaluates (dogleg_choose.hpp) -
@@ -207,10 +207,10 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
                          int nblocks_unpack, int nblocks_zero, int reg_mode)
 {
     double* __restrict__ joint = B.joint;
-    const int nblocks_obs = (P.Nobs_board + 63)/64;
+    const int nblocks_obs = (P.Nobs_board + PRO_T - 1)/PRO_T;
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack + nblocks_zero)
     {
-        const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*64 + threadIdx.x;
+        const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*PRO_T + threadIdx.x;
         if(reg_mode == 1)      regularization_row_at<true, false>(P, b, O.x, O.Jv, (int32_t*)NULL, (int32_t*)NULL, i);
         else if(reg_mode == 0) regularization_row_at<false,false>(P, b, O.x, O.Jv, (int32_t*)NULL, (int32_t*)NULL, i);
         return;
@@ -223,7 +223,7 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
     {
         const long long nz = nblocks_zero;
-        for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*64 + threadIdx.x; i < B.zero_total; i += nz*64)
+        for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*PRO_T + threadIdx.x; i < B.zero_total; i += nz*PRO_T)
         {
             long long j = i;
             if(j < B.zero_n[0]) { O.A[j] = 0.0; continue; }        j -= B.zero_n[0];
@@ -271,7 +271,7 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     for(int i=0;i<JOINT_STRIDE;i++) out[i] = rec[i];
 }
 template<bool CHOOSE>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(PRO_T)
 void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode,
                            int nblocks_reg, ChooseArgs ca)
 {
@@ -280,10 +280,10 @@ void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, i
     {
         __shared__ double scratch[17*7];
         const ChooseOut c = dogleg_choose_scalars(ca, scratch);
-        const int first = (P.Nobs_board + 63)/64 + nblocks_unpack + nblocks_zero + nblocks_reg;
+        const int first = (P.Nobs_board + PRO_T - 1)/PRO_T + nblocks_unpack + nblocks_zero + nblocks_reg;
         if((int)blockIdx.x >= first)
         {
-            dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*64 + threadIdx.x);
+            dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*PRO_T + threadIdx.x);
             if((int)blockIdx.x == first && threadIdx.x == 0) dogleg_choose_record(ca, c);
             return;
         }
@@ -1682,12 +1682,12 @@ static void launch_prologue(const DeviceProblem& P, const EvalBuffers& B, int nb
     const int n = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg;
     if(B.choose != NULL)
     {
-        const int nblocks_choose = (B.choose->nd.Nstate + 63)/64;
-        hipLaunchKernelGGL(board_prologue_kernel<true>, dim3(n + nblocks_choose), dim3(64), 0, stream,
+        const int nblocks_choose = (B.choose->nd.Nstate + PRO_T - 1)/PRO_T;
+        hipLaunchKernelGGL(board_prologue_kernel<true>, dim3(n + nblocks_choose), dim3(PRO_T), 0, stream,
                            P, B, nblocks_unpack, nblocks_zero, reg_mode, nblocks_reg, *B.choose);
     }
     else
-        hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(n), dim3(64), 0, stream,
+        hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(n), dim3(PRO_T), 0, stream,
                            P, B, nblocks_unpack, nblocks_zero, reg_mode, nblocks_reg, ChooseArgs());
 }
 static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
@@ -1695,11 +1695,11 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
 {
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
-        const int nblocks_obs    = (P.Nobs_board + 63)/64;
-        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
+        const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
+        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
         const int Nreg_rows      = 0;      // the splined regularization has its own kernel
-        const int nblocks_reg    = (Nreg_rows + 63)/64;
+        const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
         launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
@@ -1719,8 +1719,8 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
         {
             EvalBuffers Bu = B;
             Bu.zero_total = 0;
-            const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
-            hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(nblocks_unpack), dim3(64), 0, stream, P, Bu, nblocks_unpack, 0, -1, 0, ChooseArgs());
+            const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
+            hipLaunchKernelGGL(board_prologue_kernel<false>, dim3(nblocks_unpack), dim3(PRO_T), 0, stream, P, Bu, nblocks_unpack, 0, -1, 0, ChooseArgs());
         }
         if(with_jacobian)
             hipLaunchKernelGGL((point_splined_kernel<true>),  dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream, P, B.R, B.Ji);
@@ -2161,11 +2161,11 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
 {
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
-        const int nblocks_obs    = (P.Nobs_board + 63)/64;
-        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + 63)/64;
+        const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
+        const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
         const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
         const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
-        const int nblocks_reg    = (Nreg_rows + 63)/64;
+        const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
         launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);
     }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))

@@ -40,7 +40,15 @@ struct OpRef
 __device__ __forceinline__ bool opref_skip(const OpRef& r) { return r.skip != NULL && *r.skip != 0; }
 __device__ __forceinline__ const OpDev& opref_get(const OpRef& r) { return r.ops[r.sel ? *r.sel : 0]; }
 
-struct ChooseArgs;      // dogleg_choose.hpp
+struct ChooseArgs;
+// threads of a workgroup of the prologue launch and of the stand-alone choice of the trial point: the SAME number,
+// since every workgroup of either sums the dog-leg scalars over the state with its threads, in an order that
+// their number fixes - and every rank of a sharded solve, with or without boards in its shard, must get the same bits
+// (64, one wave. 256 - a quarter of the trips of the scalars' reduction - was measured: the launch 21.0 us instead
+//  of 17.5 at the metric's size; the pose records' long dependent chains want their waves spread over all CUs)
+#ifndef PRO_T
+#define PRO_T 64
+#endif      // dogleg_choose.hpp
 // what one evaluation reads and writes
 struct EvalBuffers
 {

@@ -3289,7 +3289,7 @@ __device__ __forceinline__ void ctl_accept(const OpDev* __restrict__ ops, Solver
 //   sharded. NULL: single GPU, the partial sums are read where they were left.
 // The dog-leg step from the current point: dogleg_choose.hpp. As a launch of its own where the evaluation that
 // follows has no prologue launch to carry it (problems without boards, the splined models, the protocol driver)
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(PRO_T)
 void step2_choose_kernel(ChooseArgs a)
 {
     __shared__ double scratch[17*7];
@@ -3914,7 +3914,7 @@ hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream)
     const NormalDims& nd = *a.nd;
     // (workgroups of 64, like the prologue's when the choice rides there: the fixed-order sums depend on the
     //  workgroup size, and the ranks of a sharded solve - with or without boards in their shard - must get the same bits)
-    hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + 63)/64), dim3(64), 0, stream, step2_choose_args(a));
+    hipLaunchKernelGGL(step2_choose_kernel, dim3((nd.Nstate + PRO_T - 1)/PRO_T), dim3(PRO_T), 0, stream, step2_choose_args(a));
     return hipGetLastError();
 }
 
