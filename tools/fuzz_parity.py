@@ -55,8 +55,14 @@ for icase in range(N):
         # the solve: only where the problem is well posed enough for two solvers to be expected at the same point:
         # enough data per unknown, the distortions regularized, no discrete points at made-up pixels (a point seen once
         # has no depth: a singular 3x3 block; seen twice at random pixels it sits wherever its rays happen to pass)
+        # ... and at least three board measurements per unknown (eight for a splined surface, whose knots away from
+        # the boards no measurement sees): a splined surface of 88 knots fitted to five small
+        # boards is held by its regularization alone, and where two dog-leg implementations run out of iterations
+        # on that plateau says nothing about either (such cases: callback only)
+        Nstate = mrcal_amd.num_states(**oi)
         well_posed = (not with_points) and W*H >= 30 and Nf >= 5 and \
-                     (sel["do_apply_regularization"] or not sel["do_optimize_intrinsics_distortions"])
+                     (sel["do_apply_regularization"] or not sel["do_optimize_intrinsics_distortions"]) and \
+                     oi["observations_board"].size//3*2 >= (8 if splined else 3)*Nstate
         if not well_posed:
             print(what, "ok (callback only)", flush=True)
             continue
