@@ -406,9 +406,13 @@ def test_world2_points_and_pairs(amd, tmp_path):
 
 
 # ---- the C++ sharded solve at world > 1 on one device: collectives staged through the host (csrc/comm.cpp) ----
-HOST_CASES = ("boards", "boards_splined", "everything", "fewer_frames_than_ranks")
+HOST_CASES = ("boards", "boards_splined", "everything", "fewer_frames_than_ranks", "metric_size")
 def _host_case(api, which):
     from mrcal_amd.synthetic import make_calibration_problem
+    if which == "metric_size":
+        # the benchmark's own problem: 8 cameras x 1000 frames OPENCV8 (bench.py)
+        return make_calibration_problem(api, Ncameras=8, Nframes=1000, lensmodel="LENSMODEL_OPENCV8",
+                                        object_width_n=10, object_height_n=10, seed=0)[0]
     if which == "boards":         oi = _problem(api)
     if which == "boards_splined": oi = _problem(api, SPLINED)
     if which == "everything":
@@ -458,7 +462,7 @@ def _host_worker(rank, world, port, out_path, which):
 
 
 @pytest.mark.parametrize("which,world", (("boards", 2), ("boards_splined", 2), ("everything", 2), ("everything", 3),
-                                         ("fewer_frames_than_ranks", 3)))
+                                         ("fewer_frames_than_ranks", 3), ("metric_size", 8)))
 def test_cpp_sharded_solve_over_the_host_transport(amd, tmp_path, which, world):
     """The PRODUCT solver with more than one rank on a one-GPU box: ShardedProblem(_driver="host") is the C++
     sharded solve - the device-controlled step with its two all-reduces, mark_outliers() with its three, the
@@ -488,7 +492,9 @@ def test_cpp_sharded_solve_over_the_host_transport(amd, tmp_path, which, world):
         assert s1["Noutliers_board"] > 0
     assert int(r["Noutliers"]) == s1["Noutliers_board"]
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
-    assert np.abs(r["b"] - b1).max() < (1e-3 if which == "boards_splined" else 2e-5)
+    # (the metric's problem: 7843 outliers out of 800 000 corners, the same ones; the state to what two summation
+    #  orders leave of it after 150 iterations)
+    assert np.abs(r["b"] - b1).max() < (1e-3 if which == "boards_splined" else 1e-4 if which == "metric_size" else 2e-5)
     assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
 
 
