@@ -461,6 +461,21 @@ __device__ __forceinline__ void gram_step_ops(double (&acc)[NM], const GramRd& r
     gram_mfmas<NBLK>(acc, op, std::make_integer_sequence<int, NM>{});
 }
 
+// a's lanes 32..63 and b's lanes 0..31 trade places (a[32+i] <-> b[i]): v_permlane32_swap_b32 on both halves of the
+// doubles (measured semantics: tools/exp/permlane32_swap_probe.hip)
+__device__ __forceinline__ void permlane32_swap_f64(double& a, double& b)
+{
+    union { double d; unsigned u[2]; } ua, ub;
+    ua.d = a; ub.d = b;
+#pragma unroll
+    for(int i = 0; i < 2; i++)
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(ua.u[i], ub.u[i], false, false);
+        ua.u[i] = r[0]; ub.u[i] = r[1];
+    }
+    a = ua.d; b = ub.d;
+}
+
 // ---- explicit DS instructions and waits for the fused Gram + copy-out path
 template<int OFF>
 __device__ __forceinline__ double lds_read_b64_at(unsigned lds_byte_address)
@@ -935,7 +950,17 @@ void board_kernel(DeviceProblem P,
         if(!WITH_J) continue;
         TSACC(2, tcur);     // projection + rows
 
-        // the two halves of the pass go through the tile one after the other
+        // The two halves of the pass (its first and its second 32 corners) go through the 64-row tile one after
+        // the other. All 64 lanes write each of them, one row each: lanes 0..31 the x rows of the half's corners,
+        // lanes 32..63 their y rows. (32 lanes writing both rows of their own corners took twice the ds_write
+        // instructions, each moving half a wave's worth: a ds_write_b64 costs the VGPR->LDS path its 6 clocks
+        // whatever the number of lanes under exec, and the tile writes are on this kernel's critical path where
+        // the arithmetic is not - profiles/r03_board_kernel_ablation.txt.) For that the y rows of the first 32
+        // corners (lanes 0..31) and the x rows of the last 32 (lanes 32..63) trade places: v_permlane32_swap
+        // (gfx950) exchanges the upper half of one register with the lower half of another, two per double.
+        // After it slot 0 of a lane holds its row of the first half, slot 1 its row of the second
+#pragma unroll
+        for(int c=0;c<NCOLS4;c++) permlane32_swap_f64(row[0][c], row[1][c]);
         for(int h = 0; h < 2; h++)
         {
             const int nc    = NPTS - pt0 - 32*h;          // corners in this half
@@ -944,14 +969,17 @@ void board_kernel(DeviceProblem P,
 
             // WAR: the previous half's tile reads are complete (in-order LDS)
             __builtin_amdgcn_wave_barrier();
-            if((lane >> 5) == h)
             {
-                double* __restrict__ t0 = tile + (size_t)(2*(lane & 31))*KS;
-#pragma unroll
-                for(int c=0;c<NCOLS4;c++)
+                double* __restrict__ t0 = tile + (size_t)(2*(lane & 31) + (lane >> 5))*KS;
+                if(h == 0)
                 {
-                    t0[c]      = row[0][c];
-                    t0[KS + c] = row[1][c];
+#pragma unroll
+                    for(int c=0;c<NCOLS4;c++) t0[c] = row[0][c];
+                }
+                else
+                {
+#pragma unroll
+                    for(int c=0;c<NCOLS4;c++) t0[c] = row[1][c];
                 }
             }
             __builtin_amdgcn_wave_barrier();
