@@ -958,7 +958,12 @@ void board_kernel(DeviceProblem P,
         // the arithmetic is not - profiles/r03_board_kernel_ablation.txt.) For that the y rows of the first 32
         // corners (lanes 0..31) and the x rows of the last 32 (lanes 32..63) trade places: v_permlane32_swap
         // (gfx950) exchanges the upper half of one register with the lower half of another, two per double.
-        // After it slot 0 of a lane holds its row of the first half, slot 1 its row of the second
+        // After it slot 0 of a lane holds its row of the first half, slot 1 its row of the second.
+        // (A 16-lane group now writes every second tile row, two lanes to a bank: SQ_LDS_BANK_CONFLICT went up by 220
+        //  per observation while the instructions halved. The conflict-free variant - lanes 0..7 of each 16-lane row
+        //  on the first half's corners, lanes 8..15 on the second's, a DPP rotation by 8 and two selects per value,
+        //  16 consecutive rows per group - was built: same bits, 74.8 us against 73.5. It is the instruction count
+        //  on the VGPR->LDS path that matters, not the conflicts)
 #pragma unroll
         for(int c=0;c<NCOLS4;c++) permlane32_swap_f64(row[0][c], row[1][c]);
         for(int h = 0; h < 2; h++)
