@@ -1379,6 +1379,8 @@ void regularization_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowpt
 // by observation: assemble_splined_kernel, solver_kernels.hip). One lane per
 // chessboard corner, rows written directly.
 // Reference: mrcal.c:2075-2293 (projection), 4734-4760 (row layout)
+// row stride of the staging tile of board_splined_kernel (doubles; entries per row <= 2 + 16 + 6 + 6 + 2): odd
+#define SPLB_KT 33
 template<bool WITH_J>
 __global__ __launch_bounds__(64)
 void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ joint,
@@ -1388,8 +1390,12 @@ void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ j
     double* __restrict__ x  = opref_get(R).x;
     double* __restrict__ Jv = opref_get(R).Jv;
     const int NPTS = P.W*P.H;
-    const int gi   = blockIdx.x*blockDim.x + threadIdx.x;
-    if(gi >= P.Nobs_board*NPTS) return;
+    const int lane = threadIdx.x;
+    // (the lanes past the last corner take part in the cooperative copy-out below: they repeat the last corner's
+    //  arithmetic and store nothing)
+    const int  gi_   = blockIdx.x*blockDim.x + threadIdx.x;
+    const bool valid = gi_ < P.Nobs_board*NPTS;
+    const int  gi    = valid ? gi_ : P.Nobs_board*NPTS - 1;
     const int iobs = gi / NPTS;
     const int pt   = gi - iobs*NPTS;
     const BoardObsMeta m = P.board_meta[iobs];
@@ -1424,16 +1430,38 @@ void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ j
     const double* __restrict__ obs = P.board_pool + ((size_t)iobs*NPTS + pt)*3;
     const double w = obs[2];
     const bool inlier = (w >= 0.0);
-    x[m.i_meas0 + 2*pt + 0] = inlier ? (q[0] - obs[0])*w : 0.0;
-    x[m.i_meas0 + 2*pt + 1] = inlier ? (q[1] - obs[1])*w : 0.0;
+    if(valid)
+    {
+        x[m.i_meas0 + 2*pt + 0] = inlier ? (q[0] - obs[0])*w : 0.0;
+        x[m.i_meas0 + 2*pt + 1] = inlier ? (q[1] - obs[1])*w : 0.0;
+    }
     if(!WITH_J) return;
+
+    // The rows go through LDS, 32 corners (64 rows) at a time, and leave as ONE contiguous stream: the rows of
+    // consecutive corners - and of consecutive observations with the same number of entries per row - are adjacent
+    // in the CSR arrays. (A lane storing its own rows, as this kernel did, is 64 eight-byte segments 250 bytes
+    // apart per instruction: 62 us for 46 MB at BASELINE configuration 2.) Tile: the x rows of the 32 corners in
+    // rows 0..31, their y rows in rows 32..63 (an odd row stride and one row per lane and pass of the loop below:
+    // no bank conflicts); the values first, the column indices behind them. The columns of the spline's control
+    // points are the only ones that depend on the data (the others were written at set-up)
+    extern __shared__ double lds_spl[];
+    double*  __restrict__ lv = lds_spl;
+    int32_t* __restrict__ lc = (int32_t*)(lds_spl + 64*SPLB_KT);
+    const long long dest0 = m.i_nnz0 + (long long)(2*pt)*k;          // this corner's first entry
+    const int cs = P.Ncore_state ? 2 : 0;                             // the control points' columns: [cs, cs + ns)
+    const int ns = P.Ndist_state ? (P.cfg.spline_order + 1)*(P.cfg.spline_order + 1) : 0;
+    for(int h = 0; h < 2; h++)
+    {
+    const bool mine = valid && (lane >> 5) == h;
+    if(mine)
+    {
 
     const double ww = inlier ? w : 0.0;     // outliers: same columns, zero values
     const int n = P.cfg.spline_order + 1;
     for(int xy=0;xy<2;xy++)
     {
-        double*  __restrict__ row = Jv     + m.i_nnz0 + (size_t)(2*pt + xy)*k;
-        int32_t* __restrict__ ci  = colidx + m.i_nnz0 + (size_t)(2*pt + xy)*k;
+        double*  __restrict__ row = lv + ((lane & 31) + 32*xy)*SPLB_KT;
+        int32_t* __restrict__ ci  = lc + ((lane & 31) + 32*xy)*SPLB_KT;
         int c = 0;
         if(P.Ncore_state)
         {
@@ -1497,6 +1525,43 @@ void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ j
             row[c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
         }
     }
+    }   // mine
+    __builtin_amdgcn_wave_barrier();
+    // the half's rows are one extent if its corners have the same number of entries per row and follow each other
+    // (always within an observation; across two of them unless one camera sits at the reference and the other does not)
+    const unsigned long long live = __ballot(mine);
+    if(live == 0ull) break;
+    const int       lead = 32*h;
+    const long long base = __shfl(dest0, lead);
+    const int       kk   = __shfl(k, lead);
+    const int       nrow = 2*__popcll(live);
+    const bool uniform = __all(!mine || (k == kk && dest0 == base + (long long)(2*(lane & 31))*kk));
+    if(uniform)
+    {
+        const int total = nrow*kk;
+        // (r, c): CSR row of the half and entry of element e, kept by increments (one division here, none in the loop)
+        const int dr = 64 / kk, dc = 64 - dr*kk;
+        int r = lane / kk, c = lane - r*kk;
+        for(int e = lane; e < total; e += 64, r += dr, c += dc)
+        {
+            if(c >= kk) { c -= kk; r++; }
+            const int src = ((r >> 1) + 32*(r & 1))*SPLB_KT + c;
+            Jv[base + e] = lv[src];          // (an ordinary store: the assembly reads these rows next)
+            if(c >= cs && c < cs + ns) colidx[base + e] = lc[src];
+        }
+    }
+    else if(mine)
+        for(int xy=0;xy<2;xy++)
+        {
+            const int src = ((lane & 31) + 32*xy)*SPLB_KT;
+            for(int c = 0; c < k; c++)
+            {
+                Jv[dest0 + (long long)xy*k + c] = lv[src + c];
+                if(c >= cs && c < cs + ns) colidx[dest0 + (long long)xy*k + c] = lc[src + c];
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    }   // h
 }
 
 // discrete points, splined model: one lane per observation (2 rows)
@@ -1740,7 +1805,7 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
         if(ev_j0) hipEventRecord(ev_j0, stream);
         const int n = P.Nobs_board*P.W*P.H;
         if(with_jacobian)
-            hipLaunchKernelGGL((board_splined_kernel<true>),  dim3((n+63)/64), dim3(64), 0, stream, P, B.R, B.joint, B.Ji);
+            hipLaunchKernelGGL((board_splined_kernel<true>),  dim3((n+63)/64), dim3(64), 64*SPLB_KT*(sizeof(double) + sizeof(int32_t)), stream, P, B.R, B.joint, B.Ji);
         else
             hipLaunchKernelGGL((board_splined_kernel<false>), dim3((n+63)/64), dim3(64), 0, stream, P, B.R, B.joint, B.Ji);
         if(ev_j1) hipEventRecord(ev_j1, stream);
