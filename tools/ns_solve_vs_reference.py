@@ -2,7 +2,7 @@
 mrcal_amd.optimize() on the GPU and by the reference's own mrcal_optimize() (oracle/_ref: mrcal.c compiled in
 place, the restated libdogleg underneath) on one host core. ~3 minutes of CPU. Writes the comparison as JSON
 (default profiles/r03_ns_solve_vs_reference.json); tests/test_full_size.py::test_solve_matches_reference_at_metric_size
-asserts the same numbers when MRCAL_AMD_SLOW=1.
+asserts the same bounds in the suite.
 
     python tools/ns_solve_vs_reference.py [out.json]
 """
