@@ -101,6 +101,11 @@ typedef struct dogleg_restated_factor_t
     int*    perm;    // new -> old
     int*    pinv;    // old -> new
 
+    // the pattern of Jt this analysis was made for (pattern_matches())
+    int     Nmeas, nnz;
+    int*    Jt_p_analyzed;
+    int*    Jt_i_analyzed;
+
     // J in CSC (= transpose of Jt); structure + a map into Jt's values
     int*    Jp;      // n+1
     int*    Jj;      // measurement index of each entry
@@ -126,6 +131,7 @@ static void factor_free(factor_t* F)
 {
     if(F == NULL) return;
     free(F->perm); free(F->pinv);
+    free(F->Jt_p_analyzed); free(F->Jt_i_analyzed);
     free(F->Jp); free(F->Jj); free(F->Jsrc);
     free(F->Cp); free(F->Ci); free(F->Cx);
     free(F->parent); free(F->Lp); free(F->Li); free(F->Lx);
@@ -168,6 +174,11 @@ static factor_t* factor_analyze(int n, int Nmeas, const int* Jt_p, const int* Jt
     factor_t* F = (factor_t*)calloc(1, sizeof(*F));
     F->n = n;
     const int nnz = Jt_p[Nmeas];
+    F->Nmeas = Nmeas; F->nnz = nnz;
+    F->Jt_p_analyzed = (int*)malloc(((size_t)Nmeas+1)*sizeof(int));
+    F->Jt_i_analyzed = (int*)malloc((nnz>0?nnz:1)*sizeof(int));
+    memcpy(F->Jt_p_analyzed, Jt_p, ((size_t)Nmeas+1)*sizeof(int));
+    memcpy(F->Jt_i_analyzed, Jt_i, (size_t)nnz*sizeof(int));
 
     // J = transpose(Jt), structure only
     F->Jp   = (int*)calloc(n+1, sizeof(int));
@@ -293,6 +304,22 @@ static factor_t* factor_analyze(int n, int Nmeas, const int* Jt_p, const int* Jt
     F->Li = (int*)   malloc((F->Lp[n]>0?F->Lp[n]:1)*sizeof(int));
     F->Lx = (double*)malloc((F->Lp[n]>0?F->Lp[n]:1)*sizeof(double));
     return F;
+}
+
+// Is this the pattern the analysis was made for? The splined lens models move a row's columns with the corner
+// (which (order+1)^2 knots a projection lands on: mrcal.c:4718-4817), so Jt's pattern changes from one evaluation to
+// the next. CHOLMOD's simplicial numeric factorization (cholmod_rowfac, which libdogleg selects with supernodal = 0)
+// takes its elimination tree from the growing factor itself and is correct for ANY pattern under the analyzed
+// ordering; this restatement's symbolic work is static (the map Jsrc into Jt's values, the pattern of C, the
+// column pointers of L), so it is redone when the pattern moved. (Until round 4 it was not: the numeric phase then
+// read values of the new Jt through the old map, found "not positive definite" matrices that LAPACK factors without
+// trouble - tools/diag_splined_pd.py - and crawled through lambda: every disputed splined solve of
+// profiles/r03_fuzz_parity.txt)
+static bool pattern_matches(const factor_t* F, int Nmeas, const int* Jt_p, const int* Jt_i)
+{
+    return F->Nmeas == Nmeas && F->nnz == Jt_p[Nmeas] &&
+           memcmp(F->Jt_p_analyzed, Jt_p, ((size_t)Nmeas+1)*sizeof(int)) == 0 &&
+           memcmp(F->Jt_i_analyzed, Jt_i, (size_t)F->nnz*sizeof(int)) == 0;
 }
 
 // Numeric factorization. Returns false if not positive definite
@@ -569,6 +596,30 @@ static void computeCauchyUpdate(dogleg_operatingPoint_t* point, const dogleg_sol
         SAY("cauchy step size %.6g", sqrt(point->updateCauchy_lensq));
 }
 
+// Oracle-only knob (not in libdogleg): DOGLEG_RESTATED_DUMP_NOTPD=<prefix> writes the sparse Jt and lambda of every
+// factorization that was declared "not positive definite" to <prefix><k>.bin (int32 Nstate, Nmeas, nnz; double
+// lambda; int32 p[Nmeas+1], i[nnz]; double x[nnz]) so that the decision can be put to LAPACK on the same matrix
+// (tools/diag_splined_pd.py)
+static void dump_not_positive_definite(const dogleg_solverContext_t* ctx, const dogleg_operatingPoint_t* point)
+{
+    static int ndumped = 0;
+    const char* prefix = getenv("DOGLEG_RESTATED_DUMP_NOTPD");
+    if(prefix == NULL || !ctx->is_sparse || ndumped >= 64) return;
+    char path[1024];
+    snprintf(path, sizeof(path), "%s%d.bin", prefix, ndumped++);
+    FILE* f = fopen(path, "wb");
+    if(f == NULL) return;
+    const int    n = ctx->Nstate, m = ctx->Nmeasurements;
+    const int*   p = (const int*)point->Jt->p;
+    const int  nnz = p[m];
+    fwrite(&n, sizeof(int), 1, f); fwrite(&m, sizeof(int), 1, f); fwrite(&nnz, sizeof(int), 1, f);
+    fwrite(&ctx->lambda, sizeof(double), 1, f);
+    fwrite(p, sizeof(int), (size_t)m + 1, f);
+    fwrite(point->Jt->i, sizeof(int), (size_t)nnz, f);
+    fwrite(point->Jt->x, sizeof(double), (size_t)nnz, f);
+    fclose(f);
+}
+
 static void computeGaussNewtonUpdate(dogleg_operatingPoint_t* point, dogleg_solverContext_t* ctx)
 {
     if(point->updateGN_valid) return;
@@ -585,6 +636,12 @@ static void computeGaussNewtonUpdate(dogleg_operatingPoint_t* point, dogleg_solv
             ctx->Nfactorizations++;
             if(ctx->is_sparse)
             {
+                if(ctx->factorization != NULL &&
+                   !pattern_matches(ctx->factorization, ctx->Nmeasurements, (const int*)point->Jt->p, (const int*)point->Jt->i))
+                {
+                    factor_free(ctx->factorization);
+                    ctx->factorization = NULL;
+                }
                 if(ctx->factorization == NULL)
                     ctx->factorization = factor_analyze(n, ctx->Nmeasurements,
                                                         (const int*)point->Jt->p,
@@ -612,6 +669,7 @@ static void computeGaussNewtonUpdate(dogleg_operatingPoint_t* point, dogleg_solv
             }
             seconds_factorization += now() - t0;
             if(ok) break;
+            dump_not_positive_definite(ctx, point);
 
             // singular JtJ. Raise lambda and go again
             if(ctx->lambda == 0.0) ctx->lambda = 1e-10;

@@ -274,3 +274,36 @@ def test_reference_optimize_through_restated_solver_vs_scipy(ref_api):
     # and scipy started at the seed does not find anything better
     r0 = least_squares(fun, b0, jac=jac, method="trf", x_scale=1.0, max_nfev=60)
     assert x1 @ x1 <= 2*r0.cost*(1 + 1e-9)
+
+
+def test_restated_factorization_follows_a_changing_pattern(ref_api, tmp_path):
+    """The splined lens models move a row's columns with the corner (mrcal.c:4718-4817), so the pattern of Jt
+    changes between evaluations. CHOLMOD's simplicial factorization (what libdogleg runs: supernodal = 0) is
+    correct for any pattern; the restatement redoes its static symbolic analysis when the pattern moved. Until
+    round 4 it did not, found "not positive definite" matrices that numpy.linalg.cholesky factors without trouble
+    (52 times on this problem: tools/diag_splined_pd.py, profiles/r04_splined_checker_defect.txt), and returned
+    1.3026 px with 11 outliers where the stationary point is at 1.1814 px with 15. Sweep seed 23, case 22 of
+    tools/fuzz_parity.py, built by the reference's own library: nothing here needs a GPU"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity, arbiter
+    from mrcal_amd.synthetic import copy_inputs
+    rng = np.random.RandomState(23)
+    for ic, what, oi, *_ in fuzz_parity.board_cases(23, rng, ref_api):
+        if ic == 22: break
+    assert "SPLINED" in what
+    # the pattern does move on this problem: the seed's Jacobian and the solution's
+    o = copy_inputs(oi)
+    J0 = ref_api.optimizer_callback(no_factorization=True, **copy_inputs(o))[2]
+    os.environ["DOGLEG_RESTATED_DUMP_NOTPD"] = str(tmp_path / "notpd_")
+    try:
+        s = ref_api.optimize(**o)
+    finally:
+        del os.environ["DOGLEG_RESTATED_DUMP_NOTPD"]
+    J1 = ref_api.optimizer_callback(no_factorization=True, **copy_inputs(o))[2]
+    assert np.array_equal(J0.indptr, J1.indptr) and not np.array_equal(J0.indices, J1.indices)
+    assert list(tmp_path.glob("notpd_*.bin")) == []         # JtJ was never declared "not positive definite"
+    assert abs(s["rms_reproj_error__pixels"] - 1.18136) < 1e-4 and s["Noutliers_board"] == 15
+    st, cost, _ = arbiter.stationarity(ref_api, o)
+    assert st < 1e-7, st
+    assert arbiter.least_squares_gain(ref_api, o) < 1e-9
