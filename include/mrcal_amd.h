@@ -609,10 +609,24 @@ void* mrcal_amd_problem_sharded_comm_buffer(mrcal_amd_problem_t* problem, int wh
 bool  mrcal_amd_problem_sharded_snapshot   (mrcal_amd_problem_t* problem, int slot);
 bool  mrcal_amd_problem_sharded_wait       (mrcal_amd_problem_t* problem, int slot, int* out);
 bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* out_i, double* out_d);
-/* info[10] = { Nstate, Nie, NE, Nc, frame_lo, frame_hi, is_leader, Ncorners_local, Nframe_blocks, Npoint_blocks }.
-   State layout: [0,Nie) intrinsics+extrinsics, [Nie,Nie+NE) frames (6 each) then points (3 each), then the warp.
-   The leader owns the camera block and the points */
-void  mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info);
+/* What this shard holds. Writes min(Ninfo, MRCAL_AMD_SHARD_INFO_N) ints and returns how many it knows of (the caller
+   says how big its buffer is; the list only ever grows at the end):
+     info[0]  Nstate            the full state vector (every shard holds all of it)
+     info[1]  S_split           first state index that is NOT one of the leading dense-block variables: in a sharded
+                                (frames/points-eliminated) problem the state is [0,S_split) intrinsics + extrinsics,
+                                [S_split, S_split+NE) the eliminated variables - frames (6 each), then the variable
+                                points (3 each) -, then the board warp (mrcal_amd_problem_partition() has the general form)
+     info[2]  NE                number of eliminated variables (all shards' together)
+     info[3]  Nc                size of the dense camera block (intrinsics + extrinsics + warp)
+     info[4], info[5]  frame_lo, frame_hi     the frames [lo,hi) whose board observations and 6x6 blocks this shard owns
+     info[6]  is_leader         this shard owns the camera block of the state, the warp and the regularization rows
+     info[7]  Ncorners_local    board corners in this shard's observations
+     info[8]  Nframe_blocks     6x6 blocks of the whole problem
+     info[9]  Npoint_blocks     3x3 blocks of the whole problem
+     info[10], info[11]  point_lo, point_hi   the eliminated BLOCKS [lo,hi), lo >= Nframe_blocks, of the variable points
+                                this shard owns (its discrete-point observations and its triangulated pairs) */
+#define MRCAL_AMD_SHARD_INFO_N 12
+int   mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info, int Ninfo);
 /* Which part of the state the solver keeps as the dense block S and which it
    eliminates block by block (E). The state vector is the reference's either way;
      S index s -> state s (s < info[0]) or s + info[1];   E index e -> state info[2] + e
@@ -659,8 +673,11 @@ bool mrcal_amd_problem_drt_cross_reprojection(mrcal_amd_problem_t* problem, int 
 /* Test/diagnostic access. Evaluates at the resident state and copies out the
    normal equations N = JtJ in the solver's block form (see
    csrc/solver_kernels.hip): A (Nc*Nc), Bt (NE*Nc), D (NEb*6*6), g = Jt x
-   (Nstate), |x|^2; dims = {Nc, NE, NEb, Nfb, Nie, Nwarp}. Any pointer may be
-   NULL */
+   (Nstate), |x|^2; dims = {Nc, NE, NEb, Nfb, S_split, Nwarp}: S_split as in
+   mrcal_amd_problem_partition() - with the frames eliminated it is the number of
+   intrinsics + extrinsics variables ("Nie" before round 3); with the extrinsics
+   eliminated (moving cameras) it is the number of intrinsics variables, and the
+   frames follow in S behind the shift. Any pointer may be NULL */
 bool mrcal_amd_problem_get_normal_equations(mrcal_amd_problem_t* problem,
                                             double* A, double* Bt, double* D, double* g,
                                             double* norm2_x, int* dims);

@@ -717,13 +717,16 @@ void mrcal_amd_problem_partition(mrcal_amd_problem_t* P, int* info)
 {
     info[0] = P->nd.S_split; info[1] = P->nd.S_shift; info[2] = P->nd.E_state0; info[3] = P->nd.elim_extrinsics;
 }
-void mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info)
+int mrcal_amd_problem_shard_info(mrcal_amd_problem_t* P, int* info, int Ninfo)
 {
-    info[0] = P->nd.Nstate; info[1] = P->nd.S_split; info[2] = P->nd.NE; info[3] = P->nd.Nc;
-    info[4] = P->br.frame_lo; info[5] = P->br.frame_hi; info[6] = P->is_leader ? 1 : 0;
-    info[7] = P->D.Nobs_board * P->D.W * P->D.H;
-    info[8] = P->nd.Nfb; info[9] = P->nd.Npb;
-    info[10] = P->br.point_lo; info[11] = P->br.point_hi;      // point BLOCKS (indices >= Nfb) this shard owns
+    const int all[MRCAL_AMD_SHARD_INFO_N] = {
+        P->nd.Nstate, P->nd.S_split, P->nd.NE, P->nd.Nc,
+        P->br.frame_lo, P->br.frame_hi, P->is_leader ? 1 : 0,
+        P->D.Nobs_board * P->D.W * P->D.H,
+        P->nd.Nfb, P->nd.Npb,
+        P->br.point_lo, P->br.point_hi };      // point BLOCKS (indices >= Nfb) this shard owns
+    for(int i = 0; i < Ninfo && i < MRCAL_AMD_SHARD_INFO_N; i++) info[i] = all[i];
+    return MRCAL_AMD_SHARD_INFO_N;
 }
 // outlier statistics / marking on the local board observations
 // (mrcal.c:3978-4402). counts (device int[4]) and sums (device double[1]) are

@@ -261,8 +261,8 @@ def _declare_sharded(L):
     if getattr(L, "_mrcal_amd_sharded_declared", False):
         return
     vp = C.c_void_p
-    L.mrcal_amd_problem_shard_info.restype  = None
-    L.mrcal_amd_problem_shard_info.argtypes = [vp, C.POINTER(C.c_int)]
+    L.mrcal_amd_problem_shard_info.restype  = C.c_int
+    L.mrcal_amd_problem_shard_info.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
     L.mrcal_amd_problem_sharded_reset.restype  = C.c_bool
     L.mrcal_amd_problem_sharded_reset.argtypes = [vp, C.c_int, C.c_int, C.c_double]
     L.mrcal_amd_problem_sharded_enqueue.restype  = C.c_bool
@@ -300,7 +300,8 @@ class GpuShard:
         self.L = L = problem._lib
         _declare_sharded(L)
         info = (C.c_int*12)()
-        L.mrcal_amd_problem_shard_info(problem.handle, info)
+        assert L.mrcal_amd_problem_shard_info(problem.handle, info, len(info)) >= len(info)
+        # (Nie: S_split, the end of the leading intrinsics + extrinsics variables of a sharded problem's state)
         self.Nstate, self.Nie, self.NE, self.Nc = info[0], info[1], info[2], info[3]
         self.frame_lo, self.frame_hi = info[4], info[5]
         self.Nfb = info[8]

@@ -178,7 +178,9 @@ class Problem:
                     Noutlier_passes=i[3].value, norm2_x=d[0].value, lambda_=d[1].value, seconds=d[2].value)
 
     def normal_equations(self):
-        """evaluates at the resident state; returns dict(A,Bt,D,g,norm2_x,+dims)"""
+        """evaluates at the resident state; returns dict(A,Bt,D,g,norm2_x,+dims). Nie is S_split (== the partition()'s):
+        the number of intrinsics + extrinsics variables when the frames are eliminated, of intrinsics variables alone
+        when the extrinsics are (include/mrcal_amd.h)"""
         dims = (C.c_int*6)()
         self._check(self._lib.mrcal_amd_problem_get_normal_equations(self.handle, None,None,None,None,None, dims),
                     "get_normal_equations")

@@ -283,6 +283,19 @@ def test_splined_configuration_full_size(amd, ref_api, core):
         assert float(p.x() @ p.x()) < c0
 
 
+@pytest.mark.timeout(1200)
+def test_splined_configuration_solve_matches_reference(amd, ref_api):
+    """BASELINE.json's configuration 2 at its size (30 x 20 knots, 800 frames, core locked): the whole solve with its
+    outlier passes against the reference's mrcal_optimize() (~1 minute of one host core), at the same optimum -
+    possible since the checker's stale-analysis defect on moving patterns was fixed
+    (tests/test_solver_parity.py::test_optimize_splined) -, and the arbiter's word on both results"""
+    from test_solver_parity import _compare_splined_solves
+    oi, _ = make_calibration_problem(amd._api, Ncameras=1, Nframes=800, object_width_n=10, object_height_n=10,
+                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     seed=4, do_optimize_intrinsics_core=False)
+    _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=1e-3)
+
+
 @pytest.mark.timeout(900)
 def test_sfm_configuration_full_size(amd, ref_api):
     """config4: 4 cameras, 20k triangulated points (+ their pairs), unity_cam01
