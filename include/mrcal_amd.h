@@ -627,6 +627,13 @@ bool  mrcal_amd_problem_sharded_finish     (mrcal_amd_problem_t* problem, int* o
                                 this shard owns (its discrete-point observations and its triangulated pairs) */
 #define MRCAL_AMD_SHARD_INFO_N 12
 int   mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info, int Ninfo);
+/* Which pose blocks the problems created from now on eliminate: 0 the library chooses (default: the extrinsics when
+   there are at least 4 rt_cam_ref and more extrinsics than frame + point variables, e.g. a moving camera or a big
+   stationary rig seen in a handful of frames; the frames and points otherwise), 1 the frames and points, 2 the
+   extrinsics where the problem allows it (board rows only, no unity_cam01 row, not splined, not sharded). The results
+   of a solve do not depend on it beyond rounding; the block form of mrcal_amd_problem_get_normal_equations() and the
+   cost of a step do. Returns the previous setting. (Processes that cannot call it: MRCAL_AMD_ELIMINATE=frames|extrinsics) */
+int   mrcal_amd_set_elimination(int policy);
 /* Which part of the state the solver keeps as the dense block S and which it
    eliminates block by block (E). The state vector is the reference's either way;
      S index s -> state s (s < info[0]) or s + info[1];   E index e -> state info[2] + e
@@ -635,6 +642,11 @@ int   mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info, int 
    creation, test_calibration_helpers.py:422-493 builds such problems). The
    blocks of mrcal_amd_problem_get_normal_equations() are in these indices */
 void  mrcal_amd_problem_partition(mrcal_amd_problem_t* problem, int info[4]);
+/* The outlier bits of this problem's (this shard's) triangulated observations after a solve: flags[i] (0/1, at most
+   Nflags written) belongs to observations_point_triangulated[*first + i] of the array the problem was created from.
+   Returns the number of observations the problem holds. mrcal_optimize() writes them into the caller's array like
+   the reference does (mrcal.c:4225, 4375); a sharded solve leaves the gathering to its driver */
+int   mrcal_amd_problem_get_triangulated_outliers(mrcal_amd_problem_t* problem, int* flags, int Nflags, int* first);
 /* outlier statistics / marking on the local board observations (mrcal.c:3978-4402);
    counts (device int[4]) and sums (device double[1]) are accumulated into */
 bool  mrcal_amd_problem_phase_outlier_stats(mrcal_amd_problem_t* problem, int iop, double thresh_sq,

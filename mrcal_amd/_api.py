@@ -422,6 +422,9 @@ class Api:
                                          *self._common_args(p), check_gradient)
         if stats.rms_reproj_error__pixels < 0.0:
             raise RuntimeError("mrcal.optimize() failed!" + self._last_error())
+        # (the C records of the triangulated observations are this wrapper's, as in mrcal-pywrap.c: the outlier bits the
+        #  solve left in them do not reach the Python caller. Kept for the tests, which compare them with the reference's)
+        self._last_triangulated_flags = p.c_tri["flags"].copy() if p.Nobservations_tri else None
         return dict(rms_reproj_error__pixels     = stats.rms_reproj_error__pixels,
                     Noutliers_board              = stats.Noutliers_board,
                     Noutliers_triangulated_point = stats.Noutliers_triangulated_point,
@@ -473,12 +476,14 @@ class Api:
         Jacobian at the given state, then _mrcal_drt_cross_reprojection__dbpacked() (uncertainty.c:798)"""
         icam = -1 if icam_intrinsics is None else int(icam_intrinsics)
         kwargs = dict(kwargs, no_jacobian=False, no_factorization=True)
+        tamper = kwargs.pop("_tamper_with_J", None)      # tests: a malformed Jt must be refused, not walked
         p = self._ingest(kwargs, callback=True)
         if icam >= p.Ncameras_intrinsics:
             raise RuntimeError(f"icam_intrinsics MUST be <0 (if unused) or in [0,Ncameras_intrinsics-1]. "
                                f"got {icam} NOT in [0,{p.Ncameras_intrinsics-1}]")
         b_packed, x, J, _ = self.optimizer_callback(**kwargs)
         Nstate, Nmeas = J.shape[1], J.shape[0]
+        if tamper is not None: tamper(J)
         Jt = CholmodSparse(nrow=Nstate, ncol=Nmeas, nzmax=J.nnz,
                            p=J.indptr.ctypes.data, i=J.indices.ctypes.data, x=J.data.ctypes.data,
                            stype=0, itype=0, xtype=1, dtype=0, sorted=1, packed=1)

@@ -651,7 +651,18 @@ bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool w
 
 } // namespace mrcal_amd
 
+namespace { int& elimination_policy() { static int policy = 0; return policy; } }
+
 extern "C" {
+
+// 0: the library chooses (default); 1: the frames and points are eliminated; 2: the extrinsics, where the problem
+// allows it. For the problems created AFTER the call. Returns the previous setting
+int mrcal_amd_set_elimination(int policy)
+{
+    const int old = elimination_policy();
+    if(policy >= 0 && policy <= 2) elimination_policy() = policy;
+    return old;
+}
 
 const char* mrcal_amd_last_error(void)
 {
@@ -978,13 +989,16 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
         // one of them, and only board rows touch them: a camera's block is then written whole by the workgroup
         // that sums its observations' Grams, as a frame's is (no triangulated pairs, no discrete points, no
         // unity_cam01 row). The splined models' assembly and the sharding know frames only.
-        // MRCAL_AMD_ELIMINATE=frames|extrinsics overrides the choice where both are possible (tests)
+        // mrcal_amd_set_elimination() overrides the choice where both are possible; without a call the environment
+        // variable MRCAL_AMD_ELIMINATE=frames|extrinsics does (for a process that cannot make one)
         bool elimx = !sharded && lensmodel->type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && Ntri_local == 0 &&
                      Npoint_local == 0 && !sel.do_apply_regularization_unity_cam01 && L.Nstate_extrinsics > 0;
         if(elimx)
         {
             const char* env = getenv("MRCAL_AMD_ELIMINATE");
-            if(env && !strcmp(env, "frames"))          elimx = false;
+            if(elimination_policy() == 1)              elimx = false;
+            else if(elimination_policy() == 2)         elimx = true;
+            else if(env && !strcmp(env, "frames"))     elimx = false;
             else if(env && !strcmp(env, "extrinsics")) elimx = true;
             else elimx = Ncameras_extrinsics >= 4 && L.Nstate_frames + L.Nstate_points < L.Nstate_extrinsics;
         }

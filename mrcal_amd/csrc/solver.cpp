@@ -848,6 +848,16 @@ bool mrcal_amd_problem_sharded_finish(mrcal_amd_problem_t* P, int* out_i, double
 }
 int mrcal_amd_problem_current(mrcal_amd_problem_t* P) { return P->icur; }
 
+// The outlier bits of this problem's (this shard's) triangulated observations as mark_outliers() left them: flags[i]
+// belongs to observations_point_triangulated[*first + i] of the array the problem was created from. Returns how many
+int mrcal_amd_problem_get_triangulated_outliers(mrcal_amd_problem_t* P, int* flags, int Nflags, int* first)
+{
+    const int N = P->tri_outlier_host.empty() ? 0 : (int)P->tri_outlier_host.size() - 1;     // (one element of padding)
+    if(first) *first = P->tri_obs0;
+    for(int i = 0; i < N && i < Nflags; i++) flags[i] = P->tri_outlier_host[i];
+    return N;
+}
+
 // copies the (possibly outlier-marked) board observation pool back
 bool mrcal_amd_problem_get_board_pool(mrcal_amd_problem_t* P, mrcal_point3_t* pool_local)
 {
@@ -980,6 +990,15 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
     // new outliers are reported by negated weights in the caller's array
     if(sel.do_apply_outlier_rejection && P->stats.Noutlier_passes > 0)
         if(!mrcal_amd_problem_get_board_pool(P, observations_board_pool)) goto done;
+    // ... and by the outlier bit of the triangulated observations, which lives in the caller's (const) array: the
+    // reference's markOutliers() writes it there through the same cast (mrcal.c:4225, 4375, 6467)
+    if(sel.do_apply_outlier_rejection && observations_point_triangulated != NULL)
+    {
+        mrcal_observation_point_triangulated_t* o = (mrcal_observation_point_triangulated_t*)observations_point_triangulated;
+        const int Nt = P->tri_outlier_host.empty() ? 0 : (int)P->tri_outlier_host.size() - 1;
+        for(int i = 0; i < Nt && P->tri_obs0 + i < Nobservations_point_triangulated; i++)
+            if(P->tri_outlier_host[i]) o[P->tri_obs0 + i].outlier = true;
+    }
 
     stats.rms_reproj_error__pixels     = rms;
     stats.Noutliers_board              = Noutliers;

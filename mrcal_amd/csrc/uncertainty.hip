@@ -686,10 +686,26 @@ bool _mrcal_drt_cross_reprojection__dbpacked(double* Kpackede,  int Kpackede_str
         set_error("Inconsistent inputs. The observations take %d measurements, but Jt->ncol=%d", Nmeas_obs, (int)Jt->ncol);
         return false;
     }
+    // The kernels walk the caller's arrays (map_row: Ji[Jp[r] .. Jp[r+1])): 32-bit indices, real doubles, rowptr
+    // non-decreasing from 0 and inside nzmax, every column inside the state (as mrcal_amd_csr_Jt_x() checks its CSR)
+    if(Jt->itype != 0 /* CHOLMOD_INT */ || Jt->xtype != 1 /* CHOLMOD_REAL */ || Jt->dtype != 0 /* CHOLMOD_DOUBLE */)
+    {
+        set_error("Jt must hold 32-bit indices and real doubles (itype %d, xtype %d, dtype %d)", Jt->itype, Jt->xtype, Jt->dtype);
+        return false;
+    }
     const int32_t* Jp = (const int32_t*)Jt->p;
     const int32_t* Ji = (const int32_t*)Jt->i;
     const double*  Jx = (const double*) Jt->x;
+    if(Jp == NULL || Ji == NULL || Jx == NULL || Jp[0] != 0) { set_error("malformed Jt: its column pointers must start at 0"); return false; }
+    for(int r = 0; r < Nmeas_obs; r++)
+        if(Jp[r+1] < Jp[r]) { set_error("malformed Jt: the column pointers decrease at measurement %d", r); return false; }
     const int64_t nnz = Nmeas_obs > 0 ? Jp[Nmeas_obs] : 0;
+    if(nnz > (int64_t)Jt->nzmax) { set_error("malformed Jt: %lld entries in the observations' rows, nzmax %lld", (long long)nnz, (long long)Jt->nzmax); return false; }
+    {
+        unsigned bad = 0;
+        for(int64_t p = 0; p < nnz; p++) bad |= (unsigned)((unsigned)Ji[p] >= (unsigned)L.Nstate);
+        if(bad) { set_error("malformed Jt: a state index is outside [0,%d)", L.Nstate); return false; }
+    }
     int32_t *d_Jp = NULL, *d_Ji = NULL; double* d_Jx = NULL;
     bool ok = true;
     HIP_TRY(hipMalloc((void**)&d_Jp, (size_t)(Nmeas_obs + 1)*sizeof(int32_t)), return false);

@@ -45,15 +45,16 @@ def moving_camera_problem(api, Nposes, ref_frame0, seed=3, lensmodel="LENSMODEL_
 
 
 class eliminating:
-    """MRCAL_AMD_ELIMINATE for the problems created inside"""
+    """mrcal_amd_set_elimination() for the problems created inside (None: the library's own choice)"""
     def __init__(self, what): self.what = what
     def __enter__(self):
-        self.old = os.environ.get("MRCAL_AMD_ELIMINATE")
-        if self.what is None: os.environ.pop("MRCAL_AMD_ELIMINATE", None)
-        else:                 os.environ["MRCAL_AMD_ELIMINATE"] = self.what
+        import mrcal_amd
+        self.f = mrcal_amd._api.clib.mrcal_amd_set_elimination
+        self.old_env = os.environ.pop("MRCAL_AMD_ELIMINATE", None)
+        self.old = self.f({None: 0, "frames": 1, "extrinsics": 2}[self.what])
     def __exit__(self, *a):
-        if self.old is None: os.environ.pop("MRCAL_AMD_ELIMINATE", None)
-        else:                os.environ["MRCAL_AMD_ELIMINATE"] = self.old
+        self.f(self.old)
+        if self.old_env is not None: os.environ["MRCAL_AMD_ELIMINATE"] = self.old_env
 
 
 def test_moving_camera_problem_is_the_monocular_one(ref_api):
@@ -98,6 +99,54 @@ def test_callback_and_normal_equations(amd, ref_api, ref_frame0):
         assert p.normal_equations()["Nc"] == 8 + 2 + (0 if ref_frame0 else 6)
     with eliminating("frames"), Problem(**copy_inputs(oi)) as p:
         assert p.normal_equations()["Nc"] == 8 + 2 + 6*(9 if ref_frame0 else 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ncameras,Nframes", ((6, 4), (5, 3)))
+def test_stationary_rig_with_few_frames_under_both_eliminations(amd, ref_api, Ncameras, Nframes):
+    """A STATIONARY rig of many cameras seen in a handful of frames also has more extrinsics than frame variables,
+    and the library eliminates its extrinsics by itself (test_the_choice). Unlike the moving camera's, this problem
+    has a camera AT the reference (camera 0: no extrinsics, its observations belong to no eliminated block) and
+    several cameras per frame. Callback against the reference, the block normal equations of either partition
+    against JtJ, and the solve against the reference's mrcal_optimize() under both"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel="LENSMODEL_OPENCV4",
+                                     object_width_n=10, object_height_n=10, seed=13)
+    assert np.any(oi["indices_frame_camintrinsics_camextrinsics"][:,2] < 0)
+    oi["observations_board"][1,2,3,2] = -1.
+    b_a, x_a, J_a, _ = amd.optimizer_callback(**copy_inputs(oi), no_factorization=True)
+    b_r, x_r, J_r, _ = ref_api.optimizer_callback(**copy_inputs(oi), no_factorization=True)
+    assert np.array_equal(b_a, b_r)
+    assert np.array_equal(J_a.indptr, J_r.indptr) and np.array_equal(J_a.indices, J_r.indices)
+    assert relative_error(x_a, x_r).max() < 1e-6 and relative_error(J_a.data, J_r.data).max() < 1e-6
+    with eliminating(None), Problem(**copy_inputs(oi)) as p:
+        assert p.partition()["eliminates"] == "extrinsics"
+    Nintr = 8*Ncameras
+    for what in ("frames", "extrinsics"):
+        with eliminating(what), Problem(**copy_inputs(oi)) as p:
+            assert p.partition()["eliminates"] == what
+            ne = p.normal_equations()
+            J, x = p.J(), p.x()
+            d = p.gauss_newton_step()
+        N, g = dense_normal(J, x)
+        assert np.abs(blocks_to_dense(ne, p.Nstate) - N).max() < 1e-10*np.abs(N).max(), what
+        assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+        assert np.abs(N @ d + g).max() < 1e-6*max(np.abs(g).max(), 1.0), what
+        # the dense block: intrinsics + warp + whichever poses are NOT eliminated; dims[4] ("Nie") = S_split
+        assert ne["Nc"]  == Nintr + 2 + (6*(Ncameras-1) if what == "frames" else 6*Nframes)
+        assert ne["Nie"] == ne["S_split"] == (Nintr + 6*(Ncameras-1) if what == "frames" else Nintr)
+    oi["do_apply_outlier_rejection"] = True
+    oi_r = copy_inputs(oi)
+    s_r = ref_api.optimize(**oi_r)
+    for what in ("frames", "extrinsics"):
+        with eliminating(what):
+            oi_a = copy_inputs(oi)
+            s_a = amd.optimize(**oi_a)
+        assert s_a["Noutliers_board"] == s_r["Noutliers_board"], what
+        assert np.array_equal(oi_a["observations_board"][...,2] < 0, oi_r["observations_board"][...,2] < 0), what
+        assert abs(s_a["rms_reproj_error__pixels"] - s_r["rms_reproj_error__pixels"]) < 1e-6*s_r["rms_reproj_error__pixels"], what
+        assert np.abs(s_a["b_packed"] - s_r["b_packed"]).max() < 2e-5, what
+        assert np.abs(s_a["x"] - s_r["x"]).max() < 1e-5, what
 
 
 @pytest.mark.gpu

@@ -410,6 +410,9 @@ def test_solve_matches_checker_and_truth(amd, ref_api):
     sr = ref_api.optimize(**orr)
     assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
     assert sa["Noutliers_triangulated_point"] == sr["Noutliers_triangulated_point"]
+    # the outlier bits in the C records of the triangulated observations (mrcal.c:4225, 4375 write them into the
+    # caller's array): the same observations marked
+    assert np.array_equal(amd._api._last_triangulated_flags, ref_api._last_triangulated_flags)
     assert np.abs(oa["rt_cam_ref"] - orr["rt_cam_ref"]).max() < 1e-5
     # unity_cam01 fixes the scale: camera 1 is 1m from the reference; the
     # geometry comes out close to the truth
@@ -487,6 +490,9 @@ def test_boards_and_triangulated_in_one_problem(amd, ref_api, lensmodel, Npoints
     sr = ref_api.optimize(**orr)
     assert sa["Noutliers_board"] == sr["Noutliers_board"]
     assert sa["Noutliers_triangulated_point"] == sr["Noutliers_triangulated_point"]
+    from mrcal_amd._cabi import TRIANGULATED_OUTLIER
+    assert np.array_equal(amd._api._last_triangulated_flags, ref_api._last_triangulated_flags)
+    assert (sr["Noutliers_triangulated_point"] == 0) == (not np.any(ref_api._last_triangulated_flags & TRIANGULATED_OUTLIER))
     assert np.array_equal(oa["observations_board"][...,2] < 0, orr["observations_board"][...,2] < 0)
     assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-6*sr["rms_reproj_error__pixels"]
     assert np.abs(sa["b_packed"] - sr["b_packed"]).max() < 2e-5

@@ -256,6 +256,14 @@ def test_error_behaviour(amd):
     oi = board_problem(amd._api)
     with pytest.raises(RuntimeError):
         amd.drt_cross_reprojection__dbpacked(icam_intrinsics=7, **oi)
+    # a malformed Jt is refused before any kernel walks it (the C entry point takes the caller's cholmod_sparse)
+    def decreasing(J):  J.indptr[5] = J.indptr[4] - 1
+    def out_of_range(J): J.indices[7] = J.shape[1]
+    def negative(J):    J.indices[3] = -1
+    for tamper in (decreasing, out_of_range, negative):
+        with pytest.raises(RuntimeError, match="malformed Jt"):
+            amd.drt_cross_reprojection__dbpacked(_tamper_with_J=tamper, **oi)
+    assert np.isfinite(amd.drt_cross_reprojection__dbpacked(**oi)).all()
     # the intrinsics locked: ccp cannot tell the cameras apart (uncertainty.c:1190-1195), rrp works
     oi.update(do_optimize_intrinsics_core=False, do_optimize_intrinsics_distortions=False)
     with pytest.raises(RuntimeError):

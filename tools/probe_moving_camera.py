@@ -18,7 +18,7 @@ for ref_frame0 in (True, False):
     oi = moving_camera_problem(mrcal_amd._api, N, ref_frame0, lensmodel="LENSMODEL_OPENCV8")
     oi["do_apply_outlier_rejection"] = True
     for what in ("extrinsics", "frames"):
-        os.environ["MRCAL_AMD_ELIMINATE"] = what
+        os.environ["MRCAL_AMD_ELIMINATE"] = what      # (before the first problem; mrcal_amd_set_elimination() is the API)
         with Problem(**copy_inputs(oi)) as p:
             part = p.partition()
             ne = p.normal_equations()
