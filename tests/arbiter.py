@@ -9,32 +9,10 @@ from mrcal_amd.synthetic import copy_inputs
 
 def with_state(api, oi, b_packed):
     """a copy of the inputs with the packed state b written into the arrays the callback reads"""
-    o = copy_inputs(oi)
-    b = np.array(b_packed, dtype=float)
-    api.unpack_state(b, **o)
-    core  = bool(o.get("do_optimize_intrinsics_core", True))
-    dist  = bool(o.get("do_optimize_intrinsics_distortions", True))
-    Ncam  = o["intrinsics"].shape[0]
-    if core or dist:
-        Nopt = api.num_intrinsics_optimization_params(**o)
-        for i in range(Ncam):
-            i0 = api.state_index_intrinsics(i, **o)
-            if i0 is None: continue
-            dst = o["intrinsics"][i, (0 if core else 4):(None if dist else 4)]
-            assert dst.size == Nopt
-            dst[:] = b[i0:i0+Nopt]
-    if o.get("do_optimize_extrinsics", True):
-        for i in range(o["rt_cam_ref"].shape[0]):
-            i0 = api.state_index_extrinsics(i, **o)
-            if i0 is not None: o["rt_cam_ref"].reshape(-1,6)[i] = b[i0:i0+6]
-    if o.get("do_optimize_frames", True):
-        for i in range(o["rt_ref_frame"].shape[0]):
-            i0 = api.state_index_frames(i, **o)
-            if i0 is not None: o["rt_ref_frame"].reshape(-1,6)[i] = b[i0:i0+6]
-    if o.get("do_optimize_calobject_warp", False) and o.get("calobject_warp") is not None:
-        i0 = api.state_index_calobject_warp(**o)
-        if i0 is not None: o["calobject_warp"][:] = b[i0:i0+2]
-    return o
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import schur_numpy
+    return schur_numpy.with_state(api, oi, b_packed, copy_inputs)
 
 
 def stationarity(api, oi_solved):
