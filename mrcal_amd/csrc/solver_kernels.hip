@@ -1955,14 +1955,6 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
 #pragma unroll
     for(int c = 0; c < CHOL_PB; c++) Lc[0][c] = Lc[1][c] = 0.0;
     double* __restrict__ mycb = cbuf + lane;
-#if defined(CHOL_DIAG_VARIANT) && CHOL_DIAG_VARIANT >= 2
-    double lpN[CHOL_DIAG_VARIANT + 1];
-    double LcN[CHOL_DIAG_VARIANT + 1][CHOL_PB];
-#pragma unroll
-    for(int q = 0; q <= CHOL_DIAG_VARIANT; q++) { lpN[q] = 0.0;
-#pragma unroll
-        for(int c = 0; c < CHOL_PB; c++) LcN[q][c] = 0.0; }
-#endif
 #define IC(v) std::integral_constant<int,(v)>{}
     auto column = [&](auto J)
     {
@@ -1978,37 +1970,6 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
         const double u2  = fma(hp, rd1*rd1, 1.5);
         const double l   = (lr*u)*u2;            // block lane j: piv/sqrt(piv)
         row[j] = l;
-#if defined(CHOL_DIAG_VARIANT) && CHOL_DIAG_VARIANT >= 2
-        // the next FAST columns by readlane; the others through LDS, applied FAST columns later (FAST+1 register sets)
-        {
-            constexpr int FAST = CHOL_DIAG_VARIANT;
-            constexpr int NS = FAST + 1;
-            if constexpr(j + 1 + FAST < CHOL_PB)
-            {
-                mycb[64*(j % NS)] = l;
-                const double* __restrict__ cb = cbuf + 64*(j % NS);
-#pragma unroll
-                for(int c = j + 1 + FAST; c < CHOL_PB; c++) LcN[j % NS][c] = cb[c];
-                lpN[j % NS] = l;
-            }
-#pragma unroll
-            for(int f = 1; f <= FAST; f++)
-                if(j + f < CHOL_PB) row[j+f] = fma(-l, readlane_f64(l, j+f), row[j+f]);
-            if constexpr(j >= FAST)
-            {
-#pragma unroll
-                for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-lpN[(j-FAST) % NS], LcN[(j-FAST) % NS][c], row[c]);
-            }
-        }
-        return;
-#endif
-#if defined(CHOL_DIAG_VARIANT) && CHOL_DIAG_VARIANT == 1
-        // every multiplier by readlane: no LDS round trip anywhere
-#pragma unroll
-        for(int c = j + 1; c < CHOL_PB; c++) row[c] = fma(-l, readlane_f64(l, c), row[c]);
-        (void)lp; (void)Lc; (void)mycb;
-        return;
-#endif
         if constexpr(j + 2 < CHOL_PB)
         {
             // (every lane stores: no exec juggling; lanes 0..15 are the block)
