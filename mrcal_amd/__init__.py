@@ -27,7 +27,8 @@ except ImportError:         # the C ABI and the single-GPU path do not need it
 from ._cabi import MrcalLib as _MrcalLib
 from ._api  import Api as _Api, optimization_inputs_known_keys as _optimization_inputs_known_keys
 
-_libpath = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmrcal_amd.so")
+# (MRCAL_AMD_LIB: another build of the same library - the measurement build libmrcal_amd_dev.so of csrc/build.sh, dev tools only)
+_libpath = _os.environ.get("MRCAL_AMD_LIB") or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "libmrcal_amd.so")
 if not _os.path.exists(_libpath):
     raise ImportError(
         f"{_libpath} is missing. Build it with mrcal_amd/csrc/build.sh (or "

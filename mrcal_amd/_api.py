@@ -66,6 +66,28 @@ class _Problem:
     pass
 
 
+class _sigint_default:
+    """Ctrl-C during the C call: the reference's wrapper puts SIGINT back to SIG_DFL for the duration of
+    optimize() / optimizer_callback() / drt_cross_reprojection__dbpacked() and restores Python's handler afterwards
+    (python-wrapping-utilities.h:18-32, mrcal-pywrap.c:1581, 2139): Python's own handler only sets a flag that
+    nothing reads while C code runs, so a long solve could not be interrupted. Same here (ctypes holds the
+    interpreter the same way). Signal handlers belong to the main thread: elsewhere this does nothing"""
+    def __enter__(self):
+        import signal, threading
+        self.old = None
+        if threading.current_thread() is threading.main_thread():
+            try:
+                self.old = signal.signal(signal.SIGINT, signal.SIG_DFL)
+            except (ValueError, OSError):
+                self.old = None
+        return self
+    def __exit__(self, *a):
+        import signal
+        if self.old is not None:
+            signal.signal(signal.SIGINT, self.old)
+        return False
+
+
 class Api:
     def __init__(self, lib):
         self.lib  = lib       # a _cabi.MrcalLib
@@ -417,9 +439,10 @@ class Api:
         Nstate, Nmeas = self._sizes(p)
         b_packed = np.empty((Nstate,), dtype=np.float64)
         x        = np.empty((Nmeas,),  dtype=np.float64)
-        stats = self.clib.mrcal_optimize(None if check_gradient else _ptr(b_packed), Nstate*8,
-                                         None if check_gradient else _ptr(x), Nmeas*8,
-                                         *self._common_args(p), check_gradient)
+        with _sigint_default():
+            stats = self.clib.mrcal_optimize(None if check_gradient else _ptr(b_packed), Nstate*8,
+                                             None if check_gradient else _ptr(x), Nmeas*8,
+                                             *self._common_args(p), check_gradient)
         if stats.rms_reproj_error__pixels < 0.0:
             raise RuntimeError("mrcal.optimize() failed!" + self._last_error())
         # (the C records of the triangulated observations are this wrapper's, as in mrcal-pywrap.c: the outlier bits the
@@ -454,9 +477,10 @@ class Api:
             Jt = CholmodSparse(nrow=Nstate, ncol=Nmeas, nzmax=Nnz,
                                p=P.ctypes.data, i=I.ctypes.data, x=X.ctypes.data,
                                stype=0, itype=0, xtype=1, dtype=0, sorted=1, packed=1)
-        ok = self.clib.mrcal_optimizer_callback(_ptr(b_packed), Nstate*8, _ptr(x), Nmeas*8,
-                                                C.byref(Jt) if Jt is not None else None,
-                                                *self._common_args(p))
+        with _sigint_default():
+            ok = self.clib.mrcal_optimizer_callback(_ptr(b_packed), Nstate*8, _ptr(x), Nmeas*8,
+                                                    C.byref(Jt) if Jt is not None else None,
+                                                    *self._common_args(p))
         if not ok:
             raise RuntimeError("mrcal_optimizer_callback() failed!" + self._last_error())
         J = None
@@ -496,12 +520,13 @@ class Api:
         i_f  = self.clib.mrcal_state_index_frames(0, *s)
         i_p  = self.clib.mrcal_state_index_points(0, *s)
         i_cw = self.clib.mrcal_state_index_calobject_warp(*s)
-        ok = self.clib._mrcal_drt_cross_reprojection__dbpacked(
-            *block(i_e), *block(i_f), *block(i_p), *block(i_cw),
-            icam, _ptr(b_packed), Nstate*8, C.byref(Jt),
-            p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
-            p.Nobservations_board, p.Nobservations_point,
-            C.byref(p.lensmodel), p.sel, p.width_n, p.height_n)
+        with _sigint_default():
+            ok = self.clib._mrcal_drt_cross_reprojection__dbpacked(
+                *block(i_e), *block(i_f), *block(i_p), *block(i_cw),
+                icam, _ptr(b_packed), Nstate*8, C.byref(Jt),
+                p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
+                p.Nobservations_board, p.Nobservations_point,
+                C.byref(p.lensmodel), p.sel, p.width_n, p.height_n)
         if not ok:
             raise RuntimeError("_mrcal_drt_cross_reprojection__dbpacked() failed" + self._last_error())
         return K

@@ -596,6 +596,12 @@ void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const i
                                 std::make_integer_sequence<int, 16>{});
 }
 
+// the ablation knob of the measurement builds (problem.hpp); a compile-time 0 in the shipped library
+#ifdef MRCAL_AMD_DEV
+#define ABLATE(P, bits) ((P).debug_ablate & (bits))
+#else
+#define ABLATE(P, bits) 0
+#endif
 #ifdef BOARD_TS
 #define TS(i) do { ts[i] = clock64(); } while(0)
 #define TSACC(i, t0) do { const long long _t = clock64(); ts[i] += _t - (t0); (t0) = _t; } while(0)
@@ -791,7 +797,7 @@ void board_kernel(DeviceProblem P,
         obs_lds[idx] = pool[idx < last ? idx : last];
     }
     __builtin_amdgcn_wave_barrier();   // obs_lds is complete (one wave: the LDS is in order)
-    if(P.debug_ablate & 16) { if(obs_lds[lane] + intr[0] + warp0 + jp[0] == 12345.678) x[0] = 1.0; return; }
+    if(ABLATE(P, 16)) { if(obs_lds[lane] + intr[0] + warp0 + jp[0] == 12345.678) x[0] = 1.0; return; }
 
 #ifdef BOARD_TS
     TS(1);
@@ -837,7 +843,7 @@ void board_kernel(DeviceProblem P,
                 p[i] = jp[JOINT_R+3*i+0]*bx + jp[JOINT_R+3*i+1]*by + jp[JOINT_R+3*i+2]*bz + jp[JOINT_T+i];
 
             double q[2], dq_dp[2][3], dq_dk[2][NDIST > 0 ? NDIST : 1];
-            if(P.debug_ablate & 4)
+            if(ABLATE(P, 4))
             {
                 q[0] = p[0]; q[1] = p[1];
 #pragma unroll
@@ -992,7 +998,7 @@ void board_kernel(DeviceProblem P,
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
             gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
-            if(ALLOPT || (WITH_GRAM && co_fast && !(P.debug_ablate & 3)))
+            if(ALLOPT || (WITH_GRAM && co_fast && !ABLATE(P, 3)))
             {
                 // all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
                 const int  rs    = ALLOPT ? co_rsub_c : co_rsub;
@@ -1010,7 +1016,7 @@ void board_kernel(DeviceProblem P,
                 TSACC(5, tcur);
                 continue;
             }
-            if(!(P.debug_ablate & 1))
+            if(!ABLATE(P, 1))
             {
                 if(co_fast && nrows == 64)
                 {
@@ -1048,7 +1054,7 @@ void board_kernel(DeviceProblem P,
             }
 
             TSACC(4, tcur);     // copy-out
-            if(WITH_GRAM && !(P.debug_ablate & 2))
+            if(WITH_GRAM && !ABLATE(P, 2))
             {
                 // G += Tt T over this half. 4 tile rows per k-step; the rows
                 // between nrows and the end of the last step belong to lanes
@@ -2272,7 +2278,7 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
         // (the ablation probes keep the general kernel)
         constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
         const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
-                            P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !P.debug_ablate;
+                            P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
         if(with_jacobian && B.gram != NULL && allopt)
         {
             if constexpr (kfull_even)

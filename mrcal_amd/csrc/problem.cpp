@@ -1249,8 +1249,12 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
 double mrcal_amd_problem_debug_time_evaluate(mrcal_amd_problem_t* p, bool with_gram, int ablate, int nrep)
 {
     if(with_gram && !problem_prepare_solver(p)) return -1.0;
+#ifdef MRCAL_AMD_DEV
     const int saved = p->D.debug_ablate;
     p->D.debug_ablate = ablate;
+#else
+    if(ablate != 0) { set_error("the ablation knob exists in measurement builds only (build.sh -DMRCAL_AMD_DEV)"); return -1.0; }
+#endif
     const EvalBuffers B = p->eval_buffers(p->icur, with_gram);
     double total = 0.0;
     for(int i=0; i<nrep+1; i++)
@@ -1261,11 +1265,14 @@ double mrcal_amd_problem_debug_time_evaluate(mrcal_amd_problem_t* p, bool with_g
         hipEventElapsedTime(&ms, p->ev_j0, p->ev_j1);
         if(i > 0) total += ms;
     }
+#ifdef MRCAL_AMD_DEV
     p->D.debug_ablate = saved;
+#endif
     return total/nrep;
 }
 
-// profiling builds (-DBOARD_TS): per-observation phase timestamps of ONE board
+#if defined(MRCAL_AMD_DEV) && defined(BOARD_TS)
+// measurement builds (-DMRCAL_AMD_DEV -DBOARD_TS): per-observation phase timestamps of ONE board
 // kernel launch, out[Nobs_board][8]. Returns the number of observations
 int mrcal_amd_problem_debug_timestamps(mrcal_amd_problem_t* p, bool with_gram, long long* out)
 {
@@ -1286,6 +1293,7 @@ int mrcal_amd_problem_debug_timestamps(mrcal_amd_problem_t* p, bool with_gram, l
     hipFree(d);
     return p->D.Nobs_board;
 }
+#endif
 
 double mrcal_amd_problem_last_jacobian_kernel_ms(mrcal_amd_problem_t* p)
 {

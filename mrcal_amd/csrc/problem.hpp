@@ -265,10 +265,13 @@ struct DeviceProblem
     // model configuration that is not in the intrinsics vector
     LensConfig cfg;
 
-    // performance-debugging knob (tools/probe_board.py): bit0 skip the J copy-out,
-    // bit1 skip the MFMAs, bit2 skip the projection arithmetic. 0 in production
+#ifdef MRCAL_AMD_DEV
+    // MEASUREMENT BUILDS ONLY (bash csrc/build.sh -DMRCAL_AMD_DEV [-DBOARD_TS ...] -> libmrcal_amd_dev.so; the shipped
+    // library has neither field nor any of the code behind them). Ablation knob of tools/probe_board.py: bit0 skip the J
+    // copy-out, bit1 skip the MFMAs, bit2 skip the projection arithmetic, bit4 exit after the start-up loads
     int debug_ablate;
-    long long* debug_ts;     // per-observation phase timestamps (profiling builds, -DBOARD_TS)
+    long long* debug_ts;     // per-observation phase timestamps (-DBOARD_TS)
+#endif
 
     // regularization
     int do_apply_regularization;

@@ -108,6 +108,15 @@ def test_callback_factorization_solves(amd, lensmodel, Ncam, Nf, with_points):
     if cond < 1e10:
         assert np.abs(xt - xtrue).max() < 1e-14*cond*10*np.abs(xtrue).max()
     assert 0. < F.rcond() <= 1.
+    # rcond() IS cholmod_rcond()'s definition for an LL' factor (mrcal-pywrap.c:576-592 -> cholmod_rcond():
+    # (min L_ii / max L_ii)^2), evaluated on THIS factor: numpy's Cholesky of the matrix in this factor's order
+    # (sys='P' applied to 0..Nstate-1 is the order) gives the same number. CHOLMOD's differs from it only through
+    # its own (AMD) ordering
+    order = F.solve_xt_JtJ_bt(np.arange(J.shape[1], dtype=float), sys="P").round().astype(int)
+    assert sorted(order) == list(range(J.shape[1]))
+    dL = np.diag(np.linalg.cholesky(N[np.ix_(order, order)]))
+    expected = (dL.min()/dL.max())**2
+    assert abs(F.rcond() - expected) < (1e-6 if cond < 1e10 else 0.5)*expected, (F.rcond(), expected, cond)
 
 
 MODELS = [

@@ -87,3 +87,28 @@ def test_optimize_rejects_callback_flags(ref_api, good):
     with pytest.raises(TypeError) as e:
         ref_api.optimize(no_jacobian=True, **copy_inputs(good))
     assert "invalid keyword argument" in str(e.value)
+
+
+def test_sigint_is_default_during_the_c_call_and_restored(ref_api):
+    """python-wrapping-utilities.h:18-32: SIGINT is SIG_DFL while the C code runs (so that Ctrl-C ends a long
+    solve) and Python's handler is back afterwards. Checked on the wrapper with the reference's library: no GPU"""
+    import signal
+    from mrcal_amd._api import _sigint_default
+    from mrcal_amd.synthetic import make_calibration_problem
+    mine = lambda *a: None
+    old = signal.signal(signal.SIGINT, mine)
+    try:
+        with _sigint_default():
+            assert signal.getsignal(signal.SIGINT) == signal.SIG_DFL
+        assert signal.getsignal(signal.SIGINT) is mine
+        oi, _ = make_calibration_problem(ref_api, Ncameras=1, Nframes=3, lensmodel="LENSMODEL_OPENCV4",
+                                         object_width_n=4, object_height_n=4, seed=1)
+        ref_api.optimizer_callback(no_factorization=True, **oi)
+        assert signal.getsignal(signal.SIGINT) is mine
+        # a failing call restores it too
+        import pytest
+        with pytest.raises(Exception):
+            ref_api.optimize(**dict(oi, lensmodel="LENSMODEL_NOSUCH"))
+        assert signal.getsignal(signal.SIGINT) is mine
+    finally:
+        signal.signal(signal.SIGINT, old)
