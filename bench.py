@@ -231,12 +231,30 @@ def main():
     nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
     assert n == args.steps
 
+    dt_rank = dt
     if sharded:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     st = problem.solver_stats()
+    per_rank = None
+    if sharded:
+        # what lets a scaling run be checked from its own line: every rank's wall clock over the
+        # timed steps, its shard of the Jacobian build against the HBM roofline (shard bytes / shard kernel time), the
+        # collectives it queued and how many ranks its transport says the communicator has
+        ci = problem.comm_info()
+        mine = dict(rank = rank, device = torch.cuda.current_device(), seconds = dt_rank,
+                    frames = list(problem.frame_range),
+                    board_kernel_ms_avg = (ktot_ms/nlaunch) if nlaunch else None,
+                    algorithmic_bytes_per_launch = problem.jacobian_algorithmic_bytes(),
+                    collectives = ci["Ncollectives"], collective_bytes = ci["bytes"],
+                    comm_world_observed = ci["world_observed"])
+        if mine["board_kernel_ms_avg"]:
+            mine["roofline_achieved_GBs"] = mine["algorithmic_bytes_per_launch"]/1e9/(mine["board_kernel_ms_avg"]*1e-3)
+            mine["roofline_frac"] = mine["roofline_achieved_GBs"]/HBM_PEAK_GBS
+        per_rank = [None]*world
+        dist.all_gather_object(per_rank, mine)
 
     # the dominant kernel: the board Jacobian build. Algorithmic bytes per
     # launch: per observation of P corners and k nonzeros per
@@ -314,6 +332,16 @@ def main():
         solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"],
                       **({"collectives": st["Ncollectives"]} if sharded else {})),
     )
+    if per_rank is not None:
+        secs = [r["seconds"] for r in per_rank]
+        result["ranks"] = per_rank
+        result["rank_seconds_max"] = max(secs)
+        result["rank_seconds_min"] = min(secs)
+        result["comm_world_observed"] = sorted(set(r["comm_world_observed"] for r in per_rank))
+        # (every rank queues the same collectives - the control block is replicated -; a scaling line whose ranks
+        #  disagree, or whose transport counts another number of ranks than the launcher's, measured something else)
+        result["consistent"] = (len(set(r["collectives"] for r in per_rank)) == 1 and
+                                result["comm_world_observed"] in ([world], [-1]))
 
     if ONE_DEVICE:
         result["transport"] = "host shared memory, all ranks on ONE device (MRCAL_AMD_BENCH_ONE_DEVICE=1): a check of the multi-rank path, NOT a measurement"

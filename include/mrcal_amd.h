@@ -580,6 +580,8 @@ void              mrcal_amd_comm_destroy(mrcal_amd_comm_t* comm);
 int               mrcal_amd_comm_rank (const mrcal_amd_comm_t* comm);
 int               mrcal_amd_comm_world(const mrcal_amd_comm_t* comm);
 long              mrcal_amd_comm_Ncollectives(const mrcal_amd_comm_t* comm);
+long long         mrcal_amd_comm_Ndoubles(const mrcal_amd_comm_t* comm);        /* doubles summed, over all collectives */
+int               mrcal_amd_comm_world_observed(const mrcal_amd_comm_t* comm);  /* ncclCommCount(): what the transport itself says */
 /* in-place sum over the ranks of n doubles in device memory, queued on the HIP stream */
 bool              mrcal_amd_comm_allreduce_sum(mrcal_amd_comm_t* comm, double* buf_dev, int64_t n, void* stream);
 

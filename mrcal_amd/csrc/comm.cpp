@@ -48,6 +48,7 @@ struct Rccl
     int         (*CommDestroy)(Comm) = NULL;
     int         (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = NULL;
     const char* (*GetErrorString)(int) = NULL;
+    int         (*CommCount)(Comm, int*) = NULL;
 };
 Rccl* rccl()
 {
@@ -68,6 +69,7 @@ Rccl* rccl()
     R.CommDestroy    = (int (*)(Comm))                       dlsym(h, "ncclCommDestroy");
     R.AllReduce      = (int (*)(const void*, void*, size_t, int, int, Comm, hipStream_t)) dlsym(h, "ncclAllReduce");
     R.GetErrorString = (const char* (*)(int))                dlsym(h, "ncclGetErrorString");
+    R.CommCount      = (int (*)(Comm, int*))                 dlsym(h, "ncclCommCount");        // (optional)
     if(!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce)
     {
         set_error("the RCCL library lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce");
@@ -143,6 +145,7 @@ struct mrcal_amd_comm
     HostTransport* host = NULL;
     int  rank  = 0, world = 1;
     long Ncollectives = 0;
+    long long Ndoubles = 0;      // summed over the collectives
 };
 
 extern "C" {
@@ -247,11 +250,24 @@ void mrcal_amd_comm_destroy(mrcal_amd_comm_t* c)
 int  mrcal_amd_comm_rank (const mrcal_amd_comm_t* c) { return c ? c->rank  : 0; }
 int  mrcal_amd_comm_world(const mrcal_amd_comm_t* c) { return c ? c->world : 1; }
 long mrcal_amd_comm_Ncollectives(const mrcal_amd_comm_t* c) { return c ? c->Ncollectives : 0; }
+long long mrcal_amd_comm_Ndoubles(const mrcal_amd_comm_t* c) { return c ? c->Ndoubles : 0; }
+// how many ranks the TRANSPORT says the communicator has (ncclCommCount(); the host transport's segment): what a
+// scaling run reports beside the world size it was told, -1 if the library cannot say
+int mrcal_amd_comm_world_observed(const mrcal_amd_comm_t* c)
+{
+    if(c == NULL) return 1;
+    if(c->host) return c->world;
+    Rccl* R = rccl();
+    int n = -1;
+    if(R && R->CommCount && c->comm && R->CommCount(c->comm, &n) == 0) return n;
+    return -1;
+}
 
 // in-place sum over the ranks of n doubles in device memory, queued on `stream`
 bool mrcal_amd_comm_allreduce_sum(mrcal_amd_comm_t* c, double* buf, int64_t n, void* stream)
 {
     if(c == NULL || n <= 0) return true;
+    c->Ndoubles += n;
     if(c->host)
     {
         HostTransport* T = c->host;

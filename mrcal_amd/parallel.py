@@ -285,6 +285,8 @@ def _declare_sharded(L):
     L.mrcal_amd_comm_create_host.restype, L.mrcal_amd_comm_create_host.argtypes = vp, [C.c_char_p, C.c_int, C.c_int]
     L.mrcal_amd_comm_destroy.restype,    L.mrcal_amd_comm_destroy.argtypes    = None, [vp]
     L.mrcal_amd_comm_Ncollectives.restype, L.mrcal_amd_comm_Ncollectives.argtypes = C.c_long, [vp]
+    L.mrcal_amd_comm_Ndoubles.restype, L.mrcal_amd_comm_Ndoubles.argtypes = C.c_longlong, [vp]
+    L.mrcal_amd_comm_world_observed.restype, L.mrcal_amd_comm_world_observed.argtypes = C.c_int, [vp]
     L.mrcal_amd_problem_attach_comm.restype,  L.mrcal_amd_problem_attach_comm.argtypes  = C.c_bool, [vp, vp]
     L.mrcal_amd_problem_gather_state.restype, L.mrcal_amd_problem_gather_state.argtypes = C.c_bool, [vp]
     L._mrcal_amd_sharded_declared = True
@@ -466,6 +468,15 @@ class ShardedProblem:
         if self.dogleg is not None:
             return self.comm.Ncollectives
         return int(self._lib.mrcal_amd_comm_Ncollectives(self._comm_handle))
+
+    def comm_info(self):
+        """dict(world_observed, Ncollectives, bytes) of this rank's communicator: the transport's own rank count
+        (ncclCommCount()), how many all-reduces it has queued and how many bytes they summed"""
+        if self.dogleg is not None:
+            return dict(world_observed=self.comm.world, Ncollectives=self.comm.Ncollectives, bytes=None)
+        return dict(world_observed=int(self._lib.mrcal_amd_comm_world_observed(self._comm_handle)),
+                    Ncollectives=int(self._lib.mrcal_amd_comm_Ncollectives(self._comm_handle)),
+                    bytes=8*int(self._lib.mrcal_amd_comm_Ndoubles(self._comm_handle)))
 
     def run_steps(self, Nsteps, trustregion=None):
         if self.dogleg is not None:

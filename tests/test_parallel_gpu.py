@@ -517,3 +517,11 @@ def test_bench_multi_rank_path_on_one_device(world):
     assert d["scaling"] == "strong" and d["unit"] == "iterations/s" and "NOT a measurement" in d["transport"]
     assert d["solver"]["collectives"] >= 2*d["solver"]["evaluations"]
     assert d["roofline"]["launches_timed"] > 0 and d["cpu_baseline"] is None
+    # the line checks itself: every rank reported, the same collectives on every rank, the transport's own count of
+    # the ranks, each rank's shard of the Jacobian build against the roofline, max and min of the ranks' clocks
+    assert len(d["ranks"]) == world and [r["rank"] for r in d["ranks"]] == list(range(world))
+    assert d["consistent"] and d["comm_world_observed"] == [world]
+    assert all(r["collectives"] == d["solver"]["collectives"] and r["collective_bytes"] > 0 for r in d["ranks"])
+    assert sum(r["frames"][1] - r["frames"][0] for r in d["ranks"]) == 40
+    assert all(r["roofline_frac"] > 0 for r in d["ranks"])
+    assert d["rank_seconds_min"] <= d["rank_seconds_max"] and abs(d["rank_seconds_max"]*1e3/6 - d["ms_per_step"]) < 1e-6
