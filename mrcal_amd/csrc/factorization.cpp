@@ -239,11 +239,14 @@ bool mrcal_amd_factorization_Jt_x(mrcal_amd_factorization_t* f, const double* x,
     last_error_string().clear();
     const size_t n = (size_t)f->nd.Nstate;
     HIP_TRY(hipMemcpyAsync(f->op.x, x, (size_t)f->Nmeas*sizeof(double), hipMemcpyHostToDevice, f->stream), return false);
-    HIP_TRY(hipMemsetAsync(f->d_sol, 0, n*sizeof(double), f->stream), return false);
-    HIP_TRY(launch_csr_Jt_x(f->Nmeas, f->d_Jp, f->d_Ji, f->op.Jv, f->op.x, f->d_sol, f->stream), return false);
-    HIP_TRY(hipMemcpyAsync(y, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), return false);
-    HIP_TRY(hipStreamSynchronize(f->stream), return false);
-    return true;
+    double* scratch = NULL;
+    HIP_TRY(hipMalloc((void**)&scratch, csr_Jt_x_scratch_doubles(f->Nmeas, (int)n)*sizeof(double)), return false);
+    bool ok = true;
+    HIP_TRY(launch_csr_Jt_x(f->Nmeas, (int)n, f->d_Jp, f->d_Ji, f->op.Jv, f->op.x, f->d_sol, scratch, f->stream), ok = false);
+    if(ok) HIP_TRY(hipMemcpyAsync(y, f->d_sol, n*sizeof(double), hipMemcpyDeviceToHost, f->stream), ok = false);
+    if(ok) HIP_TRY(hipStreamSynchronize(f->stream), ok = false);
+    hipFree(scratch);
+    return ok;
 }
 
 // out (Nx x Nx) = A Jt J At over the Nleading_rows_J leading rows of J, A (Nx x Nstate) row-major, host:
@@ -260,11 +263,11 @@ bool mrcal_amd_factorization_A_Jt_J_At(mrcal_amd_factorization_t* f, const doubl
     const size_t n = (size_t)f->nd.Nstate;
     double *dA = NULL, *dout = NULL;
     bool ok = true;
+    const size_t nscratch = (size_t)64*((Nleading_rows_J + 255)/256);
     HIP_TRY(hipMalloc((void**)&dA, (size_t)Nx*n*sizeof(double)), return false);
-    HIP_TRY(hipMalloc((void**)&dout, 64*sizeof(double)), ok = false);
+    HIP_TRY(hipMalloc((void**)&dout, (64 + nscratch)*sizeof(double)), ok = false);
     if(ok) HIP_TRY(hipMemcpyAsync(dA, A, (size_t)Nx*n*sizeof(double), hipMemcpyHostToDevice, f->stream), ok = false);
-    if(ok) HIP_TRY(hipMemsetAsync(dout, 0, 64*sizeof(double), f->stream), ok = false);
-    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, (int)n, f->d_Jp, f->d_Ji, f->op.Jv, dA, dout, f->stream), ok = false);
+    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, (int)n, f->d_Jp, f->d_Ji, f->op.Jv, dA, dout, dout + 64, f->stream), ok = false);
     if(ok) HIP_TRY(hipMemcpyAsync(out, dout, (size_t)Nx*Nx*sizeof(double), hipMemcpyDeviceToHost, f->stream), ok = false);
     if(ok) HIP_TRY(hipStreamSynchronize(f->stream), ok = false);
     hipFree(dA); hipFree(dout);
@@ -314,11 +317,10 @@ bool mrcal_amd_csr_Jt_x(int Nrows, int Ncols, const int32_t* Jp, const int32_t* 
     double *dx = NULL, *dy = NULL;
     bool ok = true;
     HIP_TRY(hipMalloc((void**)&dx, (size_t)(Nrows > 0 ? Nrows : 1)*sizeof(double)), return false);
-    HIP_TRY(hipMalloc((void**)&dy, (size_t)(Ncols > 0 ? Ncols : 1)*sizeof(double)), ok = false);
+    HIP_TRY(hipMalloc((void**)&dy, ((size_t)(Ncols > 0 ? Ncols : 1) + csr_Jt_x_scratch_doubles(Nrows, Ncols))*sizeof(double)), ok = false);
     if(ok) HIP_TRY(hipMemcpy(dx, x, (size_t)Nrows*sizeof(double), hipMemcpyHostToDevice), ok = false);
-    if(ok) HIP_TRY(hipMemset(dy, 0, (size_t)Ncols*sizeof(double)), ok = false);
     if(ok) HIP_TRY(hipDeviceSynchronize(), ok = false);
-    if(ok) HIP_TRY(launch_csr_Jt_x(Nrows, J.Jp, J.Ji, J.Jx, dx, dy, NULL), ok = false);
+    if(ok) HIP_TRY(launch_csr_Jt_x(Nrows, Ncols, J.Jp, J.Ji, J.Jx, dx, dy, dy + (Ncols > 0 ? Ncols : 1), NULL), ok = false);
     if(ok) HIP_TRY(hipMemcpy(y, dy, (size_t)Ncols*sizeof(double), hipMemcpyDeviceToHost), ok = false);
     hipFree(dx); hipFree(dy);
     return ok;
@@ -339,12 +341,12 @@ bool mrcal_amd_csr_A_Jt_J_At(int Nrows, int Ncols, const int32_t* Jp, const int3
     if(!J.ok) { set_error("could not put J on the device"); return false; }
     double *dA = NULL, *dout = NULL;
     bool ok = true;
+    const size_t nscratch = (size_t)64*((Nleading_rows_J + 255)/256);
     HIP_TRY(hipMalloc((void**)&dA, (size_t)Nx*Ncols*sizeof(double)), return false);
-    HIP_TRY(hipMalloc((void**)&dout, 64*sizeof(double)), ok = false);
+    HIP_TRY(hipMalloc((void**)&dout, (64 + nscratch)*sizeof(double)), ok = false);
     if(ok) HIP_TRY(hipMemcpy(dA, A, (size_t)Nx*Ncols*sizeof(double), hipMemcpyHostToDevice), ok = false);
-    if(ok) HIP_TRY(hipMemset(dout, 0, 64*sizeof(double)), ok = false);
     if(ok) HIP_TRY(hipDeviceSynchronize(), ok = false);
-    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, Ncols, J.Jp, J.Ji, J.Jx, dA, dout, NULL), ok = false);
+    if(ok) HIP_TRY(launch_csr_A_Jt_J_At(Nx, Nleading_rows_J, Ncols, J.Jp, J.Ji, J.Jx, dA, dout, dout + 64, NULL), ok = false);
     if(ok) HIP_TRY(hipMemcpy(out, dout, (size_t)Nx*Nx*sizeof(double), hipMemcpyDeviceToHost), ok = false);
     hipFree(dA); hipFree(dout);
     return ok;

@@ -4490,46 +4490,67 @@ void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* 
 
 // ---- the consumers of J that mrcal's projection uncertainty uses (mrcal-genpywrap.py:477-731), on the
 // device-resident CSR J of a factorization
-// y = Jt x, atomics into y (zeroed by the caller). 64 rows per wave, grouped as in rows_generic_wave(): the
-// rows of a half-wave that have the columns of its first pending row are summed across the half, and one
-// lane adds the sums. (One lane per row: 37 M atomics on 6140 addresses, 200 000 of them on each intrinsic: 41 ms)
+// y = Jt x without atomics (round 4: the same bits every time, like the solve). The rows are cut into chunks of a
+// fixed number of rows (a function of the matrix's shape alone); ONE wave walks a chunk's rows in order, a lane per
+// entry of the row, adding into the chunk's own copy of y in LDS - the columns of one row are distinct, so a wave
+// instruction never adds to one address twice, and consecutive rows are consecutive instructions of the same wave: the
+// order of every sum is the row order. The chunks' copies go to part[chunk][.] and csr_Jt_x_sum_kernel adds them per
+// column in chunk order. A y longer than the LDS tile is done in column tiles (a pass over the chunk's rows each).
+// (History: one lane per row with atomics, 41 ms at the metric's size; rows of a half-wave with the same columns summed
+//  first, then atomics, 2.1 ms; this - see profiles/r04_*)
+#define JTX_TILE 7680          // doubles of y per pass: 60 KB of LDS
 __global__ __launch_bounds__(64)
-void csr_Jt_x_kernel(int Nrows, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, const double* __restrict__ Jx,
-                     const double* __restrict__ x, double* __restrict__ y)
+void csr_Jt_x_chunk_kernel(int Nrows, int Ncols, int rows_per_chunk, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                           const double* __restrict__ Jx, const double* __restrict__ x, double* __restrict__ part)
 {
-    const int lane = threadIdx.x & 63, half = lane >> 5, first = half << 5;
-    const int r = blockIdx.x*64 + 2*(lane & 31) + half;
-    const bool valid = r < Nrows;
-    const int p0 = valid ? Jp[r] : 0, p1 = valid ? Jp[r+1] : 0;
-    const int len = p1 - p0;
-    const double xr = valid ? x[r] : 0.0;
-    bool todo = valid && xr != 0.0;
-    while(__any(todo))
+    __shared__ double acc[JTX_TILE];
+    const int lane = threadIdx.x;
+    const int r0 = blockIdx.x*rows_per_chunk, r1 = min(Nrows, r0 + rows_per_chunk);
+    double* __restrict__ out = part + (size_t)blockIdx.x*Ncols;
+    for(int c0 = 0; c0 < Ncols; c0 += JTX_TILE)
     {
-        const unsigned long long pending = __ballot(todo);
-        const unsigned mine = (unsigned)(pending >> first);
-        const bool active = mine != 0u;
-        const int  leader = first + (active ? __ffs(mine) - 1 : 0);
-        const int  lp0 = __shfl(p0, leader), llen = active ? __shfl(len, leader) : 0;
-        const int  lenmax = max(__shfl(llen, 0), __shfl(llen, 32));
-        const int32_t* __restrict__ cols = Ji + lp0;
-        bool member = todo && len == llen;
-        for(int k = 0; k < lenmax; k++)
-            if(member && k < llen) member = Ji[p0 + k] == cols[k];
-        const bool adder = active && lane == leader;
-        if(__popcll(__ballot(member)) < 8)
+        const int nc = min(JTX_TILE, Ncols - c0);
+        for(int i = lane; i < nc; i += 64) acc[i] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        for(int r = r0; r < r1; r++)
         {
-            // no runs: one lane per row for what is pending
-            if(todo) for(int p = p0; p < p1; p++) atomicAdd(&y[Ji[p]], Jx[p]*xr);
-            return;
+            const double xr = x[r];
+            if(xr == 0.0) continue;                         // (wave-uniform; outlier rows are all zero)
+            const int p0 = Jp[r], p1 = Jp[r+1];
+            for(int p = p0 + lane; p < p1; p += 64)
+            {
+                const int c = Ji[p] - c0;
+                if(c >= 0 && c < nc) acc[c] += Jx[p]*xr;
+            }
+            // (a row longer than 64 entries: its later entries are later instructions; LDS serves a wave in order)
         }
-        for(int k = 0; k < lenmax; k++)
-        {
-            const double sk = half_wave_sum_f64((member && k < llen) ? Jx[p0 + k]*xr : 0.0);
-            if(adder && k < llen) atomicAdd(&y[cols[k]], sk);
-        }
-        todo = todo && !member;
+        __builtin_amdgcn_wave_barrier();
+        for(int i = lane; i < nc; i += 64) out[c0 + i] = acc[i];
+        __builtin_amdgcn_wave_barrier();
     }
+}
+__global__ __launch_bounds__(256)
+void csr_Jt_x_sum_kernel(int Ncols, int Nchunks, const double* __restrict__ part, double* __restrict__ y)
+{
+    const int c = blockIdx.x*blockDim.x + threadIdx.x;
+    if(c >= Ncols) return;
+    double a = 0.0;
+    for(int k = 0; k < Nchunks; k++) a += part[(size_t)k*Ncols + c];
+    y[c] = a;
+}
+// how many chunks / rows per chunk for a matrix of this shape (and nothing else: the summation order must not
+// depend on the device or on the day)
+int csr_Jt_x_chunks(int Nrows, int* rows_per_chunk)
+{
+    int rpc = (Nrows + 1023)/1024;
+    if(rpc < 512) rpc = 512;
+    *rows_per_chunk = rpc;
+    return (Nrows + rpc - 1)/rpc;
+}
+size_t csr_Jt_x_scratch_doubles(int Nrows, int Ncols)
+{
+    int rpc;
+    return (size_t)csr_Jt_x_chunks(Nrows, &rpc)*(size_t)(Ncols > 0 ? Ncols : 1);
 }
 // out (NX x NX) += sum over the leading rows of outer(A j, A j), A (NX x Nstate) row-major
 template<int NX>
@@ -4560,27 +4581,44 @@ void csr_A_Jt_J_At_kernel(int Nrows, int Nstate, const int32_t* __restrict__ Jp,
             if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][i*NX + j] = v;
         }
     __syncthreads();
+    // (per-workgroup partials, added in workgroup order by csr_A_Jt_J_At_sum_kernel: no atomics, the same bits every time)
     if(threadIdx.x < NX*NX)
-        atomicAdd(&out[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+        out[(size_t)blockIdx.x*64 + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
-hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream)
+__global__ __launch_bounds__(64)
+void csr_A_Jt_J_At_sum_kernel(int n, int Nblocks, const double* __restrict__ part, double* __restrict__ out)
 {
-    if(Nrows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(csr_Jt_x_kernel, dim3((Nrows + 63)/64), dim3(64), 0, stream, Nrows, Jp, Ji, Jx, x, y);
+    if((int)threadIdx.x >= n) return;
+    double a = 0.0;
+    for(int k = 0; k < Nblocks; k++) a += part[(size_t)k*64 + threadIdx.x];
+    out[threadIdx.x] = a;
+}
+// scratch: csr_Jt_x_scratch_doubles(Nrows, Ncols) doubles. y need not be cleared
+hipError_t launch_csr_Jt_x(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y,
+                           double* scratch, hipStream_t stream)
+{
+    if(Ncols <= 0) return hipSuccess;
+    if(Nrows <= 0) return hipMemsetAsync(y, 0, (size_t)Ncols*sizeof(double), stream);
+    int rpc;
+    const int nchunks = csr_Jt_x_chunks(Nrows, &rpc);
+    hipLaunchKernelGGL(csr_Jt_x_chunk_kernel, dim3(nchunks), dim3(64), 0, stream, Nrows, Ncols, rpc, Jp, Ji, Jx, x, scratch);
+    hipLaunchKernelGGL(csr_Jt_x_sum_kernel, dim3((Ncols + 255)/256), dim3(256), 0, stream, Ncols, nchunks, scratch, y);
     return hipGetLastError();
 }
+// scratch: 64 doubles per 256 rows ((Nrows + 255)/256 * 64)
 hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,
-                                const double* A, double* out, hipStream_t stream)
+                                const double* A, double* out, double* scratch, hipStream_t stream)
 {
-    if(Nrows <= 0) return hipSuccess;
+    if(Nrows <= 0) return hipMemsetAsync(out, 0, (size_t)NX*NX*sizeof(double), stream);
     const dim3 g((Nrows + 255)/256), b(256);
     switch(NX)
     {
-#define CASE(n) case n: hipLaunchKernelGGL(csr_A_Jt_J_At_kernel<n>, g, b, 0, stream, Nrows, Nstate, Jp, Ji, Jx, A, out); break;
+#define CASE(n) case n: hipLaunchKernelGGL(csr_A_Jt_J_At_kernel<n>, g, b, 0, stream, Nrows, Nstate, Jp, Ji, Jx, A, scratch); break;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     default: return hipErrorInvalidValue;
     }
+    hipLaunchKernelGGL(csr_A_Jt_J_At_sum_kernel, dim3(1), dim3(64), 0, stream, NX*NX, (int)g.x, scratch, out);
     return hipGetLastError();
 }
 

@@ -333,9 +333,13 @@ hipError_t launch_fsolve_sys_batch(const NormalDims& nd, const FactorBuffers& F,
                                    const double* b, double* x, int nrhs,
                                    double* y, double* r, double* part, size_t part_per_rhs, hipStream_t stream);
 // y += Jt x ; out (NX x NX) += A Jt J At over the leading rows (mrcal-genpywrap.py:477-731), CSR J on the device
-hipError_t launch_csr_Jt_x(int Nrows, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y, hipStream_t stream);
+// y = Jt x and A Jt J At of a device-resident CSR matrix, in a fixed summation order (no atomics). scratch:
+// csr_Jt_x_scratch_doubles(Nrows, Ncols) doubles for the first, 64*((Nrows + 255)/256) for the second
+size_t csr_Jt_x_scratch_doubles(int Nrows, int Ncols);
+hipError_t launch_csr_Jt_x(int Nrows, int Ncols, const int32_t* Jp, const int32_t* Ji, const double* Jx, const double* x, double* y,
+                           double* scratch, hipStream_t stream);
 hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp, const int32_t* Ji, const double* Jx,
-                                const double* A, double* out, hipStream_t stream);
+                                const double* A, double* out, double* scratch, hipStream_t stream);
 // out2[0] = min, out2[1] = max of the factor's diagonal; preset to (+big, 0)
 hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream);
 // the normal equations of a bare CSR matrix into the blocks of R's operating point

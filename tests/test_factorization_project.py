@@ -271,6 +271,13 @@ def test_Jt_x_and_A_Jt_J_At(amd):
                           amd._A_Jt_J_At(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead))
     with pytest.raises(RuntimeError, match="Nleading_rows_J must be passed"):
         amd._A_Jt_J_At(A, J.indptr, J.indices, J.data)
+    # the same bits every time: no floating-point atomics behind either product (round 4)
+    for rep in range(3):
+        out2 = np.zeros((Nstate,))
+        amd._Jt_x(J.indptr, J.indices, J.data, x, out=out2)
+        assert np.array_equal(out2, out) and np.array_equal(F._Jt_x(x), out)
+        assert np.array_equal(amd._A_Jt_J_At(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead),
+                              amd._A_Jt_J_At__2(A, J.indptr, J.indices, J.data, Nleading_rows_J=Nlead))
     # a malformed CSR is an error, not an out-of-bounds write on the device
     bad = J.indices.copy(); bad[7] = Nstate + 3
     with pytest.raises(RuntimeError, match="column index"):
@@ -287,3 +294,21 @@ def test_Jt_x_and_A_Jt_J_At(amd):
     JtJ = (J.T @ J).toarray()
     Ad = np.linalg.solve(JtJ, dF.T).T
     assert np.abs(Var - Ad @ Jl.T @ Jl @ Ad.T).max() < 1e-7*np.abs(Var).max()
+
+
+@pytest.mark.timeout(600)
+def test_Jt_x_at_the_metric_size_is_exact_and_reproducible(amd):
+    """y = Jt x at 1.6 M x 6140 with 37 M entries, and with a y longer than one LDS tile (16 cameras x 1400 frames:
+    8684 columns, two tiles): against scipy, and the same bits three times"""
+    for Ncameras, Nframes in ((8, 1000), (16, 1400)):
+        oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel="LENSMODEL_OPENCV8",
+                                         object_width_n=10, object_height_n=10, seed=0)
+        _, x, J, _ = amd.optimizer_callback(no_factorization=True, **oi)
+        ref = J.T @ x
+        outs = []
+        for rep in range(3):
+            out = np.zeros((J.shape[1],))
+            amd._Jt_x(J.indptr, J.indices, J.data, x, out=out)
+            outs.append(out)
+        assert np.abs(outs[0] - ref).max() < 1e-11*np.abs(ref).max()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
