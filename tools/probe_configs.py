@@ -27,6 +27,8 @@ CONFIGS = (("0: 1 cam x 40 frames OPENCV4",            lambda: board(Ncameras=1,
            ("3: 16 cams x 2000 frames OPENCV8",        lambda: board(Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8")),
            ("4: SfM, 4 cams, 20k triangulated points", sfm),
            ("5: SfM + boards, 4 cams, 20k triangulated points, 400 board frames", sfm_boards))
+print("(board problems, the splined one included: make_calibration_problem(seed=2); the SfM ones sfm_problem(seed=6). bench.py's solve of the metric's problem is seed 0)")
+print()
 print("| configuration | Nstate | Nmeas | Nnz(J) | trial step | full solve (iterations, outlier passes) |")
 print("|---|---|---|---|---|---|")
 only = [a for a in sys.argv[1:]]          # e.g. "3": just that configuration (for rocprofv3)
