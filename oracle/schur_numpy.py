@@ -85,9 +85,16 @@ def normal_equations(J, x, lay):
     return A, Bt, D, gS, gE
 
 
-def gauss_newton_step_schur(J, x, lay):
-    """d (Nstate) with (JtJ) d = -Jt x, by block elimination of the frames + one dense Cholesky"""
+def _damp(A, D, mu):
+    if mu > 0.0:
+        A = A + mu*np.eye(A.shape[0]); D = D + mu*np.eye(6)[None]
+    return A, D
+
+
+def gauss_newton_step_schur(J, x, lay, mu=0.0):
+    """d (Nstate) with (JtJ + mu I) d = -Jt x, by block elimination of the frames + one dense Cholesky"""
     A, Bt, D, gS, gE = normal_equations(J, x, lay)
+    A, D = _damp(A, D, mu)
     L  = np.linalg.cholesky(D)                                       # batched dpotrf
     Li = np.linalg.inv(L)                                            # 6x6 triangles: cheaper than a batched gesv of 140 columns
     Wt = np.matmul(Li, Bt)                                           # L^-1 Bt   (Nf,6,Nc)
@@ -104,11 +111,12 @@ def gauss_newton_step_schur(J, x, lay):
     return d
 
 
-def gauss_newton_step_superlu(J, x, lay):
+def gauss_newton_step_superlu(J, x, lay, mu=0.0):
     """the same blocks assembled into one sparse matrix and handed to scipy.sparse.linalg.splu (SuperLU: an LU
     factorization with partial pivoting, NOT a Cholesky - the SciPy solver SURVEY.md 8d names)"""
     import scipy.sparse.linalg
     A, Bt, D, gS, gE = normal_equations(J, x, lay)
+    A, D = _damp(A, D, mu)
     Nf, Nc = lay.Nframes, lay.Nc
     B  = sp.csr_matrix(Bt.reshape(6*Nf, Nc))
     Dm = sp.block_diag([D[f] for f in range(Nf)], format="csr") if Nf < 64 else \
@@ -153,28 +161,34 @@ def with_state(api, oi, b_packed, copy_inputs):
 
 
 def timed_trial_steps(api, oi, Nsteps, solver, copy_inputs):
-    """Nsteps trial steps on the host: each = one optimizer_callback() of `api` (the reference's) at the trial point
-    + (when the point was accepted) one Gauss-Newton solve by `solver` (gauss_newton_step_schur / _superlu). A
-    trial whose cost went up is rejected and the step halved, the way a trust region would shrink. Returns
-    dict(seconds, seconds_callback, seconds_solve, Ntrials, Nsolves, cost0, cost1)"""
+    """Nsteps trial steps on the host, each EXACTLY the metric's unit (one residual + Jacobian evaluation
+    and one normal-equation solve): the step from the current point by `solver` (gauss_newton_step_schur / _superlu)
+    with the current damping, then one optimizer_callback() of `api` (the reference's) at the trial point. Levenberg's
+    rule stands in for the trust region: a trial whose cost went up is rejected and the damping raised (x10, from
+    1e-3 of the mean diagonal), an accepted one lowers it (/10, to 0 below 1e-6 of it) - so a rejected trial is followed
+    by a NEW solve, as a dog-leg step with a smaller radius would reuse the old one: this loop never solves less often
+    than the product does. Returns dict(seconds, seconds_callback, seconds_solve, Ntrials, Nsolves, cost0, cost1)"""
     import time
     lay = BoardLayout(api, oi)
     t_cb = t_sv = 0.0
     t0 = time.perf_counter()
     b, x, J, _ = api.optimizer_callback(no_factorization=True, **copy_inputs(oi))
     cost = cost0 = float(x @ x)
+    scale = float((J.multiply(J)).sum())/J.shape[1]                 # mean diagonal of JtJ
+    mu = 0.0
     Ntrials = Nsolves = 0
-    d, scale = None, 1.0
     while Ntrials < Nsteps:
-        if d is None:
-            t = time.perf_counter(); d = solver(J, x, lay); t_sv += time.perf_counter() - t
-            Nsolves += 1; scale = 1.0
+        t = time.perf_counter(); d = solver(J, x, lay, mu); t_sv += time.perf_counter() - t
+        Nsolves += 1
         t = time.perf_counter()
-        bt, xt, Jt, _ = api.optimizer_callback(no_factorization=True, **with_state(api, oi, b + scale*d, copy_inputs))
+        bt, xt, Jt, _ = api.optimizer_callback(no_factorization=True, **with_state(api, oi, b + d, copy_inputs))
         t_cb += time.perf_counter() - t
         Ntrials += 1
         ct = float(xt @ xt)
-        if ct < cost: b, x, J, cost, d = bt, xt, Jt, ct, None
-        else:         scale *= 0.5
+        if ct < cost:
+            b, x, J, cost = bt, xt, Jt, ct
+            mu = mu/10.0 if mu > 1e-6*scale else 0.0
+        else:
+            mu = max(10.0*mu, 1e-3*scale)
     return dict(seconds=time.perf_counter() - t0, seconds_callback=t_cb, seconds_solve=t_sv, Ntrials=Ntrials,
                 Nsolves=Nsolves, cost0=cost0, cost1=cost)

@@ -84,3 +84,59 @@ def test_verbose_reports_and_does_not_change_the_solve(amd):
                                      object_width_n=4, object_height_n=3, seed=2, make_outliers=False)
     s = amd.optimize(**oi)
     assert ("rms %.12g" % s["rms_reproj_error__pixels"]) in out
+
+
+TRAJECTORY_SCRIPT = r'''
+import sys, os, numpy as np
+sys.path.insert(0, %(root)r)
+which = sys.argv[1]
+import mrcal_amd
+from mrcal_amd._cabi import MrcalLib
+from mrcal_amd._api  import Api
+from mrcal_amd.synthetic import make_calibration_problem
+api = mrcal_amd._api if which == "amd" else Api(MrcalLib(%(reflib)r))
+oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=2, Nframes=50, lensmodel="LENSMODEL_OPENCV4",
+                                 object_width_n=8, object_height_n=7, seed=11, make_outliers=False)
+oi["do_apply_outlier_rejection"] = False
+if which == "amd": oi["verbose"] = True
+s = api.optimize(**oi)
+print("rms %%.15g" %% s["rms_reproj_error__pixels"])
+'''
+
+
+def test_the_trajectory_is_the_restated_libdoglegs_step_for_step():
+    """Not only the same optimum: the same SEQUENCE of trial points. The device-side dog-leg (eager Gauss-Newton, all
+    decisions on the GPU: csrc/solver_kernels.hip "dog-leg control") and the restated libdogleg (lazy Gauss-Newton, the
+    published loop: oracle/dogleg_restated.c) driving the reference's own callback, on a well-conditioned calibration
+    from the same seed: the cost after every trial step - accepted or rejected - and the trust region it was taken
+    with, side by side from the two traces. (What this can pin is the restatement, not libdogleg itself: DESIGN.md 3)"""
+    import re
+    if not os.path.exists(REFLIB_PATH):
+        pytest.skip("oracle/_ref/libmrcal_ref.so is not built")
+    def run(which, env):
+        r = subprocess.run([sys.executable, "-c", TRAJECTORY_SCRIPT % dict(root=ROOT, reflib=REFLIB_PATH), which],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout, r.stderr
+    out_a, err_a = run("amd", {})
+    out_r, err_r = run("ref", {"DOGLEG_RESTATED_TRACE": "1"})
+    # the checker: "step N: norm2_x A -> B; expected improvement ..., got ...; rho R; trustregion T" per TRIAL
+    ref = [(float(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)))
+           for m in re.finditer(r"step \\d+: norm2_x (\\S+) -> (\\S+); expected improvement \\S+, got \\S+; rho (\\S+); trustregion (\\S+)", err_r)]
+    # the product: "trial N: accepted K tr T |x|^2 C ..." per trial, C = the cost of the CURRENT point after the trial
+    ours = [(int(m.group(1)), float(m.group(2)), float(m.group(3)))
+            for m in re.finditer(r"trial\\s+\\d+: accepted\\s+(\\d+) tr (\\S+)\\s+\\|x\\|\\^2 (\\S+)", err_a)]
+    assert len(ref) > 8 and len(ours) >= len(ref)
+    # the cost of the current point after each of the checker's trials: the new one if rho > 0, else the old one
+    cost_ref = [b if rho > 0 else a for a, b, rho, tr in ref]
+    naccepted_ref = np.cumsum([rho > 0 for a, b, rho, tr in ref])
+    n = len(ref)
+    cost_a = np.array([c for k, tr, c in ours[:n]])
+    assert np.array_equal(np.array([k for k, tr, c in ours[:n]]), naccepted_ref), "accept/reject decisions differ"
+    # (8 significant digits are printed on the checker's side)
+    assert np.abs(cost_a - np.array(cost_ref)).max() < 2e-7*cost_ref[0], (cost_a, cost_ref)
+    # the trust region each trial left behind: the checker prints the one it was TAKEN with, ours the one after
+    tr_after_ref = [tr for a, b, rho, tr in ref[1:]]
+    tr_after_a   = [tr for k, tr, c in ours[:n-1]]
+    assert np.abs(np.array(tr_after_a)/np.array(tr_after_ref) - 1).max() < 1e-3
+    assert out_a.split()[-1][:12] == out_r.split()[-1][:12]
