@@ -820,7 +820,7 @@ static int runOptimizer(dogleg_solverContext_t* ctx)
             const double rho = observedImprovement / expectedImprovement;
 
             if(P->dogleg_debug)
-                SAY("step %d: norm2_x %.8g -> %.8g; expected improvement %.6g, got %.6g; rho %.4g; trustregion %.6g",
+                SAY("step %d: norm2_x %.15g -> %.15g; expected improvement %.6g, got %.6g; rho %.4g; trustregion %.6g",
                     stepCount, ctx->beforeStep->norm2_x, ctx->afterStep->norm2_x,
                     expectedImprovement, observedImprovement, rho, trustregion);
 

@@ -95,8 +95,9 @@ from mrcal_amd._cabi import MrcalLib
 from mrcal_amd._api  import Api
 from mrcal_amd.synthetic import make_calibration_problem
 api = mrcal_amd._api if which == "amd" else Api(MrcalLib(%(reflib)r))
-oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=2, Nframes=50, lensmodel="LENSMODEL_OPENCV4",
-                                 object_width_n=8, object_height_n=7, seed=11, make_outliers=False)
+# (OPENCV8 with its 1 %% of gross outliers left in and outlier rejection off: a few dozen steps that mean something)
+oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=2, Nframes=30, lensmodel="LENSMODEL_OPENCV8",
+                                 object_width_n=8, object_height_n=7, seed=11)
 oi["do_apply_outlier_rejection"] = False
 if which == "amd": oi["verbose"] = True
 s = api.optimize(**oi)
@@ -122,21 +123,32 @@ def test_the_trajectory_is_the_restated_libdoglegs_step_for_step():
     out_r, err_r = run("ref", {"DOGLEG_RESTATED_TRACE": "1"})
     # the checker: "step N: norm2_x A -> B; expected improvement ..., got ...; rho R; trustregion T" per TRIAL
     ref = [(float(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)))
-           for m in re.finditer(r"step \\d+: norm2_x (\\S+) -> (\\S+); expected improvement \\S+, got \\S+; rho (\\S+); trustregion (\\S+)", err_r)]
+           for m in re.finditer(r"step \d+: norm2_x (\S+) -> (\S+); expected improvement \S+, got \S+; rho (\S+); trustregion (\S+)", err_r)]
     # the product: "trial N: accepted K tr T |x|^2 C ..." per trial, C = the cost of the CURRENT point after the trial
+    # (the first line is the evaluation of the seed in the checker's count of steps? no: both count trial steps)
     ours = [(int(m.group(1)), float(m.group(2)), float(m.group(3)))
-            for m in re.finditer(r"trial\\s+\\d+: accepted\\s+(\\d+) tr (\\S+)\\s+\\|x\\|\\^2 (\\S+)", err_a)]
+            for m in re.finditer(r"trial\s+\d+: accepted\s+(\d+) tr (\S+)\s+\|x\|\^2 (\S+)", err_a)]
     assert len(ref) > 8 and len(ours) >= len(ref)
     # the cost of the current point after each of the checker's trials: the new one if rho > 0, else the old one
     cost_ref = [b if rho > 0 else a for a, b, rho, tr in ref]
     naccepted_ref = np.cumsum([rho > 0 for a, b, rho, tr in ref])
-    n = len(ref)
+    # ... for as long as the steps mean something: once a step changes the cost in its 10th digit and beyond, the sign
+    # of the gain ratio - accept or reject - is rounding noise in either solver (they go on for a dozen such trials)
+    n = 0
+    while n < len(ref) and abs(ref[n][1] - ref[n][0]) > 1e-10*ref[n][0]: n += 1
+    assert n >= 8, n
+    naccepted_ref = naccepted_ref[:n]; cost_ref = cost_ref[:n]; ref = ref[:n]
     cost_a = np.array([c for k, tr, c in ours[:n]])
     assert np.array_equal(np.array([k for k, tr, c in ours[:n]]), naccepted_ref), "accept/reject decisions differ"
-    # (8 significant digits are printed on the checker's side)
-    assert np.abs(cost_a - np.array(cost_ref)).max() < 2e-7*cost_ref[0], (cost_a, cost_ref)
+    # The costs along the way: equal to what two exact factorizations of the same JtJ (condition 1e12: OPENCV8) leave of
+    # a step - observed 1.2e-7 relative after the first step (from the identical seed cost, 311135.2423000849 in
+    # both), 4e-8 after the second, 1e-11 from the tenth on. (10 significant digits are printed on the product's side)
+    assert np.abs(cost_a/np.array(cost_ref) - 1).max() < 1e-6, (cost_a, cost_ref)
+    assert np.abs(cost_a[-3:]/np.array(cost_ref[-3:]) - 1).max() < 1e-9
+    print(f"{n} trial steps compared, {int(naccepted_ref[-1])} of them accepted: cost {cost_ref[0]:.10g} -> {cost_ref[-1]:.10g}")
     # the trust region each trial left behind: the checker prints the one it was TAKEN with, ours the one after
     tr_after_ref = [tr for a, b, rho, tr in ref[1:]]
     tr_after_a   = [tr for k, tr, c in ours[:n-1]]
     assert np.abs(np.array(tr_after_a)/np.array(tr_after_ref) - 1).max() < 1e-3
-    assert out_a.split()[-1][:12] == out_r.split()[-1][:12]
+    # and where they end: the same rms to 10 digits
+    assert abs(float(out_a.split()[-1]) - float(out_r.split()[-1])) < 1e-10*float(out_r.split()[-1])
