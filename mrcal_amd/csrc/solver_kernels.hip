@@ -2768,7 +2768,7 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
 // rows r0 .. r0+63 (up to the rhs row n) of a panel:  L21 = M21 L11^-T, in place
 __device__ __forceinline__
 void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __restrict__ X, int b,
-                      double* __restrict__ MI, double* __restrict__ Xs)
+                      double* __restrict__ MI, double* __restrict__ Xs, double* __restrict__ zc)
 {
     constexpr int NB = LCH_NB, LD = LCH_NB + 1;
     const int t = threadIdx.x, lane = t & 63;
@@ -2794,15 +2794,120 @@ void lchol_trsm_block(int n, double* __restrict__ M, int j0, const double* __res
         {
             const int i = 16*wi + kq + 4*v, j = 16*wc + r16;
             if(r0 + i <= n && j < nb) M[(size_t)(r0 + i)*n + j0 + j] = l[v];
+            // (the solved right-hand side z = L^-1 r once more, outside the matrix: lchol_apply_inverse_kernel reads
+            //  it while it writes the solution over row n)
+            if(r0 + i == n && j < nb && zc != NULL) zc[j0 + j] = l[v];
         }
     }
 }
+
+// ---- L^-1 on the side (round 4), so that the solve needs no backward sweep.
+// The sweep L^T d = z is a chain of panels again, and every link wants the whole block column of L below it: one
+// workgroup streams it at ~50 GB/s, so it went in four groups of panels - seven launches, 103 us of configuration 2's
+// 930. Instead Y = L^-1 (lower triangular, 64 x 64 blocks Y_pq, p >= q, Y_pp = X_p) is built WHILE the panels are
+// factored, in workgroups of the same launches on CUs that have nothing to do, and the solve ends with one product
+// d = -Y^T z. Column block q of Y is a forward substitution of its own:
+//     Y_pq = -X_p ( T_pq + L_{p,p-1} Y_{p-1,q} ),      T_pq = sum_{k=q}^{p-2} L_pk Y_kq
+//   chain workgroup (p, q), in the launch after panel p-1 was solved (launch p+1): the two products above; T_pq is
+//     complete by then and lives where Y_pq goes
+//   tile workgroup (p, q, k), p >= k+2, in the launch after row k of Y was made (launch k+2): T_pq (+)= L_pk Y_kq;
+//     the first contribution (k == q) writes, the others add - one launch apart each, and never in the launch in which
+//     the chain reads T_pq (its last tile contribution, k = p-2, is one launch earlier)
+// Twice the flops of the factorization, none of them on its critical path: a chain workgroup is two 64^3 products
+// (14k cycles of a 43k-cycle launch), a launch has at most ~100 of the tiles
+// Yb: [npad][npad] row-major, npad = 64 npanels. Blocks of L come from M (rows >= n: zero), X_p from Linv
+__device__ __forceinline__
+void lchol_inverse_block(int n, int npad, const double* __restrict__ M, const double* __restrict__ Linv, double* __restrict__ Yb,
+                         int p, int q, int k, bool chain, double* __restrict__ LA, double* __restrict__ LB, double* __restrict__ LX)
+{
+    constexpr int NB = LCH_NB, LD = LCH_NB + 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    auto tile_of = [&](int u, int* wi, int* wc) { const int w = wave_u + LCH_NW*u; *wi = w >> 2; *wc = w & 3; };
+    // chain: k = p-1. A = L_pk (rows of block p, columns of block k), B = Y_kq, transposed into LDS for A B
+    const double* __restrict__ Ysrc = (k == q) ? Linv + (size_t)k*NB*NB : Yb + (size_t)k*NB*npad + (size_t)q*NB;
+    const int ldy = (k == q) ? NB : npad;
+    double* __restrict__ Tdst = Yb + (size_t)p*NB*npad + (size_t)q*NB;
+    const bool have_T = chain ? (q <= p - 2) : (k > q);
+    {
+        constexpr int NIT = NB*NB/LCH_THREADS;
+        double va[NIT], vb[NIT], vx[NIT];
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, c = idx - i*NB;
+            const int row = p*NB + i;
+            va[u] = M[(size_t)(row < n ? row : 0)*n + k*NB + c];         // (block k is a full block: k < p)
+            if(row >= n) va[u] = 0.0;
+            vb[u] = Ysrc[(size_t)i*ldy + c];
+            vx[u] = chain ? Linv[(size_t)p*NB*NB + idx] : 0.0;
+        }
+#pragma unroll
+        for(int u = 0; u < NIT; u++)
+        {
+            const int idx = t + LCH_THREADS*u;
+            const int i = idx / NB, c = idx - i*NB;
+            LA[i*LD + c] = va[u];
+            // (X_k as Y_kk: its upper triangle is not kept clean by the factorization: only j <= i counts)
+            LB[c*LD + i] = (k == q && c > i) ? 0.0 : vb[u];
+            if(chain) LX[i*LD + c] = (c <= i) ? vx[u] : 0.0;
+        }
+    }
+    __syncthreads();
+    syrk_d4 acc[LCH_TPW];
+#pragma unroll
+    for(int u = 0; u < LCH_TPW; u++)
+    {
+        int wi, wc; tile_of(u, &wi, &wc);
+        acc[u] = lch_tile_ABt(LA, LB, wi, wc, r16, kq, false);
+        if(have_T)
+        {
+#pragma unroll
+            for(int v = 0; v < 4; v++) acc[u][v] += Tdst[(size_t)(16*wi + kq + 4*v)*npad + 16*wc + r16];
+        }
+    }
+    if(!chain)
+    {
+#pragma unroll
+        for(int u = 0; u < LCH_TPW; u++)
+        {
+            int wi, wc; tile_of(u, &wi, &wc);
+#pragma unroll
+            for(int v = 0; v < 4; v++) Tdst[(size_t)(16*wi + kq + 4*v)*npad + 16*wc + r16] = acc[u][v];
+        }
+        return;
+    }
+    // Y_pq = -X_p (T + L Y): the sum, transposed, where A was
+    __syncthreads();
+#pragma unroll
+    for(int u = 0; u < LCH_TPW; u++)
+    {
+        int wi, wc; tile_of(u, &wi, &wc);
+#pragma unroll
+        for(int v = 0; v < 4; v++) LA[(16*wc + r16)*LD + 16*wi + kq + 4*v] = acc[u][v];
+    }
+    __syncthreads();
+#pragma unroll
+    for(int u = 0; u < LCH_TPW; u++)
+    {
+        int wi, wc; tile_of(u, &wi, &wc);
+        // (X_p is lower triangular: row block wi has nothing beyond k = 16 wi + 15)
+        const syrk_d4 y = lch_tile_ABt(LX, LA, wi, wc, r16, kq, true, 16*(wi + 1));
+#pragma unroll
+        for(int v = 0; v < 4; v++) Tdst[(size_t)(16*wi + kq + 4*v)*npad + 16*wc + r16] = y[v];
+    }
+}
 // block 0: the next panel's diagonal block (if there is a next panel); then the tiles; then the previous panel's solve
+// what a launch does for Y = L^-1 (lchol_inverse_block): the chain of row block prow (prow workgroups, q < prow) and the
+// tiles fed by row block krow (targets p = krow+2 .. npanels-1, q <= krow); -1: none
+struct LcholInverseWork { double* Yb; double* zc; const double* Linv; int npad, npanels, prow, krow, nchain, ntile; };
 __global__ __launch_bounds__(LCH_THREADS)
 void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
                         int j0, const double* __restrict__ X, int ntiles,
                         double* __restrict__ Xnext, int* __restrict__ status,
-                        int jprev, const double* __restrict__ Xprev, int ntrsm)
+                        int jprev, const double* __restrict__ Xprev, int ntrsm, LcholInverseWork W)
 {
     if(skip != NULL && *skip) return;
     __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
@@ -2822,7 +2927,60 @@ void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict_
     if(Xnext != NULL) __builtin_amdgcn_s_sleep(127);
 #endif
     if(b < ntiles) lchol_update_tile(n, M, j0, X, b, MI, MC, Xs);
-    else if(b < ntiles + ntrsm) lchol_trsm_block(n, M, jprev, Xprev, b - ntiles, MI, Xs);
+    else if(b < ntiles + ntrsm) lchol_trsm_block(n, M, jprev, Xprev, b - ntiles, MI, Xs, W.zc);
+    else if(b < ntiles + ntrsm + W.nchain)
+        lchol_inverse_block(n, W.npad, M, W.Linv, W.Yb, W.prow, b - ntiles - ntrsm, W.prow - 1, true, MI, MC, Xs);
+    else if(b < ntiles + ntrsm + W.nchain + W.ntile)
+    {
+        const int w = b - ntiles - ntrsm - W.nchain;
+        const int nq = W.krow + 1;
+        lchol_inverse_block(n, W.npad, M, W.Linv, W.Yb, W.krow + 2 + w/nq, w % nq, W.krow, false, MI, MC, Xs);
+    }
+}
+
+// d = -Y^T z with Y = L^-1 in 64 x 64 blocks (diagonal blocks: X_p in Linv; the others: Yb), z = zc; the result over row n
+// of M (which held z). One workgroup of 256 per 16 columns (a row of 16 doubles is one 128-byte line): 16 slices of the
+// rows, added in slice order. (A workgroup per 64 columns - 19 of them at 1206 variables, the first one walking 617 KB
+// alone - took 16 us; 76 of these take the same 5.8 MB through four times as many CUs)
+#define LCH_AI_COLS 16
+__global__ __launch_bounds__(256)
+void lchol_apply_inverse_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, const double* __restrict__ Linv,
+                                const double* __restrict__ Yb, const double* __restrict__ zc, int npad)
+{
+    if(skip != NULL && *skip) return;
+    constexpr int NB = LCH_NB;
+    __shared__ double part[16][LCH_AI_COLS];
+    const int t = threadIdx.x, j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
+    const int c = blockIdx.x*LCH_AI_COLS + j16;
+    const int q = c / NB, j = c - q*NB;
+    double a0 = 0.0, a1 = 0.0;
+    if(c < n)
+    {
+        // the diagonal block: Y[i][c] = X_q[i - 64 q][j], i >= c
+        const double* __restrict__ X = Linv + (size_t)q*NB*NB;
+        for(int i = j + slice; i < NB && q*NB + i < n; i += 16)
+            a0 = fma(X[(size_t)i*NB + j], zc[q*NB + i], a0);
+        const double* __restrict__ col = Yb + c;
+        int i = (q + 1)*NB + slice;
+        constexpr int UB = 8;
+        for(; i + 16*(UB-1) < n; i += 16*UB)
+        {
+            double v[UB], z[UB];
+#pragma unroll
+            for(int u = 0; u < UB; u++) { v[u] = col[(size_t)(i + 16*u)*npad]; z[u] = zc[i + 16*u]; }
+#pragma unroll
+            for(int u = 0; u < UB; u += 2) { a0 = fma(v[u], z[u], a0); a1 = fma(v[u+1], z[u+1], a1); }
+        }
+        for(; i < n; i += 16) a0 = fma(col[(size_t)i*npad], zc[i], a0);
+    }
+    part[slice][j16] = a0 + a1;
+    __syncthreads();
+    if(t < LCH_AI_COLS && c < n)
+    {
+        double sacc = 0.0;
+        for(int k = 0; k < 16; k++) sacc += part[k][t];
+        M[(size_t)n*n + c] = -sacc;
+    }
 }
 
 // L^T d = z, panel by panel from the last: one workgroup. z is row n of M; on
@@ -2940,12 +3098,31 @@ void lchol_backward_apply_kernel(int n, const int* __restrict__ skip, double* __
     if(t < LCH_NB && c < row_lo) z[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
+// the workspace behind FactorBuffers::Linv: [npanels][64][64] inverse diagonal blocks | Yb [npad][npad] | zc [npad]
+static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB; }
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    const int npad    = (int)lchol_npad(n);
+    double* Yb = Linv + (size_t)npanels*LCH_NB*LCH_NB;
+    double* zc = Yb + (size_t)npad*npad;
+    // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
+    // L^-1 built on the side (lchol_inverse_block); for comparisons
+    static const bool sweep = (getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
     auto Xof = [&](int p) { return Linv + (size_t)p*LCH_NB*LCH_NB; };
     // rows below a panel, the rhs row included, in blocks of 64 (the panel solve's)
     auto ntrsm_of = [&](int p) { const int m0 = std::min(n, (p + 1)*LCH_NB); return (n + 1 - m0 + LCH_NB - 1)/LCH_NB; };
+    // launch l (0 .. npanels): the chain of row block l-1 of Y, the tiles fed by row block l-2
+    auto inverse_work = [&](int l)
+    {
+        LcholInverseWork W;
+        W.Yb = Yb; W.zc = zc; W.Linv = Linv; W.npad = npad; W.npanels = npanels;
+        W.prow = l - 1; W.krow = l - 2; W.nchain = 0; W.ntile = 0;
+        if(sweep) { W.zc = NULL; return W; }
+        if(W.prow >= 1 && W.prow < npanels) W.nchain = W.prow;
+        if(W.krow >= 0 && W.krow + 2 < npanels) W.ntile = (npanels - W.krow - 2)*(W.krow + 1);
+        return W;
+    };
     hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n, skip, M, 0, Xof(0), status);
     for(int p = 0; p < npanels; p++)
     {
@@ -2956,15 +3133,25 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         const int nbt = (n - m0 + LCH_NB - 1)/LCH_NB;
         const int ntiles = has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
         const int ntrsm  = (p > 0) ? ntrsm_of(p - 1) : 0;
-        if(!has_next && ntrsm == 0) continue;
-        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm), dim3(LCH_THREADS), 0, stream,
+        const LcholInverseWork W = inverse_work(p);
+        if(!has_next && ntrsm == 0 && W.nchain + W.ntile == 0) continue;
+        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm + W.nchain + W.ntile), dim3(LCH_THREADS), 0, stream,
                            n, skip, M, j0, (const double*)Xof(p), ntiles, has_next ? Xof(p + 1) : (double*)NULL, status,
-                           (p > 0) ? j0 - LCH_NB : 0, (const double*)((p > 0) ? Xof(p - 1) : Xof(0)), ntrsm);
+                           (p > 0) ? j0 - LCH_NB : 0, (const double*)((p > 0) ? Xof(p - 1) : Xof(0)), ntrsm, W);
     }
-    // the last panel's solve: the rhs row alone
-    hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1)), dim3(LCH_THREADS), 0, stream,
-                       n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
-                       (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1));
+    // the last panel's solve: the rhs row alone (and the last row block of Y)
+    {
+        const LcholInverseWork W = inverse_work(npanels);
+        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1) + W.nchain + W.ntile), dim3(LCH_THREADS), 0, stream,
+                           n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
+                           (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1), W);
+    }
+    if(!sweep)
+    {
+        hipLaunchKernelGGL(lchol_apply_inverse_kernel, dim3((n + LCH_AI_COLS - 1)/LCH_AI_COLS), dim3(256), 0, stream, n, skip, M,
+                           (const double*)Linv, (const double*)Yb, (const double*)zc, npad);
+        return hipGetLastError();
+    }
     // the backward sweep, in groups of panels (see lchol_backward_kernel)
     const int ngroups = (npanels >= 12) ? 4 : (npanels >= 6) ? 2 : 1;
     for(int g = ngroups - 1; g >= 0; g--)
@@ -2980,7 +3167,8 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
 size_t cholesky_large_workspace_doubles(int n)
 {
     if(chol_fits_lds(n)) return 1;       // the LDS kernel serves
-    return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB*LCH_NB;
+    const size_t npad = lchol_npad(n);
+    return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB*LCH_NB + npad*npad + npad;
 }
 
 // d_e = -L^-T (y_e + Wt_e d_s);  also scatters d_s into the state-ordered step
