@@ -715,6 +715,10 @@ mrcal_amd_factorization_t*
 mrcal_amd_factorization_create(int Nmeas, int Nstate,
                                const int32_t* rowptr, const int32_t* colidx, const double* values,
                                int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp);
+/* The same object from a resident problem, at its current state: x, J and the block normal equations by the problem's own
+   kernels (no atomics: the same bits every time), copied device to device. What optimizer_callback() returns */
+mrcal_amd_factorization_t* mrcal_amd_factorization_create_from_problem(mrcal_amd_problem_t* problem);
+int    mrcal_amd_factorization_Nmeasurements(const mrcal_amd_factorization_t* f);
 void   mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f);
 int    mrcal_amd_factorization_Nstate (const mrcal_amd_factorization_t* f);
 /* xt[i,:] = (JtJ)^-1 bt[i,:]; host, C-contiguous (Nrhs,Nstate) */

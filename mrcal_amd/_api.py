@@ -537,6 +537,14 @@ class Api:
         if not self.lib.has_symbol("mrcal_amd_factorization_create"):
             return None
         from ._factorization import CHOLMOD_factorization
+        if self.lib.has_symbol("mrcal_amd_factorization_create_from_problem"):
+            # from a resident copy of the problem at the same state: its own atomics-free normal equations, and the
+            # 466 MB of CSR (at the metric's size) that just came down do not go back up
+            from .resident import Problem
+            from . import _lib
+            if _lib is self.lib:
+                with Problem(_ingested=p) as prob:
+                    return prob.factorization()
         s = (p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
              p.Nobservations_board, p.sel, C.byref(p.lensmodel))
         Ni  = self.clib.mrcal_num_states_intrinsics(p.Ncameras_intrinsics, p.sel, C.byref(p.lensmodel))

@@ -30,6 +30,23 @@ import numpy as np
 
 
 class CHOLMOD_factorization:
+    @classmethod
+    def _from_problem(cls, problem):
+        """the factorization of JtJ at a resident problem's current state, from the problem's own (atomics-free) normal
+        equations: what optimizer_callback() returns. None if JtJ is singular"""
+        from . import _lib
+        L = _lib.lib
+        cls._declare(L)
+        h = L.mrcal_amd_factorization_create_from_problem(problem.handle)
+        if not h:
+            return None
+        self = cls.__new__(cls)
+        self._L = L
+        self._h = h
+        self._Nstate = int(L.mrcal_amd_factorization_Nstate(h))
+        self._Nmeas  = int(L.mrcal_amd_factorization_Nmeasurements(h))
+        return self
+
     def __init__(self, J=None, _partition=None):
         import scipy.sparse
         from . import _lib
@@ -62,6 +79,10 @@ class CHOLMOD_factorization:
         vp = C.c_void_p
         L.mrcal_amd_factorization_create.restype  = vp
         L.mrcal_amd_factorization_create.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.mrcal_amd_factorization_create_from_problem.restype  = vp
+        L.mrcal_amd_factorization_create_from_problem.argtypes = [vp]
+        L.mrcal_amd_factorization_Nstate.restype, L.mrcal_amd_factorization_Nstate.argtypes = C.c_int, [vp]
+        L.mrcal_amd_factorization_Nmeasurements.restype, L.mrcal_amd_factorization_Nmeasurements.argtypes = C.c_int, [vp]
         L.mrcal_amd_factorization_destroy.restype  = None
         L.mrcal_amd_factorization_destroy.argtypes = [vp]
         L.mrcal_amd_factorization_solve.restype  = C.c_bool

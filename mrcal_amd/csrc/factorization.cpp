@@ -20,6 +20,7 @@
 #include "problem.hpp"
 #include "kernels.hpp"
 #include "solver_kernels.hpp"
+#include "problem_object.hpp"
 #include "../../include/mrcal_amd.h"
 
 using namespace mrcal_amd;
@@ -80,40 +81,18 @@ struct mrcal_amd_factorization
 
 extern "C" {
 
-mrcal_amd_factorization_t*
-mrcal_amd_factorization_create(int Nmeas, int Nstate,
-                               const int32_t* rowptr, const int32_t* colidx, const double* values,
-                               int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp)
+// the buffers of a factorization of this shape; nd and br are the caller's
+static mrcal_amd_factorization* factorization_alloc(const NormalDims& nd_in, const BlockRanges& br, int Nmeas, int64_t Nnz)
 {
-    last_error_string().clear();
-    if(mrcal_amd_device_count() <= 0)
-    {
-        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
-        return NULL;
-    }
-    const int NE = 6*Nframe_blocks + 3*Npoint_blocks;
-    if(Nstate_shared_leading < 0 || Nstate_shared_leading + NE + Nwarp != Nstate ||
-       (Nwarp != 0 && Nwarp != 2) || Nmeas < 0)
-    {
-        set_error("inconsistent state partition: %d + 6*%d + 3*%d + %d != %d",
-                  Nstate_shared_leading, Nframe_blocks, Npoint_blocks, Nwarp, Nstate);
-        return NULL;
-    }
-    const int64_t Nnz = rowptr[Nmeas];
     mrcal_amd_factorization* f = new mrcal_amd_factorization();
     f->Nmeas = Nmeas;
-    NormalDims& nd = f->nd;
-    nd.Nstate = Nstate; nd.Nwarp = Nwarp;
-    nd.i_state_warp = Nstate - Nwarp; nd.Nc = Nstate_shared_leading + nd.Nwarp;
-    normal_dims_set_partition(nd, Nstate_shared_leading);
-    nd.NE = NE; nd.Nfb = Nframe_blocks; nd.Npb = Npoint_blocks; nd.NEb = nd.Nfb + nd.Npb;
-    f->br.frame_lo = 0; f->br.frame_hi = nd.Nfb; f->br.point_lo = nd.Nfb; f->br.point_hi = nd.NEb;
+    f->nd = nd_in; f->br = br;
+    const NormalDims& nd = f->nd;
     if((double)nd.Nc*nd.Nc*8.0 > 64e9)
     {
         set_error("the dense block of this factorization would be %d x %d: too large", nd.Nc, nd.Nc);
         delete f; return NULL;
     }
-
     bool ok = true;
     memset(&f->op, 0, sizeof(f->op));
     HIP_TRY(hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking), ok = false);
@@ -140,22 +119,15 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     ok = ok && f->alloc(&f->d_mm, 2);
     if(!ok) { delete f; return NULL; }
     f->F.r = f->F.S + (size_t)nd.Nc*nd.Nc;
-
-    HIP_TRY(hipMemcpy(f->d_Jp, rowptr, ((size_t)Nmeas+1)*sizeof(int32_t), hipMemcpyHostToDevice), ok = false);
-    HIP_TRY(hipMemcpy(f->d_Ji, colidx, (size_t)Nnz*sizeof(int32_t),        hipMemcpyHostToDevice), ok = false);
-    HIP_TRY(hipMemcpy(f->op.Jv, values, (size_t)Nnz*sizeof(double),        hipMemcpyHostToDevice), ok = false);
-    // (on f->stream: it is a non-blocking stream, which does not order itself behind the null stream's memsets)
-    HIP_TRY(hipMemsetAsync(f->op.x, 0, (size_t)(Nmeas > 0 ? Nmeas : 1)*sizeof(double), f->stream), ok = false);
-    HIP_TRY(hipMemcpy(f->d_op, &f->op, sizeof(OpDev), hipMemcpyHostToDevice), ok = false);
-    HIP_TRY(hipMemsetAsync(f->F.status, 0, sizeof(int), f->stream), ok = false);
-    if(!ok) { delete f; return NULL; }
-
-    // (the partition is validated by the assembly itself, on the device: a row that touches two eliminated
-    //  blocks or has a column out of range raises SC_BAD_STRUCTURE. A loop over all entries on the host was
-    //  25 ms at 37 M entries)
+    return f;
+}
+// the blocks of f->op hold the normal equations: eliminate, factor, check. Deletes f on failure
+static mrcal_amd_factorization* factorization_finish(mrcal_amd_factorization* f)
+{
+    const NormalDims& nd = f->nd;
+    bool ok = true;
     const OpRef R = { f->d_op, NULL, NULL };
-    HIP_TRY(launch_assemble_rows(nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream), ok = false);
-    if(ok) HIP_TRY(launch_factor_local(nd, f->br, R, f->F, 0.0, NULL, true, f->stream), ok = false);
+    HIP_TRY(launch_factor_local(nd, f->br, R, f->F, 0.0, NULL, true, f->stream), ok = false);
     if(ok) HIP_TRY(launch_solve_backsub(nd, f->br, R, f->F, NULL, true, f->stream), ok = false);
     int status = 0;
     double bad_structure = 0.0;
@@ -178,6 +150,101 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     }
     return f;
 }
+
+mrcal_amd_factorization_t*
+mrcal_amd_factorization_create(int Nmeas, int Nstate,
+                               const int32_t* rowptr, const int32_t* colidx, const double* values,
+                               int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp)
+{
+    last_error_string().clear();
+    if(mrcal_amd_device_count() <= 0)
+    {
+        set_error("no HIP device is visible: libmrcal_amd has no CPU fallback");
+        return NULL;
+    }
+    const int NE = 6*Nframe_blocks + 3*Npoint_blocks;
+    if(Nstate_shared_leading < 0 || Nstate_shared_leading + NE + Nwarp != Nstate ||
+       (Nwarp != 0 && Nwarp != 2) || Nmeas < 0)
+    {
+        set_error("inconsistent state partition: %d + 6*%d + 3*%d + %d != %d",
+                  Nstate_shared_leading, Nframe_blocks, Npoint_blocks, Nwarp, Nstate);
+        return NULL;
+    }
+    const int64_t Nnz = rowptr[Nmeas];
+    NormalDims nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.Nstate = Nstate; nd.Nwarp = Nwarp;
+    nd.i_state_warp = Nstate - Nwarp; nd.Nc = Nstate_shared_leading + nd.Nwarp;
+    normal_dims_set_partition(nd, Nstate_shared_leading);
+    nd.NE = NE; nd.Nfb = Nframe_blocks; nd.Npb = Npoint_blocks; nd.NEb = nd.Nfb + nd.Npb;
+    BlockRanges br;
+    memset(&br, 0, sizeof(br));
+    br.frame_lo = 0; br.frame_hi = nd.Nfb; br.point_lo = nd.Nfb; br.point_hi = nd.NEb;
+    mrcal_amd_factorization* f = factorization_alloc(nd, br, Nmeas, Nnz);
+    if(f == NULL) return NULL;
+
+    bool ok = true;
+    HIP_TRY(hipMemcpy(f->d_Jp, rowptr, ((size_t)Nmeas+1)*sizeof(int32_t), hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemcpy(f->d_Ji, colidx, (size_t)Nnz*sizeof(int32_t),        hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemcpy(f->op.Jv, values, (size_t)Nnz*sizeof(double),        hipMemcpyHostToDevice), ok = false);
+    // (on f->stream: it is a non-blocking stream, which does not order itself behind the null stream's memsets)
+    HIP_TRY(hipMemsetAsync(f->op.x, 0, (size_t)(Nmeas > 0 ? Nmeas : 1)*sizeof(double), f->stream), ok = false);
+    HIP_TRY(hipMemcpy(f->d_op, &f->op, sizeof(OpDev), hipMemcpyHostToDevice), ok = false);
+    HIP_TRY(hipMemsetAsync(f->F.status, 0, sizeof(int), f->stream), ok = false);
+    if(!ok) { delete f; return NULL; }
+
+    // (the partition is validated by the assembly itself, on the device: a row that touches two eliminated
+    //  blocks or has a column out of range raises SC_BAD_STRUCTURE. A loop over all entries on the host was
+    //  25 ms at 37 M entries)
+    // This assembly goes row by row with atomics (rows_generic_kernel): exact to rounding, not the same bits twice.
+    // The factorization optimizer_callback() returns does not come through here: mrcal_amd_factorization_create_from_problem()
+    const OpRef R = { f->d_op, NULL, NULL };
+    HIP_TRY(launch_assemble_rows(f->nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream), { delete f; return NULL; });
+    return factorization_finish(f);
+}
+
+// The factorization of JtJ at the problem's current state, from the problem itself (round 4): x, J and the block
+// normal equations are evaluated by the problem's own kernels - the per-observation Grams, the fixed-order sums:
+// no atomics, the same bits every time - and copied device to device; then the same elimination and Cholesky as
+// above. What optimizer_callback() returns is built this way: the CSR it hands to the caller does not come back up
+// across PCIe (31 ms at the metric's size), and nothing in it depends on the order in which atomics landed
+mrcal_amd_factorization_t* mrcal_amd_factorization_create_from_problem(mrcal_amd_problem_t* P)
+{
+    last_error_string().clear();
+    if(P == NULL) { set_error("no problem"); return NULL; }
+    if((int)P->board_sel.size() != P->L.dims.Nobservations_board || P->comm != NULL)
+    {
+        set_error("factorization: this problem is a shard (it holds a part of the rows)");
+        return NULL;
+    }
+    if(!problem_prepare_solver(P)) return NULL;
+    if(!problem_evaluate_op(P, P->icur, true, true)) return NULL;
+    const mrcal_amd_oppoint& N = P->op[P->icur];
+    mrcal_amd_factorization* f = factorization_alloc(P->nd, P->br, P->L.Nmeas, P->Nnz);
+    if(f == NULL) return NULL;
+    const NormalDims& nd = f->nd;
+    bool ok = true;
+    hipStream_t st = P->stream;
+    auto copy = [&](void* dst, const void* src, size_t bytes)
+    {
+        if(ok && bytes > 0) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st), ok = false);
+    };
+    copy(f->d_Jp,  P->d_Jp, ((size_t)P->L.Nmeas + 1)*sizeof(int32_t));
+    copy(f->d_Ji,  P->d_Ji, (size_t)P->Nnz*sizeof(int32_t));
+    copy(f->op.Jv, N.Jv,    (size_t)P->Nnz*sizeof(double));
+    copy(f->op.A,  N.A,     (size_t)nd.Nc*nd.Nc*sizeof(double));
+    copy(f->op.Bt, N.Bt,    (size_t)nd.NE*nd.Nc*sizeof(double));
+    copy(f->op.D,  N.D,     (size_t)nd.NEb*36*sizeof(double));
+    copy(f->op.g,  N.g,     (size_t)nd.Nstate*sizeof(double));
+    copy(f->op.scalars, N.scalars, (size_t)NSCALARS*sizeof(double));
+    if(ok) HIP_TRY(hipStreamSynchronize(st), ok = false);
+    if(ok) HIP_TRY(hipMemcpy(f->d_op, &f->op, sizeof(OpDev), hipMemcpyHostToDevice), ok = false);
+    if(ok) HIP_TRY(hipMemsetAsync(f->F.status, 0, sizeof(int), f->stream), ok = false);
+    if(ok) HIP_TRY(hipMemsetAsync(f->op.x, 0, (size_t)(f->Nmeas > 0 ? f->Nmeas : 1)*sizeof(double), f->stream), ok = false);
+    if(!ok) { delete f; return NULL; }
+    return factorization_finish(f);
+}
+int mrcal_amd_factorization_Nmeasurements(const mrcal_amd_factorization_t* f) { return f->Nmeas; }
 
 void mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f) { delete f; }
 int  mrcal_amd_factorization_Nstate(const mrcal_amd_factorization_t* f) { return f->nd.Nstate; }

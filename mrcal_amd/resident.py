@@ -18,12 +18,14 @@ class Problem:
         x = p.x()                    # host copies on demand
     """
 
-    def __init__(self, _shard=(0,-1), _leader=True, _shard_points=(0,-1), _shard_tripoints=(0,-1), **optimization_inputs):
+    def __init__(self, _shard=(0,-1), _leader=True, _shard_points=(0,-1), _shard_tripoints=(0,-1), _ingested=None,
+                 **optimization_inputs):
         from . import _api, _lib
         self._api = _api
         self._lib = _lib.lib
         self._declare()
-        p = _api._ingest(optimization_inputs, callback=False)
+        # (_ingested: the marshalled arguments of an optimizer_callback() call, which holds them already)
+        p = _ingested if _ingested is not None else _api._ingest(optimization_inputs, callback=False)
         self._inputs = p   # keeps the numpy arrays alive
         a = _api._common_args(p)
         # common args: ..., lensmodel, imagersizes, sel, problem_constants, spacing, W, H, verbose
@@ -176,6 +178,12 @@ class Problem:
         self._lib.mrcal_amd_problem_solver_stats(self.handle, *[C.byref(v) for v in i], *[C.byref(v) for v in d])
         return dict(Niterations=i[0].value, Nevaluations=i[1].value, Nfactorizations=i[2].value,
                     Noutlier_passes=i[3].value, norm2_x=d[0].value, lambda_=d[1].value, seconds=d[2].value)
+
+    def factorization(self):
+        """CHOLMOD_factorization of JtJ at the resident state (None if singular), from this problem's own normal
+        equations: no atomics anywhere (include/mrcal_amd.h, mrcal_amd_factorization_create_from_problem)"""
+        from ._factorization import CHOLMOD_factorization
+        return CHOLMOD_factorization._from_problem(self)
 
     def normal_equations(self):
         """evaluates at the resident state; returns dict(A,Bt,D,g,norm2_x,+dims). Nie is S_split (== the partition()'s):

@@ -312,3 +312,31 @@ def test_Jt_x_at_the_metric_size_is_exact_and_reproducible(amd):
             outs.append(out)
         assert np.abs(outs[0] - ref).max() < 1e-11*np.abs(ref).max()
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_callback_factorization_is_the_problems_own_and_reproducible(amd):
+    """optimizer_callback()'s factorization comes from the resident problem's atomics-free normal equations
+    (mrcal_amd_factorization_create_from_problem): the same bits twice, and the same solve - to what two exact
+    factorizations of a badly conditioned matrix leave of it - as the factorization built from the returned matrix"""
+    oi, _ = make_calibration_problem(amd._api, Ncameras=3, Nframes=12, lensmodel="LENSMODEL_OPENCV8",
+                                     object_width_n=8, object_height_n=7, seed=5)
+    b, x, J, F  = amd.optimizer_callback(**oi)
+    _, _, _, F2 = amd.optimizer_callback(**oi)
+    assert F is not None and F2 is not None
+    rng = np.random.RandomState(1)
+    bt = rng.normal(size=(4, J.shape[1]))
+    xt = F.solve_xt_JtJ_bt(bt)
+    assert np.array_equal(xt, F2.solve_xt_JtJ_bt(bt))
+    assert F.rcond() == F2.rcond()
+    Fj = amd.CHOLMOD_factorization(J, _partition=None) if J.shape[1] < 400 else None
+    Jd = J.toarray(); N = Jd.T @ Jd
+    resid = np.abs(xt @ N - bt).max() / (np.abs(N).max()*np.abs(xt).max())
+    assert resid < 1e-10
+    # the products the uncertainty code takes from the resident J
+    xx = rng.normal(size=(J.shape[0],))
+    assert np.abs(F._Jt_x(xx) - J.T @ xx).max() < 1e-11*np.abs(J.T @ xx).max()
+    assert np.array_equal(F._Jt_x(xx), F2._Jt_x(xx))
+    # a state where JtJ is singular: None, like the reference (mrcal-pywrap.c:1981-1988)
+    o2 = dict(oi, do_apply_regularization=False)
+    o2["observations_board"] = oi["observations_board"].copy(); o2["observations_board"][..., 2] = -1.     # nothing observed
+    assert amd.optimizer_callback(**o2)[3] is None
