@@ -269,6 +269,8 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
         joint_pose_record(rec, NULL, rt_frame);
     double* out = joint + (size_t)iobs*JOINT_STRIDE;
     for(int i=0;i<JOINT_STRIDE;i++) out[i] = rec[i];
+    // splined models: the observation's box of control points starts empty (board_splined_kernel fills it)
+    if(O.spl_box != NULL) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 template<bool CHOOSE>
 __global__ __launch_bounds__(PRO_T)
@@ -1442,6 +1444,39 @@ void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ j
         x[m.i_meas0 + 2*pt + 1] = inlier ? (q[1] - obs[1])*w : 0.0;
     }
     if(!WITH_J) return;
+
+    // The box of control points under each observation, for the assembly of the normal equations (it used to find
+    // the box itself, from the column indices: 25k of a workgroup's 140k cycles). The inliers' patches only: an
+    // outlier's rows are zero. A wave's corners belong to one or two observations (more if a board has fewer than
+    // 64 corners): one reduction and four integer atomics per observation and wave - any order, the same box
+    int* __restrict__ box = opref_get(R).spl_box;
+    if(box != NULL && P.Ndist_state)
+    {
+        const int  n1   = P.cfg.spline_order + 1;
+        const int  knot = (ivar0 - 4) >> 1;
+        const int  kiy  = knot / P.cfg.spline_Nx, kix = knot - kiy*P.cfg.spline_Nx;
+        const bool ok   = valid && inlier;
+        unsigned long long todo = __ballot(ok);
+        while(todo)
+        {
+            const int  lead = __ffsll((long long)todo) - 1;
+            const int  ob   = __shfl(iobs, lead);
+            const bool in   = ok && iobs == ob;
+            int x0 = in ? kix : 0x7fffffff, x1 = in ? kix + n1 - 1 : -1;
+            int y0 = in ? kiy : 0x7fffffff, y1 = in ? kiy + n1 - 1 : -1;
+            for(int off = 32; off > 0; off >>= 1)
+            {
+                x0 = min(x0, __shfl_xor(x0, off)); x1 = max(x1, __shfl_xor(x1, off));
+                y0 = min(y0, __shfl_xor(y0, off)); y1 = max(y1, __shfl_xor(y1, off));
+            }
+            if(lane == lead)
+            {
+                atomicMin(&box[4*ob + 0], x0); atomicMax(&box[4*ob + 1], x1);
+                atomicMin(&box[4*ob + 2], y0); atomicMax(&box[4*ob + 3], y1);
+            }
+            todo &= ~__ballot(in);
+        }
+    }
 
     // The rows go through LDS, 32 corners (64 rows) at a time, and leave as ONE contiguous stream: the rows of
     // consecutive corners - and of consecutive observations with the same number of entries per row - are adjacent

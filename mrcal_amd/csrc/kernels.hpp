@@ -23,6 +23,10 @@ struct OpDev
     double* scalars;      // [NSCALARS]
     double* step_cauchy;  // [Nstate]
     double* step_gn;      // [Nstate]
+    // splined models: the box of control points under each board observation at this point, [Nobs_board][4] =
+    // (min ix, max ix, min iy, max iy). Reset by the prologue launch, filled by board_splined_kernel<true>
+    // (integer atomicMin/Max: any order, the same result), read by assemble_splined_kernel. NULL: another model
+    int*    spl_box;
 };
 
 // Which operating point a kernel works on. The index is either known to the

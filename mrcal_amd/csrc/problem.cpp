@@ -58,7 +58,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_joint); hipFree(d_gram); hipFree(d_Jp); hipFree(d_Ji);
     for(int i=0;i<2;i++)
     {
-        hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv);
+        hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv); hipFree(op[i].spl_box);
         hipFree(op[i].A); hipFree(op[i].Bt); hipFree(op[i].D); hipFree(op[i].g); hipFree(op[i].scalars);
         hipFree(op[i].step_cauchy); hipFree(op[i].step_gn);
     }
@@ -74,7 +74,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(G.scol); hipFree(G.part); hipFree(G.dest_id); hipFree(G.dest_begin); hipFree(G.dest_src); hipFree(G.group_chunk_begin);
         hipFree(G.eb_block); hipFree(G.eb_begin); hipFree(G.eb_rows); hipFree(G.eb_group); hipFree(G.eb_epos);
     }
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -261,6 +261,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->op[1].b,  (size_t)L.Nstate);
     ok = ok && dev_alloc(&P->op[1].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc(&P->op[1].Jv, (size_t)P->Nnz);
+    if(P->op[0].spl_box != NULL) ok = ok && dev_alloc(&P->op[1].spl_box, (size_t)4*P->D.Nobs_board);
     if(L.lensmodel.type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && (size_t)P->D.Nobs_board*gram_stride(L.Ndist) >= ((size_t)1 << 32))
     {
         // (reduce_pair_chunk() addresses the Grams with 32-bit element offsets; this is 34 GB of Grams)
@@ -282,7 +283,10 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     ok = ok && dev_alloc(&P->F.Linv,  cholesky_large_workspace_doubles(nd.Nc));
     // the tile occupancy of Wt: only where the couplings are sparse (the splined models) and the strip SYRK runs
     if(L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && nd.Nc > 256 && nd.Nc <= 4096)
+    {
         ok = ok && dev_alloc(&P->F.occ, (size_t)(nd.NEb > 0 ? nd.NEb : 1)*occ_words(nd));
+        ok = ok && dev_alloc(&P->F.Wtile, (size_t)((nd.Nc + 15)/16)*16*(size_t)(nd.NE > 0 ? nd.NE : 1));
+    }
     {
         char* ctl = NULL;
         ok = ok && dev_alloc(&ctl, solver_ctl_bytes());
@@ -973,6 +977,8 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     ok = ok && dev_alloc (&P->d_joint,  (size_t)Nboard_local*JOINT_STRIDE + (size_t)Ncameras_intrinsics*L.Nintrinsics + 2);
     ok = ok && dev_alloc (&P->op[0].x,  (size_t)L.Nmeas);
     ok = ok && dev_alloc (&P->op[0].Jv, (size_t)innz);
+    if(L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && Nboard_local > 0)
+        ok = ok && dev_alloc(&P->op[0].spl_box, (size_t)4*Nboard_local);
     ok = ok && dev_alloc (&P->d_Jp,     (size_t)L.Nmeas+1);
     ok = ok && dev_alloc (&P->d_Ji,     (size_t)innz);
     if(!ok) { delete P; return NULL; }

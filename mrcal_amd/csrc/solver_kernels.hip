@@ -438,32 +438,64 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
 #define SPL_TW      128         // local columns
 #define SPL_NDENSE  12
 #define SPL_NEXTRA  (SPL_NDENSE + 6 + 1)
-// Thread (ty, tx) of the 16 x 16 owns the local rows ty + 16 a and columns tx + 16 b, a, b < 8: whatever the
-// number of columns in use, every thread has the same share of them, and of the lower triangle (a >= b). A row
-// of J in LDS has the 8 columns of a thread side by side
-__device__ __forceinline__ int spl_pos(int c) { return ((c & 15) << 3) + (c >> 4); }
+// The Gram of a pass on the matrix cores (round 4; it was 36 multiply-adds per row and thread fed by 16 LDS reads:
+// 57k of a workgroup's 142k cycles). NS = ceil(NC/16) tile columns in use; the lower triangle of the NS x NS grid
+// of 16 x 16 tiles is dealt to the four waves BY TILE ROW, so that a wave's tiles share their operands: wave w has
+// row Ia = NS-1-w with its Ia+1 tiles and, if it exists, row Ib = w-(8-NS) (NS = 8: 9 tiles each; 7: 7 each;
+// 6: 6,5,5,5; 5: 5,4,3,3). v_mfma_f64_16x16x4: lane (r16 = lane % 16, kq = lane / 16) feeds Jd[4 s + kq][16 I + r16]
+// and Jd[4 s + kq][16 J + r16], register v of the result is G[16 I + kq + 4 v][16 J + r16]. A step s of a wave is
+// Ia+1 (+2) LDS reads for up to 9 matrix instructions; the reads of step s+1 are issued before the instructions of
+// step s. Row stride LD = 16 NS, + 16 if that is a multiple of 32 doubles: the four kq groups of a read then start 32
+// banks apart. The rows of a pass that fit the tile (64 KB: two workgroups a CU with room to spare) are taken in one go (100 corners x 80 columns do).
+#define SPL_LDS_DOUBLES 8192
+typedef double spl_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int spl_tri(int r) { return (r*(r + 1)) >> 1; }
-
-// += the Gram of nr rows, the slots a >= b of the first NS slots
-template<int NS> __device__ __forceinline__
-void spl_gram_rows(const double* __restrict__ Jd, int nr, int ty, int tx, double (&acc)[36])
+// a workgroup barrier that orders the LDS traffic only: the global stores in flight (the staged triangle) are not waited for
+__device__ __forceinline__ void spl_lds_barrier()
 {
-    for(int i = 0; i < nr; i++)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// (+)= the Gram of nsteps x 4 rows (rows past the data are zero): the NA = Ia + 1 tiles of row Ia in acc[0 .. NA-1], the
+// nb <= min(4, 9 - NA) tiles of row Ib behind them. FIRST: the accumulators start here (the first rows of a pass)
+template<int NA, bool FIRST> __device__ __forceinline__
+void spl_gram_mfma(const double* __restrict__ Jd, int LD, int nsteps, int r16, int kq, int offIa, int offIb, int nb, spl_d4 (&acc)[9])
+{
+    if(FIRST)
     {
-        const double2* __restrict__ ra = (const double2*)(Jd + i*SPL_TW + 8*ty);
-        const double2* __restrict__ rb = (const double2*)(Jd + i*SPL_TW + 8*tx);
-        double va[8], vb[8];
 #pragma unroll
-        for(int u = 0; u < (NS + 1)/2; u++)
-        {
-            const double2 a2 = ra[u], b2 = rb[u];
-            va[2*u] = a2.x; va[2*u+1] = a2.y; vb[2*u] = b2.x; vb[2*u+1] = b2.y;
-        }
-#pragma unroll
-        for(int a = 0; a < NS; a++)
-#pragma unroll
-            for(int b = 0; b <= a; b++) acc[((a*(a+1)) >> 1) + b] += va[a]*vb[b];
+        for(int u = 0; u < 9; u++) acc[u] = spl_d4{0.0, 0.0, 0.0, 0.0};
     }
+    const double* __restrict__ rowp = Jd + kq*LD + r16;
+    const int step = 4*LD;
+    double b0[NA], b1[NA], aA0, aA1, aB0 = 0.0, aB1 = 0.0;
+    auto load = [&](double (&bb)[NA], double& aA, double& aB, const double* __restrict__ rp)
+    {
+#pragma unroll
+        for(int J = 0; J < NA; J++) bb[J] = rp[16*J];
+        aA = rp[offIa];
+        if(nb > 0) aB = rp[offIb];
+    };
+    auto mma = [&](const double (&bb)[NA], double aA, double aB)
+    {
+#pragma unroll
+        for(int J = 0; J < NA; J++) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, bb[J], acc[J], 0, 0, 0);
+#define SPL_ROWB(J) if constexpr((J) < NA && NA + (J) < 9) { if((J) < nb) acc[NA + (J)] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, bb[J], acc[NA + (J)], 0, 0, 0); }
+        SPL_ROWB(0) SPL_ROWB(1) SPL_ROWB(2) SPL_ROWB(3)
+#undef SPL_ROWB
+    };
+    load(b0, aA0, aB0, rowp);
+    int s = 0;
+#pragma unroll 1
+    for(; s + 2 <= nsteps; s += 2)
+    {
+        load(b1, aA1, aB1, rowp + step);
+        mma(b0, aA0, aB0);
+        rowp += 2*step;
+        // (past the end: the last rows once more, unused)
+        load(b0, aA0, aB0, (s + 2 < nsteps) ? rowp : rowp - step);
+        mma(b1, aA1, aB1);
+    }
+    if(s < nsteps) mma(b0, aA0, aB0);
 }
 // state index of local column c of a pass, -1: not a camera-block variable of this pass (a frame column, x,
 // or a variable that is not being optimized)
@@ -495,23 +527,28 @@ void spl_rows_fallback(const NormalDims& nd, const OpDev& O, int r_first, int r1
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU)))
 void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int rows_cap)
+                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
     if(opref_skip(R)) return;
-    extern __shared__ double lds_s[];                   // Jd[rows_cap][SPL_TW]
-    double* __restrict__ Jd = lds_s;
-    __shared__ int bbox[4];
+    __shared__ __attribute__((aligned(16))) double Jd[SPL_LDS_DOUBLES];     // [rows][LD] of a pass
+    __shared__ double F[7*SPL_TW];          // the frame rows and the x row of a pass's Gram
+    __shared__ double FD[7*6];              // the frame's own block and its part of the gradient, summed over the passes
+    __shared__ double FB[6*SPL_NDENSE];     // the frame rows against the core, the extrinsics and the warp: over an observation's two passes (the warp: over the frame)
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
     const double* __restrict__ x  = O.x;
     const int f = blockIdx.x, t = threadIdx.x;
-    const int ty = t >> 4, tx = t & 15;
-    const int o0 = plan.frame_obs_begin[f], o1 = plan.frame_obs_begin[f+1];
-    const int NPTS = P.W*P.H, Nx = P.cfg.spline_Nx, order1 = P.cfg.spline_order + 1;
+    const int lane = t & 63, r16 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int o0 = __builtin_amdgcn_readfirstlane(plan.frame_obs_begin[f]), o1 = __builtin_amdgcn_readfirstlane(plan.frame_obs_begin[f+1]);
+    const int NPTS = P.W*P.H, Nx = P.cfg.spline_Nx;
     const int Ncs = P.Ncore_state;
+    if(t < 42) FD[t] = 0.0;
+    if(t < 6*SPL_NDENSE) FB[t] = 0.0;
     // (-DSPL_TS: cycles per phase, printed by three of the workgroups)
 #ifdef SPL_TS
     long long ts_bbox = 0, ts_zero = 0, ts_scatter = 0, ts_gram = 0, ts_out = 0, ts0 = clock64(), ts1;
+    const long long tw0 = wall_clock64(), tc0 = ts0;
 #define SPL_TICK(what) { ts1 = clock64(); what += ts1 - ts0; ts0 = ts1; }
 #else
 #define SPL_TICK(what)
@@ -519,30 +556,23 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
 
     for(int o = o0; o < o1; o++)
     {
-        const BoardObsMeta m = P.board_meta[o];
-        const int r0 = m.i_meas0, r1 = m.i_meas0 + 2*NPTS;
+        // (the observation's record and its box are the same for every lane, and said so: the tile's geometry, the
+        //  waves' shares and the loops' bounds stay in scalar registers)
+        const BoardObsMeta mv = P.board_meta[o];
+        const int4 boxv = ((const int4*)O.spl_box)[o];
+        const int m_isi = __builtin_amdgcn_readfirstlane(mv.i_state_intrinsics);
+        const int m_ise = __builtin_amdgcn_readfirstlane(mv.i_state_extrinsics);
+        const int r0 = __builtin_amdgcn_readfirstlane(mv.i_meas0), r1 = r0 + 2*NPTS;
         // (rowptr[i_meas0 + r] = i_nnz0 + r*nnz_per_row: board_splined_kernel. From the record: two loads fewer in line)
-        const int p00 = (int)m.i_nnz0;
-        const int L   = m.nnz_per_row;                  // entries per row, the same for all rows of the observation
-        // bounding box of the knots under this observation: from the first spline column of every x row
-        if(t < 4) bbox[t] = (t & 1) ? -1 : 0x7fffffff;
-        __syncthreads();
-        if(P.Ndist_row > 0)
-            for(int c = t; c < NPTS; c += blockDim.x)
-            {
-                // (outliers have x == 0 and all-zero rows: whatever columns they carry do not matter)
-                if(x[r0 + 2*c] == 0.0 && x[r0 + 2*c + 1] == 0.0) continue;
-                const int rel  = Ji[p00 + 2*c*L + (Ncs ? 2 : 0)] - (m.i_state_intrinsics + Ncs);
-                const int knot = rel >> 1, ix = knot % Nx, iy = knot / Nx;
-                atomicMin(&bbox[0], ix); atomicMax(&bbox[1], ix + order1 - 1);
-                atomicMin(&bbox[2], iy); atomicMax(&bbox[3], iy + order1 - 1);
-            }
-        __syncthreads();
-        const bool any = (P.Ndist_row > 0) && bbox[1] >= 0;
-        const int ix0 = any ? bbox[0] : 0, iy0 = any ? bbox[2] : 0;
-        const int wx = any ? bbox[1] - bbox[0] + 1 : 0, wy = any ? bbox[3] - bbox[2] + 1 : 0;
+        const int p00 = __builtin_amdgcn_readfirstlane((int)mv.i_nnz0);
+        const int L   = __builtin_amdgcn_readfirstlane(mv.nnz_per_row);     // entries per row, the same for all rows of the observation
+        // the box of control points under this observation's inliers: board_splined_kernel left it with the rows
+        const int4 box  = make_int4(__builtin_amdgcn_readfirstlane(boxv.x), __builtin_amdgcn_readfirstlane(boxv.y),
+                                    __builtin_amdgcn_readfirstlane(boxv.z), __builtin_amdgcn_readfirstlane(boxv.w));
+        const bool any = (P.Ndist_row > 0) && box.y >= 0;
+        const int ix0 = any ? box.x : 0, iy0 = any ? box.z : 0;
+        const int wx = any ? box.y - box.x + 1 : 0, wy = any ? box.w - box.z + 1 : 0;
         const int K  = wx*wy;
-        __syncthreads();            // bbox is reused by the next observation
         SPL_TICK(ts_bbox)
         if(K + SPL_NEXTRA > SPL_TW)
         {
@@ -552,124 +582,223 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         }
         if(t == 0) plan.spl_hdr[o] = SplHdr{ ix0, iy0, wx, wy };
         const int NC = K + SPL_NEXTRA;                  // local columns in use
-        const int NS = (NC + 15) >> 4;                  // slots of a thread in use
+        const int NS = (NC + 15) >> 4;                  // 16-column tiles in use
+        const int LD = 16*(NS + 1 - (NS & 1));          // row stride: an odd number of tiles
+        const int rows_cap = min((NPTS + 3) & ~3, (SPL_LDS_DOUBLES / LD) & ~3);
         const int lx = K + SPL_NDENSE + 6;              // the x column
+        const int fr0 = K + SPL_NDENSE;                 // the first frame column
+        // this wave's tile rows
+        // (every second workgroup deals the rows the other way round: two workgroups share a CU, and their waves w a SIMD)
+        const int wv = (((f >> 8) ^ f) & 1) ? 3 - wave : wave;
+        const int Ia = NS - 1 - wv, Ib = wv - (8 - NS);
+        const int na = (Ia >= 0) ? Ia + 1 : 0, nb = (Ib >= 0 && Ia >= 0) ? Ib + 1 : 0;
+        const unsigned L_magic = (unsigned)((0x100000000ull + (unsigned)L - 1)/(unsigned)L);      // e / L = e L_magic >> 32, e (L-1) < 2^32
 
+#pragma unroll 1
         for(int xy = 0; xy < 2; xy++)
         {
             // state index -> local column of this pass
             auto local_of = [&](int col) -> int
             {
-                if(P.do_optimize_frames && col >= nd.E_state0 && col < nd.E_state0 + nd.NE) return K + SPL_NDENSE + (col - (nd.E_state0 + 6*f));
-                if(m.i_state_intrinsics >= 0 && col >= m.i_state_intrinsics && col < m.i_state_intrinsics + P.Nintr_state)
+                if(P.do_optimize_frames && col >= nd.E_state0 && col < nd.E_state0 + nd.NE) return fr0 + (col - (nd.E_state0 + 6*f));
+                if(m_isi >= 0 && col >= m_isi && col < m_isi + P.Nintr_state)
                 {
-                    const int rel = col - m.i_state_intrinsics;
+                    const int rel = col - m_isi;
                     if(rel < Ncs) return K + rel;
                     const int knot = (rel - Ncs) >> 1;
                     return (knot / Nx - iy0)*wx + (knot % Nx - ix0);
                 }
-                if(m.i_state_extrinsics >= 0 && col >= m.i_state_extrinsics && col < m.i_state_extrinsics + 6)
-                    return K + 4 + (col - m.i_state_extrinsics);
+                if(m_ise >= 0 && col >= m_ise && col < m_ise + 6)
+                    return K + 4 + (col - m_ise);
                 return K + 10 + (col - P.i_state_warp);
             };
-            double acc[36];
-#pragma unroll
-            for(int i = 0; i < 36; i++) acc[i] = 0.0;
-
+            // A board's rows mostly fit the tile at once. When they do not, every chunk of rows makes its own Gram and
+            // ADDS it to what is staged (and to F): no accumulator is live while rows are fetched - held across the
+            // loop they were spilled on every path, and a reload from scratch waits for every store in flight
+            double* __restrict__ G = plan.chunk_part + ((size_t)2*o + xy)*SPL_TRI;
+#pragma unroll 1
             for(int c0 = 0; c0 < NPTS; c0 += rows_cap)
             {
-                const int nr = min(rows_cap, NPTS - c0);
-                for(int i = t; i < nr*(SPL_TW/2); i += blockDim.x) ((double2*)Jd)[i] = make_double2(0.0, 0.0);
-                __syncthreads();
-                SPL_TICK(ts_zero)
+                constexpr bool first = true;
+                spl_d4 acc[9];
+                // (the lane's indices made opaque at the head of each phase: what is computed from them is computed in
+                //  the phase, not in front of the loop over the observations and carried - spilled - through everything)
+                int tq = t;
+                asm volatile("" : "+v"(tq));
+                const int nr = min(rows_cap, NPTS - c0), nr4 = (nr + 3) & ~3;
                 const int pbase = p00 + (2*c0 + xy)*L;
-                // (four entries per thread asked for together: one entry at a time, its column only when the
-                //  value is not zero, is two memory round trips per entry: 10 000 cycles per 64 rows)
-                for(int e0 = 0; e0 < nr*L; e0 += 4*256)
+                const int ne = nr*L;
+                // Six entries per thread asked for together (one entry at a time, its column only when the value is
+                // not zero, is two memory round trips per entry), the first six BEFORE the tile is cleared: their
+                // trip to memory and the clearing overlap
+                // (nothing is done with what a load returns before the batch is put away: a select on the spot is a wait on the spot)
+                constexpr int EB = 4;
+                double v0[EB], v1[EB]; int ci0[EB], ci1[EB], ii0[EB], ii1[EB];
+                auto ask = [&](int e0, double (&v)[EB], int (&ci)[EB], int (&ii)[EB])
                 {
-                    double v[4]; int ci[4], ii[4];
 #pragma unroll
-                    for(int u = 0; u < 4; u++)
+                    for(int u = 0; u < EB; u++)
                     {
-                        const int e = e0 + 256*u + t;
-                        const bool ok = e < nr*L;
-                        const int i = ok ? e / L : 0, k = ok ? e - i*L : 0;
-                        const int p = pbase + 2*i*L + k;
-                        ii[u] = i;
-                        const double jv = Jv[p];        // (p is a valid entry either way)
-                        v[u]  = ok ? jv : 0.0;
+                        const int e = e0 + 256*u + tq;
+                        const bool ok = e < ne;
+                        const int i = ok ? (int)__umulhi((unsigned)e, L_magic) : 0, k = ok ? e - i*L : 0;
+                        const int p = pbase + 2*i*L + k;        // (a valid entry either way)
+                        ii[u] = ok ? i : -1;
+                        v[u]  = Jv[p];
                         ci[u] = Ji[p];
                     }
-#pragma unroll
-                    for(int u = 0; u < 4; u++)
-                        if(v[u] != 0.0) Jd[ii[u]*SPL_TW + spl_pos(local_of(ci[u]))] = v[u];
-                }
-                for(int i = t; i < nr; i += blockDim.x) Jd[i*SPL_TW + spl_pos(lx)] = x[r0 + 2*(c0 + i) + xy];
-                __syncthreads();
-                SPL_TICK(ts_scatter)
-                switch(NS)
+                };
+                auto put = [&](const double (&v)[EB], const int (&ci)[EB], const int (&ii)[EB])
                 {
-                case 2: spl_gram_rows<2>(Jd, nr, ty, tx, acc); break;
-                case 3: spl_gram_rows<3>(Jd, nr, ty, tx, acc); break;
-                case 4: spl_gram_rows<4>(Jd, nr, ty, tx, acc); break;
-                case 5: spl_gram_rows<5>(Jd, nr, ty, tx, acc); break;
-                case 6: spl_gram_rows<6>(Jd, nr, ty, tx, acc); break;
-                case 7: spl_gram_rows<7>(Jd, nr, ty, tx, acc); break;
-                default:spl_gram_rows<8>(Jd, nr, ty, tx, acc); break;
+#pragma unroll
+                    for(int u = 0; u < EB; u++)
+                        if(ii[u] >= 0 && v[u] != 0.0) Jd[ii[u]*LD + local_of(ci[u])] = v[u];
+                };
+                ask(0, v0, ci0, ii0);
+                const double xv = x[r0 + 2*(c0 + min(tq, nr - 1)) + xy];
+                for(int i = tq; i < nr4*(LD/2); i += blockDim.x) ((double2*)Jd)[i] = make_double2(0.0, 0.0);
+                spl_lds_barrier();
+                SPL_TICK(ts_zero)
+                for(int e0 = 0; e0 < ne; e0 += 2*EB*256)
+                {
+                    if(e0 + EB*256 < ne)   ask(e0 + EB*256, v1, ci1, ii1);
+                    put(v0, ci0, ii0);
+                    if(e0 + EB*256 >= ne)  break;
+                    if(e0 + 2*EB*256 < ne) ask(e0 + 2*EB*256, v0, ci0, ii0);
+                    put(v1, ci1, ii1);
                 }
-                __syncthreads();
+                if(tq < nr) Jd[tq*LD + lx] = xv;
+                for(int i = tq + blockDim.x; i < nr; i += blockDim.x) Jd[i*LD + lx] = x[r0 + 2*(c0 + i) + xy];
+                spl_lds_barrier();
+                SPL_TICK(ts_scatter)
+                int r16g = r16, kqg = kq;
+                asm volatile("" : "+v"(r16g), "+v"(kqg));
+                switch(na)
+                {
+                case 0: if(first) { for(int u = 0; u < 9; u++) acc[u] = spl_d4{0.0, 0.0, 0.0, 0.0}; } break;
+                case 1: spl_gram_mfma<1, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 2: spl_gram_mfma<2, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 3: spl_gram_mfma<3, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 4: spl_gram_mfma<4, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 5: spl_gram_mfma<5, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 6: spl_gram_mfma<6, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                case 7: spl_gram_mfma<7, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                default:spl_gram_mfma<8, first>(Jd, LD, nr4 >> 2, r16g, kqg, 16*Ia, 16*Ib, nb, acc); break;
+                }
                 SPL_TICK(ts_gram)
-            }
-
-            // out: the whole lower triangle is staged - the camera-block rows and the x row for the gather, the
-            // six frame rows for the second half of this (the unrolled stores stay simple: with the frame rows'
-            // three destinations in each of the 36 the kernel spilled registers)
-            double* __restrict__ G = plan.chunk_part + ((size_t)2*o + xy)*SPL_TRI;
+                // out: the whole lower triangle is staged - the camera-block rows and the x row for the gather - with
+                // stores nobody here waits for; the six frame rows and the x row also go to F, for the second half of this
+                // (the lane's coordinates made opaque here: left alone, the compiler computes the 36 store addresses once,
+                //  in front of the loop over the observations, and keeps them - the kernel spills)
+                int kq_o = kq, r16_o = r16;
+                asm volatile("" : "+v"(kq_o), "+v"(r16_o));
+                const bool add = c0 > 0;
+                auto out_tile = [&](const spl_d4& a4, int I, int J)
+                {
+                    const int col = 16*J + r16_o;
 #pragma unroll
-            for(int a = 0; a < 8; a++)
-            {
-                const int row = ty + 16*a;
-                if(row >= NC) continue;
-                double* __restrict__ Grow = G + spl_tri(row) + tx;
+                    for(int vv = 0; vv < 4; vv++)
+                    {
+                        const int row = 16*I + kq_o + 4*vv;
+                        if(row < NC && col <= row)
+                        {
+                            double* __restrict__ g = &G[spl_tri(row) + col];
+                            *g = add ? *g + a4[vv] : a4[vv];
+                            if(row >= fr0)
+                            {
+                                double* __restrict__ ff = &F[(row - fr0)*SPL_TW + col];
+                                *ff = add ? *ff + a4[vv] : a4[vv];
+                            }
+                        }
+                    }
+                };
+                if(!add)
+                {
 #pragma unroll
-                for(int b = 0; b <= a; b++)
-                    if(tx + 16*b <= row) Grow[16*b] = acc[((a*(a+1)) >> 1) + b];
+                    for(int u = 0; u < 9; u++)
+                    {
+                        if(u < na)           out_tile(acc[u], Ia, u);
+                        else if(u - na < nb) out_tile(acc[u], Ib, u - na);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for(int u = 0; u < 9; u++)
+                    {
+                        if(u < na)           out_tile(acc[u], Ia, u);
+                        else if(u - na < nb) out_tile(acc[u], Ib, u - na);
+                    }
+                }
+                // (the tile is cleared again only after everybody is through with it)
+                if(c0 + rows_cap < NPTS) spl_lds_barrier();
             }
-            __syncthreads();
-            // what belongs to the frame, added in place: rows K+12 .. K+17 against the camera-block columns (Bt)
-            // and against each other (D_f); the x row against the frame columns (g_f)
+            spl_lds_barrier();
+            // what belongs to the frame: rows K+12 .. K+17 against the camera-block columns (Bt) and against each
+            // other (D_f); the x row against the frame columns (g_f). Element (ia, col) is the same thread's in every
+            // pass and observation: its read-modify-writes of one address follow each other in program order
+            int tf = t;
+            asm volatile("" : "+v"(tf));
             if(P.do_optimize_frames)
-                for(int e = t; e < 7*SPL_TW; e += blockDim.x)
+                for(int e = tf; e < 7*SPL_TW; e += blockDim.x)
                 {
                     const int ia = e >> 7, col = e & (SPL_TW - 1);      // ia 6: the x row
-                    const int row = K + SPL_NDENSE + ia;
-                    const int ib = col - (K + SPL_NDENSE);
+                    const int row = fr0 + ia;
+                    const int ib = col - fr0;
                     if(col > row || (ia == 6 && (ib < 0 || ib >= 6))) continue;
-                    const double v = G[spl_tri(row) + col];
-                    if(v == 0.0) continue;
-                    if(ia == 6) O.g[nd.E_state0 + 6*f + ib] += v;
-                    else if(ib >= 0)
-                    {
-                        O.D[(size_t)f*36 + ia*6 + ib] += v;
-                        if(ib != ia) O.D[(size_t)f*36 + ib*6 + ia] += v;
-                    }
+                    const double vv = F[ia*SPL_TW + col];
+                    if(vv == 0.0) continue;
+                    if(ib >= 0)        FD[ia*6 + ib] += vv;                     // (ia 6: g_f)
+                    else if(col >= K)  FB[ia*SPL_NDENSE + (col - K)] += vv;
                     else
                     {
-                        const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m.i_state_intrinsics, m.i_state_extrinsics);
+                        const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m_isi, m_ise);
                         if(cs < 0) continue;
                         // a knot's column is written by this pass of this observation and by nobody else
-                        double* __restrict__ dst = &O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)];
-                        if(col < K) *dst = v; else *dst += v;
+                        O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)] = vv;
                     }
                 }
-            // (the next pass, or observation, may add to the same entries of Bt, D, g from other threads)
-            __syncthreads();
+            // (F is written again after the next pass's barriers)
             SPL_TICK(ts_out)
+        }
+        // the observation's core and extrinsics columns of Bt: one addition each, nothing read back (an atomic one, as
+        // below). The warp's columns wait for the frame's last observation
+        spl_lds_barrier();
+        if(P.do_optimize_frames && t < 6*SPL_NDENSE)
+        {
+            const int ia = t / SPL_NDENSE, d = t - ia*SPL_NDENSE;
+            if(d < 10 && FB[t] != 0.0)
+            {
+                const int cs = spl_col_state(P, nd, K + d, K, ix0, iy0, wx > 0 ? wx : 1, 0, m_isi, m_ise);
+                if(cs >= 0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)], FB[t]);
+                FB[t] = 0.0;
+            }
+        }
+    }
+    // the frame's block and gradient: one addition each (an atomic one: an observation that went row by row - too many
+    // knots - adds to the same entries with atomics, possibly still in flight)
+    __syncthreads();
+    if(P.do_optimize_frames && t < 6*SPL_NDENSE)
+    {
+        const int ia = t / SPL_NDENSE, d = t - ia*SPL_NDENSE;
+        if(d >= 10 && nd.Nwarp && FB[t] != 0.0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, nd.i_state_warp + (d - 10))], FB[t]);
+    }
+    if(P.do_optimize_frames && t < 42)
+    {
+        const int ia = t / 6, ib = t - 6*ia;
+        if(ia == 6) { if(FD[t] != 0.0) atomicAdd(&O.g[nd.E_state0 + 6*f + ib], FD[t]); }
+        else
+        {
+            const double vv = (ib <= ia) ? FD[ia*6 + ib] : FD[ib*6 + ia];
+            if(vv != 0.0) atomicAdd(&O.D[(size_t)f*36 + ia*6 + ib], vv);
         }
     }
 #ifdef SPL_TS
     if((f == 0 || f == 400 || f == 799) && (t == 0 || t == 255))
         printf("splined assembly f %d t %d: bbox %lld zero %lld scatter %lld gram %lld out %lld cycles\n", f, t, ts_bbox, ts_zero, ts_scatter, ts_gram, ts_out);
+    // (the workgroup's place in time: the constant 100 MHz clock at its start and end, and its own cycles)
+    if((f % 100 == 0 || f == 255 || f == 256 || f == 511 || f == 512 || f == 799) && t == 0)
+        printf("splined assembly f %d: wall %lld .. %lld (x10 ns), %lld cycles\n", f, tw0, wall_clock64(), clock64() - tc0);
 #endif
 }
 
@@ -1289,7 +1418,7 @@ void zero_normal_kernel(NormalDims nd, OpRef R)
 __global__ __launch_bounds__(256)
 void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
-                          int* __restrict__ status, unsigned* __restrict__ occ, int nocc)
+                          int* __restrict__ status, unsigned* __restrict__ occ, int nocc, double* __restrict__ Wtile)
 {
     if(opref_skip(R)) return;
     const OpDev& O = opref_get(R);
@@ -1411,6 +1540,9 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
                                   (((m >> 32) & 0xffffull) ? 4u : 0u) | ((m >> 48) ? 8u : 0u);
             const int tile0 = (c - (t & 63)) >> 4;
             if((t & 63) == 0 && bits) atomicOr(&occ_s[tile0 >> 5], bits << (tile0 & 31));
+            // the tiled copy, of the tiles that hold something
+            if(Wtile != NULL && c < nd.Nc && ((bits >> ((t & 63) >> 4)) & 1u))
+                for(int i=0;i<de;i++) Wtile[((size_t)(c >> 4)*nd.NE + e0 + i)*16 + (c & 15)] = w[i];
         }
     }
     // wider camera blocks: the remaining columns, plainly
@@ -1430,6 +1562,10 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
             bool nz = false;
             for(int i=0;i<de;i++) nz = nz || (w[i] != 0.0);
             if(nz && c < nd.Nc) atomicOr(&occ_s[(c >> 4) >> 5], 1u << ((c >> 4) & 31));
+            // (the 16 columns of a tile are 16 neighbouring lanes here too)
+            const unsigned long long m = __ballot(nz && c < nd.Nc);
+            if(Wtile != NULL && c < nd.Nc && ((m >> (t & 48)) & 0xffffull))
+                for(int i=0;i<de;i++) Wtile[((size_t)(c >> 4)*nd.NE + e0 + i)*16 + (c & 15)] = w[i];
         }
     }
     if(occ != NULL)
@@ -1452,15 +1588,18 @@ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, dou
 __device__ __forceinline__
 void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int add_g /* r starts from g_S (else from 0) */,
                        int nslots, const double* __restrict__ Spart,
-                       double* __restrict__ S, double* __restrict__ r, int block)
+                       double* __restrict__ S, double* __restrict__ r, int block,
+                       const unsigned char* __restrict__ live = NULL /* [nslots][npairs]: the slot holds the tile (sparse SYRK); NULL: all do */)
 {
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
     // loads in flight; the 64-byte groups they read are still whole cache lines
     // across the wave (16 consecutive elements x SRED_SPLIT slots)
+    // (the sparse SYRK's few slots with anything in them: a thread per element, the slots in order)
     const int gid = block*blockDim.x + threadIdx.x;
-    const int sub = (gid >> 4) & (SRED_SPLIT-1);
-    const int idx = ((gid >> 6) << 4) | (gid & 15);      // 16 elements per wave
+    const int split = (live != NULL) ? 1 : SRED_SPLIT;
+    const int sub = (live != NULL) ? 0 : (gid >> 4) & (SRED_SPLIT-1);
+    const int idx = (live != NULL) ? gid : ((gid >> 6) << 4) | (gid & 15);      // 16 elements per wave
     const int nS  = npairs*256, nTot = nS + nb*16;
     if(idx >= nTot) return;
     const bool is_r = idx >= nS;
@@ -1468,23 +1607,52 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
     const size_t stride = is_r ? (size_t)nb*16 : (size_t)nS;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int s = sub;
-    for(; s + 3*SRED_SPLIT < nslots; s += 4*SRED_SPLIT)
+    if(live != NULL && !is_r)
     {
-        a0 += base[(size_t)(s                )*stride];
-        a1 += base[(size_t)(s +   SRED_SPLIT)*stride];
-        a2 += base[(size_t)(s + 2*SRED_SPLIT)*stride];
-        a3 += base[(size_t)(s + 3*SRED_SPLIT)*stride];
+        // the sparse SYRK leaves most slots of most tiles unwritten (no block of the slice touches the tile): what is
+        // not there is not read - the same sum, a zero added is a zero skipped
+        const unsigned char* __restrict__ lv = live + (idx >> 8);
+        for(; s + 7 < nslots; s += 8)
+        {
+            unsigned char f[8]; double v[8];
+#pragma unroll
+            for(int u = 0; u < 8; u++) f[u] = lv[(size_t)(s + u)*npairs];
+#pragma unroll
+            for(int u = 0; u < 8; u++) { v[u] = 0.0; if(f[u]) v[u] = base[(size_t)(s + u)*stride]; }
+#pragma unroll
+            for(int u = 0; u < 8; u++) a0 += v[u];
+        }
+        for(; s < nslots; s++) if(lv[(size_t)s*npairs]) a0 += base[(size_t)s*stride];
     }
-    for(; s < nslots; s += SRED_SPLIT) a0 += base[(size_t)s*stride];
+    else
+    {
+    for(; s + 3*split < nslots; s += 4*split)
+    {
+        a0 += base[(size_t)(s          )*stride];
+        a1 += base[(size_t)(s +   split)*stride];
+        a2 += base[(size_t)(s + 2*split)*stride];
+        a3 += base[(size_t)(s + 3*split)*stride];
+    }
+    for(; s < nslots; s += split) a0 += base[(size_t)s*stride];
+    }
     double acc = (a0 + a1) + (a2 + a3);
-    acc += __shfl_xor(acc, 16);
-    acc += __shfl_xor(acc, 32);
+    if(split > 1)
+    {
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+    }
     if(sub != 0) return;
     if(!is_r)
     {
-        int bi = 0, p = idx >> 8;
-        while(p >= nb - bi) { p -= nb - bi; bi++; }
-        const int bj = bi + p;
+        // tile pair idx >> 8 -> (bi, bj), bi <= bj, row bi of the pairs starting at bi nb - bi (bi - 1)/2: the root of
+        // the quadratic, put right by a step either way (walking the rows from 0 was up to 76 steps for every one of
+        // the 3 M threads of a 1206-column camera block: most of this kernel's 25 us)
+        const int pp = idx >> 8;
+        int bi = (int)(0.5*((double)(2*nb + 1) - sqrt((double)(2*nb + 1)*(double)(2*nb + 1) - 8.0*(double)pp)));
+        bi = max(0, min(nb - 1, bi));
+        while(bi > 0 && bi*nb - ((bi*(bi - 1)) >> 1) > pp) bi--;
+        while(bi + 1 < nb && (bi + 1)*nb - (((bi + 1)*bi) >> 1) <= pp) bi++;
+        const int bj = bi + (pp - (bi*nb - ((bi*(bi - 1)) >> 1)));
         const int v = (idx >> 6) & 3, lane = idx & 63;
         const int i = 16*bi + (lane >> 4) + 4*v, j = 16*bj + (lane & 15);
         if(i < nd.Nc && j < nd.Nc && j >= i)
@@ -1500,11 +1668,11 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
 __global__ __launch_bounds__(256)
 void schur_reduce_kernel(NormalDims nd, OpRef R, double lambda_host, const SolverCtl* ctl, int is_leader,
                          int nslots, const double* __restrict__ Spart,
-                         double* __restrict__ S, double* __restrict__ r)
+                         double* __restrict__ S, double* __restrict__ r, const unsigned char* __restrict__ live)
 {
     if(opref_skip(R)) return;
     const double lambda = is_leader ? (ctl ? ctl->lambda : lambda_host) : 0.0;
-    schur_reduce_body(nd, opref_get(R), lambda, is_leader, nslots, Spart, S, r, blockIdx.x);
+    schur_reduce_body(nd, opref_get(R), lambda, is_leader, nslots, Spart, S, r, blockIdx.x, live);
 }
 
 // Wt^T Wt and Wt^T y on the FP64 matrix cores: one wave per (16x16 tile of S,
@@ -1614,6 +1782,9 @@ void schur_syrk_mfma_kernel(NormalDims nd, const int* __restrict__ skip, int e_l
 // four tiles (bi, bj0 .. bj0+3): one A operand serves four B operands, 5 loads
 // per 4 MFMAs instead of 8. Same slots, same reduction
 #define SYRK_STRIP 4
+#ifndef SYRK_DEPTH
+#define SYRK_DEPTH 2      // blocks whose operands are in flight together (schur_syrk_sparse_kernel)
+#endif
 #define SYRK_STRIP_UNROLL 8
 __global__ __launch_bounds__(64)
 void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
@@ -1706,31 +1877,43 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
 // only the B tiles the block touches are. A block's 6 (3) rows are two (one) k-steps of 4, the missing
 // rows zero: a third more matrix instructions per processed block, for an eighth of the blocks x tiles.
 // Slices cut blocks wherever they fall: each side takes its rows
-__global__ __launch_bounds__(64)
+// The blocks that count are few but unevenly spread: nine strips in ten have none or two in a slice, the strips over
+// the middle of the imager sixty, and ~1000 matrix instructions one after the other on ONE wave were the kernel's
+// 62 us (with either the loads or the matrix instructions compiled out: ~50; with neither: 8). So a workgroup is
+// SYRK_SPARSE_WAVES waves on the one strip, wave w taking every SYRK_SPARSE_WAVES-th block of the slice; their sums
+// are added in wave order (LDS) - the same bits every time. (Tried instead: four STRIPS a workgroup, 104 us against
+// 89; 16 and 32 slices, 53 and 60 us alone against 67 - and the reduction pays for the slots)
+#define SYRK_SPARSE_WAVES 4
+__global__ __launch_bounds__(64*SYRK_SPARSE_WAVES)
 void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
                               int slot0, int nslots_total,
                               const double* __restrict__ Wt, const double* __restrict__ y,
                               double* __restrict__ Spart, int nslices, FinalizeRide fr,
-                              const unsigned* __restrict__ occ, int nocc)
+                              const unsigned* __restrict__ occ, int nocc, unsigned char* __restrict__ live_out, int nstrips)
 {
     if((int)blockIdx.y >= nslices) { finalize_ride(fr, nd); return; }
     if(skip != NULL && *skip) return;
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     int px, sy;
     syrk_xcd_map(nslices, &px, &sy);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int bi = 0, sidx = px;
     for(;;) { const int ng = (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP; if(sidx < ng) break; sidx -= ng; bi++; }
     const int bj0 = bi + SYRK_STRIP*sidx;
     const int ntile = min(SYRK_STRIP, nb - bj0);
     const int pair0 = bi*nb - (bi*(bi-1))/2 + (bj0 - bi);
-    const int e_begin = e_lo + sy*e_per_slice;
-    const int e_end   = min(e_hi, e_begin + e_per_slice);
+    // A slice is every nslices-th BLOCK of the range (not a run of rows): eblock_factor_kernel's workgroup i runs on
+    // XCD i % 8 and leaves block i's rows of Wt in THAT XCD's L2, and syrk_xcd_map() puts slice s on XCD s % 8 - with
+    // 8 slices a workgroup here finds what it reads in its own L2 (a trip of ~700 cycles instead of ~4000 to another
+    // XCD's data; the walk is nothing but such trips)
+    const int e_begin = e_lo, e_end = e_hi;
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int kk = lane >> 4, cc = lane & 15;
     const int ci = 16*bi + cc;
     const bool oki = ci < nd.Nc;
-    const double* __restrict__ pi = Wt + (oki ? ci : 0);
+    // (Wt here is eblock_factor_kernel's tiled copy, [tile][row][16]: a block's rows of a tile are contiguous)
+    const double* __restrict__ pi = Wt + (size_t)bi*nd.NE*16 + cc;
     const double* __restrict__ pj[SYRK_STRIP];
     bool okj[SYRK_STRIP];
 #pragma unroll
@@ -1738,7 +1921,7 @@ void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e
     {
         const int cj = 16*(bj0 + q) + cc;
         okj[q] = (q < ntile) && cj < nd.Nc;
-        pj[q]  = Wt + (okj[q] ? cj : 0);
+        pj[q]  = Wt + (size_t)min(bj0 + q, nb - 1)*nd.NE*16 + cc;
     }
     const bool diag = (bj0 == bi);
 
@@ -1746,70 +1929,74 @@ void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e
 #pragma unroll
     for(int q = 0; q < SYRK_STRIP; q++) acc[q] = syrk_d4{0.0, 0.0, 0.0, 0.0};
     syrk_d4 accr = {0.0, 0.0, 0.0, 0.0};
+    unsigned touched = 0;       // bit q: a block of this slice touched B tile q of the strip (and the A tile)
+#ifdef SYRK_TS
+    long long sts_scan = 0, sts_blocks = 0, sts_t0 = clock64(), sts_t1; int sts_live = 0, sts_mma = 0;
+    const long long sts_begin = sts_t0, sts_wall0 = wall_clock64();
+#define SYRK_TICK(w) { sts_t1 = clock64(); w += sts_t1 - sts_t0; sts_t0 = sts_t1; }
+#else
+#define SYRK_TICK(w)
+#endif
     if(e_begin < e_end)
     {
         auto block_of   = [&](int e) { return (e < 6*nd.Nfb) ? e/6 : nd.Nfb + (e - 6*nd.Nfb)/3; };
-        auto block_row0 = [&](int b) { return (b < nd.Nfb) ? 6*b : 6*nd.Nfb + 3*(b - nd.Nfb); };
-        const int b_first = block_of(e_begin), b_last = block_of(e_end - 1);
+        const int b_lo = block_of(e_begin), b_hi = block_of(e_end - 1) + 1;
+        const int b_first = b_lo + sy;
+        const int nblk = (b_first < b_hi) ? (b_hi - b_first + nslices - 1)/nslices : 0;
         const unsigned wi = bi >> 5, mi = 1u << (bi & 31);
         // The occupancy bits of 64 blocks at a time, one block per lane: ONE round trip for the lot, then the
         // wave goes through the blocks that touch its tiles. (Read block by block - a dependent load in front
         // of every block, skipped or not - the walk over a slice's 100 blocks was most of the kernel's 104 us.)
         // And the operands of the NEXT block that counts are asked for before the products of the current one
-        struct Operands { double a0, a1, b0[SYRK_STRIP], b1[SYRK_STRIP], y0, y1; unsigned mb; bool two; };
+        // (nothing is done with what a load returns before the block is applied: a select on the spot is a wait on the
+        //  spot, and the ten loads of a block were ten trips to memory one after the other)
+        // A block is six rows (a frame) or three (a point), whole (the slices are made of blocks): two k-steps of 4, or
+        // one. What a lane's row and column are worth is decided once, per kind of block, not per block: the walk is a
+        // chain of trips to memory with ~30 instructions between them (it was ~200, and those were half of its time)
+        struct Operands { double a0, a1, b0[SYRK_STRIP], b1[SYRK_STRIP], y0, y1; unsigned mb; bool six; };
+        const int  ka6 = kk, kb6 = 4 + (kk & 1), ka3 = (kk < 3) ? kk : 0;          // the lane's rows of the block (valid rows always)
+        const bool ma6 = oki, mb6 = oki && kk < 2, ma3 = oki && kk < 3;             // ... and whether they count
         auto fetch = [&](int b, unsigned mb, Operands& o)
         {
-            const int br0 = block_row0(b);
-            const int r0 = max(br0, e_begin), r1 = min(br0 + ((b < nd.Nfb) ? 6 : 3), e_end);
-            o.two = (r1 - r0) > 4; o.mb = mb;
-            const int  ea = r0 + kk, eb = r0 + 4 + kk;
-            const bool oka = ea < r1, okb = eb < r1;
-            const size_t rowa = (size_t)(oka ? ea : r0)*nd.Nc, rowb = (size_t)(okb ? eb : r0)*nd.Nc;
-            o.a0 = pi[rowa]; o.a1 = o.two ? pi[rowb] : 0.0;
-            if(!oka || !oki) o.a0 = 0.0;
-            if(!okb || !oki) o.a1 = 0.0;
+            o.six = b < nd.Nfb; o.mb = mb;
+            const int e0 = o.six ? 6*b : 6*nd.Nfb + 3*(b - nd.Nfb);
+            const int ea = e0 + (o.six ? ka6 : ka3), eb = e0 + (o.six ? kb6 : 0);
+            const size_t rowa = (size_t)ea*16, rowb = (size_t)eb*16;
+            o.a0 = pi[rowa]; o.a1 = pi[rowb];
 #pragma unroll
             for(int q = 0; q < SYRK_STRIP; q++)
-            {
-                o.b0[q] = 0.0; o.b1[q] = 0.0;
-                if((mb >> q) & 1u)
-                {
-                    o.b0[q] = pj[q][rowa]; o.b1[q] = o.two ? pj[q][rowb] : 0.0;
-                    if(!oka || !okj[q]) o.b0[q] = 0.0;
-                    if(!okb || !okj[q]) o.b1[q] = 0.0;
-                }
-            }
-            o.y0 = 0.0; o.y1 = 0.0;
-            if(diag)
-            {
-                const double u0 = y[oka ? ea : r0], u1 = y[okb ? eb : r0];
-                o.y0 = (cc == 0 && oka) ? u0 : 0.0; o.y1 = (cc == 0 && okb) ? u1 : 0.0;
-            }
+                if((mb >> q) & 1u) { o.b0[q] = pj[q][rowa]; o.b1[q] = pj[q][rowb]; }
+            if(diag) { o.y0 = y[ea]; o.y1 = y[eb]; }
         };
         auto apply = [&](const Operands& o)
         {
+            const double a0 = (o.six ? ma6 : ma3) ? o.a0 : 0.0, a1 = mb6 ? o.a1 : 0.0;
 #pragma unroll
             for(int q = 0; q < SYRK_STRIP; q++)
                 if((o.mb >> q) & 1u)
                 {
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.b0[q], acc[q], 0, 0, 0);
-                    if(o.two) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.b1[q], acc[q], 0, 0, 0);
+                    // (the columns past the matrix, in its last tile, were never written: not even a zero times them)
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, okj[q] ? o.b0[q] : 0.0, acc[q], 0, 0, 0);
+                    if(o.six) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, okj[q] ? o.b1[q] : 0.0, acc[q], 0, 0, 0);
                 }
             if(diag)
             {
-                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a0, o.y0, accr, 0, 0, 0);
-                if(o.two) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a1, o.y1, accr, 0, 0, 0);
+                accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, (cc == 0) ? o.y0 : 0.0, accr, 0, 0, 0);
+                if(o.six) accr = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, (cc == 0) ? o.y1 : 0.0, accr, 0, 0, 0);
             }
         };
-        Operands cur, nxt;
-        bool have = false;
-        const int nblk = b_last - b_first + 1;
-        for(int base = 0; base < nblk; base += 64)
+        // (round 4: SYRK_DEPTH blocks' operands in flight at once - the walk was one block ahead, and a block's ten
+        //  loads are ten cache lines 9.6 KB apart: a trip to memory per block that counts, ~15 of them a workgroup)
+        Operands ring[SYRK_DEPTH];
+        int nring = 0;
+        // (wave w: the blocks w, w + SYRK_SPARSE_WAVES, ... of the slice, 64 of them at a time)
+        for(int base = 0; SYRK_SPARSE_WAVES*base + wave < nblk; base += 64)
         {
             unsigned m = 0;         // bits 0..3: the block touches B tile q of the strip; bit 4: it touches the A tile
-            if(base + lane < nblk)
+            const int jblk = SYRK_SPARSE_WAVES*(base + lane) + wave;
+            if(jblk < nblk)
             {
-                const unsigned* __restrict__ ob = occ + (size_t)(b_first + base + lane)*nocc;
+                const unsigned* __restrict__ ob = occ + (size_t)(b_first + nslices*jblk)*nocc;
                 const unsigned wa = ob[wi];
                 const int w0i = bj0 >> 5, w1i = min((bj0 + SYRK_STRIP - 1) >> 5, nocc - 1);
                 const unsigned w0 = ob[w0i], w1 = ob[w1i];
@@ -1823,23 +2010,82 @@ void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e
                 if(wa & mi) m |= 16u;
             }
             unsigned long long live = __ballot((m & 16u) && (diag || (m & 15u)));
+            SYRK_TICK(sts_scan)
+#ifdef SYRK_TS
+            sts_live += __popcll(live);
+#endif
             while(live)
             {
-                const int bit = __ffsll((long long)live) - 1;
-                live &= live - 1;
-                const unsigned mb = (unsigned)__builtin_amdgcn_readlane((int)m, bit);
-                fetch(b_first + base + bit, mb, nxt);
-                if(have) apply(cur);
-                cur = nxt; have = true;
+                // fill the ring, then spend it
+#pragma unroll
+                for(int d = 0; d < SYRK_DEPTH; d++)
+                    if(d >= nring && live)
+                    {
+                        const int bit = __ffsll((long long)live) - 1;
+                        live &= live - 1;
+                        const unsigned mb = (unsigned)__builtin_amdgcn_readlane((int)m, bit);
+                        fetch(b_first + nslices*(SYRK_SPARSE_WAVES*(base + bit) + wave), mb, ring[d]);
+                        nring = d + 1;
+                        touched |= mb;
+#ifdef SYRK_TS
+                        sts_mma += __popc(mb & 15u);
+#endif
+                    }
+                if(nring == SYRK_DEPTH)
+                {
+#pragma unroll
+                    for(int d = 0; d < SYRK_DEPTH; d++) apply(ring[d]);
+                    nring = 0;
+                }
             }
+            SYRK_TICK(sts_blocks)
         }
-        if(have) apply(cur);
+#pragma unroll
+        for(int d = 0; d < SYRK_DEPTH; d++) if(d < nring) apply(ring[d]);
+        SYRK_TICK(sts_blocks)
     }
+    // the waves' sums, in wave order
+    if(SYRK_SPARSE_WAVES > 1)
+    {
+        __shared__ double red[SYRK_SPARSE_WAVES - 1][(SYRK_STRIP + 1)*256];
+        __shared__ unsigned s_touched[SYRK_SPARSE_WAVES];
+        if(lane == 0) s_touched[wave] = touched;
+        if(wave > 0 && touched)
+        {
+            double* __restrict__ o = red[wave - 1];
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+#pragma unroll
+                for(int v=0;v<4;v++) o[q*256 + 64*v + lane] = acc[q][v];
+#pragma unroll
+            for(int v=0;v<4;v++) o[SYRK_STRIP*256 + 64*v + lane] = accr[v];
+        }
+        __syncthreads();
+        if(wave > 0) return;
+        for(int w = 1; w < SYRK_SPARSE_WAVES; w++)
+        {
+            const unsigned tw = s_touched[w];
+            if(!tw) continue;       // (nothing but zeros)
+            touched |= tw;
+            const double* __restrict__ o = red[w - 1];
+#pragma unroll
+            for(int q = 0; q < SYRK_STRIP; q++)
+#pragma unroll
+                for(int v=0;v<4;v++) acc[q][v] += o[q*256 + 64*v + lane];
+#pragma unroll
+            for(int v=0;v<4;v++) accr[v] += o[SYRK_STRIP*256 + 64*v + lane];
+        }
+    }
+    // A tile no block of the slice touched is not written: its flag says so and the reduction does not read it
+    // (7 of 8 slots at BASELINE configuration 2: 49 MB of zeros written and read back, before)
     const int slot = slot0 + sy;
 #pragma unroll
     for(int q = 0; q < SYRK_STRIP; q++)
     {
         if(q >= ntile) break;
+        const bool any = (touched >> q) & 1u;
+        if(lane == 0) live_out[(size_t)slot*npairs + pair0 + q] = any ? 1 : 0;
+        if(!any) continue;
         double* __restrict__ o = Spart + ((size_t)slot*npairs + pair0 + q)*256;
 #pragma unroll
         for(int v=0;v<4;v++) o[64*v + lane] = acc[q][v];
@@ -1850,6 +2096,11 @@ void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e
 #pragma unroll
         for(int v=0;v<4;v++) rpart[kk + 4*v] = accr[v];
     }
+#ifdef SYRK_TS
+    if(lane == 0 && sy == 3 && (px % 97 == 0))
+        printf("syrk strip %d (tile row %d, from tile %d) slice %d: wall %lld, whole %lld cycles: scan %lld, blocks %lld (%d live, %d B tiles)\n",
+               px, bi, bj0, sy, sts_wall0, clock64() - sts_begin, sts_scan, sts_blocks, sts_live, sts_mma);
+#endif
 }
 
 // Dense Cholesky of S (lower triangle valid on input) and the solve S d = -r,
@@ -3494,7 +3745,8 @@ __global__ __launch_bounds__(256)
 void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const SolverCtl* __restrict__ ctl,
                          const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
                          int nslots, const double* __restrict__ Spart,
-                         double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status)
+                         double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status,
+                         const unsigned char* __restrict__ live)
 {
     if(fl->skip_elim) return;
     const OpDev& O = ops[fl->elim_sel];
@@ -3504,7 +3756,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         // (every rank adds its own); of a point re-eliminated later it is already the
         // sum over the ranks (step2_finish unpacked it): the leader alone adds it
         const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
-        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x);
+        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live);
         return;
     }
     double* __restrict__ tail = r + nd.Nc;
@@ -3803,10 +4055,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
         if(splined_boards)
         {
-            const int rows_cap = std::min(P.W*P.H, SPL_ROWS_CAP);          // 64 KB of LDS: two workgroups per CU
-            const size_t lds = (size_t)rows_cap*SPL_TW*sizeof(double);
-            hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), lds, stream,
-                               P, nd, B.R, plan, B.Jp, B.Ji, rows_cap);
+            // (72 KB of LDS for the tile: two workgroups per CU)
+            hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), 0, stream,
+                               P, nd, B.R, plan, B.Jp, B.Ji);
             // a copy of the row per wave, as many waves as the LDS holds copies
             const size_t row_bytes = (size_t)(nd.Nc + 1)*sizeof(double);
             const int nwaves = (int)std::min<size_t>(SPLG_WAVES, (size_t)(150*1024)/row_bytes);
@@ -3817,7 +4068,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // What follows the workgroups above writes the camera block's A and g, and |x|^2: nothing the block
             // elimination or the SYRK read. With a side stream it runs beside them (unless there are other rows
             // - discrete points - that add to A with atomics at the same time)
-            if(side != NULL && forked != NULL && rows_to == rows_from)
+            // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
+            static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
+            if(side != NULL && forked != NULL && rows_to == rows_from && !one_stream)
             {
                 hipError_t e = hipEventRecord(ev_fork, stream);           if(e != hipSuccess) return e;
                 e = hipStreamWaitEvent(side, ev_fork, 0);                 if(e != hipSuccess) return e;
@@ -3892,18 +4145,26 @@ static int syrk_grid_x(const NormalDims& nd)
     for(int bi = 0; bi < nb; bi++) nstrips += (nb - bi + SYRK_STRIP - 1)/SYRK_STRIP;
     return nstrips;
 }
+// The sparse SYRK (the splined models) takes more slices than the dense ones: a strip's blocks that count are few but
+// unevenly spread - the strips over the middle of the imager have a third of a slice's blocks to go through, one trip
+// to memory each, while nine strips in ten have none -, and a slot nobody wrote costs the reduction a flag
+#ifndef SYRK_SPARSE_SLICES
+#define SYRK_SPARSE_SLICES 8
+#endif
+static bool syrk_sparse_range(const NormalDims& nd) { return nd.Nc > SYRK_STRIP_FROM && nd.Nc <= 4096; }
 // slices per part at most: a multiple of 8
-static int syrk_max_slices(const NormalDims& nd)
+static int syrk_max_slices(const NormalDims& nd, bool sparse)
 {
+    if(sparse) return SYRK_SPARSE_SLICES;
     int ns = SYRK_TARGET_WAVES / syrk_grid_x(nd);
     if(ns < 1) ns = 1;
     return (ns + 7) & ~7;
 }
-static void syrk_slicing(const NormalDims& nd, int nrows, int* nslices, int* e_per_slice)
+static void syrk_slicing(const NormalDims& nd, int nrows, bool sparse, int* nslices, int* e_per_slice)
 {
     // no camera variables at all (a solve for the frames alone): no Schur complement, no slices
     if(nd.Nc == 0) { *nslices = 0; *e_per_slice = 4*SYRK_UNROLL; return; }
-    int ns = syrk_max_slices(nd);
+    int ns = syrk_max_slices(nd, sparse);
     int per = (nrows + ns - 1)/ns;
     per = ((per + 4*SYRK_UNROLL - 1)/(4*SYRK_UNROLL))*(4*SYRK_UNROLL);
     if(per < 4*SYRK_UNROLL) per = 4*SYRK_UNROLL;
@@ -3915,23 +4176,33 @@ size_t schur_partial_doubles(const NormalDims& nd)
 {
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     if(nd.Nc == 0) return 64;
-    const size_t nslots = 2*(size_t)syrk_max_slices(nd);
-    return nslots*npairs*256 + nslots*nb*16 + 64;
+    // (the slots of the sparse SYRK if the camera block is of its size: which kernel runs is the caller's FactorBuffers::occ)
+    const size_t nslots = 2*(size_t)std::max(syrk_max_slices(nd, false), syrk_sparse_range(nd) ? syrk_max_slices(nd, true) : 0);
+    return nslots*npairs*256 + nslots*nb*16 + 64 + (nslots*npairs + 7)/8;
+}
+// the sparse SYRK's flags [nslots][npairs], behind the partial products
+static unsigned char* syrk_live_flags(const NormalDims& nd, const FactorBuffers& F, int nslots)
+{
+    const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    return (unsigned char*)(F.Spart + (size_t)nslots*npairs*256 + (size_t)nslots*nb*16 + 64);
 }
 
 // the SYRK of the local E rows (two contiguous ranges: frames, points) into
 // Spart; ride (optional): assemble_finalize() in an extra row of the first launch
 static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* skip, const FactorBuffers& F,
-                       const FinalizeRide* ride, hipStream_t stream)
+                       const FinalizeRide* ride, hipStream_t stream, const unsigned char** live /* out: the slots' flags, or NULL */)
 {
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
+    const bool sparse = nd.Nc > SYRK_STRIP_FROM && F.occ != NULL && F.Wtile != NULL;
     int e_lo[2], e_hi[2], ns[2] = {0,0}, per[2] = {0,0};
     for(int part = 0; part < 2; part++)
     {
         br.e_range(nd, part, &e_lo[part], &e_hi[part]);
-        if(e_hi[part] > e_lo[part]) syrk_slicing(nd, e_hi[part] - e_lo[part], &ns[part], &per[part]);
+        if(e_hi[part] > e_lo[part]) syrk_slicing(nd, e_hi[part] - e_lo[part], sparse, &ns[part], &per[part]);
     }
     const int nslots = ns[0] + ns[1];
+    unsigned char* flags = sparse ? syrk_live_flags(nd, F, nslots) : NULL;
+    *live = flags;
     FinalizeRide none; memset(&none, 0, sizeof(none));
     bool rode = false;
     for(int part = 0, slot0 = 0; part < 2; slot0 += ns[part], part++)
@@ -3943,10 +4214,10 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
             const int extra = with_ride ? (ride->plan.Ndest*FIN_LANES + gx*64 - 1)/(gx*64) : 0;
             fr.row0 = ns[part];
             rode = rode || with_ride;
-            if(nd.Nc > SYRK_STRIP_FROM && F.occ != NULL)
-                hipLaunchKernelGGL(schur_syrk_sparse_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
-                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr,
-                                   F.occ, occ_words(nd));
+            if(sparse)
+                hipLaunchKernelGGL(schur_syrk_sparse_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64*SYRK_SPARSE_WAVES), 0, stream,
+                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wtile, F.y, F.Spart, ns[part], fr,
+                                   F.occ, occ_words(nd), flags, syrk_grid_x(nd));
             else if(nd.Nc > SYRK_STRIP_FROM)
                 hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
                                    nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
@@ -3966,13 +4237,14 @@ hipError_t launch_factor_local(const NormalDims& nd, const BlockRanges& br,
 {
     if(br.count() > 0)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(br.count()), dim3(nd.Nc > 255 ? 256 : 64), 0, stream,
-                           nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status, F.occ, occ_words(nd));
+                           nd, br, 0, R, lambda, ctl, F.Wt, F.LD, F.y, F.status, F.occ, occ_words(nd), F.Wtile);
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
-    const int nslots = launch_syrk(nd, br, R.skip, F, NULL, stream);
+    const unsigned char* live = NULL;
+    const int nslots = launch_syrk(nd, br, R.skip, F, NULL, stream, &live);
     {
-        const int n = (npairs*256 + nb*16)*SRED_SPLIT;
+        const int n = (npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT);
         hipLaunchKernelGGL(schur_reduce_kernel, dim3((n + 255)/256), dim3(256), 0, stream,
-                           nd, R, lambda, ctl, is_leader ? 1 : 0, nslots, F.Spart, F.S, F.r);
+                           nd, R, lambda, ctl, is_leader ? 1 : 0, nslots, F.Spart, F.S, F.r, live);
     }
     return hipGetLastError();
 }
@@ -4152,7 +4424,8 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
         //  allocated for the splined models, whose blocks all do)
         hipLaunchKernelGGL(eblock_factor_kernel, dim3(nrest), dim3(nd.Nc > 255 ? 256 : 64), 0, stream,
                            nd, br, nframes_fused, R, 0.0, a.ctl, a.F->Wt, a.F->LD, a.F->y, a.F->status,
-                           (nframes_fused == 0) ? a.F->occ : (unsigned*)NULL, occ_words(nd));
+                           (nframes_fused == 0) ? a.F->occ : (unsigned*)NULL, occ_words(nd),
+                           (nframes_fused == 0) ? a.F->Wtile : (double*)NULL);
     }
     return hipGetLastError();
 }
@@ -4171,7 +4444,8 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
     {
         ride.npos = gram_stride(P.Ndist); ride.ops = a.ops; ride.sel = &fl->elim_sel; ride.skip = &fl->skip_asm; ride.plan = *a.plan;
     }
-    const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream);
+    const unsigned char* live = NULL;
+    const int nslots = launch_syrk(nd, br, &fl->skip_elim, F, ride.npos ? &ride : NULL, stream, &live);
     if(with_grams)
     {
         // (after the ride: one adder per destination at a time)
@@ -4186,9 +4460,9 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
         step2_side_pending = false;
     }
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
-    const int nred = ((npairs*256 + nb*16)*SRED_SPLIT + 255)/256;
+    const int nred = ((npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT) + 255)/256;
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status);
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }

@@ -94,6 +94,9 @@ struct FactorBuffers
     int*    status;   // [1] nonzero: not positive definite
     unsigned* occ;    // [NEb][occ_words(nd)] bit per 16-column tile of the camera block: does the block's Wt hold a nonzero there?
                       // Written by eblock_factor_kernel, read by the sparse SYRK (the splined models). NULL: not tracked
+    double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -
+                      // [ceil(Nc/16)][NE][16] - for the sparse SYRK: a block's rows of a tile are 768 contiguous bytes
+                      // (in Wt itself they are six pieces 9.6 KB apart, and a workgroup's few blocks that count are all over 46 MB)
 };
 inline int occ_words(const NormalDims& nd) { return (((nd.Nc + 15) >> 4) + 31) >> 5; }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The kernels of ONE trial step in time order, with start offsets and durations (us), from a rocprofv3
 --kernel-trace CSV directory: python tools/step_trace_dump.py <dir> [which_step]   (dev tool)
-A step begins at a step2_choose_kernel. Shows what overlaps what when a step uses two streams"""
+A step begins at a step2_choose_kernel (or at the prologue launch that carries the choice). Shows what overlaps what when a step uses two streams"""
 import sys, csv, glob
 rows = []
 for fn in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
@@ -9,6 +9,8 @@ for fn in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("mrcal_amd::", "").replace("void ", "")))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if "step2_choose" in r[2]]
+if len(starts) < 3:     # the choice rides in the prologue launch
+    starts = [i for i, r in enumerate(rows) if "board_prologue_kernel<true>" in r[2]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts)//2
 i0, i1 = starts[k], starts[k+1]
 t0 = rows[i0][0]
