@@ -808,26 +808,33 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
 __host__ __device__ inline int splg_nknotrows(const DeviceProblem& P) { return P.Nintr_state > 0 ? P.Ncameras_intrinsics*(P.Nintr_state - P.Ncore_state) : 0; }
 __host__ __device__ inline int splg_ndense(const DeviceProblem& P, const NormalDims& nd) { return nd.Nc + 1 - splg_nknotrows(P); }
 __global__ __launch_bounds__(64*SPLG_WAVES)
-void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nwaves)
+// window > 0 (a launch of the knots' rows alone): a wave's copy of the row is its last window+1 columns and the
+// camera's core - a knot's row of A holds nothing else: two control points meet in a Gram only if some corner's
+// (order+1)^2 patch holds both, so only within `order` knots of each other either way, and the lower triangle is the
+// part at or before the row: window = 2 (order Nx + order) columns. (The whole row, 1207 doubles a wave, was 77 KB of
+// LDS a workgroup - two workgroups a CU, 12 of its 20 us clearing and adding up zeros.) block0: the first row's number
+__global__ __launch_bounds__(64*SPLG_WAVES)
+void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nwaves, int block0, int window)
 {
     if(opref_skip(R)) return;
-    extern __shared__ double accs[];        // [nwaves][Nc+1]
+    extern __shared__ double accs[];        // [nwaves][stride]
     const OpDev& O = opref_get(R);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int stride = nd.Nc + 1;
+    const int stride = (window > 0) ? window + 1 + 4 : nd.Nc + 1;
     const int Nx = P.cfg.spline_Nx, Ncs = P.Ncore_state;
     const int nknot = splg_nknotrows(P), nintr = P.Nintr_state > 0 ? P.Ncameras_intrinsics*P.Nintr_state : 0;
+    const int blk = block0 + (int)blockIdx.x;
     // the row, and the observations this workgroup walks
     int r, obs0, obs1, dense = -1, chunk = 0;
-    if((int)blockIdx.x < nknot)
+    if(blk < nknot)
     {
-        const int per = P.Nintr_state - Ncs, ic = blockIdx.x / per;
-        r = ic*P.Nintr_state + Ncs + (blockIdx.x - ic*per);
+        const int per = P.Nintr_state - Ncs, ic = blk / per;
+        r = ic*P.Nintr_state + Ncs + (blk - ic*per);
         obs0 = 0; obs1 = P.Nobs_board;
     }
     else
     {
-        dense = (blockIdx.x - nknot) / SPLG_E; chunk = (blockIdx.x - nknot) % SPLG_E;
+        dense = (blk - nknot) / SPLG_E; chunk = (blk - nknot) % SPLG_E;
         const int ncore = P.Nintr_state > 0 ? P.Ncameras_intrinsics*Ncs : 0;
         r = (dense < ncore) ? (dense / Ncs)*P.Nintr_state + dense % Ncs : nintr + (dense - ncore);
         const int per = (P.Nobs_board + SPLG_E - 1)/SPLG_E;
@@ -941,10 +948,21 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                             const int c = cs[k][it];
                             const double vv = v[k][xy][it];
                             if(c == -1 || vv == 0.0) continue;
-                            if(c == -2) acc[nd.Nc] += vv;
-                            else        acc[state_to_SE(nd, c + ((lane + 64*it < Kk[k]) ? xy : 0))] += vv;
+                            if(c == -2) { acc[nd.Nc] += vv; continue; }
+                            const int se = state_to_SE(nd, c + ((lane + 64*it < Kk[k]) ? xy : 0));
+                            if(window <= 0) acc[se] += vv;
+                            else
+                            {
+                                // (a control point further away than a patch reaches: a structural zero that is not one)
+                                const int pw = se - (r - window);
+                                if(pw >= 0) acc[pw] += vv; else O.scalars[SC_BAD_STRUCTURE] = 1.0;
+                            }
                         }
-                        if(csc[k] >= 0 && vc[k][xy] != 0.0) acc[state_to_SE(nd, csc[k])] += vc[k][xy];
+                        if(csc[k] >= 0 && vc[k][xy] != 0.0)
+                        {
+                            if(window <= 0) acc[state_to_SE(nd, csc[k])] += vc[k][xy];
+                            else            acc[window + 1 + lane] += vc[k][xy];        // (csc = the camera's core + lane)
+                        }
                     }
             }
         }
@@ -956,7 +974,13 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
         double s = 0.0;
         for(int w = 0; w < nwaves; w++) s += accs[w*stride + c];
         if(dense >= 0) { plan.spl_part[((size_t)dense*SPLG_E + chunk)*stride + c] = s; continue; }
-        if(s != 0.0 && c <= r) O.A[(size_t)r*nd.Nc + c] += s;
+        int col = c;
+        if(window > 0)
+        {
+            const int per = P.Nintr_state - Ncs, ic = blk / per;
+            col = (c <= window) ? r - window + c : ic*P.Nintr_state + (c - window - 1);
+        }
+        if(s != 0.0 && col >= 0 && col <= r) O.A[(size_t)r*nd.Nc + col] += s;
     }
 }
 // The regularization rows of a splined model (regularization_splined_kernel in kernels.hip): per knot a radial
@@ -4077,8 +4101,14 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                 *forked = true;
                 gstream = side;
             }
-            hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(splg_nknotrows(P) + ndense*SPLG_E), dim3(64*SPLG_WAVES),
-                               nwaves*row_bytes, gstream, P, nd, B.R, plan, nwaves);
+            // the knots' rows (a window of columns each), then the rows every pass holds (whole)
+            const int nknotrows = splg_nknotrows(P);
+            const int window = 2*(P.cfg.spline_order*P.cfg.spline_Nx + P.cfg.spline_order);
+            if(nknotrows > 0)
+                hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(nknotrows), dim3(64*SPLG_WAVES),
+                                   (size_t)SPLG_WAVES*(window + 1 + 4)*sizeof(double), gstream, P, nd, B.R, plan, SPLG_WAVES, 0, window);
+            hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(ndense*SPLG_E), dim3(64*SPLG_WAVES),
+                               nwaves*row_bytes, gstream, P, nd, B.R, plan, nwaves, nknotrows, 0);
             // (the regularization rows: in pairs, rows_pairs_kernel, after whatever other rows there are)
         }
         bool planned = false;
