@@ -67,7 +67,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(plan.chunk_pair); hipFree(plan.obs_pair); hipFree(plan.pair_table); hipFree(plan.frame_pos); hipFree(plan.obs_cols);
     hipFree(plan.chunk_part); hipFree(plan.dest_id); hipFree(plan.dest_begin); hipFree(plan.dest_src);
     hipFree(plan.pair_chunk_begin); hipFree(plan.row_part); hipFree(plan.qf_part); hipFree(plan.dots_part);
-    hipFree(plan.spl_hdr); hipFree(plan.spl_part);
+    hipFree(plan.spl_hdr); hipFree(plan.spl_part); hipFree(plan.spl_hdr_extra); hipFree(plan.chunk_extra);
     {
         mrcal_amd::GenPlan& G = plan.gen;
         hipFree(G.rows); hipFree(G.chunk_begin); hipFree(G.chunk_group); hipFree(G.group_k); hipFree(G.group_off); hipFree(G.spos);
@@ -558,8 +558,8 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             // splined models: the staged Grams of assemble_splined_kernel (two passes per observation), the knot
             // boxes, and the parts of the rows of the camera block that are not knots (+ the x row)
             const int nknotrows = P->D.Nintr_state > 0 ? P->D.Ncameras_intrinsics*(P->D.Nintr_state - P->D.Ncore_state) : 0;
-            ok = ok && dev_alloc(&P->plan.chunk_part, (size_t)2*Nobs*SPL_TRI);
-            ok = ok && dev_alloc(&P->plan.spl_hdr,    (size_t)Nobs);
+            ok = ok && dev_alloc(&P->plan.chunk_part,    (size_t)2*Nobs*SPL_TRI);
+            ok = ok && dev_alloc(&P->plan.spl_hdr,       (size_t)Nobs);
             ok = ok && dev_alloc(&P->plan.spl_part,   (size_t)(nd.Nc + 1 - nknotrows)*SPLG_E*(nd.Nc + 1));
         }
         ok = ok && build_gen_plan(P);
@@ -572,6 +572,13 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             ok = ok && dev_alloc(&P->plan.qf_part, (size_t)4*(P->plan.qf_part_n > 0 ? P->plan.qf_part_n : 1));
             ok = ok && dev_alloc(&P->plan.dots_part, (size_t)2*(nd.NEb > 0 ? nd.NEb : 1));
         }
+    }
+    // (the second, third and fourth sub-boxes of the splined models' close-ups, which mostly nobody touches: last)
+    if(P->plan.spl_hdr != NULL)
+    {
+        const size_t Nobs = (size_t)(P->D.Nobs_board > 0 ? P->D.Nobs_board : 1);
+        ok = ok && dev_alloc(&P->plan.chunk_extra,   (size_t)2*Nobs*(SPL_MAXSUB - 1)*SPL_TRI);
+        ok = ok && dev_alloc(&P->plan.spl_hdr_extra, Nobs*(SPL_MAXSUB - 1));
     }
     if(!ok) return false;
     // rows of blocks nobody writes (frames without observations in this shard) must read as zero

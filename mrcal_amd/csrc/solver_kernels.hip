@@ -450,6 +450,19 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
 #define SPL_LDS_DOUBLES 8192
 typedef double spl_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int spl_tri(int r) { return (r*(r + 1)) >> 1; }
+// where pass (observation o, surface xy, sub-box isub) stages its triangle, and its header: the first sub-box of every
+// observation where the only one always was (the usual case reads what it always read), the others behind all of those
+// (in allocations of their own: with one allocation four times the size, the launches that run side by side - the
+//  gather, the SYRK - were 40% slower at BASELINE configuration 2, which has no second sub-box anywhere)
+__device__ __forceinline__ double* spl_slot(const AssemblyPlan& plan, int o, int xy, int isub)
+{
+    return (isub == 0) ? plan.chunk_part  + ((size_t)2*o + xy)*SPL_TRI
+                       : plan.chunk_extra + (((size_t)2*o + xy)*(SPL_MAXSUB - 1) + (isub - 1))*SPL_TRI;
+}
+__device__ __forceinline__ SplHdr* spl_hdr_at(const AssemblyPlan& plan, int o, int isub)
+{
+    return (isub == 0) ? plan.spl_hdr + o : plan.spl_hdr_extra + (size_t)o*(SPL_MAXSUB - 1) + (isub - 1);
+}
 // a workgroup barrier that orders the LDS traffic only: the global stores in flight (the staged triangle) are not waited for
 __device__ __forceinline__ void spl_lds_barrier()
 {
@@ -533,6 +546,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     __shared__ __attribute__((aligned(16))) double Jd[SPL_LDS_DOUBLES];     // [rows][LD] of a pass
     __shared__ double F[7*SPL_TW];          // the frame rows and the x row of a pass's Gram
     __shared__ double FD[7*6];              // the frame's own block and its part of the gradient, summed over the passes
+    __shared__ unsigned char own[1024];     // sub-boxes: which of them a corner belongs to
     __shared__ double FB[6*SPL_NDENSE];     // the frame rows against the core, the extrinsics and the warp: over an observation's two passes (the warp: over the frame)
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
@@ -570,17 +584,47 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int4 box  = make_int4(__builtin_amdgcn_readfirstlane(boxv.x), __builtin_amdgcn_readfirstlane(boxv.y),
                                     __builtin_amdgcn_readfirstlane(boxv.z), __builtin_amdgcn_readfirstlane(boxv.w));
         const bool any = (P.Ndist_row > 0) && box.y >= 0;
-        const int ix0 = any ? box.x : 0, iy0 = any ? box.z : 0;
-        const int wx = any ? box.y - box.x + 1 : 0, wy = any ? box.w - box.z + 1 : 0;
-        const int K  = wx*wy;
+        const int ox0 = any ? box.x : 0, oy0 = any ? box.z : 0;
+        const int owx = any ? box.y - box.x + 1 : 0, owy = any ? box.w - box.z + 1 : 0;
+        // sub-boxes (solver_kernels.hpp): one if the box fits the tile, else a grid of them, SPL_SUB_MAX wide and
+        // high at most, each owning the corners whose patch starts in its first SPL_SUB_MAX - order columns and rows
+        const int order = P.cfg.spline_order, T = SPL_SUB_MAX - order;
+        int nsx = 1, nsy = 1;
+        if(owx*owy + SPL_NEXTRA > SPL_TW)
+        {
+            nsx = max(1, (owx - order + T - 1)/T);
+            nsy = max(1, (owy - order + T - 1)/T);
+        }
+        const int nsub = nsx*nsy;
         SPL_TICK(ts_bbox)
-        if(K + SPL_NEXTRA > SPL_TW)
+        if(nsub > SPL_MAXSUB || (nsub > 1 && NPTS > (int)sizeof(own)))
         {
             if(t == 0) plan.spl_hdr[o] = SplHdr{ 0, 0, -1, -1 };
             spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
             continue;
         }
-        if(t == 0) plan.spl_hdr[o] = SplHdr{ ix0, iy0, wx, wy };
+        if(nsub > 1)
+        {
+            // whose corner: from the first control point of its x row (an outlier's, outside the box: nobody's)
+            for(int c = t; c < NPTS; c += blockDim.x)
+            {
+                const int rel  = Ji[p00 + 2*c*L + (Ncs ? 2 : 0)] - (m_isi + Ncs);
+                const int knot = rel >> 1, px = knot % Nx - ox0, py = knot / Nx - oy0;
+                const int gx = px / T, gy = py / T;
+                own[c] = (px >= 0 && py >= 0 && gx < nsx && gy < nsy) ? (unsigned char)(gy*nsx + gx) : (unsigned char)255;
+            }
+            __syncthreads();
+        }
+#pragma unroll 1
+        for(int isub = 0; isub < nsub; isub++)
+        {
+        const int sgx = isub % nsx, sgy = isub / nsx;
+        const int ix0 = ox0 + ((nsub > 1) ? sgx*T : 0), iy0 = oy0 + ((nsub > 1) ? sgy*T : 0);
+        const int wx  = (nsub > 1) ? min(T + order, ox0 + owx - ix0) : owx;
+        const int wy  = (nsub > 1) ? min(T + order, oy0 + owy - iy0) : owy;
+        const int K   = wx*wy;
+        // (the first header says how many there are: wy | nsub << 16)
+        if(t == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx, (isub == 0) ? (wy | (nsub << 16)) : wy };
         const int NC = K + SPL_NEXTRA;                  // local columns in use
         const int NS = (NC + 15) >> 4;                  // 16-column tiles in use
         const int LD = 16*(NS + 1 - (NS & 1));          // row stride: an odd number of tiles
@@ -615,7 +659,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             // A board's rows mostly fit the tile at once. When they do not, every chunk of rows makes its own Gram and
             // ADDS it to what is staged (and to F): no accumulator is live while rows are fetched - held across the
             // loop they were spilled on every path, and a reload from scratch waits for every store in flight
-            double* __restrict__ G = plan.chunk_part + ((size_t)2*o + xy)*SPL_TRI;
+            double* __restrict__ G = spl_slot(plan, o, xy, isub);
 #pragma unroll 1
             for(int c0 = 0; c0 < NPTS; c0 += rows_cap)
             {
@@ -652,7 +696,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                 {
 #pragma unroll
                     for(int u = 0; u < EB; u++)
-                        if(ii[u] >= 0 && v[u] != 0.0) Jd[ii[u]*LD + local_of(ci[u])] = v[u];
+                        if(ii[u] >= 0 && v[u] != 0.0 && (nsub == 1 || own[c0 + ii[u]] == isub)) Jd[ii[u]*LD + local_of(ci[u])] = v[u];
                 };
                 ask(0, v0, ci0, ii0);
                 const double xv = x[r0 + 2*(c0 + min(tq, nr - 1)) + xy];
@@ -667,8 +711,9 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     if(e0 + 2*EB*256 < ne) ask(e0 + 2*EB*256, v0, ci0, ii0);
                     put(v1, ci1, ii1);
                 }
-                if(tq < nr) Jd[tq*LD + lx] = xv;
-                for(int i = tq + blockDim.x; i < nr; i += blockDim.x) Jd[i*LD + lx] = x[r0 + 2*(c0 + i) + xy];
+                if(tq < nr && (nsub == 1 || own[c0 + tq] == isub)) Jd[tq*LD + lx] = xv;
+                for(int i = tq + blockDim.x; i < nr; i += blockDim.x)
+                    if(nsub == 1 || own[c0 + i] == isub) Jd[i*LD + lx] = x[r0 + 2*(c0 + i) + xy];
                 spl_lds_barrier();
                 SPL_TICK(ts_scatter)
                 int r16g = r16, kqg = kq;
@@ -754,13 +799,17 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     {
                         const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m_isi, m_ise);
                         if(cs < 0) continue;
-                        // a knot's column is written by this pass of this observation and by nobody else
-                        O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)] = vv;
+                        // a knot's column is written by this pass of this observation and by nobody else - or, cut
+                        // into sub-boxes, by the passes of those that hold it, one after the other (the barrier below)
+                        double* __restrict__ dst = &O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)];
+                        if(nsub == 1) *dst = vv; else *dst += vv;
                     }
                 }
+            if(nsub > 1) __syncthreads();
             // (F is written again after the next pass's barriers)
             SPL_TICK(ts_out)
         }
+        }   // isub
         // the observation's core and extrinsics columns of Bt: one addition each, nothing read back (an atomic one, as
         // below). The warp's columns wait for the frame's last observation
         spl_lds_barrier();
@@ -769,7 +818,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             const int ia = t / SPL_NDENSE, d = t - ia*SPL_NDENSE;
             if(d < 10 && FB[t] != 0.0)
             {
-                const int cs = spl_col_state(P, nd, K + d, K, ix0, iy0, wx > 0 ? wx : 1, 0, m_isi, m_ise);
+                const int cs = spl_col_state(P, nd, d, 0, 0, 0, 1, 0, m_isi, m_ise);      // (a column past the control points: their box does not matter)
                 if(cs >= 0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)], FB[t]);
                 FB[t] = 0.0;
             }
@@ -803,7 +852,8 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
 }
 
 #define SPLG_WAVES 8
-#define SPLG_BATCH 4      // passes whose loads are in flight together
+#define SPLG_BATCH 3      // passes whose loads are in flight together (4: 104 registers with the sub-boxes' loop, and two of these
+                          // workgroups and a SYRK workgroup no longer share a CU's registers: the launch beside the SYRK 122 us instead of 86)
 // rows of the camera block that are knots (a workgroup each), and the others + the x row (SPLG_E workgroups each)
 __host__ __device__ inline int splg_nknotrows(const DeviceProblem& P) { return P.Nintr_state > 0 ? P.Ncameras_intrinsics*(P.Nintr_state - P.Ncore_state) : 0; }
 __host__ __device__ inline int splg_ndense(const DeviceProblem& P, const NormalDims& nd) { return nd.Nc + 1 - splg_nknotrows(P); }
@@ -852,14 +902,22 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
         for(int ob = w0; ob < w1; ob += 64)
         {
             // lane l: does observation ob + l hold the row, and where (local row of the x pass, of the y pass)
+            // (an observation cut into sub-boxes has a pass, a header and a staged triangle for each: first the first
+            //  sub-box of the 64 observations, then the second of those that have one, ...)
             const int o = ob + lane;
-            int lr0 = -1, lr1 = -1, kind = 2;       // kind 0: a knot's row, 1: a core row, 2: the others
-            SplHdr h = { 0, 0, -1, -1 };
-            int isi = -1, ise = -1;
+            int isi = -1, ise = -1, nsub_l = 0;
+            SplHdr h0 = { 0, 0, -1, -1 };
             if(o < w1)
             {
-                h = plan.spl_hdr[o];
+                h0 = plan.spl_hdr[o];
                 isi = P.board_meta[o].i_state_intrinsics; ise = P.board_meta[o].i_state_extrinsics;
+                if(h0.wx >= 0) { nsub_l = h0.wy >> 16; h0.wy &= 0xffff; }
+            }
+            auto passes_of = [&](const int isub, const SplHdr h) __attribute__((always_inline))
+            {
+            int lr0 = -1, lr1 = -1, kind = 2;       // kind 0: a knot's row, 1: a core row, 2: the others
+            if(isub < nsub_l)
+            {
                 if(h.wx >= 0)
                 {
                     const int K = h.wx*h.wy;
@@ -918,7 +976,7 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                     {
                         const int lr = xy ? l1 : l0;
                         on[k][xy] = have && lr >= 0;
-                        const double* __restrict__ Gp = plan.chunk_part + ((size_t)2*oo + xy)*SPL_TRI;
+                        const double* __restrict__ Gp = spl_slot(plan, oo, xy, isub);
 #pragma unroll
                         for(int it = 0; it < 2; it++)
                         {
@@ -965,6 +1023,18 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                         }
                     }
             }
+            };
+            // (the first sub-box - almost always the only one - exactly as before there were any)
+            passes_of(0, h0);
+#ifndef SPLG_NO_SUB
+            if(__any(nsub_l > 1))
+                for(int isub = 1; __any(isub < nsub_l); isub++)
+                {
+                    SplHdr h = { 0, 0, -1, -1 };
+                    if(isub < nsub_l) h = *spl_hdr_at(plan, o, isub);
+                    passes_of(isub, h);
+                }
+#endif
         }
     }
     __syncthreads();

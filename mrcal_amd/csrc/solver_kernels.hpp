@@ -126,6 +126,13 @@ enum { FRAMEPOS_NONE = 0, FRAMEPOS_D, FRAMEPOS_D_MIRROR, FRAMEPOS_GF, FRAMEPOS_B
 #define SPL_TRI (128*129/2)
 #define SPLG_E  8         // workgroups sharing a row of the camera block that every pass holds (assemble_splined_gather_kernel)
 struct SplHdr { int ix0, iy0, wx, wy; };      // wx < 0: the observation went row by row, nothing is staged
+// An observation whose box of control points does not fit the local tile (more than SPL_SUB_MAX^2 of them) is cut into
+// up to SPL_MAXSUB SUB-BOXES of at most SPL_SUB_MAX x SPL_SUB_MAX control points that overlap by `order` - every corner's
+// (order+1)^2 patch lies whole in the sub-box its first control point belongs to - and each sub-box is a pass of its
+// own over the corners it owns: its own header, its own staged triangle. (Close-ups: a board over a third of a 30 x 20
+// grid is 17 x 17 control points. They used to go row by row, with atomics)
+#define SPL_MAXSUB  4
+#define SPL_SUB_MAX 10
 #ifndef QF_ROWS_PER_WAVE
 #define QF_ROWS_PER_WAVE 2    // rows of [A ; Bt] a wave of the quadratic-form workgroups takes
 #endif
@@ -209,7 +216,10 @@ struct AssemblyPlan
     int     qf_part_n;        // = quadform workgroups: (Nc + NE) rows, 4 waves x QF_ROWS_PER_WAVE rows each
     double* dots_part;        // [NEb][2] per-block (|d_e|^2, d_e . g_e) of the back-substitution
     // splined models (assemble_splined_kernel): chunk_part holds the staged Grams, [2 Nobs_board][SPL_TRI]
-    SplHdr* spl_hdr;          // [Nobs_board] the knot box of each observation
+    SplHdr* spl_hdr;          // [Nobs_board] the knot box of each observation's first (mostly: only) pass, with the number of
+                              // its sub-boxes in wy's upper half
+    SplHdr* spl_hdr_extra;    // [Nobs_board][SPL_MAXSUB - 1] the boxes of the other sub-boxes
+    double* chunk_extra;      // [2 Nobs_board (SPL_MAXSUB - 1)][SPL_TRI] ... and their staged triangles (spl_slot())
     double* spl_part;         // [rows every pass holds][SPLG_E][Nc+1]
 };
 

@@ -97,6 +97,46 @@ def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
     assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
+@pytest.mark.parametrize("distance,grid", ((1.2, "order=3_Nx=30_Ny=20"), (2.0, "order=3_Nx=30_Ny=20"), (1.5, "order=2_Nx=24_Ny=18"),
+                                           (2.5, "order=3_Nx=40_Ny=30")))
+def test_normal_equations_splined_closeups(amd, distance, grid):
+    """Boards close to the camera: an observation's box of control points (17 x 17 of a 30 x 20 grid at 1.2 m) does
+    not fit the assembly's local tile of 109, and is cut into sub-boxes that overlap by the spline's order, each a
+    pass over the corners it owns (solver_kernels.hpp SPL_MAXSUB; until round 4 such observations went row by row
+    with floating-point atomics). The normal equations against JtJ, and the same bits twice"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6,
+                                     lensmodel=f"LENSMODEL_SPLINED_STEREOGRAPHIC_{grid}_fov_x_deg=120",
+                                     object_width_n=10, object_height_n=10, seed=31, board_distance=distance)
+    oi["do_optimize_intrinsics_core"] = False
+    oi["observations_board"][2,1:3,4:6,2] = -1.   # some input outliers
+    with Problem(**oi) as p:
+        ne = p.normal_equations()
+        J, x = p.J(), p.x()
+        ne2 = p.normal_equations()
+    # (the boxes of the observations: what this test is about)
+    Nx = int(grid.split("Nx=")[1].split("_")[0])
+    Jd = J.toarray()
+    NPTS = 100
+    i0 = p.Nstate - p.Nstate     # (the control points follow the locked core: state index 0 on)
+    boxes = []
+    for o in range(oi["indices_frame_camintrinsics_camextrinsics"].shape[0]):
+        rows = Jd[2*NPTS*o:2*NPTS*(o+1)]
+        icam = oi["indices_frame_camintrinsics_camextrinsics"][o,1]
+        nk = (oi["intrinsics"].shape[1] - 4)//2
+        cols = np.nonzero(np.abs(rows[:, icam*2*nk:(icam+1)*2*nk]).sum(axis=0))[0]//2
+        if len(cols): boxes.append((cols % Nx).max() - (cols % Nx).min() + 1) ; boxes.append((cols // Nx).max() - (cols // Nx).min() + 1)
+    print(f"distance {distance} {grid}: the observations' boxes are up to {max(boxes)} control points across")
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    scale = np.abs(N).max()
+    assert np.abs(N_gpu - N).max() < 1e-10*scale
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    for k in ("A", "Bt", "D", "g"):
+        assert np.array_equal(ne[k], ne2[k]), k
+
+
 def test_normal_equations_splined_with_points(amd):
     """a splined model with discrete points beside the boards: the points' rows add to the camera block with
     atomics (the generic rows), so the gather of the staged board Grams stays on the main stream, in front of them"""
