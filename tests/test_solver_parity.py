@@ -340,6 +340,25 @@ def test_optimize_splined(amd, ref_api):
 
 
 @pytest.mark.timeout(900)
+def test_optimize_splined_closeups(amd, ref_api):
+    """A splined solve whose boards are close to the camera (1.5 m: an observation covers up to ~15 x 15 of the 30 x 20
+    control points, more than the assembly's local tile holds: the sub-boxes of solver_kernels.hpp) against the
+    reference's mrcal_optimize() at the same optimum - and again from the same inputs: the same bits (these
+    observations went row by row with floating-point atomics until round 4)"""
+    oi, truth = make_calibration_problem(amd._api, Ncameras=1, Nframes=40,
+                                         lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                         object_width_n=10, object_height_n=10, seed=35, board_distance=1.5)
+    oi["do_optimize_intrinsics_core"]  = False
+    oi["do_apply_outlier_rejection"]   = False
+    oa, sa = _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=5e-3)
+    ob = copy_inputs(oi)
+    sb = amd.optimize(**ob)
+    assert sb["rms_reproj_error__pixels"] == sa["rms_reproj_error__pixels"]
+    for k in ("intrinsics", "rt_ref_frame", "calobject_warp"):
+        assert np.array_equal(np.asarray(oa[k]), np.asarray(ob[k])), k
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("seed,icase", ((23, 22), (11, 29), (11, 120)))
 def test_optimize_splined_disputed_fuzz_cases(amd, ref_api, seed, icase):
     """The splined problems of the round-3 fuzz sweeps on which product and checker ended apart
