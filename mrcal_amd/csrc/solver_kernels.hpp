@@ -130,8 +130,9 @@ struct SplHdr { int ix0, iy0, wx, wy; };      // wx < 0: the observation went ro
 // up to SPL_MAXSUB SUB-BOXES of at most SPL_SUB_MAX x SPL_SUB_MAX control points that overlap by `order` - every corner's
 // (order+1)^2 patch lies whole in the sub-box its first control point belongs to - and each sub-box is a pass of its
 // own over the corners it owns: its own header, its own staged triangle. (Close-ups: a board over a third of a 30 x 20
-// grid is 17 x 17 control points. They used to go row by row, with atomics)
-#define SPL_MAXSUB  4
+// grid is 17 x 17 control points, 2 x 2 sub-boxes; one that fills the imager is the whole grid, 4 x 3 of them.
+// They used to go row by row, with atomics)
+#define SPL_MAXSUB  12
 #define SPL_SUB_MAX 10
 #ifndef QF_ROWS_PER_WAVE
 #define QF_ROWS_PER_WAVE 2    // rows of [A ; Bt] a wave of the quadratic-form workgroups takes

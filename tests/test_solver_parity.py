@@ -98,16 +98,17 @@ def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
 
 
 @pytest.mark.parametrize("distance,grid", ((1.2, "order=3_Nx=30_Ny=20"), (2.0, "order=3_Nx=30_Ny=20"), (1.5, "order=2_Nx=24_Ny=18"),
-                                           (2.5, "order=3_Nx=40_Ny=30")))
+                                           (2.5, "order=3_Nx=40_Ny=30"), (-1.4, "order=3_Nx=30_Ny=20")))
 def test_normal_equations_splined_closeups(amd, distance, grid):
-    """Boards close to the camera: an observation's box of control points (17 x 17 of a 30 x 20 grid at 1.2 m) does
+    """Boards close to the camera: an observation's box of control points (15 x 15 of a 30 x 20 grid at 1.2 m, 18 across under a board twice the size) does
     not fit the assembly's local tile of 109, and is cut into sub-boxes that overlap by the spline's order, each a
     pass over the corners it owns (solver_kernels.hpp SPL_MAXSUB; until round 4 such observations went row by row
     with floating-point atomics). The normal equations against JtJ, and the same bits twice"""
     from mrcal_amd.resident import Problem
     oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6,
                                      lensmodel=f"LENSMODEL_SPLINED_STEREOGRAPHIC_{grid}_fov_x_deg=120",
-                                     object_width_n=10, object_height_n=10, seed=31, board_distance=distance)
+                                     object_width_n=10, object_height_n=10, seed=31, board_distance=abs(distance),
+                                     object_spacing=0.2 if distance < 0 else 0.1)       # (< 0: a board twice the size)
     oi["do_optimize_intrinsics_core"] = False
     oi["observations_board"][2,1:3,4:6,2] = -1.   # some input outliers
     with Problem(**oi) as p:
