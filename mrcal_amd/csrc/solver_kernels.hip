@@ -547,6 +547,8 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     __shared__ double F[7*SPL_TW];          // the frame rows and the x row of a pass's Gram
     __shared__ double FD[7*6];              // the frame's own block and its part of the gradient, summed over the passes
     __shared__ unsigned char own[1024];     // sub-boxes: which of them a corner belongs to
+    __shared__ unsigned short crow[1024];   // ... and its row among the corners of the sub-box being assembled (0xffff: another's)
+    __shared__ int s_nown;
     __shared__ double FB[6*SPL_NDENSE];     // the frame rows against the core, the extrinsics and the warp: over an observation's two passes (the warp: over the frame)
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
@@ -625,6 +627,28 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int K   = wx*wy;
         // (the first header says how many there are: wy | nsub << 16)
         if(t == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx, (isub == 0) ? (wy | (nsub << 16)) : wy };
+        // a sub-box's pass is over ITS corners only, packed: their rows in the tile, in corner order (a pass over all
+        // the corners with the others' rows left zero is as long as the whole observation's: 0.29 ms more a step with
+        // 2 x 2 sub-boxes under every board)
+        if(nsub > 1)
+        {
+            __syncthreads();        // (the previous sub-box's passes are through with crow)
+            if(wave == 0)
+            {
+                int nown = 0;
+                for(int cb = 0; cb < NPTS; cb += 64)
+                {
+                    const int  c    = cb + lane;
+                    const bool mine = c < NPTS && own[c] == isub;
+                    const unsigned long long mm = __ballot(mine);
+                    if(c < NPTS) crow[c] = mine ? (unsigned short)(nown + __popcll(mm & ((1ull << lane) - 1ull))) : (unsigned short)0xffff;
+                    nown += __popcll(mm);
+                }
+                if(lane == 0) s_nown = nown;
+            }
+            __syncthreads();
+        }
+        const int nrows = (nsub > 1) ? s_nown : NPTS;   // the pass's rows
         const int NC = K + SPL_NEXTRA;                  // local columns in use
         const int NS = (NC + 15) >> 4;                  // 16-column tiles in use
         const int LD = 16*(NS + 1 - (NS & 1));          // row stride: an odd number of tiles
@@ -661,7 +685,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             // loop they were spilled on every path, and a reload from scratch waits for every store in flight
             double* __restrict__ G = spl_slot(plan, o, xy, isub);
 #pragma unroll 1
-            for(int c0 = 0; c0 < NPTS; c0 += rows_cap)
+            for(int c0 = 0; c0 < max(nrows, 1); c0 += rows_cap)
             {
                 constexpr bool first = true;
                 spl_d4 acc[9];
@@ -669,9 +693,11 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                 //  the phase, not in front of the loop over the observations and carried - spilled - through everything)
                 int tq = t;
                 asm volatile("" : "+v"(tq));
-                const int nr = min(rows_cap, NPTS - c0), nr4 = (nr + 3) & ~3;
-                const int pbase = p00 + (2*c0 + xy)*L;
-                const int ne = nr*L;
+                const int nr = min(rows_cap, nrows - c0), nr4 = (nr + 3) & ~3;
+                // (one box: the entries of the corners c0 .. c0 + nr; sub-boxes: of all the corners, kept if the corner's
+                //  packed row is one of this chunk's)
+                const int pbase = p00 + ((nsub == 1 ? 2*c0 : 0) + xy)*L;
+                const int ne = (nsub == 1 ? nr : NPTS)*L;
                 // Six entries per thread asked for together (one entry at a time, its column only when the value is
                 // not zero, is two memory round trips per entry), the first six BEFORE the tile is cleared: their
                 // trip to memory and the clearing overlap
@@ -696,10 +722,15 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                 {
 #pragma unroll
                     for(int u = 0; u < EB; u++)
-                        if(ii[u] >= 0 && v[u] != 0.0 && (nsub == 1 || own[c0 + ii[u]] == isub)) Jd[ii[u]*LD + local_of(ci[u])] = v[u];
+                    {
+                        if(ii[u] < 0 || v[u] == 0.0) continue;
+                        int row = ii[u];
+                        if(nsub > 1) { row = (int)crow[ii[u]] - c0; if(row < 0 || row >= nr) continue; }
+                        Jd[row*LD + local_of(ci[u])] = v[u];
+                    }
                 };
                 ask(0, v0, ci0, ii0);
-                const double xv = x[r0 + 2*(c0 + min(tq, nr - 1)) + xy];
+                const double xv = x[r0 + 2*(((nsub == 1) ? c0 : 0) + max(0, min(tq, ((nsub == 1) ? nr : NPTS) - 1))) + xy];
                 for(int i = tq; i < nr4*(LD/2); i += blockDim.x) ((double2*)Jd)[i] = make_double2(0.0, 0.0);
                 spl_lds_barrier();
                 SPL_TICK(ts_zero)
@@ -711,9 +742,17 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     if(e0 + 2*EB*256 < ne) ask(e0 + 2*EB*256, v0, ci0, ii0);
                     put(v1, ci1, ii1);
                 }
-                if(tq < nr && (nsub == 1 || own[c0 + tq] == isub)) Jd[tq*LD + lx] = xv;
-                for(int i = tq + blockDim.x; i < nr; i += blockDim.x)
-                    if(nsub == 1 || own[c0 + i] == isub) Jd[i*LD + lx] = x[r0 + 2*(c0 + i) + xy];
+                if(nsub == 1)
+                {
+                    if(tq < nr) Jd[tq*LD + lx] = xv;
+                    for(int i = tq + blockDim.x; i < nr; i += blockDim.x) Jd[i*LD + lx] = x[r0 + 2*(c0 + i) + xy];
+                }
+                else
+                    for(int i = tq; i < NPTS; i += blockDim.x)
+                    {
+                        const int row = (int)crow[i] - c0;
+                        if(row >= 0 && row < nr) Jd[row*LD + lx] = (i == tq) ? xv : x[r0 + 2*i + xy];
+                    }
                 spl_lds_barrier();
                 SPL_TICK(ts_scatter)
                 int r16g = r16, kqg = kq;
@@ -776,7 +815,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     }
                 }
                 // (the tile is cleared again only after everybody is through with it)
-                if(c0 + rows_cap < NPTS) spl_lds_barrier();
+                if(c0 + rows_cap < nrows) spl_lds_barrier();
             }
             spl_lds_barrier();
             // what belongs to the frame: rows K+12 .. K+17 against the camera-block columns (Bt) and against each
