@@ -196,11 +196,18 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     // (the partition is validated by the assembly itself, on the device: a row that touches two eliminated
     //  blocks or has a column out of range raises SC_BAD_STRUCTURE. A loop over all entries on the host was
     //  25 ms at 37 M entries)
-    // This assembly goes row by row with atomics (rows_generic_kernel): exact to rounding, not the same bits twice.
+    // This assembly goes row by row with atomics, on sums made so that no addition rounds (rows_repro_kernel, round 4): the same
+    // bits whatever order the atomics land in. (MRCAL_AMD_PLAIN_ROW_SUMS: the plain sums of before, for comparisons.)
     // The factorization optimizer_callback() returns does not come through here: mrcal_amd_factorization_create_from_problem()
     const OpRef R = { f->d_op, NULL, NULL };
-    HIP_TRY(launch_assemble_rows(f->nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream), { delete f; return NULL; });
-    return factorization_finish(f);
+    double* scratch = NULL;
+    static const bool plain = (getenv("MRCAL_AMD_PLAIN_ROW_SUMS") != NULL);
+    if(!plain) HIP_TRY(hipMalloc((void**)&scratch, assemble_rows_scratch_doubles(f->nd)*sizeof(double)), { delete f; return NULL; });
+    const hipError_t ea = launch_assemble_rows(f->nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream, scratch, Nnz);
+    mrcal_amd_factorization* out = (ea == hipSuccess) ? factorization_finish(f) : NULL;      // (synchronizes the stream)
+    if(ea != hipSuccess) { set_error("launch_assemble_rows: %s", hipGetErrorString(ea)); delete f; }
+    if(scratch != NULL) hipFree(scratch);
+    return out;
 }
 
 // The factorization of JtJ at the problem's current state, from the problem itself (round 4): x, J and the block

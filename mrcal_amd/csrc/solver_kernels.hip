@@ -5312,17 +5312,156 @@ hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& 
     return hipGetLastError();
 }
 // normal equations of a bare CSR matrix (every row through the generic path)
+//
+// Nothing is known about such a matrix but its partition, so every row adds the products of its entries to A, Bt
+// and D with atomics - and the sum of doubles in the order the atomics happen to land is not the same twice. It IS
+// the same twice when no addition rounds (round 4; the idea of Demmel & Nguyen's pre-rounded reproducible sums):
+// with c_i = the binary exponent above the largest |entry| of column i (a pass of integer atomicMax: any order, the
+// same result), a product t of columns i, j is below 2^(c_i + c_j), and of the n < 2^(N-1) products that can meet in
+// one place
+//     q1 = t rounded to a multiple of u1 = 2^(c_i + c_j + N - 52)       ((t + 1.5 2^52 u1) - 1.5 2^52 u1, exactly)
+// sum to less than 2^52 u1: every partial sum is a multiple of u1 with 52 bits or fewer, no addition rounds, any
+// order gives the same double. The remainder r1 = t - q1 is exact and at most u1/2; it is split the same way one
+// level down, and that one's remainder once more: three accumulators per entry, what is dropped below
+// 2^(c_i + c_j + 3N - 159) a product (N = 23: 2^-90 of the largest product that can occur there). The entry is
+// (s1 + s2) + s3. Three times the atomics of the plain row-by-row assembly (rows_generic_kernel), and the same bits
+// every time: what a CHOLMOD_factorization(J) made from a bare matrix is built from.
+__global__ __launch_bounds__(256)
+void csr_column_max_kernel(long long Nnz, int Nstate, const int32_t* __restrict__ Ji, const double* __restrict__ Jv,
+                           unsigned long long* __restrict__ cmax /* [Nstate], zeroed: the bits of the largest |value| */)
+{
+    for(long long p = (long long)blockIdx.x*blockDim.x + threadIdx.x; p < Nnz; p += (long long)gridDim.x*blockDim.x)
+    {
+        const int c = Ji[p];
+        if((unsigned)c >= (unsigned)Nstate) continue;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(Jv[p]));
+        if(b > cmax[c]) atomicMax(&cmax[c], b);      // (monotone in |value|; NaN ends up largest and poisons the sums, as it should)
+    }
+}
+struct ReproAcc { double *A, *Bt, *D; };
+// t, below 2^c in magnitude, added to the three levels at offset i
+__device__ __forceinline__ void repro_add(const ReproAcc (&acc)[3], int which, size_t i, double t, int c, int N)
+{
+    double* const dst[3] = { which == 0 ? acc[0].A : (which == 1 ? acc[0].Bt : acc[0].D),
+                             which == 0 ? acc[1].A : (which == 1 ? acc[1].Bt : acc[1].D),
+                             which == 0 ? acc[2].A : (which == 1 ? acc[2].Bt : acc[2].D) };
+#pragma unroll
+    for(int l = 0; l < 3; l++)
+    {
+        // M = 1.5 2^(c + N): an ulp of 2^(c + N - 52)
+        const double M = __longlong_as_double(((long long)(1023 + c + N) << 52) | (1ll << 51));
+        const double q = __dadd_rn(__dadd_rn(t, M), -M);
+        if(q != 0.0) atomicAdd(&dst[l][i], q);
+        t = __dadd_rn(t, -q);
+        c += N - 52;
+    }
+}
+__global__ __launch_bounds__(64)
+void rows_repro_kernel(NormalDims nd, OpRef R, int row0, int row1, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                       const unsigned long long* __restrict__ cmax, int N, ReproAcc a0, ReproAcc a1, ReproAcc a2)
+{
+    const OpDev& O = opref_get(R);
+    const double* __restrict__ Jv = O.Jv;
+    const ReproAcc acc[3] = { a0, a1, a2 };
+    const int r = row0 + blockIdx.x*blockDim.x + threadIdx.x;
+    if(r >= row1) return;
+    const int p0 = Jp[r], p1 = Jp[r+1];
+    // the exponent above a column's largest |value|: biased exponent - 1023 + 1
+    auto cexp = [&](int c) { return (int)((cmax[c] >> 52) & 0x7ff) - 1022; };
+    for(int p = p0; p < p1; p++)
+    {
+        const int    ci = Ji[p];
+        const double vi = Jv[p];
+        if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
+        if(vi == 0.0) continue;
+        const int si = state_to_SE(nd, ci), ei = cexp(ci);
+        for(int q = p0; q < p1; q++)
+        {
+            const int cj = Ji[q];
+            if((unsigned)cj >= (unsigned)nd.Nstate) continue;
+            const double t = __dmul_rn(vi, Jv[q]);
+            if(t == 0.0) continue;
+            const int sj = state_to_SE(nd, cj);
+            const int c  = ei + cexp(cj);
+            // (the exponents the levels' constants are made of must exist: columns of ~1e+-100 and smaller are not served)
+            if(c + N > 900 || c + 3*N - 160 < -900) { O.scalars[SC_BAD_STRUCTURE] = 2.0; continue; }
+            // (the lower triangles of A and of the D blocks: repro_combine_kernel mirrors them)
+            if(si >= 0 && sj >= 0)     { if(sj <= si) repro_add(acc, 0, (size_t)si*nd.Nc + sj, t, c, N); }
+            else if(si < 0 && sj >= 0) repro_add(acc, 1, (size_t)(-si-1)*nd.Nc + sj, t, c, N);
+            else if(si < 0 && sj < 0)
+            {
+                int bi, ai, di, e0i, bj, aj, dj, e0j;
+                E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
+                E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
+                if(bi == bj) { if(aj <= ai) repro_add(acc, 2, (size_t)bi*36 + ai*6 + aj, t, c, N); }
+                else         O.scalars[SC_BAD_STRUCTURE] = 1.0;      // no row may touch two E blocks
+            }
+        }
+    }
+}
+// entry = (level 1 + level 2) + level 3. sym > 0: the array is made of sym x sym blocks of which the lower triangles
+// were summed; the upper ones are their mirror images
+__global__ __launch_bounds__(256)
+void repro_combine_kernel(size_t n, int sym, double* __restrict__ s1, const double* __restrict__ s2, const double* __restrict__ s3)
+{
+    for(size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x*blockDim.x)
+    {
+        size_t j = i;
+        if(sym > 0)
+        {
+            const size_t blk = i / ((size_t)sym*sym), e = i - blk*(size_t)sym*sym;
+            const size_t r = e / sym, c = e - r*sym;
+            if(c > r) continue;                 // (written by its mirror image's thread)
+            j = blk*(size_t)sym*sym + c*sym + r;
+        }
+        const double v = (s1[i] + s2[i]) + s3[i];
+        s1[i] = v;
+        if(j != i) s1[j] = v;
+    }
+}
+size_t assemble_rows_scratch_doubles(const NormalDims& nd)
+{
+    const size_t one = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36;
+    return 2*one + (size_t)nd.Nstate + 64;
+}
+// scratch: assemble_rows_scratch_doubles(nd) doubles (the second and third levels of A, Bt, D; the columns' maxima), or
+// NULL: the plain row-by-row assembly, whose sums depend on the order the atomics land in. x is not looked at with a
+// scratch (a bare matrix has none: g and |x|^2 stay zero)
 hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
-                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream)
+                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream, double* scratch, long long Nnz)
 {
     {
         const size_t total = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + nd.Nstate + NSCALARS;
         int nb = (int)((total + 255)/256); if(nb > 2048) nb = 2048;
         hipLaunchKernelGGL(zero_normal_kernel, dim3(nb), dim3(256), 0, stream, nd, R);
     }
-    if(Nmeas > 0)
+    if(Nmeas <= 0) return hipGetLastError();
+    if(scratch == NULL || R.sel != NULL)
+    {
         hipLaunchKernelGGL(rows_generic_kernel, dim3((Nmeas + 63)/64), dim3(64), 0, stream,
                            nd, R, 0, Nmeas, Jp, Ji);
+        return hipGetLastError();
+    }
+    const size_t nA = (size_t)nd.Nc*nd.Nc, nB = (size_t)nd.NE*nd.Nc, nD = (size_t)nd.NEb*36, one = nA + nB + nD;
+    hipError_t e = hipMemsetAsync(scratch, 0, assemble_rows_scratch_doubles(nd)*sizeof(double), stream);
+    if(e != hipSuccess) return e;
+    // (R.sel == NULL: the operating point's pointers are the host's to read)
+    OpDev O;
+    e = hipMemcpyAsync(&O, R.ops, sizeof(OpDev), hipMemcpyDeviceToHost, stream);   if(e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);                                               if(e != hipSuccess) return e;
+    unsigned long long* cmax = (unsigned long long*)(scratch + 2*one);
+    int N = 2; while(((long long)1 << (N - 2)) < (long long)Nmeas) N++;      // Nmeas <= 2^(N-2): products that meet < 2^(N-1)
+    {
+        long long nb = (Nnz + 255)/256; if(nb > 4096) nb = 4096; if(nb < 1) nb = 1;
+        hipLaunchKernelGGL(csr_column_max_kernel, dim3((int)nb), dim3(256), 0, stream, Nnz, nd.Nstate, Ji, O.Jv, cmax);
+    }
+    const ReproAcc a0 = { O.A, O.Bt, O.D };
+    const ReproAcc a1 = { scratch, scratch + nA, scratch + nA + nB };
+    const ReproAcc a2 = { scratch + one, scratch + one + nA, scratch + one + nA + nB };
+    hipLaunchKernelGGL(rows_repro_kernel, dim3((Nmeas + 63)/64), dim3(64), 0, stream, nd, R, 0, Nmeas, Jp, Ji, cmax, N, a0, a1, a2);
+    if(nA > 0) hipLaunchKernelGGL(repro_combine_kernel, dim3((int)std::min<size_t>(2048, (nA + 255)/256)), dim3(256), 0, stream, nA, nd.Nc, O.A,  a1.A,  a2.A);
+    if(nB > 0) hipLaunchKernelGGL(repro_combine_kernel, dim3((int)std::min<size_t>(2048, (nB + 255)/256)), dim3(256), 0, stream, nB, 0,     O.Bt, a1.Bt, a2.Bt);
+    if(nD > 0) hipLaunchKernelGGL(repro_combine_kernel, dim3((int)std::min<size_t>(2048, (nD + 255)/256)), dim3(256), 0, stream, nD, 6,     O.D,  a1.D,  a2.D);
     return hipGetLastError();
 }
 

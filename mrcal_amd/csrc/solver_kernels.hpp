@@ -357,8 +357,11 @@ hipError_t launch_csr_A_Jt_J_At(int NX, int Nrows, int Nstate, const int32_t* Jp
 // out2[0] = min, out2[1] = max of the factor's diagonal; preset to (+big, 0)
 hipError_t launch_fsolve_diag_minmax(const NormalDims& nd, const FactorBuffers& F, double* out2, hipStream_t stream);
 // the normal equations of a bare CSR matrix into the blocks of R's operating point
+// (scratch, assemble_rows_scratch_doubles(nd) doubles: the sums made so that no addition rounds - the same bits whatever the
+//  order of the atomics; NULL: the plain sums)
+size_t assemble_rows_scratch_doubles(const NormalDims& nd);
 hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
-                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream);
+                                const int32_t* Jp, const int32_t* Ji, hipStream_t stream, double* scratch, long long Nnz);
 
 // ---- The device-controlled dog-leg trial step (solver.cpp enqueue_trial_step()). Per trial, in this order:
 //   choose            the dog-leg step from the current point, b_trial; the first trial from a new point also

@@ -340,3 +340,48 @@ def test_callback_factorization_is_the_problems_own_and_reproducible(amd):
     o2 = dict(oi, do_apply_regularization=False)
     o2["observations_board"] = oi["observations_board"].copy(); o2["observations_board"][..., 2] = -1.     # nothing observed
     assert amd.optimizer_callback(**o2)[3] is None
+
+
+@pytest.mark.parametrize("case", ("boards", "dense", "wide range"))
+def test_factorization_of_a_bare_matrix_is_reproducible(amd, case):
+    """CHOLMOD_factorization(J) of a matrix the caller made: the block normal equations are summed row by row with
+    atomics, in sums made so that no addition rounds (launch_assemble_rows: three levels of pre-rounded parts, the
+    columns' largest entries setting the units) - the same bits whatever order the atomics land in - and exact: against
+    numpy's JtJ, and against the plain sums of before (MRCAL_AMD_PLAIN_ROW_SUMS in a second process is not needed: the
+    solve is the check). Until round 4 this was the last user-visible result that was not the same twice"""
+    import scipy.sparse
+    from mrcal_amd import CHOLMOD_factorization
+    rng = np.random.RandomState(7)
+    if case == "boards":
+        oi, _ = make_calibration_problem(amd._api, Ncameras=3, Nframes=40, lensmodel="LENSMODEL_OPENCV8",
+                                         object_width_n=10, object_height_n=10, seed=9)
+        _, _, J, _ = amd.optimizer_callback(**oi, no_factorization=True)
+        part = (3*12 + 2*6, 40, 0, 2)        # [intrinsics | extrinsics] leading, 40 frames, the board's warp last
+        assert J.shape[1] == part[0] + 6*part[1] + part[3]
+    else:
+        Nc, Nfb, rows = 37, 25, []
+        for f in range(Nfb):
+            for _ in range(60):
+                r = np.zeros(Nc + 6*Nfb); r[:Nc] = rng.normal(size=Nc)*(rng.uniform(size=Nc) < 0.4)
+                r[Nc + 6*f: Nc + 6*f + 6] = rng.normal(size=6)
+                rows.append(r)
+        A = np.array(rows)
+        if case == "wide range":
+            A = A * 10.0**rng.uniform(-40, 40, size=A.shape[1])[None, :]      # columns from 1e-40 to 1e+40
+        J, part = scipy.sparse.csr_matrix(A), (Nc, Nfb, 0, 0)
+    Fs = [CHOLMOD_factorization(J, _partition=part) for _ in range(3)]
+    bt = rng.normal(size=(3, J.shape[1]))
+    xs = [F.solve_xt_JtJ_bt(bt) for F in Fs]
+    for x in xs[1:]:
+        assert np.array_equal(x, xs[0])
+    assert Fs[0].rcond() == Fs[1].rcond() == Fs[2].rcond()
+    if case != "wide range":
+        Jd = J.toarray(); N = Jd.T @ Jd
+        resid = np.abs(xs[0] @ N - bt).max() / (np.abs(N).max()*np.abs(xs[0]).max())
+        assert resid < 1e-10, resid
+    else:
+        # (JtJ of such columns does not fit numpy's doubles' range in one matrix norm: column by column)
+        Jd = J.toarray(); s = np.abs(Jd).max(axis=0)
+        Ns = (Jd/s).T @ (Jd/s)
+        resid = np.abs((xs[0]*s) @ Ns - bt/s).max() / np.abs(bt/s).max()
+        assert resid < 1e-8, resid
