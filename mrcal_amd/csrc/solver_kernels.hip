@@ -3617,7 +3617,9 @@ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restric
 //  walking 46 MB of Bt: 1.4 TB/s)
 // this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
 __device__ __forceinline__
-double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false)
+double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false,
+                     const unsigned* __restrict__ occ = NULL /* eblock_factor_kernel's bit per (block, 16-column tile) of Wt - and of Bt: the same columns */,
+                     int nocc = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Nrows = nd.Nc + nd.NE;
@@ -3637,17 +3639,34 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
     for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] = 0.0;
     // (of A only the lower triangle: the splined assembly writes no other. An entry below the diagonal counts twice)
     int rowc[QF_ROWS_PER_WAVE];
+    // (the splined models: a row of Bt holds something under the frame's board only - a sixth of its 76 tiles, 46 MB of
+    //  zeros a step otherwise: a lane whose tile is empty asks for nothing)
+    const unsigned* __restrict__ ob[QF_ROWS_PER_WAVE];
 #pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) rowc[rr] = min(row0 + rr, Nrows - 1);
+    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
+    {
+        rowc[rr] = min(row0 + rr, Nrows - 1);
+        ob[rr] = NULL;
+        if(occ != NULL && rowc[rr] >= nd.Nc)
+        {
+            int blk, a, de, e0;
+            E_to_block(nd, rowc[rr] - nd.Nc, &blk, &a, &de, &e0);
+            ob[rr] = occ + (size_t)blk*nocc;
+        }
+    }
 #pragma unroll 4
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double vs = v[S_to_state(nd, c)];
+        const int tile = c >> 4;
 #pragma unroll
         for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
         {
             const double wgt = (rowc[rr] >= nd.Nc) ? 1.0 : (c < rowc[rr]) ? 2.0 : (c == rowc[rr]) ? 1.0 : 0.0;
-            if(wgt != 0.0) acc[rr] += wgt*(M[rr][c]*vs);
+            // (a branch around the load: the lanes without one reading the row's first entry instead - no branch, the loads
+            //  of four steps in flight - measured slower, 24 us against 20)
+            const bool there = (ob[rr] == NULL) || ((ob[rr][tile >> 5] >> (tile & 31)) & 1u);
+            if(wgt != 0.0 && there) acc[rr] += wgt*(M[rr][c]*vs);
         }
     }
 #pragma unroll
@@ -4009,7 +4028,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
                                    const double* __restrict__ Wt, const double* __restrict__ LD,
                                    const double* __restrict__ y, const double* __restrict__ ds,
                                    double* __restrict__ dots_part, double* __restrict__ qf_part, int nbs,
-                                   SolverCtl* __restrict__ snap)
+                                   SolverCtl* __restrict__ snap, const unsigned* __restrict__ occ, int nocc)
 {
     const OpDev& O = ops[ctl->ib];
     const int b = blockIdx.x;
@@ -4022,7 +4041,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     {
         if(!ctl->derive) return;
         const int qb = b - nbs - 1;
-        const double mine = quadform_body(nd, O, O.g, qb, true);
+        const double mine = quadform_body(nd, O, O.g, qb, true, occ, nocc);
         if(threadIdx.x < 3) qf_part[4*qb + threadIdx.x] = mine;
         return;
     }
@@ -4047,10 +4066,14 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
     const double gv = O.g[nd.E_state0 + e0 + min(lane, de - 1)];
     double part[6] = {0,0,0,0,0,0};
     // (four column groups asked for together: with a 1206-variable camera block the loop is 19 round trips otherwise)
+    // (the tiles of Wt that hold nothing - five in six under the splined models - are not asked for)
+    const unsigned* __restrict__ ob = (occ != NULL) ? occ + (size_t)blk*nocc : (const unsigned*)NULL;
 #pragma unroll 4
     for(int c = lane; c < nd.Nc; c += 64)
     {
         const double d = ds[c];
+        const int tile = c >> 4;
+        if(ob != NULL && !((ob[tile >> 5] >> (tile & 31)) & 1u)) continue;
 #pragma unroll
         for(int i=0;i<6;i++) if(i < de) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
     }
@@ -4630,7 +4653,8 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
     }
     const int nbs = (br.count() + 3)/4, nqf = quadform_blocks(nd);
     hipLaunchKernelGGL(step2_backsub_quadform_kernel, dim3(nbs + 1 + nqf), dim3(256), 0, stream,
-                       nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs, a.snap);
+                       nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs, a.snap,
+                       (nd.Nc > SYRK_STRIP_FROM) ? F.occ : (const unsigned*)NULL, occ_words(nd));
     if(a.comm2 != NULL)
         hipLaunchKernelGGL(step2_pack2_kernel, dim3(1), dim3(256), 0, stream,
                            a.ctl, fl, a.plan->qf_part, nqf, a.plan->dots_part, br.count(), (double*)a.comm2);
