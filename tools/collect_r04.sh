@@ -51,7 +51,7 @@ if has mfma; then
     timeout 600 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d /tmp/pmc_ns -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-full-solve > /dev/null 2>&1
     python $R/tools/mfma_util.py /tmp/pmc_ns $O/${tag}_mfma_ns.json board_kernel schur_syrk_mfma_kernel schur_cholesky_solve_kernel > /dev/null
     timeout 600 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d /tmp/pmc_c2 -- python $R/tools/probe_config2.py > /dev/null 2>&1
-    python $R/tools/mfma_util.py /tmp/pmc_c2 $O/${tag}_mfma_config2.json schur_syrk_sparse_kernel lchol_panel_kernel lchol_backward_kernel > /dev/null
+    python $R/tools/mfma_util.py /tmp/pmc_c2 $O/${tag}_mfma_config2.json schur_syrk_sparse_kernel lchol_panel_kernel assemble_splined_kernel > /dev/null
 fi
 if has ns; then
     python $R/tools/ns_solve_vs_reference.py $O/${tag}_ns_solve_vs_reference.json > $O/${tag}_ns_solve.log 2>&1
