@@ -535,9 +535,6 @@ void spl_rows_fallback(const NormalDims& nd, const OpDev& O, int r_first, int r1
 #ifndef SPL_WAVES_PER_EU
 #define SPL_WAVES_PER_EU 2
 #endif
-#ifndef SPL_ROWS_CAP
-#define SPL_ROWS_CAP 64
-#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU)))
 void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
                              const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
@@ -2009,7 +2006,7 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
 // a block that does not touch tile bi is skipped (scalar test), of the others the A operand is loaded and
 // only the B tiles the block touches are. A block's 6 (3) rows are two (one) k-steps of 4, the missing
 // rows zero: a third more matrix instructions per processed block, for an eighth of the blocks x tiles.
-// Slices cut blocks wherever they fall: each side takes its rows
+// A slice is every nslices-th block of the range, whole (the operands come from the tiled copy of Wt, Wtile).
 // The blocks that count are few but unevenly spread: nine strips in ten have none or two in a slice, the strips over
 // the middle of the imager sixty, and ~1000 matrix instructions one after the other on ONE wave were the kernel's
 // 62 us (with either the loads or the matrix instructions compiled out: ~50; with neither: 8). So a workgroup is
@@ -2018,11 +2015,11 @@ void schur_syrk_strip_kernel(NormalDims nd, const int* __restrict__ skip, int e_
 // 89; 16 and 32 slices, 53 and 60 us alone against 67 - and the reduction pays for the slots)
 #define SYRK_SPARSE_WAVES 4
 __global__ __launch_bounds__(64*SYRK_SPARSE_WAVES)
-void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi, int e_per_slice,
+void schur_syrk_sparse_kernel(NormalDims nd, const int* __restrict__ skip, int e_lo, int e_hi,
                               int slot0, int nslots_total,
                               const double* __restrict__ Wt, const double* __restrict__ y,
                               double* __restrict__ Spart, int nslices, FinalizeRide fr,
-                              const unsigned* __restrict__ occ, int nocc, unsigned char* __restrict__ live_out, int nstrips)
+                              const unsigned* __restrict__ occ, int nocc, unsigned char* __restrict__ live_out)
 {
     if((int)blockIdx.y >= nslices) { finalize_ride(fr, nd); return; }
     if(skip != NULL && *skip) return;
@@ -4378,8 +4375,8 @@ static int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* s
             rode = rode || with_ride;
             if(sparse)
                 hipLaunchKernelGGL(schur_syrk_sparse_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64*SYRK_SPARSE_WAVES), 0, stream,
-                                   nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wtile, F.y, F.Spart, ns[part], fr,
-                                   F.occ, occ_words(nd), flags, syrk_grid_x(nd));
+                                   nd, skip, e_lo[part], e_hi[part], slot0, nslots, F.Wtile, F.y, F.Spart, ns[part], fr,
+                                   F.occ, occ_words(nd), flags);
             else if(nd.Nc > SYRK_STRIP_FROM)
                 hipLaunchKernelGGL(schur_syrk_strip_kernel, dim3(syrk_grid_x(nd), ns[part] + extra), dim3(64), 0, stream,
                                    nd, skip, e_lo[part], e_hi[part], per[part], slot0, nslots, F.Wt, F.y, F.Spart, ns[part], fr);
