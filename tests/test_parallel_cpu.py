@@ -573,3 +573,89 @@ def test_sharded_triangulated_solve(tmp_path, ref_api, Nboard_frames):
     s = ref_api.optimize(**oi2)
     assert abs(s["rms_reproj_error__pixels"] - float(r2["rms"])) < 1e-6*s["rms_reproj_error__pixels"]
     assert np.abs(unpacked(s["b_packed"]) - unpacked(r2["b"])).max() < 5e-5
+
+
+def test_one_collective_takes_three_camera_blocks():
+    """DESIGN.md section 7, "Why two collectives": the four scalars the dog-leg's next choice needs from all ranks -
+    g^T N g, |g_E|^2, |gn_E|^2, gn_E . g_E - can ride in the FIRST all-reduce only as coefficients of forms in vectors
+    that exist after it (the summed camera gradient g_S, the solution d_s of the summed system). This test builds three
+    shards of a small block problem with numpy, sums ONE buffer
+        [ S | r | g_S | M | m | A | Bt^T g_E | |x|^2, status, c, |y|^2, g_E^T D g_E, |g_E|^2 ]     3 Nc^2 + 4 Nc + 6
+    and recovers from it, on every rank alike, what the two-collective step computes with the second all-reduce. It
+    also shows what the review's 2 Nc^2 + 4 Nc + 6 misses: without the summed A, g^T N g cannot be formed (each rank's
+    A_r meets the SUMMED g_S on both sides)"""
+    rng = np.random.RandomState(11)
+    Nc, Nf, world = 9, 12, 3
+    def spd(n, scale=1.0):
+        a = rng.normal(size=(n + 3, n))
+        return scale*(a.T @ a)
+    # a consistent problem: J = [Jc | Jf blocks], rows assigned to frames, frames to ranks
+    rows_per_frame = 14
+    Jc = [rng.normal(size=(rows_per_frame, Nc)) for _ in range(Nf)]
+    Jf = [rng.normal(size=(rows_per_frame, 6))  for _ in range(Nf)]
+    x  = [rng.normal(size=rows_per_frame)       for _ in range(Nf)]
+    owner = [f % world for f in range(Nf)]
+    # what every rank has from its own frames
+    local = []
+    for rk in range(world):
+        fr = [f for f in range(Nf) if owner[f] == rk]
+        A   = sum(Jc[f].T @ Jc[f] for f in fr)
+        gS  = sum(Jc[f].T @ x[f]  for f in fr)
+        Bt  = {f: Jf[f].T @ Jc[f] for f in fr}
+        D   = {f: Jf[f].T @ Jf[f] for f in fr}
+        gE  = {f: Jf[f].T @ x[f]  for f in fr}
+        local.append(dict(fr=fr, A=A, gS=gS, Bt=Bt, D=D, gE=gE, n2=sum(x[f] @ x[f] for f in fr)))
+    # the ONE buffer
+    def summand(L):
+        S = L["A"].copy(); r = L["gS"].copy()
+        M = np.zeros((Nc, Nc)); m = np.zeros(Nc); Btg = np.zeros(Nc)
+        c = y2 = gDg = gE2 = 0.0
+        for f in L["fr"]:
+            Lf = np.linalg.cholesky(L["D"][f])
+            Wt = np.linalg.solve(Lf, L["Bt"][f]); y = np.linalg.solve(Lf, L["gE"][f])
+            S -= Wt.T @ Wt; r -= Wt.T @ y
+            Z  = np.linalg.solve(Lf.T, Wt); z = np.linalg.solve(Lf.T, y)
+            M += Z.T @ Z; m += Z.T @ z; c += z @ z; y2 += y @ y
+            Btg += L["Bt"][f].T @ L["gE"][f]
+            gDg += L["gE"][f] @ L["D"][f] @ L["gE"][f]; gE2 += L["gE"][f] @ L["gE"][f]
+        return np.concatenate([S.ravel(), r, L["gS"], M.ravel(), m, L["A"].ravel(), Btg, [L["n2"], 0.0, c, y2, gDg, gE2]])
+    buf = sum(summand(L) for L in local)
+    assert buf.size == 3*Nc*Nc + 4*Nc + 6
+    o = 0
+    def take(n):
+        nonlocal o
+        v = buf[o:o+n]; o += n
+        return v
+    S = take(Nc*Nc).reshape(Nc, Nc); r = take(Nc); gS = take(Nc); M = take(Nc*Nc).reshape(Nc, Nc); m = take(Nc)
+    A = take(Nc*Nc).reshape(Nc, Nc); Btg = take(Nc); n2, status, c, y2, gDg, gE2 = take(6)
+    ds = -np.linalg.solve(S, r)
+    one = dict(gNg   = gS @ A @ gS + 2.0*(gS @ Btg) + gDg,
+               gE2   = gE2,
+               gnE2  = ds @ M @ ds + 2.0*(m @ ds) + c,
+               gnEgE = -(y2 + (gS - r) @ ds))
+    # the two-collective step: the second all-reduce sums what each rank computes from ITS frames with the summed g_S, d_s
+    two = dict(gNg=0.0, gE2=0.0, gnE2=0.0, gnEgE=0.0)
+    for L in local:
+        g_loc = 0.0
+        for f in L["fr"]:
+            dE = -np.linalg.solve(L["D"][f], L["gE"][f] + L["Bt"][f] @ ds)
+            two["gnE2"]  += dE @ dE
+            two["gnEgE"] += dE @ L["gE"][f]
+            two["gE2"]   += L["gE"][f] @ L["gE"][f]
+            g_loc += 2.0*(L["gE"][f] @ (L["Bt"][f] @ gS)) + L["gE"][f] @ L["D"][f] @ L["gE"][f]
+        two["gNg"] += gS @ L["A"] @ gS + g_loc          # (its own A_r against the SUMMED g_S)
+    # ... and the whole thing against the dense J
+    J = np.zeros((Nf*rows_per_frame, Nc + 6*Nf)); xx = np.concatenate(x)
+    for f in range(Nf):
+        J[f*rows_per_frame:(f+1)*rows_per_frame, :Nc] = Jc[f]
+        J[f*rows_per_frame:(f+1)*rows_per_frame, Nc+6*f:Nc+6*f+6] = Jf[f]
+    g = J.T @ xx; N = J.T @ J
+    gn = -np.linalg.solve(N, g)
+    dense = dict(gNg=g @ N @ g, gE2=g[Nc:] @ g[Nc:], gnE2=gn[Nc:] @ gn[Nc:], gnEgE=gn[Nc:] @ g[Nc:])
+    for k in one:
+        assert abs(one[k] - two[k])   < 1e-9*abs(two[k]),   (k, one[k], two[k])
+        assert abs(one[k] - dense[k]) < 1e-8*abs(dense[k]), (k, one[k], dense[k])
+    assert np.abs(ds - gn[:Nc]).max() < 1e-9*np.abs(gn[:Nc]).max()
+    # without the summed A (the 2 Nc^2 buffer): g_S^T A g_S from the pieces a rank has is its own A_r only
+    partial = gS @ local[0]["A"] @ gS
+    assert abs(partial - gS @ A @ gS) > 1e-3*abs(gS @ A @ gS)
