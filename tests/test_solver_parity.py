@@ -97,6 +97,29 @@ def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
     assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
+@pytest.mark.parametrize("W,H,distance", ((7, 5, 4.0), (9, 11, 4.0), (9, 11, 1.3), (3, 2, 2.0), (17, 15, 2.0)))
+def test_normal_equations_splined_board_sizes(amd, W, H, distance):
+    """boards whose corner count is not a multiple of 4 (the Gram's k-steps), smaller than a wave, larger than the local
+    tile's rows (255 corners: more than one chunk of rows a pass), far and close: the normal equations against JtJ"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=5,
+                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     object_width_n=W, object_height_n=H, seed=37, board_distance=distance,
+                                     object_spacing=0.1 if W < 12 else 0.06)
+    oi["do_optimize_intrinsics_core"] = False
+    with Problem(**oi) as p:
+        ne = p.normal_equations()
+        J, x = p.J(), p.x()
+        ne2 = p.normal_equations()
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    assert np.abs(N_gpu - N).max() < 1e-10*np.abs(N).max()
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    for k in ("A", "Bt", "D", "g"):
+        assert np.array_equal(ne[k], ne2[k]), k
+
+
 @pytest.mark.parametrize("distance,grid", ((1.2, "order=3_Nx=30_Ny=20"), (2.0, "order=3_Nx=30_Ny=20"), (1.5, "order=2_Nx=24_Ny=18"),
                                            (2.5, "order=3_Nx=40_Ny=30"), (-1.4, "order=3_Nx=30_Ny=20")))
 def test_normal_equations_splined_closeups(amd, distance, grid):
