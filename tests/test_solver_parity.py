@@ -97,15 +97,15 @@ def test_normal_equations_splined(amd, grid, frames_opt, core_opt):
     assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
 
 
-@pytest.mark.parametrize("W,H,distance", ((7, 5, 4.0), (9, 11, 4.0), (9, 11, 1.3), (3, 2, 2.0), (17, 15, 2.0)))
+@pytest.mark.parametrize("W,H,distance", ((7, 5, 4.0), (9, 11, 4.0), (9, 11, 1.3), (3, 2, 2.0), (17, 15, 2.0), (17, 15, -1.6)))
 def test_normal_equations_splined_board_sizes(amd, W, H, distance):
     """boards whose corner count is not a multiple of 4 (the Gram's k-steps), smaller than a wave, larger than the local
     tile's rows (255 corners: more than one chunk of rows a pass), far and close: the normal equations against JtJ"""
     from mrcal_amd.resident import Problem
     oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=5,
                                      lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
-                                     object_width_n=W, object_height_n=H, seed=37, board_distance=distance,
-                                     object_spacing=0.1 if W < 12 else 0.06)
+                                     object_width_n=W, object_height_n=H, seed=37, board_distance=abs(distance),
+                                     object_spacing=0.1 if (W < 12 or distance < 0) else 0.06)    # (< 0: sub-boxes AND chunks of rows)
     oi["do_optimize_intrinsics_core"] = False
     with Problem(**oi) as p:
         ne = p.normal_equations()
