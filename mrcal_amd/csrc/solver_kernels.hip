@@ -550,7 +550,13 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
     const double* __restrict__ x  = O.x;
-    const int f = blockIdx.x, t = threadIdx.x;
+    // A workgroup per frame and SURFACE (round 4; it was per frame, the two passes one after the other): the x rows touch
+    // the x surface's control points only, the y rows the y surface's, so the two passes share nothing they write but
+    // the frame's block, its part of the gradient and the core / extrinsics / warp columns of Bt - to each of which
+    // each of the two adds ONE number, atomically, onto zero: a + b is b + a. Twice the workgroups of half the length:
+    // nothing at BASELINE configuration 2 (800 frames on 512 places), and a calibration of 186 frames of close-ups,
+    // eight passes each, no longer leaves a quarter of the CUs without a workgroup
+    const int f = blockIdx.x >> 1, xy0 = blockIdx.x & 1, t = threadIdx.x;
     const int lane = t & 63, r16 = lane & 15, kq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int o0 = __builtin_amdgcn_readfirstlane(plan.frame_obs_begin[f]), o1 = __builtin_amdgcn_readfirstlane(plan.frame_obs_begin[f+1]);
@@ -598,8 +604,11 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         SPL_TICK(ts_bbox)
         if(nsub > SPL_MAXSUB || (nsub > 1 && NPTS > (int)sizeof(own)))
         {
-            if(t == 0) plan.spl_hdr[o] = SplHdr{ 0, 0, -1, -1 };
-            spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
+            if(xy0 == 0)
+            {
+                if(t == 0) plan.spl_hdr[o] = SplHdr{ 0, 0, -1, -1 };
+                spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
+            }
             continue;
         }
         if(nsub > 1)
@@ -623,7 +632,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int wy  = (nsub > 1) ? min(T + order, oy0 + owy - iy0) : owy;
         const int K   = wx*wy;
         // (the first header says how many there are: wy | nsub << 16)
-        if(t == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx, (isub == 0) ? (wy | (nsub << 16)) : wy };
+        if(t == 0 && xy0 == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx, (isub == 0) ? (wy | (nsub << 16)) : wy };
         // a sub-box's pass is over ITS corners only, packed: their rows in the tile, in corner order (a pass over all
         // the corners with the others' rows left zero is as long as the whole observation's: 0.29 ms more a step with
         // 2 x 2 sub-boxes under every board)
@@ -654,14 +663,13 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int fr0 = K + SPL_NDENSE;                 // the first frame column
         // this wave's tile rows
         // (every second workgroup deals the rows the other way round: two workgroups share a CU, and their waves w a SIMD)
-        const int wv = (((f >> 8) ^ f) & 1) ? 3 - wave : wave;
+        const int wv = ((((int)blockIdx.x >> 8) ^ (int)blockIdx.x) & 1) ? 3 - wave : wave;
         const int Ia = NS - 1 - wv, Ib = wv - (8 - NS);
         const int na = (Ia >= 0) ? Ia + 1 : 0, nb = (Ib >= 0 && Ia >= 0) ? Ib + 1 : 0;
         const unsigned L_magic = (unsigned)((0x100000000ull + (unsigned)L - 1)/(unsigned)L);      // e / L = e L_magic >> 32, e (L-1) < 2^32
 
-#pragma unroll 1
-        for(int xy = 0; xy < 2; xy++)
         {
+            const int xy = xy0;
             // state index -> local column of this pass
             auto local_of = [&](int col) -> int
             {
@@ -4209,7 +4217,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         if(splined_boards)
         {
             // (72 KB of LDS for the tile: two workgroups per CU)
-            hipLaunchKernelGGL(assemble_splined_kernel, dim3(P.Nframes), dim3(256), 0, stream,
+            hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes), dim3(256), 0, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji);
             // a copy of the row per wave, as many waves as the LDS holds copies
             const size_t row_bytes = (size_t)(nd.Nc + 1)*sizeof(double);
