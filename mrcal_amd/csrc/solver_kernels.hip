@@ -938,6 +938,9 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
     __syncthreads();
     const bool xrow = (r == nd.Nc);
     const int  sr   = xrow ? -1 : (S_to_state(nd, r));     // state index of the row
+#ifdef SPLG_TS
+    long long gts0 = clock64(), gts_match = 0, gtq; int gn_match = 0, gn_batch = 0;
+#endif
     if(wave < nwaves)
     {
         double* __restrict__ acc = accs + wave*stride;
@@ -986,12 +989,22 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                 }
             }
             unsigned long long mm = __ballot(lr0 >= 0 || lr1 >= 0);
+#ifdef SPLG_TS
+            gn_match += __popcll(mm); gtq = clock64();
+#endif
             while(mm)
             {
+#ifdef SPLG_TS
+                gn_batch++;
+#endif
                 // up to SPLG_BATCH observations: every load first, then the sums in order
                 double v[SPLG_BATCH][2][2], vc[SPLG_BATCH][2];
                 int    cs[SPLG_BATCH][2], csc[SPLG_BATCH], Kk[SPLG_BATCH];
                 bool   on[SPLG_BATCH][2];
+                // (nothing is done with what a load returns before all of a batch's loads are out - a select on the spot is a
+                //  wait on the spot, and the 18 loads of three matches were most of 18 trips to memory: 20k cycles a batch.
+                //  Which of the values count: a bit each)
+                unsigned wanted = 0u;         // (six bits a match)
 #pragma unroll
                 for(int k = 0; k < SPLG_BATCH; k++)
                 {
@@ -1027,14 +1040,14 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                             const int lc = lane + 64*it;
                             // (always a load, from an address that is always valid: a load under a condition is a branch and a wait)
                             const bool want = on[k][xy] && lc <= lr && cs[k][it] != -1;
-                            const double g = Gp[want ? spl_tri(lr) + lc : 0];
-                            v[k][xy][it] = want ? g : 0.0;
+                            v[k][xy][it] = Gp[want ? spl_tri(lr) + lc : 0];
+                            if(want) wanted |= 1u << (6*k + 2*xy + it);
                         }
                         // a knot's row against the core: below it in local order
                         {
                             const bool want = on[k][xy] && csc[k] >= 0;
-                            const double g = Gp[want ? spl_tri(K + lane) + lr : 0];
-                            vc[k][xy] = want ? g : 0.0;
+                            vc[k][xy] = Gp[want ? spl_tri(K + lane) + lr : 0];
+                            if(want) wanted |= 1u << (6*k + 4 + xy);
                         }
                     }
                 }
@@ -1048,7 +1061,7 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                         for(int it = 0; it < 2; it++)
                         {
                             const int c = cs[k][it];
-                            const double vv = v[k][xy][it];
+                            const double vv = ((wanted >> (6*k + 2*xy + it)) & 1u) ? v[k][xy][it] : 0.0;
                             if(c == -1 || vv == 0.0) continue;
                             if(c == -2) { acc[nd.Nc] += vv; continue; }
                             const int se = state_to_SE(nd, c + ((lane + 64*it < Kk[k]) ? xy : 0));
@@ -1060,13 +1073,17 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                                 if(pw >= 0) acc[pw] += vv; else O.scalars[SC_BAD_STRUCTURE] = 1.0;
                             }
                         }
-                        if(csc[k] >= 0 && vc[k][xy] != 0.0)
+                        const double vcc = ((wanted >> (6*k + 4 + xy)) & 1u) ? vc[k][xy] : 0.0;
+                        if(csc[k] >= 0 && vcc != 0.0)
                         {
-                            if(window <= 0) acc[state_to_SE(nd, csc[k])] += vc[k][xy];
-                            else            acc[window + 1 + lane] += vc[k][xy];        // (csc = the camera's core + lane)
+                            if(window <= 0) acc[state_to_SE(nd, csc[k])] += vcc;
+                            else            acc[window + 1 + lane] += vcc;        // (csc = the camera's core + lane)
                         }
                     }
             }
+#ifdef SPLG_TS
+            gts_match += clock64() - gtq;
+#endif
             };
             // (the first sub-box - almost always the only one - exactly as before there were any)
             passes_of(0, h0);
@@ -1081,6 +1098,10 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
 #endif
         }
     }
+#ifdef SPLG_TS
+    if(lane == 0 && (wave == 0 || wave == 5) && window > 0 && (blk % 149 == 0))
+        printf("gather row %d wave %d: %lld cycles to the barrier, %lld of them in %d matches (%d batches)\n", blk, wave, clock64() - gts0, gts_match, gn_match, gn_batch);
+#endif
     __syncthreads();
     // the waves' copies, in wave order
     for(int c = t; c < stride; c += blockDim.x)
