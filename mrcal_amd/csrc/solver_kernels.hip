@@ -510,15 +510,22 @@ void spl_gram_mfma(const double* __restrict__ Jd, int LD, int nsteps, int r16, i
     }
     if(s < nsteps) mma(b0, aA0, aB0);
 }
+// c / wx = (c spl_magic(wx)) >> 16 for 0 <= c < 2^16/wx: the local columns (< 128) of a box up to 128 wide. (An integer
+// division is ~40 vector instructions; the gather made four for every pass that held its row, and its waves share a SIMD
+// four at a time: those, and nine ds_bpermute, were most of the 18k cycles a batch of three passes took)
+__host__ __device__ __forceinline__ int spl_magic(int wx) { return (65536 + wx - 1)/(wx > 0 ? wx : 1); }
 // state index of local column c of a pass, -1: not a camera-block variable of this pass (a frame column, x,
 // or a variable that is not being optimized)
 __device__ __forceinline__
 int spl_col_state(const DeviceProblem& P, const NormalDims& nd, int c, int K, int ix0, int iy0, int wx, int xy,
-                  int i_state_intrinsics, int i_state_extrinsics)
+                  int i_state_intrinsics, int i_state_extrinsics, int wx_magic /* spl_magic(wx): c / wx without the division */)
 {
     if(c < K)
+    {
+        const int cy = (c*wx_magic) >> 16, cx = c - cy*wx;
         return (i_state_intrinsics >= 0)
-            ? i_state_intrinsics + P.Ncore_state + 2*((iy0 + c / wx)*P.cfg.spline_Nx + ix0 + c % wx) + xy : -1;
+            ? i_state_intrinsics + P.Ncore_state + 2*((iy0 + cy)*P.cfg.spline_Nx + ix0 + cx) + xy : -1;
+    }
     const int d = c - K;
     if(d < 4)           return (i_state_intrinsics >= 0 && d < P.Ncore_state) ? i_state_intrinsics + d : -1;
     if(d < 10)          return (i_state_extrinsics >= 0) ? i_state_extrinsics + (d - 4) : -1;
@@ -632,7 +639,9 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
         const int wy  = (nsub > 1) ? min(T + order, oy0 + owy - iy0) : owy;
         const int K   = wx*wy;
         // (the first header says how many there are: wy | nsub << 16)
-        if(t == 0 && xy0 == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx, (isub == 0) ? (wy | (nsub << 16)) : wy };
+        // (wx with its reciprocal for the gather: wx | spl_magic(wx) << 8)
+        const int wx_magic = spl_magic(wx);
+        if(t == 0 && xy0 == 0) *spl_hdr_at(plan, o, isub) = SplHdr{ ix0, iy0, wx | (wx_magic << 8), (isub == 0) ? (wy | (nsub << 16)) : wy };
         // a sub-box's pass is over ITS corners only, packed: their rows in the tile, in corner order (a pass over all
         // the corners with the others' rows left zero is as long as the whole observation's: 0.29 ms more a step with
         // 2 x 2 sub-boxes under every board)
@@ -841,7 +850,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
                     else if(col >= K)  FB[ia*SPL_NDENSE + (col - K)] += vv;
                     else
                     {
-                        const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m_isi, m_ise);
+                        const int cs = spl_col_state(P, nd, col, K, ix0, iy0, wx > 0 ? wx : 1, xy, m_isi, m_ise, wx_magic);
                         if(cs < 0) continue;
                         // a knot's column is written by this pass of this observation and by nobody else - or, cut
                         // into sub-boxes, by the passes of those that hold it, one after the other (the barrier below)
@@ -862,7 +871,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             const int ia = t / SPL_NDENSE, d = t - ia*SPL_NDENSE;
             if(d < 10 && FB[t] != 0.0)
             {
-                const int cs = spl_col_state(P, nd, d, 0, 0, 0, 1, 0, m_isi, m_ise);      // (a column past the control points: their box does not matter)
+                const int cs = spl_col_state(P, nd, d, 0, 0, 0, 1, 0, m_isi, m_ise, 0);   // (a column past the control points: their box does not matter)
                 if(cs >= 0) atomicAdd(&O.Bt[(size_t)(6*f + ia)*nd.Nc + state_to_SE(nd, cs)], FB[t]);
                 FB[t] = 0.0;
             }
@@ -960,12 +969,15 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                 isi = P.board_meta[o].i_state_intrinsics; ise = P.board_meta[o].i_state_extrinsics;
                 if(h0.wx >= 0) { nsub_l = h0.wy >> 16; h0.wy &= 0xffff; }
             }
-            auto passes_of = [&](const int isub, const SplHdr h) __attribute__((always_inline))
+            auto passes_of = [&](const int isub, const SplHdr hraw) __attribute__((always_inline))
             {
             int lr0 = -1, lr1 = -1, kind = 2;       // kind 0: a knot's row, 1: a core row, 2: the others
+            SplHdr h = hraw;
+            int hmagic = 0;
+            if(hraw.wx >= 0) { h.wx = hraw.wx & 0xff; hmagic = hraw.wx >> 8; }
             if(isub < nsub_l)
             {
-                if(h.wx >= 0)
+                if(hraw.wx >= 0)
                 {
                     const int K = h.wx*h.wy;
                     if(xrow) lr0 = lr1 = K + SPL_NDENSE + 6;
@@ -1009,12 +1021,15 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                 for(int k = 0; k < SPLG_BATCH; k++)
                 {
                     const bool have = mm != 0ull;
-                    const int src = have ? __ffsll((long long)mm) - 1 : 0;
+                    const int src = __builtin_amdgcn_readfirstlane(have ? __ffsll((long long)mm) - 1 : 0);
                     if(have) mm &= mm - 1;
                     const int oo  = ob + src;
-                    const int ix0 = __shfl(h.ix0, src), iy0 = __shfl(h.iy0, src), wx = __shfl(h.wx, src), wy = __shfl(h.wy, src);
-                    const int si  = __shfl(isi, src), se = __shfl(ise, src), kd = __shfl(kind, src);
-                    const int l0  = __shfl(lr0, src), l1 = __shfl(lr1, src);
+                    // (one lane's values for the wave: v_readlane, not nine trips through the LDS crossbar)
+                    const int ix0 = __builtin_amdgcn_readlane(h.ix0, src), iy0 = __builtin_amdgcn_readlane(h.iy0, src);
+                    const int wx  = __builtin_amdgcn_readlane(h.wx, src),  wy  = __builtin_amdgcn_readlane(h.wy, src);
+                    const int wxm = __builtin_amdgcn_readlane(hmagic, src);
+                    const int si  = __builtin_amdgcn_readlane(isi, src), se = __builtin_amdgcn_readlane(ise, src), kd = __builtin_amdgcn_readlane(kind, src);
+                    const int l0  = __builtin_amdgcn_readlane(lr0, src), l1 = __builtin_amdgcn_readlane(lr1, src);
                     const int K   = wx*wy;
                     Kk[k]  = K;
                     csc[k] = (have && kd == 0 && lane < Ncs && si >= 0) ? si + lane : -1;
@@ -1023,7 +1038,7 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
                     {
                         const int lc = lane + 64*it;
                         // the column's variable: the same in both passes but for the surface of a knot
-                        int c = spl_col_state(P, nd, lc, K, ix0, iy0, wx > 0 ? wx : 1, 0, si, se);
+                        int c = spl_col_state(P, nd, lc, K, ix0, iy0, wx > 0 ? wx : 1, 0, si, se, wxm);
                         if(kd == 1 && lc < K) c = -1;                      // a core row: the knots are above the diagonal
                         if(xrow && lc == K + SPL_NDENSE + 6) c = -2;        // |x|^2
                         cs[k][it] = have ? c : -1;
