@@ -1133,6 +1133,134 @@ void assemble_splined_gather_kernel(DeviceProblem P, NormalDims nd, OpRef R, Ass
         if(s != 0.0 && col >= 0 && col <= r) O.A[(size_t)r*nd.Nc + col] += s;
     }
 }
+// The rows of the camera block that are control points, the other way round (round 4; the kernel above still takes the
+// rows every pass holds). A control point's row of A's lower triangle has (order)(2 order + 1) + order + 1 places that
+// can hold anything - the control points of its surface up to `order` back in either direction, 25 for order 3 - and the
+// camera's core: one LANE per place, and a pass that holds the row is ONE load for the wave (half a wave: lanes 32..63
+// take the next pass): G[tri(lr) + lr + dy wx + dx]. No LDS copy of the row, no search for what a column is, nothing
+// read that is a structural zero; each lane adds its place's entries in a fixed order (its half's passes in order, the
+// two halves, then the waves in order), the same bits every time. A wave scans 64 observations' headers at a time and
+// leaves those that hold the row in an LDS list; SPLK_INFLIGHT entries a half are asked for together.
+// (The row-per-workgroup gather above spent 18-20k cycles on a batch of three passes - 128 local columns looked up,
+//  loaded and added through LDS for the 25 that count: 79 us at BASELINE configuration 2, 108 on a real calibration)
+#define SPLK_WAVES    4
+#define SPLK_INFLIGHT 4
+struct SplkMatch { int slot; int lr; int wx; int ax_wy; };  // the pass's staged triangle (index of its slot), the row, the box (wx | which allocation << 16; ax | wy << 16)
+__global__ __launch_bounds__(64*SPLK_WAVES)
+void assemble_splined_gather_knots_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan)
+{
+    if(opref_skip(R)) return;
+    __shared__ SplkMatch list[SPLK_WAVES][64];
+    __shared__ double    part[SPLK_WAVES][32];
+    const OpDev& O = opref_get(R);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int half = lane >> 5, j = lane & 31;
+    const int Nx = P.cfg.spline_Nx, Ncs = P.Ncore_state, order = P.cfg.spline_order;
+    // the row: control point (kx, ky) of surface s of camera ic
+    const int blk = blockIdx.x;
+    const int per = P.Nintr_state - Ncs, ic = blk / per, rel = blk - ic*per;
+    const int r   = ic*P.Nintr_state + Ncs + rel;                   // its index in the camera block
+    const int sr  = S_to_state(nd, r);
+    const int knot = rel >> 1, s = rel & 1, kx = knot % Nx, ky = knot / Nx;
+    // this lane's place: (dx, dy), dy < 0 any dx, dy == 0 dx <= 0; or a core variable; or none
+    const int ndx = 2*order + 1, nback = order*ndx, nplaces = nback + order + 1;
+    int dx = 0, dy = 0, core = -1;
+    bool place = false;
+    if(j < nback)          { dy = -order + j / ndx; dx = -order + j % ndx; place = true; }
+    else if(j < nplaces)   { dy = 0; dx = -order + (j - nback); place = true; }
+    else if(j < nplaces + Ncs) core = j - nplaces;
+    place = place && kx + dx >= 0 && kx + dx < Nx && ky + dy >= 0;
+    double acc = 0.0;
+
+    const int Nobs = P.Nobs_board;
+    const int per_wave = (Nobs + SPLK_WAVES - 1)/SPLK_WAVES;
+    const int w0 = min(Nobs, wave*per_wave), w1 = min(Nobs, w0 + per_wave);
+    SplkMatch* __restrict__ mine = list[wave];
+    for(int ob = w0; ob < w1; ob += 64)
+    {
+        const int o = ob + lane;
+        int nsub_l = 0;
+        SplHdr h0 = { 0, 0, -1, -1 };
+        bool cam = false;
+        if(o < w1)
+        {
+            h0 = plan.spl_hdr[o];
+            const int isi = P.board_meta[o].i_state_intrinsics;
+            cam = isi >= 0 && sr >= isi && sr < isi + P.Nintr_state;
+            if(h0.wx >= 0) { nsub_l = h0.wy >> 16; h0.wy &= 0xffff; }
+            if(!cam) nsub_l = 0;
+        }
+        for(int isub = 0; __any(isub < nsub_l); isub++)
+        {
+            SplHdr h = h0;
+            if(isub > 0 && isub < nsub_l) h = *spl_hdr_at(plan, o, isub);
+            bool hit = false;
+            int  lr = 0, wx = 1, wy = 1;
+            if(isub < nsub_l && h.wx >= 0)
+            {
+                wx = h.wx & 0xff; wy = h.wy;
+                const int ax = kx - h.ix0, ay = ky - h.iy0;
+                hit = ax >= 0 && ax < wx && ay >= 0 && ay < wy;
+                lr  = ay*wx + ax;
+            }
+            // the passes that hold the row, in observation order, into the list
+            const unsigned long long mm = __ballot(hit);
+            const int n = __popcll(mm);
+            if(hit)
+            {
+                const int at = __popcll(mm & ((1ull << lane) - 1ull));
+                const double* __restrict__ G = spl_slot(plan, o, s, isub);
+                mine[at] = SplkMatch{ (int)((G - ((isub > 0) ? plan.chunk_extra : plan.chunk_part))/SPL_TRI), lr, wx | ((isub > 0) ? 0x10000 : 0), (kx - h.ix0) | (wy << 16) };
+            }
+            // (the list is this wave's own: no barrier, the LDS keeps a wave's accesses in order)
+            for(int i0 = 0; i0 < n; i0 += 2*SPLK_INFLIGHT)
+            {
+                double v[SPLK_INFLIGHT];
+                bool   on[SPLK_INFLIGHT];
+#pragma unroll
+                for(int b = 0; b < SPLK_INFLIGHT; b++)
+                {
+                    const int i = i0 + 2*b + half;
+                    on[b] = false; v[b] = 0.0;
+                    if(i < n)
+                    {
+                        const SplkMatch m = mine[i];
+                        const int mwx = m.wx & 0xffff;
+                        // (a second, third.. sub-box's triangle is in the other allocation: spl_slot())
+                        const double* __restrict__ G = ((m.wx & 0x10000) ? plan.chunk_extra : plan.chunk_part) + (size_t)m.slot*SPL_TRI;
+                        const int ax = m.ax_wy & 0xffff;
+                        if(place && ax + dx >= 0 && ax + dx < mwx && m.lr + dy*mwx >= 0)
+                        {
+                            on[b] = true;
+                            v[b]  = G[spl_tri(m.lr) + m.lr + dy*mwx + dx];
+                        }
+                        else if(core >= 0)
+                        {
+                            on[b] = true;
+                            v[b]  = G[spl_tri(mwx*(m.ax_wy >> 16) + core) + m.lr];
+                        }
+                    }
+                }
+#pragma unroll
+                for(int b = 0; b < SPLK_INFLIGHT; b++) if(on[b]) acc += v[b];
+            }
+        }
+    }
+    // the halves, then the waves, in order
+    acc += __shfl(acc, (lane + 32) & 63);
+    if(lane < 32) part[wave][lane] = acc;
+    __syncthreads();
+    if(t < 32)
+    {
+        double total = 0.0;
+        for(int w = 0; w < SPLK_WAVES; w++) total += part[w][t];
+        if(total != 0.0)
+        {
+            const int col = (core >= 0) ? ic*P.Nintr_state + core : r + 2*(dy*Nx + dx);
+            if((place || core >= 0) && col >= 0 && col <= r) O.A[(size_t)r*nd.Nc + col] += total;
+        }
+    }
+}
 // The regularization rows of a splined model (regularization_splined_kernel in kernels.hip): per knot a radial
 // and a tangential row on the knot's two variables, then one row per centre-pixel variable, then unity_cam01.
 // Rows 2 i and 2 i + 1 share their columns; no two PAIRS do. One lane per pair, the pair's rows one after the
@@ -4277,7 +4405,13 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // the knots' rows (a window of columns each), then the rows every pass holds (whole)
             const int nknotrows = splg_nknotrows(P);
             const int window = 2*(P.cfg.spline_order*P.cfg.spline_Nx + P.cfg.spline_order);
-            if(nknotrows > 0)
+            // (MRCAL_AMD_SPL_ROW_GATHER: the control points' rows by the row-per-workgroup kernel too, as until the end of round 4)
+            static const bool row_gather = (getenv("MRCAL_AMD_SPL_ROW_GATHER") != NULL);
+            const int order = P.cfg.spline_order;
+            const bool pull = !row_gather && order*(2*order + 1) + order + 1 + P.Ncore_state <= 32;
+            if(nknotrows > 0 && pull)
+                hipLaunchKernelGGL(assemble_splined_gather_knots_kernel, dim3(nknotrows), dim3(64*SPLK_WAVES), 0, gstream, P, nd, B.R, plan);
+            else if(nknotrows > 0)
                 hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(nknotrows), dim3(64*SPLG_WAVES),
                                    (size_t)SPLG_WAVES*(window + 1 + 4)*sizeof(double), gstream, P, nd, B.R, plan, SPLG_WAVES, 0, window);
             hipLaunchKernelGGL(assemble_splined_gather_kernel, dim3(ndense*SPLG_E), dim3(64*SPLG_WAVES),
