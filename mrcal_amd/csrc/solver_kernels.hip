@@ -416,24 +416,25 @@ void rows_generic_row(const NormalDims& nd, const OpDev& O, int r, int row1,
 //     board, K = (order+1 + span)^2 of them per surface;
 //   - an x row touches the x surface only, a y row the y surface only
 //     (board_splined_kernel: column col0 + .. + xy), and all rows are equally long
-// Two kernels, no atomics, the same bits every time:
-//   assemble_splined_kernel: one workgroup per frame, two passes per observation
-//     (x rows, y rows). A pass writes its rows DENSELY over the local columns
+// Three kernels, no atomics whose order matters, the same bits every time:
+//   assemble_splined_kernel: one workgroup per frame and surface (x rows, y rows: a pass each). A pass writes its
+//     rows DENSELY over the local columns
 //         [ K knots | 4 core | 6 extrinsics | 2 warp | 6 frame | x ]
-//     into LDS and the 256 threads form the lower triangle of that matrix's Gram
-//     product in registers: one product yields the A, Bt, D_f, g and |x|^2
-//     contributions at once. What belongs to the frame (Bt, D_f, g_f: nobody else
-//     writes them) is added in place; the camera-block rows and the x row are
-//     STAGED, a packed lower triangle per pass, with the knot box in a header.
-//   assemble_splined_gather_kernel: one workgroup per ROW of the camera block
-//     (+ one for the x row: g and |x|^2). It walks the passes in order, and where
-//     the pass holds its row adds the row's staged entries into an LDS copy of
-//     the row of A; the copy is added to A at the end. A knot's row is in ~1 pass
-//     in 10; the rows every pass holds (core, extrinsics, warp, x) are split over
-//     SPLG_E workgroups each, summed in order by assemble_splined_combine_kernel.
+//     into an LDS tile and forms the lower triangle of that matrix's Gram on the FP64 matrix cores: one product
+//     yields the A, Bt, D_f, g and |x|^2 contributions at once. What belongs to the frame (Bt, D_f, g_f) leaves
+//     through LDS sums - one addition per entry and workgroup -; the camera-block rows and the x row are
+//     STAGED, a packed lower triangle per pass, with the knot box in a header. An observation whose box does not fit
+//     the tile (more than SPL_TW-19 = 109 knots: a close-up) is cut into overlapping SUB-BOXES, each a pass of its own
+//     over the corners it owns (solver_kernels.hpp SPL_MAXSUB)
+//   assemble_splined_gather_knots_kernel: a workgroup per control point's row of the camera block, a LANE per place
+//     of the row that can hold anything (25 + the core); a pass that holds the row is one load for half a wave
+//   assemble_splined_gather_kernel: one workgroup per row that every pass holds (core, extrinsics, warp; the x row:
+//     g and |x|^2), split over SPLG_E workgroups each and summed in order by assemble_splined_combine_kernel. It walks
+//     the passes in order and adds the row's staged entries into an LDS copy of the row. (Until the end of round 4
+//     the control points' rows came this way too: MRCAL_AMD_SPL_ROW_GATHER)
 // (The one-kernel version flushed each pass's tile sums with global atomics, 8000 of them
 //  per observation; two thirds of a workgroup's time was that flush: 340 us at 30 x 20 knots,
-//  800 frames.) An observation covering more than SPL_TW-19 knots goes the generic way,
+//  800 frames.) An observation of more than SPL_MAXSUB sub-boxes goes the generic way,
 // row by row, with atomics; its header says so. Only the lower triangle of A is written
 #define SPL_TW      128         // local columns
 #define SPL_NDENSE  12
@@ -4380,7 +4381,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
         if(splined_boards)
         {
-            // (72 KB of LDS for the tile: two workgroups per CU)
+            // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes), dim3(256), 0, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji);
             // a copy of the row per wave, as many waves as the LDS holds copies
