@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-iterations", type=int, default=4)
     ap.add_argument("--no-full-solve", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the other single-GPU BASELINE.json configurations (the line's configs[])")
+    ap.add_argument("--only-config", default=None,
+                    help="dev: time just this entry of configs[] (1, 2, 3, 4 or 5) and print it instead of the line")
     ap.add_argument("--sharded", action="store_true",
                     help="diagnostic: take the multi-GPU code path (frame shards + RCCL all-reduces from C++) even with one rank")
     return ap.parse_args()
@@ -114,6 +118,8 @@ def cpu_baseline(oi, Niterations):
     return dict(value  = best["value"],
                 unit   = "iterations/s",
                 cores  = 1,
+                host_cores = os.cpu_count(),
+                host_cores_usable = (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()),
                 kind   = "reference",
                 sample = f"same problem, first trial steps from the seed: {', '.join(str(v['trial_steps']) + ' (' + v['name'] + ')' for v in variants)}; "
                          f"value = {best['name']}; {seconds:.1f} s of one core in all",
@@ -123,10 +129,91 @@ def cpu_baseline(oi, Niterations):
                 # what is the reference's OWN code in these figures is the callback; the reference cannot be faster than
                 # its callback alone:
                 value_upper_bound_callback_only = 1e3/callback_ms if callback_ms > 0 else None,
+                cores_note = "cores = the threads used: the reference's optimize() path is single-threaded (mrcal.c has no threads; "
+                             "BLAS pinned to 1), host_cores = what this box has",
                 note = "the reference's libdogleg + CHOLMOD are not installed here: value = the fastest exact-Cholesky stand-in "
                        "beside the reference's own callback; value_upper_bound_callback_only = evaluations/s of the reference's "
                        "optimizer_callback() alone (a solve of zero cost). The reference with the real CHOLMOD lies in "
                        "[value, value_upper_bound_callback_only]")
+
+
+# The other configurations BASELINE.json lists (the metric's own is the line's value): every one of them fits ONE
+# MI355X, so every one of them is timed here, on rank 0 of a single-GPU run, AFTER the line's timed region and
+# outside it - a witnessed number per configuration instead of a table made by hand.
+# configs[0] (1 camera x 40 frames OPENCV4) is the reference's own CPU-runnable plumbing case: a parity test, not a
+# bench line. Per entry: the problem's sizes, the seed, ms per trial step over STEPS trial steps from the seed (after
+# WARMUP untimed ones), the full solve on a fresh copy, and - where there are boards - the Jacobian kernel's roofline
+# from HIP event pairs around its launches during EXTRA further steps (not during the timed ones: a pair costs the
+# stream 11 us)
+def other_configurations(only=None):
+    import numpy as np
+    import torch
+    import mrcal_amd
+    from mrcal_amd.resident  import Problem
+    from mrcal_amd.synthetic import make_calibration_problem, make_sfm_problem, copy_inputs, CONFIG2_LENSMODEL
+    SEED_BOARDS, SEED_SFM, STEPS, WARMUP, EXTRA = 0, 6, 20, 3, 12
+    def boards(**kw):
+        return make_calibration_problem(mrcal_amd._api, object_width_n=10, object_height_n=10, seed=SEED_BOARDS, **kw)[0]
+    table = (
+        ("1", "BASELINE.json configs[1]: 4 cameras x 400 frames x 10x10 corners, LENSMODEL_OPENCV8, all variables optimized, warp + regularization",
+         SEED_BOARDS, lambda: boards(Ncameras=4, Nframes=400, lensmodel="LENSMODEL_OPENCV8")),
+        ("2", f"BASELINE.json configs[2]: 1 camera x 800 frames x 10x10 corners, {CONFIG2_LENSMODEL} (30x20 control points over 150 degrees), "
+              "core locked (mrcal-calibrate-cameras' recipe for the splined models), frames + warp + regularization",
+         SEED_BOARDS, lambda: boards(Ncameras=1, Nframes=800, lensmodel=CONFIG2_LENSMODEL, do_optimize_intrinsics_core=False)),
+        ("3", "BASELINE.json configs[3]: 16 cameras x 2000 frames x 10x10 corners, LENSMODEL_OPENCV8, unsharded on ONE MI355X (it fits)",
+         SEED_BOARDS, lambda: boards(Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8")),
+        ("4", "BASELINE.json configs[4] without boards: SfM, 4 cameras LENSMODEL_OPENCV4 (intrinsics locked), 20000 triangulated points, "
+              "extrinsics optimized, unity_cam01 regularization, unsharded on ONE MI355X",
+         SEED_SFM, lambda: make_sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=SEED_SFM, noise=0.3)[0]),
+        ("5", "BASELINE.json configs[4]: the same + 400 board frames (1600 board observations), frames optimized too",
+         SEED_SFM, lambda: make_sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=SEED_SFM, noise=0.3, Nboard_frames=400)[0]))
+    out = []
+    for key, workload, seed, make in table:
+        if only is not None and key != str(only):
+            continue
+        entry = dict(config = key, workload = workload, seed = seed, data = "synthetic", n_gpus = 1)
+        try:
+            oi = make()
+            with Problem(**copy_inputs(oi)) as p:
+                _, tr = p.run_steps(WARMUP, None)
+                p.synchronize(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n, tr = p.run_steps(STEPS, tr)
+                p.synchronize(); torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                st = p.solver_stats()
+                entry.update(Nstate = p.Nstate, Nmeasurements = p.Nmeas, Nnz_J = p.Nnz, steps = n, warmup = WARMUP,
+                             ms_per_step = 1e3*dt/n, iterations_per_s = n/dt,
+                             solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"]))
+                alg = p.jacobian_algorithmic_bytes()
+                if alg > 0:
+                    p.jacobian_timing_begin(EXTRA + 2, 1)
+                    p.run_steps(EXTRA, tr)
+                    p.synchronize()
+                    nl, ktot, kmin, kmax = p.jacobian_timing_end()
+                    if nl > 0 and ktot > 0:
+                        kms = ktot/nl
+                        ach = alg/1e9/(kms*1e-3)
+                        entry["roofline"] = dict(bound = "hbm", kernel = "the board Jacobian build of this configuration "
+                                                 "(board_kernel / board_splined_kernel: residuals x, CSR Jacobian values" +
+                                                 ("" if "SPLINED" in workload else ", per-observation Gram") + ")",
+                                                 achieved = ach, peak = HBM_PEAK_GBS, unit = "GB/s", frac = ach/HBM_PEAK_GBS,
+                                                 algorithmic_bytes_per_launch = alg, kernel_ms_avg = kms, kernel_ms_min = kmin,
+                                                 kernel_ms_max = kmax, launches_timed = nl, timed_every = 1,
+                                                 timed_in = f"{EXTRA} further trial steps behind the {n} timed ones", traffic = None)
+            with Problem(**copy_inputs(oi)) as p2:
+                p2.synchronize(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s2 = p2.solve()
+                p2.synchronize()
+                entry["full_solve"] = dict(seconds = time.perf_counter() - t0, iterations = s2["Niterations"],
+                                           evaluations = s2["Nevaluations"], outlier_passes = s2["Noutlier_passes"],
+                                           rms_reproj_error__pixels = s2["rms_reproj_error__pixels"],
+                                           Noutliers_board = s2["Noutliers_board"])
+        except Exception as e:      # a configuration that fails says so in its entry; the line is still printed
+            entry["error"] = f"{type(e).__name__}: {e}"
+        out.append(entry)
+    return out
 
 
 # MRCAL_AMD_BENCH_ONE_DEVICE=1: every rank on device 0, the solve's collectives staged through host shared memory
@@ -185,6 +272,10 @@ def main():
 
     import mrcal_amd
     from mrcal_amd.synthetic import make_calibration_problem
+
+    if args.only_config is not None:
+        print(json.dumps(other_configurations(args.only_config)), flush=True)
+        return
 
     oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=args.cameras, Nframes=args.frames,
                                      lensmodel="LENSMODEL_OPENCV8",
@@ -361,6 +452,8 @@ def main():
                                     Noutliers_board = s2["Noutliers_board"])
         p2.close()
 
+    if rank == 0 and not sharded and not args.no_configs:
+        result["configs"] = other_configurations()
     if rank == 0:
         cb = None
         if not sharded and not args.no_cpu_baseline:

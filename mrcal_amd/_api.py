@@ -543,8 +543,16 @@ class Api:
             from .resident import Problem
             from . import _lib
             if _lib is self.lib:
-                with Problem(_ingested=p) as prob:
-                    return prob.factorization()
+                # None means "JtJ is singular" and nothing else (mrcal-pywrap.c:1981-1988). Anything else that stops
+                # this route - no device memory for a second resident problem, a shard, a Gram past 2^32 doubles -
+                # falls through to the factorization of the CSR that was just made, which needs far less
+                try:
+                    with Problem(_ingested=p) as prob:
+                        F = prob.factorization()
+                        if F is not None or "not positive definite" in self._last_error():
+                            return F
+                except RuntimeError:
+                    pass
         s = (p.Ncameras_intrinsics, p.Ncameras_extrinsics, p.Nframes, p.Npoints, p.Npoints_fixed,
              p.Nobservations_board, p.sel, C.byref(p.lensmodel))
         Ni  = self.clib.mrcal_num_states_intrinsics(p.Ncameras_intrinsics, p.sel, C.byref(p.lensmodel))

@@ -540,6 +540,13 @@ void spl_rows_fallback(const NormalDims& nd, const OpDev& O, int r_first, int r1
 {
     for(int r = r_first; r < r1; r += blockDim.x) rows_generic_row(nd, O, r, r1, Jp, Ji);
 }
+// can an observation of this problem take the fallback above? (The whole grid under one board is the largest box)
+static bool spl_fallback_possible(const DeviceProblem& P)
+{
+    const int order = P.cfg.spline_order, T = SPL_SUB_MAX - order;
+    const int nsx = std::max(1, ((int)P.cfg.spline_Nx - order + T - 1)/T), nsy = std::max(1, ((int)P.cfg.spline_Ny - order + T - 1)/T);
+    return nsx*nsy > SPL_MAXSUB || P.W*P.H > 1024;
+}
 #ifndef SPL_WAVES_PER_EU
 #define SPL_WAVES_PER_EU 2
 #endif
@@ -3192,11 +3199,15 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
     if((t == 0 || t == 64*5) && (j0 == 128 || j0 == 640)) printf("lchol diag j0 %d t %d: issue loads %lld, pre-update %lld, factor %lld (diag16 %lld, b %lld, c %lld, barriers %lld), store %lld cycles\n", j0, t, ts[1]-ts[0], ts[2]-ts[1], ts[3]-ts[2], tsd, tsb, tsc, tsy, ts[4]-ts[3]);
 #endif
 }
+// with_finish (round 5): the end of the trial step (step2_finish: one workgroup anyway) opens this launch instead of
+// being a launch of its own in front of it - 4.8 us of pure launch on every trial step of a big camera block; what it
+// decides (fl->skip_chol, which is what `skip` points at) is what the panel launches behind this one read
 __global__ __launch_bounds__(LCH_THREADS)
 void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
-                       double* __restrict__ Linv, int* __restrict__ status)
+                       double* __restrict__ Linv, int* __restrict__ status, int with_finish, Step2Dev sd)
 {
-    if(skip != NULL && *skip) return;
+    if(with_finish) { if(!step2_finish(sd, status)) return; }
+    else if(skip != NULL && *skip) return;
     __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
     lchol_diag_block(n, M, j0, Linv, status, NULL, 0, lds);
 }
@@ -3499,9 +3510,13 @@ void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict_
 #define LCH_AI_COLS 16
 __global__ __launch_bounds__(256)
 void lchol_apply_inverse_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, const double* __restrict__ Linv,
-                                const double* __restrict__ Yb, const double* __restrict__ zc, int npad)
+                                const double* __restrict__ Yb, const double* __restrict__ zc, int npad,
+                                int with_post, Step2Dev sd, const int* __restrict__ chol_status)
 {
     if(skip != NULL && *skip) return;
+    // with_post (round 5): what step2_post_kernel did in a launch of its own - the factorization's verdict into the
+    // control block (every panel's diagonal workgroup has run: the status is final) - by one thread of this launch
+    if(with_post && blockIdx.x == 0 && threadIdx.x == 0) step2_chol_done(sd, *chol_status != 0);
     constexpr int NB = LCH_NB;
     __shared__ double part[16][LCH_AI_COLS];
     const int t = threadIdx.x, j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
@@ -3654,7 +3669,11 @@ void lchol_backward_apply_kernel(int n, const int* __restrict__ skip, double* __
 
 // the workspace behind FactorBuffers::Linv: [npanels][64][64] inverse diagonal blocks | Yb [npad][npad] | zc [npad]
 static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB; }
-hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream)
+// sd (optional): the trial step this factorization belongs to - its end-of-trial logic rides in the first launch and
+// the verdict in the last (no step2_finish_kernel / step2_post_kernel around the call). *fused says whether that happened
+// (not with the backward sweep of MRCAL_AMD_LCHOL_SWEEP, whose last launch is another)
+hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
+                                 const Step2Dev* sd = NULL, bool* fused = NULL)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
     const int npad    = (int)lchol_npad(n);
@@ -3677,7 +3696,11 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         if(W.krow >= 0 && W.krow + 2 < npanels) W.ntile = (npanels - W.krow - 2)*(W.krow + 1);
         return W;
     };
-    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n, skip, M, 0, Xof(0), status);
+    Step2Dev sd0; memset(&sd0, 0, sizeof(sd0));
+    const bool fuse = (sd != NULL && !sweep);
+    if(fused != NULL) *fused = fuse;
+    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n, skip, M, 0, Xof(0), status,
+                       fuse ? 1 : 0, fuse ? *sd : sd0);
     for(int p = 0; p < npanels; p++)
     {
         const int j0 = p*LCH_NB;
@@ -3703,7 +3726,8 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     if(!sweep)
     {
         hipLaunchKernelGGL(lchol_apply_inverse_kernel, dim3((n + LCH_AI_COLS - 1)/LCH_AI_COLS), dim3(256), 0, stream, n, skip, M,
-                           (const double*)Linv, (const double*)Yb, (const double*)zc, npad);
+                           (const double*)Linv, (const double*)Yb, (const double*)zc, npad,
+                           fuse ? 1 : 0, fuse ? *sd : sd0, (const int*)status);
         return hipGetLastError();
     }
     // the backward sweep, in groups of panels (see lchol_backward_kernel)
@@ -4379,8 +4403,34 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         int rows_from = row0, rows_to = P.Nmeas;
         hipStream_t gstream = stream;
         const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
+        bool pairs_early = false;
         if(splined_boards)
         {
+            rows_from = 2*P.W*P.H*P.Nobs_board;
+            if(P.i_meas_regularization >= rows_from && P.i_meas_regularization < P.Nmeas) rows_to = P.i_meas_regularization;
+            // What follows assemble_splined_kernel writes the camera block's A and g, and |x|^2: nothing the block
+            // elimination or the SYRK read. With a side stream it runs beside them (unless there are other rows
+            // - discrete points - that add to A with atomics at the same time)
+            // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
+            static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
+            const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !one_stream;
+            // Round 5: the regularization rows' pairs go FIRST on the side stream, beside assemble_splined_kernel (which
+            // writes the frames' blocks and Bt, never A or the camera block's g): they were 10 us at the end of the side
+            // stream's chain, which is the longer of the two the reduction waits for. A's entries then take the pairs'
+            // products before the gathered sums instead of after (other bits than round 4's, the same every time: the
+            // side stream orders the two). MRCAL_AMD_SPL_PAIRS_LATE: where they were
+            static const bool pairs_late = (getenv("MRCAL_AMD_SPL_PAIRS_LATE") != NULL);
+            const int nrp_early = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
+            // (not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
+            //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
+            //  plain read-modify-writes must not run beside those)
+            if(use_side && nrp_early > 0 && !pairs_late && !spl_fallback_possible(P))
+            {
+                hipError_t e = hipEventRecord(ev_fork, stream);           if(e != hipSuccess) return e;
+                e = hipStreamWaitEvent(side, ev_fork, 0);                 if(e != hipSuccess) return e;
+                hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp_early), dim3(256), 0, side, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
+                pairs_early = true;
+            }
             // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes), dim3(256), 0, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji);
@@ -4389,14 +4439,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             const int nwaves = (int)std::min<size_t>(SPLG_WAVES, (size_t)(150*1024)/row_bytes);
             if(nwaves < 1) return hipErrorInvalidValue;
             const int ndense = splg_ndense(P, nd);
-            rows_from = 2*P.W*P.H*P.Nobs_board;
-            if(P.i_meas_regularization >= rows_from && P.i_meas_regularization < P.Nmeas) rows_to = P.i_meas_regularization;
-            // What follows the workgroups above writes the camera block's A and g, and |x|^2: nothing the block
-            // elimination or the SYRK read. With a side stream it runs beside them (unless there are other rows
-            // - discrete points - that add to A with atomics at the same time)
-            // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
-            static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
-            if(side != NULL && forked != NULL && rows_to == rows_from && !one_stream)
+            if(use_side)
             {
                 hipError_t e = hipEventRecord(ev_fork, stream);           if(e != hipSuccess) return e;
                 e = hipStreamWaitEvent(side, ev_fork, 0);                 if(e != hipSuccess) return e;
@@ -4446,7 +4489,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         if(splined_boards)
         {
             const int nrp = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
-            if(nrp > 0)
+            if(nrp > 0 && !pairs_early)
                 hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp), dim3(256), 0, gstream, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
             hipLaunchKernelGGL(assemble_splined_combine_kernel, dim3(splg_ndense(P, nd)), dim3(256), 0, gstream, P, nd, B.R, plan, nrp);
             if(gstream != stream)
@@ -4822,9 +4865,15 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
                                n, (const int*)NULL, 0, F.S, F.r, F.status, sd);
         else
         {
-            hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
-            launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream);
-            hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
+            // (round 5: finish and post ride in the factorization's first and last launch; MRCAL_AMD_LCHOL_SEPARATE_FINISH
+            //  brings the two launches back, for comparisons)
+            // (with the backward sweep of MRCAL_AMD_LCHOL_SWEEP the factorization's last launch is another: separate too)
+            static const bool separate = (getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
+            bool fused = false;
+            if(separate) hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
+            launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused);
+            if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
+            else if(!fused) return hipErrorInvalidValue;
         }
     }
     const int nbs = (br.count() + 3)/4, nqf = quadform_blocks(nd);
@@ -5293,9 +5342,10 @@ void fsolve_permute_kernel(NormalDims nd, const double* __restrict__ b, double* 
 // device-resident CSR J of a factorization
 // y = Jt x without atomics (round 4: the same bits every time, like the solve). The rows are cut into chunks of a
 // fixed number of rows (a function of the matrix's shape alone); ONE wave walks a chunk's rows in order, a lane per
-// entry of the row, adding into the chunk's own copy of y in LDS - the columns of one row are distinct, so a wave
-// instruction never adds to one address twice, and consecutive rows are consecutive instructions of the same wave: the
-// order of every sum is the row order. The chunks' copies go to part[chunk][.] and csr_Jt_x_sum_kernel adds them per
+// entry of the row, adding into the chunk's own copy of y in LDS with LDS atomics - the columns of one row are distinct in every Jacobian
+// the problems make, so a wave instruction adds to an address once (a caller's row that repeats a column is served too:
+// the LDS takes an instruction's adds in lane order), and consecutive rows are consecutive instructions of the same
+// wave: the order of every sum is the row order. The chunks' copies go to part[chunk][.] and csr_Jt_x_sum_kernel adds them per
 // column in chunk order. A y longer than the LDS tile is done in column tiles (a pass over the chunk's rows each).
 // (History: one lane per row with atomics, 41 ms at the metric's size; rows of a half-wave with the same columns summed
 //  first, then atomics, 2.1 ms; this - see profiles/r04_*)
@@ -5321,7 +5371,11 @@ void csr_Jt_x_chunk_kernel(int Nrows, int Ncols, int rows_per_chunk, const int32
             for(int p = p0 + lane; p < p1; p += 64)
             {
                 const int c = Ji[p] - c0;
-                if(c >= 0 && c < nc) acc[c] += Jx[p]*xr;
+                // (ds_add_f64, not a read-modify-write: a CSR row may list a column twice - scipy allows it, the
+                //  reference's loop adds both - and two lanes of one instruction then meet at one address: the LDS
+                //  applies the adds of an instruction one after the other, lane by lane. With distinct columns, the
+                //  only case the problems' own Jacobians have, it is the same a + v as before)
+                if(c >= 0 && c < nc) atomicAdd(&acc[c], Jx[p]*xr);
             }
             // (a row longer than 64 entries: its later entries are later instructions; LDS serves a wave in order)
         }

@@ -302,7 +302,11 @@ class GpuShard:
         self.L = L = problem._lib
         _declare_sharded(L)
         info = (C.c_int*12)()
-        assert L.mrcal_amd_problem_shard_info(problem.handle, info, len(info)) >= len(info)
+        # (called unconditionally: under `python -O` an assert - and the call inside it - is not there)
+        nfilled = L.mrcal_amd_problem_shard_info(problem.handle, info, len(info))
+        if nfilled < len(info):
+            raise RuntimeError(f"mrcal_amd_problem_shard_info() filled {nfilled} of {len(info)} fields: "
+                               "libmrcal_amd.so and mrcal_amd/parallel.py are not of the same build")
         # (Nie: S_split, the end of the leading intrinsics + extrinsics variables of a sharded problem's state)
         self.Nstate, self.Nie, self.NE, self.Nc = info[0], info[1], info[2], info[3]
         self.frame_lo, self.frame_hi = info[4], info[5]

@@ -27,7 +27,7 @@ metric's 8 x 1000, 2 (splined 30x20 knots, 800 frames), 3 (16 x 2000), 4 (SfM:
 import numpy as np
 import pytest
 
-from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 
 pytestmark = pytest.mark.gpu
 
@@ -262,7 +262,7 @@ def test_splined_configuration_full_size(amd, ref_api, core):
     from mrcal_amd.resident import Problem
     rng = np.random.RandomState(3)
     oi, _ = make_calibration_problem(amd._api, Ncameras=1, Nframes=800, object_width_n=10, object_height_n=10,
-                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     lensmodel=CONFIG2_LENSMODEL,
                                      seed=4, do_optimize_intrinsics_core=core)
     assert oi["intrinsics"].shape[1] == 4 + 2*30*20
     assert amd.num_states(**oi) == (6006 if core else 6002)
@@ -291,7 +291,7 @@ def test_splined_configuration_solve_matches_reference(amd, ref_api):
     (tests/test_solver_parity.py::test_optimize_splined) -, and the arbiter's word on both results"""
     from test_solver_parity import _compare_splined_solves
     oi, _ = make_calibration_problem(amd._api, Ncameras=1, Nframes=800, object_width_n=10, object_height_n=10,
-                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     lensmodel=CONFIG2_LENSMODEL,
                                      seed=4, do_optimize_intrinsics_core=False)
     _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=1e-3)
 
@@ -379,7 +379,7 @@ def test_sfm_configuration_full_size(amd, ref_api):
     # the splined assembly (staged local Grams, gathered in order; regularization rows in pairs): two cameras
     # with the core, and BASELINE configuration 2
     (2, 40,   "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", {}),
-    (1, 800,  "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120", {"do_optimize_intrinsics_core": False})))
+    (1, 800,  CONFIG2_LENSMODEL, {"do_optimize_intrinsics_core": False})))
 def test_solve_is_bit_reproducible(amd, Ncameras, Nframes, lensmodel, extra):
     """The block normal equations are summed in a fixed order (no floating-point
     atomics between the Grams and the Cholesky: DESIGN.md section 5): the same

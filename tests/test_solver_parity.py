@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from conftest import relative_error
-from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 
 pytestmark = pytest.mark.gpu
 
@@ -411,7 +411,7 @@ def test_optimize_splined_reduced_configuration_2(amd, ref_api):
     Cholesky -, solved with outlier rejection by the product and by the reference's mrcal_optimize() (15 s of one
     host core), then judged by the arbiter"""
     oi, _ = make_calibration_problem(amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
-                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                     lensmodel=CONFIG2_LENSMODEL,
                                      seed=4, do_optimize_intrinsics_core=False)
     assert amd.num_states(**oi) == 2*30*20 + 6*200 + 2
     _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=1e-3)

@@ -28,85 +28,8 @@ def R_from_r(r):
     return np.eye(3) + np.sin(th)*K + (1-np.cos(th))*(K@K)
 
 
-def sfm_problem(lensmodel="LENSMODEL_PINHOLE", Ncam=4, Npoints=40, seed=0, noise=0.5, Nboard_frames=0,
-                board_wh=(10,10), board_spacing=0.1):
-    """Nboard_frames > 0: chessboard frames beside the triangulated points, every camera seeing every board
-    (BASELINE.json's configuration 5: "4 cameras + 20k triangulated points + board frames"; allowed by
-    mrcal.c:6043-6051 with the intrinsics locked). The frame poses are then optimized too"""
-    rng = np.random.RandomState(seed)
-    W, H = 4000, 2200
-    core = np.array((600., 600., (W-1)/2., (H-1)/2.))
-    if lensmodel == "LENSMODEL_PINHOLE":
-        intr = np.tile(core, (Ncam,1))
-    elif lensmodel == "LENSMODEL_OPENCV4":
-        intr = np.tile(np.r_[core, -0.01, 0.02, 1e-3, -2e-3], (Ncam,1))
-    else:
-        raise ValueError(lensmodel)
-    # camera 0 at the reference, the others ~1m apart along x, slightly rotated
-    rt_cam_ref = np.zeros((Ncam-1, 6))
-    for i in range(1, Ncam):
-        rt_cam_ref[i-1,:3] = rng.uniform(-0.05, 0.05, 3)
-        rt_cam_ref[i-1,3:] = (-1.0*i, rng.uniform(-0.1,0.1), rng.uniform(-0.1,0.1))
-
-    def pixel(ic, pref):
-        """perfect pixel of a point given in the reference frame, seen by camera ic"""
-        p = pref if ic == 0 else R_from_r(rt_cam_ref[ic-1,:3]) @ pref + rt_cam_ref[ic-1,3:]
-        x, y = p[0]/p[2], p[1]/p[2]
-        if lensmodel == "LENSMODEL_OPENCV4":
-            k = intr[ic,4:]
-            r2 = x*x + y*y
-            cd = 1 + k[0]*r2 + k[1]*r2*r2
-            x, y = x*cd + 2*k[2]*x*y + k[3]*(r2+2*x*x), y*cd + k[2]*(r2+2*y*y) + 2*k[3]*x*y
-        return core[:2]*np.array((x,y)) + core[2:]
-
-    pts = np.column_stack((rng.uniform(-3, 5, Npoints), rng.uniform(-2, 2, Npoints), rng.uniform(8, 30, Npoints)))
-    obs, idx = [], []
-    for ip in range(Npoints):
-        cams = np.sort(rng.choice(Ncam, size=rng.randint(2, Ncam+1), replace=False))
-        for ic in cams:
-            q = pixel(ic, pts[ip]) + rng.normal(0, noise, 2)
-            obs.append((q[0], q[1], 1.0))
-            idx.append((ip, ic, ic-1))
-    obs = np.array(obs); idx = np.array(idx, dtype=np.int32)
-    obs[5,2] = -1.      # an outlier on input
-    # seed: the truth, perturbed
-    seedrt = rt_cam_ref + rng.normal(0, 1, rt_cam_ref.shape)*np.array((0.01,0.01,0.01,0.05,0.05,0.05))
-    oi = dict(intrinsics = intr, lensmodel = lensmodel,
-              imagersizes = np.tile(np.array((W,H), dtype=np.int32), (Ncam,1)),
-              rt_cam_ref = np.ascontiguousarray(seedrt),
-              observations_point_triangulated = np.ascontiguousarray(obs),
-              indices_point_triangulated_camintrinsics_camextrinsics = np.ascontiguousarray(idx),
-              do_optimize_intrinsics_core = False, do_optimize_intrinsics_distortions = False,
-              do_optimize_extrinsics = True, do_optimize_frames = False, do_optimize_calobject_warp = False,
-              do_apply_regularization = True, do_apply_regularization_unity_cam01 = True,
-              do_apply_outlier_rejection = False, verbose = False)
-    truth = dict(rt_cam_ref=rt_cam_ref, points=pts)
-    if Nboard_frames:
-        Wb, Hb = board_wh
-        rb = np.random.RandomState(seed + 77771)     # (its own stream: the points above do not depend on the boards)
-        rt_ref_frame = np.column_stack((rb.uniform(-0.3, 0.3, (Nboard_frames,3)),
-                                        rb.uniform(-2.5, 0.5, Nboard_frames), rb.uniform(-1, 0.5, Nboard_frames),
-                                        rb.uniform(4, 8, Nboard_frames)))
-        gx, gy = np.meshgrid(np.arange(Wb)*board_spacing, np.arange(Hb)*board_spacing)
-        corners = np.stack((gx, gy, np.zeros_like(gx)), axis=-1)          # (Hb,Wb,3): y-major then x (mrcal.c:2794)
-        ob = np.zeros((Nboard_frames*Ncam, Hb, Wb, 3))
-        ib = np.zeros((Nboard_frames*Ncam, 3), dtype=np.int32)
-        for f in range(Nboard_frames):
-            pref = corners @ R_from_r(rt_ref_frame[f,:3]).T + rt_ref_frame[f,3:]
-            for ic in range(Ncam):
-                o = f*Ncam + ic
-                ib[o] = (f, ic, ic-1)
-                for iy in range(Hb):
-                    for ix in range(Wb):
-                        ob[o,iy,ix,:2] = pixel(ic, pref[iy,ix])
-        ob[...,:2] += rb.normal(0, noise, ob[...,:2].shape)
-        ob[...,2]   = rb.uniform(0.5, 1.0, ob.shape[:3])
-        ob[1, min(2, Hb-1), min(3, Wb-1), 2] = -1.      # an outlier on input
-        oi.update(rt_ref_frame = np.ascontiguousarray(rt_ref_frame + rb.normal(0, 1, rt_ref_frame.shape)*np.array((5e-3,)*3 + (2e-2,)*3)),
-                  observations_board = ob, indices_frame_camintrinsics_camextrinsics = ib,
-                  calibration_object_spacing = board_spacing, do_optimize_frames = True)
-        truth["rt_ref_frame"] = rt_ref_frame
-    return oi, truth
+# (the generator lives with the other synthetic workloads since round 5: bench.py times these configurations too)
+from mrcal_amd.synthetic import make_sfm_problem as sfm_problem
 
 
 # ------------------------------------------------------------------ CPU ---

@@ -3,10 +3,10 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mrcal_amd
-from mrcal_amd.synthetic import make_calibration_problem
+from mrcal_amd.synthetic import make_calibration_problem, CONFIG2_LENSMODEL
 from mrcal_amd.resident import Problem
 oi,_ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=800, object_width_n=10, object_height_n=10,
-                                lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120", seed=4,
+                                lensmodel=CONFIG2_LENSMODEL, seed=4,
                                 do_optimize_intrinsics_core=False)
 p = Problem(**oi)
 _, tr = p.run_steps(2, None); p.synchronize()

@@ -7,22 +7,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import mrcal_amd
-from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 from mrcal_amd.resident import Problem
 
 def board(**kw):
     return make_calibration_problem(mrcal_amd._api, object_width_n=10, object_height_n=10, seed=2, **kw)[0]
 def sfm():
-    from test_triangulated import sfm_problem
+    from mrcal_amd.synthetic import make_sfm_problem as sfm_problem
     return sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=6, noise=0.3)[0]
 def sfm_boards():
-    from test_triangulated import sfm_problem
+    from mrcal_amd.synthetic import make_sfm_problem as sfm_problem
     return sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=20000, seed=6, noise=0.3, Nboard_frames=400)[0]
 CONFIGS = (("0: 1 cam x 40 frames OPENCV4",            lambda: board(Ncameras=1,  Nframes=40,   lensmodel="LENSMODEL_OPENCV4")),
            ("1: 4 cams x 400 frames OPENCV8",          lambda: board(Ncameras=4,  Nframes=400,  lensmodel="LENSMODEL_OPENCV8")),
            ("metric: 8 cams x 1000 frames OPENCV8",    lambda: board(Ncameras=8,  Nframes=1000, lensmodel="LENSMODEL_OPENCV8")),
            ("2: 1 cam x 800 frames SPLINED 30x20",     lambda: board(Ncameras=1,  Nframes=800,
-                                                                      lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=30_Ny=20_fov_x_deg=120",
+                                                                      lensmodel=CONFIG2_LENSMODEL,
                                                                       do_optimize_intrinsics_core=False)),     # the core is redundant with the surface (mrcal's own recipe locks it)
            ("3: 16 cams x 2000 frames OPENCV8",        lambda: board(Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8")),
            ("4: SfM, 4 cams, 20k triangulated points", sfm),
