@@ -321,6 +321,10 @@ def main():
     dt = time.perf_counter() - t0
     nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
     assert n == args.steps
+    # (round 5) where the choice of the trial point, its poses and the Jacobian are ONE launch the event pairs bracket all
+    # of it; the launch's own stamps say what the Jacobian stream alone took (first Jacobian store -> end)
+    fused = (not sharded) and problem.fuses_prologue()
+    sn, stream_ms, pose_ms, first_store_ms = problem.jacobian_stream_timing() if not sharded else (0, 0., 0., 0.)
 
     dt_rank = dt
     if sharded:
@@ -412,6 +416,14 @@ def main():
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
                         frac = achieved/HBM_PEAK_GBS,
+                        **(dict(one_launch_with_choice_and_poses = True,
+                                kernel_ms_avg_meaning = "the WHOLE launch, event pair to event pair: the choice of the trial point, the joint poses "
+                                                        "and the Jacobian build (until round 4: the Jacobian launch alone, its poses a launch earlier)",
+                                jacobian_stream_ms_avg = stream_ms/sn, poses_ms_avg = pose_ms/sn, first_store_after_ms_avg = first_store_ms/sn,
+                                frac_jacobian_stream = alg_bytes/1e9/(stream_ms/sn*1e-3)/HBM_PEAK_GBS,
+                                jacobian_stream_meaning = "first Jacobian store -> last wave done, from wall-clock stamps (100 MHz) a sample of the "
+                                                          "launch's own waves leaves: the same bytes over the time the Jacobian stream runs")
+                           if (fused and sn > 0 and stream_ms > 0) else {}),
                         traffic = traffic,
                         traffic_source = None if traffic is None else
                             "committed constant: profiles/board_kernel_hbm_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "

@@ -548,6 +548,17 @@ bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int c
 bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* problem, int capacity, int stride);
 bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
                                            double* total_ms, double* min_ms, double* max_ms);
+/* Round 5: where every variable group is optimized and the lens model is of the OPENCV family, a trial step's choice
+   of the trial point, the prologue of its evaluation (the joint poses) and the Jacobian kernel are ONE launch
+   (_fuses_prologue() != 0): the Jacobian kernel's waves stage their pixels while the poses are being made and start
+   on their rows when their pose record's flag goes up. The event pairs above then bracket that whole launch - poses
+   included. _jacobian_stream_timing(), called after _timing_end(): of the launches it timed, how many left
+   device-side stamps and the sum over them of (end of the launch - first Jacobian store), ms: the Jacobian stream
+   alone, from wall-clock stamps a sample of the waves leaves (100 MHz). OPT-IN (MRCAL_AMD_FUSED_PROLOGUE=1 in the
+   environment when the problem is created): measured 4-6 us a step slower than the two launches at the metric's size
+   (profiles/r05_fused_prologue.txt), so the two launches stay the default and _fuses_prologue() is 0 */
+void mrcal_amd_problem_jacobian_stream_timing(mrcal_amd_problem_t* problem, int* Nlaunches, double* total_ms);
+int  mrcal_amd_problem_fuses_prologue(mrcal_amd_problem_t* problem);
 
 /* ---- multi-GPU: one process per GPU, frames sharded over the ranks ----------
    No counterpart in the reference (it is single-threaded). Every rank creates

@@ -27,6 +27,7 @@
 // is produced once by the *_structure kernels at problem creation.
 #include <hip/hip_runtime.h>
 #include <utility>
+#include <stdlib.h>
 #include "problem.hpp"
 #include "device_math.hpp"
 #include "lens_models.hpp"
@@ -201,13 +202,53 @@ void regularization_row(const DeviceProblem& P, const OpRef& R,
 // the entries of the trial state they need from them (TrialState: the same instructions, hence the same bits,
 // as the workgroups at the end of the grid that write the step and the trial state out), and whether the trial
 // evaluates anything at all is taken from the derived numbers, not from the flag being written
-template<class BV>
+// ---- the hand-off of the pose records INSIDE a launch (board_fused_kernel, round 5)
+// The per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores: what a wave of the same
+// launch is to read is stored write-through (sc1), 16 bytes a store; every storing lane drains its stores
+// (s_waitcnt vmcnt(0)) before it raises its observation's flag with an agent-scope store; the reader polls the flag
+// with agent-scope loads and reads the record with sc1 loads (cdna_hip_programming.md, Guideline 16, form R1).
+// ready[iobs]: 0 at rest | FUSED_READY: the record is there | FUSED_SKIP: this trial evaluates nothing. The reader
+// puts it back to 0 (the next launch that raises it is a kernel boundary away)
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+// observations a pose workgroup of the one-launch form takes (a lane each). 64; with 16 - four times the waves, a
+// quarter of the records each to push out - the poses were through 4 us LATER (500 choose reductions instead of 125)
+// and the stores took as long: profiles/r05_fused_prologue.txt
+#ifndef FUSED_OBS
+#define FUSED_OBS 64
+#endif
+#define FUSED_READY 1u
+#define FUSED_SKIP  2u
+typedef double d2_sc1_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_sc1_b128(double* p, double a, double b)
+{
+    d2_sc1_t v; v.x = a; v.y = b;
+    // (s_nop 1 inside the string: a store of more than 64 bits reads its data registers a little after it issues, and
+    //  the compiler's hazard recognizer, which keeps the next write to them away for that long, does not look into asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ double load_sc1_f64(const double* p)
+{
+    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)u);
+}
+
+template<class BV, bool FUSED = false>
 __device__ __forceinline__
 void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV& b, const OpDev& O,
-                         int nblocks_unpack, int nblocks_zero, int reg_mode)
+                         int nblocks_unpack, int nblocks_zero, int reg_mode, unsigned* __restrict__ ready = NULL,
+                         double* __restrict__ lds_stage = NULL /* FUSED: 64 x 17 doubles of LDS */,
+                         unsigned long long* __restrict__ fused_ts = NULL)
 {
     double* __restrict__ joint = B.joint;
-    const int nblocks_obs = (P.Nobs_board + PRO_T - 1)/PRO_T;
+    // (FUSED: FUSED_OBS observations a workgroup instead of one a thread - see the stores below)
+    constexpr int OBS_PER_WG = FUSED ? FUSED_OBS : PRO_T;
+    const int nblocks_obs = (P.Nobs_board + OBS_PER_WG - 1)/OBS_PER_WG;
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack + nblocks_zero)
     {
         const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*PRO_T + threadIdx.x;
@@ -253,13 +294,25 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
         return;
     }
 
-    const int iobs = blockIdx.x*blockDim.x + threadIdx.x;
-    if(iobs >= P.Nobs_board) return;
+    const int iobs_raw = FUSED ? ((int)threadIdx.x < OBS_PER_WG ? (int)blockIdx.x*OBS_PER_WG + (int)threadIdx.x : P.Nobs_board)
+                               : (int)(blockIdx.x*blockDim.x + threadIdx.x);
+    if(!FUSED && iobs_raw >= P.Nobs_board) return;
+    // (FUSED: the wave stores its 64 records together, below: the lanes past the last observation work on the last one)
+    const int iobs = (iobs_raw < P.Nobs_board) ? iobs_raw : P.Nobs_board - 1;
     const BoardObsMeta m = P.board_meta[iobs];
 
     double rt_frame[6], rt_cam[6];
     get_rt_ref_frame(rt_frame, P, b, m.iframe);
-    double rec[JOINT_STRIDE];
+    double xtra[18];
+    if constexpr(FUSED)
+    {
+#pragma unroll
+        for(int i=0;i<16;i++) xtra[i] = (i < P.Nintrinsics) ? get_intrinsic(P, b, m.icam_intrinsics, i) : 0.0;
+        double w[2] = {0.0, 0.0};
+        if(P.has_warp_seed) get_warp(w, P, b);
+        xtra[16] = w[0]; xtra[17] = w[1];           // (the warp at JOINT_INTR + 16, whatever the lens model)
+    }
+    double rec[JOINT_REC];
     if(m.icam_extrinsics >= 0)
     {
         get_rt_cam_ref(rt_cam, P, b, m.icam_extrinsics);
@@ -268,9 +321,57 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     else
         joint_pose_record(rec, NULL, rt_frame);
     double* out = joint + (size_t)iobs*JOINT_STRIDE;
-    for(int i=0;i<JOINT_STRIDE;i++) out[i] = rec[i];
+    if constexpr(FUSED)
+    {
+        // The records, write-through; behind each the camera's intrinsics and the warp at this state (asked for
+        // above, beside the poses: their loads are in flight under the pose's arithmetic).
+        // WHOLE LINES: a record is 7 lines of 128 bytes; a lane storing its own record 16 bytes at a time makes every
+        // store instruction 64 partial writes to 64 different lines, and a write-through store goes to memory as it
+        // is - 408 k sixteen-byte writes a launch at the metric's size, which the pose workgroups waited 8 us for
+        // (poses through 25.6 us after the launch's start instead of 17.6 as a launch of their own). So the wave
+        // turns its 64 records round in LDS, a line of every record at a time: lane l leaves entries 16 c .. 16 c + 15
+        // of its record in row l, then lane l stores piece l % 8 of record 8 k + l / 8, k = 0 .. 7: eight complete lines
+        // an instruction
+        // (-DFUSED_TS stamps: the stores of a wave's records are out 6.5 us after the records are computed, whole
+        //  lines or not, 64 records a wave or 16: the latency of write-through stores under the launch's own traffic)
+        const int lane = threadIdx.x;
+        const int wave_obs0 = blockIdx.x*OBS_PER_WG;
+#ifdef FUSED_TS
+        { const double dep = rec[0] + rec[83]; asm volatile("" :: "v"(dep)); }
+        if(fused_ts != NULL && lane == 0) atomicMax(&fused_ts[5], (unsigned long long)wall_clock64());
+#endif
+        double* __restrict__ stage = lds_stage;                  // [64][17] doubles (odd stride: the column reads spread over the banks)
+#pragma unroll
+        for(int c = 0; c < JOINT_STRIDE/16; c++)
+        {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for(int i = 0; i < 16; i++)
+            {
+                const int e = 16*c + i;
+                double v = 0.0;                                 // (e is a constant once the loops are unrolled)
+                if(e < JOINT_REC) v = rec[e]; else if(e < JOINT_INTR + 18) v = xtra[e - JOINT_INTR];
+                if(lane < OBS_PER_WG) stage[lane*17 + i] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for(int k = 0; k < OBS_PER_WG/8; k++)
+            {
+                const int r = 8*k + (lane >> 3), piece = lane & 7;
+                const double a = stage[r*17 + 2*piece], bb = stage[r*17 + 2*piece + 1];
+                if(wave_obs0 + r < P.Nobs_board)
+                    store_sc1_b128(joint + (size_t)(wave_obs0 + r)*JOINT_STRIDE + 16*c + 2*piece, a, bb);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if(iobs_raw < P.Nobs_board)
+            __hip_atomic_store(&ready[iobs_raw], FUSED_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)out;
+    }
+    else
+        for(int i=0;i<JOINT_REC;i++) out[i] = rec[i];
     // splined models: the observation's box of control points starts empty (board_splined_kernel fills it)
-    if(O.spl_box != NULL) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
+    if(O.spl_box != NULL && iobs_raw < P.Nobs_board) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 template<bool CHOOSE>
 __global__ __launch_bounds__(PRO_T)
@@ -649,15 +750,23 @@ void copy_out_invariants(int lane, int& A0, int& A1, int& B0, int& B1, unsigned&
 // extrinsics columns (absent from its rows) are computed regardless in this
 // variant: they are never copied out, and the Gram entries they produce sit at
 // positions that the assembly has no destination for
-template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
-void board_kernel(DeviceProblem P,
-                  OpRef R,
-                  const double* __restrict__ joint,
-                  double*       __restrict__ gram)
+// FUSED (round 5): the wave belongs to the launch that also makes its pose record (board_fused_kernel below): it asks
+// for its pixels, then waits for the record's flag (ready[iobs]; the hand-off's rules: board_prologue_body), takes
+// the record, its camera's intrinsics and the warp from the record with sc1 loads instead of from what a launch
+// before this one left, and whether the trial evaluates anything from the flag instead of from R.skip.
+// ts (FUSED, may be NULL): [0] <- min over a sample of the waves of the time of the first Jacobian store, [1] <- max
+// of the time a sampled wave ends (wall_clock64: 100 MHz): what the launch's Jacobian stream took without the wait
+// for the poses. err (FUSED): set to 2 by a wave that gave up waiting (cannot happen with workgroups dispatched in
+// index order; a bound on the wait is what keeps a surprise from hanging the GPU)
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT, bool FUSED>
+__device__ __forceinline__
+void board_observation(const DeviceProblem& P,
+                       const OpRef& R,
+                       const double* __restrict__ joint,
+                       double*       __restrict__ gram,
+                       const int iobs, double* __restrict__ lds,
+                       unsigned* __restrict__ ready, int* __restrict__ err, unsigned long long* __restrict__ ts)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-
     constexpr int EXT0   = 4 + NDIST;
     constexpr int FRAME0 = EXT0 + 6;
     constexpr int WARP0  = FRAME0 + 6;
@@ -669,7 +778,6 @@ void board_kernel(DeviceProblem P,
     constexpr int NM     = gram_nmfma_blk(NBLK); // accumulators (problem.hpp)
     static_assert(NBLK <= 8, "the Gram scheme covers 32 tile columns");
 
-    const int iobs = blockIdx.x;
     const int lane = threadIdx.x;
 #ifdef BOARD_TS
     long long ts[8] = {0,0,0,0,0,0,0,0};
@@ -687,8 +795,12 @@ void board_kernel(DeviceProblem P,
     const double* __restrict__ pool      = P.board_pool + (size_t)iobs*NPTS*3;
     const double* __restrict__ jp_global = joint + (size_t)iobs*JOINT_STRIDE;
     const int n3 = 3*NPTS, last = n3 - 1;
-    const double j0 = jp_global[lane];
-    const double j1 = jp_global[(lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1];
+    double j0 = 0.0, j1 = 0.0;
+    if constexpr(!FUSED)
+    {
+        j0 = jp_global[lane];
+        j1 = jp_global[(lane < JOINT_REC - 64) ? 64 + lane : JOINT_REC - 1];
+    }
     // the first 512 values (boards of up to 170 corners: all of them) in
     // straight-line code: 8 loads in flight
     double v_obs[8];
@@ -700,7 +812,27 @@ void board_kernel(DeviceProblem P,
             v_obs[j] = pool[idx < last ? idx : last];
         }
 
-    if(opref_skip(R)) return;
+    if constexpr(FUSED)
+    {
+        // the record of this observation: made by a lane of this launch's first workgroups. One word, polled
+        // with agent-scope loads (the pixel loads above are in flight meanwhile)
+        unsigned f = 0;
+        // (measured: keeping the first generation's waves quiet for the first 10 us, or the pose waves at a higher
+        //  priority, changes nothing - the polls are not in the pose lanes' way)
+        for(int spins = 0; spins < (1 << 19); spins++)
+        {
+            f = __hip_atomic_load(&ready[iobs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if(f != 0) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        f = __builtin_amdgcn_readfirstlane(f);
+        if(f != 0 && lane == 0) __hip_atomic_store(&ready[iobs], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(f == 0 && lane == 0) *err = 2;
+        if(f != FUSED_READY) return;
+        j0 = load_sc1_f64(jp_global + lane);
+        j1 = load_sc1_f64(jp_global + ((lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1));
+    }
+    else if(opref_skip(R)) return;
     // the output pointers come out of a table in memory: say that they are
     // global, or every store becomes a FLAT store (which also counts against the
     // LDS counter and stalls the LDS waits)
@@ -720,12 +852,24 @@ void board_kernel(DeviceProblem P,
     double* __restrict__ jp      = obs_lds + ((3*NPTS + 63) & ~63);
 
     // intrinsics of this camera and the board warp, unpacked by the prologue kernel
-    const double* __restrict__ ip = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
     double intr[4 + NDIST];
+    double warp0, warp1;
+    if constexpr(FUSED)
+    {
+        // (from the record: lane l of j1 holds entry 64 + l. Wave-uniform values, back into scalar registers)
 #pragma unroll
-    for(int i=0;i<4+NDIST;i++) intr[i] = ip[i];
-    const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
-    const double warp0 = wp[0], warp1 = wp[1];
+        for(int i=0;i<4+NDIST;i++) intr[i] = readlane_f64(j1, JOINT_INTR - 64 + i);
+        warp0 = readlane_f64(j1, JOINT_INTR - 64 + 16);
+        warp1 = readlane_f64(j1, JOINT_INTR - 64 + 17);
+    }
+    else
+    {
+        const double* __restrict__ ip = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
+#pragma unroll
+        for(int i=0;i<4+NDIST;i++) intr[i] = ip[i];
+        const double* __restrict__ wp = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
+        warp0 = wp[0]; warp1 = wp[1];
+    }
 
     // wave-uniform reciprocals, once per observation: an FP64 division is ~12
     // instructions, and the pass loop had four of these per corner
@@ -792,7 +936,7 @@ void board_kernel(DeviceProblem P,
         if(64*j < n3)
             obs_lds[64*j + lane] = v_obs[j];
     jp[lane] = j0;
-    if(lane < JOINT_STRIDE - 64) jp[64 + lane] = j1;
+    if(lane < JOINT_REC - 64) jp[64 + lane] = j1;
     for(int base = 512; base < n3; base += 64)
     {
         const int idx = base + lane;
@@ -1000,6 +1144,8 @@ void board_kernel(DeviceProblem P,
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
             gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
+            if constexpr(FUSED)
+                if(ts != NULL && (iobs & 63) == 0 && pt0 == 0 && h == 0 && lane == 0) atomicMin(&ts[0], (unsigned long long)wall_clock64());
             if(ALLOPT || (WITH_GRAM && co_fast && !ABLATE(P, 3)))
             {
                 // all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
@@ -1085,6 +1231,8 @@ void board_kernel(DeviceProblem P,
         for(int mm=0;mm<NM;mm++)
             g[mm*64 + lane] = acc[mm];
     }
+    if constexpr(FUSED)
+        if(ts != NULL && (iobs & 63) == 0 && lane == 0) atomicMax(&ts[1], (unsigned long long)wall_clock64());
 #ifdef BOARD_TS
     TS(6);
     if(P.debug_ts != NULL && lane == 0)
@@ -1096,6 +1244,62 @@ void board_kernel(DeviceProblem P,
         o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4]; o[5] = ts[5]; o[6] = ts[6]; o[7] = hwid;
     }
 #endif
+}
+
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+void board_kernel(DeviceProblem P,
+                  OpRef R,
+                  const double* __restrict__ joint,
+                  double*       __restrict__ gram)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    board_observation<PROJ,NDIST,WITH_J,WITH_GRAM,ALLOPT,false>(P, R, joint, gram, blockIdx.x, lds, NULL, NULL, NULL);
+}
+
+// ONE launch for the choice of the trial point, the prologue of its evaluation AND the board kernel (round 5): the
+// first npro workgroups are board_prologue_kernel<true>'s, in its order (the pose lanes first); the others are
+// board_kernel<PROJ,NDIST,true,true,true>'s, one wave per observation, which stage their pixels while the poses are
+// being made and start on their rows the moment their record's flag goes up - instead of after a launch boundary
+// and a cold start. Workgroups are dispatched in index order, so every prologue workgroup has its place on the chip
+// before the first board wave takes one: nothing the waves wait for can be queued behind them.
+// For the trial steps of problems whose variable groups are all optimized (ALLOPT), OPENCV-type models
+static_assert(PRO_T == 64, "board_fused_kernel runs both roles in workgroups of one wave");
+template<int PROJ, int NDIST>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+void board_fused_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode,
+                        int nblocks_reg, ChooseArgs ca, int npro, unsigned* __restrict__ ready, unsigned long long* __restrict__ ts)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if((int)blockIdx.x >= npro)
+    {
+        board_observation<PROJ,NDIST,true,true,true,true>(P, B.R, B.joint, B.gram, (int)blockIdx.x - npro, lds, ready, &ca.ctl->error, ts);
+        return;
+    }
+    if(ts != NULL && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(&ts[2], (unsigned long long)wall_clock64());
+    const ChooseOut c = dogleg_choose_scalars(ca, lds /* [17*7] */);
+    const int nblocks_obs = (P.Nobs_board + FUSED_OBS - 1)/FUSED_OBS;
+    const int first = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg;
+#ifdef FUSED_TS
+    if(ts != NULL && (int)blockIdx.x < nblocks_obs && threadIdx.x == 0) atomicMax(&ts[4], (unsigned long long)wall_clock64());
+#endif
+    if((int)blockIdx.x >= first)
+    {
+        dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*PRO_T + threadIdx.x);
+        if((int)blockIdx.x == first && threadIdx.x == 0) dogleg_choose_record(ca, c);
+        return;
+    }
+    if(c.skip_eval)
+    {
+        // nothing is evaluated: the board waves hear it from the pose workgroups
+        const int iobs = blockIdx.x*FUSED_OBS + threadIdx.x;
+        if((int)blockIdx.x < nblocks_obs && (int)threadIdx.x < FUSED_OBS && iobs < P.Nobs_board)
+            __hip_atomic_store(&ready[iobs], FUSED_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    board_prologue_body<TrialState, true>(P, B, dogleg_trial_state(ca, c), ca.ops[c.ia], nblocks_unpack, nblocks_zero, reg_mode, ready, lds, ts);
+    // (stamps: [2] the launch's first workgroup starts, [3] the last pose workgroup is through)
+    if(ts != NULL && (int)blockIdx.x < nblocks_obs && threadIdx.x == 0) atomicMax(&ts[3], (unsigned long long)wall_clock64());
 }
 
 // CSR structure of the board rows: rowptr and colidx. Same tiling as above,
@@ -2298,6 +2502,31 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
                           int lds_bytes, hipStream_t stream,
                           hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
+    // (the ablation probes keep the general kernel)
+    constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
+    const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
+                        P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
+    // the choice, the prologue and the board kernel in ONE launch (board_fused_kernel): a trial step of the solver
+    // (B.choose) on a problem of the kind board_launch_fuses_prologue() names
+    constexpr bool fusable = (PROJ == PROJ_OPENCV) && (NDIST == 0 || NDIST == 4 || NDIST == 8);
+    if constexpr(fusable)
+        if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE) && (parts & EVAL_PART_BOARD) && B.choose != NULL &&
+           with_jacobian && B.gram != NULL && B.fused_ready != NULL && allopt && board_launch_fuses_prologue(P))
+        {
+            const int nblocks_obs    = (P.Nobs_board + FUSED_OBS - 1)/FUSED_OBS;
+            const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
+            const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
+            const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
+            const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
+            const int nblocks_choose = (B.choose->nd.Nstate + PRO_T - 1)/PRO_T;
+            const int npro           = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg + nblocks_choose;
+            if(ev_j0) hipEventRecord(ev_j0, stream);
+            hipLaunchKernelGGL((board_fused_kernel<PROJ,NDIST>), dim3(npro + P.Nobs_board), dim3(64), lds_bytes, stream,
+                               P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? 1 : -1, nblocks_reg, *B.choose, npro,
+                               B.fused_ready, B.fused_ts);
+            if(ev_j1) hipEventRecord(ev_j1, stream);
+            parts &= ~(EVAL_PART_PROLOGUE | EVAL_PART_BOARD);
+        }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
         const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
@@ -2310,10 +2539,6 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     if(P.Nobs_board > 0 && (parts & EVAL_PART_BOARD))
     {
         if(ev_j0) hipEventRecord(ev_j0, stream);
-        // (the ablation probes keep the general kernel)
-        constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
-        const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
-                            P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
         if(with_jacobian && B.gram != NULL && allopt)
         {
             if constexpr (kfull_even)
@@ -2355,6 +2580,30 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     }
 }
 
+// Problems whose trial steps take the one launch for choice + prologue + board kernel: boards under an OPENCV-type
+// model (pinhole, OPENCV4, OPENCV8) with every variable group optimized - what the board kernel's ALLOPT variant serves.
+// OPT-IN: MRCAL_AMD_FUSED_PROLOGUE=1. Built in round 5 because the review asked for it, measured, and not the default: at
+// the metric's size the one launch is 4-6 us a step SLOWER than prologue + board kernel as two (184.8 against 181.0 us;
+// profiles/r05_fused_prologue.txt). Its Jacobian stream is shorter (67 us from the first store against the board
+// kernel's 72.5 alone: the waves' pixels are staged when the poses arrive), but the poses are through 23-25 us after
+// the launch's start instead of 17.6 as a launch of their own: every pose lane's record has to reach memory
+// (write-through) before its flag may go up, 6.5 us under the launch's own traffic, and the flag and the record then
+// travel back, 2 more
+bool board_launch_fuses_prologue(const DeviceProblem& P)
+{
+    static const bool wanted = (getenv("MRCAL_AMD_FUSED_PROLOGUE") != NULL);
+    if(!wanted || P.Nobs_board <= 0 || ABLATE(P, ~0)) return false;
+    int ndist;
+    switch(P.lens_type)
+    {
+    case MRCAL_LENSMODEL_PINHOLE: ndist = 0; break;
+    case MRCAL_LENSMODEL_OPENCV4: ndist = 4; break;
+    case MRCAL_LENSMODEL_OPENCV8: ndist = 8; break;
+    default: return false;
+    }
+    return P.Ncore_state && (ndist == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
+           P.do_optimize_frames && P.has_warp_state && P.has_warp_seed;
+}
 bool prologue_takes_choose(const DeviceProblem& P)
 {
     // (every evaluation of a problem with boards starts with the prologue launch, the splined models' too)

@@ -69,7 +69,14 @@ struct EvalBuffers
     // the prologue launch choose the trial point it evaluates (board_prologue_kernel<true>); R then only names the
     // operating point for the kernels AFTER the prologue
     const ChooseArgs* choose;
+    // the hand-off flags of the launch that carries prologue AND board kernel (board_fused_kernel; NULL: that launch is
+    // not used), [Nobs_board], zero at rest; and, if that launch is being timed, where it leaves the wall-clock stamps
+    // of its Jacobian stream ([2]: first store, end)
+    unsigned*           fused_ready;
+    unsigned long long* fused_ts;
 };
+// does an evaluation with parts PROLOGUE | BOARD (and B.choose, B.gram, B.fused_ready given) go as ONE launch?
+bool board_launch_fuses_prologue(const DeviceProblem& P);
 // can the evaluation's prologue launch carry the choice of the trial point (EvalBuffers::choose)?
 bool prologue_takes_choose(const DeviceProblem& P);
 

@@ -56,6 +56,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_point_meta); hipFree(d_point_pool); hipFree(d_imagersizes);
     hipFree(d_tri_meta); hipFree(d_tri_px); hipFree(d_tri_outlier);
     hipFree(d_joint); hipFree(d_gram); hipFree(d_Jp); hipFree(d_Ji);
+    hipFree(d_fused_ready); hipFree(d_fused_ts);
     for(int i=0;i<2;i++)
     {
         hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv); hipFree(op[i].spl_box);
@@ -85,6 +86,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     if(ev_j1)  hipEventDestroy(ev_j1);
     if(ev_fork) hipEventDestroy(ev_fork);
     if(ev_join) hipEventDestroy(ev_join);
+    if(ev_fork0) hipEventDestroy(ev_fork0);
     if(side_stream) hipStreamDestroy(side_stream);
     if(stream) hipStreamDestroy(stream);
 }
@@ -269,6 +271,11 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         return false;
     }
     ok = ok && dev_alloc(&P->d_gram,   (L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) ? (size_t)1 : (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
+    if(ok && P->D.Nobs_board > 0 && board_launch_fuses_prologue(P->D))
+    {
+        ok = ok && dev_alloc(&P->d_fused_ready, (size_t)P->D.Nobs_board);
+        if(ok) HIP_TRY(hipMemset(P->d_fused_ready, 0, (size_t)P->D.Nobs_board*sizeof(unsigned)), ok = false);
+    }
     for(int i=0;i<2 && ok;i++)
     {
         ok = ok && dev_alloc(&P->op[i].A,       (size_t)nd.Nc*nd.Nc);
@@ -637,6 +644,8 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
         {
             if((P->ev_pool_seen++ % P->ev_pool_stride) == 0 && P->ev_pool_used + 2 <= (int)P->ev_pool.size())
             {
+                if(P->d_fused_ts != NULL && P->ev_pool_used/2 < P->fused_ts_capacity)
+                    B.fused_ts = P->d_fused_ts + 8*(size_t)(P->ev_pool_used/2);
                 e0 = P->ev_pool[P->ev_pool_used++];
                 e1 = P->ev_pool[P->ev_pool_used++];
             }
@@ -923,7 +932,7 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     // weights (the splined models' kernels use none)
     const bool splined = (lensmodel->type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC);
     // the tile + the staged observation (in whole 64-element chunks) + the joint pose record
-    P->lds_bytes = splined ? 0 : (64*tile_stride(L.Ndist) + ((3*NPTS + 63) & ~63) + JOINT_STRIDE + 4) * (int)sizeof(double);
+    P->lds_bytes = splined ? 0 : (64*tile_stride(L.Ndist) + ((3*NPTS + 63) & ~63) + JOINT_REC + 4) * (int)sizeof(double);
     if(P->lds_bytes > 160*1024)
     {
         set_error("the board has %d corners and the lens model %d distortion parameters: the LDS tile would not fit", NPTS, L.Ndist);
@@ -952,6 +961,7 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     HIP_TRY(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking), ok = false);
     HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), ok = false);
     HIP_TRY(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), ok = false);
+    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork0, hipEventDisableTiming), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j0), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j1), ok = false);
 
@@ -1227,6 +1237,21 @@ bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* p, int
     p->ev_pool_seen = 0;
     p->ev_pool_stride = stride > 0 ? stride : 1;
     p->ev_pool_enabled = capacity > 0;
+    p->fused_stream_ms_total = 0.0; p->fused_stream_n = 0;
+    if(capacity > 0 && p->d_fused_ready != NULL)
+    {
+        if(p->fused_ts_capacity < capacity)
+        {
+            hipFree(p->d_fused_ts); p->d_fused_ts = NULL; p->fused_ts_capacity = 0;
+            HIP_TRY(hipMalloc((void**)&p->d_fused_ts, (size_t)8*capacity*sizeof(unsigned long long)), return false);
+            p->fused_ts_capacity = capacity;
+        }
+        // [first store: min over the sampled waves | end: max]
+        // [first Jacobian store: min over the sampled waves | end: max | the launch's first workgroup starts: min | the pose workgroups are through: max]
+        std::vector<unsigned long long> init((size_t)8*p->fused_ts_capacity, 0ull);     // ([4..7]: -DFUSED_TS builds)
+        for(int i = 0; i < p->fused_ts_capacity; i++) { init[8*i] = ~0ull; init[8*i+2] = ~0ull; }
+        HIP_TRY(hipMemcpy(p->d_fused_ts, init.data(), init.size()*sizeof(unsigned long long), hipMemcpyHostToDevice), return false);
+    }
     while((int)p->ev_pool.size() < 2*capacity)
     {
         hipEvent_t e;
@@ -1248,6 +1273,25 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
         HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i+1]), return false);
         n++; tot += ms; if(ms < mn) mn = ms; if(ms > mx) mx = ms;
     }
+    p->fused_stream_ms_total = 0.0; p->fused_stream_n = 0;
+    if(p->d_fused_ts != NULL && n > 0)
+    {
+        std::vector<unsigned long long> ts((size_t)8*std::min(n, p->fused_ts_capacity));
+        HIP_TRY(hipMemcpy(ts.data(), p->d_fused_ts, ts.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost), return false);
+        p->fused_pose_ms_total = 0.0; p->fused_first_store_ms_total = 0.0;
+        for(size_t i = 0; i + 7 < ts.size(); i += 8)
+            if(ts[i] != ~0ull && ts[i+1] > ts[i])
+            {
+                if(getenv("MRCAL_AMD_FUSED_TS_PRINT") != NULL && ts[i+2] != ~0ull)
+                    fprintf(stderr, "fused launch, us after its first workgroup starts: choose through %.2f | pose records computed %.2f | stored %.2f | first J store %.2f | end %.2f\n",
+                            ts[i+4] ? (double)(ts[i+4] - ts[i+2])*1e-2 : -1., ts[i+5] ? (double)(ts[i+5] - ts[i+2])*1e-2 : -1., (double)(ts[i+3] - ts[i+2])*1e-2,
+                            (double)(ts[i] - ts[i+2])*1e-2, (double)(ts[i+1] - ts[i+2])*1e-2);
+                p->fused_stream_ms_total += (double)(ts[i+1] - ts[i])*1e-5;        // 100 MHz ticks -> ms
+                if(ts[i+2] != ~0ull && ts[i+3] > ts[i+2]) p->fused_pose_ms_total += (double)(ts[i+3] - ts[i+2])*1e-5;
+                if(ts[i+2] != ~0ull && ts[i] > ts[i+2])   p->fused_first_store_ms_total += (double)(ts[i] - ts[i+2])*1e-5;
+                p->fused_stream_n++;
+            }
+    }
     p->ev_pool_enabled = false;
     p->ev_pool_used = 0;
     if(Nlaunches) *Nlaunches = n;
@@ -1256,6 +1300,23 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
     if(max_ms)    *max_ms    = mx;
     return true;
 }
+
+// The launch that carries prologue and board kernel (board_fused_kernel): of the launches the last
+// jacobian_timing_begin()/_end() pair timed, how many left stamps and the sum of (end - first Jacobian store) in ms:
+// the Jacobian stream without the wait for the poses in front of it. 0 launches: the step does not use that launch
+void mrcal_amd_problem_jacobian_stream_timing(mrcal_amd_problem_t* p, int* Nlaunches, double* total_ms)
+{
+    if(Nlaunches) *Nlaunches = p->fused_stream_n;
+    if(total_ms)  *total_ms  = p->fused_stream_ms_total;
+}
+// dev: of the same launches, the sums of (the pose workgroups are through - the launch's first workgroup starts) and
+// (first Jacobian store - the launch's first workgroup starts), ms
+void mrcal_amd_problem_jacobian_stream_timing_detail(mrcal_amd_problem_t* p, double* pose_ms, double* first_store_ms)
+{
+    if(pose_ms)        *pose_ms        = p->fused_pose_ms_total;
+    if(first_store_ms) *first_store_ms = p->fused_first_store_ms_total;
+}
+int mrcal_amd_problem_fuses_prologue(mrcal_amd_problem_t* p) { return p->d_fused_ready != NULL ? 1 : 0; }
 
 // dev tool: average duration (ms) of nrep back-to-back launches of the
 // evaluation kernels alone, with the given debug_ablate bits

@@ -43,7 +43,7 @@ struct mrcal_amd_problem
     // a second stream for work of a step that nothing on the first one waits for at once (the gather of the
     // splined assembly runs beside the block elimination and the SYRK): fork / join events
     hipStream_t side_stream = NULL;
-    hipEvent_t  ev_fork = NULL, ev_join = NULL;
+    hipEvent_t  ev_fork = NULL, ev_join = NULL, ev_fork0 = NULL;
     bool        have_jacobian_timing = false;
     bool        capturing = false;      // a hipGraph capture is in progress on the stream
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region
@@ -51,6 +51,13 @@ struct mrcal_amd_problem
     int         ev_pool_used = 0;
     int         ev_pool_seen = 0, ev_pool_stride = 1;      // launches since _begin(); every stride-th one is timed
     bool        ev_pool_enabled = false;
+    // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
+    // ([launch][2]: the first Jacobian store, the end, wall_clock64 ticks of 10 ns), and what _timing_end() made of them
+    unsigned*           d_fused_ready = NULL;
+    unsigned long long* d_fused_ts    = NULL;
+    int                 fused_ts_capacity = 0;
+    double              fused_stream_ms_total = 0.0, fused_pose_ms_total = 0.0, fused_first_store_ms_total = 0.0;
+    int                 fused_stream_n = 0;
 
     // inputs
     double* d_seed_intrinsics   = NULL;
@@ -118,6 +125,7 @@ struct mrcal_amd_problem
         for(int i=0;i<5;i++) B.zero_n[i] = 0;
         B.zero_total = 0;
         B.choose = NULL;
+        B.fused_ready = d_fused_ready; B.fused_ts = NULL;
         return B;
     }
     mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const { return eval_buffers(opref(i), with_gram); }

@@ -111,7 +111,7 @@ Step2Args step2_args(mrcal_amd_problem* P)
     a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
     a.comm2 = (P->comm != NULL || P->sharded_external) ? P->d_comm : NULL;
     a.snap  = P->capturing ? NULL : P->snap_target;
-    a.side = P->side_stream; a.ev_fork = P->ev_fork; a.ev_join = P->ev_join;
+    a.side = P->side_stream; a.ev_fork = P->ev_fork; a.ev_join = P->ev_join; a.ev_fork0 = P->ev_fork0;
     return a;
 }
 
@@ -141,6 +141,12 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
     return true;
 }
 
+// does a trial step of this problem take ONE launch for the choice, the prologue and the board kernel?
+static bool step_is_fused(const mrcal_amd_problem* P)
+{
+    return P->d_fused_ready != NULL && prologue_takes_choose(P->D) && board_launch_fuses_prologue(P->D);
+}
+
 // One trial step of the dog-leg, entirely queued: every decision is taken on
 // the device (solver_kernels.hip, "the fused step"). segment: 0 = all of it;
 // 1 = up to the board kernel, 2 = the board kernel alone, 3 = after it
@@ -149,7 +155,18 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     SolverCtl* ctl = P->d_ctl;
     const Step2Args a = step2_args(P);
     const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
-    if(segment == 0 || segment == 1)
+    // (round 5) where the problem allows it the choice, the prologue and the board kernel are ONE launch
+    // (kernels.hip board_fused_kernel): it is "the board kernel" of segment 2, and segment 1 is empty
+    const bool fused = step_is_fused(P);
+    if(fused)
+    {
+        if(segment == 0 || segment == 2)
+        {
+            const ChooseArgs ca = step2_choose_args(a);
+            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD, NULL, &ca)) return false;
+        }
+    }
+    else if(segment == 0 || segment == 1)
     {
         // the step from the current point (its Gauss-Newton step was computed when the
         // point was accepted); then the joint poses of the trial point
@@ -165,7 +182,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
             if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
         }
     }
-    if(segment == 0 || segment == 2)
+    if(!fused && (segment == 0 || segment == 2))
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_BOARD)) return false;
     if(segment == 0 || segment == 3)
     {
@@ -217,9 +234,11 @@ bool queue_trial_step(mrcal_amd_problem* P)
         HIP_TRY(hipGraphLaunch(P->step_graph[0], P->stream), return false);
         return true;
     }
-    if(P->step_graph[1] == NULL && !capture_segment(P, 1, &P->step_graph[1])) return false;
+    // (segment 1 is empty where the choice and the prologue ride in the board kernel's launch)
+    const bool seg1 = !step_is_fused(P);
+    if(seg1 && P->step_graph[1] == NULL && !capture_segment(P, 1, &P->step_graph[1])) return false;
     if(P->step_graph[2] == NULL && !capture_segment(P, 3, &P->step_graph[2])) return false;
-    HIP_TRY(hipGraphLaunch(P->step_graph[1], P->stream), return false);
+    if(seg1) HIP_TRY(hipGraphLaunch(P->step_graph[1], P->stream), return false);
     if(!enqueue_trial_step(P, 2)) return false;
     HIP_TRY(hipGraphLaunch(P->step_graph[2], P->stream), return false);
     return true;
@@ -319,7 +338,8 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     if(!read_ctl(P, &c)) return false;
     if(c.error)
     {
-        set_error("could not make JtJ positive definite");
+        set_error(c.error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record"
+                               : "could not make JtJ positive definite");
         return false;
     }
     if(!c.done)
@@ -627,7 +647,7 @@ int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trus
         if(!queue_trial_step(P)) return -1;
     SolverCtl c;
     if(!read_ctl(P, &c)) return -1;
-    if(c.error) { set_error("could not make JtJ positive definite"); return -1; }
+    if(c.error) { set_error(c.error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record" : "could not make JtJ positive definite"); return -1; }
     absorb_ctl(P, c);
     P->stats.Nevaluations    = c.Nevaluations;
     P->stats.Nfactorizations = c.Nfactorizations;

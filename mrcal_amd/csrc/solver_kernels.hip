@@ -4375,7 +4375,7 @@ static hipError_t launch_gen_finalize(const NormalDims& nd, const AssemblyPlan& 
 //   assemble_finalize (here: its own launch; in the fused step it rides along in the SYRK launch)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream,
-                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool* forked)
+                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool* forked, hipEvent_t ev_fork0)
 {
     if(forked) *forked = false;
     // splined models: no per-observation Gram; every row goes through the generic path
@@ -4424,10 +4424,10 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // (not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
             //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
             //  plain read-modify-writes must not run beside those)
-            if(use_side && nrp_early > 0 && !pairs_late && !spl_fallback_possible(P))
+            if(use_side && ev_fork0 != NULL && nrp_early > 0 && !pairs_late && !spl_fallback_possible(P))
             {
-                hipError_t e = hipEventRecord(ev_fork, stream);           if(e != hipSuccess) return e;
-                e = hipStreamWaitEvent(side, ev_fork, 0);                 if(e != hipSuccess) return e;
+                hipError_t e = hipEventRecord(ev_fork0, stream);          if(e != hipSuccess) return e;
+                e = hipStreamWaitEvent(side, ev_fork0, 0);                if(e != hipSuccess) return e;
                 hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp_early), dim3(256), 0, side, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
                 pairs_early = true;
             }
@@ -4791,7 +4791,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
         EvalBuffers B; memset(&B, 0, sizeof(B));
         B.R = OpRef{ a.ops, sel_eval, &fl->skip_asm }; B.Jp = (int32_t*)a.Jp; B.Ji = (int32_t*)a.Ji;
         bool forked = false;
-        const hipError_t e = launch_assemble(P, nd, br, *a.plan, B, stream, a.side, a.ev_fork, a.ev_join, &forked);
+        const hipError_t e = launch_assemble(P, nd, br, *a.plan, B, stream, a.side, a.ev_fork, a.ev_join, &forked, a.ev_fork0);
         if(e != hipSuccess) return e;
         step2_side_pending = forked;
     }

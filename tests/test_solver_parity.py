@@ -262,6 +262,22 @@ def test_optimize_matches_checker(amd, ref_api, lensmodel, Ncam, Nf, btol):
     assert sa["Noutliers_board"] == sr["Noutliers_board"]
     # same outliers marked in the caller's array
     assert np.array_equal(oa["observations_board"][...,2] < 0, orr["observations_board"][...,2] < 0)
+    if lensmodel == "LENSMODEL_CAHVOR":
+        # The valley again, seen from the other side (round 5): the two solvers are the same algorithm in different
+        # arithmetic, and in CAHVOR's valley a difference in the last bit of a residual decides whether the
+        # 1e-7-step termination test fires at a given trial. Until round 5 both stopped at the SAME premature point
+        # (|Jt x|/(|J||x|) = 1.3e-3, rms 1.4868517); since the board kernel was recompiled for the one-launch trial
+        # step (other contractions of multiply-adds, other last bits) the product walks on to the stationary point
+        # (4e-11, rms 1.4868245, 1.2 packed units along the valley) where scipy finds nothing more to gain, while
+        # from the checker's end it still finds 3.6e-5 (tools/exp/dbg_cahvor.py). So here the arbiter decides
+        # (tests/arbiter.py): wherever the checker is NOT at a stationary point the product must be no worse
+        st_a, cost_a, gain_a = _solve_report(ref_api, "product", oa, sa)
+        st_r, cost_r, gain_r = _solve_report(ref_api, "checker", orr, sr)
+        if st_r >= 1e-6:
+            assert cost_a <= cost_r*(1. + 1e-6), (cost_a, cost_r)
+            assert st_a <= st_r and gain_a <= max(gain_r, 1e-9), (st_a, st_r, gain_a, gain_r)
+            assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < 1e-4*sr["rms_reproj_error__pixels"]
+            return
     assert abs(sa["rms_reproj_error__pixels"] - sr["rms_reproj_error__pixels"]) < \
         1e-6*sr["rms_reproj_error__pixels"]
     # the optimum. Both stop when a step is shorter than 1e-7 (packed units)
@@ -415,3 +431,45 @@ def test_optimize_splined_reduced_configuration_2(amd, ref_api):
                                      seed=4, do_optimize_intrinsics_core=False)
     assert amd.num_states(**oi) == 2*30*20 + 6*200 + 2
     _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=1e-3)
+
+
+def test_one_launch_trial_step_opt_in(amd):
+    """The opt-in form of the trial step (MRCAL_AMD_FUSED_PROLOGUE=1: the choice of the trial point, the joint poses and
+    the board Jacobian kernel in ONE launch, the pose records handed to the board waves inside it through write-through
+    stores and per-observation flags; profiles/r05_fused_prologue.txt for why it is not the default) must solve what
+    the two-launch form solves: same outliers, the same optimum. In a process of its own (the switch is read when
+    the library first asks)"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import mrcal_amd
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
+from mrcal_amd.resident import Problem
+out = {}
+for nc, nf, lm in ((3, 12, "LENSMODEL_OPENCV8"), (2, 9, "LENSMODEL_OPENCV4"), (2, 7, "LENSMODEL_PINHOLE"), (8, 300, "LENSMODEL_OPENCV8")):
+    oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=nc, Nframes=nf, lensmodel=lm, seed=5)
+    runs = []
+    for k in range(2):
+        with Problem(**copy_inputs(oi)) as p:
+            s = p.solve()
+            fused = p.fuses_prologue()            # (known once the solver's buffers exist)
+            runs.append((s["Niterations"], s["Noutliers_board"], s["rms_reproj_error__pixels"], s["norm2_x"], p.b_packed().tolist()))
+    assert runs[0] == runs[1], "not the same bits twice"
+    out["%%dx%%d %%s" %% (nc, nf, lm)] = dict(fused=bool(fused), Noutliers=runs[0][1], rms=runs[0][2], b=runs[0][4])
+print("RESULT " + json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for tag, env in (("two", {}), ("one", {"MRCAL_AMD_FUSED_PROLOGUE": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for k in res["two"]:
+        a, b = res["one"][k], res["two"][k]
+        assert b["fused"] is False and a["fused"] is True, (k, a["fused"], b["fused"])
+        # (the two forms agree to ~1e-13 in x and J - differently compiled kernels - which is enough to put ONE corner of
+        #  240 000 on the other side of the outlier threshold: 2367 against 2368 at 8 x 300)
+        assert abs(a["Noutliers"] - b["Noutliers"]) <= 2, (k, a["Noutliers"], b["Noutliers"])
+        same = a["Noutliers"] == b["Noutliers"]
+        assert abs(a["rms"] - b["rms"]) < (1e-7 if same else 1e-4)*b["rms"], (k, a["rms"], b["rms"])
+        assert np.abs(np.array(a["b"]) - np.array(b["b"])).max() < (2e-5 if same else 1e-3), k
