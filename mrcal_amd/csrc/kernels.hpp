@@ -27,6 +27,11 @@ struct OpDev
     // (min ix, max ix, min iy, max iy). Reset by the prologue launch, filled by board_splined_kernel<true>
     // (integer atomicMin/Max: any order, the same result), read by assemble_splined_kernel. NULL: another model
     int*    spl_box;
+    // splined models (round 5): the camera block with the control points no board covers at this point put last -
+    // [Nc] position -> camera-block variable | [Nc] variable -> position | [1] how many come first (the coupled ones).
+    // Made by spl_compact_kernel from spl_box after an evaluation; read by the reduction of a trial step, which leaves
+    // the Cholesky the coupled part alone (solver_kernels.hip, LcholCompact). NULL: not tracked
+    int*    cperm;
 };
 
 // Which operating point a kernel works on. The index is either known to the

@@ -76,6 +76,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(G.eb_block); hipFree(G.eb_begin); hipFree(G.eb_rows); hipFree(G.eb_group); hipFree(G.eb_epos);
     }
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
+    hipFree(cperm_cur_alloc); hipFree(F.iso); hipFree(op[0].cperm); hipFree(op[1].cperm);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -293,6 +294,31 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     {
         ok = ok && dev_alloc(&P->F.occ, (size_t)(nd.NEb > 0 ? nd.NEb : 1)*occ_words(nd));
         ok = ok && dev_alloc(&P->F.Wtile, (size_t)((nd.Nc + 15)/16)*16*(size_t)(nd.NE > 0 ? nd.NE : 1));
+    }
+    // The splined models' camera block without the control points no board covers (round 5; solver_kernels.hip,
+    // spl_compact_kernel / LcholCompact): where the big camera block's launch-per-panel Cholesky runs, every row that
+    // touches a control point is a board's (no discrete points: they have no boxes) and all rows are here (not a shard:
+    // the ranks of a sharded solve sum their camera blocks entry by entry). MRCAL_AMD_NO_SPL_COMPACT=1: off
+    {
+        static const bool off = (getenv("MRCAL_AMD_NO_SPL_COMPACT") != NULL);
+        const bool whole = (int)P->board_sel.size() == L.dims.Nobservations_board && P->comm == NULL;
+        if(!off && whole && L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && cholesky_large_workspace_doubles(nd.Nc) > 1 && nd.Nc <= 4096 &&
+           P->D.Nobs_board > 0 && P->D.Nobs_point == 0 && P->D.Ndist_state > 0 && !nd.elim_extrinsics)
+        {
+            for(int i=0;i<2 && ok;i++)
+            {
+                ok = ok && dev_alloc(&P->op[i].cperm, (size_t)2*nd.Nc + 1);
+                // (until the first evaluation: the identity)
+                std::vector<int> id((size_t)2*nd.Nc + 1);
+                for(int c = 0; c < nd.Nc; c++) { id[c] = c; id[nd.Nc + c] = c; }
+                id[2*nd.Nc] = nd.Nc;
+                if(ok) HIP_TRY(hipMemcpy(P->op[i].cperm, id.data(), id.size()*sizeof(int), hipMemcpyHostToDevice), ok = false);
+            }
+            ok = ok && dev_alloc(&P->cperm_cur_alloc, (size_t)2*nd.Nc + 1);
+            ok = ok && dev_alloc(&P->F.iso, (size_t)4*(nd.Nc/2 + 1) + nd.Nc + 2);
+            P->F.cperm_cur = P->cperm_cur_alloc;
+            P->plan.spl_compact = 1;
+        }
     }
     {
         char* ctl = NULL;

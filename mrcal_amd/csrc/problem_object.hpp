@@ -53,6 +53,7 @@ struct mrcal_amd_problem
     bool        ev_pool_enabled = false;
     // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
     // ([launch][2]: the first Jacobian store, the end, wall_clock64 ticks of 10 ns), and what _timing_end() made of them
+    int*                cperm_cur_alloc = NULL;    // what F.cperm_cur points at while the compaction is on (a communicator turns it off)
     unsigned*           d_fused_ready = NULL;
     unsigned long long* d_fused_ts    = NULL;
     int                 fused_ts_capacity = 0;

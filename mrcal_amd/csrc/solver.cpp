@@ -721,6 +721,8 @@ bool mrcal_amd_problem_attach_comm(mrcal_amd_problem_t* P, mrcal_amd_comm_t* com
     if(!problem_prepare_solver(P)) return false;
     P->comm = comm;
     P->ctl_initialized = false;
+    // (the ranks of a sharded solve sum their camera blocks entry by entry: no rank puts its own in another order)
+    P->F.cperm_cur = NULL; P->plan.spl_compact = 0;
     return true;
 }
 bool mrcal_amd_problem_gather_state(mrcal_amd_problem_t* P)
@@ -775,6 +777,7 @@ bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_terminati
     if(max_iterations > 0)  prm.max_iterations = max_iterations;
     if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
     P->sharded_external = true;     // the caller sums comm_buffer(0), comm_buffer(1) over the shards itself
+    P->F.cperm_cur = NULL; P->plan.spl_compact = 0;
     P->stats.lambda = 0.0;          // a new run starts unregularized, like a new libdogleg context
     return ctl_reset(P, prm, check_termination != 0);
 }

@@ -1313,6 +1313,77 @@ void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
     __syncthreads();
     if(threadIdx.x == 0) row_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
+// Which control points does a board cover at this point? (Round 5.) The others have their regularization rows and
+// nothing else: a 2 x 2 block of the camera block each, coupled to nothing - and in the Cholesky of the camera block
+// every one of their columns is a pivot of the sequential chain all the same: at BASELINE configuration 2 (30 x 20
+// control points over 150 degrees, boards 4 m away) 277 of the 600 control points, 554 of 1206 pivots. So the
+// camera block is put in the order [coupled variables | isolated pairs] (each part in its own order), the reduction
+// writes the coupled part as a dense matrix of its own and the pairs' blocks beside it (schur_reduce_body), and the
+// factorization's launches past the coupled part's last panel find nothing to do (lchol_plan()).
+// One workgroup: the observations' boxes (OpDev::spl_box, left by board_splined_kernel) marked in LDS, then a scan over
+// the camera block's variables. cperm: [Nc] position -> variable | [Nc] variable -> position | [1] the coupled ones
+#define SPLC_T 1024
+__global__ __launch_bounds__(SPLC_T)
+void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    if(O.cperm == NULL) return;
+    extern __shared__ int lds_c[];                       // [Nknots_all] used | [SPLC_T/64] wave totals
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int Nx = P.cfg.spline_Nx, Ny = P.cfg.spline_Ny, NK = Nx*Ny;
+    const int nknots = P.Ncameras_intrinsics*NK;
+    int* __restrict__ used = lds_c;
+    int* __restrict__ wtot = lds_c + nknots;
+    for(int i = t; i < nknots; i += SPLC_T) used[i] = 0;
+    __syncthreads();
+    if(P.Ndist_state > 0 && O.spl_box != NULL)
+        for(int o = t; o < P.Nobs_board; o += SPLC_T)
+        {
+            const int4 box = ((const int4*)O.spl_box)[o];
+            const int isi = P.board_meta[o].i_state_intrinsics;
+            if(box.y < 0 || isi < 0) continue;                       // no inlier under this observation
+            const int icam = (isi - P.i_state_intrinsics)/P.Nintr_state;
+            for(int iy = box.z; iy <= box.w; iy++)
+                for(int ix = box.x; ix <= box.y; ix++)
+                    used[icam*NK + iy*Nx + ix] = 1;                  // (everybody writes the same 1)
+        }
+    __syncthreads();
+    // the variables, a run of consecutive ones per thread: coupled unless it is a control point's that no box holds
+    const int per = (nd.Nc + SPLC_T - 1)/SPLC_T;
+    const int c0 = min(nd.Nc, t*per), c1 = min(nd.Nc, c0 + per);
+    auto coupled = [&](int c) -> bool
+    {
+        const int st = S_to_state(nd, c);
+        const int rel = st - P.i_state_intrinsics;
+        if(P.Ndist_state <= 0 || rel < 0 || rel >= P.Ncameras_intrinsics*P.Nintr_state) return true;
+        const int icam = rel / P.Nintr_state, k = rel - icam*P.Nintr_state - P.Ncore_state;
+        if(k < 0) return true;                                       // the core
+        return used[icam*NK + (k >> 1)] != 0;
+    };
+    int mine = 0;
+    for(int c = c0; c < c1; c++) mine += coupled(c) ? 1 : 0;
+    // exclusive scan of `mine` over the threads: within the wave, then the waves' totals
+    int incl = mine;
+    for(int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if(lane >= off) incl += v; }
+    if(lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int before = incl - mine, total = 0;
+    for(int w = 0; w < SPLC_T/64; w++) { const int v = wtot[w]; if(w < wave) before += v; total += v; }
+    // (a camera block with nothing coupled in it cannot be: boards make rows. If it were, nothing is compacted)
+    const int n1 = (total > 0) ? total : nd.Nc;
+    int* __restrict__ perm = O.cperm;
+    int* __restrict__ iperm = O.cperm + nd.Nc;
+    int at_c = before, at_i = n1 + (c0 - before);
+    for(int c = c0; c < c1; c++)
+    {
+        const bool cpl = (total > 0) ? coupled(c) : true;
+        const int pos = cpl ? at_c++ : at_i++;
+        perm[pos] = c; iperm[c] = pos;
+    }
+    if(t == 0) O.cperm[2*nd.Nc] = n1;
+}
+
 // the SPLG_E parts of a row every pass holds, in order; and |x|^2 of the regularization rows
 __global__ __launch_bounds__(256)
 void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nrow_parts)
@@ -1899,7 +1970,9 @@ __device__ __forceinline__
 void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int add_g /* r starts from g_S (else from 0) */,
                        int nslots, const double* __restrict__ Spart,
                        double* __restrict__ S, double* __restrict__ r, int block,
-                       const unsigned char* __restrict__ live = NULL /* [nslots][npairs]: the slot holds the tile (sparse SYRK); NULL: all do */)
+                       const unsigned char* __restrict__ live = NULL /* [nslots][npairs]: the slot holds the tile (sparse SYRK); NULL: all do */,
+                       double* __restrict__ iso = NULL /* given: S goes out COMPACTED by O.cperm (LcholCompact): the coupled
+                                                         variables' n' x n' matrix with its rhs as row n', the isolated pairs' blocks here */)
 {
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
@@ -1966,13 +2039,34 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
         const int v = (idx >> 6) & 3, lane = idx & 63;
         const int i = 16*bi + (lane >> 4) + 4*v, j = 16*bj + (lane & 15);
         if(i < nd.Nc && j < nd.Nc && j >= i)
-            S[(size_t)j*nd.Nc + i] = O.A[(size_t)j*nd.Nc + i] + ((i==j) ? lambda : 0.0) - acc;
+        {
+            const double v = O.A[(size_t)j*nd.Nc + i] + ((i==j) ? lambda : 0.0) - acc;
+            if(iso == NULL) S[(size_t)j*nd.Nc + i] = v;
+            else
+            {
+                const int* __restrict__ ip = O.cperm + nd.Nc;
+                const int n1 = O.cperm[2*nd.Nc], pi = ip[i], pj = ip[j];
+                if(pi < n1 && pj < n1) S[(size_t)max(pi, pj)*n1 + min(pi, pj)] = v;
+                else if(pi >= n1 && pj >= n1 && ((pi - n1) >> 1) == ((pj - n1) >> 1))
+                    iso[4*((pi - n1) >> 1) + ((pi - n1) & 1) + ((pj - n1) & 1)] = v;      // (0,0) -> 0, (1,0) -> 1, (1,1) -> 2
+                else if(v != 0.0) O.scalars[SC_BAD_STRUCTURE] = 3.0;       // an isolated variable that is coupled after all
+            }
+        }
     }
     else
     {
         const int i = idx - nS;
         if(i < nd.Nc)
-            r[i] = (add_g ? O.g[S_to_state(nd, i)] : 0.0) - acc;
+        {
+            const double v = (add_g ? O.g[S_to_state(nd, i)] : 0.0) - acc;
+            if(iso == NULL) r[i] = v;
+            else
+            {
+                const int n1 = O.cperm[2*nd.Nc], pi = O.cperm[nd.Nc + i];
+                if(pi < n1) S[(size_t)n1*n1 + pi] = v;
+                else        iso[4*(nd.Nc/2 + 1) + (pi - n1)] = v;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(256)
@@ -3202,13 +3296,27 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
 // with_finish (round 5): the end of the trial step (step2_finish: one workgroup anyway) opens this launch instead of
 // being a launch of its own in front of it - 4.8 us of pure launch on every trial step of a big camera block; what it
 // decides (fl->skip_chol, which is what `skip` points at) is what the panel launches behind this one read
+__device__ __forceinline__ int lchol_n(const int* __restrict__ n_dev, int n_host);
 __global__ __launch_bounds__(LCH_THREADS)
-void lchol_diag_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, int j0,
-                       double* __restrict__ Linv, int* __restrict__ status, int with_finish, Step2Dev sd)
+void lchol_diag_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M, int j0,
+                       double* __restrict__ Linv, int* __restrict__ status, int with_finish, Step2Dev sd,
+                       const double* __restrict__ iso, int iso_Nc)
 {
     if(with_finish) { if(!step2_finish(sd, status)) return; }
     else if(skip != NULL && *skip) return;
     __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    const int n = lchol_n(n_dev, n_host);
+    // (the isolated pairs of a compacted camera block, LcholCompact: a pair that is not positive definite is this
+    //  factorization's failure like a pivot of the big matrix; found here, a thread a pair, so that the status is final
+    //  when the last launch reads it)
+    if(iso != NULL)
+        for(int p0 = n + 2*(int)threadIdx.x; p0 < iso_Nc; p0 += 2*LCH_THREADS)
+        {
+            const double* __restrict__ b = iso + (size_t)4*((p0 - n) >> 1);
+            const bool two = p0 + 1 < iso_Nc;
+            const double s00 = b[0], s10 = two ? b[1] : 0.0, s11 = two ? b[2] : 1.0;
+            if(!(s00 > 0.0) || !(s11 - s10*(s10/s00) > 0.0)) atomicExch(status, 1);
+        }
     lchol_diag_block(n, M, j0, Linv, status, NULL, 0, lds);
 }
 
@@ -3468,38 +3576,103 @@ void lchol_inverse_block(int n, int npad, const double* __restrict__ M, const do
 // what a launch does for Y = L^-1 (lchol_inverse_block): the chain of row block prow (prow workgroups, q < prow) and the
 // tiles fed by row block krow (targets p = krow+2 .. npanels-1, q <= krow); -1: none
 struct LcholInverseWork { double* Yb; double* zc; const double* Linv; int npad, npanels, prow, krow, nchain, ntile; };
+// What launch l = 0 .. npanels of the factorization of an n x n matrix does (round 5: one function for the host, which
+// sizes the grid with it, and for the kernel, which may learn n only on the device - the splined models' camera block
+// without the control points no board covers, launch_cholesky_large(n_dev) - and then finds itself to be a panel's
+// launch, the closing one (l == npanels: the last panel's solve and the last row block of L^-1) or nothing (l > npanels)):
+//   panel l < npanels:  [0] the next diagonal block | the trailing update's tiles | the previous panel's solve | L^-1
+struct LcholPlan
+{
+    int npanels, npad;
+    int j0;             // first column of panel l
+    int has_next;       // there is a diagonal block behind panel l (workgroup 0 factors it)
+    int ntiles, ntrsm, jprev, pprev;
+    int prow, krow, nchain, ntile;
+    int nblocks;        // workgroups of the launch (0: nothing to do)
+};
+__host__ __device__ inline LcholPlan lchol_plan(int n, int l, bool with_inverse)
+{
+    LcholPlan q;
+    q.npanels = (n + LCH_NB - 1)/LCH_NB;
+    q.npad    = q.npanels*LCH_NB;
+    q.j0 = 0; q.has_next = 0; q.ntiles = 0; q.ntrsm = 0; q.jprev = 0; q.pprev = 0;
+    q.prow = l - 1; q.krow = l - 2; q.nchain = 0; q.ntile = 0; q.nblocks = 0;
+    if(l > q.npanels || n <= 0) return q;
+    // rows below panel p, the rhs row included, in blocks of 64 (the panel solve's)
+    auto ntrsm_of = [&](int p) { const int m0 = (n < (p + 1)*LCH_NB) ? n : (p + 1)*LCH_NB; return (n + 1 - m0 + LCH_NB - 1)/LCH_NB; };
+    if(with_inverse)
+    {
+        // the chain of row block l-1 of Y, the tiles fed by row block l-2
+        if(q.prow >= 1 && q.prow < q.npanels) q.nchain = q.prow;
+        if(q.krow >= 0 && q.krow + 2 < q.npanels) q.ntile = (q.npanels - q.krow - 2)*(q.krow + 1);
+    }
+    if(l < q.npanels)
+    {
+        q.j0 = l*LCH_NB;
+        const int m0 = (n < q.j0 + LCH_NB) ? n : q.j0 + LCH_NB;
+        q.has_next = (l + 1 < q.npanels) ? 1 : 0;
+        // tiles: the 64-row blocks of the trailing matrix by pairs, without the next diagonal block, and the rhs row against each
+        const int nbt = (n - m0 + LCH_NB - 1)/LCH_NB;
+        q.ntiles = q.has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
+        q.ntrsm  = (l > 0) ? ntrsm_of(l - 1) : 0;
+        q.pprev  = (l > 0) ? l - 1 : 0;
+    }
+    else
+    {
+        // the last panel's solve: the rhs row alone (and the last row block of Y)
+        q.ntrsm = ntrsm_of(q.npanels - 1);
+        q.pprev = q.npanels - 1;
+    }
+    q.jprev = q.pprev*LCH_NB;
+    const int work = q.ntiles + q.ntrsm + q.nchain + q.ntile;
+    q.nblocks = (q.has_next || work > 0) ? 1 + work : 0;
+    return q;
+}
+// n_dev (optional): the size of the matrix, on the device (<= n_host, which the grids were sized for; NULL: n_host)
+__device__ __forceinline__ int lchol_n(const int* __restrict__ n_dev, int n_host)
+{
+    if(n_dev == NULL) return n_host;
+    const int n = *n_dev;
+    return (n > 0 && n <= n_host) ? n : n_host;
+}
 __global__ __launch_bounds__(LCH_THREADS)
-void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict__ M,
-                        int j0, const double* __restrict__ X, int ntiles,
-                        double* __restrict__ Xnext, int* __restrict__ status,
-                        int jprev, const double* __restrict__ Xprev, int ntrsm, LcholInverseWork W)
+void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
+                        int l, double* __restrict__ Linv, int* __restrict__ status, int with_inverse)
 {
     if(skip != NULL && *skip) return;
+    const int n = lchol_n(n_dev, n_host);
+    const LcholPlan q = lchol_plan(n, l, with_inverse != 0);
+    if((int)blockIdx.x >= q.nblocks) return;
     __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
     static_assert(LCH_LDS_DOUBLES >= 3*LCH_NB*(LCH_NB+1), "the tile workgroups take three 64 x 65 arrays");
     double* __restrict__ MI = lds;
     double* __restrict__ MC = MI + LCH_NB*(LCH_NB+1);
     double* __restrict__ Xs = MC + LCH_NB*(LCH_NB+1);
+    // the workspace: [npanels][64][64] inverse diagonal blocks | Yb [npad][npad] | zc [npad]  (of THIS n)
+    double* __restrict__ Yb = Linv + (size_t)q.npanels*LCH_NB*LCH_NB;
+    double* __restrict__ zc = with_inverse ? Yb + (size_t)q.npad*q.npad : (double*)NULL;
+    const double* __restrict__ X     = Linv + (size_t)((l < q.npanels) ? l : 0)*LCH_NB*LCH_NB;
+    const double* __restrict__ Xprev = Linv + (size_t)q.pprev*LCH_NB*LCH_NB;
     const int b = (int)blockIdx.x - 1;
     if(b < 0)
     {
-        if(Xnext != NULL) lchol_diag_block(n, M, j0 + LCH_NB, Xnext, status, X, j0, lds);
+        if(q.has_next) lchol_diag_block(n, M, q.j0 + LCH_NB, Linv + (size_t)(l + 1)*LCH_NB*LCH_NB, status, X, q.j0, lds);
         return;
     }
     // The diagonal workgroup is the long one (24 us against 9), and it starts with a cold read of 96 KB. With
     // two hundred workgroups asking for theirs at the same moment that read took 6 us; the others wait 3 first
 #ifndef LCH_NO_SLEEP
-    if(Xnext != NULL) __builtin_amdgcn_s_sleep(127);
+    if(q.has_next) __builtin_amdgcn_s_sleep(127);
 #endif
-    if(b < ntiles) lchol_update_tile(n, M, j0, X, b, MI, MC, Xs);
-    else if(b < ntiles + ntrsm) lchol_trsm_block(n, M, jprev, Xprev, b - ntiles, MI, Xs, W.zc);
-    else if(b < ntiles + ntrsm + W.nchain)
-        lchol_inverse_block(n, W.npad, M, W.Linv, W.Yb, W.prow, b - ntiles - ntrsm, W.prow - 1, true, MI, MC, Xs);
-    else if(b < ntiles + ntrsm + W.nchain + W.ntile)
+    if(b < q.ntiles) lchol_update_tile(n, M, q.j0, X, b, MI, MC, Xs);
+    else if(b < q.ntiles + q.ntrsm) lchol_trsm_block(n, M, q.jprev, Xprev, b - q.ntiles, MI, Xs, zc);
+    else if(b < q.ntiles + q.ntrsm + q.nchain)
+        lchol_inverse_block(n, q.npad, M, Linv, Yb, q.prow, b - q.ntiles - q.ntrsm, q.prow - 1, true, MI, MC, Xs);
+    else if(b < q.ntiles + q.ntrsm + q.nchain + q.ntile)
     {
-        const int w = b - ntiles - ntrsm - W.nchain;
-        const int nq = W.krow + 1;
-        lchol_inverse_block(n, W.npad, M, W.Linv, W.Yb, W.krow + 2 + w/nq, w % nq, W.krow, false, MI, MC, Xs);
+        const int w = b - q.ntiles - q.ntrsm - q.nchain;
+        const int nq = q.krow + 1;
+        lchol_inverse_block(n, q.npad, M, Linv, Yb, q.krow + 2 + w/nq, w % nq, q.krow, false, MI, MC, Xs);
     }
 }
 
@@ -3508,16 +3681,59 @@ void lchol_panel_kernel(int n, const int* __restrict__ skip, double* __restrict_
 // rows, added in slice order. (A workgroup per 64 columns - 19 of them at 1206 variables, the first one walking 617 KB
 // alone - took 16 us; 76 of these take the same 5.8 MB through four times as many CUs)
 #define LCH_AI_COLS 16
+// Round 5, the splined models: the matrix that was factored may be the camera block WITHOUT its isolated variables (the
+// control points no board covers: all they have is their regularization, a 2 x 2 block a control point, coupled to
+// nothing: LcholCompact below). Then column c of the factored matrix is camera-block variable perm[c], the solution goes
+// to dout[perm[c]], and the workgroups past the columns' solve the 2 x 2 blocks: d = -S2^-1 r2 by the closed form of a
+// 2 x 2 Cholesky (not positive definite: status, like a pivot of the big matrix)
+struct LcholCompact
+{
+    const int*    cperm;     // [Nc] position -> camera-block variable | [Nc] variable -> position | [1] n = the coupled ones (they come first); NULL: none of this
+    const double* iso;       // [Nc/2][4]: per isolated pair (positions n + 2 q, n + 2 q + 1) s00, s10, s11, then [Nc] their rhs behind all blocks
+    double*       dout;      // [Nc] the solution in the camera block's own order
+    int           Nc;
+};
 __global__ __launch_bounds__(256)
-void lchol_apply_inverse_kernel(int n, const int* __restrict__ skip, double* __restrict__ M, const double* __restrict__ Linv,
-                                const double* __restrict__ Yb, const double* __restrict__ zc, int npad,
-                                int with_post, Step2Dev sd, const int* __restrict__ chol_status)
+void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
+                                const double* __restrict__ Linv, int with_post, Step2Dev sd, int* __restrict__ chol_status,
+                                LcholCompact cp)
 {
     if(skip != NULL && *skip) return;
+    const int n = lchol_n(n_dev, n_host);
+    constexpr int NB = LCH_NB;
+    const int npanels = (n + NB - 1)/NB, npad = npanels*NB;
+    const double* __restrict__ Yb = Linv + (size_t)npanels*NB*NB;
+    const double* __restrict__ zc = Yb + (size_t)npad*npad;
+    const int ncolblocks = (n + LCH_AI_COLS - 1)/LCH_AI_COLS;
+    if((int)blockIdx.x >= ncolblocks)
+    {
+        // the isolated pairs, a thread each
+        if(cp.cperm == NULL) return;
+        const int pair = ((int)blockIdx.x - ncolblocks)*blockDim.x + threadIdx.x;
+        const int p0 = n + 2*pair;
+        if(p0 >= cp.Nc) return;
+        const double* __restrict__ b = cp.iso + (size_t)4*pair;
+        const double* __restrict__ rr = cp.iso + (size_t)4*(cp.Nc/2 + 1) + 2*pair;
+        const bool two = p0 + 1 < cp.Nc;
+        const double s00 = b[0], s10 = two ? b[1] : 0.0, s11 = two ? b[2] : 1.0;
+        const double r0 = rr[0], r1 = two ? rr[1] : 0.0;
+        // L = [l00 0; l10 l11]
+        bool bad = !(s00 > 0.0);
+        const double l00 = sqrt(bad ? 1.0 : s00), l10 = s10/l00;
+        const double t11 = s11 - l10*l10;
+        bad = bad || !(t11 > 0.0);
+        const double l11 = sqrt(bad ? 1.0 : t11);
+        const double z0 = r0/l00, z1 = (r1 - l10*z0)/l11;
+        const double x1 = z1/l11, x0 = (z0 - l10*x1)/l00;
+        cp.dout[cp.cperm[p0]] = -x0;
+        if(two) cp.dout[cp.cperm[p0 + 1]] = -x1;
+        // (a pair that is not positive definite was reported by the factorization's first launch: lchol_diag_kernel)
+        (void)bad;
+        return;
+    }
     // with_post (round 5): what step2_post_kernel did in a launch of its own - the factorization's verdict into the
     // control block (every panel's diagonal workgroup has run: the status is final) - by one thread of this launch
     if(with_post && blockIdx.x == 0 && threadIdx.x == 0) step2_chol_done(sd, *chol_status != 0);
-    constexpr int NB = LCH_NB;
     __shared__ double part[16][LCH_AI_COLS];
     const int t = threadIdx.x, j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
     const int c = blockIdx.x*LCH_AI_COLS + j16;
@@ -3548,7 +3764,8 @@ void lchol_apply_inverse_kernel(int n, const int* __restrict__ skip, double* __r
     {
         double sacc = 0.0;
         for(int k = 0; k < 16; k++) sacc += part[k][t];
-        M[(size_t)n*n + c] = -sacc;
+        if(cp.cperm != NULL) cp.dout[cp.cperm[c]] = -sacc;
+        else                 M[(size_t)n*n + c] = -sacc;
     }
 }
 
@@ -3671,63 +3888,40 @@ void lchol_backward_apply_kernel(int n, const int* __restrict__ skip, double* __
 static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB; }
 // sd (optional): the trial step this factorization belongs to - its end-of-trial logic rides in the first launch and
 // the verdict in the last (no step2_finish_kernel / step2_post_kernel around the call). *fused says whether that happened
-// (not with the backward sweep of MRCAL_AMD_LCHOL_SWEEP, whose last launch is another)
+// (not with the backward sweep of MRCAL_AMD_LCHOL_SWEEP, whose last launch is another).
+// n_dev (optional, round 5): the size of the matrix as the DEVICE knows it, <= n (LcholCompact: the camera block without
+// its isolated variables, whose number follows the boards). The launches and their grids are those of n; a launch past
+// the device's last panel finds nothing to do
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
-                                 const Step2Dev* sd = NULL, bool* fused = NULL)
+                                 const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
-    const int npad    = (int)lchol_npad(n);
-    double* Yb = Linv + (size_t)npanels*LCH_NB*LCH_NB;
-    double* zc = Yb + (size_t)npad*npad;
     // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
     // L^-1 built on the side (lchol_inverse_block); for comparisons
     static const bool sweep = (getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
-    auto Xof = [&](int p) { return Linv + (size_t)p*LCH_NB*LCH_NB; };
-    // rows below a panel, the rhs row included, in blocks of 64 (the panel solve's)
-    auto ntrsm_of = [&](int p) { const int m0 = std::min(n, (p + 1)*LCH_NB); return (n + 1 - m0 + LCH_NB - 1)/LCH_NB; };
-    // launch l (0 .. npanels): the chain of row block l-1 of Y, the tiles fed by row block l-2
-    auto inverse_work = [&](int l)
-    {
-        LcholInverseWork W;
-        W.Yb = Yb; W.zc = zc; W.Linv = Linv; W.npad = npad; W.npanels = npanels;
-        W.prow = l - 1; W.krow = l - 2; W.nchain = 0; W.ntile = 0;
-        if(sweep) { W.zc = NULL; return W; }
-        if(W.prow >= 1 && W.prow < npanels) W.nchain = W.prow;
-        if(W.krow >= 0 && W.krow + 2 < npanels) W.ntile = (npanels - W.krow - 2)*(W.krow + 1);
-        return W;
-    };
+    if(sweep && (n_dev != NULL || compact != NULL)) return hipErrorInvalidValue;
     Step2Dev sd0; memset(&sd0, 0, sizeof(sd0));
+    LcholCompact cp0; memset(&cp0, 0, sizeof(cp0));
     const bool fuse = (sd != NULL && !sweep);
     if(fused != NULL) *fused = fuse;
-    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n, skip, M, 0, Xof(0), status,
-                       fuse ? 1 : 0, fuse ? *sd : sd0);
-    for(int p = 0; p < npanels; p++)
+    hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n_dev, n, skip, M, 0, Linv, status,
+                       fuse ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0);
+    for(int l = 0; l <= npanels; l++)
     {
-        const int j0 = p*LCH_NB;
-        const int m0 = std::min(n, j0 + LCH_NB);
-        const bool has_next = (p + 1 < npanels);
-        // tiles: the 64-row blocks of the trailing matrix by pairs, without the next diagonal block, and the rhs row against each
-        const int nbt = (n - m0 + LCH_NB - 1)/LCH_NB;
-        const int ntiles = has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
-        const int ntrsm  = (p > 0) ? ntrsm_of(p - 1) : 0;
-        const LcholInverseWork W = inverse_work(p);
-        if(!has_next && ntrsm == 0 && W.nchain + W.ntile == 0) continue;
-        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntiles + ntrsm + W.nchain + W.ntile), dim3(LCH_THREADS), 0, stream,
-                           n, skip, M, j0, (const double*)Xof(p), ntiles, has_next ? Xof(p + 1) : (double*)NULL, status,
-                           (p > 0) ? j0 - LCH_NB : 0, (const double*)((p > 0) ? Xof(p - 1) : Xof(0)), ntrsm, W);
-    }
-    // the last panel's solve: the rhs row alone (and the last row block of Y)
-    {
-        const LcholInverseWork W = inverse_work(npanels);
-        hipLaunchKernelGGL(lchol_panel_kernel, dim3(1 + ntrsm_of(npanels - 1) + W.nchain + W.ntile), dim3(LCH_THREADS), 0, stream,
-                           n, skip, M, 0, (const double*)Xof(0), 0, (double*)NULL, status,
-                           (npanels - 1)*LCH_NB, (const double*)Xof(npanels - 1), ntrsm_of(npanels - 1), W);
+        const LcholPlan q = lchol_plan(n, l, !sweep);
+        // (with a size the device decides, a launch that is a panel's at n may be the closing one there: its grid covers both)
+        // (with a size the device decides, a launch that is a panel's at n may be the closing one there, or nothing: the
+        //  plan of n has the workgroups for either - lchol_plan() grows with n term by term)
+        const int nblocks = q.nblocks;
+        if(nblocks <= 0) continue;
+        hipLaunchKernelGGL(lchol_panel_kernel, dim3(nblocks), dim3(LCH_THREADS), 0, stream,
+                           n_dev, n, skip, M, l, Linv, status, sweep ? 0 : 1);
     }
     if(!sweep)
     {
-        hipLaunchKernelGGL(lchol_apply_inverse_kernel, dim3((n + LCH_AI_COLS - 1)/LCH_AI_COLS), dim3(256), 0, stream, n, skip, M,
-                           (const double*)Linv, (const double*)Yb, (const double*)zc, npad,
-                           fuse ? 1 : 0, fuse ? *sd : sd0, (const int*)status);
+        const int niso_blocks = (compact != NULL) ? (n/2 + 1 + 255)/256 : 0;
+        hipLaunchKernelGGL(lchol_apply_inverse_kernel, dim3((n + LCH_AI_COLS - 1)/LCH_AI_COLS + niso_blocks), dim3(256), 0, stream,
+                           n_dev, n, skip, M, (const double*)Linv, fuse ? 1 : 0, fuse ? *sd : sd0, status, compact ? *compact : cp0);
         return hipGetLastError();
     }
     // the backward sweep, in groups of panels (see lchol_backward_kernel)
@@ -4092,7 +4286,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
                          const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
                          int nslots, const double* __restrict__ Spart,
                          double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status,
-                         const unsigned char* __restrict__ live)
+                         const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso)
 {
     if(fl->skip_elim) return;
     const OpDev& O = ops[fl->elim_sel];
@@ -4102,9 +4296,14 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         // (every rank adds its own); of a point re-eliminated later it is already the
         // sum over the ranks (step2_finish unpacked it): the leader alone adds it
         const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
-        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live);
+        schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live,
+                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL);
         return;
     }
+    // (the permutation this reduction went by, for the factorization and the solve behind it: which of the two
+    //  operating points was reduced is the device's to know)
+    if(cperm_cur != NULL && O.cperm != NULL)
+        for(int i = threadIdx.x; i < 2*nd.Nc + 1; i += blockDim.x) cperm_cur[i] = O.cperm[i];
     double* __restrict__ tail = r + nd.Nc;
     for(int i = threadIdx.x; i < nd.Nc + 2; i += blockDim.x)
     {
@@ -4420,6 +4619,10 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // products before the gathered sums instead of after (other bits than round 4's, the same every time: the
             // side stream orders the two). MRCAL_AMD_SPL_PAIRS_LATE: where they were
             static const bool pairs_late = (getenv("MRCAL_AMD_SPL_PAIRS_LATE") != NULL);
+            // (round 5) which control points a board covers at this point: spl_compact_kernel, for the reduction of this
+            // trial step. On the side stream if there is one (it is free until the assembly is through)
+            const int nknots_all = P.Ncameras_intrinsics*P.cfg.spline_Nx*P.cfg.spline_Ny;
+            bool compact_pending = plan.spl_compact != 0;
             const int nrp_early = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
             // (not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
             //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
@@ -4430,7 +4633,14 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                 e = hipStreamWaitEvent(side, ev_fork0, 0);                if(e != hipSuccess) return e;
                 hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp_early), dim3(256), 0, side, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
                 pairs_early = true;
+                if(compact_pending)
+                {
+                    hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), side, P, nd, B.R);
+                    compact_pending = false;
+                }
             }
+            if(compact_pending)
+                hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), stream, P, nd, B.R);
             // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes), dim3(256), 0, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji);
@@ -4843,7 +5053,7 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nred = ((npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT) + 255)/256;
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live);
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }
@@ -4871,7 +5081,12 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
             static const bool separate = (getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
             bool fused = false;
             if(separate) hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
-            launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused);
+            // (the splined models: the camera block as the reduction left it - without the control points no board covers)
+            LcholCompact cp; memset(&cp, 0, sizeof(cp));
+            const bool compact = F.cperm_cur != NULL && !separate;
+            if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
+            launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused,
+                                  compact ? F.cperm_cur + 2*n : (const int*)NULL, compact ? &cp : (const LcholCompact*)NULL);
             if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
             else if(!fused) return hipErrorInvalidValue;
         }

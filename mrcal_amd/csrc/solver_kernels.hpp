@@ -94,6 +94,9 @@ struct FactorBuffers
     int*    status;   // [1] nonzero: not positive definite
     unsigned* occ;    // [NEb][occ_words(nd)] bit per 16-column tile of the camera block: does the block's Wt hold a nonzero there?
                       // Written by eblock_factor_kernel, read by the sparse SYRK (the splined models). NULL: not tracked
+    int*    cperm_cur; // [2 Nc + 1] the permutation (OpDev::cperm) of the point whose camera block was reduced last: what the
+                      // factorization and the solve behind that reduction go by. NULL: no compaction
+    double* iso;      // with cperm_cur: [4 (Nc/2 + 1)] the 2 x 2 blocks of the isolated pairs (s00, s10, s11, -) | [Nc] their rhs
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -
                       // [ceil(Nc/16)][NE][16] - for the sparse SYRK: a block's rows of a tile are 768 contiguous bytes
                       // (in Wt itself they are six pieces 9.6 KB apart, and a workgroup's few blocks that count are all over 46 MB)
@@ -179,6 +182,7 @@ struct GenPlan
 struct AssemblyPlan
 {
     GenPlan gen;
+    int  spl_compact;      // splined models: the evaluation's assembly also makes OpDev::cperm (spl_compact_kernel)
     int* frame_obs_begin;  // [blocks+1] the board observations of each 6x6 eliminated block (a frame: contiguous) ...
     int* frame_obs;        // ... or, if not NULL, entries [begin, end) of this list (a camera's, with elim_extrinsics)
     int* chunk_begin;      // [Nchunks+1]
