@@ -135,6 +135,14 @@ static mrcal_amd_factorization* factorization_finish(mrcal_amd_factorization* f)
     if(ok) HIP_TRY(hipMemcpyAsync(&bad_structure, f->op.scalars + SC_BAD_STRUCTURE, sizeof(double), hipMemcpyDeviceToHost, f->stream), ok = false);
     if(ok) HIP_TRY(hipStreamSynchronize(f->stream), ok = false);
     if(!ok) { delete f; return NULL; }
+    if(bad_structure == 2.0)
+    {
+        // (rows_repro_row / rows_generic_wave<true>: the pre-rounded sums are made of constants 2^(c_i + c_j + N ...), which
+        //  must be doubles: columns whose largest |value| is beyond ~1e+-100, or not finite, are not served)
+        set_error("the factorization failed: the matrix holds values that are not finite, or columns beyond 1e+-100 in magnitude");
+        delete f;
+        return NULL;
+    }
     if(bad_structure != 0.0)
     {
         set_error("a row couples two eliminated blocks, or a column index is out of range: this matrix does not have the declared structure");

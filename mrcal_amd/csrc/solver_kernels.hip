@@ -1410,6 +1410,67 @@ void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, As
     }
 }
 
+struct ReproAcc { double *A, *Bt, *D; };
+// t, below 2^c in magnitude, added to the three levels at offset i
+__device__ __forceinline__ void repro_add(const ReproAcc (&acc)[3], int which, size_t i, double t, int c, int N)
+{
+    double* const dst[3] = { which == 0 ? acc[0].A : (which == 1 ? acc[0].Bt : acc[0].D),
+                             which == 0 ? acc[1].A : (which == 1 ? acc[1].Bt : acc[1].D),
+                             which == 0 ? acc[2].A : (which == 1 ? acc[2].Bt : acc[2].D) };
+#pragma unroll
+    for(int l = 0; l < 3; l++)
+    {
+        // M = 1.5 2^(c + N): an ulp of 2^(c + N - 52)
+        const double M = __longlong_as_double(((long long)(1023 + c + N) << 52) | (1ll << 51));
+        const double q = __dadd_rn(__dadd_rn(t, M), -M);
+        if(q != 0.0) atomicAdd(&dst[l][i], q);
+        t = __dadd_rn(t, -q);
+        c += N - 52;
+    }
+}
+// what a kernel that adds through repro_add() needs: the three levels, the columns' maxima, N
+struct ReproCtx { ReproAcc acc[3]; const unsigned long long* cmax; int N; };
+// one row, by one lane: the products of its entries, pair by pair, through repro_add()
+__device__ __forceinline__
+void rows_repro_row(const NormalDims& nd, const OpDev& O, int r, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                    const ReproCtx& rc, int extra_bits)
+{
+    const double* __restrict__ Jv = O.Jv;
+    const int N = rc.N;
+    const int p0 = Jp[r], p1 = Jp[r+1];
+    // the exponent above a column's largest |value|: biased exponent - 1023 + 1
+    auto cexp = [&](int c) { return (int)((rc.cmax[c] >> 52) & 0x7ff) - 1022; };
+    for(int p = p0; p < p1; p++)
+    {
+        const int    ci = Ji[p];
+        const double vi = Jv[p];
+        if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
+        if(vi == 0.0) continue;
+        const int si = state_to_SE(nd, ci), ei = cexp(ci);
+        for(int q = p0; q < p1; q++)
+        {
+            const int cj = Ji[q];
+            if((unsigned)cj >= (unsigned)nd.Nstate) continue;
+            const double t = __dmul_rn(vi, Jv[q]);
+            if(t == 0.0) continue;
+            const int sj = state_to_SE(nd, cj);
+            const int c  = ei + cexp(cj) + extra_bits;
+            // (the exponents the levels' constants are made of must exist: columns of ~1e+-100 and smaller are not served)
+            if(c + N > 900 || c + 3*N - 160 < -900) { O.scalars[SC_BAD_STRUCTURE] = 2.0; continue; }
+            // (the lower triangles of A and of the D blocks: repro_combine_kernel mirrors them)
+            if(si >= 0 && sj >= 0)     { if(sj <= si) repro_add(rc.acc, 0, (size_t)si*nd.Nc + sj, t, c, N); }
+            else if(si < 0 && sj >= 0) repro_add(rc.acc, 1, (size_t)(-si-1)*nd.Nc + sj, t, c, N);
+            else if(si < 0 && sj < 0)
+            {
+                int bi, ai, di, e0i, bj, aj, dj, e0j;
+                E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
+                E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
+                if(bi == bj) { if(aj <= ai) repro_add(rc.acc, 2, (size_t)bi*36 + ai*6 + aj, t, c, N); }
+                else         O.scalars[SC_BAD_STRUCTURE] = 1.0;      // no row may touch two E blocks
+            }
+        }
+    }
+}
 // sum over the 32 lanes of this lane's half of the wave, to all of them
 __device__ __forceinline__ double half_wave_sum_f64(double v)
 {
@@ -1425,9 +1486,14 @@ __device__ __forceinline__ double half_wave_sum_f64(double v)
 // group (the rows past an observation boundary), until no row is pending. A run of 32 rows
 // costs the atomics of one. (A bare CSR Jacobian handed to CHOLMOD_factorization(J) has no
 // Grams to assemble from: at 1.6 M rows x 24 entries one lane per row is 922 M atomics, 97 ms)
+// REPRO (round 5, CHOLMOD_factorization(J) of a bare matrix): the group sums - made across the half-wave in a fixed
+// order, whatever the scheduling - go to memory through repro_add(), pre-rounded so that no addition of the atomics
+// rounds (launch_assemble_rows); a group sum of up to 32 products of columns i, j is below 2^(c_i + c_j + 5). The
+// rows outside runs go one lane a row through the same. x is not looked at (a bare matrix has none)
+template<bool REPRO>
 __device__ __forceinline__
 void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int row1,
-                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, const ReproCtx* __restrict__ rc = NULL)
 {
     const int lane = threadIdx.x & 63, half = lane >> 5, first = half << 5;
     const int r = r_first + 2*(lane & 31) + half;
@@ -1435,7 +1501,8 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
     const int p0 = valid ? Jp[r] : 0, p1 = valid ? Jp[r+1] : 0;
     const int len = p1 - p0;
     const double* __restrict__ Jv = O.Jv;
-    const double xr = valid ? O.x[r] : 0.0;
+    const double xr = (valid && !REPRO) ? O.x[r] : 0.0;
+    auto cexp = [&](int c) { return (int)((rc->cmax[c] >> 52) & 0x7ff) - 1022; };   // (REPRO) the exponent above a column's largest |value|
     bool todo = valid;
     while(__any(todo))
     {
@@ -1453,29 +1520,57 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
         // no runs here (regularization rows: every row its own columns): the rows still pending go one lane per row
         if(__popcll(__ballot(member)) < 8)
         {
-            if(todo) rows_generic_row(nd, O, r, row1, Jp, Ji);
+            if constexpr(REPRO) { if(todo) rows_repro_row(nd, O, r, Jp, Ji, *rc, 0); }
+            else                { if(todo) rows_generic_row(nd, O, r, row1, Jp, Ji); }
             return;
         }
 
-        const double n2 = half_wave_sum_f64(member ? xr*xr : 0.0);
-        if(adder) atomicAdd(&O.scalars[SC_NORM2_X], n2);
+        if constexpr(!REPRO)
+        {
+            const double n2 = half_wave_sum_f64(member ? xr*xr : 0.0);
+            if(adder) atomicAdd(&O.scalars[SC_NORM2_X], n2);
+        }
         for(int p = 0; p < lenmax; p++)
         {
             const bool inp = member && p < llen;
             const double vi = inp ? Jv[p0 + p] : 0.0;
-            const double gs = half_wave_sum_f64(vi*xr);
             bool addp = adder && p < llen;
             int  ci = addp ? cols[p] : 0;
             if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; addp = false; ci = 0; }
             const int  si = state_to_SE(nd, ci);
-            if(addp) atomicAdd(&O.g[ci], gs);
+            if constexpr(!REPRO)
+            {
+                const double gs = half_wave_sum_f64(vi*xr);
+                if(addp) atomicAdd(&O.g[ci], gs);
+            }
+            const int ei = (REPRO && addp) ? cexp(ci) : 0;
             for(int q = p; q < lenmax; q++)
             {
-                const double v = half_wave_sum_f64((inp && q < llen) ? vi*Jv[p0 + q] : 0.0);
+                // (REPRO: the products rounded one by one, then summed over the half-wave in the butterfly's fixed order)
+                const double v = half_wave_sum_f64((inp && q < llen) ? __dmul_rn(vi, Jv[p0 + q]) : 0.0);
                 if(!addp || q >= llen) continue;
                 const int cj = cols[q];
                 if((unsigned)cj >= (unsigned)nd.Nstate) continue;       // (flagged when it comes up as p)
                 const int sj = state_to_SE(nd, cj);
+                if constexpr(REPRO)
+                {
+                    // the lower triangles of A and of the D blocks only (repro_combine_kernel mirrors them); Bt whole
+                    if(v == 0.0) continue;
+                    const int c = ei + cexp(cj) + 5;
+                    if(c + rc->N > 900 || c + 3*rc->N - 160 < -900) { O.scalars[SC_BAD_STRUCTURE] = 2.0; continue; }
+                    const int sh = max(si, sj), sl = min(si, sj);       // (S indices >= 0, E indices < 0)
+                    if(sl >= 0)                 repro_add(rc->acc, 0, (size_t)sh*nd.Nc + sl, v, c, rc->N);
+                    else if(sh >= 0)            repro_add(rc->acc, 1, (size_t)(-sl-1)*nd.Nc + sh, v, c, rc->N);
+                    else
+                    {
+                        int bi, ai, di, e0i, bj, aj, dj, e0j;
+                        E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
+                        E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
+                        if(bi == bj) repro_add(rc->acc, 2, (size_t)bi*36 + max(ai, aj)*6 + min(ai, aj), v, c, rc->N);
+                        else         O.scalars[SC_BAD_STRUCTURE] = 1.0;
+                    }
+                    continue;
+                }
                 // both orientations of the pair, as the row-by-row loop over (p,q) and (q,p) adds them
                 for(int o = 0; o < ((p == q) ? 1 : 2); o++)
                 {
@@ -1501,7 +1596,7 @@ void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
                          const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
     if(opref_skip(R)) return;
-    rows_generic_wave(nd, opref_get(R), row0 + blockIdx.x*blockDim.x, row1, Jp, Ji);
+    rows_generic_wave<false>(nd, opref_get(R), row0 + blockIdx.x*blockDim.x, row1, Jp, Ji);
 }
 
 // The same for problems made of such rows (structure from motion: tens of
@@ -5807,66 +5902,14 @@ void csr_column_max_kernel(long long Nnz, int Nstate, const int32_t* __restrict_
         if(b > cmax[c]) atomicMax(&cmax[c], b);      // (monotone in |value|; NaN ends up largest and poisons the sums, as it should)
     }
 }
-struct ReproAcc { double *A, *Bt, *D; };
-// t, below 2^c in magnitude, added to the three levels at offset i
-__device__ __forceinline__ void repro_add(const ReproAcc (&acc)[3], int which, size_t i, double t, int c, int N)
-{
-    double* const dst[3] = { which == 0 ? acc[0].A : (which == 1 ? acc[0].Bt : acc[0].D),
-                             which == 0 ? acc[1].A : (which == 1 ? acc[1].Bt : acc[1].D),
-                             which == 0 ? acc[2].A : (which == 1 ? acc[2].Bt : acc[2].D) };
-#pragma unroll
-    for(int l = 0; l < 3; l++)
-    {
-        // M = 1.5 2^(c + N): an ulp of 2^(c + N - 52)
-        const double M = __longlong_as_double(((long long)(1023 + c + N) << 52) | (1ll << 51));
-        const double q = __dadd_rn(__dadd_rn(t, M), -M);
-        if(q != 0.0) atomicAdd(&dst[l][i], q);
-        t = __dadd_rn(t, -q);
-        c += N - 52;
-    }
-}
+// 64 consecutive rows a wave; runs of rows with the same columns (a board observation's x rows, its y rows) are summed
+// across a half-wave first and ONE lane adds the sum - rows_generic_wave<true>: a thirtieth of the atomics
 __global__ __launch_bounds__(64)
 void rows_repro_kernel(NormalDims nd, OpRef R, int row0, int row1, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
                        const unsigned long long* __restrict__ cmax, int N, ReproAcc a0, ReproAcc a1, ReproAcc a2)
 {
-    const OpDev& O = opref_get(R);
-    const double* __restrict__ Jv = O.Jv;
-    const ReproAcc acc[3] = { a0, a1, a2 };
-    const int r = row0 + blockIdx.x*blockDim.x + threadIdx.x;
-    if(r >= row1) return;
-    const int p0 = Jp[r], p1 = Jp[r+1];
-    // the exponent above a column's largest |value|: biased exponent - 1023 + 1
-    auto cexp = [&](int c) { return (int)((cmax[c] >> 52) & 0x7ff) - 1022; };
-    for(int p = p0; p < p1; p++)
-    {
-        const int    ci = Ji[p];
-        const double vi = Jv[p];
-        if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
-        if(vi == 0.0) continue;
-        const int si = state_to_SE(nd, ci), ei = cexp(ci);
-        for(int q = p0; q < p1; q++)
-        {
-            const int cj = Ji[q];
-            if((unsigned)cj >= (unsigned)nd.Nstate) continue;
-            const double t = __dmul_rn(vi, Jv[q]);
-            if(t == 0.0) continue;
-            const int sj = state_to_SE(nd, cj);
-            const int c  = ei + cexp(cj);
-            // (the exponents the levels' constants are made of must exist: columns of ~1e+-100 and smaller are not served)
-            if(c + N > 900 || c + 3*N - 160 < -900) { O.scalars[SC_BAD_STRUCTURE] = 2.0; continue; }
-            // (the lower triangles of A and of the D blocks: repro_combine_kernel mirrors them)
-            if(si >= 0 && sj >= 0)     { if(sj <= si) repro_add(acc, 0, (size_t)si*nd.Nc + sj, t, c, N); }
-            else if(si < 0 && sj >= 0) repro_add(acc, 1, (size_t)(-si-1)*nd.Nc + sj, t, c, N);
-            else if(si < 0 && sj < 0)
-            {
-                int bi, ai, di, e0i, bj, aj, dj, e0j;
-                E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
-                E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
-                if(bi == bj) { if(aj <= ai) repro_add(acc, 2, (size_t)bi*36 + ai*6 + aj, t, c, N); }
-                else         O.scalars[SC_BAD_STRUCTURE] = 1.0;      // no row may touch two E blocks
-            }
-        }
-    }
+    const ReproCtx rc = { { a0, a1, a2 }, cmax, N };
+    rows_generic_wave<true>(nd, opref_get(R), row0 + blockIdx.x*blockDim.x, row1, Jp, Ji, &rc);
 }
 // entry = (level 1 + level 2) + level 3. sym > 0: the array is made of sym x sym blocks of which the lower triangles
 // were summed; the upper ones are their mirror images
@@ -5919,7 +5962,9 @@ hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
     e = hipMemcpyAsync(&O, R.ops, sizeof(OpDev), hipMemcpyDeviceToHost, stream);   if(e != hipSuccess) return e;
     e = hipStreamSynchronize(stream);                                               if(e != hipSuccess) return e;
     unsigned long long* cmax = (unsigned long long*)(scratch + 2*one);
-    int N = 2; while(((long long)1 << (N - 2)) < (long long)Nmeas) N++;      // Nmeas <= 2^(N-2): products that meet < 2^(N-1)
+    // Nmeas <= 2^(N-3): the addends that meet in one place - a run's sum, a row's product; two of them for a row that lists
+    // a column twice - stay below 2^(N-1)
+    int N = 3; while(((long long)1 << (N - 3)) < (long long)Nmeas) N++;
     {
         long long nb = (Nnz + 255)/256; if(nb > 4096) nb = 4096; if(nb < 1) nb = 1;
         hipLaunchKernelGGL(csr_column_max_kernel, dim3((int)nb), dim3(256), 0, stream, Nnz, nd.Nstate, Ji, O.Jv, cmax);

@@ -128,7 +128,7 @@ def test_the_trajectory_is_the_restated_libdoglegs_step_for_step():
     # (the first line is the evaluation of the seed in the checker's count of steps? no: both count trial steps)
     ours = [(int(m.group(1)), float(m.group(2)), float(m.group(3)))
             for m in re.finditer(r"trial\s+\d+: accepted\s+(\d+) tr (\S+)\s+\|x\|\^2 (\S+)", err_a)]
-    assert len(ref) > 8 and len(ours) >= len(ref)
+    assert len(ref) > 8
     # the cost of the current point after each of the checker's trials: the new one if rho > 0, else the old one
     cost_ref = [b if rho > 0 else a for a, b, rho, tr in ref]
     naccepted_ref = np.cumsum([rho > 0 for a, b, rho, tr in ref])
@@ -137,6 +137,8 @@ def test_the_trajectory_is_the_restated_libdoglegs_step_for_step():
     n = 0
     while n < len(ref) and abs(ref[n][1] - ref[n][0]) > 1e-10*ref[n][0]: n += 1
     assert n >= 8, n
+    # (how many trials either solver goes on for behind those is rounding noise too: whoever's termination test fires first)
+    assert len(ours) >= n, (len(ours), n)
     naccepted_ref = naccepted_ref[:n]; cost_ref = cost_ref[:n]; ref = ref[:n]
     cost_a = np.array([c for k, tr, c in ours[:n]])
     assert np.array_equal(np.array([k for k, tr, c in ours[:n]]), naccepted_ref), "accept/reject decisions differ"

