@@ -77,6 +77,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     }
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
     hipFree(cperm_cur_alloc); hipFree(F.iso); hipFree(op[0].cperm); hipFree(op[1].cperm);
+    hipFree(plan.repro.lvl[0]); hipFree(plan.repro.lvl[1]); hipFree(plan.repro.lvl[2]); hipFree(plan.repro.cmax); hipFree(plan.repro.any);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
     if(h_ctl_ring) hipHostFree(h_ctl_ring);
@@ -300,7 +301,8 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     // touches a control point is a board's (no discrete points: they have no boxes) and all rows are here (not a shard:
     // the ranks of a sharded solve sum their camera blocks entry by entry). MRCAL_AMD_NO_SPL_COMPACT=1: off
     {
-        static const bool off = (getenv("MRCAL_AMD_NO_SPL_COMPACT") != NULL);
+        // (nor with the backward sweep of MRCAL_AMD_LCHOL_SWEEP, which knows nothing of a size the device decides)
+        static const bool off = (getenv("MRCAL_AMD_NO_SPL_COMPACT") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
         const bool whole = (int)P->board_sel.size() == L.dims.Nobservations_board && P->comm == NULL;
         if(!off && whole && L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && cholesky_large_workspace_doubles(nd.Nc) > 1 && nd.Nc <= 4096 &&
            P->D.Nobs_board > 0 && P->D.Nobs_point == 0 && P->D.Ndist_state > 0 && !nd.elim_extrinsics)
@@ -319,6 +321,22 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             P->F.cperm_cur = P->cperm_cur_alloc;
             P->plan.spl_compact = 1;
         }
+    }
+    // the rows of a splined problem that no plan covers: their three levels of pre-rounded sums (ReproStep), zero at rest
+    if(ok && splined_needs_repro_rows(P->D))
+    {
+        ReproStep& rs = P->plan.repro;
+        rs.one = (size_t)nd.Nc*nd.Nc + (size_t)nd.NE*nd.Nc + (size_t)nd.NEb*36 + (size_t)nd.Nstate + 1;
+        for(int l = 0; l < 3 && ok; l++)
+        {
+            ok = ok && dev_alloc(&rs.lvl[l], rs.one);
+            if(ok) HIP_TRY(hipMemset(rs.lvl[l], 0, rs.one*sizeof(double)), ok = false);
+        }
+        ok = ok && dev_alloc(&rs.cmax, (size_t)nd.Nstate + 1);
+        ok = ok && dev_alloc(&rs.any, 1);
+        if(ok) HIP_TRY(hipMemset(rs.cmax, 0, ((size_t)nd.Nstate + 1)*sizeof(unsigned long long)), ok = false);
+        if(ok) HIP_TRY(hipMemset(rs.any, 0, sizeof(int)), ok = false);
+        if(!ok) rs.lvl[0] = NULL;
     }
     {
         char* ctl = NULL;

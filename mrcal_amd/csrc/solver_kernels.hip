@@ -547,6 +547,13 @@ static bool spl_fallback_possible(const DeviceProblem& P)
     const int nsx = std::max(1, ((int)P.cfg.spline_Nx - order + T - 1)/T), nsy = std::max(1, ((int)P.cfg.spline_Ny - order + T - 1)/T);
     return nsx*nsy > SPL_MAXSUB || P.W*P.H > 1024;
 }
+bool splined_needs_repro_rows(const DeviceProblem& P)
+{
+    if(P.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) return false;
+    // discrete points whose rows' patch columns move with every evaluation, or a board that can cover more than the
+    // sub-boxes hold
+    return (P.Nobs_point > 0 && P.Ndist_state > 0) || (P.Nobs_board > 0 && P.Nframes > 0 && spl_fallback_possible(P));
+}
 #ifndef SPL_WAVES_PER_EU
 #define SPL_WAVES_PER_EU 2
 #endif
@@ -622,7 +629,9 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
             if(xy0 == 0)
             {
                 if(t == 0) plan.spl_hdr[o] = SplHdr{ 0, 0, -1, -1 };
-                spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
+                // (round 5: its rows go through the pre-rounded sums behind this launch, repro_step_*: the same bits
+                //  every time. Without their buffers - never, for a problem that can come here - row by row with atomics)
+                if(plan.repro.lvl[0] == NULL) spl_rows_fallback(nd, O, r0 + t, r1, Jp, Ji);
             }
             continue;
         }
@@ -1410,13 +1419,12 @@ void assemble_splined_combine_kernel(DeviceProblem P, NormalDims nd, OpRef R, As
     }
 }
 
-struct ReproAcc { double *A, *Bt, *D; };
+struct ReproAcc { double *A, *Bt, *D, *g, *n2; };      // (g, n2: the solver step's rows; NULL for a bare matrix)
 // t, below 2^c in magnitude, added to the three levels at offset i
 __device__ __forceinline__ void repro_add(const ReproAcc (&acc)[3], int which, size_t i, double t, int c, int N)
 {
-    double* const dst[3] = { which == 0 ? acc[0].A : (which == 1 ? acc[0].Bt : acc[0].D),
-                             which == 0 ? acc[1].A : (which == 1 ? acc[1].Bt : acc[1].D),
-                             which == 0 ? acc[2].A : (which == 1 ? acc[2].Bt : acc[2].D) };
+    auto pick = [&](const ReproAcc& a) { return which == 0 ? a.A : (which == 1 ? a.Bt : (which == 2 ? a.D : (which == 3 ? a.g : a.n2))); };
+    double* const dst[3] = { pick(acc[0]), pick(acc[1]), pick(acc[2]) };
 #pragma unroll
     for(int l = 0; l < 3; l++)
     {
@@ -1433,13 +1441,20 @@ struct ReproCtx { ReproAcc acc[3]; const unsigned long long* cmax; int N; };
 // one row, by one lane: the products of its entries, pair by pair, through repro_add()
 __device__ __forceinline__
 void rows_repro_row(const NormalDims& nd, const OpDev& O, int r, const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
-                    const ReproCtx& rc, int extra_bits)
+                    const ReproCtx& rc, int extra_bits, bool with_x = false /* g and |x|^2 too: x is column Nstate of cmax */)
 {
     const double* __restrict__ Jv = O.Jv;
     const int N = rc.N;
     const int p0 = Jp[r], p1 = Jp[r+1];
     // the exponent above a column's largest |value|: biased exponent - 1023 + 1
     auto cexp = [&](int c) { return (int)((rc.cmax[c] >> 52) & 0x7ff) - 1022; };
+    auto in_range = [&](int c) { return !(c + N > 900 || c + 3*N - 160 < -900); };
+    const double xr = with_x ? O.x[r] : 0.0;
+    const int    ex = with_x ? cexp(nd.Nstate) : 0;
+    if(with_x && xr != 0.0)
+    {
+        if(in_range(2*ex)) repro_add(rc.acc, 4, 0, __dmul_rn(xr, xr), 2*ex, N); else O.scalars[SC_BAD_STRUCTURE] = 2.0;
+    }
     for(int p = p0; p < p1; p++)
     {
         const int    ci = Ji[p];
@@ -1447,6 +1462,10 @@ void rows_repro_row(const NormalDims& nd, const OpDev& O, int r, const int32_t* 
         if((unsigned)ci >= (unsigned)nd.Nstate) { O.scalars[SC_BAD_STRUCTURE] = 1.0; continue; }
         if(vi == 0.0) continue;
         const int si = state_to_SE(nd, ci), ei = cexp(ci);
+        if(with_x && xr != 0.0)
+        {
+            if(in_range(ei + ex)) repro_add(rc.acc, 3, (size_t)ci, __dmul_rn(vi, xr), ei + ex, N); else O.scalars[SC_BAD_STRUCTURE] = 2.0;
+        }
         for(int q = p0; q < p1; q++)
         {
             const int cj = Ji[q];
@@ -1591,6 +1610,97 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
         todo = todo && !member;
     }
 }
+// ---- the rows of a splined problem that no plan covers, in the solver's step (ReproStep, solver_kernels.hpp) ----
+// which rows: the board observations assemble_splined_kernel marked (SplHdr::wx < 0: more than SPL_MAXSUB sub-boxes),
+// and the rows [rows_from, rows_to) (discrete points). Thread i: a board row for i < nboard, row rows_from + i - nboard
+__device__ __forceinline__
+int repro_step_row(const DeviceProblem& P, const AssemblyPlan& plan, int i, int nboard, int rows_from, int rows_to)
+{
+    if(i < nboard)
+    {
+        if(plan.spl_hdr == NULL || plan.spl_hdr[i/(2*P.W*P.H)].wx >= 0) return -1;
+        return i;
+    }
+    const int r = rows_from + (i - nboard);
+    return (r < rows_to) ? r : -1;
+}
+// pass 1: every column's largest |value| over those rows (the last column: x); any row at all -> *any
+__global__ __launch_bounds__(256)
+void repro_step_colmax_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nboard, int rows_from, int rows_to,
+                              const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+{
+    if(opref_skip(R)) return;
+    const OpDev& O = opref_get(R);
+    const int r = repro_step_row(P, plan, blockIdx.x*blockDim.x + threadIdx.x, nboard, rows_from, rows_to);
+    if(r < 0) return;
+    unsigned long long* __restrict__ cmax = plan.repro.cmax;
+    *plan.repro.any = 1;
+    for(int p = Jp[r]; p < Jp[r+1]; p++)
+    {
+        const int c = Ji[p];
+        if((unsigned)c >= (unsigned)nd.Nstate) continue;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(O.Jv[p]));
+        if(b > cmax[c]) atomicMax(&cmax[c], b);
+    }
+    const unsigned long long bx = (unsigned long long)__double_as_longlong(fabs(O.x[r]));
+    if(bx > cmax[nd.Nstate]) atomicMax(&cmax[nd.Nstate], bx);
+}
+__device__ __forceinline__ ReproCtx repro_step_ctx(const NormalDims& nd, const ReproStep& rs, int N)
+{
+    const size_t nA = (size_t)nd.Nc*nd.Nc, nB = (size_t)nd.NE*nd.Nc, nD = (size_t)nd.NEb*36;
+    ReproCtx rc;
+    for(int l = 0; l < 3; l++)
+    {
+        double* b = rs.lvl[l];
+        rc.acc[l] = ReproAcc{ b, b + nA, b + nA + nB, b + nA + nB + nD, b + nA + nB + nD + nd.Nstate };
+    }
+    rc.cmax = rs.cmax; rc.N = N;
+    return rc;
+}
+// pass 2: the products, pre-rounded, into the three levels (atomics whose order does not matter)
+__global__ __launch_bounds__(64)
+void repro_step_rows_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan, int nboard, int rows_from, int rows_to,
+                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int N)
+{
+    if(opref_skip(R)) return;
+    if(!*plan.repro.any) return;
+    const int r = repro_step_row(P, plan, blockIdx.x*blockDim.x + threadIdx.x, nboard, rows_from, rows_to);
+    if(r < 0) return;
+    const ReproCtx rc = repro_step_ctx(nd, plan.repro, N);
+    rows_repro_row(nd, opref_get(R), r, Jp, Ji, rc, 0, true);
+}
+// pass 3: entry += (level 1 + level 2) + level 3, the levels back to zero; the D blocks' lower triangles mirrored (the
+// levels hold them alone, like A's - whose upper triangle nobody reads for these models). Block 0 clears the maxima
+__global__ __launch_bounds__(256)
+void repro_step_combine_kernel(NormalDims nd, OpRef R, ReproStep rs)
+{
+    if(opref_skip(R)) return;
+    if(!*rs.any) return;
+    const OpDev& O = opref_get(R);
+    const size_t nA = (size_t)nd.Nc*nd.Nc, nB = (size_t)nd.NE*nd.Nc, nD = (size_t)nd.NEb*36;
+    for(size_t i = (size_t)blockIdx.x*blockDim.x + threadIdx.x; i < rs.one; i += (size_t)gridDim.x*blockDim.x)
+    {
+        const double l1 = rs.lvl[0][i], l2 = rs.lvl[1][i], l3 = rs.lvl[2][i];
+        if(l1 == 0.0 && l2 == 0.0 && l3 == 0.0) continue;
+        rs.lvl[0][i] = 0.0; rs.lvl[1][i] = 0.0; rs.lvl[2][i] = 0.0;
+        const double v = (l1 + l2) + l3;
+        size_t j = i;
+        if(j < nA) { O.A[j] += v; continue; }                     j -= nA;
+        if(j < nB) { O.Bt[j] += v; continue; }                    j -= nB;
+        if(j < nD)
+        {
+            O.D[j] += v;
+            const size_t blk = j/36, e = j - blk*36, a = e/6, b = e - a*6;
+            if(a != b) O.D[blk*36 + b*6 + a] += v;
+            continue;
+        }                                                         j -= nD;
+        if(j < (size_t)nd.Nstate) { O.g[j] += v; continue; }
+        O.scalars[SC_NORM2_X] += v;
+    }
+    if(blockIdx.x == 0)
+        for(int i = threadIdx.x; i <= nd.Nstate; i += blockDim.x) rs.cmax[i] = 0ull;
+}
+
 __global__ __launch_bounds__(64)
 void rows_generic_kernel(NormalDims nd, OpRef R, int row0, int row1,
                          const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
@@ -4698,6 +4808,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
         hipStream_t gstream = stream;
         const bool splined_boards = by_rows && P.Nobs_board > 0 && P.Nframes > 0;
         bool pairs_early = false;
+        // (round 5) rows no fixed-order plan covers go through sums in which no addition rounds (ReproStep): everything
+        // then stays on the one stream, the rows' sums are added to the blocks last
+        const bool repro = plan.repro.lvl[0] != NULL;
         if(splined_boards)
         {
             rows_from = 2*P.W*P.H*P.Nobs_board;
@@ -4707,7 +4820,7 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // - discrete points - that add to A with atomics at the same time)
             // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
             static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
-            const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !one_stream;
+            const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !one_stream && !repro;
             // Round 5: the regularization rows' pairs go FIRST on the side stream, beside assemble_splined_kernel (which
             // writes the frames' blocks and Bt, never A or the camera block's g): they were 10 us at the end of the side
             // stream's chain, which is the longer of the two the reduction waits for. A's entries then take the pairs'
@@ -4780,7 +4893,24 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                 hipLaunchKernelGGL(rows_single_kernel, dim3(1), dim3(256), 0, stream, nd, B.R, plan.gen.row_end, rows_to, B.Jp, B.Ji);
             planned = true;
         }
-        if(rows_to > rows_from && !planned)
+        if(repro)
+        {
+            // the marked board observations (where the grid is big enough for any) and the rows without a plan
+            const int nboard = (splined_boards && spl_fallback_possible(P)) ? 2*P.W*P.H*P.Nobs_board : 0;
+            const int r0 = planned ? rows_to : rows_from;
+            const int nthreads = nboard + std::max(0, rows_to - r0);
+            int N = 3; while(((long long)1 << (N - 3)) < (long long)P.Nmeas) N++;      // (as launch_assemble_rows)
+            hipError_t e = hipMemsetAsync(plan.repro.any, 0, sizeof(int), stream);
+            if(e != hipSuccess) return e;
+            if(nthreads > 0)
+            {
+                hipLaunchKernelGGL(repro_step_colmax_kernel, dim3((nthreads + 255)/256), dim3(256), 0, stream,
+                                   P, nd, B.R, plan, nboard, r0, rows_to, B.Jp, B.Ji);
+                hipLaunchKernelGGL(repro_step_rows_kernel, dim3((nthreads + 63)/64), dim3(64), 0, stream,
+                                   P, nd, B.R, plan, nboard, r0, rows_to, B.Jp, B.Ji, N);
+            }
+        }
+        else if(rows_to > rows_from && !planned)
         {
             // many rows on a small camera block: sum in LDS first (rows_generic_lds_kernel)
             if(nd.Nc <= ROWS_LDS_NC && rows_to - rows_from >= 4096)
@@ -4803,6 +4933,10 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
                 if(e != hipSuccess) return e;
             }
         }
+        // (the pre-rounded sums, onto whatever the blocks hold by now: the last adder of every entry)
+        if(repro)
+            hipLaunchKernelGGL(repro_step_combine_kernel, dim3((int)std::min<size_t>(2048, (plan.repro.one + 255)/256)), dim3(256), 0, stream,
+                               nd, B.R, plan.repro);
     }
     return hipGetLastError();
 }
@@ -5178,7 +5312,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
             if(separate) hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
             // (the splined models: the camera block as the reduction left it - without the control points no board covers)
             LcholCompact cp; memset(&cp, 0, sizeof(cp));
-            const bool compact = F.cperm_cur != NULL && !separate;
+            const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with MRCAL_AMD_LCHOL_SWEEP: problem_prepare_solver())
             if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
             launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused,
                                   compact ? F.cperm_cur + 2*n : (const int*)NULL, compact ? &cp : (const LcholCompact*)NULL);
@@ -5969,9 +6103,9 @@ hipError_t launch_assemble_rows(const NormalDims& nd, const OpRef& R, int Nmeas,
         long long nb = (Nnz + 255)/256; if(nb > 4096) nb = 4096; if(nb < 1) nb = 1;
         hipLaunchKernelGGL(csr_column_max_kernel, dim3((int)nb), dim3(256), 0, stream, Nnz, nd.Nstate, Ji, O.Jv, cmax);
     }
-    const ReproAcc a0 = { O.A, O.Bt, O.D };
-    const ReproAcc a1 = { scratch, scratch + nA, scratch + nA + nB };
-    const ReproAcc a2 = { scratch + one, scratch + one + nA, scratch + one + nA + nB };
+    const ReproAcc a0 = { O.A, O.Bt, O.D, NULL, NULL };
+    const ReproAcc a1 = { scratch, scratch + nA, scratch + nA + nB, NULL, NULL };
+    const ReproAcc a2 = { scratch + one, scratch + one + nA, scratch + one + nA + nB, NULL, NULL };
     hipLaunchKernelGGL(rows_repro_kernel, dim3((Nmeas + 63)/64), dim3(64), 0, stream, nd, R, 0, Nmeas, Jp, Ji, cmax, N, a0, a1, a2);
     if(nA > 0) hipLaunchKernelGGL(repro_combine_kernel, dim3((int)std::min<size_t>(2048, (nA + 255)/256)), dim3(256), 0, stream, nA, nd.Nc, O.A,  a1.A,  a2.A);
     if(nB > 0) hipLaunchKernelGGL(repro_combine_kernel, dim3((int)std::min<size_t>(2048, (nB + 255)/256)), dim3(256), 0, stream, nB, 0,     O.Bt, a1.Bt, a2.Bt);

@@ -179,9 +179,24 @@ struct GenPlan
     int*    eb_group;      // the group of each of those rows
     int*    eb_epos;       // position within the row of the block's first column
 };
+// Rows of a splined problem that no fixed-order plan covers (round 5): discrete points under a splined model whose
+// distortions are optimized (their patch columns move with every evaluation), and a board observation whose box of
+// control points is past SPL_MAXSUB sub-boxes. They used to add to A, Bt, D, g with floating-point atomics, in whatever
+// order they landed. Now: sums in which no addition rounds (the pre-rounded sums of launch_assemble_rows(): three levels
+// of [A | Bt | D | g | |x|^2], cleared and combined only when such rows exist), added to the blocks at a fixed place in
+// the launch order. lvl[0] == NULL: this problem cannot have such rows
+struct ReproStep
+{
+    double*             lvl[3];      // each `one` doubles: [A: Nc^2 | Bt: NE Nc | D: NEb 36 | g: Nstate | |x|^2: 1]; zero at rest
+    unsigned long long* cmax;        // [Nstate + 1] the bits of each column's largest |value| over those rows (the last: x); zero at rest
+    int*                any;         // [1] some row of this evaluation went this way
+    size_t              one;
+};
+bool splined_needs_repro_rows(const DeviceProblem& P);
 struct AssemblyPlan
 {
     GenPlan gen;
+    ReproStep repro;
     int  spl_compact;      // splined models: the evaluation's assembly also makes OpDev::cperm (spl_compact_kernel)
     int* frame_obs_begin;  // [blocks+1] the board observations of each 6x6 eliminated block (a frame: contiguous) ...
     int* frame_obs;        // ... or, if not NULL, entries [begin, end) of this list (a camera's, with elim_extrinsics)

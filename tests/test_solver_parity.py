@@ -184,6 +184,95 @@ def test_normal_equations_splined_with_points(amd):
     assert np.abs(N @ d + g).max() < 1e-6*max(np.abs(g).max(), 1.0)
 
 
+def _same_normal_equations_three_times(p):
+    runs = [p.normal_equations() for _ in range(3)]
+    for r in runs[1:]:
+        for k in ("A", "Bt", "D", "g"):
+            assert np.array_equal(r[k], runs[0][k]), k
+        assert r["norm2_x"] == runs[0]["norm2_x"]
+    return runs[0]
+
+
+def test_splined_points_with_optimized_distortions_are_bit_reproducible(amd):
+    """Round 5, the first of the two places where the order of floating-point atomics still showed: discrete points under
+    a splined model whose control points are optimized (a point row's 16 patch columns move with every evaluation: no
+    fixed-order plan). Their rows now go through sums in which no addition rounds (solver_kernels.hpp ReproStep): the
+    normal equations against JtJ, the same bits three times, and the same solve twice"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=2, Nframes=6,
+                                     lensmodel="LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120",
+                                     object_width_n=10, object_height_n=10, seed=29)
+    oi["do_optimize_intrinsics_core"] = False
+    oi = _with_points(oi, np.random.RandomState(3), Npoints=40)
+    oi["observations_point"][:,:2] = np.random.RandomState(4).uniform(700, 3300, size=oi["observations_point"][:,:2].shape)
+    oi["observations_point"][:,1]  = np.random.RandomState(5).uniform(500, 1700, size=oi["observations_point"].shape[0])
+    assert oi["do_optimize_intrinsics_distortions"]
+    with Problem(**copy_inputs(oi)) as p:
+        ne = _same_normal_equations_three_times(p)
+        J, x = p.J(), p.x()
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    assert np.abs(N_gpu - N).max() < 1e-10*np.abs(N).max()
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    runs = []
+    for i in range(2):
+        with Problem(**copy_inputs(oi)) as p:
+            s = p.solve()
+            runs.append((s["Niterations"], s["Nevaluations"], s["norm2_x"], p.b_packed()))
+    assert runs[0][:3] == runs[1][:3] and np.array_equal(runs[0][3], runs[1][3])
+    assert runs[0][0] > 3
+
+
+def test_splined_board_over_more_than_twelve_sub_boxes_is_bit_reproducible(amd):
+    """... and the second: a board observation whose box of control points is past the assembly's twelve sub-boxes - a
+    40 x 30 grid under a board that fills the imager. Its rows took the row-by-row atomics until round 5; now the same
+    pre-rounded sums: JtJ, the same bits three times, the same solve twice"""
+    from mrcal_amd.resident import Problem
+    LM, W, H, SP = "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=40_Ny=30_fov_x_deg=120", 15, 7, 0.15
+    oi, truth = make_calibration_problem(amd._api, Ncameras=1, Nframes=5, lensmodel=LM,
+                                         object_width_n=W, object_height_n=H, seed=31, object_spacing=SP)
+    oi["do_optimize_intrinsics_core"] = False
+    # frame 0: the board square in front of the camera, 0.75 m away - 2.1 m wide: all but the edge of the imager
+    rt0 = np.array((0.02, -0.03, 0.01, -(W-1)*SP/2., -(H-1)*SP/2., 0.75))
+    obs1 = np.zeros((1, H, W, 3)); obs1[...,2] = 1.
+    q = amd._api.optimizer_callback(intrinsics=truth["intrinsics"], rt_cam_ref=truth["rt_cam_ref"], rt_ref_frame=rt0[None],
+                                    observations_board=obs1, indices_frame_camintrinsics_camextrinsics=np.array(((0,0,-1),), dtype=np.int32),
+                                    lensmodel=LM, imagersizes=oi["imagersizes"], calobject_warp=truth["calobject_warp"],
+                                    calibration_object_spacing=SP, do_optimize_calobject_warp=False, do_apply_regularization=False,
+                                    no_jacobian=True, no_factorization=True)[1][:2*W*H].reshape(H, W, 2)
+    assert q[...,0].min() > 0 and q[...,0].max() < 3999 and q[...,1].min() > 0 and q[...,1].max() < 2199
+    oi["observations_board"][0,:,:,:2] = q + np.random.RandomState(6).normal(0, 0.3, q.shape)
+    oi["rt_ref_frame"][0] = rt0 + np.array((1e-3, -1e-3, 1e-3, 5e-3, -5e-3, 5e-3))
+    oi["observations_board"][2,1:3,4:6,2] = -1.
+    with Problem(**copy_inputs(oi)) as p:
+        ne = _same_normal_equations_three_times(p)
+        J, x = p.J(), p.x()
+    # the boxes: at least one observation must be past 12 sub-boxes of <= 10 x 10 that overlap by 3 (more than 31 x 24)
+    Nx, NPTS = 40, W*H
+    big = 0
+    Jc = J.tocsr()
+    for o in range(oi["indices_frame_camintrinsics_camextrinsics"].shape[0]):
+        rows = Jc[2*NPTS*o:2*NPTS*(o+1)]
+        cols = np.unique(rows.indices[rows.indices < 2*40*30])//2
+        if len(cols):
+            w, h = (cols % Nx).max() - (cols % Nx).min() + 1, (cols // Nx).max() - (cols // Nx).min() + 1
+            nsx, nsy = max(1, (w - 3 + 6)//7), max(1, (h - 3 + 6)//7)
+            big = max(big, nsx*nsy)
+    assert big > 12, f"the largest observation takes {big} sub-boxes: the test does not reach the rows it is about"
+    N, g = dense_normal(J, x)
+    N_gpu = blocks_to_dense(ne, p.Nstate)
+    assert np.abs(N_gpu - N).max() < 1e-10*np.abs(N).max()
+    assert np.abs(ne["g"] - g).max() < 1e-10*np.abs(g).max()
+    assert abs(ne["norm2_x"] - x @ x) < 1e-10*(x @ x)
+    runs = []
+    for i in range(2):
+        with Problem(**copy_inputs(oi)) as p:
+            s = p.solve()
+            runs.append((s["Niterations"], s["Nevaluations"], s["norm2_x"], p.b_packed()))
+    assert runs[0][:3] == runs[1][:3] and np.array_equal(runs[0][3], runs[1][3])
+
+
 @pytest.mark.parametrize("case", ("boards", "boards+points", "no-extrinsics-opt", "monocular"))
 def test_normal_equations_match_JtJ(amd, case):
     from mrcal_amd.resident import Problem
@@ -476,3 +565,36 @@ print("RESULT " + json.dumps(out))
         assert a["Noutliers"] == b["Noutliers"], (k, a["Noutliers"], b["Noutliers"])
         assert a["rms"] == b["rms"], (k, a["rms"], b["rms"])
         assert np.array_equal(np.array(a["b"]), np.array(b["b"])), k
+
+
+@pytest.mark.timeout(900)
+def test_solve_through_the_explicit_inverse_matches_the_backward_sweep(amd):
+    """the big camera block's solve ends with d = -L^-T z as a product with an explicitly formed L^-1
+    (launch_cholesky_large: no backward sweep), and multiplying by an explicit inverse is not backward stable - its error
+    grows with cond(L), and the splined camera blocks have cond(JtJ) ~ 1e13. Configuration 2 reduced to 200 frames,
+    solved in two processes - the default, and MRCAL_AMD_LCHOL_SWEEP=1 (the triangular sweep of rounds 2-3, which also
+    turns the compaction of the camera block off): the same outliers, the same optimum"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import mrcal_amd
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
+from mrcal_amd.resident import Problem
+oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
+                                 lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False)
+with Problem(**copy_inputs(oi)) as p:
+    d0 = p.gauss_newton_step()
+    s = p.solve()
+    print("RESULT " + json.dumps(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), d0=d0.tolist())))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for tag, env in (("inverse", {}), ("sweep", {"MRCAL_AMD_LCHOL_SWEEP": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    a, b = res["inverse"], res["sweep"]
+    print(f"inverse: {a['N']} iterations, rms {a['rms']!r}; sweep: {b['N']} iterations, rms {b['rms']!r}")
+    assert a["Nout"] == b["Nout"]
+    assert abs(a["rms"] - b["rms"]) < 1e-8*b["rms"]
+    assert np.abs(np.array(a["b"]) - np.array(b["b"])).max() < 1e-4
