@@ -67,6 +67,54 @@ __device__ __forceinline__ void thread_sum_fixed(int n, F&& v, double* __restric
         }
     }
 }
+// The same sums with the loads of SEVERAL of them in flight together (round 5): a thread's first U items of a sum are
+// asked for by chunk_load() - nothing is added yet -, the sums' chunks one after the other; chunk_add() then adds them
+// in index order, and thread_sum_fixed_from() goes on behind item U W the way thread_sum_fixed() does. The order of
+// every thread's additions is the one thread_sum_fixed() has (items t, t + W, t + 2 W, ...): the same bits; what
+// changes is that the choice's four sums wait for memory once between them instead of once or twice each
+template<int NOUT, int U, class F>
+__device__ __forceinline__ void chunk_load(int n, F&& v, double (&t)[U][NOUT])
+{
+#pragma unroll
+    for(int u = 0; u < U; u++)
+    {
+        const int i = threadIdx.x + u*blockDim.x;
+        v(i < n ? i : (n > 0 ? n - 1 : 0), t[u]);
+    }
+}
+template<int NOUT, int U>
+__device__ __forceinline__ void chunk_add(int n, const double (&t)[U][NOUT], double* __restrict__ acc)
+{
+#pragma unroll
+    for(int u = 0; u < U; u++)
+    {
+        const bool in = (int)(threadIdx.x + u*blockDim.x) < n;
+#pragma unroll
+        for(int k = 0; k < NOUT; k++) acc[k] += in ? t[u][k] : 0.0;
+    }
+}
+template<int NOUT, class F>
+__device__ __forceinline__ void thread_sum_fixed_from(int first, int n, F&& v, double* __restrict__ acc)
+{
+    constexpr int U = 8;
+    for(int i0 = first + threadIdx.x; i0 < n; i0 += U*blockDim.x)
+    {
+        double t[U][NOUT];
+#pragma unroll
+        for(int u = 0; u < U; u++)
+        {
+            const int i = i0 + u*blockDim.x;
+            v(i < n ? i : n - 1, t[u]);
+        }
+#pragma unroll
+        for(int u = 0; u < U; u++)
+        {
+            const bool in = i0 + u*(int)blockDim.x < n;
+#pragma unroll
+            for(int k = 0; k < NOUT; k++) acc[k] += in ? t[u][k] : 0.0;
+        }
+    }
+}
 template<int NOUT>
 __device__ __forceinline__ void block_sum_finish(double (&acc)[NOUT], double (&out)[NOUT], double* __restrict__ scratch /* [17][NOUT] */)
 {
@@ -155,19 +203,22 @@ ChooseOut dogleg_choose_scalars(const ChooseArgs& a, double* __restrict__ scratc
     if(derive || have_fresh)
     {
         double acc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        if(derive)
-        {
-            thread_sum_fixed<1>(nd.Nc, [&](int i, double (&t)[1]) { const double v = from.g[s_to_state(i)]; t[0] = v*v; }, acc + 0);
-            if(a.comm2 == NULL)
-                thread_sum_fixed<2>(a.qf_n, [&](int i, double (&t)[2]) { t[0] = a.qf_part[4*i]; t[1] = a.qf_part[4*i + 2]; }, acc + 1);
-        }
-        if(have_fresh)
-        {
-            thread_sum_fixed<2>(nd.Nc, [&](int i, double (&t)[2])
-                                { const int is = s_to_state(i); const double gn = from.step_gn[is]; t[0] = gn*gn; t[1] = gn*from.g[is]; }, acc + 3);
-            if(a.comm2 == NULL)
-                thread_sum_fixed<2>(a.dots_n, [&](int i, double (&t)[2]) { t[0] = a.dots_part[2*i]; t[1] = a.dots_part[2*i + 1]; }, acc + 5);
-        }
+        // (the four sums' loads in flight together, then their additions - each in its own, unchanged order)
+        constexpr int US = 4, UL = 16;          // a thread's first items of the short sums (the camera block) and of the long ones (the partials)
+        auto f_g2  = [&](int i, double (&t)[1]) { const double v = from.g[s_to_state(i)]; t[0] = v*v; };
+        auto f_qf  = [&](int i, double (&t)[2]) { t[0] = a.qf_part[4*i]; t[1] = a.qf_part[4*i + 2]; };
+        auto f_gn  = [&](int i, double (&t)[2]) { const int is = s_to_state(i); const double gn = from.step_gn[is]; t[0] = gn*gn; t[1] = gn*from.g[is]; };
+        auto f_dot = [&](int i, double (&t)[2]) { t[0] = a.dots_part[2*i]; t[1] = a.dots_part[2*i + 1]; };
+        const bool do_qf = derive && a.comm2 == NULL, do_dot = have_fresh && a.comm2 == NULL;
+        double t_g2[US][1], t_qf[UL][2], t_gn[US][2], t_dot[UL][2];
+        if(derive)     chunk_load<1, US>(nd.Nc,    f_g2,  t_g2);
+        if(do_qf)      chunk_load<2, UL>(a.qf_n,   f_qf,  t_qf);
+        if(have_fresh) chunk_load<2, US>(nd.Nc,    f_gn,  t_gn);
+        if(do_dot)     chunk_load<2, UL>(a.dots_n, f_dot, t_dot);
+        if(derive)     { chunk_add<1, US>(nd.Nc,    t_g2,  acc + 0); thread_sum_fixed_from<1>(US*blockDim.x, nd.Nc,    f_g2,  acc + 0); }
+        if(do_qf)      { chunk_add<2, UL>(a.qf_n,   t_qf,  acc + 1); thread_sum_fixed_from<2>(UL*blockDim.x, a.qf_n,   f_qf,  acc + 1); }
+        if(have_fresh) { chunk_add<2, US>(nd.Nc,    t_gn,  acc + 3); thread_sum_fixed_from<2>(US*blockDim.x, nd.Nc,    f_gn,  acc + 3); }
+        if(do_dot)     { chunk_add<2, UL>(a.dots_n, t_dot, acc + 5); thread_sum_fixed_from<2>(UL*blockDim.x, a.dots_n, f_dot, acc + 5); }
         block_sum_finish<7>(acc, o, scratch);
         if(a.comm2 != NULL) { o[1] = a.comm2[COMM2_GNG]; o[2] = a.comm2[COMM2_GGE]; o[5] = a.comm2[COMM2_GNE2]; o[6] = a.comm2[COMM2_GNE_GE]; }
     }
