@@ -316,7 +316,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
                 id[2*nd.Nc] = nd.Nc;
                 if(ok) HIP_TRY(hipMemcpy(P->op[i].cperm, id.data(), id.size()*sizeof(int), hipMemcpyHostToDevice), ok = false);
             }
-            ok = ok && dev_alloc(&P->cperm_cur_alloc, (size_t)2*nd.Nc + 1);
+            ok = ok && dev_alloc(&P->cperm_cur_alloc, (size_t)2*nd.Nc + 2);
             ok = ok && dev_alloc(&P->F.iso, (size_t)4*(nd.Nc/2 + 1) + nd.Nc + 2);
             P->F.cperm_cur = P->cperm_cur_alloc;
             P->plan.spl_compact = 1;

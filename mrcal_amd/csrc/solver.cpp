@@ -260,6 +260,24 @@ void absorb_ctl(mrcal_amd_problem* P, const SolverCtl& c)
     P->op[0].have_normal = P->op[1].have_normal = true;
 }
 
+// The splined models' compacted camera block (LcholCompact): how many of its factorization's launches the host
+// provides one by one - the panels of the coupled variables at THIS solve's first point; whatever a
+// later point needs beyond that is lchol_tail_kernel's. A function of the inputs alone, and the result of a step
+// does not depend on it
+static bool learn_likely_size(mrcal_amd_problem* P)
+{
+    if(P->F.cperm_cur == NULL) return true;
+    int n1 = 0;
+    HIP_TRY(hipMemcpyAsync(&n1, P->op[P->icur].cperm + 2*P->nd.Nc, sizeof(int), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    if(n1 <= 0 || n1 > P->nd.Nc) n1 = P->nd.Nc;
+    // (launch l = npanels is the closing one: launches 0 .. npanels of THIS size one by one)
+    P->F.lchol_likely_panels = (n1 + 63)/64;
+    // (MRCAL_AMD_LCHOL_LIKELY=k: k instead - the tests make lchol_tail_kernel do the work with it)
+    if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) P->F.lchol_likely_panels = k; }
+    return true;
+}
+
 // libdogleg's main loop. The host only keeps the queue fed and looks, a few
 // steps behind, at whether the device has declared the solve finished. On
 // return op[P->icur] is the final operating point
@@ -267,6 +285,7 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
 {
     if(!ctl_reset(P, prm, true)) return false;
     if(!enqueue_initial_point(P)) return false;
+    if(!learn_likely_size(P)) return false;
 
     const int LAG = 3;      // how many steps the host may run ahead of what it has seen
     // verbose (mrcal.c:6291 turns on libdogleg's per-iteration report with it), or the environment
@@ -642,6 +661,7 @@ int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trus
     {
         if(!ctl_reset(P, prm, false)) return -1;
         if(!enqueue_initial_point(P)) return -1;
+        if(!learn_likely_size(P)) return -1;
     }
     for(int n = 0; n < Nsteps; n++)
         if(!queue_trial_step(P)) return -1;

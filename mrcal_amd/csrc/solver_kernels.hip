@@ -3505,8 +3505,10 @@ __device__ __forceinline__ int lchol_n(const int* __restrict__ n_dev, int n_host
 __global__ __launch_bounds__(LCH_THREADS)
 void lchol_diag_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M, int j0,
                        double* __restrict__ Linv, int* __restrict__ status, int with_finish, Step2Dev sd,
-                       const double* __restrict__ iso, int iso_Nc)
+                       const double* __restrict__ iso, int iso_Nc, unsigned* __restrict__ tail_counter)
 {
+    // (lchol_tail_kernel's barrier counts from zero: cleared here, launches ahead of it, instead of by a memset of its own)
+    if(tail_counter != NULL && threadIdx.x == 0) *tail_counter = 0u;
     if(with_finish) { if(!step2_finish(sd, status)) return; }
     else if(skip != NULL && *skip) return;
     __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
@@ -3840,15 +3842,11 @@ __device__ __forceinline__ int lchol_n(const int* __restrict__ n_dev, int n_host
     const int n = *n_dev;
     return (n > 0 && n <= n_host) ? n : n_host;
 }
-__global__ __launch_bounds__(LCH_THREADS)
-void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
-                        int l, double* __restrict__ Linv, int* __restrict__ status, int with_inverse)
+// workgroup bk of launch l (plan q)
+__device__ __forceinline__
+void lchol_panel_body(int n, int l, const LcholPlan& q, int bk, double* __restrict__ M, double* __restrict__ Linv,
+                      int* __restrict__ status, bool with_inverse, double* __restrict__ lds)
 {
-    if(skip != NULL && *skip) return;
-    const int n = lchol_n(n_dev, n_host);
-    const LcholPlan q = lchol_plan(n, l, with_inverse != 0);
-    if((int)blockIdx.x >= q.nblocks) return;
-    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
     static_assert(LCH_LDS_DOUBLES >= 3*LCH_NB*(LCH_NB+1), "the tile workgroups take three 64 x 65 arrays");
     double* __restrict__ MI = lds;
     double* __restrict__ MC = MI + LCH_NB*(LCH_NB+1);
@@ -3858,7 +3856,7 @@ void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __
     double* __restrict__ zc = with_inverse ? Yb + (size_t)q.npad*q.npad : (double*)NULL;
     const double* __restrict__ X     = Linv + (size_t)((l < q.npanels) ? l : 0)*LCH_NB*LCH_NB;
     const double* __restrict__ Xprev = Linv + (size_t)q.pprev*LCH_NB*LCH_NB;
-    const int b = (int)blockIdx.x - 1;
+    const int b = bk - 1;
     if(b < 0)
     {
         if(q.has_next) lchol_diag_block(n, M, q.j0 + LCH_NB, Linv + (size_t)(l + 1)*LCH_NB*LCH_NB, status, X, q.j0, lds);
@@ -3878,6 +3876,64 @@ void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __
         const int w = b - q.ntiles - q.ntrsm - q.nchain;
         const int nq = q.krow + 1;
         lchol_inverse_block(n, q.npad, M, Linv, Yb, q.krow + 2 + w/nq, w % nq, q.krow, false, MI, MC, Xs);
+    }
+}
+__global__ __launch_bounds__(LCH_THREADS)
+void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
+                        int l, double* __restrict__ Linv, int* __restrict__ status, int with_inverse)
+{
+    if(skip != NULL && *skip) return;
+    const int n = lchol_n(n_dev, n_host);
+    const LcholPlan q = lchol_plan(n, l, with_inverse != 0);
+    if((int)blockIdx.x >= q.nblocks) return;
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    lchol_panel_body(n, l, q, blockIdx.x, M, Linv, status, with_inverse != 0, lds);
+}
+// The launches past the ones the host provided one by one, in ONE (round 5): with the size of the matrix decided on
+// the device (LcholCompact) the host provides launches for the size it finds likely - the coupled variables of the
+// solve's first point and a panel to spare - and this kernel for whatever is left: usually nothing (it returns), else
+// panel by panel with a barrier over its workgroups where a launch boundary would be. A step's result does not depend
+// on which of the two ways a panel was done. (Nineteen launches for a matrix that needs eleven cost 5 us apiece -
+// workgroups of 100 KB of LDS that are dispatched to find out they have nothing to do)
+#define LCH_TAIL_WGS 96
+__device__ __forceinline__ void lchol_grid_barrier(unsigned* __restrict__ counter, unsigned nwg, unsigned epoch, int* __restrict__ status)
+{
+    __syncthreads();
+    if(threadIdx.x == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch*nwg;
+        int spins = 0;
+        while(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        {
+            __builtin_amdgcn_s_sleep(8);
+            if(++spins > (1 << 23)) { atomicExch(status, 3); break; }        // (a workgroup that never came: not a hang)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(LCH_THREADS)
+void lchol_tail_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
+                       int l_first, double* __restrict__ Linv, int* __restrict__ status, int with_inverse, unsigned* __restrict__ counter)
+{
+    if(skip != NULL && *skip) return;
+    const int n = lchol_n(n_dev, n_host);
+    const int npanels = (n + LCH_NB - 1)/LCH_NB;
+    if(l_first > npanels) return;                       // (every workgroup finds the same)
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    unsigned epoch = 0;
+    for(int l = l_first; l <= npanels; l++)
+    {
+        const LcholPlan q = lchol_plan(n, l, with_inverse != 0);
+        for(int bk = blockIdx.x; bk < q.nblocks; bk += gridDim.x)
+        {
+            lchol_panel_body(n, l, q, bk, M, Linv, status, with_inverse != 0, lds);
+            __syncthreads();                            // (the LDS is the next block's)
+        }
+        lchol_grid_barrier(counter, gridDim.x, ++epoch, status);
     }
 }
 
@@ -4098,7 +4154,9 @@ static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB
 // its isolated variables, whose number follows the boards). The launches and their grids are those of n; a launch past
 // the device's last panel finds nothing to do
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
-                                 const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL)
+                                 const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL,
+                                 int likely_panels = 0 /* with n_dev: launches 0 .. likely_panels one by one, the rest in lchol_tail_kernel; 0: all one by one */,
+                                 unsigned* tail_counter = NULL)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
     // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
@@ -4110,8 +4168,11 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     const bool fuse = (sd != NULL && !sweep);
     if(fused != NULL) *fused = fuse;
     hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n_dev, n, skip, M, 0, Linv, status,
-                       fuse ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0);
-    for(int l = 0; l <= npanels; l++)
+                       fuse ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0,
+                       (n_dev != NULL) ? tail_counter : (unsigned*)NULL);
+    const bool with_tail = n_dev != NULL && tail_counter != NULL && likely_panels > 0 && likely_panels < npanels && !sweep;
+    const int  l_last = with_tail ? likely_panels : npanels;
+    for(int l = 0; l <= l_last; l++)
     {
         const LcholPlan q = lchol_plan(n, l, !sweep);
         // (with a size the device decides, a launch that is a panel's at n may be the closing one there: its grid covers both)
@@ -4122,6 +4183,9 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         hipLaunchKernelGGL(lchol_panel_kernel, dim3(nblocks), dim3(LCH_THREADS), 0, stream,
                            n_dev, n, skip, M, l, Linv, status, sweep ? 0 : 1);
     }
+    if(with_tail)
+        hipLaunchKernelGGL(lchol_tail_kernel, dim3(LCH_TAIL_WGS), dim3(LCH_THREADS), 0, stream,
+                           n_dev, n, skip, M, l_last + 1, Linv, status, 1, tail_counter);
     if(!sweep)
     {
         const int niso_blocks = (compact != NULL) ? (n/2 + 1 + 255)/256 : 0;
@@ -5315,7 +5379,8 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
             const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with MRCAL_AMD_LCHOL_SWEEP: problem_prepare_solver())
             if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
             launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused,
-                                  compact ? F.cperm_cur + 2*n : (const int*)NULL, compact ? &cp : (const LcholCompact*)NULL);
+                                  compact ? F.cperm_cur + 2*n : (const int*)NULL, compact ? &cp : (const LcholCompact*)NULL,
+                                  compact ? F.lchol_likely_panels : 0, compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL);
             if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
             else if(!fused) return hipErrorInvalidValue;
         }

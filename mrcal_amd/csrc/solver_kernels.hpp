@@ -94,7 +94,8 @@ struct FactorBuffers
     int*    status;   // [1] nonzero: not positive definite
     unsigned* occ;    // [NEb][occ_words(nd)] bit per 16-column tile of the camera block: does the block's Wt hold a nonzero there?
                       // Written by eblock_factor_kernel, read by the sparse SYRK (the splined models). NULL: not tracked
-    int*    cperm_cur; // [2 Nc + 1] the permutation (OpDev::cperm) of the point whose camera block was reduced last: what the
+    int     lchol_likely_panels; // with cperm_cur: the factorization's launches the host provides one by one (the rest: lchol_tail_kernel); 0: all
+    int*    cperm_cur; // [2 Nc + 2] (the last word: lchol_tail_kernel's barrier) the permutation (OpDev::cperm) of the point whose camera block was reduced last: what the
                       // factorization and the solve behind that reduction go by. NULL: no compaction
     double* iso;      // with cperm_cur: [4 (Nc/2 + 1)] the 2 x 2 blocks of the isolated pairs (s00, s10, s11, -) | [Nc] their rhs
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -

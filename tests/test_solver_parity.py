@@ -598,3 +598,37 @@ with Problem(**copy_inputs(oi)) as p:
     assert a["Nout"] == b["Nout"]
     assert abs(a["rms"] - b["rms"]) < 1e-8*b["rms"]
     assert np.abs(np.array(a["b"]) - np.array(b["b"])).max() < 1e-4
+
+
+@pytest.mark.timeout(900)
+def test_factorization_launches_and_tail_kernel_give_the_same_bits(amd):
+    """The splined models' compacted camera block (solver_kernels.hip LcholCompact): the size of the matrix that is
+    factored follows the boards, the host provides the launches of the size the solve's first point has, and whatever a
+    later point needs beyond those is done by ONE kernel with barriers over its workgroups where the launch boundaries
+    would be (lchol_tail_kernel). Which of the two ways a panel is done must not show: configuration 2 reduced to 200
+    frames solved as it is, with all but the first two panels left to the tail kernel (MRCAL_AMD_LCHOL_LIKELY=2), and
+    without the compaction at all (MRCAL_AMD_NO_SPL_COMPACT=1: the 1206-variable matrix, 554 pivots of which are the
+    uncovered control points' own 2 x 2 blocks) - the first two to the last bit, the third to what another order of the
+    pivots leaves"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import mrcal_amd
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
+from mrcal_amd.resident import Problem
+oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
+                                 lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False)
+with Problem(**copy_inputs(oi)) as p:
+    s = p.solve()
+    print("RESULT " + json.dumps(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist())))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for tag, env in (("launches", {}), ("tail", {"MRCAL_AMD_LCHOL_LIKELY": "2"}), ("whole", {"MRCAL_AMD_NO_SPL_COMPACT": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    a, b, c = res["launches"], res["tail"], res["whole"]
+    assert (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"]
+    assert a["Nout"] == c["Nout"] and abs(a["rms"] - c["rms"]) < 1e-8*c["rms"]
+    assert np.abs(np.array(a["b"]) - np.array(c["b"])).max() < 1e-4
