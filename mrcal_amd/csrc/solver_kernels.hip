@@ -557,12 +557,27 @@ bool splined_needs_repro_rows(const DeviceProblem& P)
 #ifndef SPL_WAVES_PER_EU
 #define SPL_WAVES_PER_EU 2
 #endif
+__device__ __forceinline__ void rows_pairs_body(const NormalDims& nd, const OpDev& O, int row0, int row1, const int32_t* __restrict__ Jp,
+                                                const int32_t* __restrict__ Ji, double* __restrict__ row_part, int block);
+__device__ __forceinline__ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c);
+// Riding along behind the frames' workgroups (round 5; they were launches of their own on the side stream, behind a fork
+// that cost the main stream 8 us): `npairs_extra` workgroups of rows_pairs_body() - the regularization rows from
+// pairs_row0 on, which write the camera block's A and g: nothing this kernel's own workgroups touch (never where they can
+// fall back to row-by-row atomics: the launcher sees to it) - and, if compact_extra, one of spl_compact_body()
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SPL_WAVES_PER_EU)))
 void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPlan plan,
-                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+                             const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji,
+                             int npairs_extra, int pairs_row0, int compact_extra)
 {
     if(opref_skip(R)) return;
     __shared__ __attribute__((aligned(16))) double Jd[SPL_LDS_DOUBLES];     // [rows][LD] of a pass
+    if((int)blockIdx.x >= 2*P.Nframes)
+    {
+        const int e = (int)blockIdx.x - 2*P.Nframes;
+        if(e < npairs_extra)   rows_pairs_body(nd, opref_get(R), pairs_row0, P.Nmeas, Jp, Ji, plan.row_part, e);
+        else if(compact_extra) spl_compact_body(P, nd, opref_get(R), (int*)Jd);
+        return;
+    }
     __shared__ double F[7*SPL_TW];          // the frame rows and the x row of a pass's Gram
     __shared__ double FD[7*6];              // the frame's own block and its part of the gradient, summed over the passes
     __shared__ unsigned char own[1024];     // sub-boxes: which of them a corner belongs to
@@ -1283,14 +1298,12 @@ void assemble_splined_gather_knots_kernel(DeviceProblem P, NormalDims nd, OpRef 
 // Rows 2 i and 2 i + 1 share their columns; no two PAIRS do. One lane per pair, the pair's rows one after the
 // other, plain adds: the same bits every time. (Row by row with atomics, the two rows of a knot race.) |x|^2 of a
 // workgroup's rows goes to row_part[blockIdx.x]; the combine kernel adds those in order. Lower triangle of A only
-__global__ __launch_bounds__(256)
-void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
-                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, double* __restrict__ row_part)
+__device__ __forceinline__
+void rows_pairs_body(const NormalDims& nd, const OpDev& O, int row0, int row1,
+                     const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, double* __restrict__ row_part, int block)
 {
-    if(opref_skip(R)) return;
-    const OpDev& O = opref_get(R);
     const double* __restrict__ Jv = O.Jv;
-    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    const int i = block*blockDim.x + threadIdx.x;
     double n2 = 0.0;
     for(int k = 0; k < 2; k++)
     {
@@ -1320,7 +1333,14 @@ void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
     __shared__ double part[4];
     if((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n2;
     __syncthreads();
-    if(threadIdx.x == 0) row_part[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    if(threadIdx.x == 0) row_part[block] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256)
+void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
+                       const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, double* __restrict__ row_part)
+{
+    if(opref_skip(R)) return;
+    rows_pairs_body(nd, opref_get(R), row0, row1, Jp, Ji, row_part, blockIdx.x);
 }
 // Which control points does a board cover at this point? (Round 5.) The others have their regularization rows and
 // nothing else: a 2 x 2 block of the camera block each, coupled to nothing - and in the Cholesky of the camera block
@@ -1331,14 +1351,11 @@ void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
 // factorization's launches past the coupled part's last panel find nothing to do (lchol_plan()).
 // One workgroup: the observations' boxes (OpDev::spl_box, left by board_splined_kernel) marked in LDS, then a scan over
 // the camera block's variables. cperm: [Nc] position -> variable | [Nc] variable -> position | [1] the coupled ones
-#define SPLC_T 1024
-__global__ __launch_bounds__(SPLC_T)
-void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R)
+#define SPLC_T 256
+__device__ __forceinline__
+void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c /* [Nknots_all] used | [SPLC_T/64] wave totals */)
 {
-    if(opref_skip(R)) return;
-    const OpDev& O = opref_get(R);
     if(O.cperm == NULL) return;
-    extern __shared__ int lds_c[];                       // [Nknots_all] used | [SPLC_T/64] wave totals
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int Nx = P.cfg.spline_Nx, Ny = P.cfg.spline_Ny, NK = Nx*Ny;
     const int nknots = P.Ncameras_intrinsics*NK;
@@ -1391,6 +1408,13 @@ void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R)
         perm[pos] = c; iperm[c] = pos;
     }
     if(t == 0) O.cperm[2*nd.Nc] = n1;
+}
+__global__ __launch_bounds__(SPLC_T)
+void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R)
+{
+    if(opref_skip(R)) return;
+    extern __shared__ int lds_cc[];
+    spl_compact_body(P, nd, opref_get(R), lds_cc);
 }
 
 // the SPLG_E parts of a row every pass holds, in order; and |x|^2 of the regularization rows
@@ -4899,23 +4923,18 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // (not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
             //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
             //  plain read-modify-writes must not run beside those)
-            if(use_side && ev_fork0 != NULL && nrp_early > 0 && !pairs_late && !spl_fallback_possible(P))
-            {
-                hipError_t e = hipEventRecord(ev_fork0, stream);          if(e != hipSuccess) return e;
-                e = hipStreamWaitEvent(side, ev_fork0, 0);                if(e != hipSuccess) return e;
-                hipLaunchKernelGGL(rows_pairs_kernel, dim3(nrp_early), dim3(256), 0, side, nd, B.R, rows_to, P.Nmeas, B.Jp, B.Ji, plan.row_part);
-                pairs_early = true;
-                if(compact_pending)
-                {
-                    hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), side, P, nd, B.R);
-                    compact_pending = false;
-                }
-            }
-            if(compact_pending)
+            // (in the assembly's own launch, behind the frames' workgroups: on the side stream behind a fork of its own - the
+            //  first form of this round - the fork cost the main stream 8 us: profiles/r05_config2_step_in_time_order.txt has
+            //  the gaps the other fork and the join still cost)
+            const bool pairs_ride   = nrp_early > 0 && !pairs_late && !spl_fallback_possible(P) && rows_to == rows_from;
+            const bool compact_ride = compact_pending && (size_t)(nknots_all + SPLC_T/64)*sizeof(int) <= SPL_LDS_DOUBLES*sizeof(double);
+            if(compact_pending && !compact_ride)
                 hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), stream, P, nd, B.R);
+            pairs_early = pairs_ride;
+            (void)ev_fork0;
             // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
-            hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes), dim3(256), 0, stream,
-                               P, nd, B.R, plan, B.Jp, B.Ji);
+            hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes + (pairs_ride ? nrp_early : 0) + (compact_ride ? 1 : 0)), dim3(256), 0, stream,
+                               P, nd, B.R, plan, B.Jp, B.Ji, pairs_ride ? nrp_early : 0, rows_to, compact_ride ? 1 : 0);
             // a copy of the row per wave, as many waves as the LDS holds copies
             const size_t row_bytes = (size_t)(nd.Nc + 1)*sizeof(double);
             const int nwaves = (int)std::min<size_t>(SPLG_WAVES, (size_t)(150*1024)/row_bytes);
