@@ -311,9 +311,10 @@ def main():
     if args.warmup > 0:
         _, tr = problem.run_steps(args.warmup, tr)
     sync_all()
-    # an event pair around a launch costs the stream ~11 us (5.6 on each side of the kernel): every 4th launch of
-    # the dominant kernel is timed, not every one (which lengthened the measured step by those 11 us)
-    TIMED_EVERY = 4
+    # an event pair around a launch costs the stream ~11 us (5.6 on each side of the kernel): every 8th launch of
+    # the dominant kernel is timed (7 of the default run's 56), not every one (which lengthened the measured step by
+    # those 11 us; every 4th, until round 5, by 2.8)
+    TIMED_EVERY = 8 if args.steps >= 40 else (4 if args.steps >= 16 else 1)      # (short runs: enough launches to average)
     problem.jacobian_timing_begin(args.steps//TIMED_EVERY + 4, TIMED_EVERY)
     t0 = time.perf_counter()
     n, tr = problem.run_steps(args.steps, tr)
