@@ -88,7 +88,6 @@ mrcal_amd_problem::~mrcal_amd_problem()
     if(ev_j1)  hipEventDestroy(ev_j1);
     if(ev_fork) hipEventDestroy(ev_fork);
     if(ev_join) hipEventDestroy(ev_join);
-    if(ev_fork0) hipEventDestroy(ev_fork0);
     if(side_stream) hipStreamDestroy(side_stream);
     if(stream) hipStreamDestroy(stream);
 }
@@ -1005,7 +1004,6 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     HIP_TRY(hipStreamCreateWithFlags(&P->side_stream, hipStreamNonBlocking), ok = false);
     HIP_TRY(hipEventCreateWithFlags(&P->ev_fork, hipEventDisableTiming), ok = false);
     HIP_TRY(hipEventCreateWithFlags(&P->ev_join, hipEventDisableTiming), ok = false);
-    HIP_TRY(hipEventCreateWithFlags(&P->ev_fork0, hipEventDisableTiming), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j0), ok = false);
     HIP_TRY(hipEventCreate(&P->ev_j1), ok = false);
 
@@ -1290,7 +1288,6 @@ bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* p, int
             HIP_TRY(hipMalloc((void**)&p->d_fused_ts, (size_t)8*capacity*sizeof(unsigned long long)), return false);
             p->fused_ts_capacity = capacity;
         }
-        // [first store: min over the sampled waves | end: max]
         // [first Jacobian store: min over the sampled waves | end: max | the launch's first workgroup starts: min | the pose workgroups are through: max]
         std::vector<unsigned long long> init((size_t)8*p->fused_ts_capacity, 0ull);     // ([4..7]: -DFUSED_TS builds)
         for(int i = 0; i < p->fused_ts_capacity; i++) { init[8*i] = ~0ull; init[8*i+2] = ~0ull; }

@@ -43,7 +43,7 @@ struct mrcal_amd_problem
     // a second stream for work of a step that nothing on the first one waits for at once (the gather of the
     // splined assembly runs beside the block elimination and the SYRK): fork / join events
     hipStream_t side_stream = NULL;
-    hipEvent_t  ev_fork = NULL, ev_join = NULL, ev_fork0 = NULL;
+    hipEvent_t  ev_fork = NULL, ev_join = NULL;
     bool        have_jacobian_timing = false;
     bool        capturing = false;      // a hipGraph capture is in progress on the stream
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region
@@ -51,9 +51,10 @@ struct mrcal_amd_problem
     int         ev_pool_used = 0;
     int         ev_pool_seen = 0, ev_pool_stride = 1;      // launches since _begin(); every stride-th one is timed
     bool        ev_pool_enabled = false;
-    // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
-    // ([launch][2]: the first Jacobian store, the end, wall_clock64 ticks of 10 ns), and what _timing_end() made of them
     int*                cperm_cur_alloc = NULL;    // what F.cperm_cur points at while the compaction is on (a communicator turns it off)
+    // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
+    // ([launch][8]: the first Jacobian store, the end, the launch's start, the poses through, wall_clock64 ticks of 10 ns;
+    // [4..7]: -DFUSED_TS builds), and what _timing_end() made of them
     unsigned*           d_fused_ready = NULL;
     unsigned long long* d_fused_ts    = NULL;
     int                 fused_ts_capacity = 0;

@@ -111,7 +111,7 @@ Step2Args step2_args(mrcal_amd_problem* P)
     a.Jp = P->d_Jp; a.Ji = P->d_Ji; a.step = P->d_step; a.is_leader = P->is_leader;
     a.comm2 = (P->comm != NULL || P->sharded_external) ? P->d_comm : NULL;
     a.snap  = P->capturing ? NULL : P->snap_target;
-    a.side = P->side_stream; a.ev_fork = P->ev_fork; a.ev_join = P->ev_join; a.ev_fork0 = P->ev_fork0;
+    a.side = P->side_stream; a.ev_fork = P->ev_fork; a.ev_join = P->ev_join;
     return a;
 }
 
@@ -141,6 +141,13 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
     return true;
 }
 
+// SolverCtl::error, in words
+static const char* solver_error_text(int error)
+{
+    return error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record" :
+           error == 3 ? "internal error: a control point taken for uncovered by every board is coupled to other variables (spl_compact_kernel)" :
+                        "could not make JtJ positive definite";
+}
 // does a trial step of this problem take ONE launch for the choice, the prologue and the board kernel?
 static bool step_is_fused(const mrcal_amd_problem* P)
 {
@@ -357,8 +364,7 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     if(!read_ctl(P, &c)) return false;
     if(c.error)
     {
-        set_error(c.error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record"
-                               : "could not make JtJ positive definite");
+        set_error("%s", solver_error_text(c.error));
         return false;
     }
     if(!c.done)
@@ -667,7 +673,7 @@ int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trus
         if(!queue_trial_step(P)) return -1;
     SolverCtl c;
     if(!read_ctl(P, &c)) return -1;
-    if(c.error) { set_error(c.error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record" : "could not make JtJ positive definite"); return -1; }
+    if(c.error) { set_error("%s", solver_error_text(c.error)); return -1; }
     absorb_ctl(P, c);
     P->stats.Nevaluations    = c.Nevaluations;
     P->stats.Nfactorizations = c.Nfactorizations;

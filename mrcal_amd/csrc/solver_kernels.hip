@@ -2201,7 +2201,8 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
                        double* __restrict__ S, double* __restrict__ r, int block,
                        const unsigned char* __restrict__ live = NULL /* [nslots][npairs]: the slot holds the tile (sparse SYRK); NULL: all do */,
                        double* __restrict__ iso = NULL /* given: S goes out COMPACTED by O.cperm (LcholCompact): the coupled
-                                                         variables' n' x n' matrix with its rhs as row n', the isolated pairs' blocks here */)
+                                                         variables' n' x n' matrix with its rhs as row n', the isolated pairs' blocks here */,
+                       int* __restrict__ err = NULL /* with iso: set to 3 if an entry that the compaction has no place for is not zero */)
 {
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
@@ -2278,7 +2279,7 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
                 if(pi < n1 && pj < n1) S[(size_t)max(pi, pj)*n1 + min(pi, pj)] = v;
                 else if(pi >= n1 && pj >= n1 && ((pi - n1) >> 1) == ((pj - n1) >> 1))
                     iso[4*((pi - n1) >> 1) + ((pi - n1) & 1) + ((pj - n1) & 1)] = v;      // (0,0) -> 0, (1,0) -> 1, (1,1) -> 2
-                else if(v != 0.0) O.scalars[SC_BAD_STRUCTURE] = 3.0;       // an isolated variable that is coupled after all
+                else if(v != 0.0 && err != NULL) *err = 3;                  // an isolated variable that is coupled after all: the solve fails, loudly
             }
         }
     }
@@ -4199,7 +4200,6 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     for(int l = 0; l <= l_last; l++)
     {
         const LcholPlan q = lchol_plan(n, l, !sweep);
-        // (with a size the device decides, a launch that is a panel's at n may be the closing one there: its grid covers both)
         // (with a size the device decides, a launch that is a panel's at n may be the closing one there, or nothing: the
         //  plan of n has the workgroups for either - lchol_plan() grows with n term by term)
         const int nblocks = q.nblocks;
@@ -4579,7 +4579,8 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
                          const SolverCtlFlags* __restrict__ fl, int is_leader, int nred,
                          int nslots, const double* __restrict__ Spart,
                          double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status,
-                         const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso)
+                         const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso,
+                         int* __restrict__ err /* SolverCtl::error */)
 {
     if(fl->skip_elim) return;
     const OpDev& O = ops[fl->elim_sel];
@@ -4590,7 +4591,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         // sum over the ranks (step2_finish unpacked it): the leader alone adds it
         const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
         schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live,
-                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL);
+                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL, err);
         return;
     }
     // (the permutation this reduction went by, for the factorization and the solve behind it: which of the two
@@ -4867,7 +4868,7 @@ static hipError_t launch_gen_finalize(const NormalDims& nd, const AssemblyPlan& 
 //   assemble_finalize (here: its own launch; in the fused step it rides along in the SYRK launch)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream,
-                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool* forked, hipEvent_t ev_fork0)
+                           hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool* forked)
 {
     if(forked) *forked = false;
     // splined models: no per-observation Gram; every row goes through the generic path
@@ -4909,29 +4910,27 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
             static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
             const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !one_stream && !repro;
-            // Round 5: the regularization rows' pairs go FIRST on the side stream, beside assemble_splined_kernel (which
-            // writes the frames' blocks and Bt, never A or the camera block's g): they were 10 us at the end of the side
-            // stream's chain, which is the longer of the two the reduction waits for. A's entries then take the pairs'
-            // products before the gathered sums instead of after (other bits than round 4's, the same every time: the
-            // side stream orders the two). MRCAL_AMD_SPL_PAIRS_LATE: where they were
-            static const bool pairs_late = (getenv("MRCAL_AMD_SPL_PAIRS_LATE") != NULL);
-            // (round 5) which control points a board covers at this point: spl_compact_kernel, for the reduction of this
-            // trial step. On the side stream if there is one (it is free until the assembly is through)
-            const int nknots_all = P.Ncameras_intrinsics*P.cfg.spline_Nx*P.cfg.spline_Ny;
-            bool compact_pending = plan.spl_compact != 0;
-            const int nrp_early = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
-            // (not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
+            // Round 5: the regularization rows' pairs ride in assemble_splined_kernel's launch, behind the frames'
+            // workgroups (which write the frames' blocks and Bt, never A or the camera block's g): they were 10 us at the
+            // end of the side stream's chain, the longer of the two the reduction waits for. A's entries then take the
+            // pairs' products before the gathered sums instead of after (other bits than round 4's, the same every time:
+            // the launch boundary orders the two). MRCAL_AMD_SPL_PAIRS_LATE: where they were.
+            // (Not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
             //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
-            //  plain read-modify-writes must not run beside those)
-            // (in the assembly's own launch, behind the frames' workgroups: on the side stream behind a fork of its own - the
-            //  first form of this round - the fork cost the main stream 8 us: profiles/r05_config2_step_in_time_order.txt has
-            //  the gaps the other fork and the join still cost)
-            const bool pairs_ride   = nrp_early > 0 && !pairs_late && !spl_fallback_possible(P) && rows_to == rows_from;
-            const bool compact_ride = compact_pending && (size_t)(nknots_all + SPLC_T/64)*sizeof(int) <= SPL_LDS_DOUBLES*sizeof(double);
+            //  plain read-modify-writes must not run beside those. Nor on the side stream behind a fork of their own -
+            //  the first form of this round -: the fork cost the main stream 8 us; profiles/r05_config2_step_in_time_order.txt
+            //  has the gaps the other fork and the join still cost)
+            static const bool pairs_late = (getenv("MRCAL_AMD_SPL_PAIRS_LATE") != NULL);
+            const int  nrp_early  = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
+            const bool pairs_ride = nrp_early > 0 && !pairs_late && !spl_fallback_possible(P) && rows_to == rows_from;
+            // (round 5) which control points a board covers at this point: spl_compact_body, for the reduction of this
+            // trial step - one more workgroup of the same launch if its marks fit the launch's LDS, else a launch in front
+            const int  nknots_all      = P.Ncameras_intrinsics*P.cfg.spline_Nx*P.cfg.spline_Ny;
+            const bool compact_pending = plan.spl_compact != 0;
+            const bool compact_ride    = compact_pending && (size_t)(nknots_all + SPLC_T/64)*sizeof(int) <= SPL_LDS_DOUBLES*sizeof(double);
             if(compact_pending && !compact_ride)
                 hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), stream, P, nd, B.R);
             pairs_early = pairs_ride;
-            (void)ev_fork0;
             // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes + (pairs_ride ? nrp_early : 0) + (compact_ride ? 1 : 0)), dim3(256), 0, stream,
                                P, nd, B.R, plan, B.Jp, B.Ji, pairs_ride ? nrp_early : 0, rows_to, compact_ride ? 1 : 0);
@@ -5313,7 +5312,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
         EvalBuffers B; memset(&B, 0, sizeof(B));
         B.R = OpRef{ a.ops, sel_eval, &fl->skip_asm }; B.Jp = (int32_t*)a.Jp; B.Ji = (int32_t*)a.Ji;
         bool forked = false;
-        const hipError_t e = launch_assemble(P, nd, br, *a.plan, B, stream, a.side, a.ev_fork, a.ev_join, &forked, a.ev_fork0);
+        const hipError_t e = launch_assemble(P, nd, br, *a.plan, B, stream, a.side, a.ev_fork, a.ev_join, &forked);
         if(e != hipSuccess) return e;
         step2_side_pending = forked;
     }
@@ -5365,7 +5364,7 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nred = ((npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT) + 255)/256;
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso);
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso, &a.ctl->error);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }

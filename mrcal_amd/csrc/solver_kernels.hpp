@@ -316,7 +316,7 @@ struct SolverCtl
     int    done;                // the solve has terminated: every later kernel is a no-op
     int    abort_step;          // this trial step is void (factorization failed, lambda was raised)
     int    need_gn;             // this step needs the Gauss-Newton direction, and it is not computed yet
-    int    error;               // lambda ran away
+    int    error;               // 1: lambda ran away; 2, 3: internal (solver.cpp solver_error_text())
 
     // the step being tried
     double step_len_sq, expected_improvement;
@@ -405,7 +405,7 @@ struct Step2Args
     const double* comm2;     // sharded: [4] g^T N g, |g_E|^2, |gn_E|^2, gn_E . g_E summed over the ranks; NULL: single GPU
     SolverCtl* snap;         // host-visible (pinned) copy of the control block to leave behind at the end of the step; NULL: none
     // a side stream with its fork and join events (NULL: none): _assemble may leave work there that _reduce waits for
-    hipStream_t side; hipEvent_t ev_fork, ev_join, ev_fork0;     // (ev_fork0: an earlier fork, in front of the kernels Bt, D come from)
+    hipStream_t side; hipEvent_t ev_fork, ev_join;
 };
 hipError_t launch_step2_choose(const Step2Args& a, hipStream_t stream);
 // the same as arguments, for an evaluation whose prologue launch carries the choice (EvalBuffers::choose)
@@ -424,8 +424,7 @@ const int* solver_ctl_skip_eval2(const SolverCtl* ctl);
 //  forked after the kernels Bt, D come from; *forked tells the caller to wait for ev_join before it reads those)
 hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const BlockRanges& br, const AssemblyPlan& plan,
                            const EvalBuffers& B, hipStream_t stream,
-                           hipStream_t side = NULL, hipEvent_t ev_fork = NULL, hipEvent_t ev_join = NULL, bool* forked = NULL,
-                           hipEvent_t ev_fork0 = NULL);
+                           hipStream_t side = NULL, hipEvent_t ev_fork = NULL, hipEvent_t ev_join = NULL, bool* forked = NULL);
 
 // the control block is followed in memory by its derived flags
 size_t     solver_ctl_bytes();
