@@ -32,6 +32,8 @@ struct OpDev
     // Made by spl_compact_kernel from spl_box after an evaluation; read by the reduction of a trial step, which leaves
     // the Cholesky the coupled part alone (solver_kernels.hip, LcholCompact). NULL: not tracked
     int*    cperm;
+    // ... and, if not NULL, the nested-dissection plan of the coupled part (solver_kernels.hpp, NDH_*)
+    int*    ndp;
 };
 
 // Which operating point a kernel works on. The index is either known to the

@@ -77,6 +77,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     }
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
     hipFree(cperm_cur_alloc); hipFree(F.iso); hipFree(op[0].cperm); hipFree(op[1].cperm);
+    hipFree(op[0].ndp); hipFree(op[1].ndp); hipFree(F.ndp_cur); hipFree(F.ndMA); hipFree(F.ndMB); hipFree(F.ndLinvA); hipFree(F.ndLinvB); hipFree(F.nd_lim_dev);
     hipFree(plan.repro.lvl[0]); hipFree(plan.repro.lvl[1]); hipFree(plan.repro.lvl[2]); hipFree(plan.repro.cmax); hipFree(plan.repro.any);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -319,6 +320,30 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             ok = ok && dev_alloc(&P->F.iso, (size_t)4*(nd.Nc/2 + 1) + nd.Nc + 2);
             P->F.cperm_cur = P->cperm_cur_alloc;
             P->plan.spl_compact = 1;
+            // ... and in a nested-dissection order where the boards leave a strip worth having (solver_kernels.hip,
+            // lchol_nd_*): one camera's grid. MRCAL_AMD_NO_ND=1: off (MRCAL_AMD_LCHOL_SEPARATE_FINISH, whose launches
+            // the dissection's would not go with, too)
+            static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL || getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL);
+            if(!nd_off && P->D.Ncameras_intrinsics == 1)
+            {
+                const size_t Npos = (size_t)nd.Nc + 2*ND_PANEL;
+                const size_t W = LCH_ND_WMAX, wsz = (W/ND_PANEL)*ND_PANEL*ND_PANEL + W*W + W;
+                std::vector<int> h0(nd_plan_ints(nd.Nc), 0);
+                h0[NDH_NS] = nd.Nc; h0[NDH_NSEFF] = nd.Nc;
+                for(int i=0;i<2 && ok;i++)
+                {
+                    ok = ok && dev_alloc(&P->op[i].ndp, h0.size());
+                    if(ok) HIP_TRY(hipMemcpy(P->op[i].ndp, h0.data(), h0.size()*sizeof(int), hipMemcpyHostToDevice), ok = false);
+                }
+                ok = ok && dev_alloc(&P->F.ndp_cur, h0.size());
+                if(ok) HIP_TRY(hipMemcpy(P->F.ndp_cur, h0.data(), h0.size()*sizeof(int), hipMemcpyHostToDevice), ok = false);
+                ok = ok && dev_alloc(&P->F.ndMA, (Npos + 1)*Npos) && dev_alloc(&P->F.ndMB, (Npos + 1)*Npos);
+                ok = ok && dev_alloc(&P->F.ndLinvA, wsz) && dev_alloc(&P->F.ndLinvB, wsz);
+                ok = ok && dev_alloc(&P->F.nd_lim_dev, 2);
+                if(ok) HIP_TRY(hipMemset(P->F.nd_lim_dev, 0, 2*sizeof(int)), ok = false);
+                P->F.nd_lim = NdLimits{0, 0}; P->F.nd_likely_panels = 0;
+                P->plan.nd_lim = P->F.nd_lim_dev;
+            }
         }
     }
     // the rows of a splined problem that no plan covers: their three levels of pre-rounded sums (ReproStep), zero at rest

@@ -134,7 +134,7 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
     if(!problem_evaluate_ref(P, R, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD | EVAL_PART_REST)) return false;
     const Step2Args a = step2_args(P);
     HIP_TRY(launch_step2_assemble(a, true, P->stream), return false);
-    HIP_TRY(launch_step2_reduce(a, P->stream), return false);
+    HIP_TRY(launch_step2_reduce(a, P->stream, 1), return false);
     if(!step_collective(P, 0)) return false;
     HIP_TRY(launch_step2_factor(a, true, P->stream), return false);
     if(!step_collective(P, 1)) return false;
@@ -195,7 +195,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     {
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_REST)) return false;
         HIP_TRY(launch_step2_assemble(a, false, P->stream), return false);
-        HIP_TRY(launch_step2_reduce(a, P->stream), return false);
+        HIP_TRY(launch_step2_reduce(a, P->stream, 0), return false);
         if(!step_collective(P, 0)) return false;
         HIP_TRY(launch_step2_factor(a, false, P->stream), return false);
         if(!step_collective(P, 1)) return false;
@@ -282,6 +282,30 @@ static bool learn_likely_size(mrcal_amd_problem* P)
     P->F.lchol_likely_panels = (n1 + 63)/64;
     // (MRCAL_AMD_LCHOL_LIKELY=k: k instead - the tests make lchol_tail_kernel do the work with it)
     if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) P->F.lchol_likely_panels = k; }
+    // The nested-dissection order (lchol_nd_*): the first evaluation of the problem's first solve has made a plan without
+    // using it (no launches were provided: NdLimits zero). If it found a strip worth having, launches for THAT plan are
+    // what every later factorization of this problem gets - rounds for the longer side, a border a panel larger than the
+    // separator - and the plans of later points are used where they fit (else the point goes the ordinary way through the
+    // same launches). Decided once: the trial step is captured as a graph with these launches in it
+    if(P->F.ndMA != NULL && P->op[P->icur].ndp != NULL && !P->nd_learned)
+    {
+        int h[NDH_WORDS];
+        HIP_TRY(hipMemcpyAsync(h, P->op[P->icur].ndp, sizeof(h), hipMemcpyDeviceToHost, P->stream), return false);
+        HIP_TRY(hipStreamSynchronize(P->stream), return false);
+        P->nd_learned = true;
+        if(h[NDH_IDEAL_A] > 0 && h[NDH_IDEAL_B] > 0)
+        {
+            const int a = (h[NDH_IDEAL_A] + ND_PANEL - 1)/ND_PANEL, b = (h[NDH_IDEAL_B] + ND_PANEL - 1)/ND_PANEL;
+            NdLimits lim = { std::max(a, b), h[NDH_IDEAL_NS] + ND_PANEL };
+            if(ND_PANEL*lim.rounds <= LCH_ND_WMAX)
+            {
+                P->F.nd_lim = lim;
+                P->F.nd_likely_panels = (h[NDH_IDEAL_NS] + ND_PANEL - 1)/ND_PANEL;
+                HIP_TRY(hipMemcpyAsync(P->F.nd_lim_dev, &P->F.nd_lim, sizeof(NdLimits), hipMemcpyHostToDevice, P->stream), return false);
+                HIP_TRY(hipStreamSynchronize(P->stream), return false);       // (the source is this problem's member: let it be read)
+            }
+        }
+    }
     return true;
 }
 
@@ -748,7 +772,7 @@ bool mrcal_amd_problem_attach_comm(mrcal_amd_problem_t* P, mrcal_amd_comm_t* com
     P->comm = comm;
     P->ctl_initialized = false;
     // (the ranks of a sharded solve sum their camera blocks entry by entry: no rank puts its own in another order)
-    P->F.cperm_cur = NULL; P->plan.spl_compact = 0;
+    P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
     return true;
 }
 bool mrcal_amd_problem_gather_state(mrcal_amd_problem_t* P)
@@ -803,7 +827,7 @@ bool mrcal_amd_problem_sharded_reset(mrcal_amd_problem_t* P, int check_terminati
     if(max_iterations > 0)  prm.max_iterations = max_iterations;
     if(trustregion0 > 0.0)  prm.trustregion0   = trustregion0;
     P->sharded_external = true;     // the caller sums comm_buffer(0), comm_buffer(1) over the shards itself
-    P->F.cperm_cur = NULL; P->plan.spl_compact = 0;
+    P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
     P->stats.lambda = 0.0;          // a new run starts unregularized, like a new libdogleg context
     return ctl_reset(P, prm, check_termination != 0);
 }

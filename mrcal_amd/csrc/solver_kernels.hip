@@ -559,7 +559,7 @@ bool splined_needs_repro_rows(const DeviceProblem& P)
 #endif
 __device__ __forceinline__ void rows_pairs_body(const NormalDims& nd, const OpDev& O, int row0, int row1, const int32_t* __restrict__ Jp,
                                                 const int32_t* __restrict__ Ji, double* __restrict__ row_part, int block);
-__device__ __forceinline__ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c);
+__device__ __forceinline__ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c, const int* __restrict__ nd_lim);
 // Riding along behind the frames' workgroups (round 5; they were launches of their own on the side stream, behind a fork
 // that cost the main stream 8 us): `npairs_extra` workgroups of rows_pairs_body() - the regularization rows from
 // pairs_row0 on, which write the camera block's A and g: nothing this kernel's own workgroups touch (never where they can
@@ -575,7 +575,7 @@ void assemble_splined_kernel(DeviceProblem P, NormalDims nd, OpRef R, AssemblyPl
     {
         const int e = (int)blockIdx.x - 2*P.Nframes;
         if(e < npairs_extra)   rows_pairs_body(nd, opref_get(R), pairs_row0, P.Nmeas, Jp, Ji, plan.row_part, e);
-        else if(compact_extra) spl_compact_body(P, nd, opref_get(R), (int*)Jd);
+        else if(compact_extra) spl_compact_body(P, nd, opref_get(R), (int*)Jd, plan.nd_lim);
         return;
     }
     __shared__ double F[7*SPL_TW];          // the frame rows and the x row of a pass's Gram
@@ -1353,7 +1353,8 @@ void rows_pairs_kernel(NormalDims nd, OpRef R, int row0, int row1,
 // the camera block's variables. cperm: [Nc] position -> variable | [Nc] variable -> position | [1] the coupled ones
 #define SPLC_T 256
 __device__ __forceinline__
-void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c /* [Nknots_all] used | [SPLC_T/64] wave totals */)
+void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev& O, int* __restrict__ lds_c /* [Nknots_all] used | [SPLC_T/64] wave totals | spl_compact_lds_ints(): the dissection's scratch */,
+                      const int* __restrict__ nd_lim /* NdLimits on the device; NULL: no dissection */)
 {
     if(O.cperm == NULL) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1361,7 +1362,10 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
     const int nknots = P.Ncameras_intrinsics*NK;
     int* __restrict__ used = lds_c;
     int* __restrict__ wtot = lds_c + nknots;
+    // (the dissection's scratch behind the wave totals: [0] the widest box | [1..4] the plan | [8 ..] covered control points per grid column | 64-bit scan words)
+    int* __restrict__ ndw = wtot + SPLC_T/64;
     for(int i = t; i < nknots; i += SPLC_T) used[i] = 0;
+    if(t < 8 + Nx && t < SPLC_T) ndw[t] = 0;
     __syncthreads();
     if(P.Ndist_state > 0 && O.spl_box != NULL)
         for(int o = t; o < P.Nobs_board; o += SPLC_T)
@@ -1369,6 +1373,7 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
             const int4 box = ((const int4*)O.spl_box)[o];
             const int isi = P.board_meta[o].i_state_intrinsics;
             if(box.y < 0 || isi < 0) continue;                       // no inlier under this observation
+            atomicMax(&ndw[0], box.y - box.x + 1);
             const int icam = (isi - P.i_state_intrinsics)/P.Nintr_state;
             for(int iy = box.z; iy <= box.w; iy++)
                 for(int ix = box.x; ix <= box.y; ix++)
@@ -1408,13 +1413,102 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
         perm[pos] = c; iperm[c] = pos;
     }
     if(t == 0) O.cperm[2*nd.Nc] = n1;
+
+    // ---- the dissection (lchol_nd_*): a strip of grid columns as wide as the widest box less one; A the covered control
+    // points left of it, B those right of it, S the strip's and every coupled variable that is no control point
+    if(O.ndp == NULL) return;
+    int* __restrict__ ndh   = O.ndp;
+    int* __restrict__ npos  = ndh + NDH_WORDS;
+    int* __restrict__ nperm = npos + nd.Nc;
+    int* __restrict__ colcnt = ndw + 8;
+    const bool eligible = nd_lim != NULL && P.Ncameras_intrinsics == 1 && total > 0 && P.Ndist_state > 0 && Nx + 8 <= SPLC_T;
+    if(eligible && t < Nx)
+    {
+        int k = 0;
+        for(int iy = 0; iy < Ny; iy++) k += used[iy*Nx + t];
+        colcnt[t] = k;
+    }
+    __syncthreads();
+    if(t == 0)
+    {
+        int act = 0, bestA = 0, bestB = 0, bestS = n1, bestc0 = 0, bestcost = (n1 + ND_PANEL - 1)/ND_PANEL, ws = 0;
+        if(eligible && ndw[0] >= 2)
+        {
+            ws = ndw[0] - 1;
+            int left = 0, all = 0;
+            for(int x = 0; x < Nx; x++) all += colcnt[x];
+            int strip = 0;
+            for(int x = 0; x < ws && x < Nx; x++) strip += colcnt[x];       // the strip [s0, s0 + ws), s0 = 0 to begin with
+            for(int s0 = 0; s0 + ws < Nx; s0++)
+            {
+                if(s0 > 0) { left += colcnt[s0 - 1]; strip += colcnt[s0 + ws - 1] - colcnt[s0 - 1]; }
+                const int ar = 2*left, br = 2*(all - left - strip), sr = n1 - ar - br;
+                const int a = (ar + ND_PANEL - 1)/ND_PANEL, b = (br + ND_PANEL - 1)/ND_PANEL, s = (sr + ND_PANEL - 1)/ND_PANEL;
+                if(a < 1 || b < 1) continue;
+                // launches on the chain: the rounds of the longer side, the junction, the separator's panels
+                const int cost = max(a, b) + 1 + s;
+                if(cost < bestcost) { bestcost = cost; bestA = ar; bestB = br; bestS = sr; bestc0 = s0; act = 1; }
+            }
+        }
+        ndh[NDH_IDEAL_A] = act ? bestA : 0; ndh[NDH_IDEAL_B] = act ? bestB : 0; ndh[NDH_IDEAL_NS] = act ? bestS : 0;
+        // what the host provided launches for (NdLimits): R rounds, a border of NSprov at most
+        const int a = (bestA + ND_PANEL - 1)/ND_PANEL, b = (bestB + ND_PANEL - 1)/ND_PANEL;
+        if(act && !(nd_lim[0] > 0 && a <= nd_lim[0] && b <= nd_lim[0] && bestS <= nd_lim[1] && ND_PANEL*max(a, b) <= LCH_ND_WMAX)) act = 0;
+        ndh[NDH_ACTIVE] = act;
+        ndh[NDH_NA] = act ? ND_PANEL*a : 0; ndh[NDH_NB] = act ? ND_PANEL*b : 0; ndh[NDH_NS] = act ? bestS : n1;
+        ndh[NDH_NSEFF] = act ? bestS : n1;
+        ndw[1] = act; ndw[2] = bestc0; ndw[3] = ws; ndw[4] = bestA; ndw[5] = bestB;
+    }
+    __syncthreads();
+    if(!ndw[1]) return;
+    {
+        const int sc0 = ndw[2], sws = ndw[3], arw = ndw[4], brw = ndw[5];
+        const int nA = ndh[NDH_NA], nB = ndh[NDH_NB];
+        // class of a coupled variable: 1 A, 2 B, 0 S
+        auto cls_of = [&](int c) -> int
+        {
+            const int st = S_to_state(nd, c);
+            const int rel = st - P.i_state_intrinsics;
+            if(rel < 0 || rel >= P.Nintr_state) return 0;
+            const int k = rel - P.Ncore_state;
+            if(k < 0) return 0;
+            const int x = (k >> 1) % Nx;
+            return (x < sc0) ? 1 : ((x >= sc0 + sws) ? 2 : 0);
+        };
+        // exclusive scans of the three classes' counts over the threads' runs, in one 64-bit word (21 bits a count)
+        unsigned long long mine3 = 0ull;
+        for(int c = c0; c < c1; c++)
+            if(coupled(c)) mine3 += 1ull << (21*cls_of(c));
+        unsigned long long incl3 = mine3;
+        for(int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl3, off); if(lane >= off) incl3 += v; }
+        unsigned long long* __restrict__ wt3 = (unsigned long long*)(((size_t)(colcnt + Nx) + 7) & ~(size_t)7);
+        __syncthreads();
+        if(lane == 63) wt3[wave] = incl3;
+        __syncthreads();
+        unsigned long long before3 = incl3 - mine3;
+        for(int w = 0; w < wave; w++) before3 += wt3[w];
+        int at[3] = { (int)(before3 & 0x1fffff), (int)((before3 >> 21) & 0x1fffff), (int)((before3 >> 42) & 0x1fffff) };
+        const int base[3] = { nA + nB, 0, nA };
+        for(int c = c0; c < c1; c++)
+        {
+            if(!coupled(c)) { npos[c] = 3 << 28; continue; }
+            const int k = cls_of(c), idx = at[k]++;
+            npos[c] = (k << 28) | idx;
+            nperm[base[k] + idx] = c;
+        }
+        // the pads: positions without a variable
+        for(int p = arw + t; p < nA; p += SPLC_T) nperm[p] = -1;
+        for(int p = nA + brw + t; p < nA + nB; p += SPLC_T) nperm[p] = -1;
+    }
 }
+// ints of LDS spl_compact_body() needs
+__host__ __device__ inline size_t spl_compact_lds_ints(int nknots_all, int Nx) { return (size_t)nknots_all + SPLC_T/64 + 8 + ((Nx + 1) & ~1) + 2*(SPLC_T/64) + 8; }
 __global__ __launch_bounds__(SPLC_T)
-void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R)
+void spl_compact_kernel(DeviceProblem P, NormalDims nd, OpRef R, const int* __restrict__ nd_lim)
 {
     if(opref_skip(R)) return;
     extern __shared__ int lds_cc[];
-    spl_compact_body(P, nd, opref_get(R), lds_cc);
+    spl_compact_body(P, nd, opref_get(R), lds_cc, nd_lim);
 }
 
 // the SPLG_E parts of a row every pass holds, in order; and |x|^2 of the regularization rows
@@ -2202,8 +2296,13 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
                        const unsigned char* __restrict__ live = NULL /* [nslots][npairs]: the slot holds the tile (sparse SYRK); NULL: all do */,
                        double* __restrict__ iso = NULL /* given: S goes out COMPACTED by O.cperm (LcholCompact): the coupled
                                                          variables' n' x n' matrix with its rhs as row n', the isolated pairs' blocks here */,
-                       int* __restrict__ err = NULL /* with iso: set to 3 if an entry that the compaction has no place for is not zero */)
+                       int* __restrict__ err = NULL /* with iso: set to 3 if an entry that the compaction has no place for is not zero */,
+                       double* __restrict__ ndMA = NULL, double* __restrict__ ndMB = NULL /* with iso and an active plan in O.ndp: the two sides' matrices (lchol_nd_*) */)
 {
+    // (the dissection: the coupled variables go to three matrices by their classes - the separator's to S)
+    const bool ndact = (iso != NULL && ndMA != NULL && O.ndp != NULL && O.ndp[NDH_ACTIVE] != 0);
+    const int  ndA = ndact ? O.ndp[NDH_NA] : 0, ndB = ndact ? O.ndp[NDH_NB] : 0, ndS = ndact ? O.ndp[NDH_NS] : 0;
+    const int* __restrict__ npos = ndact ? O.ndp + NDH_WORDS : (const int*)NULL;
     const int nb = (nd.Nc + 15) >> 4, npairs = nb*(nb+1)/2;
     // SRED_SPLIT threads per element, each taking every SRED_SPLIT-th slot, 4
     // loads in flight; the 64-byte groups they read are still whole cache lines
@@ -2276,7 +2375,29 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
             {
                 const int* __restrict__ ip = O.cperm + nd.Nc;
                 const int n1 = O.cperm[2*nd.Nc], pi = ip[i], pj = ip[j];
-                if(pi < n1 && pj < n1) S[(size_t)max(pi, pj)*n1 + min(pi, pj)] = v;
+                if(pi < n1 && pj < n1)
+                {
+                    if(!ndact) S[(size_t)max(pi, pj)*n1 + min(pi, pj)] = v;
+                    else
+                    {
+                        const int ci = npos[i], cj = npos[j], ki = ci >> 28, kj = cj >> 28, xi = ci & 0xfffffff, xj = cj & 0xfffffff;
+                        if(ki == kj)
+                        {
+                            double* __restrict__ Mk = (ki == 0) ? S : ((ki == 1) ? ndMA : ndMB);
+                            const int ldk = (ki == 0) ? ndS : ((ki == 1) ? ndA + ndS : ndB + ndS);
+                            Mk[(size_t)max(xi, xj)*ldk + min(xi, xj)] = v;
+                        }
+                        else if(ki == 0 || kj == 0)
+                        {
+                            // a side's variable against the separator's: the side's border rows
+                            const int kx = ki ? ki : kj, xs = ki ? xj : xi, xx = ki ? xi : xj;
+                            double* __restrict__ Mk = (kx == 1) ? ndMA : ndMB;
+                            const int nx = (kx == 1) ? ndA : ndB;
+                            Mk[(size_t)(nx + xs)*(nx + ndS) + xx] = v;
+                        }
+                        else if(v != 0.0 && err != NULL) *err = 3;          // the two sides are coupled after all
+                    }
+                }
                 else if(pi >= n1 && pj >= n1 && ((pi - n1) >> 1) == ((pj - n1) >> 1))
                     iso[4*((pi - n1) >> 1) + ((pi - n1) & 1) + ((pj - n1) & 1)] = v;      // (0,0) -> 0, (1,0) -> 1, (1,1) -> 2
                 else if(v != 0.0 && err != NULL) *err = 3;                  // an isolated variable that is coupled after all: the solve fails, loudly
@@ -2293,7 +2414,17 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
             else
             {
                 const int n1 = O.cperm[2*nd.Nc], pi = O.cperm[nd.Nc + i];
-                if(pi < n1) S[(size_t)n1*n1 + pi] = v;
+                if(pi < n1)
+                {
+                    if(!ndact) S[(size_t)n1*n1 + pi] = v;
+                    else
+                    {
+                        const int ci = npos[i], ki = ci >> 28, xi = ci & 0xfffffff;
+                        if(ki == 0)      S[(size_t)ndS*ndS + xi] = v;
+                        else if(ki == 1) ndMA[(size_t)(ndA + ndS)*(ndA + ndS) + xi] = v;
+                        else             ndMB[(size_t)(ndB + ndS)*(ndB + ndS) + xi] = v;
+                    }
+                }
                 else        iso[4*(nd.Nc/2 + 1) + (pi - n1)] = v;
             }
         }
@@ -2779,7 +2910,7 @@ struct Step2Dev
     NormalDims nd; const OpDev* ops; SolverCtl* ctl; SolverCtlFlags* fl;
     int initial; const double* comm1_tail;       // [g_S (Nc) | |x|^2 | status] behind S and r
 };
-__device__ bool step2_finish(const Step2Dev& sd, int* chol_status);        // one workgroup; true: factor
+__device__ bool step2_finish(const Step2Dev& sd, int* chol_status, bool no_unpack = false);        // one workgroup; true: factor
 __device__ void step2_chol_done(const Step2Dev& sd, bool not_positive_definite);   // one thread
 
 // LDS of the kernel: the packed triangle (n+1 rows), the inverse diagonal blocks, factor_diag's scratch
@@ -3339,7 +3470,10 @@ __device__ __forceinline__ void lch_tile_for_X(int wave, int* wi, int* wc) { *wi
 __device__ __forceinline__
 void lchol_diag_block(int n, double* __restrict__ M, int j0,
                       double* __restrict__ Linv /* [LCH_NB][LCH_NB] of this panel */, int* __restrict__ status,
-                      const double* __restrict__ Xprev, int jprev, double* __restrict__ lds /* LCH_LDS_DOUBLES, 16-byte aligned */)
+                      const double* __restrict__ Xprev, int jprev, double* __restrict__ lds /* LCH_LDS_DOUBLES, 16-byte aligned */,
+                      const double* __restrict__ E1 = NULL, int ld1 = 0, const double* __restrict__ E2 = NULL, int ld2 = 0
+                      /* (round 5, the separator's first block: what the two sides' chains left for it in their borders
+                          - element (i, j) of the block at E[i ld + j] - is added as the block is loaded: (M + E1) + E2) */)
 {
     constexpr int NB = LCH_NB, NR = 2*LCH_NB, LD = LCH_NB + 1;
     static_assert(LCH_PB == CHOL_PB, "chol_factor_diag16() is the block factorization");
@@ -3371,6 +3505,7 @@ void lchol_diag_block(int n, double* __restrict__ M, int j0,
             const int i = idx / NB, j = idx - i*NB;
             const bool ina = (i < nb && j < nb && j <= i);
             va[u] = M[ina ? (size_t)(j0+i)*n + j0 + j : (size_t)0];
+            if(E1 != NULL) va[u] = (va[u] + E1[ina ? (size_t)i*ld1 + j : (size_t)0]) + E2[ina ? (size_t)i*ld2 + j : (size_t)0];
             if(Xprev != NULL)
             {
                 vp[u] = M[(i < nb) ? (size_t)(j0+i)*n + jprev + j : (size_t)0];
@@ -3562,18 +3697,20 @@ void lchol_diag_kernel(const int* __restrict__ n_dev, int n_host, const int* __r
 // 8 us and the gaps between them; it is one launch as long as the longest of the three kinds
 // rows of the trailing matrix come in blocks of 64; the rhs row n is a block of its own (the last)
 __device__ __forceinline__
-void lch_tile_of(int q, int nbt, int* bi, int* bj)
+void lch_tile_of(int q, int nbt, int* bi, int* bj, int incl00 = 0)
 {
-    // q = 0 ..: the pairs (bi, bj), bj <= bi < nbt, but (0, 0) [the diagonal workgroup's]; then (nbt, bj), bj < nbt
-    const int ntri = nbt*(nbt + 1)/2 - 1;
+    // q = 0 ..: the pairs (bi, bj), bj <= bi < nbt, but (0, 0) [the diagonal workgroup's; incl00: with it - the last panel
+    // of a chain that stops in front of its border, LcholPlan::own]; then (nbt, bj), bj < nbt
+    const int skip = incl00 ? 0 : 1;
+    const int ntri = nbt*(nbt + 1)/2 - skip;
     if(q >= ntri) { *bi = nbt; *bj = q - ntri; return; }
-    int i = 0, p = q + 1;
+    int i = 0, p = q + skip;
     while(p > i) { p -= i + 1; i++; }
     *bi = i; *bj = p;
 }
 __device__ __forceinline__
 void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __restrict__ X, int q,
-                       double* __restrict__ MI, double* __restrict__ MC, double* __restrict__ Xs)
+                       double* __restrict__ MI, double* __restrict__ MC, double* __restrict__ Xs, int incl00 = 0)
 {
     constexpr int NB = LCH_NB, LD = LCH_NB + 1;
     const int t = threadIdx.x, lane = t & 63;
@@ -3584,7 +3721,7 @@ void lchol_update_tile(int n, double* __restrict__ M, int j0, const double* __re
     const int m0 = j0 + NB;
     const int nbt = (n - m0 + NB - 1)/NB;
     int bi, bj;
-    lch_tile_of(q, nbt, &bi, &bj);
+    lch_tile_of(q, nbt, &bi, &bj, incl00);
 #ifdef LCH_TS
     const long long tt0 = clock64();
 #endif
@@ -3813,21 +3950,26 @@ struct LcholInverseWork { double* Yb; double* zc; const double* Linv; int npad, 
 // without the control points no board covers, launch_cholesky_large(n_dev) - and then finds itself to be a panel's
 // launch, the closing one (l == npanels: the last panel's solve and the last row block of L^-1) or nothing (l > npanels)):
 //   panel l < npanels:  [0] the next diagonal block | the trailing update's tiles | the previous panel's solve | L^-1
+// own (round 5, the nested-dissection chains): the first `own` panels alone are factored - the matrix's other rows and
+// columns are a BORDER that takes the panels' updates and is somebody else's to factor; L^-1 is made for those panels
+// alone (its workspace: [own][64][64] | Yb [64 own][64 own] | zc) and launch l = own is the closing one. -1: all of them
 struct LcholPlan
 {
-    int npanels, npad;
+    int npanels, npad;  // (the panels that are factored, and 64 x that)
     int j0;             // first column of panel l
     int has_next;       // there is a diagonal block behind panel l (workgroup 0 factors it)
+    int incl00;         // no next block of its own, but a border: the tile behind the panel is a tile like the others
     int ntiles, ntrsm, jprev, pprev;
     int prow, krow, nchain, ntile;
     int nblocks;        // workgroups of the launch (0: nothing to do)
 };
-__host__ __device__ inline LcholPlan lchol_plan(int n, int l, bool with_inverse)
+__host__ __device__ inline LcholPlan lchol_plan(int n, int l, bool with_inverse, int own = -1)
 {
     LcholPlan q;
     q.npanels = (n + LCH_NB - 1)/LCH_NB;
+    if(own >= 0 && own < q.npanels) q.npanels = own;
     q.npad    = q.npanels*LCH_NB;
-    q.j0 = 0; q.has_next = 0; q.ntiles = 0; q.ntrsm = 0; q.jprev = 0; q.pprev = 0;
+    q.j0 = 0; q.has_next = 0; q.incl00 = 0; q.ntiles = 0; q.ntrsm = 0; q.jprev = 0; q.pprev = 0;
     q.prow = l - 1; q.krow = l - 2; q.nchain = 0; q.ntile = 0; q.nblocks = 0;
     if(l > q.npanels || n <= 0) return q;
     // rows below panel p, the rhs row included, in blocks of 64 (the panel solve's)
@@ -3845,7 +3987,8 @@ __host__ __device__ inline LcholPlan lchol_plan(int n, int l, bool with_inverse)
         q.has_next = (l + 1 < q.npanels) ? 1 : 0;
         // tiles: the 64-row blocks of the trailing matrix by pairs, without the next diagonal block, and the rhs row against each
         const int nbt = (n - m0 + LCH_NB - 1)/LCH_NB;
-        q.ntiles = q.has_next ? nbt*(nbt + 1)/2 - 1 + nbt : 0;
+        q.incl00 = (!q.has_next && nbt > 0) ? 1 : 0;
+        q.ntiles = (nbt > 0) ? nbt*(nbt + 1)/2 - (q.has_next ? 1 : 0) + nbt : 0;
         q.ntrsm  = (l > 0) ? ntrsm_of(l - 1) : 0;
         q.pprev  = (l > 0) ? l - 1 : 0;
     }
@@ -3892,7 +4035,7 @@ void lchol_panel_body(int n, int l, const LcholPlan& q, int bk, double* __restri
 #ifndef LCH_NO_SLEEP
     if(q.has_next) __builtin_amdgcn_s_sleep(127);
 #endif
-    if(b < q.ntiles) lchol_update_tile(n, M, q.j0, X, b, MI, MC, Xs);
+    if(b < q.ntiles) lchol_update_tile(n, M, q.j0, X, b, MI, MC, Xs, q.incl00);
     else if(b < q.ntiles + q.ntrsm) lchol_trsm_block(n, M, q.jprev, Xprev, b - q.ntiles, MI, Xs, zc);
     else if(b < q.ntiles + q.ntrsm + q.nchain)
         lchol_inverse_block(n, q.npad, M, Linv, Yb, q.prow, b - q.ntiles - q.ntrsm, q.prow - 1, true, MI, MC, Xs);
@@ -3978,6 +4121,9 @@ struct LcholCompact
     const double* iso;       // [Nc/2][4]: per isolated pair (positions n + 2 q, n + 2 q + 1) s00, s10, s11, then [Nc] their rhs behind all blocks
     double*       dout;      // [Nc] the solution in the camera block's own order
     int           Nc;
+    // the dissection (lchol_nd_*; NULL: none): the plan of the point that was reduced (FactorBuffers::ndp_cur). Where it is
+    // active the matrix factored here is the SEPARATOR's: its column c is position nA + nB + c of the plan's map
+    const int*    ndh;
 };
 __global__ __launch_bounds__(256)
 void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
@@ -3991,18 +4137,21 @@ void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const
     const double* __restrict__ Yb = Linv + (size_t)npanels*NB*NB;
     const double* __restrict__ zc = Yb + (size_t)npad*npad;
     const int ncolblocks = (n + LCH_AI_COLS - 1)/LCH_AI_COLS;
+    const bool ndact = cp.ndh != NULL && cp.ndh[NDH_ACTIVE] != 0;
+    const int* __restrict__ ndmap = ndact ? cp.ndh + NDH_WORDS + cp.Nc + cp.ndh[NDH_NA] + cp.ndh[NDH_NB] : (const int*)NULL;
     if((int)blockIdx.x >= ncolblocks)
     {
-        // the isolated pairs, a thread each
+        // the isolated pairs, a thread each (their positions: behind ALL the coupled variables, cperm's count)
         if(cp.cperm == NULL) return;
         const int pair = ((int)blockIdx.x - ncolblocks)*blockDim.x + threadIdx.x;
-        const int p0 = n + 2*pair;
+        const int p0 = cp.cperm[2*cp.Nc] + 2*pair;
         if(p0 >= cp.Nc) return;
         const double* __restrict__ b = cp.iso + (size_t)4*pair;
         const double* __restrict__ rr = cp.iso + (size_t)4*(cp.Nc/2 + 1) + 2*pair;
         const bool two = p0 + 1 < cp.Nc;
         const double s00 = b[0], s10 = two ? b[1] : 0.0, s11 = two ? b[2] : 1.0;
         const double r0 = rr[0], r1 = two ? rr[1] : 0.0;
+        (void)n;
         // L = [l00 0; l10 l11]
         bool bad = !(s00 > 0.0);
         const double l00 = sqrt(bad ? 1.0 : s00), l10 = s10/l00;
@@ -4050,8 +4199,209 @@ void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const
     {
         double sacc = 0.0;
         for(int k = 0; k < 16; k++) sacc += part[k][t];
-        if(cp.cperm != NULL) cp.dout[cp.cperm[c]] = -sacc;
-        else                 M[(size_t)n*n + c] = -sacc;
+        if(ndact)                 cp.dout[ndmap[c]] = -sacc;
+        else if(cp.cperm != NULL) cp.dout[cp.cperm[c]] = -sacc;
+        else                      M[(size_t)n*n + c] = -sacc;
+    }
+}
+
+////////////////////////////////////////////////////////////////////////////////
+// Round 5: a nested-dissection order of the splined models' camera block.
+// With the frames eliminated every board couples ALL control points of the box under it; a strip of grid columns as wide
+// as the widest box less one is a SEPARATOR: every box lies in the strip and ONE side of it. The coupled variables in
+// the order [side A | side B | separator S (and whatever is no control point)] have S_BA = 0, so A's panels and B's
+// panels are factored side by side - two chains in the same launches instead of one after the other:
+//   M_A = [ S_AA      ;     M_B likewise;     M_S = [ S_SS ; r_S ]
+//           S_SA  0   ;
+//           r_A   0 ]     (nA + nS + 1 rows, nA + nS columns: the last nS rows and columns are the BORDER, zero at first)
+// * lchol_nd_first_kernel: the two first diagonal blocks.  * lchol_nd_pair_kernel, launch l = 0 .. R-1: launch l of the
+//   standard factorization (lchol_panel_body) of each chain, which stops behind its own panels (LcholPlan::own): the
+//   trailing updates reach into the chain's border, the panel solves give L_SA (L_SB) and z_A (z_B), L_AA^-1 (L_BB^-1)
+//   is made on the side.  * lchol_nd_junction_kernel: the separator's first diagonal block - what the reduction left of it
+//   plus the two borders' - factored; the other tiles of the borders added to M_S; the chains' closing launches.
+//   * then M_S is a matrix like any other: lchol_panel_kernel / lchol_tail_kernel / lchol_apply_inverse_kernel (d_S).
+//   * lchol_nd_apply_kernel: d_A = -Y_A^T (z_A + L_SA^T d_S), likewise B.
+// Sizes are the device's (spl_compact_body plans after every evaluation: the boxes move with the state); nA, nB are
+// padded to whole panels with identity rows (positions without a variable). The host provides R rounds and grids for a
+// border of NSprov (what the solve's first point needs, NdLimits); a plan that does not fit is not used (everything is
+// "separator": the launches of the chains find nothing to do).
+////////////////////////////////////////////////////////////////////////////////
+struct LcholChain
+{
+    double*    M;        // [(nx + ns + 1)][nx + ns]
+    double*    Linv;     // [own][64][64] | Yb [64 own][64 own] | zc [64 own],  own = nx/64
+    const int* nx_dev;   // the chain's own columns (a multiple of 64)
+    const int* ns_dev;   // its border
+};
+__global__ __launch_bounds__(LCH_THREADS)
+void lchol_nd_first_kernel(LcholChain A, LcholChain B, const int* __restrict__ ndh, const int* __restrict__ skip, int* __restrict__ status)
+{
+    if(skip != NULL && *skip) return;
+    if(!ndh[NDH_ACTIVE]) return;
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    const LcholChain& C = (blockIdx.x == 0) ? A : B;
+    const int nx = *C.nx_dev, ns = *C.ns_dev;
+    if(nx < LCH_NB) return;
+    lchol_diag_block(nx + ns, C.M, 0, C.Linv, status, NULL, 0, lds);
+}
+__global__ __launch_bounds__(LCH_THREADS)
+void lchol_nd_pair_kernel(LcholChain A, LcholChain B, const int* __restrict__ ndh, const int* __restrict__ skip, int l, int* __restrict__ status)
+{
+    if(skip != NULL && *skip) return;
+    if(!ndh[NDH_ACTIVE]) return;
+    const int nA = *A.nx_dev, nB = *B.nx_dev, nS = *A.ns_dev;
+    LcholPlan qA = lchol_plan(nA + nS, l, true, nA/LCH_NB), qB = lchol_plan(nB + nS, l, true, nB/LCH_NB);
+    if(nA < LCH_NB) qA.nblocks = 0;
+    if(nB < LCH_NB) qB.nblocks = 0;
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    // the two long workgroups (the chains' next diagonal blocks) first, then A's others, then B's
+    int bk = blockIdx.x;
+    if(bk == 0) { if(qA.nblocks > 0) lchol_panel_body(nA + nS, l, qA, 0, A.M, A.Linv, status, true, lds); return; }
+    if(bk == 1) { if(qB.nblocks > 0) lchol_panel_body(nB + nS, l, qB, 0, B.M, B.Linv, status, true, lds); return; }
+    bk -= 2;
+    const int ra = (qA.nblocks > 1) ? qA.nblocks - 1 : 0, rb = (qB.nblocks > 1) ? qB.nblocks - 1 : 0;
+    if(bk < ra)           lchol_panel_body(nA + nS, l, qA, bk + 1,      A.M, A.Linv, status, true, lds);
+    else if(bk - ra < rb) lchol_panel_body(nB + nS, l, qB, bk - ra + 1, B.M, B.Linv, status, true, lds);
+}
+// workgroups of lchol_nd_junction_kernel: [0] the separator's first block | the merge of the other tiles of the two
+// borders into M_S (tile q as lch_tile_of(q, nbt = blocks of nS, incl00) numbers them, (0,0) left out; the rhs row's tiles last)
+// | launch l_close of both chains (their closing launch if they have l_close panels)
+__host__ __device__ inline int lchol_nd_merge_tiles(int nS) { const int nb = (nS + LCH_NB - 1)/LCH_NB; return nb*(nb + 1)/2 - 1 + nb; }
+__global__ __launch_bounds__(LCH_THREADS)
+void lchol_nd_junction_kernel(LcholChain A, LcholChain B, const int* __restrict__ ndh, const int* __restrict__ skip,
+                              double* __restrict__ MS, double* __restrict__ LinvS, int n_host, int l_close, int nmerge_host,
+                              int* __restrict__ status, const int* __restrict__ n1_dev, const double* __restrict__ iso, int iso_Nc,
+                              unsigned* __restrict__ tail_counter)
+{
+    if(tail_counter != NULL && blockIdx.x == 0 && threadIdx.x == 0) *tail_counter = 0u;
+    if(skip != NULL && *skip) return;
+    __shared__ __attribute__((aligned(16))) double lds[LCH_LDS_DOUBLES];
+    const int active = ndh[NDH_ACTIVE];
+    const int nS = lchol_n(ndh + NDH_NSEFF, n_host);
+    const int nA = active ? *A.nx_dev : 0, nB = active ? *B.nx_dev : 0;
+    const int NA = nA + nS, NB = nB + nS;
+    if(blockIdx.x == 0)
+    {
+        // (the isolated pairs: as in lchol_diag_kernel)
+        if(iso != NULL)
+        {
+            const int n1 = *n1_dev;
+            for(int p0 = n1 + 2*(int)threadIdx.x; p0 < iso_Nc; p0 += 2*LCH_THREADS)
+            {
+                const double* __restrict__ b = iso + (size_t)4*((p0 - n1) >> 1);
+                const bool two = p0 + 1 < iso_Nc;
+                const double s00 = b[0], s10 = two ? b[1] : 0.0, s11 = two ? b[2] : 1.0;
+                if(!(s00 > 0.0) || !(s11 - s10*(s10/s00) > 0.0)) atomicExch(status, 1);
+            }
+        }
+        if(active) lchol_diag_block(nS, MS, 0, LinvS, status, NULL, 0, lds,
+                                    A.M + (size_t)nA*NA + nA, NA, B.M + (size_t)nB*NB + nB, NB);
+        else       lchol_diag_block(nS, MS, 0, LinvS, status, NULL, 0, lds);
+        return;
+    }
+    if(!active) return;
+    int bk = (int)blockIdx.x - 1;
+    if(bk < nmerge_host)
+    {
+        const int nbt = (nS + LCH_NB - 1)/LCH_NB;
+        if(bk >= lchol_nd_merge_tiles(nS)) return;
+        int bi, bj;
+        lch_tile_of(bk, nbt, &bi, &bj);
+        const bool rhs = (bi == nbt), diag = (bi == bj);
+        const int i0 = rhs ? nS : LCH_NB*bi, c0 = LCH_NB*bj;
+        const int ni = rhs ? 1 : min(LCH_NB, nS - i0), nc = min(LCH_NB, nS - c0);
+        for(int idx = threadIdx.x; idx < ni*LCH_NB; idx += LCH_THREADS)
+        {
+            const int i = idx / LCH_NB, c = idx - i*LCH_NB;
+            if(c >= nc || (diag && c > i)) continue;
+            double* __restrict__ dst = &MS[(size_t)(i0 + i)*nS + c0 + c];
+            *dst = (*dst + A.M[(size_t)(nA + i0 + i)*NA + nA + c0 + c]) + B.M[(size_t)(nB + i0 + i)*NB + nB + c0 + c];
+        }
+        return;
+    }
+    bk -= nmerge_host;
+    LcholPlan qA = lchol_plan(NA, l_close, true, nA/LCH_NB), qB = lchol_plan(NB, l_close, true, nB/LCH_NB);
+    if(nA < LCH_NB) qA.nblocks = 0;
+    if(nB < LCH_NB) qB.nblocks = 0;
+    const int ra = (qA.nblocks > 1) ? qA.nblocks - 1 : 0, rb = (qB.nblocks > 1) ? qB.nblocks - 1 : 0;
+    if(bk < ra)           lchol_panel_body(NA, l_close, qA, bk + 1,      A.M, A.Linv, status, true, lds);
+    else if(bk - ra < rb) lchol_panel_body(NB, l_close, qB, bk - ra + 1, B.M, B.Linv, status, true, lds);
+}
+// d_X = -Y_X^T (z_X + L_SX^T d_S) for X = A (workgroups [0, ncb_host)) and B (the others): 16 columns a workgroup as in
+// lchol_apply_inverse_kernel; w = z_X + L_SX^T d_S is made by every workgroup for itself, in LDS: nX x nS multiply-adds,
+// half a megabyte of the side's border rows from the L2 - by 1024 threads, a row and a quarter of the separator each,
+// sixteen loads in flight a thread (a thread a row, one load at a time, was 41 us of latency). d_S is read where
+// lchol_apply_inverse_kernel left it: dout, by the separator's positions
+#define LCH_NDA_T 1024
+__global__ __launch_bounds__(LCH_NDA_T)
+void lchol_nd_apply_kernel(LcholChain A, LcholChain B, const int* __restrict__ ndh, const int* __restrict__ skip, int ncb_host,
+                           const int* __restrict__ nperm, double* __restrict__ dout)
+{
+    if(skip != NULL && *skip) return;
+    if(!ndh[NDH_ACTIVE]) return;
+    const bool isA = (int)blockIdx.x < ncb_host;
+    const LcholChain& C = isA ? A : B;
+    const int cb = isA ? (int)blockIdx.x : (int)blockIdx.x - ncb_host;
+    const int nx = *C.nx_dev, nS = *C.ns_dev, N = nx + nS;
+    if(nx < LCH_NB || nx > LCH_ND_WMAX || cb*LCH_AI_COLS >= nx) return;
+    const int nA = *A.nx_dev, nB = *B.nx_dev;
+    const int pos0 = isA ? 0 : nA, posS = nA + nB;
+    constexpr int NB = LCH_NB;
+    const int own = nx/NB, npad = nx;
+    const double* __restrict__ Yb = C.Linv + (size_t)own*NB*NB;
+    const double* __restrict__ zc = Yb + (size_t)npad*npad;
+    extern __shared__ double nda_lds[];                // [nS] d_S | [4][nx] the quarters' sums, then w in the first
+    __shared__ double part[16][LCH_AI_COLS];
+    double* __restrict__ dS = nda_lds;
+    double* __restrict__ wq = nda_lds + ((nS + 1) & ~1);
+    const int t = threadIdx.x;
+    for(int s = t; s < nS; s += LCH_NDA_T) dS[s] = dout[nperm[posS + s]];
+    __syncthreads();
+    // rows >= this workgroup's first column alone are read below
+    const int c_first = cb*LCH_AI_COLS;
+    const int quarter = t >> 8, s_lo = (int)((long long)nS*quarter/4), s_hi = (int)((long long)nS*(quarter + 1)/4);
+    for(int i = c_first + (t & 255); i < nx; i += 256)
+    {
+        const double* __restrict__ col = C.M + (size_t)nx*N + i;
+        double acc = 0.0;
+        int s = s_lo;
+        constexpr int U = 16;
+        for(; s + U <= s_hi; s += U)
+        {
+            double m[U];
+#pragma unroll
+            for(int u = 0; u < U; u++) m[u] = col[(size_t)(s + u)*N];
+#pragma unroll
+            for(int u = 0; u < U; u++) acc = fma(m[u], dS[s + u], acc);
+        }
+        for(; s < s_hi; s++) acc = fma(col[(size_t)s*N], dS[s], acc);
+        wq[quarter*nx + i] = acc;
+    }
+    __syncthreads();
+    for(int i = c_first + t; i < nx; i += LCH_NDA_T)
+        wq[i] = zc[i] + ((wq[i] + wq[nx + i]) + (wq[2*nx + i] + wq[3*nx + i]));
+    __syncthreads();
+    const double* __restrict__ w = wq;
+    if(t >= 256) return;
+    const int j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
+    const int c = c_first + j16;
+    const int q = c / NB, j = c - q*NB;
+    double a0 = 0.0, a1 = 0.0;
+    if(c < nx)
+    {
+        const double* __restrict__ X = C.Linv + (size_t)q*NB*NB;
+        for(int i = j + slice; i < NB; i += 16) a0 = fma(X[(size_t)i*NB + j], w[q*NB + i], a0);
+        const double* __restrict__ col = Yb + c;
+        for(int i = (q + 1)*NB + slice; i < nx; i += 16) a1 = fma(col[(size_t)i*npad], w[i], a1);
+    }
+    part[slice][j16] = a0 + a1;
+    __syncthreads();            // (of the waves that are left: the others have ended)
+    if(t < LCH_AI_COLS && c < nx)
+    {
+        double sacc = 0.0;
+        for(int k = 0; k < 16; k++) sacc += part[k][t];
+        const int v = nperm[pos0 + c];
+        if(v >= 0) dout[v] = -sacc;
     }
 }
 
@@ -4178,10 +4528,15 @@ static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB
 // n_dev (optional, round 5): the size of the matrix as the DEVICE knows it, <= n (LcholCompact: the camera block without
 // its isolated variables, whose number follows the boards). The launches and their grids are those of n; a launch past
 // the device's last panel finds nothing to do
+// nds (round 5): the dissection's chains in front (lchol_nd_*): M is then the separator's matrix, the first launches are
+// lchol_nd_first_kernel, R of lchol_nd_pair_kernel and lchol_nd_junction_kernel (in lchol_diag_kernel's place), the last
+// lchol_nd_apply_kernel; the end-of-trial logic has run already (it rides in the reduction: step2_reduce_kernel), the
+// verdict rides in lchol_apply_inverse_kernel as ever
+struct LcholNdLaunch { LcholChain A, B; const int* ndh; NdLimits lim; };
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
                                  const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL,
                                  int likely_panels = 0 /* with n_dev: launches 0 .. likely_panels one by one, the rest in lchol_tail_kernel; 0: all one by one */,
-                                 unsigned* tail_counter = NULL)
+                                 unsigned* tail_counter = NULL, const LcholNdLaunch* nds = NULL)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
     // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
@@ -4192,6 +4547,26 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     LcholCompact cp0; memset(&cp0, 0, sizeof(cp0));
     const bool fuse = (sd != NULL && !sweep);
     if(fused != NULL) *fused = fuse;
+    if(nds != NULL)
+    {
+        if(sweep || !fuse || n_dev == NULL || compact == NULL) return hipErrorInvalidValue;
+        const int R = nds->lim.rounds, Nprov = LCH_NB*R + nds->lim.ns_max;
+        hipLaunchKernelGGL(lchol_nd_first_kernel, dim3(2), dim3(LCH_THREADS), 0, stream, nds->A, nds->B, nds->ndh, skip, status);
+        for(int l = 0; l < R; l++)
+        {
+            // (a chain with fewer panels, or a smaller border, has no more workgroups in launch l than this one: lchol_plan()
+            //  grows with n and own term by term, and a closing launch is no larger than the panel's launch in its place)
+            const LcholPlan q = lchol_plan(Nprov, l, true, R);
+            hipLaunchKernelGGL(lchol_nd_pair_kernel, dim3(2 + 2*std::max(q.nblocks - 1, 0)), dim3(LCH_THREADS), 0, stream,
+                               nds->A, nds->B, nds->ndh, skip, l, status);
+        }
+        const LcholPlan qc = lchol_plan(Nprov, R, true, R);
+        const int nmerge = lchol_nd_merge_tiles(nds->lim.ns_max);
+        hipLaunchKernelGGL(lchol_nd_junction_kernel, dim3(1 + nmerge + 2*std::max(qc.nblocks - 1, 0)), dim3(LCH_THREADS), 0, stream,
+                           nds->A, nds->B, nds->ndh, skip, M, Linv, n, R, nmerge, status,
+                           compact->cperm + 2*compact->Nc, compact->iso, compact->Nc, tail_counter);
+    }
+    else
     hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n_dev, n, skip, M, 0, Linv, status,
                        fuse ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0,
                        (n_dev != NULL) ? tail_counter : (unsigned*)NULL);
@@ -4215,6 +4590,13 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         const int niso_blocks = (compact != NULL) ? (n/2 + 1 + 255)/256 : 0;
         hipLaunchKernelGGL(lchol_apply_inverse_kernel, dim3((n + LCH_AI_COLS - 1)/LCH_AI_COLS + niso_blocks), dim3(256), 0, stream,
                            n_dev, n, skip, M, (const double*)Linv, fuse ? 1 : 0, fuse ? *sd : sd0, status, compact ? *compact : cp0);
+        if(nds != NULL)
+        {
+            const int ncb = LCH_NB*nds->lim.rounds/LCH_AI_COLS;
+            const size_t ldsb = ((size_t)((nds->lim.ns_max + 1) & ~1) + 4*(size_t)LCH_NB*nds->lim.rounds)*sizeof(double);
+            hipLaunchKernelGGL(lchol_nd_apply_kernel, dim3(2*ncb), dim3(LCH_NDA_T), ldsb, stream, nds->A, nds->B, nds->ndh, skip, ncb,
+                               nds->ndh + NDH_WORDS + compact->Nc, compact->dout);
+        }
         return hipGetLastError();
     }
     // the backward sweep, in groups of panels (see lchol_backward_kernel)
@@ -4580,10 +4962,43 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
                          int nslots, const double* __restrict__ Spart,
                          double* __restrict__ S, double* __restrict__ r, const int* __restrict__ status,
                          const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso,
-                         int* __restrict__ err /* SolverCtl::error */)
+                         int* __restrict__ err /* SolverCtl::error */,
+                         double* __restrict__ ndMA, double* __restrict__ ndMB, int* __restrict__ ndp_cur, int nfill /* workgroups behind the last */,
+                         int ride_finish, Step2Dev sd)
 {
-    if(fl->skip_elim) return;
+    if(fl->skip_elim)
+    {
+        // (nothing is reduced; the end of the trial step still has to be decided where it rides here)
+        if(ride_finish && (int)blockIdx.x == nred) (void)step2_finish(sd, (int*)status, true);
+        return;
+    }
     const OpDev& O = ops[fl->elim_sel];
+    if((int)blockIdx.x > nred)
+    {
+        // The dissection's matrices, what no entry of the camera block goes to: the borders (zero: the chains' updates
+        // add up there), the pads' rows and columns (identity). Every entry (i, j <= i) of the two matrices, rhs row included
+        if(ndMA == NULL || O.ndp == NULL || !O.ndp[NDH_ACTIVE]) return;
+        const int nA = O.ndp[NDH_NA], nB = O.ndp[NDH_NB], nS = O.ndp[NDH_NS];
+        const int* __restrict__ nperm = O.ndp + NDH_WORDS + nd.Nc;
+        const int NA = nA + nS, NB = nB + nS;
+        const long long eA = (long long)(NA + 1)*(NA + 2)/2, eB = (long long)(NB + 1)*(NB + 2)/2;
+        for(long long e = (long long)((int)blockIdx.x - nred - 1)*blockDim.x + threadIdx.x; e < eA + eB; e += (long long)nfill*blockDim.x)
+        {
+            const bool inA = e < eA;
+            const long long ee = inA ? e : e - eA;
+            // row i: the largest i with i (i + 1)/2 <= ee
+            int i = (int)((sqrt(8.0*(double)ee + 1.0) - 1.0)*0.5);
+            while((long long)(i + 1)*(i + 2)/2 <= ee) i++;
+            while((long long)i*(i + 1)/2 > ee) i--;
+            const int j = (int)(ee - (long long)i*(i + 1)/2);
+            const int nx = inA ? nA : nB, N = inA ? NA : NB, p0 = inA ? 0 : nA;
+            if(j >= N) continue;                                        // (the rhs row has N entries)
+            const bool padi = i < nx && nperm[p0 + i] < 0, padj = j < nx && nperm[p0 + j] < 0;
+            if(padi || padj || (i >= nx && j >= nx))
+                (inA ? ndMA : ndMB)[(size_t)i*N + j] = (i == j && padi) ? 1.0 : 0.0;
+        }
+        return;
+    }
     if((int)blockIdx.x < nred)
     {
         // r starts from this rank's g_S: of a point just assembled that is its own summand
@@ -4591,13 +5006,19 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         // sum over the ranks (step2_finish unpacked it): the leader alone adds it
         const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
         schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live,
-                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL, err);
+                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL, err, ndMA, ndMB);
         return;
     }
     // (the permutation this reduction went by, for the factorization and the solve behind it: which of the two
     //  operating points was reduced is the device's to know)
     if(cperm_cur != NULL && O.cperm != NULL)
         for(int i = threadIdx.x; i < 2*nd.Nc + 1; i += blockDim.x) cperm_cur[i] = O.cperm[i];
+    if(ndp_cur != NULL && O.ndp != NULL)
+    {
+        // (not active: the header alone - NDH_NSEFF is what the factorization's launches size themselves by)
+        const int nints = O.ndp[NDH_ACTIVE] ? (int)nd_plan_ints(nd.Nc) : (int)NDH_WORDS;
+        for(int i = threadIdx.x; i < nints; i += blockDim.x) ndp_cur[i] = O.ndp[i];
+    }
     double* __restrict__ tail = r + nd.Nc;
     for(int i = threadIdx.x; i < nd.Nc + 2; i += blockDim.x)
     {
@@ -4607,6 +5028,9 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         else                v = (*status != 0) ? 1.0 : 0.0;
         tail[i] = v;
     }
+    // (round 5, where the dissection's launches follow: the end of the trial step, which the factorization's first launch
+    //  carries otherwise - there the first launch is two workgroups that both need its verdict)
+    if(ride_finish) { __syncthreads(); (void)step2_finish(sd, (int*)status, true); }
 }
 
 // End of a trial, in ONE workgroup, in front of the factorization: the rho test
@@ -4615,7 +5039,8 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
 // every thread. comm1 = [S | r | g_S | |x|^2 | status] is complete (summed over
 // the ranks when sharded): the camera-block part of the new point's gradient is
 // taken from it
-__device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
+// no_unpack: the caller is the reduction that made the tail from this very gradient (single GPU): nothing to copy back
+__device__ bool step2_finish(const Step2Dev& sd, int* chol_status, bool no_unpack)
 {
     const NormalDims& nd = sd.nd;
     SolverCtl* ctl = sd.ctl;
@@ -4665,7 +5090,7 @@ __device__ bool step2_finish(const Step2Dev& sd, int* chol_status)
         (void)chol_status;
     }
     __syncthreads();
-    if(s_unpack)
+    if(s_unpack && !no_unpack)
     {
         const OpDev& O = sd.ops[ip];
         for(int i = t; i < nd.Nc; i += nt) O.g[S_to_state(nd, i)] = tail[i];
@@ -4927,9 +5352,10 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // trial step - one more workgroup of the same launch if its marks fit the launch's LDS, else a launch in front
             const int  nknots_all      = P.Ncameras_intrinsics*P.cfg.spline_Nx*P.cfg.spline_Ny;
             const bool compact_pending = plan.spl_compact != 0;
-            const bool compact_ride    = compact_pending && (size_t)(nknots_all + SPLC_T/64)*sizeof(int) <= SPL_LDS_DOUBLES*sizeof(double);
+            const size_t compact_lds   = spl_compact_lds_ints(nknots_all, P.cfg.spline_Nx)*sizeof(int);
+            const bool compact_ride    = compact_pending && compact_lds <= SPL_LDS_DOUBLES*sizeof(double);
             if(compact_pending && !compact_ride)
-                hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), (size_t)(nknots_all + SPLC_T/64)*sizeof(int), stream, P, nd, B.R);
+                hipLaunchKernelGGL(spl_compact_kernel, dim3(1), dim3(SPLC_T), compact_lds, stream, P, nd, B.R, plan.nd_lim);
             pairs_early = pairs_ride;
             // (a workgroup per frame and surface; 64 KB of LDS for the tile: two workgroups per CU)
             hipLaunchKernelGGL(assemble_splined_kernel, dim3(2*P.Nframes + (pairs_ride ? nrp_early : 0) + (compact_ride ? 1 : 0)), dim3(256), 0, stream,
@@ -5333,7 +5759,7 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
 }
 
 // SYRK (+ finalize of A, g, |x|^2) | S, r and the tail of comm1. (Sharded: comm1 is all-reduced after this)
-hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
+hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initial)
 {
     const DeviceProblem& P = *a.P;
     const NormalDims& nd = *a.nd;
@@ -5363,8 +5789,17 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream)
     }
     const int nb = (nd.Nc + 15)/16, npairs = nb*(nb+1)/2;
     const int nred = ((npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT) + 255)/256;
-    hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1), dim3(256), 0, stream,
-                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso, &a.ctl->error);
+    // (the dissection: its matrices' borders and pads by nfill more workgroups; where its launches follow, the end of the
+    //  trial step rides in this launch's last ordinary workgroup - launch_step2_factor() then leaves it out)
+    const bool nd_on = F.ndMA != NULL && F.cperm_cur != NULL;
+    const bool nd_launches = nd_on && F.nd_lim.rounds > 0 && initial >= 0;
+    const int  nfill = nd_launches ? 32 : 0;
+    Step2Dev sd; memset(&sd, 0, sizeof(sd));
+    if(nd_launches) { sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0; sd.comm1_tail = F.r + nd.Nc; }
+    hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1 + nfill), dim3(256), 0, stream,
+                       nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso, &a.ctl->error,
+                       nd_launches ? F.ndMA : (double*)NULL, nd_launches ? F.ndMB : (double*)NULL, nd_on ? F.ndp_cur : (int*)NULL, nfill,
+                       nd_launches ? 1 : 0, sd);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }
@@ -5396,9 +5831,22 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
             LcholCompact cp; memset(&cp, 0, sizeof(cp));
             const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with MRCAL_AMD_LCHOL_SWEEP: problem_prepare_solver())
             if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
+            // (the dissection's launches, where the host has provided for them: learn_likely_size())
+            const bool nd_launches = compact && F.ndMA != NULL && F.nd_lim.rounds > 0 && !separate;
+            LcholNdLaunch nds; memset(&nds, 0, sizeof(nds));
+            if(nd_launches)
+            {
+                const int* h = F.ndp_cur;
+                nds.A = LcholChain{ F.ndMA, F.ndLinvA, h + NDH_NA, h + NDH_NS };
+                nds.B = LcholChain{ F.ndMB, F.ndLinvB, h + NDH_NB, h + NDH_NS };
+                nds.ndh = h; nds.lim = F.nd_lim;
+                cp.ndh = h;
+            }
             launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused,
-                                  compact ? F.cperm_cur + 2*n : (const int*)NULL, compact ? &cp : (const LcholCompact*)NULL,
-                                  compact ? F.lchol_likely_panels : 0, compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL);
+                                  compact ? (nd_launches ? F.ndp_cur + NDH_NSEFF : F.cperm_cur + 2*n) : (const int*)NULL,
+                                  compact ? &cp : (const LcholCompact*)NULL,
+                                  compact ? (nd_launches ? F.nd_likely_panels : F.lchol_likely_panels) : 0,
+                                  compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL, nd_launches ? &nds : (const LcholNdLaunch*)NULL);
             if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
             else if(!fused) return hipErrorInvalidValue;
         }

@@ -81,6 +81,22 @@ enum
     NSCALARS = 16
 };
 
+// The nested-dissection order of the splined models' camera block (round 5; solver_kernels.hip, lchol_nd_*).
+// OpDev::ndp, made by spl_compact_body after every evaluation:  [NDH_WORDS] the plan | [Nc] camera-block variable -> its
+// class << 28 | its index within the class (class 0: separator, 1: side A, 2: side B, 3: not coupled) | [Nc + 2 ND_PANEL]
+// position -> variable over [A padded | B padded | separator] (-1: a pad)
+#define ND_PANEL 64              // = LCH_NB: the sides are padded to whole panels of the factorization
+#define LCH_ND_WMAX 1024         // the most columns a side may have
+enum { NDH_ACTIVE = 0,           // this point's camera block goes by the dissection
+       NDH_NA, NDH_NB,           // columns of the two sides, padded (0 if not active)
+       NDH_NS,                   // the separator's (not active: all the coupled variables)
+       NDH_IDEAL_A, NDH_IDEAL_B, NDH_IDEAL_NS,   // what the best strip would give (unpadded), whether it fits what the host provided or not: learn_likely_size() sizes that from it
+       NDH_NSEFF,                // the size of the matrix the ordinary factorization factors: NDH_NS if active, else the coupled variables
+       NDH_WORDS };
+__host__ __device__ inline size_t nd_plan_ints(int Nc) { return (size_t)NDH_WORDS + (size_t)Nc + (size_t)Nc + 2*ND_PANEL; }
+// what the host provided launches for: [0] rounds (panels a side; 0: none - the plans are made and not used) | [1] the largest separator
+struct NdLimits { int rounds, ns_max; };
+
 // factorization scratch, one set
 struct FactorBuffers
 {
@@ -98,6 +114,13 @@ struct FactorBuffers
     int*    cperm_cur; // [2 Nc + 2] (the last word: lchol_tail_kernel's barrier) the permutation (OpDev::cperm) of the point whose camera block was reduced last: what the
                       // factorization and the solve behind that reduction go by. NULL: no compaction
     double* iso;      // with cperm_cur: [4 (Nc/2 + 1)] the 2 x 2 blocks of the isolated pairs (s00, s10, s11, -) | [Nc] their rhs
+    // the dissection (NULL / 0: none): the two sides' matrices and workspaces, the plan of the point reduced last (a copy
+    // of its OpDev::ndp), the limits as the host set them (and their device copy, which the plans are made against)
+    double* ndMA; double* ndMB; double* ndLinvA; double* ndLinvB;
+    int*    ndp_cur;
+    int*    nd_lim_dev;
+    NdLimits nd_lim;
+    int     nd_likely_panels;   // the separator's panels at the solve's first point (as lchol_likely_panels)
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -
                       // [ceil(Nc/16)][NE][16] - for the sparse SYRK: a block's rows of a tile are 768 contiguous bytes
                       // (in Wt itself they are six pieces 9.6 KB apart, and a workgroup's few blocks that count are all over 46 MB)
@@ -199,6 +222,7 @@ struct AssemblyPlan
     GenPlan gen;
     ReproStep repro;
     int  spl_compact;      // splined models: the evaluation's assembly also makes OpDev::cperm (spl_compact_kernel)
+    const int* nd_lim;     // ... and OpDev::ndp, against these limits (FactorBuffers::nd_lim_dev); NULL: no dissection
     int* frame_obs_begin;  // [blocks+1] the board observations of each 6x6 eliminated block (a frame: contiguous) ...
     int* frame_obs;        // ... or, if not NULL, entries [begin, end) of this list (a camera's, with elim_extrinsics)
     int* chunk_begin;      // [Nchunks+1]
@@ -414,7 +438,9 @@ ChooseArgs step2_choose_args(const Step2Args& a);
 hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t stream);
 // ... comm1 = [S | r | g_S | |x|^2 | status] (F.S, step2_comm1_doubles()) is this rank's summand after _reduce;
 // _factor expects it summed over the ranks, and leaves this rank's summand of comm2 (if a.comm2 is given)
-hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream);
+// initial (0 / 1; -1: not said): the reduction of a trial step / of the starting point - where the dissection's launches follow
+// (FactorBuffers::nd_lim), the end-of-trial logic rides in this launch and launch_step2_factor(a, initial) leaves it out
+hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initial = -1);
 hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t stream);
 int64_t    step2_comm1_doubles(const NormalDims& nd);
 hipError_t launch_mask_state(const NormalDims& nd, const BlockRanges& br, bool is_leader, double* b, hipStream_t stream);
