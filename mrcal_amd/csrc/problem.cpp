@@ -77,7 +77,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
     }
     hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
     hipFree(cperm_cur_alloc); hipFree(F.iso); hipFree(op[0].cperm); hipFree(op[1].cperm);
-    hipFree(op[0].ndp); hipFree(op[1].ndp); hipFree(F.ndp_cur); hipFree(F.ndMA); hipFree(F.ndMB); hipFree(F.ndLinvA); hipFree(F.ndLinvB); hipFree(F.nd_lim_dev);
+    hipFree(op[0].ndp); hipFree(op[1].ndp); hipFree(F.ndp_cur); hipFree(F.ndMA); hipFree(F.ndMB); hipFree(F.ndLinvA); hipFree(F.ndLinvB); hipFree(F.ndPart); hipFree(F.nd_lim_dev);
     hipFree(plan.repro.lvl[0]); hipFree(plan.repro.lvl[1]); hipFree(plan.repro.lvl[2]); hipFree(plan.repro.cmax); hipFree(plan.repro.any);
     hipFree(d_step); hipFree(d_comm); hipFree(d_counts); hipFree(d_outlier_part); hipFree(d_ctl);
     if(h_scalars)  hipHostFree(h_scalars);
@@ -339,6 +339,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
                 if(ok) HIP_TRY(hipMemcpy(P->F.ndp_cur, h0.data(), h0.size()*sizeof(int), hipMemcpyHostToDevice), ok = false);
                 ok = ok && dev_alloc(&P->F.ndMA, (Npos + 1)*Npos) && dev_alloc(&P->F.ndMB, (Npos + 1)*Npos);
                 ok = ok && dev_alloc(&P->F.ndLinvA, wsz) && dev_alloc(&P->F.ndLinvB, wsz);
+                ok = ok && dev_alloc(&P->F.ndPart, (size_t)((nd.Nc + 15)/16)*2*LCH_ND_WMAX);
                 ok = ok && dev_alloc(&P->F.nd_lim_dev, 2);
                 if(ok) HIP_TRY(hipMemset(P->F.nd_lim_dev, 0, 2*sizeof(int)), ok = false);
                 P->F.nd_lim = NdLimits{0, 0}; P->F.nd_likely_panels = 0;

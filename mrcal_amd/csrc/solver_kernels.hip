@@ -4124,6 +4124,11 @@ struct LcholCompact
     // the dissection (lchol_nd_*; NULL: none): the plan of the point that was reduced (FactorBuffers::ndp_cur). Where it is
     // active the matrix factored here is the SEPARATOR's: its column c is position nA + nB + c of the plan's map
     const int*    ndh;
+    // ... and then every workgroup, with its 16 entries of d_S at hand, leaves the sides' share of them behind:
+    // ndpart[column block][position i of A | B] = sum over its 16 columns s of L_SX[s][i] d_S[s]  (lchol_nd_apply_kernel adds the
+    // blocks' shares in block order: w = z + L_SX^T d_S)
+    const double* ndMA; const double* ndMB;
+    double*       ndpart;    // [ceil(Nc/16)][2 LCH_ND_WMAX]
 };
 __global__ __launch_bounds__(256)
 void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
@@ -4202,6 +4207,26 @@ void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const
         if(ndact)                 cp.dout[ndmap[c]] = -sacc;
         else if(cp.cperm != NULL) cp.dout[cp.cperm[c]] = -sacc;
         else                      M[(size_t)n*n + c] = -sacc;
+        part[0][t] = -sacc;
+    }
+    if(ndact && cp.ndpart != NULL)
+    {
+        if(t < LCH_AI_COLS && c >= n) part[0][t] = 0.0;
+        __syncthreads();
+        const int nA = cp.ndh[NDH_NA], nB = cp.ndh[NDH_NB], s0 = blockIdx.x*LCH_AI_COLS;
+        for(int i = t; i < nA + nB; i += blockDim.x)
+        {
+            const bool inA = i < nA;
+            const int nx = inA ? nA : nB, ii = inA ? i : i - nA, N = nx + n;
+            const double* __restrict__ colp = (inA ? cp.ndMA : cp.ndMB) + (size_t)(nx + s0)*N + ii;
+            double m[LCH_AI_COLS];
+#pragma unroll
+            for(int k = 0; k < LCH_AI_COLS; k++) m[k] = colp[(size_t)((s0 + k < n) ? k : 0)*N];
+            double acc = 0.0;
+#pragma unroll
+            for(int k = 0; k < LCH_AI_COLS; k++) acc = fma(m[k], part[0][k], acc);
+            cp.ndpart[(size_t)blockIdx.x*(2*LCH_ND_WMAX) + i] = acc;
+        }
     }
 }
 
@@ -4300,6 +4325,10 @@ void lchol_nd_junction_kernel(LcholChain A, LcholChain B, const int* __restrict_
         return;
     }
     if(!active) return;
+    // (the first workgroup is the long one and starts with a cold read: the others wait, as in lchol_panel_body)
+#ifndef LCH_NO_SLEEP
+    __builtin_amdgcn_s_sleep(127);
+#endif
     int bk = (int)blockIdx.x - 1;
     if(bk < nmerge_host)
     {
@@ -4328,61 +4357,50 @@ void lchol_nd_junction_kernel(LcholChain A, LcholChain B, const int* __restrict_
     else if(bk - ra < rb) lchol_panel_body(NB, l_close, qB, bk - ra + 1, B.M, B.Linv, status, true, lds);
 }
 // d_X = -Y_X^T (z_X + L_SX^T d_S) for X = A (workgroups [0, ncb_host)) and B (the others): 16 columns a workgroup as in
-// lchol_apply_inverse_kernel; w = z_X + L_SX^T d_S is made by every workgroup for itself, in LDS: nX x nS multiply-adds,
-// half a megabyte of the side's border rows from the L2 - by 1024 threads, a row and a quarter of the separator each,
-// sixteen loads in flight a thread (a thread a row, one load at a time, was 41 us of latency). d_S is read where
-// lchol_apply_inverse_kernel left it: dout, by the separator's positions
-#define LCH_NDA_T 1024
-__global__ __launch_bounds__(LCH_NDA_T)
+// lchol_apply_inverse_kernel, which has left L_SX^T d_S behind in shares of 16 entries of d_S (LcholCompact::ndpart): w = z +
+// the shares in block order, made by every workgroup for itself in LDS. (w from the border rows themselves, here: every
+// workgroup half a megabyte from the L2 - 41 us a thread a row, 17 us by 1024 threads with sixteen loads in flight)
+__global__ __launch_bounds__(256)
 void lchol_nd_apply_kernel(LcholChain A, LcholChain B, const int* __restrict__ ndh, const int* __restrict__ skip, int ncb_host,
-                           const int* __restrict__ nperm, double* __restrict__ dout)
+                           const int* __restrict__ nperm, double* __restrict__ dout, const double* __restrict__ ndpart)
 {
     if(skip != NULL && *skip) return;
     if(!ndh[NDH_ACTIVE]) return;
     const bool isA = (int)blockIdx.x < ncb_host;
     const LcholChain& C = isA ? A : B;
     const int cb = isA ? (int)blockIdx.x : (int)blockIdx.x - ncb_host;
-    const int nx = *C.nx_dev, nS = *C.ns_dev, N = nx + nS;
+    const int nx = *C.nx_dev, nS = *C.ns_dev;
     if(nx < LCH_NB || nx > LCH_ND_WMAX || cb*LCH_AI_COLS >= nx) return;
-    const int nA = *A.nx_dev, nB = *B.nx_dev;
-    const int pos0 = isA ? 0 : nA, posS = nA + nB;
+    const int nA = *A.nx_dev;
+    const int pos0 = isA ? 0 : nA;
     constexpr int NB = LCH_NB;
     const int own = nx/NB, npad = nx;
     const double* __restrict__ Yb = C.Linv + (size_t)own*NB*NB;
     const double* __restrict__ zc = Yb + (size_t)npad*npad;
-    extern __shared__ double nda_lds[];                // [nS] d_S | [4][nx] the quarters' sums, then w in the first
+    __shared__ double w[LCH_ND_WMAX];
     __shared__ double part[16][LCH_AI_COLS];
-    double* __restrict__ dS = nda_lds;
-    double* __restrict__ wq = nda_lds + ((nS + 1) & ~1);
     const int t = threadIdx.x;
-    for(int s = t; s < nS; s += LCH_NDA_T) dS[s] = dout[nperm[posS + s]];
-    __syncthreads();
     // rows >= this workgroup's first column alone are read below
     const int c_first = cb*LCH_AI_COLS;
-    const int quarter = t >> 8, s_lo = (int)((long long)nS*quarter/4), s_hi = (int)((long long)nS*(quarter + 1)/4);
-    for(int i = c_first + (t & 255); i < nx; i += 256)
+    const int ncbS = (nS + LCH_AI_COLS - 1)/LCH_AI_COLS;
+    for(int i = c_first + t; i < nx; i += 256)
     {
-        const double* __restrict__ col = C.M + (size_t)nx*N + i;
+        const double* __restrict__ pp = ndpart + pos0 + i;
         double acc = 0.0;
-        int s = s_lo;
-        constexpr int U = 16;
-        for(; s + U <= s_hi; s += U)
+        int b = 0;
+        constexpr int U = 8;
+        for(; b + U <= ncbS; b += U)
         {
             double m[U];
 #pragma unroll
-            for(int u = 0; u < U; u++) m[u] = col[(size_t)(s + u)*N];
+            for(int u = 0; u < U; u++) m[u] = pp[(size_t)(b + u)*(2*LCH_ND_WMAX)];
 #pragma unroll
-            for(int u = 0; u < U; u++) acc = fma(m[u], dS[s + u], acc);
+            for(int u = 0; u < U; u++) acc += m[u];
         }
-        for(; s < s_hi; s++) acc = fma(col[(size_t)s*N], dS[s], acc);
-        wq[quarter*nx + i] = acc;
+        for(; b < ncbS; b++) acc += pp[(size_t)b*(2*LCH_ND_WMAX)];
+        w[i] = zc[i] + acc;
     }
     __syncthreads();
-    for(int i = c_first + t; i < nx; i += LCH_NDA_T)
-        wq[i] = zc[i] + ((wq[i] + wq[nx + i]) + (wq[2*nx + i] + wq[3*nx + i]));
-    __syncthreads();
-    const double* __restrict__ w = wq;
-    if(t >= 256) return;
     const int j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
     const int c = c_first + j16;
     const int q = c / NB, j = c - q*NB;
@@ -4395,7 +4413,7 @@ void lchol_nd_apply_kernel(LcholChain A, LcholChain B, const int* __restrict__ n
         for(int i = (q + 1)*NB + slice; i < nx; i += 16) a1 = fma(col[(size_t)i*npad], w[i], a1);
     }
     part[slice][j16] = a0 + a1;
-    __syncthreads();            // (of the waves that are left: the others have ended)
+    __syncthreads();
     if(t < LCH_AI_COLS && c < nx)
     {
         double sacc = 0.0;
@@ -4593,9 +4611,8 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
         if(nds != NULL)
         {
             const int ncb = LCH_NB*nds->lim.rounds/LCH_AI_COLS;
-            const size_t ldsb = ((size_t)((nds->lim.ns_max + 1) & ~1) + 4*(size_t)LCH_NB*nds->lim.rounds)*sizeof(double);
-            hipLaunchKernelGGL(lchol_nd_apply_kernel, dim3(2*ncb), dim3(LCH_NDA_T), ldsb, stream, nds->A, nds->B, nds->ndh, skip, ncb,
-                               nds->ndh + NDH_WORDS + compact->Nc, compact->dout);
+            hipLaunchKernelGGL(lchol_nd_apply_kernel, dim3(2*ncb), dim3(256), 0, stream, nds->A, nds->B, nds->ndh, skip, ncb,
+                               nds->ndh + NDH_WORDS + compact->Nc, compact->dout, (const double*)compact->ndpart);
         }
         return hipGetLastError();
     }
@@ -4977,25 +4994,32 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
     {
         // The dissection's matrices, what no entry of the camera block goes to: the borders (zero: the chains' updates
         // add up there), the pads' rows and columns (identity). Every entry (i, j <= i) of the two matrices, rhs row included
-        if(ndMA == NULL || O.ndp == NULL || !O.ndp[NDH_ACTIVE]) return;
-        const int nA = O.ndp[NDH_NA], nB = O.ndp[NDH_NB], nS = O.ndp[NDH_NS];
-        const int* __restrict__ nperm = O.ndp + NDH_WORDS + nd.Nc;
-        const int NA = nA + nS, NB = nB + nS;
-        const long long eA = (long long)(NA + 1)*(NA + 2)/2, eB = (long long)(NB + 1)*(NB + 2)/2;
-        for(long long e = (long long)((int)blockIdx.x - nred - 1)*blockDim.x + threadIdx.x; e < eA + eB; e += (long long)nfill*blockDim.x)
+        // ... and, a thread an entry, the copies of the permutation and of the plan that the factorization goes by (one
+        // workgroup's ten trips to memory for them were half of this launch's time)
+        const long long e_first = (long long)((int)blockIdx.x - nred - 1)*blockDim.x + threadIdx.x, e_step = (long long)nfill*blockDim.x;
+        if(cperm_cur != NULL && O.cperm != NULL)
+            for(long long e = e_first; e < 2*nd.Nc + 1; e += e_step) cperm_cur[e] = O.cperm[e];
+        if(ndp_cur != NULL && O.ndp != NULL)
         {
-            const bool inA = e < eA;
-            const long long ee = inA ? e : e - eA;
-            // row i: the largest i with i (i + 1)/2 <= ee
-            int i = (int)((sqrt(8.0*(double)ee + 1.0) - 1.0)*0.5);
-            while((long long)(i + 1)*(i + 2)/2 <= ee) i++;
-            while((long long)i*(i + 1)/2 > ee) i--;
-            const int j = (int)(ee - (long long)i*(i + 1)/2);
-            const int nx = inA ? nA : nB, N = inA ? NA : NB, p0 = inA ? 0 : nA;
-            if(j >= N) continue;                                        // (the rhs row has N entries)
-            const bool padi = i < nx && nperm[p0 + i] < 0, padj = j < nx && nperm[p0 + j] < 0;
-            if(padi || padj || (i >= nx && j >= nx))
-                (inA ? ndMA : ndMB)[(size_t)i*N + j] = (i == j && padi) ? 1.0 : 0.0;
+            const long long nints = O.ndp[NDH_ACTIVE] ? (long long)nd_plan_ints(nd.Nc) : (long long)NDH_WORDS;
+            for(long long e = e_first; e < nints; e += e_step) ndp_cur[e] = O.ndp[e];
+        }
+        if(ndMA == NULL || O.ndp == NULL || !O.ndp[NDH_ACTIVE]) return;
+        // a thread an entry, no loop: per side  the border with the rhs row's part of it ((nS+1) x nS) | the pads' rows
+        // (pads x nx) | the pads' columns under them ((nS+1) x pads). Sized by the host for the largest plan it provided for
+        const int nS = O.ndp[NDH_NS];
+        long long e = e_first;
+        for(int side = 0; side < 2; side++)
+        {
+            const int nx = O.ndp[side ? NDH_NB : NDH_NA], nxr = O.ndp[side ? NDH_IDEAL_B : NDH_IDEAL_A], npd = nx - nxr, N = nx + nS;
+            double* __restrict__ Mx = side ? ndMB : ndMA;
+            const long long e1 = (long long)(nS + 1)*nS, e2 = (long long)npd*nx, e3 = (long long)(nS + 1)*npd;
+            if(e < e1)      { const int i = nx + (int)(e/nS), j = nx + (int)(e % nS); if(j <= i) Mx[(size_t)i*N + j] = 0.0; return; }
+            e -= e1;
+            if(e < e2)      { const int i = nxr + (int)(e/nx), j = (int)(e % nx);     if(j <= i) Mx[(size_t)i*N + j] = (i == j) ? 1.0 : 0.0; return; }
+            e -= e2;
+            if(e < e3)      { const int i = nx + (int)(e/npd), j = nxr + (int)(e % npd); Mx[(size_t)i*N + j] = 0.0; return; }
+            e -= e3;
         }
         return;
     }
@@ -5011,9 +5035,10 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
     }
     // (the permutation this reduction went by, for the factorization and the solve behind it: which of the two
     //  operating points was reduced is the device's to know)
-    if(cperm_cur != NULL && O.cperm != NULL)
+    // (with workgroups behind this one - nfill - the copies are theirs)
+    if(nfill == 0 && cperm_cur != NULL && O.cperm != NULL)
         for(int i = threadIdx.x; i < 2*nd.Nc + 1; i += blockDim.x) cperm_cur[i] = O.cperm[i];
-    if(ndp_cur != NULL && O.ndp != NULL)
+    if(nfill == 0 && ndp_cur != NULL && O.ndp != NULL)
     {
         // (not active: the header alone - NDH_NSEFF is what the factorization's launches size themselves by)
         const int nints = O.ndp[NDH_ACTIVE] ? (int)nd_plan_ints(nd.Nc) : (int)NDH_WORDS;
@@ -5793,7 +5818,16 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initi
     //  trial step rides in this launch's last ordinary workgroup - launch_step2_factor() then leaves it out)
     const bool nd_on = F.ndMA != NULL && F.cperm_cur != NULL;
     const bool nd_launches = nd_on && F.nd_lim.rounds > 0 && initial >= 0;
-    const int  nfill = nd_launches ? 32 : 0;
+    int nfill = 0;
+    if(nd_launches)
+    {
+        // (a thread an entry of what the dissection's matrices hold beside the camera block's entries: step2_reduce_kernel)
+        const long long NSp = F.nd_lim.ns_max, nxm = (long long)ND_PANEL*F.nd_lim.rounds, pads = ND_PANEL - 1;
+        const long long per = (NSp + 1)*NSp + pads*nxm + (NSp + 1)*pads;
+        nfill = (int)((2*per + 255)/256);
+        const int ncopy = (int)((std::max<long long>(2*nd.Nc + 1, (long long)nd_plan_ints(nd.Nc)) + 255)/256);
+        nfill = std::max(nfill, ncopy);
+    }
     Step2Dev sd; memset(&sd, 0, sizeof(sd));
     if(nd_launches) { sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0; sd.comm1_tail = F.r + nd.Nc; }
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1 + nfill), dim3(256), 0, stream,
@@ -5840,7 +5874,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
                 nds.A = LcholChain{ F.ndMA, F.ndLinvA, h + NDH_NA, h + NDH_NS };
                 nds.B = LcholChain{ F.ndMB, F.ndLinvB, h + NDH_NB, h + NDH_NS };
                 nds.ndh = h; nds.lim = F.nd_lim;
-                cp.ndh = h;
+                cp.ndh = h; cp.ndMA = F.ndMA; cp.ndMB = F.ndMB; cp.ndpart = F.ndPart;
             }
             launch_cholesky_large(n, &fl->skip_chol, F.S, F.Linv, F.status, stream, separate ? NULL : &sd, &fused,
                                   compact ? (nd_launches ? F.ndp_cur + NDH_NSEFF : F.cperm_cur + 2*n) : (const int*)NULL,

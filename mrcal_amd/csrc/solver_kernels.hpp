@@ -117,6 +117,7 @@ struct FactorBuffers
     // the dissection (NULL / 0: none): the two sides' matrices and workspaces, the plan of the point reduced last (a copy
     // of its OpDev::ndp), the limits as the host set them (and their device copy, which the plans are made against)
     double* ndMA; double* ndMB; double* ndLinvA; double* ndLinvB;
+    double* ndPart;   // [ceil(Nc/16)][2 LCH_ND_WMAX] L_SX^T d_S in shares of 16 entries of d_S (LcholCompact::ndpart)
     int*    ndp_cur;
     int*    nd_lim_dev;
     NdLimits nd_lim;
