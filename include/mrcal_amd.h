@@ -559,6 +559,14 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nl
    (profiles/r05_fused_prologue.txt), so the two launches stay the default and _fuses_prologue() is 0 */
 void mrcal_amd_problem_jacobian_stream_timing(mrcal_amd_problem_t* problem, int* Nlaunches, double* total_ms);
 int  mrcal_amd_problem_fuses_prologue(mrcal_amd_problem_t* problem);
+/* Round 5, the splined models with one camera: the camera block's coupled control points in a nested-dissection order
+   where the boards leave a strip of the grid worth having - two sides whose panels the big Cholesky
+   factors side by side, the strip last. out[9]: the rounds (panels a side) the factorization's launches are provided
+   for (0: the dissection is not in use), the largest separator they serve, and the current operating point's plan:
+   used or not, the columns of side A, of side B (padded to whole panels of 64), of the separator; what the best strip there would give (side A, side B,
+   separator, unpadded). For tests and
+   tools; MRCAL_AMD_NO_ND=1 in the environment when the problem is created turns the dissection off */
+bool mrcal_amd_problem_dissection(mrcal_amd_problem_t* problem, int* out);
 
 /* ---- multi-GPU: one process per GPU, frames sharded over the ranks ----------
    No counterpart in the reference (it is single-threaded). Every rank creates

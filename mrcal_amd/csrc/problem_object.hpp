@@ -51,7 +51,6 @@ struct mrcal_amd_problem
     int         ev_pool_used = 0;
     int         ev_pool_seen = 0, ev_pool_stride = 1;      // launches since _begin(); every stride-th one is timed
     bool        ev_pool_enabled = false;
-    bool                nd_learned = false;        // learn_likely_size() has looked at the first plan of the dissection (FactorBuffers::nd_lim is final)
     int*                cperm_cur_alloc = NULL;    // what F.cperm_cur points at while the compaction is on (a communicator turns it off)
     // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
     // ([launch][8]: the first Jacobian store, the end, the launch's start, the poses through, wall_clock64 ticks of 10 ns;

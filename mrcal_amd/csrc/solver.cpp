@@ -282,28 +282,38 @@ static bool learn_likely_size(mrcal_amd_problem* P)
     P->F.lchol_likely_panels = (n1 + 63)/64;
     // (MRCAL_AMD_LCHOL_LIKELY=k: k instead - the tests make lchol_tail_kernel do the work with it)
     if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) P->F.lchol_likely_panels = k; }
-    // The nested-dissection order (lchol_nd_*): the first evaluation of the problem's first solve has made a plan without
-    // using it (no launches were provided: NdLimits zero). If it found a strip worth having, launches for THAT plan are
-    // what every later factorization of this problem gets - rounds for the longer side, a border a panel larger than the
-    // separator - and the plans of later points are used where they fit (else the point goes the ordinary way through the
-    // same launches). Decided once: the trial step is captured as a graph with these launches in it
-    if(P->F.ndMA != NULL && P->op[P->icur].ndp != NULL && !P->nd_learned)
+    // The nested-dissection order (lchol_nd_*): the evaluation of this solve's first point has made a plan - the best
+    // strip there is at that point - whether launches for it are provided or not. Launches for THAT plan are what the
+    // factorizations of this solve get: rounds for the longer side, a border a panel larger than the separator; the plans
+    // of later points are used where they fit (else the point goes the ordinary way through the same launches). Where
+    // that differs from what the last solve had, the trial step's graphs - the launches are in them - are made again
+    // (a solve from the seed and the solve after an outlier pass may well differ: the boxes move with the state)
+    if(P->F.ndMA != NULL && P->op[P->icur].ndp != NULL)
     {
         int h[NDH_WORDS];
         HIP_TRY(hipMemcpyAsync(h, P->op[P->icur].ndp, sizeof(h), hipMemcpyDeviceToHost, P->stream), return false);
         HIP_TRY(hipStreamSynchronize(P->stream), return false);
-        P->nd_learned = true;
+        NdLimits lim = { 0, 0 };
+        int likely = 0;
         if(h[NDH_IDEAL_A] > 0 && h[NDH_IDEAL_B] > 0)
         {
             const int a = (h[NDH_IDEAL_A] + ND_PANEL - 1)/ND_PANEL, b = (h[NDH_IDEAL_B] + ND_PANEL - 1)/ND_PANEL;
-            NdLimits lim = { std::max(a, b), h[NDH_IDEAL_NS] + ND_PANEL };
-            if(ND_PANEL*lim.rounds <= LCH_ND_WMAX)
-            {
-                P->F.nd_lim = lim;
-                P->F.nd_likely_panels = (h[NDH_IDEAL_NS] + ND_PANEL - 1)/ND_PANEL;
-                HIP_TRY(hipMemcpyAsync(P->F.nd_lim_dev, &P->F.nd_lim, sizeof(NdLimits), hipMemcpyHostToDevice, P->stream), return false);
-                HIP_TRY(hipStreamSynchronize(P->stream), return false);       // (the source is this problem's member: let it be read)
-            }
+            lim = NdLimits{ std::max(a, b), h[NDH_IDEAL_NS] + ND_PANEL };
+            // (MRCAL_AMD_ND_ROUNDS=k: k rounds instead - with fewer than the plan needs, every point goes the ordinary
+            //  way through the dissection's launches: the tests hold that path to the bits of the path without them)
+            if(const char* e = getenv("MRCAL_AMD_ND_ROUNDS")) { const int k = atoi(e); if(k > 0) lim.rounds = k; }
+            if(ND_PANEL*lim.rounds > LCH_ND_WMAX) lim = NdLimits{ 0, 0 };
+            likely = (h[NDH_IDEAL_NS] + ND_PANEL - 1)/ND_PANEL;
+            if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) likely = k; }
+        }
+        if(lim.rounds != P->F.nd_lim.rounds || lim.ns_max != P->F.nd_lim.ns_max || likely != P->F.nd_likely_panels)
+        {
+            P->F.nd_lim = lim; P->F.nd_likely_panels = likely;
+            HIP_TRY(launch_nd_plans_off(P->d_ops, P->nd.Nc, P->stream), return false);
+            HIP_TRY(hipMemcpyAsync(P->F.nd_lim_dev, &P->F.nd_lim, sizeof(NdLimits), hipMemcpyHostToDevice, P->stream), return false);
+            HIP_TRY(hipStreamSynchronize(P->stream), return false);       // (the source is this problem's member: let it be read)
+            for(int i = 0; i < 3; i++)
+                if(P->step_graph[i]) { hipGraphExecDestroy(P->step_graph[i]); P->step_graph[i] = NULL; }
         }
     }
     return true;
@@ -773,6 +783,21 @@ bool mrcal_amd_problem_attach_comm(mrcal_amd_problem_t* P, mrcal_amd_comm_t* com
     P->ctl_initialized = false;
     // (the ranks of a sharded solve sum their camera blocks entry by entry: no rank puts its own in another order)
     P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
+    return true;
+}
+// dev / tests: the nested-dissection order of a splined problem's camera block. out[0] rounds the host provides launches for
+// (0: none), out[1] the largest separator they serve, out[2..5] the current operating point's plan: used or not, columns of
+// side A, side B (padded to whole panels), of the separator, out[6..8] what the best strip at that point would give (unpadded)
+bool mrcal_amd_problem_dissection(mrcal_amd_problem_t* P, int* out /* [9] */)
+{
+    for(int i = 0; i < 9; i++) out[i] = 0;
+    if(P->F.ndMA == NULL || P->op[P->icur].ndp == NULL) return true;
+    out[0] = P->F.nd_lim.rounds; out[1] = P->F.nd_lim.ns_max;
+    int h[NDH_WORDS];
+    HIP_TRY(hipMemcpyAsync(h, P->op[P->icur].ndp, sizeof(h), hipMemcpyDeviceToHost, P->stream), return false);
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    out[2] = h[NDH_ACTIVE]; out[3] = h[NDH_NA]; out[4] = h[NDH_NB]; out[5] = h[NDH_NS];
+    out[6] = h[NDH_IDEAL_A]; out[7] = h[NDH_IDEAL_B]; out[8] = h[NDH_IDEAL_NS];
     return true;
 }
 bool mrcal_amd_problem_gather_state(mrcal_amd_problem_t* P)

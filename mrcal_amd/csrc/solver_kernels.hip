@@ -1431,7 +1431,10 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
     __syncthreads();
     if(t == 0)
     {
-        int act = 0, bestA = 0, bestB = 0, bestS = n1, bestc0 = 0, bestcost = (n1 + ND_PANEL - 1)/ND_PANEL, ws = 0;
+        // the best strip there is (what learn_likely_size() provides launches for), and the best one that fits what was provided
+        const int std_cost = (n1 + ND_PANEL - 1)/ND_PANEL;
+        int ideal = 0, idA = 0, idB = 0, idS = n1, idcost = std_cost;
+        int act = 0, bestA = 0, bestB = 0, bestS = n1, bestc0 = 0, bestcost = std_cost, ws = 0;
         if(eligible && ndw[0] >= 2)
         {
             ws = ndw[0] - 1;
@@ -1447,16 +1450,17 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
                 if(a < 1 || b < 1) continue;
                 // launches on the chain: the rounds of the longer side, the junction, the separator's panels
                 const int cost = max(a, b) + 1 + s;
-                if(cost < bestcost) { bestcost = cost; bestA = ar; bestB = br; bestS = sr; bestc0 = s0; act = 1; }
+                if(cost < idcost) { idcost = cost; idA = ar; idB = br; idS = sr; ideal = 1; }
+                const bool fits = nd_lim[0] > 0 && a <= nd_lim[0] && b <= nd_lim[0] && sr <= nd_lim[1] && ND_PANEL*max(a, b) <= LCH_ND_WMAX;
+                if(fits && cost < bestcost) { bestcost = cost; bestA = ar; bestB = br; bestS = sr; bestc0 = s0; act = 1; }
             }
         }
-        ndh[NDH_IDEAL_A] = act ? bestA : 0; ndh[NDH_IDEAL_B] = act ? bestB : 0; ndh[NDH_IDEAL_NS] = act ? bestS : 0;
-        // what the host provided launches for (NdLimits): R rounds, a border of NSprov at most
+        ndh[NDH_IDEAL_A] = ideal ? idA : 0; ndh[NDH_IDEAL_B] = ideal ? idB : 0; ndh[NDH_IDEAL_NS] = ideal ? idS : 0;
         const int a = (bestA + ND_PANEL - 1)/ND_PANEL, b = (bestB + ND_PANEL - 1)/ND_PANEL;
-        if(act && !(nd_lim[0] > 0 && a <= nd_lim[0] && b <= nd_lim[0] && bestS <= nd_lim[1] && ND_PANEL*max(a, b) <= LCH_ND_WMAX)) act = 0;
         ndh[NDH_ACTIVE] = act;
         ndh[NDH_NA] = act ? ND_PANEL*a : 0; ndh[NDH_NB] = act ? ND_PANEL*b : 0; ndh[NDH_NS] = act ? bestS : n1;
         ndh[NDH_NSEFF] = act ? bestS : n1;
+        ndh[NDH_ARAW] = act ? bestA : 0; ndh[NDH_BRAW] = act ? bestB : 0;
         ndw[1] = act; ndw[2] = bestc0; ndw[3] = ws; ndw[4] = bestA; ndw[5] = bestB;
     }
     __syncthreads();
@@ -1500,6 +1504,20 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
         for(int p = arw + t; p < nA; p += SPLC_T) nperm[p] = -1;
         for(int p = nA + brw + t; p < nA + nB; p += SPLC_T) nperm[p] = -1;
     }
+}
+// the plans of both operating points put out of use (the host has changed what it provides launches for: plans made
+// against the old limits may not fit the new grids; the points' next reductions go the ordinary way)
+__global__ void nd_plans_off_kernel(const OpDev* __restrict__ ops, int Nc)
+{
+    const OpDev& O = ops[threadIdx.x];
+    if(threadIdx.x >= 2 || O.ndp == NULL || O.cperm == NULL) return;
+    O.ndp[NDH_ACTIVE] = 0; O.ndp[NDH_NA] = 0; O.ndp[NDH_NB] = 0; O.ndp[NDH_ARAW] = 0; O.ndp[NDH_BRAW] = 0;
+    O.ndp[NDH_NS] = O.cperm[2*Nc]; O.ndp[NDH_NSEFF] = O.cperm[2*Nc];
+}
+hipError_t launch_nd_plans_off(const OpDev* ops, int Nc, hipStream_t stream)
+{
+    hipLaunchKernelGGL(nd_plans_off_kernel, dim3(1), dim3(64), 0, stream, ops, Nc);
+    return hipGetLastError();
 }
 // ints of LDS spl_compact_body() needs
 __host__ __device__ inline size_t spl_compact_lds_ints(int nknots_all, int Nx) { return (size_t)nknots_all + SPLC_T/64 + 8 + ((Nx + 1) & ~1) + 2*(SPLC_T/64) + 8; }
@@ -5011,7 +5029,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         long long e = e_first;
         for(int side = 0; side < 2; side++)
         {
-            const int nx = O.ndp[side ? NDH_NB : NDH_NA], nxr = O.ndp[side ? NDH_IDEAL_B : NDH_IDEAL_A], npd = nx - nxr, N = nx + nS;
+            const int nx = O.ndp[side ? NDH_NB : NDH_NA], nxr = O.ndp[side ? NDH_BRAW : NDH_ARAW], npd = nx - nxr, N = nx + nS;
             double* __restrict__ Mx = side ? ndMB : ndMA;
             const long long e1 = (long long)(nS + 1)*nS, e2 = (long long)npd*nx, e3 = (long long)(nS + 1)*npd;
             if(e < e1)      { const int i = nx + (int)(e/nS), j = nx + (int)(e % nS); if(j <= i) Mx[(size_t)i*N + j] = 0.0; return; }

@@ -92,8 +92,10 @@ enum { NDH_ACTIVE = 0,           // this point's camera block goes by the dissec
        NDH_NS,                   // the separator's (not active: all the coupled variables)
        NDH_IDEAL_A, NDH_IDEAL_B, NDH_IDEAL_NS,   // what the best strip would give (unpadded), whether it fits what the host provided or not: learn_likely_size() sizes that from it
        NDH_NSEFF,                // the size of the matrix the ordinary factorization factors: NDH_NS if active, else the coupled variables
+       NDH_ARAW, NDH_BRAW,       // the sides' variables (NDH_NA, NDH_NB less the pads)
        NDH_WORDS };
 __host__ __device__ inline size_t nd_plan_ints(int Nc) { return (size_t)NDH_WORDS + (size_t)Nc + (size_t)Nc + 2*ND_PANEL; }
+hipError_t launch_nd_plans_off(const struct OpDev* ops, int Nc, hipStream_t stream);
 // what the host provided launches for: [0] rounds (panels a side; 0: none - the plans are made and not used) | [1] the largest separator
 struct NdLimits { int rounds, ns_max; };
 

@@ -93,6 +93,7 @@ class Problem:
         L.mrcal_amd_problem_jacobian_stream_timing_detail.restype  = None
         L.mrcal_amd_problem_jacobian_stream_timing_detail.argtypes = [vp, dpp, dpp]
         L.mrcal_amd_problem_fuses_prologue.restype, L.mrcal_amd_problem_fuses_prologue.argtypes = C.c_int, [vp]
+        L.mrcal_amd_problem_dissection.restype, L.mrcal_amd_problem_dissection.argtypes = C.c_bool, [vp, ip]
         L._mrcal_amd_resident_declared = True
 
     def _check(self, ok, what):
@@ -130,6 +131,13 @@ class Problem:
         self._check(self._lib.mrcal_amd_problem_jacobian_timing_end(self.handle, C.byref(n), C.byref(t), C.byref(mn), C.byref(mx)),
                     "jacobian_timing_end")
         return n.value, t.value, mn.value, mx.value
+
+    def dissection(self):
+        """the nested-dissection order of a splined problem's camera block: dict(rounds, ns_max, active, nA, nB, nS) -
+        rounds == 0: not in use (include/mrcal_amd.h)"""
+        out = (C.c_int*9)()
+        self._check(self._lib.mrcal_amd_problem_dissection(self.handle, out), "dissection")
+        return dict(zip(("rounds", "ns_max", "active", "nA", "nB", "nS", "ideal_A", "ideal_B", "ideal_S"), [int(v) for v in out]))
 
     def fuses_prologue(self):
         """does a trial step of this problem choose its trial point, make its poses and build its Jacobian in ONE launch?"""

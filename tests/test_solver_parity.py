@@ -601,6 +601,49 @@ with Problem(**copy_inputs(oi)) as p:
 
 
 @pytest.mark.timeout(900)
+def test_nested_dissection_of_the_control_point_grid(amd):
+    """The splined models with one camera (solver_kernels.hip lchol_nd_*): where the boards leave a strip of the grid worth
+    having, the coupled control points are ordered [side A | side B | strip], the two sides' panels of the big Cholesky
+    are factored side by side, and the solve ends with d_A = -Y_A^T (z_A + L_SA^T d_S). Configuration 2 reduced to 200
+    frames, solved
+      - as it is: the dissection is in use (launches provided, the final point's plan active, both sides >= a panel);
+      - the same again: the same bits (every sum of it in a fixed order);
+      - with the separator's panels past the first left to lchol_tail_kernel: the same bits;
+      - with launches for ONE round where the plan needs more (MRCAL_AMD_ND_ROUNDS=1): no plan fits, every point goes the
+        ordinary way THROUGH the dissection's launches - the bits of
+      - the solve without the dissection (MRCAL_AMD_NO_ND=1), which the solve with it matches to what another order of
+        the pivots leaves"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import mrcal_amd
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
+from mrcal_amd.resident import Problem
+oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
+                                 lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False)
+out = []
+for rep in range(2):
+    with Problem(**copy_inputs(oi)) as p:
+        s = p.solve()
+        out.append(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), nd=p.dissection()))
+print("RESULT " + json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for tag, env in (("nd", {}), ("tail", {"MRCAL_AMD_LCHOL_LIKELY": "1"}), ("unfit", {"MRCAL_AMD_ND_ROUNDS": "1"}), ("off", {"MRCAL_AMD_NO_ND": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    nd, nd2, tail, unfit, off = res["nd"][0], res["nd"][1], res["tail"][0], res["unfit"][0], res["off"][0]
+    assert nd["nd"]["rounds"] >= 1 and nd["nd"]["active"] == 1 and nd["nd"]["nA"] >= 64 and nd["nd"]["nB"] >= 64 and nd["nd"]["nS"] > 0, nd["nd"]
+    assert off["nd"]["rounds"] == 0 and unfit["nd"]["rounds"] == 1 and unfit["nd"]["active"] == 0
+    same = lambda a, b: (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"]
+    assert same(nd, nd2) and same(nd, tail)
+    assert same(unfit, off)
+    assert nd["Nout"] == off["Nout"] and abs(nd["rms"] - off["rms"]) < 1e-8*off["rms"]
+    assert np.abs(np.array(nd["b"]) - np.array(off["b"])).max() < 1e-4
+
+
 def test_factorization_launches_and_tail_kernel_give_the_same_bits(amd):
     """The splined models' compacted camera block (solver_kernels.hip LcholCompact): the size of the matrix that is
     factored follows the boards, the host provides the launches of the size the solve's first point has, and whatever a
