@@ -4081,7 +4081,9 @@ void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __
 // panel by panel with a barrier over its workgroups where a launch boundary would be. A step's result does not depend
 // on which of the two ways a panel was done. (Nineteen launches for a matrix that needs eleven cost 5 us apiece -
 // workgroups of 100 KB of LDS that are dispatched to find out they have nothing to do)
+#ifndef LCH_TAIL_WGS
 #define LCH_TAIL_WGS 96
+#endif
 __device__ __forceinline__ void lchol_grid_barrier(unsigned* __restrict__ counter, unsigned nwg, unsigned epoch, int* __restrict__ status)
 {
     __syncthreads();
