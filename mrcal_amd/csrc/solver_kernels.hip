@@ -1447,7 +1447,7 @@ void spl_compact_body(const DeviceProblem& P, const NormalDims& nd, const OpDev&
                 if(s0 > 0) { left += colcnt[s0 - 1]; strip += colcnt[s0 + ws - 1] - colcnt[s0 - 1]; }
                 const int ar = 2*left, br = 2*(all - left - strip), sr = n1 - ar - br;
                 const int a = (ar + ND_PANEL - 1)/ND_PANEL, b = (br + ND_PANEL - 1)/ND_PANEL, s = (sr + ND_PANEL - 1)/ND_PANEL;
-                if(a < 1 || b < 1) continue;
+                if(a < 1 || b < 1 || sr < 1) continue;
                 // launches on the chain: the rounds of the longer side, the junction, the separator's panels
                 const int cost = max(a, b) + 1 + s;
                 if(cost < idcost) { idcost = cost; idA = ar; idB = br; idS = sr; ideal = 1; }
