@@ -3063,14 +3063,17 @@ bool chol_factor_diag16(const int lane, const int jb, const double* __restrict__
     return bad;
 }
 
-template<bool FINISH>
+// FINISH: 0 a factorization and solve and nothing else | 1 the end of the trial step in front, the verdict behind (sharded:
+// the end-of-trial logic needs the tail summed over the ranks, which is complete only now) | 2 the verdict behind alone:
+// the end-of-trial logic has run in the reduction's launch (single GPU, round 5: step2_reduce_kernel) and `skip` is its word
+template<int FINISH>
 __global__ __launch_bounds__(1024)
 void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_factor,
                                  double* __restrict__ S, double* __restrict__ r,
                                  int* __restrict__ status, Step2Dev sd)
 {
     if(skip != NULL && *skip) return;
-    if constexpr(FINISH) { if(!step2_finish(sd, status)) return; }
+    if constexpr(FINISH == 1) { if(!step2_finish(sd, status)) return; }
     extern __shared__ __attribute__((aligned(16))) double Mp[];
     const int t    = threadIdx.x;
     const int nt   = blockDim.x;
@@ -3328,7 +3331,7 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
             if(j <= i) S[(size_t)i*n + j] = rowptr(i)[j];
         }
     CTS();
-    if constexpr(FINISH) { if(t == 0) step2_chol_done(sd, notpd != 0); }
+    if constexpr(FINISH != 0) { if(t == 0) step2_chol_done(sd, notpd != 0); }
 #ifdef CHOL_TS
     if(t == 0) { printf("chol ts (load | diag0 | b,c per panel ... | backward | store):"); for(int i=1;i<ncts;i++) printf(" %lld", cts[i]-cts[i-1]); printf("\n"); }
 #endif
@@ -4574,7 +4577,8 @@ struct LcholNdLaunch { LcholChain A, B; const int* ndh; NdLimits lim; };
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
                                  const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL,
                                  int likely_panels = 0 /* with n_dev: launches 0 .. likely_panels one by one, the rest in lchol_tail_kernel; 0: all one by one */,
-                                 unsigned* tail_counter = NULL, const LcholNdLaunch* nds = NULL)
+                                 unsigned* tail_counter = NULL, const LcholNdLaunch* nds = NULL,
+                                 bool finish_done = false /* with sd: the end-of-trial logic has run already (the first launch goes by `skip`); the verdict still rides in the last */)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
     // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
@@ -4587,7 +4591,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     if(fused != NULL) *fused = fuse;
     if(nds != NULL)
     {
-        if(sweep || !fuse || n_dev == NULL || compact == NULL) return hipErrorInvalidValue;
+        if(sweep || !fuse || !finish_done || n_dev == NULL || compact == NULL) return hipErrorInvalidValue;
         const int R = nds->lim.rounds, Nprov = LCH_NB*R + nds->lim.ns_max;
         hipLaunchKernelGGL(lchol_nd_first_kernel, dim3(2), dim3(LCH_THREADS), 0, stream, nds->A, nds->B, nds->ndh, skip, status);
         for(int l = 0; l < R; l++)
@@ -4606,7 +4610,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
     }
     else
     hipLaunchKernelGGL(lchol_diag_kernel, dim3(1), dim3(LCH_THREADS), 0, stream, n_dev, n, skip, M, 0, Linv, status,
-                       fuse ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0,
+                       (fuse && !finish_done) ? 1 : 0, fuse ? *sd : sd0, compact ? compact->iso : (const double*)NULL, compact ? compact->Nc : 0,
                        (n_dev != NULL) ? tail_counter : (unsigned*)NULL);
     const bool with_tail = n_dev != NULL && tail_counter != NULL && likely_panels > 0 && likely_panels < npanels && !sweep;
     const int  l_last = with_tail ? likely_panels : npanels;
@@ -5633,7 +5637,7 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
         if(chol_fits_lds(n))
         {
             Step2Dev none; memset(&none, 0, sizeof(none));
-            hipLaunchKernelGGL(schur_cholesky_solve_kernel<false>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
+            hipLaunchKernelGGL(schur_cholesky_solve_kernel<0>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
                                n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status, none);
         }
         else if(F.Linv != NULL)
@@ -5804,6 +5808,17 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
 }
 
 // SYRK (+ finalize of A, g, |x|^2) | S, r and the tail of comm1. (Sharded: comm1 is all-reduced after this)
+// Does the end-of-trial logic (step2_finish) ride in the reduction's launch (round 5)? On a single GPU the tail it reads -
+// g_S, |x|^2, the block elimination's status - is complete when the reduction's last workgroup has written it, and that
+// workgroup can decide the trial there and then, beside the others: the factorization's first launch starts on its matrix
+// at once (and may be several workgroups: the dissection's). Sharded, the tail is summed over the ranks behind this launch.
+// MRCAL_AMD_LCHOL_SEPARATE_FINISH / MRCAL_AMD_LCHOL_SWEEP (comparisons): as it was
+static bool step2_finish_rides(const Step2Args& a)
+{
+    static const bool separate = (getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL ||
+                                  getenv("MRCAL_AMD_FINISH_IN_FACTOR") != NULL);
+    return a.comm2 == NULL && !separate;
+}
 hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initial)
 {
     const DeviceProblem& P = *a.P;
@@ -5836,8 +5851,9 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initi
     const int nred = ((npairs*256 + nb*16)*(live ? 1 : SRED_SPLIT) + 255)/256;
     // (the dissection: its matrices' borders and pads by nfill more workgroups; where its launches follow, the end of the
     //  trial step rides in this launch's last ordinary workgroup - launch_step2_factor() then leaves it out)
+    const bool rides = initial >= 0 && step2_finish_rides(a);
     const bool nd_on = F.ndMA != NULL && F.cperm_cur != NULL;
-    const bool nd_launches = nd_on && F.nd_lim.rounds > 0 && initial >= 0;
+    const bool nd_launches = nd_on && F.nd_lim.rounds > 0 && rides;
     int nfill = 0;
     if(nd_launches)
     {
@@ -5849,11 +5865,11 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initi
         nfill = std::max(nfill, ncopy);
     }
     Step2Dev sd; memset(&sd, 0, sizeof(sd));
-    if(nd_launches) { sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0; sd.comm1_tail = F.r + nd.Nc; }
+    if(rides) { sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0; sd.comm1_tail = F.r + nd.Nc; }
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1 + nfill), dim3(256), 0, stream,
                        nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso, &a.ctl->error,
                        nd_launches ? F.ndMA : (double*)NULL, nd_launches ? F.ndMB : (double*)NULL, nd_on ? F.ndp_cur : (int*)NULL, nfill,
-                       nd_launches ? 1 : 0, sd);
+                       rides ? 1 : 0, sd);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }
@@ -5870,9 +5886,17 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
     sd.comm1_tail = F.r + nd.Nc;
     {
         const int n = nd.Nc;
+        // (round 5, single GPU: the end-of-trial logic has run in the reduction's launch - step2_finish_rides())
+        const bool finish_done = step2_finish_rides(a);
         if(chol_fits_lds(n))
-            hipLaunchKernelGGL(schur_cholesky_solve_kernel<true>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
-                               n, (const int*)NULL, 0, F.S, F.r, F.status, sd);
+        {
+            if(finish_done)
+                hipLaunchKernelGGL(schur_cholesky_solve_kernel<2>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
+                                   n, (const int*)&fl->skip_chol, 0, F.S, F.r, F.status, sd);
+            else
+                hipLaunchKernelGGL(schur_cholesky_solve_kernel<1>, dim3(1), dim3(1024), chol_lds_bytes(n), stream,
+                                   n, (const int*)NULL, 0, F.S, F.r, F.status, sd);
+        }
         else
         {
             // (round 5: finish and post ride in the factorization's first and last launch; MRCAL_AMD_LCHOL_SEPARATE_FINISH
@@ -5886,7 +5910,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
             const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with MRCAL_AMD_LCHOL_SWEEP: problem_prepare_solver())
             if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
             // (the dissection's launches, where the host has provided for them: learn_likely_size())
-            const bool nd_launches = compact && F.ndMA != NULL && F.nd_lim.rounds > 0 && !separate;
+            const bool nd_launches = compact && F.ndMA != NULL && F.nd_lim.rounds > 0 && finish_done;
             LcholNdLaunch nds; memset(&nds, 0, sizeof(nds));
             if(nd_launches)
             {
@@ -5900,7 +5924,8 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
                                   compact ? (nd_launches ? F.ndp_cur + NDH_NSEFF : F.cperm_cur + 2*n) : (const int*)NULL,
                                   compact ? &cp : (const LcholCompact*)NULL,
                                   compact ? (nd_launches ? F.nd_likely_panels : F.lchol_likely_panels) : 0,
-                                  compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL, nd_launches ? &nds : (const LcholNdLaunch*)NULL);
+                                  compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL, nd_launches ? &nds : (const LcholNdLaunch*)NULL,
+                                  finish_done);
             if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
             else if(!fused) return hipErrorInvalidValue;
         }
