@@ -5016,10 +5016,10 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
     const OpDev& O = ops[fl->elim_sel];
     if((int)blockIdx.x > nred)
     {
-        // The dissection's matrices, what no entry of the camera block goes to: the borders (zero: the chains' updates
-        // add up there), the pads' rows and columns (identity). Every entry (i, j <= i) of the two matrices, rhs row included
-        // ... and, a thread an entry, the copies of the permutation and of the plan that the factorization goes by (one
-        // workgroup's ten trips to memory for them were half of this launch's time)
+        // The workgroups behind the reduction's own (the dissection): a thread an entry of the copies of the permutation and
+        // of the plan that the factorization goes by (one workgroup's ten trips to memory for them were half of this
+        // launch's time), then of what no entry of the camera block goes to in the sides' matrices - the borders (zero:
+        // the chains' updates add up there) and the pads' rows and columns (identity)
         const long long e_first = (long long)((int)blockIdx.x - nred - 1)*blockDim.x + threadIdx.x, e_step = (long long)nfill*blockDim.x;
         if(cperm_cur != NULL && O.cperm != NULL)
             for(long long e = e_first; e < 2*nd.Nc + 1; e += e_step) cperm_cur[e] = O.cperm[e];
