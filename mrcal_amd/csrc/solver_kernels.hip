@@ -4561,6 +4561,17 @@ void lchol_backward_apply_kernel(int n, const int* __restrict__ skip, double* __
     if(t < LCH_NB && c < row_lo) z[c] -= (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
 }
 
+} // namespace mrcal_amd
+// dev / tests (no declaration in include/: not part of the interface): what launch l of the launch-per-panel factorization
+// of an n x n matrix consists of (lchol_plan(), the function the host sizes its grids with and the kernels find their
+// role by). out[10]: npanels, has_next, incl00, ntiles, ntrsm, nchain, ntile, nblocks, pprev, npad. Needs no GPU
+extern "C" void mrcal_amd_debug_lchol_plan(int n, int l, int with_inverse, int own, int* out)
+{
+    const mrcal_amd::LcholPlan q = mrcal_amd::lchol_plan(n, l, with_inverse != 0, own);
+    out[0] = q.npanels; out[1] = q.has_next; out[2] = q.incl00; out[3] = q.ntiles; out[4] = q.ntrsm;
+    out[5] = q.nchain;  out[6] = q.ntile;    out[7] = q.nblocks; out[8] = q.pprev; out[9] = q.npad;
+}
+namespace mrcal_amd {
 // the workspace behind FactorBuffers::Linv: [npanels][64][64] inverse diagonal blocks | Yb [npad][npad] | zc [npad]
 static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB)*LCH_NB; }
 // sd (optional): the trial step this factorization belongs to - its end-of-trial logic rides in the first launch and
