@@ -606,7 +606,8 @@ def test_nested_dissection_of_the_control_point_grid(amd):
     having, the coupled control points are ordered [side A | side B | strip], the two sides' panels of the big Cholesky
     are factored side by side, and the solve ends with d_A = -Y_A^T (z_A + L_SA^T d_S). Configuration 2 reduced to 200
     frames, solved
-      - as it is: the dissection is in use (launches provided, the final point's plan active, both sides >= a panel);
+      - as it is: the dissection is in use (launches provided, the final point's plan active, both sides >= a panel),
+        and the plan is the one the planner restated on the host makes from the final point's Jacobian;
       - the same again: the same bits (every sum of it in a fixed order);
       - with the separator's panels past the first left to lchol_tail_kernel: the same bits;
       - with launches for ONE round where the plan needs more (MRCAL_AMD_ND_ROUNDS=1): no plan fits, every point goes the
@@ -622,11 +623,41 @@ from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_L
 from mrcal_amd.resident import Problem
 oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
                                  lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False)
+def restated_plan(p, nd):
+    # the planner of spl_compact_body() again, from the final point's Jacobian: the boxes of control points under the boards
+    # (columns with a value in the board's rows), the covered rectangle of every box, the cheapest strip that fits
+    lm = oi["lensmodel"]
+    Nx = int(lm.split("Nx=")[1].split("_")[0]); Ny = int(lm.split("Ny=")[1].split("_")[0]); nk = Nx*Ny
+    J = p.J().tocsr()
+    Nc = mrcal_amd.num_states_intrinsics(**oi) + (2 if oi.get("do_optimize_calobject_warp", True) and oi.get("calobject_warp") is not None else 0)
+    ncore = mrcal_amd.num_states_intrinsics(**oi) - 2*nk
+    covered = np.zeros((Ny, Nx), bool); W = 0
+    for o in range(oi["observations_board"].shape[0]):
+        rows = J[200*o:200*(o+1)]
+        idx  = rows.indices[(rows.data != 0) & (rows.indices >= ncore) & (rows.indices < ncore + 2*nk)]
+        if len(idx) == 0: continue
+        k = (np.unique(idx) - ncore)//2
+        x, y = k %% Nx, k // Nx
+        covered[y.min():y.max()+1, x.min():x.max()+1] = True
+        W = max(W, int(x.max() - x.min() + 1))
+    n1 = 2*int(covered.sum()) + (Nc - 2*nk)
+    cnt = covered.sum(axis=0); ws = W - 1
+    best = None; bestcost = -(-n1//64)
+    for s0 in range(0, Nx - ws):
+        ar = 2*int(cnt[:s0].sum()); br = 2*int(cnt[s0+ws:].sum()); sr = n1 - ar - br
+        a, b, s = -(-ar//64), -(-br//64), -(-sr//64)
+        if a < 1 or b < 1 or sr < 1: continue
+        cost = max(a, b) + 1 + s
+        fits = nd["rounds"] > 0 and a <= nd["rounds"] and b <= nd["rounds"] and sr <= nd["ns_max"] and 64*max(a, b) <= 1024
+        if fits and cost < bestcost: bestcost = cost; best = (64*a, 64*b, sr)
+    return dict(active=int(best is not None), nA=best[0] if best else 0, nB=best[1] if best else 0, nS=best[2] if best else n1)
 out = []
 for rep in range(2):
     with Problem(**copy_inputs(oi)) as p:
         s = p.solve()
-        out.append(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), nd=p.dissection()))
+        nd = p.dissection()
+        out.append(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), nd=nd,
+                        restated=restated_plan(p, nd) if rep == 0 else None))
 print("RESULT " + json.dumps(out))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
@@ -637,6 +668,9 @@ print("RESULT " + json.dumps(out))
     nd, nd2, tail, unfit, off = res["nd"][0], res["nd"][1], res["tail"][0], res["unfit"][0], res["off"][0]
     assert nd["nd"]["rounds"] >= 1 and nd["nd"]["active"] == 1 and nd["nd"]["nA"] >= 64 and nd["nd"]["nB"] >= 64 and nd["nd"]["nS"] > 0, nd["nd"]
     assert off["nd"]["rounds"] == 0 and unfit["nd"]["rounds"] == 1 and unfit["nd"]["active"] == 0
+    # the device's plan at the final point = the planner restated on the host from that point's Jacobian
+    for arm in (nd, unfit):
+        assert {k: arm["nd"][k] for k in ("active", "nA", "nB", "nS")} == arm["restated"], (arm["nd"], arm["restated"])
     same = lambda a, b: (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"]
     assert same(nd, nd2) and same(nd, tail)
     assert same(unfit, off)
