@@ -322,8 +322,9 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             P->plan.spl_compact = 1;
             // ... and in a nested-dissection order where the boards leave a strip worth having (solver_kernels.hip,
             // lchol_nd_*): one camera's grid. MRCAL_AMD_NO_ND=1: off (MRCAL_AMD_LCHOL_SEPARATE_FINISH, whose launches
-            // the dissection's would not go with, too)
-            static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL || getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL);
+            // the dissection's would not go with, and MRCAL_AMD_FINISH_IN_FACTOR, too)
+            static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL || getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL ||
+                                        getenv("MRCAL_AMD_FINISH_IN_FACTOR") != NULL);
             if(!nd_off && P->D.Ncameras_intrinsics == 1)
             {
                 const size_t Npos = (size_t)nd.Nc + 2*ND_PANEL;

@@ -601,6 +601,44 @@ with Problem(**copy_inputs(oi)) as p:
 
 
 @pytest.mark.timeout(900)
+def test_end_of_trial_in_the_reduction_or_in_the_factorization_same_bits(amd):
+    """Round 5: on a single GPU the end-of-trial logic (step2_finish: the rho test, accept / reject, the trust region,
+    termination) rides in the reduction's launch instead of heading the factorization's. A relocation: the same decisions
+    from the same numbers - a camera block in LDS (OPENCV8, 3 cameras) and a big one (splined 30x20: the launch-per-panel
+    Cholesky with the compaction and the dissection), each solved both ways (MRCAL_AMD_FINISH_IN_FACTOR=1: as it was,
+    which also turns the dissection's launches off - those need the verdict before their first launch), to the same bits
+    where the factorization is the same and to a reordering of the pivots where it is not"""
+    import os, subprocess, sys, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+import mrcal_amd
+from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
+from mrcal_amd.resident import Problem
+out = {}
+for tag, kw in (("opencv8", dict(Ncameras=3, Nframes=60, lensmodel="LENSMODEL_OPENCV8", seed=5)),
+                ("splined", dict(Ncameras=1, Nframes=120, lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False))):
+    oi, _ = make_calibration_problem(mrcal_amd._api, object_width_n=10, object_height_n=10, **kw)
+    with Problem(**copy_inputs(oi)) as p:
+        s = p.solve()
+        out[tag] = dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), rounds=p.dissection()["rounds"])
+print("RESULT " + json.dumps(out))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    res = {}
+    for tag, env in (("rides", {"MRCAL_AMD_NO_ND": "1"}), ("head", {"MRCAL_AMD_FINISH_IN_FACTOR": "1"}), ("nd", {})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for model in ("opencv8", "splined"):
+        a, b = res["rides"][model], res["head"][model]
+        assert (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"], model
+        assert a["rounds"] == 0 and b["rounds"] == 0
+    # (with the dissection's launches on top - the default - the splined solve is the same solve in another order of the pivots)
+    a, c = res["rides"]["splined"], res["nd"]["splined"]
+    assert a["Nout"] == c["Nout"] and abs(a["rms"] - c["rms"]) < 1e-8*a["rms"]
+    assert res["nd"]["opencv8"]["b"] == res["rides"]["opencv8"]["b"]
+
+
 def test_nested_dissection_of_the_control_point_grid(amd):
     """The splined models with one camera (solver_kernels.hip lchol_nd_*): where the boards leave a strip of the grid worth
     having, the coupled control points are ordered [side A | side B | strip], the two sides' panels of the big Cholesky
