@@ -152,6 +152,12 @@ def other_configurations(only=None):
     from mrcal_amd.resident  import Problem
     from mrcal_amd.synthetic import make_calibration_problem, make_sfm_problem, copy_inputs, CONFIG2_LENSMODEL
     SEED_BOARDS, SEED_SFM, STEPS, WARMUP, EXTRA = 0, 6, 20, 3, 12
+    traffic_by_config = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r06_jacobian_kernel_hbm_traffic.json")))
+        traffic_by_config = {k: v for k, v in tj.get("configs", {}).items()}
+    except Exception:
+        pass
     def boards(**kw):
         return make_calibration_problem(mrcal_amd._api, object_width_n=10, object_height_n=10, seed=SEED_BOARDS, **kw)[0]
     table = (
@@ -200,19 +206,94 @@ def other_configurations(only=None):
                                                  achieved = ach, peak = HBM_PEAK_GBS, unit = "GB/s", frac = ach/HBM_PEAK_GBS,
                                                  algorithmic_bytes_per_launch = alg, kernel_ms_avg = kms, kernel_ms_min = kmin,
                                                  kernel_ms_max = kmax, launches_timed = nl, timed_every = 1,
-                                                 timed_in = f"{EXTRA} further trial steps behind the {n} timed ones", traffic = None)
-            with Problem(**copy_inputs(oi)) as p2:
-                p2.synchronize(); torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                s2 = p2.solve()
-                p2.synchronize()
-                entry["full_solve"] = dict(seconds = time.perf_counter() - t0, iterations = s2["Niterations"],
-                                           evaluations = s2["Nevaluations"], outlier_passes = s2["Noutlier_passes"],
-                                           rms_reproj_error__pixels = s2["rms_reproj_error__pixels"],
-                                           Noutliers_board = s2["Noutliers_board"])
+                                                 timed_in = f"{EXTRA} further trial steps behind the {n} timed ones",
+                                                 traffic = traffic_by_config.get(key, {}).get("hbm_bytes_per_launch"),
+                                                 traffic_source = None if key not in traffic_by_config else
+                                                     "committed constant: profiles/r06_jacobian_kernel_hbm_traffic.json (rocprofv3 --pmc "
+                                                     "WRITE_SIZE / FETCH_SIZE, a pass each; not re-measured in this run)")
+            entry.update(full_solves(oi, Problem, copy_inputs, torch))
+            # (the product mode of round 6, never the metric: the same steps without the Jacobian stream, where the
+            #  problem has one to leave out)
+            with Problem(**copy_inputs(oi)) as p3:
+                if p3.jacobian_stream_is_optional():
+                    p3.set_jacobian_stream(False)
+                    _, tr = p3.run_steps(WARMUP, None)
+                    p3.synchronize(); torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n3, tr = p3.run_steps(STEPS, tr)
+                    p3.synchronize(); torch.cuda.synchronize()
+                    entry["ms_per_step_no_jacobian_stream"] = 1e3*(time.perf_counter() - t0)/n3
         except Exception as e:      # a configuration that fails says so in its entry; the line is still printed
             entry["error"] = f"{type(e).__name__}: {e}"
         out.append(entry)
+    return out
+
+
+def full_solves(oi, Problem, copy_inputs, torch):
+    """The second half of the metric: "one mrcal.optimize() with outlier rejection, from seed to
+    return" - the DROP-IN call, host arrays in, host arrays out, through the C ABI's mrcal_optimize()
+    (/root/reference/mrcal-pywrap.c:2149 -> mrcal.c:6179): problem creation, the observations across PCIe, the CSR
+    structure, the solve with its outlier passes, the results back, teardown. With the Jacobian stream ON in every
+    step (the metric's definition of a step). Beside it, separately named and never the metric:
+      full_solve_resident                      the solve alone on a problem already resident in HBM (what rounds 1-5
+                                               reported as full_solve), stream on
+      full_solve_no_jacobian_stream            the drop-in call as the product runs it by default (round 6: nothing
+                                               reads the CSR values a solve's steps would write; same bits out)
+      full_solve_resident_no_jacobian_stream   the resident solve in that mode"""
+    import mrcal_amd
+    out = {}
+    def stats(s, dt):
+        d = dict(seconds = dt, rms_reproj_error__pixels = s["rms_reproj_error__pixels"], Noutliers_board = s["Noutliers_board"])
+        for k_out, k_in in (("iterations", "Niterations"), ("evaluations", "Nevaluations"), ("outlier_passes", "Noutlier_passes")):
+            if k_in in s: d[k_out] = s[k_in]
+        return d
+    for key, stream in (("full_solve", True), ("full_solve_no_jacobian_stream", False)):
+        o = copy_inputs(oi)
+        prev = mrcal_amd.set_optimize_jacobian_stream(stream)
+        try:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s = mrcal_amd.optimize(**o)
+            dt = time.perf_counter() - t0
+        finally:
+            mrcal_amd.set_optimize_jacobian_stream(prev)
+        out[key] = stats(s, dt)
+        out[key]["what"] = "mrcal_amd.optimize(**optimization_inputs), seed to return, through the C ABI's mrcal_optimize(); " + \
+                           ("every step streams the CSR Jacobian to HBM (the metric's step)" if stream else
+                            "the product's default: the steps do not stream the CSR Jacobian nothing reads (NOT the metric)")
+    for key, stream in (("full_solve_resident", True), ("full_solve_resident_no_jacobian_stream", False)):
+        with Problem(**copy_inputs(oi)) as p2:
+            if not stream and not p2.jacobian_stream_is_optional():
+                continue
+            p2.set_jacobian_stream(stream)
+            p2.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s2 = p2.solve()
+            p2.synchronize()
+            out[key] = stats(s2, time.perf_counter() - t0)
+    return out
+
+
+def callback_times(oi, copy_inputs, torch, N=3):
+    """mrcal_amd.optimizer_callback(**optimization_inputs): the drop-in single evaluation, host arrays in and out
+    (/root/reference/mrcal-pywrap.c:1890-2010), ms per call (the best of N after one warm-up call): without the
+    Jacobian (x only), with it (rowptr, colidx and values across PCIe into fresh numpy arrays), and with the
+    factorization it returns by default"""
+    import mrcal_amd
+    out = {}
+    for key, kw in (("no_jacobian", dict(no_jacobian=True, no_factorization=True)),
+                    ("with_jacobian", dict(no_factorization=True)),
+                    ("with_jacobian_and_factorization", dict())):
+        best = None
+        for i in range(N + 1):
+            o = copy_inputs(oi)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = mrcal_amd.optimizer_callback(**o, **kw)
+            dt = time.perf_counter() - t0
+            del r
+            if i > 0: best = dt if best is None else min(best, dt)
+        out[key] = 1e3*best
     return out
 
 
@@ -311,21 +392,23 @@ def main():
     if args.warmup > 0:
         _, tr = problem.run_steps(args.warmup, tr)
     sync_all()
-    # an event pair around a launch costs the stream ~11 us (5.6 on each side of the kernel): every 8th launch of
-    # the dominant kernel is timed (7 of the default run's 56), not every one (which lengthened the measured step by
-    # those 11 us; every 4th, until round 5, by 2.8)
-    TIMED_EVERY = 8 if args.steps >= 40 else (4 if args.steps >= 16 else 1)      # (short runs: enough launches to average)
-    problem.jacobian_timing_begin(args.steps//TIMED_EVERY + 4, TIMED_EVERY)
+    # THE TIMED REGION: exactly --steps trial steps, nothing else on the stream (round 6: no event pairs in here at any
+    # --steps - a pair costs the stream ~11 us; until round 5 every 4th or 8th board launch carried one). Every step
+    # evaluates x AND streams the CSR values of J (the resident problem's default; said explicitly where it can be)
+    if not sharded: problem.set_jacobian_stream(True)
     t0 = time.perf_counter()
     n, tr = problem.run_steps(args.steps, tr)
     sync_all()
     dt = time.perf_counter() - t0
-    nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
     assert n == args.steps
-    # (round 5) where the choice of the trial point, its poses and the Jacobian are ONE launch the event pairs bracket all
-    # of it; the launch's own stamps say what the Jacobian stream alone took (first Jacobian store -> end)
-    fused = (not sharded) and problem.fuses_prologue()
-    sn, stream_ms, pose_ms, first_store_ms = problem.jacobian_stream_timing() if not sharded else (0, 0., 0., 0.)
+    # the dominant kernel's own duration: HIP event pairs around EVERY board launch of EXTRA further trial steps of
+    # the same solve, behind the timed ones (as configs[] does)
+    EXTRA = 16
+    problem.jacobian_timing_begin(EXTRA + 4, 1)
+    problem.run_steps(EXTRA, tr)
+    sync_all()
+    nlaunch, ktot_ms, kmin_ms, kmax_ms = problem.jacobian_timing_end()
+    TIMED_EVERY = 1
 
     dt_rank = dt
     if sharded:
@@ -417,14 +500,6 @@ def main():
                         kernel = "board_kernel<OPENCV,8,J,Gram> (residuals x, CSR Jacobian values, per-observation Gram on the FP64 matrix cores)",
                         achieved = achieved, peak = HBM_PEAK_GBS, unit = "GB/s",
                         frac = achieved/HBM_PEAK_GBS,
-                        **(dict(one_launch_with_choice_and_poses = True,
-                                kernel_ms_avg_meaning = "the WHOLE launch, event pair to event pair: the choice of the trial point, the joint poses "
-                                                        "and the Jacobian build (until round 4: the Jacobian launch alone, its poses a launch earlier)",
-                                jacobian_stream_ms_avg = stream_ms/sn, poses_ms_avg = pose_ms/sn, first_store_after_ms_avg = first_store_ms/sn,
-                                frac_jacobian_stream = alg_bytes/1e9/(stream_ms/sn*1e-3)/HBM_PEAK_GBS,
-                                jacobian_stream_meaning = "first Jacobian store -> last wave done, from wall-clock stamps (100 MHz) a sample of the "
-                                                          "launch's own waves leaves: the same bytes over the time the Jacobian stream runs")
-                           if (fused and sn > 0 and stream_ms > 0) else {}),
                         traffic = traffic,
                         traffic_source = None if traffic is None else
                             "committed constant: profiles/board_kernel_hbm_traffic.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes, "
@@ -432,6 +507,7 @@ def main():
                         algorithmic_bytes_per_launch = alg_bytes,
                         kernel_ms_avg = kernel_ms, kernel_ms_min = kmin_ms, kernel_ms_max = kmax_ms,
                         launches_timed = nlaunch, timed_every = TIMED_EVERY,
+                        timed_in = f"{EXTRA} further trial steps of the same solve behind the {args.steps} timed ones (no event pair inside the timed region)",
                         mfma = mfma),
         solver = dict(evaluations = st["Nevaluations"], factorizations = st["Nfactorizations"],
                       **({"collectives": st["Ncollectives"]} if sharded else {})),
@@ -450,20 +526,26 @@ def main():
     if ONE_DEVICE:
         result["transport"] = "host shared memory, all ranks on ONE device (MRCAL_AMD_BENCH_ONE_DEVICE=1): a check of the multi-rank path, NOT a measurement"
     if rank == 0 and not args.no_full_solve and not sharded:
-        # the second half of the metric: one full solve, seed to return,
-        # outlier rejection included, on a fresh copy
+        # the second half of the metric: one full solve, seed to return, outlier rejection included - the drop-in
+        # optimize() (round 6), the resident solve beside it, and both again in the product's no-stream mode
         from mrcal_amd.resident import Problem
-        p2 = Problem(**oi)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        s2 = p2.solve()
-        p2.synchronize()
-        result["full_solve"] = dict(seconds = time.perf_counter() - t0,
-                                    iterations = s2["Niterations"], evaluations = s2["Nevaluations"],
-                                    outlier_passes = s2["Noutlier_passes"],
-                                    rms_reproj_error__pixels = s2["rms_reproj_error__pixels"],
-                                    Noutliers_board = s2["Noutliers_board"])
-        p2.close()
+        from mrcal_amd.synthetic import copy_inputs
+        result.update(full_solves(oi, Problem, copy_inputs, torch))
+        result["optimizer_callback_ms"] = callback_times(oi, copy_inputs, torch)
+        # the metric's steps again, in the product mode that leaves the Jacobian stream out: separately named, NOT
+        # the metric (a step of the metric evaluates x AND J)
+        with Problem(**copy_inputs(oi)) as p3:
+            p3.set_jacobian_stream(False)
+            tr3 = None
+            if args.warmup > 0: _, tr3 = p3.run_steps(args.warmup, tr3)
+            p3.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n3, tr3 = p3.run_steps(args.steps, tr3)
+            p3.synchronize(); torch.cuda.synchronize()
+            result["ms_per_step_no_jacobian_stream"] = 1e3*(time.perf_counter() - t0)/n3
+            result["no_jacobian_stream_note"] = "product mode (round 6): the solve's steps do not stream the CSR values of J, which nothing " \
+                                                "in optimize() reads; identical bits in b_packed / x / outliers. NOT the metric: value, " \
+                                                "ms_per_step, roofline and full_solve are measured with the stream on"
 
     if rank == 0 and not sharded and not args.no_configs:
         result["configs"] = other_configurations()

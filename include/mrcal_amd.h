@@ -548,17 +548,6 @@ bool mrcal_amd_problem_jacobian_timing_begin(mrcal_amd_problem_t* problem, int c
 bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* problem, int capacity, int stride);
 bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* problem, int* Nlaunches,
                                            double* total_ms, double* min_ms, double* max_ms);
-/* Round 5: where every variable group is optimized and the lens model is of the OPENCV family, a trial step's choice
-   of the trial point, the prologue of its evaluation (the joint poses) and the Jacobian kernel are ONE launch
-   (_fuses_prologue() != 0): the Jacobian kernel's waves stage their pixels while the poses are being made and start
-   on their rows when their pose record's flag goes up. The event pairs above then bracket that whole launch - poses
-   included. _jacobian_stream_timing(), called after _timing_end(): of the launches it timed, how many left
-   device-side stamps and the sum over them of (end of the launch - first Jacobian store), ms: the Jacobian stream
-   alone, from wall-clock stamps a sample of the waves leaves (100 MHz). OPT-IN (MRCAL_AMD_FUSED_PROLOGUE=1 in the
-   environment when the problem is created): measured 4-6 us a step slower than the two launches at the metric's size
-   (profiles/r05_fused_prologue.txt), so the two launches stay the default and _fuses_prologue() is 0 */
-void mrcal_amd_problem_jacobian_stream_timing(mrcal_amd_problem_t* problem, int* Nlaunches, double* total_ms);
-int  mrcal_amd_problem_fuses_prologue(mrcal_amd_problem_t* problem);
 /* Round 5, the splined models with one camera: the camera block's coupled control points in a nested-dissection order
    where the boards leave a strip of the grid worth having - two sides whose panels the big Cholesky
    factors side by side, the strip last. out[9]: the rounds (panels a side) the factorization's launches are provided
@@ -655,6 +644,23 @@ int   mrcal_amd_problem_shard_info(mrcal_amd_problem_t* problem, int* info, int 
    of a solve do not depend on it beyond rounding; the block form of mrcal_amd_problem_get_normal_equations() and the
    cost of a step do. Returns the previous setting. (Processes that cannot call it: MRCAL_AMD_ELIMINATE=frames|extrinsics) */
 int   mrcal_amd_set_elimination(int policy);
+/* Round 6: the solve WITHOUT the Jacobian stream. mrcal_optimize() returns no Jacobian (mrcal.h:453-521) and nothing
+   in the device-side dog leg reads the CSR values of J - the per-observation Grams carry the normal equations -, so a
+   solve may leave the 16 P k bytes per observation unwritten: the board kernel forms its rows, the
+   residuals and the Gram exactly as ever (the same instructions in the same order: x, b_packed, the outlier marks and
+   every statistic come out THE SAME BITS) and does not stream the rows to HBM. A product mode; the benchmark's metric -
+   a step = one evaluation of x AND J + one solve of the normal equations - is measured with the stream on.
+     mrcal_amd_problem_set_jacobian_stream(problem, 0)   _solve() / _run_steps() of this resident problem leave the stream
+         out (default 1: on). J is then made on demand: _get_J(), _dev_J_values() and _evaluate(with_jacobian) evaluate
+         it at the resident state first. Honoured where the board kernel is the rows' only reader
+         (_jacobian_stream_is_optional(): boards under a parametric lens model; the splined models' assembly reads
+         the rows back, discrete points and triangulated pairs keep theirs: a few MB)
+     mrcal_amd_set_optimize_jacobian_stream(1)   the drop-in mrcal_optimize(), whose problem does not outlive the call,
+         streams J all the same (default 0: it does not)
+   Both return the previous setting */
+int   mrcal_amd_problem_set_jacobian_stream(mrcal_amd_problem_t* problem, int stream);
+int   mrcal_amd_problem_jacobian_stream_is_optional(mrcal_amd_problem_t* problem);
+int   mrcal_amd_set_optimize_jacobian_stream(int stream);
 /* Which part of the state the solver keeps as the dense block S and which it
    eliminates block by block (E). The state vector is the reference's either way;
      S index s -> state s (s < info[0]) or s + info[1];   E index e -> state info[2] + e
@@ -737,6 +743,10 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
 /* The same object from a resident problem, at its current state: x, J and the block normal equations by the problem's own
    kernels (no atomics: the same bits every time), copied device to device. What optimizer_callback() returns */
 mrcal_amd_factorization_t* mrcal_amd_factorization_create_from_problem(mrcal_amd_problem_t* problem);
+/* Why the last _create() / _create_from_problem() of the calling thread returned what it did: 0 a factorization; 1 NULL
+   because JtJ is not positive definite (the reference's None, mrcal-pywrap.c:1981-1988); 2 NULL for any other reason
+   (no device memory, a shard, a matrix without the declared structure): mrcal_amd_last_error() says which */
+int mrcal_amd_factorization_last_status(void);
 int    mrcal_amd_factorization_Nmeasurements(const mrcal_amd_factorization_t* f);
 void   mrcal_amd_factorization_destroy(mrcal_amd_factorization_t* f);
 int    mrcal_amd_factorization_Nstate (const mrcal_amd_factorization_t* f);

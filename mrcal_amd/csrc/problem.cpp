@@ -56,7 +56,6 @@ mrcal_amd_problem::~mrcal_amd_problem()
     hipFree(d_point_meta); hipFree(d_point_pool); hipFree(d_imagersizes);
     hipFree(d_tri_meta); hipFree(d_tri_px); hipFree(d_tri_outlier);
     hipFree(d_joint); hipFree(d_gram); hipFree(d_Jp); hipFree(d_Ji);
-    hipFree(d_fused_ready); hipFree(d_fused_ts);
     for(int i=0;i<2;i++)
     {
         hipFree(op[i].b); hipFree(op[i].x); hipFree(op[i].Jv); hipFree(op[i].spl_box);
@@ -273,11 +272,6 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
         return false;
     }
     ok = ok && dev_alloc(&P->d_gram,   (L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) ? (size_t)1 : (size_t)P->D.Nobs_board*gram_stride(L.Ndist));
-    if(ok && P->D.Nobs_board > 0 && board_launch_fuses_prologue(P->D))
-    {
-        ok = ok && dev_alloc(&P->d_fused_ready, (size_t)P->D.Nobs_board);
-        if(ok) HIP_TRY(hipMemset(P->d_fused_ready, 0, (size_t)P->D.Nobs_board*sizeof(unsigned)), ok = false);
-    }
     for(int i=0;i<2 && ok;i++)
     {
         ok = ok && dev_alloc(&P->op[i].A,       (size_t)nd.Nc*nd.Nc);
@@ -690,6 +684,14 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
         return false;
     }
     B.choose = choose;
+    // (round 6) a solve that was told to leave the Jacobian stream out: only the solver's own evaluations, and only
+    // where the board kernel is the rows' one reader (never the splined models, whose assembly reads them back)
+    if(P->jfree_now && with_normal && with_jacobian && P->D.Nobs_board > 0 &&
+       P->D.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC)
+    {
+        B.store_jacobian = false;
+        if(parts & EVAL_PART_BOARD) P->jacobian_stale = true;
+    }
     if(with_normal && (parts & EVAL_PART_ZERO))
     {
         if((parts & EVAL_PART_PROLOGUE) && P->D.Nobs_board > 0)
@@ -714,8 +716,6 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
         {
             if((P->ev_pool_seen++ % P->ev_pool_stride) == 0 && P->ev_pool_used + 2 <= (int)P->ev_pool.size())
             {
-                if(P->d_fused_ts != NULL && P->ev_pool_used/2 < P->fused_ts_capacity)
-                    B.fused_ts = P->d_fused_ts + 8*(size_t)(P->ev_pool_used/2);
                 e0 = P->ev_pool[P->ev_pool_used++];
                 e1 = P->ev_pool[P->ev_pool_used++];
             }
@@ -731,9 +731,19 @@ bool problem_evaluate_ref(mrcal_amd_problem* P, const OpRef& R, bool with_jacobi
     return true;
 }
 
+bool problem_ensure_jacobian(mrcal_amd_problem* P)
+{
+    if(!P->jacobian_stale) return true;
+    if(!problem_evaluate_op(P, P->icur, true, false)) return false;
+    HIP_TRY(hipStreamSynchronize(P->stream), return false);
+    return true;
+}
+
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal)
 {
     if(!problem_evaluate_ref(P, P->opref(i), with_jacobian, with_normal, EVAL_PART_ALL)) return false;
+    // (a host-driven evaluation always streams J: jfree_now is up only inside the solver's entry points)
+    if(with_jacobian && i == P->icur) P->jacobian_stale = false;
     P->stats.Nevaluations++;
     if(with_normal) P->op[i].have_normal = true;
     return true;
@@ -1257,7 +1267,29 @@ double*  mrcal_amd_problem_dev_b_packed(mrcal_amd_problem_t* p) { return p->op[p
 double*  mrcal_amd_problem_dev_x       (mrcal_amd_problem_t* p) { return p->op[p->icur].x;  }
 int32_t* mrcal_amd_problem_dev_J_rowptr(mrcal_amd_problem_t* p) { return p->d_Jp; }
 int32_t* mrcal_amd_problem_dev_J_colidx(mrcal_amd_problem_t* p) { return p->d_Ji; }
-double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* p) { return p->op[p->icur].Jv; }
+double*  mrcal_amd_problem_dev_J_values(mrcal_amd_problem_t* p) { return problem_ensure_jacobian(p) ? p->op[p->icur].Jv : NULL; }
+// (round 6) stream != 0 (the default): every evaluation of the solver writes the CSR values of J to HBM, as the
+// metric defines a step and as a caller who reads J between steps needs it. 0: mrcal_amd_problem_solve()
+// / _run_steps() leave the stream out where nothing in the solve reads it (boards under a parametric lens model): the
+// same x, b_packed, outliers - the same bits -, J made on demand (_get_J(), _dev_J_values(), _evaluate()) afterwards.
+// Returns the previous setting
+int mrcal_amd_problem_set_jacobian_stream(mrcal_amd_problem_t* p, int stream)
+{
+    const int old = p->solve_stores_jacobian ? 1 : 0;
+    if((stream != 0) != p->solve_stores_jacobian)
+    {
+        p->solve_stores_jacobian = (stream != 0);
+        // (the captured trial step has the board kernel's variant in it)
+        for(int i = 0; i < 3; i++)
+            if(p->step_graph[i]) { hipGraphExecDestroy(p->step_graph[i]); p->step_graph[i] = NULL; }
+    }
+    return old;
+}
+// does a solve of this problem go without the Jacobian stream when told to?
+int mrcal_amd_problem_jacobian_stream_is_optional(mrcal_amd_problem_t* p)
+{
+    return (p->D.Nobs_board > 0 && p->D.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC) ? 1 : 0;
+}
 void*    mrcal_amd_problem_stream      (mrcal_amd_problem_t* p) { return (void*)p->stream; }
 
 bool mrcal_amd_problem_set_b_packed(mrcal_amd_problem_t* p, const double* b)
@@ -1280,6 +1312,7 @@ bool mrcal_amd_problem_get_x(mrcal_amd_problem_t* p, double* x)
 }
 bool mrcal_amd_problem_get_J(mrcal_amd_problem_t* p, int32_t* rowptr, int32_t* colidx, double* values)
 {
+    if(values && !problem_ensure_jacobian(p)) return false;
     if(rowptr) HIP_TRY(hipMemcpyAsync(rowptr, p->d_Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), return false);
     if(colidx) HIP_TRY(hipMemcpyAsync(colidx, p->d_Ji, (size_t)p->Nnz*sizeof(int32_t),         hipMemcpyDeviceToHost, p->stream), return false);
     if(values) HIP_TRY(hipMemcpyAsync(values, p->op[p->icur].Jv, (size_t)p->Nnz*sizeof(double),          hipMemcpyDeviceToHost, p->stream), return false);
@@ -1306,20 +1339,6 @@ bool mrcal_amd_problem_jacobian_timing_begin_strided(mrcal_amd_problem_t* p, int
     p->ev_pool_seen = 0;
     p->ev_pool_stride = stride > 0 ? stride : 1;
     p->ev_pool_enabled = capacity > 0;
-    p->fused_stream_ms_total = 0.0; p->fused_stream_n = 0;
-    if(capacity > 0 && p->d_fused_ready != NULL)
-    {
-        if(p->fused_ts_capacity < capacity)
-        {
-            hipFree(p->d_fused_ts); p->d_fused_ts = NULL; p->fused_ts_capacity = 0;
-            HIP_TRY(hipMalloc((void**)&p->d_fused_ts, (size_t)8*capacity*sizeof(unsigned long long)), return false);
-            p->fused_ts_capacity = capacity;
-        }
-        // [first Jacobian store: min over the sampled waves | end: max | the launch's first workgroup starts: min | the pose workgroups are through: max]
-        std::vector<unsigned long long> init((size_t)8*p->fused_ts_capacity, 0ull);     // ([4..7]: -DFUSED_TS builds)
-        for(int i = 0; i < p->fused_ts_capacity; i++) { init[8*i] = ~0ull; init[8*i+2] = ~0ull; }
-        HIP_TRY(hipMemcpy(p->d_fused_ts, init.data(), init.size()*sizeof(unsigned long long), hipMemcpyHostToDevice), return false);
-    }
     while((int)p->ev_pool.size() < 2*capacity)
     {
         hipEvent_t e;
@@ -1341,25 +1360,6 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
         HIP_TRY(hipEventElapsedTime(&ms, p->ev_pool[i], p->ev_pool[i+1]), return false);
         n++; tot += ms; if(ms < mn) mn = ms; if(ms > mx) mx = ms;
     }
-    p->fused_stream_ms_total = 0.0; p->fused_stream_n = 0;
-    if(p->d_fused_ts != NULL && n > 0)
-    {
-        std::vector<unsigned long long> ts((size_t)8*std::min(n, p->fused_ts_capacity));
-        HIP_TRY(hipMemcpy(ts.data(), p->d_fused_ts, ts.size()*sizeof(unsigned long long), hipMemcpyDeviceToHost), return false);
-        p->fused_pose_ms_total = 0.0; p->fused_first_store_ms_total = 0.0;
-        for(size_t i = 0; i + 7 < ts.size(); i += 8)
-            if(ts[i] != ~0ull && ts[i+1] > ts[i])
-            {
-                if(getenv("MRCAL_AMD_FUSED_TS_PRINT") != NULL && ts[i+2] != ~0ull)
-                    fprintf(stderr, "fused launch, us after its first workgroup starts: choose through %.2f | pose records computed %.2f | stored %.2f | first J store %.2f | end %.2f\n",
-                            ts[i+4] ? (double)(ts[i+4] - ts[i+2])*1e-2 : -1., ts[i+5] ? (double)(ts[i+5] - ts[i+2])*1e-2 : -1., (double)(ts[i+3] - ts[i+2])*1e-2,
-                            (double)(ts[i] - ts[i+2])*1e-2, (double)(ts[i+1] - ts[i+2])*1e-2);
-                p->fused_stream_ms_total += (double)(ts[i+1] - ts[i])*1e-5;        // 100 MHz ticks -> ms
-                if(ts[i+2] != ~0ull && ts[i+3] > ts[i+2]) p->fused_pose_ms_total += (double)(ts[i+3] - ts[i+2])*1e-5;
-                if(ts[i+2] != ~0ull && ts[i] > ts[i+2])   p->fused_first_store_ms_total += (double)(ts[i] - ts[i+2])*1e-5;
-                p->fused_stream_n++;
-            }
-    }
     p->ev_pool_enabled = false;
     p->ev_pool_used = 0;
     if(Nlaunches) *Nlaunches = n;
@@ -1368,23 +1368,6 @@ bool mrcal_amd_problem_jacobian_timing_end(mrcal_amd_problem_t* p, int* Nlaunche
     if(max_ms)    *max_ms    = mx;
     return true;
 }
-
-// The launch that carries prologue and board kernel (board_fused_kernel): of the launches the last
-// jacobian_timing_begin()/_end() pair timed, how many left stamps and the sum of (end - first Jacobian store) in ms:
-// the Jacobian stream without the wait for the poses in front of it. 0 launches: the step does not use that launch
-void mrcal_amd_problem_jacobian_stream_timing(mrcal_amd_problem_t* p, int* Nlaunches, double* total_ms)
-{
-    if(Nlaunches) *Nlaunches = p->fused_stream_n;
-    if(total_ms)  *total_ms  = p->fused_stream_ms_total;
-}
-// dev: of the same launches, the sums of (the pose workgroups are through - the launch's first workgroup starts) and
-// (first Jacobian store - the launch's first workgroup starts), ms
-void mrcal_amd_problem_jacobian_stream_timing_detail(mrcal_amd_problem_t* p, double* pose_ms, double* first_store_ms)
-{
-    if(pose_ms)        *pose_ms        = p->fused_pose_ms_total;
-    if(first_store_ms) *first_store_ms = p->fused_first_store_ms_total;
-}
-int mrcal_amd_problem_fuses_prologue(mrcal_amd_problem_t* p) { return p->d_fused_ready != NULL ? 1 : 0; }
 
 // dev tool: average duration (ms) of nrep back-to-back launches of the
 // evaluation kernels alone, with the given debug_ablate bits
@@ -1419,7 +1402,7 @@ double mrcal_amd_problem_debug_time_evaluate(mrcal_amd_problem_t* p, bool with_g
 int mrcal_amd_problem_debug_timestamps(mrcal_amd_problem_t* p, bool with_gram, long long* out)
 {
     if(with_gram && !problem_prepare_solver(p)) return -1;
-    const size_t n = (size_t)p->D.Nobs_board*8;
+    const size_t n = (size_t)p->D.Nobs_board*10;
     long long* d = NULL;
     if(hipMalloc((void**)&d, n*sizeof(long long)) != hipSuccess) return -1;
     hipMemset(d, 0, n*sizeof(long long));

@@ -94,10 +94,6 @@ enum
     JOINT_MF      = 48,   // 27
     JOINT_DTJ_DTF = 75,   // 9
     JOINT_REC     = 84,   // what the board kernels read of a record
-    // (round 5) behind it, written only by the launch that carries the board kernel's waves too (board_fused_kernel):
-    // the observation's camera intrinsics (Nintrinsics <= 16; [84, 100)) and the two warp values ([100, 102)) at the trial state - what the
-    // other launches read from DeviceProblem::unpacked, which a wave of the same launch cannot rely on
-    JOINT_INTR    = 84,
     JOINT_STRIDE  = 112   // doubles between records: 896 bytes, 7 cache lines
 };
 

@@ -45,6 +45,14 @@ struct mrcal_amd_problem
     hipStream_t side_stream = NULL;
     hipEvent_t  ev_fork = NULL, ev_join = NULL;
     bool        have_jacobian_timing = false;
+    // (round 6) the solve without the Jacobian stream (include/mrcal_amd.h, mrcal_amd_problem_set_jacobian_stream):
+    // solve_stores_jacobian = what the solver's own evaluations do; jfree_now = a solver entry point is queueing
+    // evaluations in that mode right now; jacobian_stale = op[icur].Jv is NOT the Jacobian at op[icur].b: whoever
+    // hands J out (get_J, dev_J_values) evaluates first (problem_ensure_jacobian)
+    int         last_ctl_error = 0;         // SolverCtl::error of the last run_dogleg()
+    bool        solve_stores_jacobian = true;
+    bool        jfree_now             = false;
+    bool        jacobian_stale        = false;
     bool        capturing = false;      // a hipGraph capture is in progress on the stream
     // optional: an event pair per Jacobian-kernel launch, to average over a timed region
     std::vector<hipEvent_t> ev_pool;
@@ -52,14 +60,6 @@ struct mrcal_amd_problem
     int         ev_pool_seen = 0, ev_pool_stride = 1;      // launches since _begin(); every stride-th one is timed
     bool        ev_pool_enabled = false;
     int*                cperm_cur_alloc = NULL;    // what F.cperm_cur points at while the compaction is on (a communicator turns it off)
-    // the launch that carries prologue and board kernel (round 5): its hand-off flags; the stamps of the timed launches
-    // ([launch][8]: the first Jacobian store, the end, the launch's start, the poses through, wall_clock64 ticks of 10 ns;
-    // [4..7]: -DFUSED_TS builds), and what _timing_end() made of them
-    unsigned*           d_fused_ready = NULL;
-    unsigned long long* d_fused_ts    = NULL;
-    int                 fused_ts_capacity = 0;
-    double              fused_stream_ms_total = 0.0, fused_pose_ms_total = 0.0, fused_first_store_ms_total = 0.0;
-    int                 fused_stream_n = 0;
 
     // inputs
     double* d_seed_intrinsics   = NULL;
@@ -127,7 +127,7 @@ struct mrcal_amd_problem
         for(int i=0;i<5;i++) B.zero_n[i] = 0;
         B.zero_total = 0;
         B.choose = NULL;
-        B.fused_ready = d_fused_ready; B.fused_ts = NULL;
+        B.store_jacobian = true;
         return B;
     }
     mrcal_amd::EvalBuffers eval_buffers(int i, bool with_gram) const { return eval_buffers(opref(i), with_gram); }
@@ -141,6 +141,8 @@ namespace mrcal_amd {
 bool problem_prepare_solver(mrcal_amd_problem* P);
 // x, J (and the normal equations if with_normal) at op[i].b
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal);
+// makes op[icur].Jv the Jacobian at op[icur].b if a solve without the Jacobian stream left it otherwise
+bool problem_ensure_jacobian(mrcal_amd_problem* P);
 // the same, with the operating point possibly resolved on the device
 bool problem_evaluate_ref(mrcal_amd_problem* P, const mrcal_amd::OpRef& R, bool with_jacobian, bool with_normal,
                           int parts = mrcal_amd::EVAL_PART_ALL, hipStream_t stream = NULL /* default: the problem's */,

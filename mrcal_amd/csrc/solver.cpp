@@ -144,16 +144,11 @@ bool enqueue_initial_point(mrcal_amd_problem* P)
 // SolverCtl::error, in words
 static const char* solver_error_text(int error)
 {
-    return error == 2 ? "internal error: a wave of the fused prologue + board launch gave up waiting for its pose record" :
+    return error == 4 ? "internal error: the workgroups of the large Cholesky's tail kernel did not all become resident (its grid barrier timed out): "
+                        "is the GPU partitioned or CU-masked under this process? Nothing is known about the matrix" :
            error == 3 ? "internal error: a control point taken for uncovered by every board is coupled to other variables (spl_compact_kernel)" :
                         "could not make JtJ positive definite";
 }
-// does a trial step of this problem take ONE launch for the choice, the prologue and the board kernel?
-static bool step_is_fused(const mrcal_amd_problem* P)
-{
-    return P->d_fused_ready != NULL && prologue_takes_choose(P->D) && board_launch_fuses_prologue(P->D);
-}
-
 // One trial step of the dog-leg, entirely queued: every decision is taken on
 // the device (solver_kernels.hip, "the fused step"). segment: 0 = all of it;
 // 1 = up to the board kernel, 2 = the board kernel alone, 3 = after it
@@ -162,18 +157,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
     SolverCtl* ctl = P->d_ctl;
     const Step2Args a = step2_args(P);
     const OpRef Rto = { P->d_ops, &ctl->ia, solver_ctl_skip_eval2(ctl) };
-    // (round 5) where the problem allows it the choice, the prologue and the board kernel are ONE launch
-    // (kernels.hip board_fused_kernel): it is "the board kernel" of segment 2, and segment 1 is empty
-    const bool fused = step_is_fused(P);
-    if(fused)
-    {
-        if(segment == 0 || segment == 2)
-        {
-            const ChooseArgs ca = step2_choose_args(a);
-            if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO | EVAL_PART_BOARD, NULL, &ca)) return false;
-        }
-    }
-    else if(segment == 0 || segment == 1)
+    if(segment == 0 || segment == 1)
     {
         // the step from the current point (its Gauss-Newton step was computed when the
         // point was accepted); then the joint poses of the trial point
@@ -189,7 +173,7 @@ bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
             if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_PROLOGUE | EVAL_PART_ZERO)) return false;
         }
     }
-    if(!fused && (segment == 0 || segment == 2))
+    if(segment == 0 || segment == 2)
         if(!problem_evaluate_ref(P, Rto, true, true, EVAL_PART_BOARD)) return false;
     if(segment == 0 || segment == 3)
     {
@@ -241,11 +225,9 @@ bool queue_trial_step(mrcal_amd_problem* P)
         HIP_TRY(hipGraphLaunch(P->step_graph[0], P->stream), return false);
         return true;
     }
-    // (segment 1 is empty where the choice and the prologue ride in the board kernel's launch)
-    const bool seg1 = !step_is_fused(P);
-    if(seg1 && P->step_graph[1] == NULL && !capture_segment(P, 1, &P->step_graph[1])) return false;
+    if(P->step_graph[1] == NULL && !capture_segment(P, 1, &P->step_graph[1])) return false;
     if(P->step_graph[2] == NULL && !capture_segment(P, 3, &P->step_graph[2])) return false;
-    if(seg1) HIP_TRY(hipGraphLaunch(P->step_graph[1], P->stream), return false);
+    HIP_TRY(hipGraphLaunch(P->step_graph[1], P->stream), return false);
     if(!enqueue_trial_step(P, 2)) return false;
     HIP_TRY(hipGraphLaunch(P->step_graph[2], P->stream), return false);
     return true;
@@ -396,6 +378,7 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     }
     SolverCtl c;
     if(!read_ctl(P, &c)) return false;
+    P->last_ctl_error = c.error;
     if(c.error)
     {
         set_error("%s", solver_error_text(c.error));
@@ -648,7 +631,19 @@ void report_regularization(mrcal_amd_problem* P, const mrcal_problem_selections_
 
 } // namespace
 
+namespace { int& optimize_jacobian_stream_policy() { static int policy = 0; return policy; } }
+
 extern "C" {
+
+// (round 6) does the drop-in mrcal_optimize() stream the CSR values of J to HBM in every step although nothing reads
+// them? 0 (default): no - the same results to the bit, a shorter step. 1: yes, as the metric defines a step. For the
+// calls AFTER this one; returns the previous setting
+int mrcal_amd_set_optimize_jacobian_stream(int stream)
+{
+    const int old = optimize_jacobian_stream_policy();
+    optimize_jacobian_stream_policy() = stream ? 1 : 0;
+    return old;
+}
 
 // Resident tier: the full solve on a resident problem. Returns rms error, <0
 // on failure
@@ -663,12 +658,36 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
     const auto t0 = std::chrono::steady_clock::now();
     P->stats = mrcal_amd_solver_stats();
     int Noutliers = 0, Noutliers_tri = 0;
+    // (round 6: the evaluations queued from here on leave the Jacobian stream out if the problem was told so)
+    struct JfreeScope { mrcal_amd_problem* P; JfreeScope(mrcal_amd_problem* p) : P(p) { P->jfree_now = !P->solve_stores_jacobian; }
+                        ~JfreeScope() { P->jfree_now = false; } } jfree_scope(P);
     for(;;)
     {
         // the reference makes a new libdogleg context for every pass
         // (mrcal.c:6433-6439): the diagonal regularization starts over at 0
         P->stats.lambda = 0.0;
-        if(!run_dogleg(P, prm)) return -1.0;
+        P->last_ctl_error = 0;
+        if(!run_dogleg(P, prm))
+        {
+            // the compaction / dissection of a splined camera block rest on a classification of the control
+            // points (covered by a board's box or not; which side of the strip) that the reduction CHECKS against the
+            // data: an entry with no place in the compacted matrix that is not zero is error 3. Then the classification
+            // is wrong for this problem - a kind of row it does not know - and the answer is the ordinary reduction of
+            // the whole camblock, not a failed solve: both off for good, the pass again from the point it reached (every
+            // accepted point lowered the true cost). Loudly
+            if(P->last_ctl_error == 3 && P->plan.spl_compact)
+            {
+                fprintf(stderr, "mrcal_amd: WARNING: %s. Solving this problem without the compaction of its camera block\n", solver_error_text(3));
+                P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
+                for(int i = 0; i < 3; i++)
+                    if(P->step_graph[i]) { hipGraphExecDestroy(P->step_graph[i]); P->step_graph[i] = NULL; }
+                last_error_string().clear();
+                continue;
+            }
+            return -1.0;
+        }
+        // (every evaluation of a pass that streams J wrote it, the final point's included)
+        if(!P->jfree_now) P->jacobian_stale = false;
         if(!P->L.sel.do_apply_outlier_rejection) break;
         bool found;
         if(!mark_outliers(P, &Noutliers, &Noutliers_tri, &found)) return -1.0;
@@ -697,6 +716,8 @@ int mrcal_amd_problem_run_steps(mrcal_amd_problem_t* P, int Nsteps, double* trus
     if(!problem_prepare_solver(P)) return -1;
     DoglegParameters prm;
     if(trustregion_inout && *trustregion_inout > 0.0) prm.trustregion0 = *trustregion_inout;
+    struct JfreeScope { mrcal_amd_problem* P; JfreeScope(mrcal_amd_problem* p) : P(p) { P->jfree_now = !P->solve_stores_jacobian; }
+                        ~JfreeScope() { P->jfree_now = false; } } jfree_scope(P);
     if(!P->ctl_initialized || !(trustregion_inout && *trustregion_inout > 0.0))
     {
         if(!ctl_reset(P, prm, false)) return -1;
@@ -1057,6 +1078,10 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
                 Nmeas, Nstate);
 
     P->verbose = verbose;
+    // (round 6) mrcal_optimize() returns no Jacobian (mrcal.h:453-521) and the problem does not outlive the call:
+    // nothing can read the 300 MB a step would stream, unless the process was told to stream them all the same
+    // (mrcal_amd_set_optimize_jacobian_stream(): the benchmark's metric is defined with the stream)
+    mrcal_amd_problem_set_jacobian_stream(P, optimize_jacobian_stream_policy() ? 1 : 0);
     if(check_gradient)
     {
         // mrcal.c:6600-6605: no solve; libdogleg's dogleg_testGradient() for every

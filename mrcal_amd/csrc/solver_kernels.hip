@@ -1714,15 +1714,22 @@ void rows_generic_wave(const NormalDims& nd, const OpDev& O, int r_first, int ro
                     const int c = ei + cexp(cj) + 5;
                     if(c + rc->N > 900 || c + 3*rc->N - 160 < -900) { O.scalars[SC_BAD_STRUCTURE] = 2.0; continue; }
                     const int sh = max(si, sj), sl = min(si, sj);       // (S indices >= 0, E indices < 0)
-                    if(sl >= 0)                 repro_add(rc->acc, 0, (size_t)sh*nd.Nc + sl, v, c, rc->N);
-                    else if(sh >= 0)            repro_add(rc->acc, 1, (size_t)(-sl-1)*nd.Nc + sh, v, c, rc->N);
-                    else
+                    // a row that lists a column twice (p != q, the same variable): the cross term of (v_p + v_q)^2 is
+                    // 2 v_p v_q and both halves land on the one diagonal entry - rows_repro_row, which walks the ordered
+                    // pairs, adds it twice; so does this (the bound on N has room for it: launch_assemble_rows)
+                    const int times = (p != q && si == sj) ? 2 : 1;
+                    for(int t = 0; t < times; t++)
                     {
-                        int bi, ai, di, e0i, bj, aj, dj, e0j;
-                        E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
-                        E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
-                        if(bi == bj) repro_add(rc->acc, 2, (size_t)bi*36 + max(ai, aj)*6 + min(ai, aj), v, c, rc->N);
-                        else         O.scalars[SC_BAD_STRUCTURE] = 1.0;
+                        if(sl >= 0)                 repro_add(rc->acc, 0, (size_t)sh*nd.Nc + sl, v, c, rc->N);
+                        else if(sh >= 0)            repro_add(rc->acc, 1, (size_t)(-sl-1)*nd.Nc + sh, v, c, rc->N);
+                        else
+                        {
+                            int bi, ai, di, e0i, bj, aj, dj, e0j;
+                            E_to_block(nd, -si-1, &bi, &ai, &di, &e0i);
+                            E_to_block(nd, -sj-1, &bj, &aj, &dj, &e0j);
+                            if(bi == bj) repro_add(rc->acc, 2, (size_t)bi*36 + max(ai, aj)*6 + min(ai, aj), v, c, rc->N);
+                            else         O.scalars[SC_BAD_STRUCTURE] = 1.0;
+                        }
                     }
                     continue;
                 }
@@ -4087,8 +4094,14 @@ void lchol_panel_kernel(const int* __restrict__ n_dev, int n_host, const int* __
 #ifndef LCH_TAIL_WGS
 #define LCH_TAIL_WGS 96
 #endif
-__device__ __forceinline__ void lchol_grid_barrier(unsigned* __restrict__ counter, unsigned nwg, unsigned epoch, int* __restrict__ status)
+// Returns false if a workgroup never came (the grid is sized so that all of them are resident - launch_cholesky_large -, so
+// this is a surprise: a CU mask changed under the process, a debugger): *status = LCH_STATUS_BARRIER_TIMEOUT, which is
+// NOT "not positive definite" - lchol_apply_inverse_kernel turns it into SolverCtl::error 4 and the solve fails saying so
+//  - and the caller leaves the kernel instead of factoring on unsynchronized data
+#define LCH_STATUS_BARRIER_TIMEOUT 0x7fff0003
+__device__ __forceinline__ bool lchol_grid_barrier(unsigned* __restrict__ counter, unsigned nwg, unsigned epoch, int* __restrict__ status)
 {
+    __shared__ int barrier_ok;
     __syncthreads();
     if(threadIdx.x == 0)
     {
@@ -4096,15 +4109,19 @@ __device__ __forceinline__ void lchol_grid_barrier(unsigned* __restrict__ counte
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = epoch*nwg;
-        int spins = 0;
+        int spins = 0, ok = 1;
         while(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
         {
             __builtin_amdgcn_s_sleep(8);
-            if(++spins > (1 << 23)) { atomicExch(status, 3); break; }        // (a workgroup that never came: not a hang)
+            if(++spins > (1 << 23)) { atomicExch(status, LCH_STATUS_BARRIER_TIMEOUT); ok = 0; break; }
+            // (somebody else gave up: so do we)
+            if((spins & 1023) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LCH_STATUS_BARRIER_TIMEOUT) { ok = 0; break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        barrier_ok = ok;
     }
     __syncthreads();
+    return barrier_ok != 0;
 }
 __global__ __launch_bounds__(LCH_THREADS)
 void lchol_tail_kernel(const int* __restrict__ n_dev, int n_host, const int* __restrict__ skip, double* __restrict__ M,
@@ -4124,7 +4141,7 @@ void lchol_tail_kernel(const int* __restrict__ n_dev, int n_host, const int* __r
             lchol_panel_body(n, l, q, bk, M, Linv, status, with_inverse != 0, lds);
             __syncthreads();                            // (the LDS is the next block's)
         }
-        lchol_grid_barrier(counter, gridDim.x, ++epoch, status);
+        if(!lchol_grid_barrier(counter, gridDim.x, ++epoch, status)) return;
     }
 }
 
@@ -4196,7 +4213,11 @@ void lchol_apply_inverse_kernel(const int* __restrict__ n_dev, int n_host, const
     }
     // with_post (round 5): what step2_post_kernel did in a launch of its own - the factorization's verdict into the
     // control block (every panel's diagonal workgroup has run: the status is final) - by one thread of this launch
-    if(with_post && blockIdx.x == 0 && threadIdx.x == 0) step2_chol_done(sd, *chol_status != 0);
+    if(with_post && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        if(*chol_status == LCH_STATUS_BARRIER_TIMEOUT) { sd.ctl->error = 4; sd.ctl->done = 1; }      // (not a verdict on the matrix)
+        step2_chol_done(sd, *chol_status != 0);
+    }
     __shared__ double part[16][LCH_AI_COLS];
     const int t = threadIdx.x, j16 = t & (LCH_AI_COLS - 1), slice = t >> 4;
     const int c = blockIdx.x*LCH_AI_COLS + j16;
@@ -4585,6 +4606,25 @@ static inline size_t lchol_npad(int n) { return (size_t)((n + LCH_NB - 1)/LCH_NB
 // lchol_nd_apply_kernel; the end-of-trial logic has run already (it rides in the reduction: step2_reduce_kernel), the
 // verdict rides in lchol_apply_inverse_kernel as ever
 struct LcholNdLaunch { LcholChain A, B; const int* ndh; NdLimits lim; };
+// lchol_tail_kernel's workgroups wait for each other (lchol_grid_barrier): every one of them must be RESIDENT at once.
+// LCH_TAIL_WGS of them (any number gives the same bits: they share the blocks of a panel round-robin), but never more than
+// the device holds of this kernel - a partitioned or CU-masked GPU with fewer than 96 free CUs would otherwise leave the
+// resident ones spinning for the ones queued behind them. Asked once per process
+static int lchol_tail_grid()
+{
+    static const int grid = []
+    {
+        int dev = 0, ncu = 0, per_cu = 0;
+        if(hipGetDevice(&dev) != hipSuccess) return 1;
+        if(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 1;
+        if(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lchol_tail_kernel, LCH_THREADS, 0) != hipSuccess || per_cu <= 0) return 1;
+        // (the occupancy query is an upper bound where the hardware admits one block fewer - MI355X_MICROARCH.md,
+        //  "Residency and cooperative launch": one block per CU at most is always safe, and 100 KB of LDS allow no more)
+        const long long resident = (long long)ncu*(per_cu > 1 ? 1 : per_cu);
+        return (int)std::max(1LL, std::min<long long>(LCH_TAIL_WGS, resident));
+    }();
+    return grid;
+}
 hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv, int* status, hipStream_t stream,
                                  const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL,
                                  int likely_panels = 0 /* with n_dev: launches 0 .. likely_panels one by one, the rest in lchol_tail_kernel; 0: all one by one */,
@@ -4636,7 +4676,7 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
                            n_dev, n, skip, M, l, Linv, status, sweep ? 0 : 1);
     }
     if(with_tail)
-        hipLaunchKernelGGL(lchol_tail_kernel, dim3(LCH_TAIL_WGS), dim3(LCH_THREADS), 0, stream,
+        hipLaunchKernelGGL(lchol_tail_kernel, dim3(lchol_tail_grid()), dim3(LCH_THREADS), 0, stream,
                            n_dev, n, skip, M, l_last + 1, Linv, status, 1, tail_counter);
     if(!sweep)
     {

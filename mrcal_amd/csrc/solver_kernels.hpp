@@ -343,7 +343,7 @@ struct SolverCtl
     int    done;                // the solve has terminated: every later kernel is a no-op
     int    abort_step;          // this trial step is void (factorization failed, lambda was raised)
     int    need_gn;             // this step needs the Gauss-Newton direction, and it is not computed yet
-    int    error;               // 1: lambda ran away; 2, 3: internal (solver.cpp solver_error_text())
+    int    error;               // 1: lambda ran away; 3, 4: internal (solver.cpp solver_error_text())
 
     // the step being tried
     double step_len_sq, expected_improvement;

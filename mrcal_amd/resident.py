@@ -88,12 +88,9 @@ class Problem:
         L.mrcal_amd_problem_jacobian_timing_begin_strided.restype,  L.mrcal_amd_problem_jacobian_timing_begin_strided.argtypes = C.c_bool, [vp, C.c_int, C.c_int]
         L.mrcal_amd_problem_jacobian_timing_end.restype  = C.c_bool
         L.mrcal_amd_problem_jacobian_timing_end.argtypes = [vp, ip, dpp, dpp, dpp]
-        L.mrcal_amd_problem_jacobian_stream_timing.restype  = None
-        L.mrcal_amd_problem_jacobian_stream_timing.argtypes = [vp, ip, dpp]
-        L.mrcal_amd_problem_jacobian_stream_timing_detail.restype  = None
-        L.mrcal_amd_problem_jacobian_stream_timing_detail.argtypes = [vp, dpp, dpp]
-        L.mrcal_amd_problem_fuses_prologue.restype, L.mrcal_amd_problem_fuses_prologue.argtypes = C.c_int, [vp]
         L.mrcal_amd_problem_dissection.restype, L.mrcal_amd_problem_dissection.argtypes = C.c_bool, [vp, ip]
+        L.mrcal_amd_problem_set_jacobian_stream.restype, L.mrcal_amd_problem_set_jacobian_stream.argtypes = C.c_int, [vp, C.c_int]
+        L.mrcal_amd_problem_jacobian_stream_is_optional.restype, L.mrcal_amd_problem_jacobian_stream_is_optional.argtypes = C.c_int, [vp]
         L._mrcal_amd_resident_declared = True
 
     def _check(self, ok, what):
@@ -139,17 +136,14 @@ class Problem:
         self._check(self._lib.mrcal_amd_problem_dissection(self.handle, out), "dissection")
         return dict(zip(("rounds", "ns_max", "active", "nA", "nB", "nS", "ideal_A", "ideal_B", "ideal_S"), [int(v) for v in out]))
 
-    def fuses_prologue(self):
-        """does a trial step of this problem choose its trial point, make its poses and build its Jacobian in ONE launch?"""
-        return bool(self._lib.mrcal_amd_problem_fuses_prologue(self.handle))
+    def set_jacobian_stream(self, stream):
+        """stream=False: solve() / run_steps() do not write the CSR values of J to HBM in every step (nothing in the
+        solve reads them; J() evaluates them on demand afterwards). The same bits in every result. Returns the previous
+        setting (include/mrcal_amd.h)"""
+        return bool(self._lib.mrcal_amd_problem_set_jacobian_stream(self.handle, 1 if stream else 0))
 
-    def jacobian_stream_timing(self):
-        """after jacobian_timing_end(): (Nlaunches, total_ms, pose_ms, first_store_ms) from the device-side stamps of the
-        one-launch trial steps among the launches that were timed (include/mrcal_amd.h); Nlaunches 0: none were"""
-        n = C.c_int(0); t = C.c_double(0); a = C.c_double(0); b = C.c_double(0)
-        self._lib.mrcal_amd_problem_jacobian_stream_timing(self.handle, C.byref(n), C.byref(t))
-        self._lib.mrcal_amd_problem_jacobian_stream_timing_detail(self.handle, C.byref(a), C.byref(b))
-        return n.value, t.value, a.value, b.value
+    def jacobian_stream_is_optional(self):
+        return bool(self._lib.mrcal_amd_problem_jacobian_stream_is_optional(self.handle))
 
     def set_b_packed(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)

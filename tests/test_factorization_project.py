@@ -385,3 +385,36 @@ def test_factorization_of_a_bare_matrix_is_reproducible(amd, case):
         Ns = (Jd/s).T @ (Jd/s)
         resid = np.abs((xs[0]*s) @ Ns - bt/s).max() / np.abs(bt/s).max()
         assert resid < 1e-8, resid
+
+
+def test_factorization_of_a_bare_matrix_with_a_column_listed_twice_in_a_run(amd):
+    """CSR input may list a column twice in a row (scipy does not forbid it; the entries add). In a RUN of
+    such rows - 8 or more with the same column list, which is what the half-wave path of launch_assemble_rows sums
+    across lanes - the cross term of (v_p + v_q)^2 must land on the diagonal entry twice, as it does when rows go one
+    by one. Runs of 40 rows with a repeated camera-block column and a repeated frame-block column, beside rows without
+    runs: JtJ against numpy's from the summed-up dense matrix, three times the same bits"""
+    import scipy.sparse
+    from mrcal_amd import CHOLMOD_factorization
+    rng = np.random.RandomState(11)
+    Nc, Nfb = 9, 6
+    Nstate = Nc + 6*Nfb
+    indptr, indices, data = [0], [], []
+    for f in range(Nfb):
+        cols = [1, 4, 4, 7, Nc + 6*f + 0, Nc + 6*f + 2, Nc + 6*f + 2, Nc + 6*f + 5]       # 4 and one frame variable: twice
+        for _ in range(40):                                                                  # a run: the same list, row after row
+            indices += cols; data += list(rng.normal(size=len(cols))); indptr.append(len(indices))
+        for _ in range(5):                                                                   # and rows of their own
+            c = sorted(rng.choice(Nc, size=4, replace=False)) + [Nc + 6*f + k for k in range(6)]
+            indices += c; data += list(rng.normal(size=len(c))); indptr.append(len(indices))
+    J = scipy.sparse.csr_matrix((np.array(data), np.array(indices, dtype=np.int32), np.array(indptr, dtype=np.int32)),
+                                shape=(len(indptr) - 1, Nstate))
+    assert J.nnz == len(data) and not J.has_canonical_format
+    Jd = np.zeros(J.shape)
+    for r in range(J.shape[0]):
+        for k in range(J.indptr[r], J.indptr[r+1]): Jd[r, J.indices[k]] += J.data[k]
+    N = Jd.T @ Jd
+    bt = rng.normal(size=(3, Nstate))
+    xs = [CHOLMOD_factorization(J, _partition=(Nc, Nfb, 0, 0)).solve_xt_JtJ_bt(bt) for _ in range(3)]
+    for x in xs[1:]: assert np.array_equal(x, xs[0])
+    ref = np.linalg.solve(N, bt.T).T
+    assert np.abs(xs[0] - ref).max() < 1e-9*np.abs(ref).max(), np.abs(xs[0] - ref).max()

@@ -407,6 +407,31 @@ def test_solve_is_bit_reproducible(amd, Ncameras, Nframes, lensmodel, extra):
     assert n0["norm2_x"] == n1["norm2_x"]
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("Ncameras,Nframes", ((4, 400), (8, 1000), (16, 2000)))
+def test_solve_without_the_jacobian_stream_gives_the_same_bits_at_full_size(amd, Ncameras, Nframes):
+    """Round 6's product mode - a solve that does not stream the CSR values of J to HBM (include/mrcal_amd.h,
+    mrcal_amd_problem_set_jacobian_stream) - at BASELINE.json's configurations 1, the metric's and 3: the same
+    iteration counts, the same outliers, the same bits in b_packed, x and the cost as the solve WITH the stream.
+    (Configuration 2, the splined model, keeps its stream: its assembly reads the rows back; the small-size test
+    tests/test_solver_parity.py::test_solve_without_the_jacobian_stream covers that the switch is ignored there)"""
+    from mrcal_amd.resident import Problem
+    oi, _ = make_calibration_problem(amd._api, Ncameras=Ncameras, Nframes=Nframes, lensmodel="LENSMODEL_OPENCV8",
+                                     object_width_n=10, object_height_n=10, seed=0)
+    runs = []
+    for stream in (True, False):
+        with Problem(**copy_inputs(oi)) as p:
+            p.set_jacobian_stream(stream)
+            s = p.solve()
+            runs.append((s["Niterations"], s["Nevaluations"], s["Nfactorizations"], s["Noutliers_board"],
+                         s["norm2_x"], p.b_packed(), p.x(), s["seconds"]))
+    a, b = runs
+    assert a[:4] == b[:4], (a[:4], b[:4])
+    assert a[4] == b[4]
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+    print(f"{Ncameras} x {Nframes}: solve with the stream {a[7]:.4f} s, without {b[7]:.4f} s")
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("what", ("boards+points", "points only", "pairs only", "boards+pairs+points"))
 def test_solve_with_points_and_pairs_is_bit_reproducible(amd, what):

@@ -523,48 +523,71 @@ def test_optimize_splined_reduced_configuration_2(amd, ref_api):
     _compare_splined_solves(amd, ref_api, oi, rms_tol=1e-6, btol=1e-3)
 
 
-def test_one_launch_trial_step_opt_in(amd):
-    """The opt-in form of the trial step (MRCAL_AMD_FUSED_PROLOGUE=1: the choice of the trial point, the joint poses and
-    the board Jacobian kernel in ONE launch, the pose records handed to the board waves inside it through write-through
-    stores and per-observation flags; profiles/r05_fused_prologue.txt for why it is not the default) must solve what
-    the two-launch form solves: same outliers, the same optimum. In a process of its own (the switch is read when
-    the library first asks)"""
-    import os, subprocess, sys, json
-    code = r'''
-import sys, json, numpy as np
-sys.path.insert(0, %r)
-import mrcal_amd
-from mrcal_amd.synthetic import make_calibration_problem, copy_inputs
-from mrcal_amd.resident import Problem
-out = {}
-for nc, nf, lm in ((3, 12, "LENSMODEL_OPENCV8"), (2, 9, "LENSMODEL_OPENCV4"), (2, 7, "LENSMODEL_PINHOLE"), (8, 300, "LENSMODEL_OPENCV8")):
-    oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=nc, Nframes=nf, lensmodel=lm, seed=5)
-    runs = []
-    for k in range(2):
-        with Problem(**copy_inputs(oi)) as p:
-            s = p.solve()
-            fused = p.fuses_prologue()            # (known once the solver's buffers exist)
-            runs.append((s["Niterations"], s["Noutliers_board"], s["rms_reproj_error__pixels"], s["norm2_x"], p.b_packed().tolist()))
-    assert runs[0] == runs[1], "not the same bits twice"
-    out["%%dx%%d %%s" %% (nc, nf, lm)] = dict(fused=bool(fused), Noutliers=runs[0][1], rms=runs[0][2], b=runs[0][4])
-print("RESULT " + json.dumps(out))
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
-    res = {}
-    for tag, env in (("two", {}), ("one", {"MRCAL_AMD_FUSED_PROLOGUE": "1"})):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    for k in res["two"]:
-        a, b = res["one"][k], res["two"][k]
-        assert b["fused"] is False and a["fused"] is True, (k, a["fused"], b["fused"])
-        # (THE SAME BITS: the library is built with -ffp-contract=on since round 5 - a multiply-add is fused where the
-        #  source writes a*b + c in one expression and nowhere else - so the formulas the two forms share round alike in
-        #  both kernels. Built with the default (fast: the backend fuses what it finds) the one-launch kernel's x and J
-        #  differed from the two-launch kernels' in the last bits of 0.2 % of the entries, enough to put ONE corner of
-        #  240 000 on the other side of the outlier threshold at 8 x 300)
-        assert a["Noutliers"] == b["Noutliers"], (k, a["Noutliers"], b["Noutliers"])
-        assert a["rms"] == b["rms"], (k, a["rms"], b["rms"])
-        assert np.array_equal(np.array(a["b"]), np.array(b["b"])), k
+def test_solve_without_the_jacobian_stream(amd):
+    """Round 6: a solve may leave the CSR values of J unwritten (nothing in the device-side dog leg reads them;
+    mrcal_optimize() returns no Jacobian: /root/reference/mrcal.h:453-521). The board kernel then forms the same rows,
+    residuals and Grams by the same instructions: everything a solve returns must be THE SAME BITS with the stream on
+    and off - on every kind of board kernel (all variables optimized: the fused Gram + copy-out loop; a locked block:
+    the general one; boards of 7x5: partial halves; discrete points and pairs beside the boards; the splined model,
+    which ignores the switch) -, and J, asked for after a solve without the stream, must be the Jacobian AT the
+    solution (made on demand), not what an earlier evaluation left there. The drop-in optimize() likewise, under
+    set_optimize_jacobian_stream()"""
+    from mrcal_amd.resident import Problem
+    from test_callback_parity import _with_points
+    from mrcal_amd.synthetic import make_sfm_problem
+    cases = []
+    for nc, nf, lm, kw in ((3, 12, "LENSMODEL_OPENCV8", {}), (2, 9, "LENSMODEL_OPENCV4", {}), (2, 7, "LENSMODEL_PINHOLE", {}),
+                           (2, 10, "LENSMODEL_OPENCV5", {}), (2, 8, "LENSMODEL_CAHVOR", {}),
+                           (2, 9, "LENSMODEL_OPENCV8", dict(object_width_n=7, object_height_n=5)),
+                           (4, 150, "LENSMODEL_OPENCV8", {}),
+                           (1, 12, "LENSMODEL_SPLINED_STEREOGRAPHIC_order=3_Nx=16_Ny=12_fov_x_deg=120", dict(do_optimize_intrinsics_core=False))):
+        oi, _ = make_calibration_problem(amd._api, Ncameras=nc, Nframes=nf, lensmodel=lm, seed=5, **kw)
+        cases.append((f"{nc}x{nf} {lm} {kw}", oi))
+    oi, _ = make_calibration_problem(amd._api, Ncameras=3, Nframes=14, lensmodel="LENSMODEL_OPENCV8", seed=6)
+    oi["do_optimize_intrinsics_distortions"] = False
+    cases.append(("distortions locked", oi))
+    oi, _ = make_calibration_problem(amd._api, Ncameras=3, Nframes=20, lensmodel="LENSMODEL_OPENCV8", seed=7)
+    cases.append(("boards + discrete points", _with_points(oi, np.random.RandomState(1), Npoints=30, Npoints_fixed=2)))
+    oi = make_sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=300, seed=6, noise=0.3, Nboard_frames=20)[0]
+    oi["do_apply_outlier_rejection"] = True
+    cases.append(("boards + triangulated pairs", oi))
+
+    for what, oi in cases:
+        res = []
+        for stream in (True, False):
+            with Problem(**copy_inputs(oi)) as p:
+                assert p.set_jacobian_stream(stream) is True
+                s = p.solve()
+                J = p.J()
+                res.append((s, p.b_packed(), p.x(), J.data.copy(), p.jacobian_stream_is_optional()))
+                # J is the Jacobian AT the solution: what a fresh evaluation there gives
+                p.evaluate(with_jacobian=True)
+                assert np.array_equal(p.J().data, J.data), what
+        (s0, b0, x0, J0, opt0), (s1, b1, x1, J1, opt1) = res
+        assert opt0 == opt1 == ("SPLINED" not in what), what
+        for k in ("Niterations", "Nevaluations", "Nfactorizations", "Noutlier_passes", "Noutliers_board", "norm2_x",
+                  "rms_reproj_error__pixels"):
+            assert s0[k] == s1[k], (what, k, s0[k], s1[k])
+        assert np.array_equal(b0, b1), what
+        assert np.array_equal(x0, x1), what
+        assert np.array_equal(J0, J1), what
+
+    # the drop-in: by default without the stream; with it on request; the same bits
+    import mrcal_amd
+    oi = cases[0][1]
+    outs = []
+    for stream in (False, True, False):
+        prev = mrcal_amd.set_optimize_jacobian_stream(stream)
+        try:
+            o = copy_inputs(oi)
+            outs.append((amd.optimize(**o), o))
+        finally:
+            mrcal_amd.set_optimize_jacobian_stream(prev)
+    assert mrcal_amd.set_optimize_jacobian_stream(False) is False        # (the default, and what the loop restored)
+    for s, o in outs[1:]:
+        assert np.array_equal(s["b_packed"], outs[0][0]["b_packed"]) and np.array_equal(s["x"], outs[0][0]["x"])
+        assert s["Noutliers_board"] == outs[0][0]["Noutliers_board"]
+        assert np.array_equal(o["observations_board"], outs[0][1]["observations_board"])
 
 
 @pytest.mark.timeout(900)
