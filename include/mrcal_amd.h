@@ -658,6 +658,15 @@ int   mrcal_amd_set_elimination(int policy);
      mrcal_amd_set_optimize_jacobian_stream(1)   the drop-in mrcal_optimize(), whose problem does not outlive the call,
          streams J all the same (default 0: it does not)
    Both return the previous setting */
+/* Hooks for the TESTS (not configuration): force, for the problems prepared after the call, paths a solve takes by
+   itself only when a later point outgrows what its first point needed, so that the suite can hold them to the bits of
+   the ordinary path. "lchol_likely_panels" = k: k launches of the big camera block's Cholesky are provided one by one,
+   the rest goes through lchol_tail_kernel; "nd_rounds" = k: launches for k rounds of the nested dissection whatever
+   the plan needs; "lchol_sweep" = 1: the big Cholesky's solve by the backward sweep (the stable fallback the solver
+   switches to by itself when a factor's diagonal spans more than 1e8). 0: not forced. Returns the previous value,
+   -1 for an unknown name. (Round 6: these were environment variables; the library reads six of those now -
+   MRCAL_AMD_GRAPH, _ELIMINATE, _RCCL, _LIB, _NO_ND, _NO_SPL_COMPACT - and MRCAL_AMD_DEBUG_SOLVER, which only prints) */
+int   mrcal_amd_set_test_hook(const char* name, int value);
 int   mrcal_amd_problem_set_jacobian_stream(mrcal_amd_problem_t* problem, int stream);
 int   mrcal_amd_problem_jacobian_stream_is_optional(mrcal_amd_problem_t* problem);
 int   mrcal_amd_set_optimize_jacobian_stream(int stream);

@@ -99,3 +99,15 @@ def set_optimize_jacobian_stream(stream):
     f = _lib.lib.mrcal_amd_set_optimize_jacobian_stream
     f.restype, f.argtypes = ctypes.c_int, [ctypes.c_int]
     return bool(f(1 if stream else 0))
+
+
+def set_test_hook(name, value):
+    """For the tests (include/mrcal_amd.h, mrcal_amd_set_test_hook): force a path of the big camera block's
+    factorization that a solve takes by itself only when a later point outgrows what its first point needed.
+    Returns the previous value"""
+    import ctypes
+    f = _lib.lib.mrcal_amd_set_test_hook
+    f.restype, f.argtypes = ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]
+    r = f(name.encode(), int(value))
+    if r < 0: raise ValueError(f"unknown test hook {name!r}")
+    return r

@@ -21,6 +21,6 @@ done
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=on \
     -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result \
-    -o $OUT -ldl $DEV \
+    -o $OUT -ldl -pthread $DEV \
     kernels.hip solver_kernels.hip problem.cpp cabi_layout.cpp solver.cpp factorization.cpp unproject.cpp comm.cpp cameramodel_io.cpp uncertainty.hip "$@"
 echo "built $(readlink -f $OUT)"

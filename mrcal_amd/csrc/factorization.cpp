@@ -213,12 +213,11 @@ mrcal_amd_factorization_create(int Nmeas, int Nstate,
     //  blocks or has a column out of range raises SC_BAD_STRUCTURE. A loop over all entries on the host was
     //  25 ms at 37 M entries)
     // This assembly goes row by row with atomics, on sums made so that no addition rounds (rows_repro_kernel, round 4): the same
-    // bits whatever order the atomics land in. (MRCAL_AMD_PLAIN_ROW_SUMS: the plain sums of before, for comparisons.)
+    // bits whatever order the atomics land in.
     // The factorization optimizer_callback() returns does not come through here: mrcal_amd_factorization_create_from_problem()
     const OpRef R = { f->d_op, NULL, NULL };
     double* scratch = NULL;
-    static const bool plain = (getenv("MRCAL_AMD_PLAIN_ROW_SUMS") != NULL);
-    if(!plain) HIP_TRY(hipMalloc((void**)&scratch, assemble_rows_scratch_doubles(f->nd)*sizeof(double)), { delete f; return NULL; });
+    HIP_TRY(hipMalloc((void**)&scratch, assemble_rows_scratch_doubles(f->nd)*sizeof(double)), { delete f; return NULL; });
     const hipError_t ea = launch_assemble_rows(f->nd, R, Nmeas, f->d_Jp, f->d_Ji, f->stream, scratch, Nnz);
     mrcal_amd_factorization* out = (ea == hipSuccess) ? factorization_finish(f) : NULL;      // (synchronizes the stream)
     if(ea != hipSuccess) { set_error("launch_assemble_rows: %s", hipGetErrorString(ea)); delete f; }

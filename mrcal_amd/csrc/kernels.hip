@@ -169,6 +169,83 @@ void joint_pose_record(double* __restrict__ out,
         }
 }
 
+// The same record by PRO_LPO lanes (round 6): forward-mode differentiation is one independent computation per
+// tangent direction, so lane l < 6 runs the pose chain on Dual<1> numbers seeded with variable l - the instructions
+// Dual<6> runs for component l, on the same operands: THE SAME BITS in every entry - and every lane runs the values.
+// What a lane leaves: column l of Mc (l < 3) or column l - 3 of Mf and of the translation's partials; lane 0 also
+// R and t. A lane's chain is the values' (three sincos, an acos, the square roots and divisions) plus ONE tangent
+// instead of six
+__device__ __forceinline__
+void joint_pose_record_lanes(double* __restrict__ out,
+                             const double* rt_cam, // NULL: camera at the reference
+                             const double* rt_frame, const int l)
+{
+    double R[9], dR[27];
+    if(rt_cam == NULL)
+    {
+        R_from_r_with_grad(R, dR, rt_frame);
+        if(l == 0)
+        {
+            for(int i=0;i<9;i++) out[JOINT_R + i] = R[i];
+            for(int i=0;i<3;i++) out[JOINT_T + i] = rt_frame[3+i];
+        }
+        // (ll a constant of the unrolled loop: dR stays in registers)
+#pragma unroll
+        for(int ll=0;ll<3;ll++)
+            if(l == ll)
+            {
+                for(int j=0;j<3;j++)
+                    for(int i=0;i<3;i++)
+                    {
+                        out[JOINT_MC + 9*j + 3*i + ll] = 0.0;
+                        out[JOINT_MF + 9*j + 3*i + ll] = dR[9*i + 3*j + ll];
+                    }
+                for(int i=0;i<3;i++)
+                {
+                    out[JOINT_DTJ_DRC + 3*i + ll] = 0.0;
+                    out[JOINT_DTJ_DTF + 3*i + ll] = (i==ll) ? 1.0 : 0.0;
+                }
+            }
+        return;
+    }
+    // rj = rc o rf ; this lane's variable: l in 0..2 = rc[l], 3..5 = rf[l-3] (none for the lanes past 5)
+    Dual<1> rc[3], rf[3], rj[3];
+    for(int i=0;i<3;i++)
+    {
+        rc[i] = Dual<1>(rt_cam  [i]); rc[i].d[0] = (l == i)   ? 1.0 : 0.0;
+        rf[i] = Dual<1>(rt_frame[i]); rf[i].d[0] = (l == 3+i) ? 1.0 : 0.0;
+    }
+    compose_r_dual<1>(rj, rc, rf);
+
+    // tj = R(rc) tf + tc ; the lane's variable: 0..2 = rc, 3..5 = tf
+    Dual<1> tf[3], tj[3];
+    for(int i=0;i<3;i++) { tf[i] = Dual<1>(rt_frame[3+i]); tf[i].d[0] = (l == 3+i) ? 1.0 : 0.0; }
+    rotate_point_r_dual<1>(tj, rc, tf, false);
+
+    double rjv[3];
+    for(int i=0;i<3;i++) rjv[i] = rj[i].x;
+    R_from_r_with_grad(R, dR, rjv);
+
+    if(l == 0)
+    {
+        for(int i=0;i<9;i++) out[JOINT_R + i] = R[i];
+        for(int i=0;i<3;i++) out[JOINT_T + i] = tj[i].x + rt_cam[3+i];
+    }
+    if(l >= 6) return;
+    // column l of Mc, or column l - 3 of Mf: M[j][i] = sum_k dR[i][j][k] drj[k]/dvar_l, in Dual<6>'s order of k
+    const int M0 = (l < 3) ? JOINT_MC + l : JOINT_MF + (l - 3);
+    for(int j=0;j<3;j++)
+        for(int i=0;i<3;i++)
+        {
+            double mm = 0.0;
+            for(int k=0;k<3;k++)
+                mm += dR[9*i + 3*j + k] * rj[k].d[0];
+            out[M0 + 9*j + 3*i] = mm;
+        }
+    const int T0 = (l < 3) ? JOINT_DTJ_DRC + l : JOINT_DTJ_DTF + (l - 3);
+    for(int i=0;i<3;i++) out[T0 + 3*i] = tj[i].d[0];
+}
+
 // (Measured alternative, not used: R(rc o rf) = R(rc) R(rf) gives the same record
 // from two R_from_r with gradients and ~230 multiply-adds, 3-4 us less for this
 // kernel. It is the more accurate route where the reference's is ill-conditioned
@@ -190,8 +267,10 @@ void regularization_row(const DeviceProblem& P, const OpRef& R,
     regularization_row_at<WITH_J,WITH_STRUCTURE>(P, b, opref_get(R).x, opref_get(R).Jv, rowptr, colidx, i);
 }
 
-#define PROLOGUE_ZERO_BLOCKS (1024*64/PRO_T)
-// Workgroups (PRO_T threads), in order: [pose records, an observation per thread] [unpacking of the
+// (1024 whatever there is to clear: every workgroup of the launch derives the dog-leg step's scalars first, and with 4096
+//  of them BASELINE configuration 2's prologue took 33 us instead of 25)
+#define PROLOGUE_ZERO_BLOCKS(total) (1024*64/PRO_T)
+// Workgroups (PRO_T threads), in order: [pose records, PRO_LPO lanes per observation: joint_pose_record_lanes] [unpacking of the
 // intrinsics and the warp] [clearing of the normal equations, if asked for]
 // [regularization rows, one per thread: reg_mode 0 = x only, 1 = x and J, -1 = none]
 // [CHOOSE: the dog-leg step, a state variable per thread].
@@ -208,7 +287,7 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
                          int nblocks_unpack, int nblocks_zero, int reg_mode)
 {
     double* __restrict__ joint = B.joint;
-    const int nblocks_obs = (P.Nobs_board + PRO_T - 1)/PRO_T;
+    const int nblocks_obs = prologue_obs_blocks(P.Nobs_board);
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack + nblocks_zero)
     {
         const int i = ((int)blockIdx.x - (nblocks_obs + nblocks_unpack + nblocks_zero))*PRO_T + threadIdx.x;
@@ -223,15 +302,19 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     // launch of its own)
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
     {
-        const long long nz = nblocks_zero;
-        for(long long i = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*PRO_T + threadIdx.x; i < B.zero_total; i += nz*PRO_T)
+        // (round 6: array by array, 16 bytes a store. It was one element a store behind a chain of five compares; at
+        //  BASELINE configuration 2 - 58 MB of A and Bt - that was what the prologue launch waited for, not the poses)
+        const long long nthreads = (long long)nblocks_zero*PRO_T;
+        const long long t0 = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*PRO_T + threadIdx.x;
+        double* const arr[5] = { O.A, O.Bt, O.D, O.g, O.scalars };
+#pragma unroll
+        for(int q = 0; q < 5; q++)
         {
-            long long j = i;
-            if(j < B.zero_n[0]) { O.A[j] = 0.0; continue; }        j -= B.zero_n[0];
-            if(j < B.zero_n[1]) { O.Bt[j] = 0.0; continue; }       j -= B.zero_n[1];
-            if(j < B.zero_n[2]) { O.D[j] = 0.0; continue; }        j -= B.zero_n[2];
-            if(j < B.zero_n[3]) { O.g[j] = 0.0; continue; }        j -= B.zero_n[3];
-            O.scalars[j] = 0.0;
+            double* __restrict__ p = arr[q];
+            const long long n = B.zero_n[q], npairs = n >> 1;
+            const double2 z = make_double2(0.0, 0.0);
+            for(long long i = t0; i < npairs; i += nthreads) reinterpret_cast<double2*>(p)[i] = z;
+            if((n & 1) && t0 == 0) p[n - 1] = 0.0;
         }
         return;
     }
@@ -254,24 +337,39 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
         return;
     }
 
-    const int iobs = (int)(blockIdx.x*blockDim.x + threadIdx.x);
+    // PRO_LPO lanes an observation (round 6; one lane did all of it until round 5: ~3000 dependent instructions, the
+    // launch as long as that chain whatever the number of observations)
+    const int lpo  = prologue_lanes(P.Nobs_board);
+    const int iobs = (int)blockIdx.x*(PRO_T/lpo) + (int)threadIdx.x/lpo;
+    const int l    = (int)threadIdx.x % lpo;
     if(iobs >= P.Nobs_board) return;
     const BoardObsMeta m = P.board_meta[iobs];
 
     double rt_frame[6], rt_cam[6];
     get_rt_ref_frame(rt_frame, P, b, m.iframe);
-    double rec[JOINT_REC];
-    if(m.icam_extrinsics >= 0)
+    double* out = joint + (size_t)iobs*JOINT_STRIDE;
+    if(lpo == 1)
+    {
+        // (many observations: a lane each, as until round 5)
+        double rec[JOINT_REC];
+        if(m.icam_extrinsics >= 0)
+        {
+            get_rt_cam_ref(rt_cam, P, b, m.icam_extrinsics);
+            joint_pose_record(rec, rt_cam, rt_frame);
+        }
+        else
+            joint_pose_record(rec, NULL, rt_frame);
+        for(int i=0;i<JOINT_REC;i++) out[i] = rec[i];
+    }
+    else if(m.icam_extrinsics >= 0)
     {
         get_rt_cam_ref(rt_cam, P, b, m.icam_extrinsics);
-        joint_pose_record(rec, rt_cam, rt_frame);
+        joint_pose_record_lanes(out, rt_cam, rt_frame, l);
     }
     else
-        joint_pose_record(rec, NULL, rt_frame);
-    double* out = joint + (size_t)iobs*JOINT_STRIDE;
-    for(int i=0;i<JOINT_REC;i++) out[i] = rec[i];
+        joint_pose_record_lanes(out, NULL, rt_frame, l);
     // splined models: the observation's box of control points starts empty (board_splined_kernel fills it)
-    if(O.spl_box != NULL) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
+    if(O.spl_box != NULL && l == 0) ((int4*)O.spl_box)[iobs] = make_int4(0x7fffffff, -1, 0x7fffffff, -1);
 }
 template<bool CHOOSE>
 __global__ __launch_bounds__(PRO_T)
@@ -283,7 +381,7 @@ void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, i
     {
         __shared__ double scratch[17*7];
         const ChooseOut c = dogleg_choose_scalars(ca, scratch);
-        const int first = (P.Nobs_board + PRO_T - 1)/PRO_T + nblocks_unpack + nblocks_zero + nblocks_reg;
+        const int first = prologue_obs_blocks(P.Nobs_board) + nblocks_unpack + nblocks_zero + nblocks_reg;
         if((int)blockIdx.x >= first)
         {
             dogleg_choose_elementwise(ca, c, ((int)blockIdx.x - first)*PRO_T + threadIdx.x);
@@ -1627,6 +1725,229 @@ void board_splined_kernel(DeviceProblem P, OpRef R, const double* __restrict__ j
     }   // h
 }
 
+// Round 6: the same rows by a lane per ROW (boards of 16 corners and more; board_splined_kernel<true> above stays for
+// the smaller ones). With a lane per corner BASELINE configuration 2's 80 000 corners are 1250 waves on 1024 SIMDs, one
+// generation, and the kernel's time IS a wave's life: 28.7 us, 46 % of it parked on memory (profiles/r06_config2_
+// jacobian_kernel_pmc.txt: 194 vector loads a wave, most of them the pose record's entries, asked for one chain-rule
+// term at a time). Here:
+//   * a wave takes 64 consecutive ROWS of the board observations' CSR rows (row = 2 corner + coordinate): twice the waves
+//     (2500: 2.4 a SIMD), each lane the projection's shared part + ONE surface (16 of the 32 control-point values, one
+//     sum, one row's chain rule): project_splined_row(), the same bits as project_splined()'s coordinate
+//   * the pose records of the (at most three) observations a wave's rows belong to are staged in LDS by two
+//     coalesced loads each; the chain rule reads them as LDS broadcasts
+//   * the rows leave through a 32-row LDS tile, half a wave at a time, as one contiguous stream (as above)
+// LDS: 32 x 33 doubles of values + 32 x 16 column indices + 3 records = 12.5 KB: twelve waves a CU
+#define SPLR_KT   33
+#define SPLR_NREC 3
+#define SPLR_LDS_BYTES (32*SPLR_KT*8 + 32*16*4 + SPLR_NREC*JOINT_REC*8)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3)))
+void board_splined_rows_kernel(DeviceProblem P, OpRef R, const double* __restrict__ joint,
+                               int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    double* __restrict__ x  = opref_get(R).x;
+    double* __restrict__ Jv = opref_get(R).Jv;
+    const int NPTS = P.W*P.H, RPO = 2*NPTS;                  // rows per observation
+    const int lane = threadIdx.x;
+    const long long nrows = (long long)P.Nobs_board*RPO;
+    const long long g0    = (long long)blockIdx.x*64;
+    const bool valid = g0 + lane < nrows;
+    const long long gi = valid ? g0 + lane : nrows - 1;      // (the lanes past the end repeat the last row and store nothing)
+    const int iobs = (int)(gi / RPO);
+    const int r    = (int)(gi - (long long)iobs*RPO);
+    const int pt   = r >> 1, xy = r & 1;
+
+    extern __shared__ double lds_spl[];
+    double*  __restrict__ lv  = lds_spl;                                   // [32][SPLR_KT]
+    int32_t* __restrict__ lc  = (int32_t*)(lds_spl + 32*SPLR_KT);          // [32][16]
+    double*  __restrict__ jpl = lds_spl + 32*SPLR_KT + 32*16/2;            // [SPLR_NREC][JOINT_REC]
+    // the records of this wave's observations (wave-uniform range)
+    const int obs0 = (int)(g0 / RPO);
+    const long long glast = (g0 + 63 < nrows) ? g0 + 63 : nrows - 1;
+    const int nrec = (int)(glast / RPO) - obs0 + 1;                        // <= SPLR_NREC for boards of >= 16 corners
+    for(int q = 0; q < nrec; q++)
+    {
+        const double* __restrict__ src = joint + (size_t)(obs0 + q)*JOINT_STRIDE;
+        jpl[q*JOINT_REC + lane] = src[lane];
+        if(lane < JOINT_REC - 64) jpl[q*JOINT_REC + 64 + lane] = src[64 + lane];
+    }
+    const BoardObsMeta m = P.board_meta[iobs];
+    const double* __restrict__ intr = P.unpacked + (size_t)m.icam_intrinsics*P.Nintrinsics;
+    const double* __restrict__ wp   = P.unpacked + (size_t)P.Ncameras_intrinsics*P.Nintrinsics;
+    const double* __restrict__ obs  = P.board_pool + ((size_t)iobs*NPTS + pt)*3;
+    const double qobs = obs[xy], w = obs[2];
+    const int  k       = m.nnz_per_row;
+    const bool has_ext = P.do_optimize_extrinsics && m.icam_extrinsics >= 0;
+    __builtin_amdgcn_wave_barrier();       // (one wave: the LDS is in order; the records are there)
+    const double* __restrict__ jp = jpl + (iobs - obs0)*JOINT_REC;
+
+    const int iy = pt / P.W;
+    const int ix = pt - iy*P.W;
+    const double bx = (double)ix * P.spacing;
+    const double by = (double)iy * P.spacing;
+    double bz = 0.0, dz_dw[2] = {0.0, 0.0};
+    if(P.has_warp_seed)
+    {
+        const double xr = (double)ix / (double)(P.W - 1);
+        const double yr = (double)iy / (double)(P.H - 1);
+        dz_dw[0] = 4.0*xr*(1.0 - xr);
+        dz_dw[1] = 4.0*yr*(1.0 - yr);
+        bz += wp[0]*dz_dw[0];
+        bz += wp[1]*dz_dw[1];
+    }
+    double p[3];
+    for(int i=0;i<3;i++)
+        p[i] = jp[JOINT_R+3*i+0]*bx + jp[JOINT_R+3*i+1]*by + jp[JOINT_R+3*i+2]*bz + jp[JOINT_T+i];
+
+    double q, dq_dp[3], dq_df, cfx[4], cfy[4];
+    int ivar0;
+    project_splined_row<true>(xy, &q, dq_dp, &dq_df, &ivar0, cfx, cfy, p, intr, P.cfg);
+
+    const bool inlier = (w >= 0.0);
+    if(valid) x[m.i_meas0 + r] = inlier ? (q - qobs)*w : 0.0;
+
+    // the observation's box of control points (as board_splined_kernel: both rows of a corner say the same)
+    int* __restrict__ box = opref_get(R).spl_box;
+    if(box != NULL && P.Ndist_state)
+    {
+        const int  n1   = P.cfg.spline_order + 1;
+        const int  knot = (ivar0 - 4) >> 1;
+        const int  kiy  = knot / P.cfg.spline_Nx, kix = knot - kiy*P.cfg.spline_Nx;
+        const bool ok   = valid && inlier;
+        unsigned long long todo = __ballot(ok);
+        while(todo)
+        {
+            const int  lead = __ffsll((long long)todo) - 1;
+            const int  ob   = __shfl(iobs, lead);
+            const bool in   = ok && iobs == ob;
+            int x0 = in ? kix : 0x7fffffff, x1 = in ? kix + n1 - 1 : -1;
+            int y0 = in ? kiy : 0x7fffffff, y1 = in ? kiy + n1 - 1 : -1;
+            for(int off = 32; off > 0; off >>= 1)
+            {
+                x0 = min(x0, __shfl_xor(x0, off)); x1 = max(x1, __shfl_xor(x1, off));
+                y0 = min(y0, __shfl_xor(y0, off)); y1 = max(y1, __shfl_xor(y1, off));
+            }
+            if(lane == lead)
+            {
+                atomicMin(&box[4*ob + 0], x0); atomicMax(&box[4*ob + 1], x1);
+                atomicMin(&box[4*ob + 2], y0); atomicMax(&box[4*ob + 3], y1);
+            }
+            todo &= ~__ballot(in);
+        }
+    }
+
+    // this lane's row, entry by entry, in registers first (both halves compute; a half at a time goes through the tile)
+    const long long dest0 = m.i_nnz0 + (long long)r*k;               // this row's first entry
+    const int cs = P.Ncore_state ? 2 : 0;                             // the control points' columns: [cs, cs + ns)
+    const int n  = P.cfg.spline_order + 1;
+    const int ns = P.Ndist_state ? n*n : 0;
+    const double ww = inlier ? w : 0.0;                               // outliers: same columns, zero values
+    for(int h = 0; h < 2; h++)
+    {
+        const bool mine = valid && (lane >> 5) == h;
+        if(mine)
+        {
+            double*  __restrict__ row = lv + (lane & 31)*SPLR_KT;
+            int32_t* __restrict__ ci  = lc + (lane & 31)*16;
+            int c = 0;
+            if(P.Ncore_state)
+            {
+                row[c++] = inlier ? dq_df * w * SCALE_INTRINSICS_FOCAL_LENGTH : 0.0;
+                row[c++] = ww * SCALE_INTRINSICS_CENTER_PIXEL;
+            }
+            if(P.Ndist_state)
+            {
+                const int col0 = m.i_state_intrinsics + P.Ncore_state + (ivar0 - 4);
+                int e = 0;
+                for(int jy=0;jy<n;jy++)
+                    for(int jx=0;jx<n;jx++)
+                    {
+                        ci[e++]  = col0 + jy*2*P.cfg.spline_Nx + jx*2 + xy;
+                        row[c++] = inlier ? cfx[jx]*cfy[jy]*intr[xy] * w * SCALE_DISTORTION : 0.0;
+                    }
+            }
+            if(has_ext)
+            {
+                for(int l=0;l<3;l++)
+                {
+                    double dp[3];
+                    for(int i=0;i<3;i++)
+                        dp[i] =
+                            bx*jp[JOINT_MC + 0  + 3*i + l] +
+                            by*jp[JOINT_MC + 9  + 3*i + l] +
+                            bz*jp[JOINT_MC + 18 + 3*i + l] +
+                            jp[JOINT_DTJ_DRC + 3*i + l];
+                    const double g = dq_dp[0]*dp[0] + dq_dp[1]*dp[1] + dq_dp[2]*dp[2];
+                    row[c+l]   = inlier ? g * w * SCALE_ROTATION_CAMERA : 0.0;
+                    row[c+3+l] = inlier ? dq_dp[l] * w * SCALE_TRANSLATION_CAMERA : 0.0;
+                }
+                c += 6;
+            }
+            if(P.do_optimize_frames)
+            {
+                for(int l=0;l<3;l++)
+                {
+                    double dpr[3], dpt[3];
+                    for(int i=0;i<3;i++)
+                    {
+                        dpr[i] =
+                            bx*jp[JOINT_MF + 0  + 3*i + l] +
+                            by*jp[JOINT_MF + 9  + 3*i + l] +
+                            bz*jp[JOINT_MF + 18 + 3*i + l];
+                        dpt[i] = jp[JOINT_DTJ_DTF + 3*i + l];
+                    }
+                    const double gr = dq_dp[0]*dpr[0] + dq_dp[1]*dpr[1] + dq_dp[2]*dpr[2];
+                    const double gt = dq_dp[0]*dpt[0] + dq_dp[1]*dpt[1] + dq_dp[2]*dpt[2];
+                    row[c+l]   = inlier ? gr * w * SCALE_ROTATION_FRAME    : 0.0;
+                    row[c+3+l] = inlier ? gt * w * SCALE_TRANSLATION_FRAME : 0.0;
+                }
+                c += 6;
+            }
+            if(P.has_warp_state)
+            {
+                const double d =
+                    dq_dp[0]*jp[JOINT_R + 2] +
+                    dq_dp[1]*jp[JOINT_R + 5] +
+                    dq_dp[2]*jp[JOINT_R + 8];
+                row[c+0] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[0]) : 0.0;
+                row[c+1] = inlier ? (w*SCALE_CALOBJECT_WARP)*(d*dz_dw[1]) : 0.0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the half's rows are one extent if they have the same number of entries and follow each other in the CSR arrays
+        // (always within an observation; across two unless one camera sits at the reference and the other does not)
+        const unsigned long long live = __ballot(mine);
+        if(live == 0ull) break;
+        const int       lead = 32*h;
+        const long long base = __shfl(dest0, lead);
+        const int       kk   = __shfl(k, lead);
+        const int       nrow = __popcll(live);
+        const bool uniform = __all(!mine || (k == kk && dest0 == base + (long long)(lane & 31)*kk));
+        if(uniform)
+        {
+            const int total = nrow*kk;
+            const int dr = 64 / kk, dc = 64 - dr*kk;
+            int rr = lane / kk, c = lane - rr*kk;
+            for(int e = lane; e < total; e += 64, rr += dr, c += dc)
+            {
+                if(c >= kk) { c -= kk; rr++; }
+                Jv[base + e] = lv[rr*SPLR_KT + c];          // (an ordinary store: the assembly reads these rows next)
+                if(c >= cs && c < cs + ns) colidx[base + e] = lc[rr*16 + (c - cs)];
+            }
+        }
+        else if(mine)
+        {
+            const int src = (lane & 31)*SPLR_KT;
+            for(int c = 0; c < k; c++)
+            {
+                Jv[dest0 + c] = lv[src + c];
+                if(c >= cs && c < cs + ns) colidx[dest0 + c] = lc[(lane & 31)*16 + (c - cs)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // discrete points, splined model: one lane per observation (2 rows)
 template<bool WITH_J>
 __global__ __launch_bounds__(64)
@@ -1856,9 +2177,9 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
 {
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
-        const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
+        const int nblocks_obs    = prologue_obs_blocks(P.Nobs_board);
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
-        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
+        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS(B.zero_total) : 0;
         const int Nreg_rows      = 0;      // the splined regularization has its own kernel
         const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
         launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);
@@ -1867,7 +2188,10 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
     {
         if(ev_j0) hipEventRecord(ev_j0, stream);
         const int n = P.Nobs_board*P.W*P.H;
-        if(with_jacobian)
+        // (round 6) a lane per row where a wave's 64 rows belong to at most SPLR_NREC observations
+        if(with_jacobian && P.W*P.H >= 16)
+            hipLaunchKernelGGL(board_splined_rows_kernel, dim3((int)(((long long)2*n + 63)/64)), dim3(64), SPLR_LDS_BYTES, stream, P, B.R, B.joint, B.Ji);
+        else if(with_jacobian)
             hipLaunchKernelGGL((board_splined_kernel<true>),  dim3((n+63)/64), dim3(64), 64*SPLB_KT*(sizeof(double) + sizeof(int32_t)), stream, P, B.R, B.joint, B.Ji);
         else
             hipLaunchKernelGGL((board_splined_kernel<false>), dim3((n+63)/64), dim3(64), 0, stream, P, B.R, B.joint, B.Ji);
@@ -2326,9 +2650,9 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
                         P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
-        const int nblocks_obs    = (P.Nobs_board + PRO_T - 1)/PRO_T;
+        const int nblocks_obs    = prologue_obs_blocks(P.Nobs_board);
         const int nblocks_unpack = (P.Ncameras_intrinsics*P.Nintrinsics + 2 + PRO_T - 1)/PRO_T;
-        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS : 0;
+        const int nblocks_zero   = (B.zero_total > 0) ? PROLOGUE_ZERO_BLOCKS(B.zero_total) : 0;
         const int Nreg_rows      = P.Nmeas - P.i_meas_regularization;
         const int nblocks_reg    = (Nreg_rows + PRO_T - 1)/PRO_T;
         launch_prologue(P, B, nblocks_obs, nblocks_unpack, nblocks_zero, nblocks_reg, with_jacobian, stream);

@@ -60,6 +60,20 @@ struct ChooseArgs;
 #ifndef PRO_T
 #define PRO_T 64
 #endif      // dogleg_choose.hpp
+// (round 6) the pose record of an observation is made by PRO_LPO lanes: lane l < 6 carries the forward-mode tangent
+// of variable l of the pose chain (kernels.hip joint_pose_record_lanes). Pose workgroups of the prologue launch
+// - where there are few enough observations for that to shorten the launch: with 8 lanes each the metric's 8000
+// observations are 1000 pose workgroups instead of 125, every one of which derives the dog-leg step's scalars for itself
+// first (dogleg_choose_scalars), and the launch measured 2 us LONGER (20.2 against 18.2 us); at 1600 observations 2 us
+// shorter (12.6 against 14.7). Either way the same bits (the lanes run Dual<6>'s instructions component by component)
+#define PRO_LPO 8
+#define PRO_LPO_MAX_OBS 4096
+__host__ __device__ static inline int prologue_lanes(int Nobs_board) { return Nobs_board <= PRO_LPO_MAX_OBS ? PRO_LPO : 1; }
+__host__ __device__ static inline int prologue_obs_blocks(int Nobs_board)
+{
+    const int per_wg = PRO_T/prologue_lanes(Nobs_board);
+    return (Nobs_board + per_wg - 1)/per_wg;
+}
 // what one evaluation reads and writes
 struct EvalBuffers
 {

@@ -556,6 +556,94 @@ void project_splined(double* q, double (*dq_dp)[3], double* dq_dfxy,
     }
 }
 
+// ONE image coordinate of the same projection (round 6: board_splined_rows_kernel, a lane per Jacobian ROW): coordinate
+// k = 0 (x) or 1 (y) touches surface k's control points only, so a row's lane reads 16 of the 32 values and sums one
+// surface. The expressions are project_splined()'s own, in its order, for that k: the same bits in q[k], dq_dp[k][.],
+// dq_dfxy[k] and the coefficients. qk, dqk_dp[3], dqk_dfk: of coordinate k
+template<bool WITH_GRAD>
+MRCAL_AMD_HD
+void project_splined_row(const int k, double* qk, double* dqk_dp, double* dqk_dfk,
+                         int* ivar0, double* coef_x /*[4]*/, double* coef_y /*[4]*/,
+                         const double* p, const double* intr, const LensConfig& cfg)
+{
+    const double fk = intr[k], ck = intr[2 + k];
+    const int order = cfg.spline_order, Nx = cfg.spline_Nx, Ny = cfg.spline_Ny;
+    const int n = order + 1;
+
+    const double mag   = sqrt(p[0]*p[0] + p[1]*p[1] + p[2]*p[2]);
+    const double scale = 2.0/(mag + p[2]);
+    const double u[2]  = { p[0]*scale, p[1]*scale };
+
+    const double ix = u[0]*cfg.spline_segments_per_u + (double)(Nx-1)/2.;
+    const double iy = u[1]*cfg.spline_segments_per_u + (double)(Ny-1)/2.;
+    int ix0, iy0;
+    if(order == 3)
+    {
+        ix0 = (int)ix;          iy0 = (int)iy;
+        ix0 = ix0 < 1 ? 1 : (ix0 > Nx-3 ? Nx-3 : ix0);
+        iy0 = iy0 < 1 ? 1 : (iy0 > Ny-3 ? Ny-3 : iy0);
+    }
+    else
+    {
+        ix0 = (int)(ix + 0.5);  iy0 = (int)(iy + 0.5);
+        ix0 = ix0 < 1 ? 1 : (ix0 > Nx-2 ? Nx-2 : ix0);
+        iy0 = iy0 < 1 ? 1 : (iy0 > Ny-2 ? Ny-2 : iy0);
+    }
+    *ivar0 = 4 + 2*((iy0-1)*Nx + (ix0-1));
+
+    double dcx[4], dcy[4];
+    bspline_basis(order, coef_x, dcx, ix - ix0);
+    bspline_basis(order, coef_y, dcy, iy - iy0);
+
+    const double* ctrl = intr + *ivar0 + k;
+    // (all the surface's values asked for before any is used: 16 loads in flight)
+    double c[4][4];
+#pragma unroll
+    for(int jy=0;jy<4;jy++)
+#pragma unroll
+        for(int jx=0;jx<4;jx++)
+            c[jy][jx] = (jy < n && jx < n) ? ctrl[jy*2*Nx + 2*jx] : 0.0;
+    double du = 0.0, du_dx = 0.0, du_dy = 0.0;
+    {
+        double rowv[4], rowd[4];
+#pragma unroll
+        for(int jy=0;jy<4;jy++)
+        {
+            double v = 0.0, d = 0.0;
+#pragma unroll
+            for(int jx=0;jx<4;jx++)
+                if(jx < n)
+                {
+                    v += coef_x[jx]*c[jy][jx];
+                    d += dcx[jx]*c[jy][jx];
+                }
+            rowv[jy] = v; rowd[jy] = d;
+        }
+#pragma unroll
+        for(int jy=0;jy<4;jy++)
+            if(jy < n)
+            {
+                du    += coef_y[jy]*rowv[jy];
+                du_dx += coef_y[jy]*rowd[jy];
+                du_dy += dcy[jy]   *rowv[jy];
+            }
+    }
+
+    *qk = (u[k] + du)*fk + ck;
+    if(dqk_dfk) *dqk_dfk = u[k] + du;
+    if(!WITH_GRAD) return;
+
+    const double A = -scale*scale/2.0;
+    const double B = A/mag;
+    const double du_dp[2][3] = { { p[0]*(B*p[0]) + scale, p[0]*(B*p[1]),         p[0]*(B*p[2] + A) },
+                                 { p[1]*(B*p[0]),         p[1]*(B*p[1]) + scale, p[1]*(B*p[2] + A) } };
+    const double s = cfg.spline_segments_per_u;
+    // (coordinate 0: fx (du0_dp (1 + du_dx s) + du_dy s du1_dp); coordinate 1: fy (du1_dp (1 + du_dy s) + du_dx s du0_dp))
+    const double own = k ? du_dy : du_dx, other = k ? du_dx : du_dy;
+    for(int j=0;j<3;j++)
+        dqk_dp[j] = fk*(du_dp[k][j]*(1.0 + own*s) + other*s*du_dp[1-k][j]);
+}
+
 // mrcal.c:1904-1952
 MRCAL_AMD_HD double spline_segments_per_u(int order, int Nx, double fov_x_deg)
 {

@@ -15,6 +15,7 @@
 #include "problem.hpp"
 #include "kernels.hpp"
 #include "problem_object.hpp"
+#include "host_copy.hpp"
 
 using namespace mrcal_amd;
 
@@ -295,8 +296,10 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     // touches a control point is a board's (no discrete points: they have no boxes) and all rows are here (not a shard:
     // the ranks of a sharded solve sum their camera blocks entry by entry). MRCAL_AMD_NO_SPL_COMPACT=1: off
     {
-        // (nor with the backward sweep of MRCAL_AMD_LCHOL_SWEEP, which knows nothing of a size the device decides)
-        static const bool off = (getenv("MRCAL_AMD_NO_SPL_COMPACT") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
+        // (nor with the backward sweep, which knows nothing of a size the device decides)
+        P->F.use_sweep = test_hooks().lchol_sweep ? 1 : 0;
+        static const bool env_off = (getenv("MRCAL_AMD_NO_SPL_COMPACT") != NULL);
+        const bool off = env_off || P->F.use_sweep;
         const bool whole = (int)P->board_sel.size() == L.dims.Nobservations_board && P->comm == NULL;
         if(!off && whole && L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && cholesky_large_workspace_doubles(nd.Nc) > 1 && nd.Nc <= 4096 &&
            P->D.Nobs_board > 0 && P->D.Nobs_point == 0 && P->D.Ndist_state > 0 && !nd.elim_extrinsics)
@@ -315,10 +318,8 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             P->F.cperm_cur = P->cperm_cur_alloc;
             P->plan.spl_compact = 1;
             // ... and in a nested-dissection order where the boards leave a strip worth having (solver_kernels.hip,
-            // lchol_nd_*): one camera's grid. MRCAL_AMD_NO_ND=1: off (MRCAL_AMD_LCHOL_SEPARATE_FINISH, whose launches
-            // the dissection's would not go with, and MRCAL_AMD_FINISH_IN_FACTOR, too)
-            static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL || getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL ||
-                                        getenv("MRCAL_AMD_FINISH_IN_FACTOR") != NULL);
+            // lchol_nd_*): one camera's grid. MRCAL_AMD_NO_ND=1: off
+            static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL);
             if(!nd_off && P->D.Ncameras_intrinsics == 1)
             {
                 const size_t Npos = (size_t)nd.Nc + 2*ND_PANEL;
@@ -1306,17 +1307,23 @@ bool mrcal_amd_problem_get_b_packed(mrcal_amd_problem_t* p, double* b)
 }
 bool mrcal_amd_problem_get_x(mrcal_amd_problem_t* p, double* x)
 {
-    HIP_TRY(hipMemcpyAsync(x, p->op[p->icur].x, (size_t)p->L.Nmeas*sizeof(double), hipMemcpyDeviceToHost, p->stream), return false);
-    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    if(!device_to_host(x, p->op[p->icur].x, (size_t)p->L.Nmeas*sizeof(double), p->stream))
+    {
+        set_error("copying x to the host failed: %s", hipGetErrorString(hipGetLastError()));
+        return false;
+    }
     return true;
 }
 bool mrcal_amd_problem_get_J(mrcal_amd_problem_t* p, int32_t* rowptr, int32_t* colidx, double* values)
 {
     if(values && !problem_ensure_jacobian(p)) return false;
-    if(rowptr) HIP_TRY(hipMemcpyAsync(rowptr, p->d_Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), hipMemcpyDeviceToHost, p->stream), return false);
-    if(colidx) HIP_TRY(hipMemcpyAsync(colidx, p->d_Ji, (size_t)p->Nnz*sizeof(int32_t),         hipMemcpyDeviceToHost, p->stream), return false);
-    if(values) HIP_TRY(hipMemcpyAsync(values, p->op[p->icur].Jv, (size_t)p->Nnz*sizeof(double),          hipMemcpyDeviceToHost, p->stream), return false);
-    HIP_TRY(hipStreamSynchronize(p->stream), return false);
+    // (round 6: the big ones through a pinned ring and a pool of copying threads - host_copy.hpp: the caller's arrays are
+    //  fresh pages, and one thread copying out of the runtime's staging buffer was 10 GB/s)
+    bool ok = true;
+    if(rowptr) ok = ok && device_to_host(rowptr, p->d_Jp, ((size_t)p->L.Nmeas+1)*sizeof(int32_t), p->stream);
+    if(colidx) ok = ok && device_to_host(colidx, p->d_Ji, (size_t)p->Nnz*sizeof(int32_t), p->stream);
+    if(values) ok = ok && device_to_host(values, p->op[p->icur].Jv, (size_t)p->Nnz*sizeof(double), p->stream);
+    if(!ok) { set_error("copying the Jacobian to the host failed: %s", hipGetErrorString(hipGetLastError())); return false; }
     return true;
 }
 

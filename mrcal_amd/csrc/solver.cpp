@@ -262,8 +262,8 @@ static bool learn_likely_size(mrcal_amd_problem* P)
     if(n1 <= 0 || n1 > P->nd.Nc) n1 = P->nd.Nc;
     // (launch l = npanels is the closing one: launches 0 .. npanels of THIS size one by one)
     P->F.lchol_likely_panels = (n1 + 63)/64;
-    // (MRCAL_AMD_LCHOL_LIKELY=k: k instead - the tests make lchol_tail_kernel do the work with it)
-    if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) P->F.lchol_likely_panels = k; }
+    // (the tests' hook: k instead - they make lchol_tail_kernel do the work with it)
+    if(test_hooks().lchol_likely_panels > 0) P->F.lchol_likely_panels = test_hooks().lchol_likely_panels;
     // The nested-dissection order (lchol_nd_*): the evaluation of this solve's first point has made a plan - the best
     // strip there is at that point - whether launches for it are provided or not. Launches for THAT plan are what the
     // factorizations of this solve get: rounds for the longer side, a border a panel larger than the separator; the plans
@@ -281,12 +281,12 @@ static bool learn_likely_size(mrcal_amd_problem* P)
         {
             const int a = (h[NDH_IDEAL_A] + ND_PANEL - 1)/ND_PANEL, b = (h[NDH_IDEAL_B] + ND_PANEL - 1)/ND_PANEL;
             lim = NdLimits{ std::max(a, b), h[NDH_IDEAL_NS] + ND_PANEL };
-            // (MRCAL_AMD_ND_ROUNDS=k: k rounds instead - with fewer than the plan needs, every point goes the ordinary
+            // (the tests' hook nd_rounds = k: k rounds instead - with fewer than the plan needs, every point goes the ordinary
             //  way through the dissection's launches: the tests hold that path to the bits of the path without them)
-            if(const char* e = getenv("MRCAL_AMD_ND_ROUNDS")) { const int k = atoi(e); if(k > 0) lim.rounds = k; }
+            if(test_hooks().nd_rounds > 0) lim.rounds = test_hooks().nd_rounds;
             if(ND_PANEL*lim.rounds > LCH_ND_WMAX) lim = NdLimits{ 0, 0 };
             likely = (h[NDH_IDEAL_NS] + ND_PANEL - 1)/ND_PANEL;
-            if(const char* e = getenv("MRCAL_AMD_LCHOL_LIKELY")) { const int k = atoi(e); if(k > 0) likely = k; }
+            if(test_hooks().lchol_likely_panels > 0) likely = test_hooks().lchol_likely_panels;
         }
         if(lim.rounds != P->F.nd_lim.rounds || lim.ns_max != P->F.nd_lim.ns_max || likely != P->F.nd_likely_panels)
         {
@@ -632,6 +632,7 @@ void report_regularization(mrcal_amd_problem* P, const mrcal_problem_selections_
 } // namespace
 
 namespace { int& optimize_jacobian_stream_policy() { static int policy = 0; return policy; } }
+namespace mrcal_amd { TestHooks& test_hooks() { static TestHooks h = {0, 0, 0}; return h; } }
 
 extern "C" {
 
@@ -642,6 +643,18 @@ int mrcal_amd_set_optimize_jacobian_stream(int stream)
 {
     const int old = optimize_jacobian_stream_policy();
     optimize_jacobian_stream_policy() = stream ? 1 : 0;
+    return old;
+}
+
+// For the tests (include/mrcal_amd.h): "lchol_likely_panels", "nd_rounds", "lchol_sweep"; the previous value, -1 for an unknown name
+int mrcal_amd_set_test_hook(const char* name, int value)
+{
+    TestHooks& h = test_hooks();
+    int* p = !strcmp(name, "lchol_likely_panels") ? &h.lchol_likely_panels :
+             !strcmp(name, "nd_rounds")           ? &h.nd_rounds :
+             !strcmp(name, "lchol_sweep")         ? &h.lchol_sweep : (int*)NULL;
+    if(p == NULL) return -1;
+    const int old = *p; *p = value;
     return old;
 }
 

@@ -4629,12 +4629,11 @@ hipError_t launch_cholesky_large(int n, const int* skip, double* M, double* Linv
                                  const Step2Dev* sd = NULL, bool* fused = NULL, const int* n_dev = NULL, const LcholCompact* compact = NULL,
                                  int likely_panels = 0 /* with n_dev: launches 0 .. likely_panels one by one, the rest in lchol_tail_kernel; 0: all one by one */,
                                  unsigned* tail_counter = NULL, const LcholNdLaunch* nds = NULL,
-                                 bool finish_done = false /* with sd: the end-of-trial logic has run already (the first launch goes by `skip`); the verdict still rides in the last */)
+                                 bool finish_done = false /* with sd: the end-of-trial logic has run already (the first launch goes by `skip`); the verdict still rides in the last */,
+                                 bool sweep = false /* the solve by the backward sweep in groups of panels (rounds 2-3; backward stable) instead of through
+                                                       L^-1 built on the side (lchol_inverse_block): FactorBuffers::use_sweep */)
 {
     const int npanels = (n + LCH_NB - 1)/LCH_NB;
-    // MRCAL_AMD_LCHOL_SWEEP=1: the solve by the backward sweep in groups of panels (rounds 2-3) instead of through
-    // L^-1 built on the side (lchol_inverse_block); for comparisons
-    static const bool sweep = (getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
     if(sweep && (n_dev != NULL || compact != NULL)) return hipErrorInvalidValue;
     Step2Dev sd0; memset(&sd0, 0, sizeof(sd0));
     LcholCompact cp0; memset(&cp0, 0, sizeof(cp0));
@@ -5432,22 +5431,19 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // What follows assemble_splined_kernel writes the camera block's A and g, and |x|^2: nothing the block
             // elimination or the SYRK read. With a side stream it runs beside them (unless there are other rows
             // - discrete points - that add to A with atomics at the same time)
-            // (MRCAL_AMD_SPL_ONE_STREAM: everything on the one stream, for measurements)
-            static const bool one_stream = (getenv("MRCAL_AMD_SPL_ONE_STREAM") != NULL);
-            const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !one_stream && !repro;
+            const bool use_side = side != NULL && forked != NULL && rows_to == rows_from && !repro;
             // Round 5: the regularization rows' pairs ride in assemble_splined_kernel's launch, behind the frames'
             // workgroups (which write the frames' blocks and Bt, never A or the camera block's g): they were 10 us at the
             // end of the side stream's chain, the longer of the two the reduction waits for. A's entries then take the
             // pairs' products before the gathered sums instead of after (other bits than round 4's, the same every time:
-            // the launch boundary orders the two). MRCAL_AMD_SPL_PAIRS_LATE: where they were.
+            // the launch boundary orders the two).
             // (Not where assemble_splined_kernel can fall back to row-by-row atomics on A and g - a grid that one
             //  board can cover with more than SPL_MAXSUB sub-boxes, a board of more than 1024 corners -: the pairs'
             //  plain read-modify-writes must not run beside those. Nor on the side stream behind a fork of their own -
             //  the first form of this round -: the fork cost the main stream 8 us; profiles/r05_config2_step_in_time_order.txt
             //  has the gaps the other fork and the join still cost)
-            static const bool pairs_late = (getenv("MRCAL_AMD_SPL_PAIRS_LATE") != NULL);
             const int  nrp_early  = (P.Nmeas > rows_to) ? (P.Nmeas - rows_to + 511)/512 : 0;
-            const bool pairs_ride = nrp_early > 0 && !pairs_late && !spl_fallback_possible(P) && rows_to == rows_from;
+            const bool pairs_ride = nrp_early > 0 && !spl_fallback_possible(P) && rows_to == rows_from;
             // (round 5) which control points a board covers at this point: spl_compact_body, for the reduction of this
             // trial step - one more workgroup of the same launch if its marks fit the launch's LDS, else a launch in front
             const int  nknots_all      = P.Ncameras_intrinsics*P.cfg.spline_Nx*P.cfg.spline_Ny;
@@ -5475,10 +5471,9 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
             // the knots' rows (a window of columns each), then the rows every pass holds (whole)
             const int nknotrows = splg_nknotrows(P);
             const int window = 2*(P.cfg.spline_order*P.cfg.spline_Nx + P.cfg.spline_order);
-            // (MRCAL_AMD_SPL_ROW_GATHER: the control points' rows by the row-per-workgroup kernel too, as until the end of round 4)
-            static const bool row_gather = (getenv("MRCAL_AMD_SPL_ROW_GATHER") != NULL);
+            // (orders whose row of A has more than 32 places: by the row-per-workgroup kernel, as until the end of round 4)
             const int order = P.cfg.spline_order;
-            const bool pull = !row_gather && order*(2*order + 1) + order + 1 + P.Ncore_state <= 32;
+            const bool pull = order*(2*order + 1) + order + 1 + P.Ncore_state <= 32;
             if(nknotrows > 0 && pull)
                 hipLaunchKernelGGL(assemble_splined_gather_knots_kernel, dim3(nknotrows), dim3(64*SPLK_WAVES), 0, gstream, P, nd, B.R, plan);
             else if(nknotrows > 0)
@@ -5692,7 +5687,7 @@ hipError_t launch_solve_backsub(const NormalDims& nd, const BlockRanges& br,
                                n, R.skip, keep_factor ? 1 : 0, F.S, F.r, F.status, none);
         }
         else if(F.Linv != NULL)
-            launch_cholesky_large(n, R.skip, F.S, F.Linv, F.status, stream);
+            launch_cholesky_large(n, R.skip, F.S, F.Linv, F.status, stream, NULL, NULL, NULL, NULL, 0, NULL, NULL, false, F.use_sweep != 0);
         else
             hipLaunchKernelGGL(schur_cholesky_solve_global_kernel, dim3(1), dim3(1024), 0, stream,
                                n, R.skip, F.S, F.r, F.status);
@@ -5863,12 +5858,10 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
 // g_S, |x|^2, the block elimination's status - is complete when the reduction's last workgroup has written it, and that
 // workgroup can decide the trial there and then, beside the others: the factorization's first launch starts on its matrix
 // at once (and may be several workgroups: the dissection's). Sharded, the tail is summed over the ranks behind this launch.
-// MRCAL_AMD_LCHOL_SEPARATE_FINISH / MRCAL_AMD_LCHOL_SWEEP (comparisons): as it was
+// (With the backward sweep - FactorBuffers::use_sweep - the end-of-trial logic and the verdict are launches of their own.)
 static bool step2_finish_rides(const Step2Args& a)
 {
-    static const bool separate = (getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL ||
-                                  getenv("MRCAL_AMD_FINISH_IN_FACTOR") != NULL);
-    return a.comm2 == NULL && !separate;
+    return a.comm2 == NULL && !a.F->use_sweep;
 }
 hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initial)
 {
@@ -5950,15 +5943,14 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
         }
         else
         {
-            // (round 5: finish and post ride in the factorization's first and last launch; MRCAL_AMD_LCHOL_SEPARATE_FINISH
-            //  brings the two launches back, for comparisons)
-            // (with the backward sweep of MRCAL_AMD_LCHOL_SWEEP the factorization's last launch is another: separate too)
-            static const bool separate = (getenv("MRCAL_AMD_LCHOL_SEPARATE_FINISH") != NULL || getenv("MRCAL_AMD_LCHOL_SWEEP") != NULL);
+            // (round 5: finish and post ride in the factorization's first and last launch; with the backward sweep the
+            //  factorization's last launch is another: launches of their own then)
+            const bool separate = F.use_sweep != 0;
             bool fused = false;
             if(separate) hipLaunchKernelGGL(step2_finish_kernel, dim3(1), dim3(1024), 0, stream, sd, F.status);
             // (the splined models: the camera block as the reduction left it - without the control points no board covers)
             LcholCompact cp; memset(&cp, 0, sizeof(cp));
-            const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with MRCAL_AMD_LCHOL_SWEEP: problem_prepare_solver())
+            const bool compact = F.cperm_cur != NULL;       // (what the reduction went by; never with the backward sweep: solver.cpp)
             if(compact) { cp.cperm = F.cperm_cur; cp.iso = F.iso; cp.dout = F.r; cp.Nc = n; }
             // (the dissection's launches, where the host has provided for them: learn_likely_size())
             const bool nd_launches = compact && F.ndMA != NULL && F.nd_lim.rounds > 0 && finish_done;
@@ -5976,7 +5968,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
                                   compact ? &cp : (const LcholCompact*)NULL,
                                   compact ? (nd_launches ? F.nd_likely_panels : F.lchol_likely_panels) : 0,
                                   compact ? (unsigned*)(F.cperm_cur + 2*n + 1) : (unsigned*)NULL, nd_launches ? &nds : (const LcholNdLaunch*)NULL,
-                                  finish_done);
+                                  finish_done, F.use_sweep != 0);
             if(separate) hipLaunchKernelGGL(step2_post_kernel, dim3(1), dim3(64), 0, stream, sd, F.status);
             else if(!fused) return hipErrorInvalidValue;
         }

@@ -124,11 +124,24 @@ struct FactorBuffers
     int*    nd_lim_dev;
     NdLimits nd_lim;
     int     nd_likely_panels;   // the separator's panels at the solve's first point (as lchol_likely_panels)
+    int     use_sweep; // the large Cholesky's solve by the backward sweep in groups of panels (backward stable; slower: no explicit
+                      // L^-1, no compaction, the end-of-trial logic in launches of its own) instead of d = -Y^T z. Set by the
+                      // automatic fallback (solver.cpp: a factor whose diagonal spans more than 1e8) or by a test hook
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -
                       // [ceil(Nc/16)][NE][16] - for the sparse SYRK: a block's rows of a tile are 768 contiguous bytes
                       // (in Wt itself they are six pieces 9.6 KB apart, and a workgroup's few blocks that count are all over 46 MB)
 };
 inline int occ_words(const NormalDims& nd) { return (((nd.Nc + 15) >> 4) + 31) >> 5; }
+
+// Hooks for the tests (mrcal_amd_set_test_hook(), include/mrcal_amd.h): force paths a solve takes by itself only when a
+// later point of it outgrows what its first point needed. 0: not forced. Read where a solve starts
+struct TestHooks
+{
+    int lchol_likely_panels;   // launches of the large Cholesky provided one by one; the rest go through lchol_tail_kernel
+    int nd_rounds;             // rounds of the dissection provided for, whatever the plan needs
+    int lchol_sweep;           // the large Cholesky's solve by the backward sweep (FactorBuffers::use_sweep) from the start
+};
+TestHooks& test_hooks();
 
 // size of FactorBuffers::Linv: the multi-launch Cholesky of camera blocks that do not fit the LDS
 size_t cholesky_large_workspace_doubles(int n);

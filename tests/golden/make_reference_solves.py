@@ -57,7 +57,7 @@ if __name__ == "__main__":
                    outlier_mask_shape  = np.array(o["observations_board"].shape[:-1]),
                    # every 997th residual: a spot check of x itself without its 51 MB
                    x_every_997th = s["x"][::997].copy(), Nmeasurements = int(s["x"].size))
-        if "Noutliers_triangulated_point" in s:
+        if ref._last_triangulated_flags is not None:
             rec["Noutliers_triangulated_point"] = int(s["Noutliers_triangulated_point"])
             rec["triangulated_flags"] = np.array(ref._last_triangulated_flags).copy()
         for k in ("intrinsics", "rt_cam_ref", "rt_ref_frame", "calobject_warp"):

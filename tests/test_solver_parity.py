@@ -595,13 +595,16 @@ def test_solve_through_the_explicit_inverse_matches_the_backward_sweep(amd):
     """the big camera block's solve ends with d = -L^-T z as a product with an explicitly formed L^-1
     (launch_cholesky_large: no backward sweep), and multiplying by an explicit inverse is not backward stable - its error
     grows with cond(L), and the splined camera blocks have cond(JtJ) ~ 1e13. Configuration 2 reduced to 200 frames,
-    solved in two processes - the default, and MRCAL_AMD_LCHOL_SWEEP=1 (the triangular sweep of rounds 2-3, which also
-    turns the compaction of the camera block off): the same outliers, the same optimum"""
+    solved in two processes - the default, and with the test hook lchol_sweep (the triangular sweep of rounds 2-3: what
+    the solver falls back to by itself when a factor's diagonal spans more than 1e8; it also turns the compaction of the
+    camera block off): the same outliers, the same optimum"""
     import os, subprocess, sys, json
     code = r'''
-import sys, json, numpy as np
+import sys, os, json, numpy as np
 sys.path.insert(0, %r)
 import mrcal_amd
+for _kv in os.environ.get("TEST_HOOKS", "").split(","):          # (the test's own variable: hooks of the library's test API)
+    if _kv: mrcal_amd.set_test_hook(_kv.split("=")[0], int(_kv.split("=")[1]))
 from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 from mrcal_amd.resident import Problem
 oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
@@ -612,7 +615,7 @@ with Problem(**copy_inputs(oi)) as p:
     print("RESULT " + json.dumps(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), d0=d0.tolist())))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
-    for tag, env in (("inverse", {}), ("sweep", {"MRCAL_AMD_LCHOL_SWEEP": "1"})):
+    for tag, env in (("inverse", {}), ("sweep", {"TEST_HOOKS": "lchol_sweep=1"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -621,45 +624,6 @@ with Problem(**copy_inputs(oi)) as p:
     assert a["Nout"] == b["Nout"]
     assert abs(a["rms"] - b["rms"]) < 1e-8*b["rms"]
     assert np.abs(np.array(a["b"]) - np.array(b["b"])).max() < 1e-4
-
-
-@pytest.mark.timeout(900)
-def test_end_of_trial_in_the_reduction_or_in_the_factorization_same_bits(amd):
-    """Round 5: on a single GPU the end-of-trial logic (step2_finish: the rho test, accept / reject, the trust region,
-    termination) rides in the reduction's launch instead of heading the factorization's. A relocation: the same decisions
-    from the same numbers - a camera block in LDS (OPENCV8, 3 cameras) and a big one (splined 30x20: the launch-per-panel
-    Cholesky with the compaction and the dissection), each solved both ways (MRCAL_AMD_FINISH_IN_FACTOR=1: as it was,
-    which also turns the dissection's launches off - those need the verdict before their first launch), to the same bits
-    where the factorization is the same and to a reordering of the pivots where it is not"""
-    import os, subprocess, sys, json
-    code = r'''
-import sys, json, numpy as np
-sys.path.insert(0, %r)
-import mrcal_amd
-from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
-from mrcal_amd.resident import Problem
-out = {}
-for tag, kw in (("opencv8", dict(Ncameras=3, Nframes=60, lensmodel="LENSMODEL_OPENCV8", seed=5)),
-                ("splined", dict(Ncameras=1, Nframes=120, lensmodel=CONFIG2_LENSMODEL, seed=4, do_optimize_intrinsics_core=False))):
-    oi, _ = make_calibration_problem(mrcal_amd._api, object_width_n=10, object_height_n=10, **kw)
-    with Problem(**copy_inputs(oi)) as p:
-        s = p.solve()
-        out[tag] = dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist(), rounds=p.dissection()["rounds"])
-print("RESULT " + json.dumps(out))
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
-    res = {}
-    for tag, env in (("rides", {"MRCAL_AMD_NO_ND": "1"}), ("head", {"MRCAL_AMD_FINISH_IN_FACTOR": "1"}), ("nd", {})):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    for model in ("opencv8", "splined"):
-        a, b = res["rides"][model], res["head"][model]
-        assert (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"], model
-        assert a["rounds"] == 0 and b["rounds"] == 0
-    # (with the dissection's launches on top - the default - the splined solve is the same solve in another order of the pivots)
-    a, c = res["rides"]["splined"], res["nd"]["splined"]
-    assert a["Nout"] == c["Nout"] and abs(a["rms"] - c["rms"]) < 1e-8*a["rms"]
-    assert res["nd"]["opencv8"]["b"] == res["rides"]["opencv8"]["b"]
 
 
 def test_nested_dissection_of_the_control_point_grid(amd):
@@ -671,15 +635,17 @@ def test_nested_dissection_of_the_control_point_grid(amd):
         and the plan is the one the planner restated on the host makes from the final point's Jacobian;
       - the same again: the same bits (every sum of it in a fixed order);
       - with the separator's panels past the first left to lchol_tail_kernel: the same bits;
-      - with launches for ONE round where the plan needs more (MRCAL_AMD_ND_ROUNDS=1): no plan fits, every point goes the
+      - with launches for ONE round where the plan needs more (the test hook nd_rounds = 1): no plan fits, every point goes the
         ordinary way THROUGH the dissection's launches - the bits of
       - the solve without the dissection (MRCAL_AMD_NO_ND=1), which the solve with it matches to what another order of
         the pivots leaves"""
     import os, subprocess, sys, json
     code = r'''
-import sys, json, numpy as np
+import sys, os, json, numpy as np
 sys.path.insert(0, %r)
 import mrcal_amd
+for _kv in os.environ.get("TEST_HOOKS", "").split(","):          # (the test's own variable: hooks of the library's test API)
+    if _kv: mrcal_amd.set_test_hook(_kv.split("=")[0], int(_kv.split("=")[1]))
 from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 from mrcal_amd.resident import Problem
 oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
@@ -722,7 +688,7 @@ for rep in range(2):
 print("RESULT " + json.dumps(out))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
-    for tag, env in (("nd", {}), ("tail", {"MRCAL_AMD_LCHOL_LIKELY": "1"}), ("unfit", {"MRCAL_AMD_ND_ROUNDS": "1"}), ("off", {"MRCAL_AMD_NO_ND": "1"})):
+    for tag, env in (("nd", {}), ("tail", {"TEST_HOOKS": "lchol_likely_panels=1"}), ("unfit", {"TEST_HOOKS": "nd_rounds=1"}), ("off", {"MRCAL_AMD_NO_ND": "1"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -744,15 +710,17 @@ def test_factorization_launches_and_tail_kernel_give_the_same_bits(amd):
     factored follows the boards, the host provides the launches of the size the solve's first point has, and whatever a
     later point needs beyond those is done by ONE kernel with barriers over its workgroups where the launch boundaries
     would be (lchol_tail_kernel). Which of the two ways a panel is done must not show: configuration 2 reduced to 200
-    frames solved as it is, with all but the first two panels left to the tail kernel (MRCAL_AMD_LCHOL_LIKELY=2), and
+    frames solved as it is, with all but the first two panels left to the tail kernel (the test hook lchol_likely_panels = 2), and
     without the compaction at all (MRCAL_AMD_NO_SPL_COMPACT=1: the 1206-variable matrix, 554 pivots of which are the
     uncovered control points' own 2 x 2 blocks) - the first two to the last bit, the third to what another order of the
     pivots leaves"""
     import os, subprocess, sys, json
     code = r'''
-import sys, json, numpy as np
+import sys, os, json, numpy as np
 sys.path.insert(0, %r)
 import mrcal_amd
+for _kv in os.environ.get("TEST_HOOKS", "").split(","):          # (the test's own variable: hooks of the library's test API)
+    if _kv: mrcal_amd.set_test_hook(_kv.split("=")[0], int(_kv.split("=")[1]))
 from mrcal_amd.synthetic import make_calibration_problem, copy_inputs, CONFIG2_LENSMODEL
 from mrcal_amd.resident import Problem
 oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=1, Nframes=200, object_width_n=10, object_height_n=10,
@@ -762,7 +730,7 @@ with Problem(**copy_inputs(oi)) as p:
     print("RESULT " + json.dumps(dict(N=s["Niterations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist())))
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
     res = {}
-    for tag, env in (("launches", {}), ("tail", {"MRCAL_AMD_LCHOL_LIKELY": "2"}), ("whole", {"MRCAL_AMD_NO_SPL_COMPACT": "1"})):
+    for tag, env in (("launches", {}), ("tail", {"TEST_HOOKS": "lchol_likely_panels=2"}), ("whole", {"MRCAL_AMD_NO_SPL_COMPACT": "1"})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=800)
         assert r.returncode == 0, r.stderr[-2000:]
         res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
