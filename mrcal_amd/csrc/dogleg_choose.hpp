@@ -1,5 +1,5 @@
 // The dog-leg step selection of the device-controlled solver step, as device functions: used by
-// step2_choose_kernel (solver_kernels.hip) and, where an evaluation with a board prologue follows, by that
+// step2_choose_kernel (step.hip) and, where an evaluation with a board prologue follows, by that
 // prologue's launch (kernels.hip board_prologue_kernel<CHOOSE>): one launch less per trial step.
 //
 // Every workgroup that calls dogleg_choose_scalars() derives the same numbers from the same data in the same

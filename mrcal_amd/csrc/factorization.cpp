@@ -4,7 +4,7 @@
 // Reference behaviour: the mrcal.CHOLMOD_factorization Python type
 // (mrcal-pywrap.c:111-214: cholmod_analyze + cholmod_factorize of Jt;
 // :425-569 solve_xt_JtJ_bt(); :580-592 rcond()). CHOLMOD is a general sparse
-// direct solver; this is the structured solver of solver_kernels.hip given the
+// direct solver; this is the structured solver of assembly.hip / schur.hip / cholesky_*.hip given the
 // partition of the state: a dense leading block S (intrinsics, extrinsics, and
 // the trailing warp pair) and block-diagonal 6x6 / 3x3 blocks E (frames,
 // points) that no row couples to each other. A matrix without such a structure
@@ -314,7 +314,7 @@ bool mrcal_amd_factorization_solve(mrcal_amd_factorization_t* f, const double* b
 // The other systems of cholmod_solve2() (mrcal-pywrap.c:467-493; sys = CHOLMOD's
 // codes: 0 A, 1 LDLt, 2 LD, 3 DLt, 4 L, 5 Lt, 6 D, 7 P, 8 Pt) against this
 // factorization: L L^T = P (JtJ) P^T with the frame/point blocks first and D = I
-// (solver_kernels.hip, "factor order"). Vectors of the L/D systems live in that
+// (factorization_solve.hip, "factor order"). Vectors of the L/D systems live in that
 // order, as CHOLMOD's live in its own
 bool mrcal_amd_factorization_solve_sys(mrcal_amd_factorization_t* f, int sys, const double* bt, int Nrhs, double* xt)
 {

@@ -30,7 +30,7 @@ struct OpDev
     // splined models (round 5): the camera block with the control points no board covers at this point put last -
     // [Nc] position -> camera-block variable | [Nc] variable -> position | [1] how many come first (the coupled ones).
     // Made by spl_compact_kernel from spl_box after an evaluation; read by the reduction of a trial step, which leaves
-    // the Cholesky the coupled part alone (solver_kernels.hip, LcholCompact). NULL: not tracked
+    // the Cholesky the coupled part alone (cholesky_large.hip, LcholCompact). NULL: not tracked
     int*    cperm;
     // ... and, if not NULL, the nested-dissection plan of the coupled part (solver_kernels.hpp, NDH_*)
     int*    ndp;

@@ -75,7 +75,7 @@ mrcal_amd_problem::~mrcal_amd_problem()
         hipFree(G.scol); hipFree(G.part); hipFree(G.dest_id); hipFree(G.dest_begin); hipFree(G.dest_src); hipFree(G.group_chunk_begin);
         hipFree(G.eb_block); hipFree(G.eb_begin); hipFree(G.eb_rows); hipFree(G.eb_group); hipFree(G.eb_epos);
     }
-    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
+    hipFree(F.Wt); hipFree(F.LD); hipFree(F.y); hipFree(F.S); hipFree(F.Spart); hipFree(F.Linv); hipFree(F.diag_minmax); hipFree(F.status); hipFree(F.occ); hipFree(F.Wtile);
     hipFree(cperm_cur_alloc); hipFree(F.iso); hipFree(op[0].cperm); hipFree(op[1].cperm);
     hipFree(op[0].ndp); hipFree(op[1].ndp); hipFree(F.ndp_cur); hipFree(F.ndMA); hipFree(F.ndMB); hipFree(F.ndLinvA); hipFree(F.ndLinvB); hipFree(F.ndPart); hipFree(F.nd_lim_dev);
     hipFree(plan.repro.lvl[0]); hipFree(plan.repro.lvl[1]); hipFree(plan.repro.lvl[2]); hipFree(plan.repro.cmax); hipFree(plan.repro.any);
@@ -285,13 +285,14 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     }
     ok = ok && dev_alloc(&P->F.Spart, schur_partial_doubles(nd));
     ok = ok && dev_alloc(&P->F.Linv,  cholesky_large_workspace_doubles(nd.Nc));
+    if(cholesky_large_workspace_doubles(nd.Nc) > 1) ok = ok && dev_alloc(&P->F.diag_minmax, 2);
     // the tile occupancy of Wt: only where the couplings are sparse (the splined models) and the strip SYRK runs
     if(L.lensmodel.type == MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC && nd.Nc > 256 && nd.Nc <= 4096)
     {
         ok = ok && dev_alloc(&P->F.occ, (size_t)(nd.NEb > 0 ? nd.NEb : 1)*occ_words(nd));
         ok = ok && dev_alloc(&P->F.Wtile, (size_t)((nd.Nc + 15)/16)*16*(size_t)(nd.NE > 0 ? nd.NE : 1));
     }
-    // The splined models' camera block without the control points no board covers (round 5; solver_kernels.hip,
+    // The splined models' camera block without the control points no board covers (round 5; assembly_splined.hip,
     // spl_compact_kernel / LcholCompact): where the big camera block's launch-per-panel Cholesky runs, every row that
     // touches a control point is a board's (no discrete points: they have no boxes) and all rows are here (not a shard:
     // the ranks of a sharded solve sum their camera blocks entry by entry). MRCAL_AMD_NO_SPL_COMPACT=1: off
@@ -317,7 +318,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
             ok = ok && dev_alloc(&P->F.iso, (size_t)4*(nd.Nc/2 + 1) + nd.Nc + 2);
             P->F.cperm_cur = P->cperm_cur_alloc;
             P->plan.spl_compact = 1;
-            // ... and in a nested-dissection order where the boards leave a strip worth having (solver_kernels.hip,
+            // ... and in a nested-dissection order where the boards leave a strip worth having (cholesky_large.hip,
             // lchol_nd_*): one camera's grid. MRCAL_AMD_NO_ND=1: off
             static const bool nd_off = (getenv("MRCAL_AMD_NO_ND") != NULL);
             if(!nd_off && P->D.Ncameras_intrinsics == 1)

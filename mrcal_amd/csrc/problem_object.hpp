@@ -50,6 +50,8 @@ struct mrcal_amd_problem
     // evaluations in that mode right now; jacobian_stale = op[icur].Jv is NOT the Jacobian at op[icur].b: whoever
     // hands J out (get_J, dev_J_values) evaluates first (problem_ensure_jacobian)
     int         last_ctl_error = 0;         // SolverCtl::error of the last run_dogleg()
+    double      lchol_diag_ratio = 1.0;     // min / max of the diagonal of the big Cholesky's factors over the last pass
+    bool        sweep_fallback_wanted = false;
     bool        solve_stores_jacobian = true;
     bool        jfree_now             = false;
     bool        jacobian_stale        = false;

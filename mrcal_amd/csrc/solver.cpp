@@ -6,7 +6,7 @@
 // the reference tree): Powell's dog leg with a trust region. Its algorithm is
 // restated in oracle/dogleg_restated.c (CPU checker); THIS file is the
 // product: the same algorithm with every vector/matrix operation AND the
-// scalar trust-region decisions on the GPU (solver_kernels.hip, "dog-leg
+// scalar trust-region decisions on the GPU (solver_device.hpp, "dog-leg
 // control"). The host queues trial steps (one captured hipGraph each) and
 // polls a pinned snapshot of the device's control block a few steps behind.
 //
@@ -97,6 +97,9 @@ bool ctl_reset(mrcal_amd_problem* P, const DoglegParameters& prm, bool check_ter
     c.ib = P->icur; c.ia = 1 - P->icur;
     solver_ctl_init_flags(buf.data(), P->icur);
     HIP_TRY(hipMemsetAsync(P->F.status, 0, sizeof(int), P->stream), return false);
+    static const unsigned long long spread0[2] = { 0x7ff0000000000000ull, 0ull };      // (+inf, 0)
+    if(P->F.diag_minmax != NULL)
+        HIP_TRY(hipMemcpyAsync(P->F.diag_minmax, spread0, sizeof(spread0), hipMemcpyHostToDevice, P->stream), return false);
     HIP_TRY(hipMemcpyAsync(P->d_ctl, buf.data(), buf.size(), hipMemcpyHostToDevice, P->stream), return false);
     HIP_TRY(hipStreamSynchronize(P->stream), return false);   // buf goes out of scope
     P->ctl_initialized = true;
@@ -150,7 +153,7 @@ static const char* solver_error_text(int error)
                         "could not make JtJ positive definite";
 }
 // One trial step of the dog-leg, entirely queued: every decision is taken on
-// the device (solver_kernels.hip, "the fused step"). segment: 0 = all of it;
+// the device (step.hip, "the fused step"). segment: 0 = all of it;
 // 1 = up to the board kernel, 2 = the board kernel alone, 3 = after it
 bool enqueue_trial_step(mrcal_amd_problem* P, int segment)
 {
@@ -393,6 +396,22 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     P->stats.Niterations     += c.Nsteps_accepted;
     P->stats.Nevaluations    += c.Nevaluations;
     P->stats.Nfactorizations += c.Nfactorizations;
+    // (round 6) how far apart the diagonal entries of the big camera block's factors lay in this pass: the solve ends with
+    // d = -Y^T z, Y = L^-1 formed explicitly, whose error grows like n eps max/min of that diagonal. A ratio
+    // below 1e-8 - a camera block of condition 1e16: no factorization of this pass deserved much trust - sends the problem
+    // to the backward sweep for good (mrcal_amd_problem_solve() runs the pass again): slower, backward stable
+    if(P->F.diag_minmax != NULL)
+    {
+        unsigned long long mm[2];
+        HIP_TRY(hipMemcpy(mm, P->F.diag_minmax, sizeof(mm), hipMemcpyDeviceToHost), return false);
+        double lo, hi; memcpy(&lo, &mm[0], 8); memcpy(&hi, &mm[1], 8);
+        if(hi > 0.0 && lo <= hi)
+        {
+            P->lchol_diag_ratio = lo/hi;
+            const int lg = test_hooks().lchol_fallback_log10 ? test_hooks().lchol_fallback_log10 : -8;
+            if(P->lchol_diag_ratio < pow(10.0, (double)lg) && !P->F.use_sweep && P->comm == NULL) P->sweep_fallback_wanted = true;
+        }
+    }
     return true;
 }
 
@@ -632,7 +651,7 @@ void report_regularization(mrcal_amd_problem* P, const mrcal_problem_selections_
 } // namespace
 
 namespace { int& optimize_jacobian_stream_policy() { static int policy = 0; return policy; } }
-namespace mrcal_amd { TestHooks& test_hooks() { static TestHooks h = {0, 0, 0}; return h; } }
+namespace mrcal_amd { TestHooks& test_hooks() { static TestHooks h = {0, 0, 0, 0}; return h; } }
 
 extern "C" {
 
@@ -652,11 +671,16 @@ int mrcal_amd_set_test_hook(const char* name, int value)
     TestHooks& h = test_hooks();
     int* p = !strcmp(name, "lchol_likely_panels") ? &h.lchol_likely_panels :
              !strcmp(name, "nd_rounds")           ? &h.nd_rounds :
-             !strcmp(name, "lchol_sweep")         ? &h.lchol_sweep : (int*)NULL;
+             !strcmp(name, "lchol_sweep")         ? &h.lchol_sweep :
+             !strcmp(name, "lchol_fallback_log10") ? &h.lchol_fallback_log10 : (int*)NULL;
     if(p == NULL) return -1;
     const int old = *p; *p = value;
     return old;
 }
+
+// min / max of the diagonal of the big camera block's Cholesky factors over the last dog-leg pass (1: no such factorization)
+double mrcal_amd_problem_lchol_diag_ratio(mrcal_amd_problem_t* P) { return P->lchol_diag_ratio; }
+int    mrcal_amd_problem_uses_sweep(mrcal_amd_problem_t* P) { return P->F.use_sweep; }
 
 // Resident tier: the full solve on a resident problem. Returns rms error, <0
 // on failure
@@ -701,6 +725,17 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
         }
         // (every evaluation of a pass that streams J wrote it, the final point's included)
         if(!P->jfree_now) P->jacobian_stale = false;
+        if(P->sweep_fallback_wanted)
+        {
+            P->sweep_fallback_wanted = false;
+            fprintf(stderr, "mrcal_amd: WARNING: the diagonal of the camera block's Cholesky factor spans %.1e: this problem's steps go through "
+                            "the backward sweep from here on instead of the explicit inverse (slower, backward stable). The pass again\n", 1.0/P->lchol_diag_ratio);
+            P->F.use_sweep = 1;
+            P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
+            for(int i = 0; i < 3; i++)
+                if(P->step_graph[i]) { hipGraphExecDestroy(P->step_graph[i]); P->step_graph[i] = NULL; }
+            continue;
+        }
         if(!P->L.sel.do_apply_outlier_rejection) break;
         bool found;
         if(!mark_outliers(P, &Noutliers, &Noutliers_tri, &found)) return -1.0;

@@ -1,4 +1,5 @@
-// Host-visible interface of solver_kernels.hip
+// Host-visible interface of the solver's kernels (assembly.hip, assembly_splined.hip, schur.hip, cholesky_lds.hip,
+// cholesky_large.hip, step.hip, factorization_solve.hip: until round 6 one translation unit, solver_kernels.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,7 +9,7 @@
 namespace mrcal_amd {
 
 // Partition of the state into the dense shared block S and the block-diagonal
-// eliminated set E (see solver_kernels.hip). Which blocks are eliminated is a
+// eliminated set E (see assembly.hip). Which blocks are eliminated is a
 // property of the problem: the numerous, mutually independent
 // ones. Stationary cameras and a moving board (or points): the frames and
 // points are eliminated, S = intrinsics + extrinsics + warp. A moving camera
@@ -81,7 +82,7 @@ enum
     NSCALARS = 16
 };
 
-// The nested-dissection order of the splined models' camera block (round 5; solver_kernels.hip, lchol_nd_*).
+// The nested-dissection order of the splined models' camera block (round 5; cholesky_large.hip, lchol_nd_*).
 // OpDev::ndp, made by spl_compact_body after every evaluation:  [NDH_WORDS] the plan | [Nc] camera-block variable -> its
 // class << 28 | its index within the class (class 0: separator, 1: side A, 2: side B, 3: not coupled) | [Nc + 2 ND_PANEL]
 // position -> variable over [A padded | B padded | separator] (-1: a pad)
@@ -127,6 +128,8 @@ struct FactorBuffers
     int     use_sweep; // the large Cholesky's solve by the backward sweep in groups of panels (backward stable; slower: no explicit
                       // L^-1, no compaction, the end-of-trial logic in launches of its own) instead of d = -Y^T z. Set by the
                       // automatic fallback (solver.cpp: a factor whose diagonal spans more than 1e8) or by a test hook
+    unsigned long long* diag_minmax; // [2] the smallest / largest diagonal entry of the big camera block's Cholesky factor since the solve's
+                      // start (bit patterns of positive doubles; set to +inf, 0 by ctl_reset()): what the fallback to the sweep goes by. NULL: no large Cholesky
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -
                       // [ceil(Nc/16)][NE][16] - for the sparse SYRK: a block's rows of a tile are 768 contiguous bytes
                       // (in Wt itself they are six pieces 9.6 KB apart, and a workgroup's few blocks that count are all over 46 MB)
@@ -140,12 +143,13 @@ struct TestHooks
     int lchol_likely_panels;   // launches of the large Cholesky provided one by one; the rest go through lchol_tail_kernel
     int nd_rounds;             // rounds of the dissection provided for, whatever the plan needs
     int lchol_sweep;           // the large Cholesky's solve by the backward sweep (FactorBuffers::use_sweep) from the start
+    int lchol_fallback_log10;  // the automatic fallback's threshold on min / max of the factor's diagonal as a power of ten (default -8)
 };
 TestHooks& test_hooks();
 
 // size of FactorBuffers::Linv: the multi-launch Cholesky of camera blocks that do not fit the LDS
 size_t cholesky_large_workspace_doubles(int n);
-// size of FactorBuffers::Spart (solver_kernels.hip: SYRK slicing)
+// size of FactorBuffers::Spart (schur.hip: SYRK slicing)
 size_t schur_partial_doubles(const NormalDims& nd);
 
 // iteration-invariant work lists for the assembly
@@ -396,7 +400,7 @@ hipError_t launch_mark_outliers(int Npoints_board, double thresh_sq, const doubl
 // launch_solve_backsub(keep_factor)): (JtJ) x = b, device vectors in state order
 hipError_t launch_fsolve(const NormalDims& nd, const FactorBuffers& F,
                          const double* b, double* x, hipStream_t stream);
-// the systems of cholmod_solve2(), same codes (solver_kernels.hip explains the factor and its order)
+// the systems of cholmod_solve2(), same codes (factorization_solve.hip explains the factor and its order)
 enum { FSOLVE_A = 0, FSOLVE_LDLt, FSOLVE_LD, FSOLVE_DLt, FSOLVE_L, FSOLVE_Lt, FSOLVE_D, FSOLVE_P, FSOLVE_Pt };
 hipError_t launch_fsolve_sys(const NormalDims& nd, const FactorBuffers& F, int sys,
                              const double* b, double* x, hipStream_t stream);

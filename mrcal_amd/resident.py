@@ -240,3 +240,16 @@ class Problem:
         d = np.zeros((self.Nstate,))
         self._check(self._lib.mrcal_amd_problem_gauss_newton_step(self.handle, _ptr(d)), "gauss_newton_step")
         return d
+
+    def lchol_diag_ratio(self):
+        """min / max of the diagonal of the big camera block's Cholesky factors over the last dog-leg pass; 1.0 where no
+        such factorization ran (include/mrcal_amd.h)"""
+        f = self._lib.mrcal_amd_problem_lchol_diag_ratio
+        f.restype, f.argtypes = C.c_double, [C.c_void_p]
+        return float(f(self.handle))
+
+    def uses_sweep(self):
+        """has this problem's big Cholesky gone over to the backward sweep (the automatic stable fallback, or the test hook)?"""
+        f = self._lib.mrcal_amd_problem_uses_sweep
+        f.restype, f.argtypes = C.c_int, [C.c_void_p]
+        return bool(f(self.handle))

@@ -11,7 +11,7 @@ every measurement row touches at most ONE frame) by
     d_S = -chol(S)^-1 r  (ONE dense dpotrf of the camera block: 140 x 140 at the metric's size)
     d_f = -L_f^-T (y_f + Wt_f d_S)
 
-which is what csrc/solver_kernels.hip does on the GPU (assemble_factor, schur_syrk, schur_cholesky_solve, backsub), and -
+which is what csrc/assembly.hip, schur.hip, cholesky_lds.hip and step.hip do on the GPU (assemble_factor, schur_syrk, schur_cholesky_solve, backsub), and -
 for the third baseline variant - the same blocks assembled into a scipy.sparse matrix for SuperLU (LU, NOT Cholesky).
 Boards + regularization rows only (the benchmark's problem); frames eliminated."""
 import numpy as np

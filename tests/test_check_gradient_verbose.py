@@ -107,7 +107,7 @@ print("rms %%.15g" %% s["rms_reproj_error__pixels"])
 
 def test_the_trajectory_is_the_restated_libdoglegs_step_for_step():
     """Not only the same optimum: the same SEQUENCE of trial points. The device-side dog-leg (eager Gauss-Newton, all
-    decisions on the GPU: csrc/solver_kernels.hip "dog-leg control") and the restated libdogleg (lazy Gauss-Newton, the
+    decisions on the GPU: csrc/solver_device.hpp "dog-leg control") and the restated libdogleg (lazy Gauss-Newton, the
     published loop: oracle/dogleg_restated.c) driving the reference's own callback, on a well-conditioned calibration
     from the same seed: the cost after every trial step - accepted or rejected - and the trust region it was taken
     with, side by side from the two traces. (What this can pin is the restatement, not libdogleg itself: DESIGN.md 3)"""

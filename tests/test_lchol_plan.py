@@ -1,5 +1,5 @@
 """lchol_plan() - the one function by which the host sizes the grids of the launch-per-panel Cholesky's launches and every
-kernel of it finds its role (solver_kernels.hip) - checked on the CPU through its dev export: no GPU needed.
+kernel of it finds its role (cholesky_large.hip) - checked on the CPU through its dev export: no GPU needed.
 Round 5 gave it `own` (the nested-dissection chains factor their own panels and stop in front of their border) and the
 host sizes the dissection's launches for the LARGEST plan it provides for, trusting that no smaller plan needs more
 workgroups in any launch; both are held here."""

@@ -56,7 +56,7 @@ def test_partitions_of_points_and_pairs():
 class NumpyShard:
     """CPU stand-in for GpuShard (same interface), for ONE rank: the two
     segments of the sharded trial step in numpy, the device-side control logic
-    (csrc/solver_kernels.hip, "the fused step": step2_choose_kernel,
+    (csrc/step.hip, "the fused step": step2_choose_kernel,
     step2_finish, step2_chol_done) restated in Python. x and J come from the
     CPU checker; the block algebra is dense"""
     def __init__(self, ref_api, oi, frame_range, is_leader, tripoint_range=None):
@@ -258,7 +258,7 @@ class NumpyShard:
             c["error"] = c["done"] = 1
 
     def _accept(self):
-        # ctl_accept (solver_kernels.hip)
+        # ctl_accept (solver_device.hpp)
         c = self.ctl
         ib, ia = c["ib"], c["ia"]
         expected = -2.0*self.op[ib]["gs"] - self.op[ib]["sNs"]

@@ -245,10 +245,54 @@ def _rccl_world2_worker(rank, world, port, out_path):
     t = torch.from_numpy(b.copy())
     lo, hi = t.clone(), t.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    # the first box with two devices leaves MEASURED numbers behind where DESIGN.md section 7 has
+    # assumptions (25 / 35 us for the first collective, 12 us for the second): the solve's wall clock on every rank, a
+    # trial step, and the two all-reduces at the sizes of the metric's problem, configuration 3 and configuration 2,
+    # from event pairs around the library's own ncclAllReduce on a stream (one a time: latency, not throughput)
+    import time, json
+    measured = dict(rank=rank, device=torch.cuda.current_device(), solve_seconds=st.get("seconds"),
+                    evaluations=st["Nevaluations"], collectives=sp.Ncollectives)
+    try:
+        sp2 = ShardedProblem(_driver="rccl", **_problem(mrcal_amd._api))
+        _, tr = sp2.run_steps(5, None); sp2.synchronize(); dist.barrier()
+        t0 = time.perf_counter(); n, tr = sp2.run_steps(30, tr); sp2.synchronize(); dt = time.perf_counter() - t0
+        measured["trial_step_us_small_problem"] = 1e6*dt/n
+        lib, comm = sp2._lib, sp2._comm_handle
+        stream = torch.cuda.current_stream()
+        f = lib.mrcal_amd_comm_allreduce_sum
+        import ctypes as C
+        f.restype, f.argtypes = C.c_bool, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        coll = {}
+        for name, ndoubles in (("second: 4 scalars", 4), ("first, metric's problem: Nc = 140", 140*140 + 2*140 + 2),
+                               ("first, configuration 3: Nc = 284", 284*284 + 2*284 + 2), ("first, configuration 2: Nc = 1206", 1206*1206 + 2*1206 + 2)):
+            buf = torch.zeros(ndoubles, dtype=torch.float64, device="cuda")
+            for _ in range(5): f(comm, buf.data_ptr(), ndoubles, stream.cuda_stream)
+            torch.cuda.synchronize(); dist.barrier()
+            us = []
+            for _ in range(30):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream); ok = f(comm, buf.data_ptr(), ndoubles, stream.cuda_stream); e1.record(stream)
+                e1.synchronize(); us.append(1e3*e0.elapsed_time(e1))
+            coll[name] = dict(doubles=ndoubles, us_median=float(np.median(us)), us_min=float(min(us)), us_max=float(max(us)))
+        measured["allreduce"] = coll
+        sp2.close()
+    except Exception as e:          # (the numbers are a by-product: the test's verdict does not hang on them)
+        measured["error"] = f"{type(e).__name__}: {e}"
+    gathered = [None]*world
+    dist.all_gather_object(gathered, measured)
     if rank == 0:
         np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"],
                  Noutliers=st["Noutliers_board"], replicated=bool(torch.equal(lo, hi)),
                  Ncollectives=sp.Ncollectives, Nevaluations=st["Nevaluations"])
+        rec = dict(what=f"tests/test_parallel_gpu.py _rccl_world2_worker at world {world}: ShardedProblem(_driver='rccl'), one process per rank and device; "
+                        "the all-reduces are the library's own (csrc/comm.cpp) timed alone on a stream with event pairs",
+                   world=world, devices=torch.cuda.device_count(), device_name=torch.cuda.get_device_name(0), ranks=gathered)
+        for d in ("gpurun_out", "profiles"):
+            try:
+                with open(os.path.join(ROOT, d, f"r06_rccl_world{world}_measured.json"), "w") as fjson: json.dump(rec, fjson, indent=1)
+            except OSError:
+                pass
+        print(json.dumps(rec, indent=1))
     sp.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -278,6 +322,28 @@ def test_rccl_world2_on_two_devices(amd, tmp_path):
     assert abs(float(r["norm2_x"]) - s1["norm2_x"]) < 1e-9*s1["norm2_x"]
     assert np.abs(r["b"] - b1).max() < 2e-5
     assert int(r["Ncollectives"]) >= 2*int(r["Nevaluations"])
+
+
+def test_rccl_worker_measures_at_world1(amd, tmp_path):
+    """The worker of the two-device test above, at world 1 on the one device this pool's boxes have: the same code - the
+    RCCL communicator, the sharded solve, the timed steps, the event-timed all-reduces - so that the measuring part is known
+    to run before a box with two devices ever sees it; its record (gpurun_out/ and profiles/r06_rccl_world1_measured.json)
+    is what one-rank collectives cost. The solve must be the single-GPU solve's bits (test_rccl_world1... says the same)"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    oi = _problem(amd._api)
+    with Problem(**oi) as p:
+        s1 = p.solve()
+        b1 = p.b_packed()
+    out = str(tmp_path / "rccl1.npz")
+    port = 29800 + (os.getpid() % 150)
+    mp.spawn(_rccl_world2_worker, args=(1, port, out), nprocs=1, join=True)
+    r = np.load(out)
+    assert bool(r["replicated"]) and int(r["Noutliers"]) == s1["Noutliers_board"]
+    assert np.array_equal(r["b"], b1)
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r06_rccl_world1_measured.json")))
+    assert rec["world"] == 1 and "allreduce" in rec["ranks"][0], rec["ranks"][0]
 
 
 # ---- discrete points sharded by point, triangulated points by point set (SURVEY.md 8e) --------------------

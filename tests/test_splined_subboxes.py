@@ -7,7 +7,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HPP  = open(os.path.join(HERE, "..", "mrcal_amd", "csrc", "solver_kernels.hpp")).read()
-HIP  = open(os.path.join(HERE, "..", "mrcal_amd", "csrc", "solver_kernels.hip")).read()
+HIP  = open(os.path.join(HERE, "..", "mrcal_amd", "csrc", "assembly_splined.hip")).read()
 SPL_MAXSUB  = int(re.search(r"#define SPL_MAXSUB\s+(\d+)",  HPP).group(1))
 SPL_SUB_MAX = int(re.search(r"#define SPL_SUB_MAX\s+(\d+)", HPP).group(1))
 SPL_TW      = int(re.search(r"#define SPL_TW\s+(\d+)",      HIP).group(1))
