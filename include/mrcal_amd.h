@@ -663,17 +663,17 @@ int   mrcal_amd_set_elimination(int policy);
    the ordinary path. "lchol_likely_panels" = k: k launches of the big camera block's Cholesky are provided one by one,
    the rest goes through lchol_tail_kernel; "nd_rounds" = k: launches for k rounds of the nested dissection whatever
    the plan needs; "lchol_sweep" = 1: the big Cholesky's solve by the backward sweep (the stable fallback the solver
-   switches to by itself when a factor's diagonal spans more than 1e8); "lchol_fallback_log10" = k: that threshold as
+   switches to by itself when a factor's diagonal spans more than 1e10); "lchol_fallback_log10" = k: that threshold as
    10^k. 0: not forced. Returns the previous value,
    -1 for an unknown name. (Round 6: these were environment variables; the library reads six of those now -
    MRCAL_AMD_GRAPH, _ELIMINATE, _RCCL, _LIB, _NO_ND, _NO_SPL_COMPACT - and MRCAL_AMD_DEBUG_SOLVER, which only prints) */
 int   mrcal_amd_set_test_hook(const char* name, int value);
 /* Round 6: the big camera block's solve ends with d = -Y^T z, Y = L^-1 formed explicitly beside the panels: fast, and
    not backward stable - its error grows like n eps max/min of L's diagonal. The factorizations of a dog-leg pass leave
-   that ratio behind (_lchol_diag_ratio(): min / max, 1 where no such factorization ran); below 1e-8 (the test hook
-   "lchol_fallback_log10" = k: 10^k) the solver warns, switches THIS problem to the backward sweep in groups of panels
-   for good (_uses_sweep(): no explicit inverse, no compaction of the camera block; about 100 us a step slower) and runs
-   the pass again */
+   that ratio behind (_lchol_diag_ratio(): min / max, 1 where no such factorization ran); below 1e-10 (the test hook
+   "lchol_fallback_log10" = k: 10^k) the solver warns and switches THIS problem to the backward sweep in groups of panels
+   for good (_uses_sweep(): no explicit inverse, no compaction of the camera block; about 100 us a step slower), from the
+   next dog-leg pass on */
 double mrcal_amd_problem_lchol_diag_ratio(mrcal_amd_problem_t* problem);
 int    mrcal_amd_problem_uses_sweep(mrcal_amd_problem_t* problem);
 int   mrcal_amd_problem_set_jacobian_stream(mrcal_amd_problem_t* problem, int stream);

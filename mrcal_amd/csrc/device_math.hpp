@@ -220,6 +220,136 @@ MRCAL_AMD_HD void compose_r_dual(Dual<N>* r01, const Dual<N>* r0, const Dual<N>*
     }
 }
 
+////////////////////////////////////////////////////////////////////////////////
+// Duals that know WHICH variables they depend on (round 6): value + the partials with respect to the variables
+// [LO, HI) of a common numbering; every other partial is structurally zero and is neither stored nor computed.
+// The triangulated pairs' residual depends on twelve variables - the two cameras' poses -, but half of its chain
+// involves one camera's six only (and the observation vector's rotation three): as Dual<12> every operation of that
+// half spent half its multiply-adds on zeros the compiler may not drop (0 * x is not 0 for every x). The range of a
+// result is the hull of its operands' ranges; a partial both operands have is the expression Dual<N> has for it, one
+// that only one has is that expression less its zero term: the same value, to the bit.
+////////////////////////////////////////////////////////////////////////////////
+template<int LO, int HI>
+struct DualR
+{
+    static constexpr int lo = LO, hi = HI, n = (HI > LO) ? HI - LO : 0;
+    double x;
+    double d[n > 0 ? n : 1];
+    MRCAL_AMD_HD DualR() {}
+    MRCAL_AMD_HD DualR(double v) : x(v) { for(int i=0;i<n;i++) d[i] = 0.0; }
+    // from a dual of a narrower range
+    template<int L2, int H2>
+    MRCAL_AMD_HD DualR(const DualR<L2,H2>& o) : x(o.x)
+    {
+        static_assert(H2 <= L2 || (LO <= L2 && H2 <= HI), "a dual cannot be narrowed");
+        for(int i=0;i<n;i++) d[i] = (LO + i >= L2 && LO + i < H2) ? o.d[(LO + i - L2) < 0 ? 0 : (LO + i - L2)] : 0.0;
+    }
+    // the partial with respect to variable ivar (0 outside the range)
+    MRCAL_AMD_HD double partial(int ivar) const { return (ivar >= LO && ivar < HI) ? d[ivar - LO] : 0.0; }
+    static MRCAL_AMD_HD DualR variable(double v, int ivar) { DualR r(v); if(ivar >= LO && ivar < HI) r.d[ivar - LO] = 1.0; return r; }
+};
+template<class A, class B> struct DualHull
+{
+    static constexpr bool ea = A::hi <= A::lo, eb = B::hi <= B::lo;
+    static constexpr int lo = ea ? B::lo : (eb ? A::lo : (A::lo < B::lo ? A::lo : B::lo));
+    static constexpr int hi = ea ? B::hi : (eb ? A::hi : (A::hi > B::hi ? A::hi : B::hi));
+    typedef DualR<(ea && eb) ? 0 : lo, (ea && eb) ? 0 : hi> type;
+};
+#define MRCAL_AMD_DR2 template<int LA, int HA, int LB, int HB> MRCAL_AMD_HD typename DualHull<DualR<LA,HA>, DualR<LB,HB> >::type
+#define MRCAL_AMD_IN(R, L, H, i) ((R::lo + (i)) >= (L) && (R::lo + (i)) < (H))
+MRCAL_AMD_DR2 operator+(const DualR<LA,HA>& a, const DualR<LB,HB>& b)
+{
+    typedef typename DualHull<DualR<LA,HA>, DualR<LB,HB> >::type R; R r; r.x = a.x + b.x;
+    for(int i=0;i<R::n;i++)
+    {
+        const bool ia = MRCAL_AMD_IN(R,LA,HA,i), ib = MRCAL_AMD_IN(R,LB,HB,i);
+        const double da = ia ? a.d[ia ? R::lo + i - LA : 0] : 0.0, db = ib ? b.d[ib ? R::lo + i - LB : 0] : 0.0;
+        r.d[i] = (ia && ib) ? da + db : (ia ? da : (ib ? db : 0.0));
+    }
+    return r;
+}
+MRCAL_AMD_DR2 operator-(const DualR<LA,HA>& a, const DualR<LB,HB>& b)
+{
+    typedef typename DualHull<DualR<LA,HA>, DualR<LB,HB> >::type R; R r; r.x = a.x - b.x;
+    for(int i=0;i<R::n;i++)
+    {
+        const bool ia = MRCAL_AMD_IN(R,LA,HA,i), ib = MRCAL_AMD_IN(R,LB,HB,i);
+        const double da = ia ? a.d[ia ? R::lo + i - LA : 0] : 0.0, db = ib ? b.d[ib ? R::lo + i - LB : 0] : 0.0;
+        r.d[i] = (ia && ib) ? da - db : (ia ? da : (ib ? -db : 0.0));
+    }
+    return r;
+}
+MRCAL_AMD_DR2 operator*(const DualR<LA,HA>& a, const DualR<LB,HB>& b)
+{
+    typedef typename DualHull<DualR<LA,HA>, DualR<LB,HB> >::type R; R r; r.x = a.x*b.x;
+    for(int i=0;i<R::n;i++)
+    {
+        const bool ia = MRCAL_AMD_IN(R,LA,HA,i), ib = MRCAL_AMD_IN(R,LB,HB,i);
+        const double da = ia ? a.d[ia ? R::lo + i - LA : 0] : 0.0, db = ib ? b.d[ib ? R::lo + i - LB : 0] : 0.0;
+        r.d[i] = (ia && ib) ? da*b.x + a.x*db : (ia ? da*b.x : (ib ? a.x*db : 0.0));
+    }
+    return r;
+}
+MRCAL_AMD_DR2 operator/(const DualR<LA,HA>& a, const DualR<LB,HB>& b)
+{
+    typedef typename DualHull<DualR<LA,HA>, DualR<LB,HB> >::type R; R r; r.x = a.x/b.x;
+    const double inv2 = 1.0/(b.x*b.x);
+    for(int i=0;i<R::n;i++)
+    {
+        const bool ia = MRCAL_AMD_IN(R,LA,HA,i), ib = MRCAL_AMD_IN(R,LB,HB,i);
+        const double da = ia ? a.d[ia ? R::lo + i - LA : 0] : 0.0, db = ib ? b.d[ib ? R::lo + i - LB : 0] : 0.0;
+        r.d[i] = (ia && ib) ? (da*b.x - a.x*db)*inv2 : (ia ? (da*b.x)*inv2 : (ib ? (-(a.x*db))*inv2 : 0.0));
+    }
+    return r;
+}
+#undef MRCAL_AMD_DR2
+#undef MRCAL_AMD_IN
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator-(const DualR<L,H>& a)
+{ DualR<L,H> r; r.x = -a.x; for(int i=0;i<DualR<L,H>::n;i++) r.d[i] = -a.d[i]; return r; }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator*(const DualR<L,H>& a, double b)
+{ DualR<L,H> r; r.x = a.x*b; for(int i=0;i<DualR<L,H>::n;i++) r.d[i] = a.d[i]*b; return r; }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator*(double b, const DualR<L,H>& a) { return a*b; }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator+(const DualR<L,H>& a, double b) { DualR<L,H> r = a; r.x += b; return r; }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator-(const DualR<L,H>& a, double b) { DualR<L,H> r = a; r.x -= b; return r; }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> operator/(const DualR<L,H>& a, double b) { return a*(1.0/b); }
+template<int L, int H> MRCAL_AMD_HD DualR<L,H> dsqrt(const DualR<L,H>& a)
+{
+    DualR<L,H> r; r.x = sqrt(a.x);
+    const double k = 1.0/(2.0*r.x);
+    for(int i=0;i<DualR<L,H>::n;i++) r.d[i] = a.d[i]*k;
+    return r;
+}
+template<int L, int H> MRCAL_AMD_HD void dsincos(const DualR<L,H>& a, DualR<L,H>* s, DualR<L,H>* c)
+{
+    double sv, cv;
+    sincos(a.x, &sv, &cv);
+    s->x = sv; c->x = cv;
+    for(int i=0;i<DualR<L,H>::n;i++) { s->d[i] = cv*a.d[i]; c->d[i] = -sv*a.d[i]; }
+}
+
+// y = R(r) x  (or R(-r) x if inverted): rotate_point_r_dual() for duals of any ranges (y's: the hull of r's and x's)
+template<class DY, class DRr, class DX>
+MRCAL_AMD_HD void rotate_point_r_dualr(DY* y, const DRr* r, const DX* x, bool inverted)
+{
+    const double sgn = inverted ? -1.0 : 1.0;
+    const auto th2 = r[0]*r[0] + r[1]*r[1] + r[2]*r[2];
+    const DY cr[3] = { DY((r[1]*x[2] - r[2]*x[1])*sgn),
+                       DY((r[2]*x[0] - r[0]*x[2])*sgn),
+                       DY((r[0]*x[1] - r[1]*x[0])*sgn) };
+    const DY rx = r[0]*x[0] + r[1]*x[1] + r[2]*x[2];
+    if(th2.x < 1e-10)
+    {
+        for(int i=0;i<3;i++) y[i] = x[i] + cr[i] + r[i]*rx/2.0;
+        return;
+    }
+    const auto th = dsqrt(th2);
+    auto s = th, c = th;
+    dsincos(th, &s, &c);
+    const auto a = s/th;
+    const auto b = (decltype(c)(1.0) - c)/th2;
+    for(int i=0;i<3;i++) y[i] = x[i]*c + cr[i]*a + r[i]*rx*b;
+}
+
 // R (row-major 3x3) and dR[i][j]/dr[k] stored as dR[9*i + 3*j + k]
 MRCAL_AMD_HD void R_from_r_with_grad(double* R, double* dR, const double* r)
 {

@@ -120,7 +120,7 @@ private:
 // bytes from the device into pageable host memory: the pipeline above for what is big, hipMemcpyAsync otherwise
 inline bool device_to_host(void* dst, const void* src, size_t bytes, hipStream_t stream)
 {
-    if(bytes >= ((size_t)32 << 20) && HostCopyPool::get().copy(dst, src, bytes, stream)) return true;
+    if(bytes >= ((size_t)8 << 20) && HostCopyPool::get().copy(dst, src, bytes, stream)) return true;
     if(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
     return hipStreamSynchronize(stream) == hipSuccess;
 }

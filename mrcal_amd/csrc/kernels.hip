@@ -2231,12 +2231,17 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
 // Row = [6 columns of camera 0's rt, if it is not the reference]
 //       [6 columns of camera 1's rt, ...], in that order (mrcal.c:5383-5506).
 // A pair with an outlier observation keeps its columns, x = 0, values 0
+// (round 6) WITH_J: TWO lanes a pair, in different workgroups - the even ones take the partials with respect to camera
+// 0's pose, the odd ones camera 1's (triangulation.hpp: duals that carry the partials they can have). 67 000 pairs are
+// 1045 waves at a lane each: a wave to a SIMD, nothing to hide its own latencies behind, 25.8 us at BASELINE configuration
+// 5, its longest launch; the halves are 2090 waves of half the partials each
 template<bool WITH_J, bool WITH_STRUCTURE>
 __global__ __launch_bounds__(64)
 void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
 {
     if(opref_skip(R)) return;
-    const int ip = blockIdx.x*blockDim.x + threadIdx.x;
+    const int half = WITH_J ? ((int)blockIdx.x & 1) : 0;
+    const int ip = (WITH_J ? ((int)blockIdx.x >> 1) : (int)blockIdx.x)*blockDim.x + threadIdx.x;
     if(ip >= P.Npairs_tri) return;
     const TriPairMeta m = P.tri_meta[ip];
     if(WITH_STRUCTURE)
@@ -2254,8 +2259,12 @@ void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr,
     const int n1 = (m.i_state_extrinsics1 >= 0) ? 6 : 0;
     if(P.tri_outlier[m.i0] || P.tri_outlier[m.i1])
     {
-        x[m.i_meas] = 0.0;
-        if(WITH_J) for(int c=0;c<n0+n1;c++) Jv[m.i_nnz0 + c] = 0.0;
+        if(half == 0) x[m.i_meas] = 0.0;
+        if(WITH_J)
+        {
+            if(half == 0) for(int c=0;c<n0;c++)     Jv[m.i_nnz0 + c] = 0.0;
+            else          for(int c=n0;c<n0+n1;c++) Jv[m.i_nnz0 + c] = 0.0;
+        }
         return;
     }
     double rt0[6], rt1[6];
@@ -2264,27 +2273,31 @@ void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr,
     const double* v0 = P.tri_px + 3*(size_t)m.i0;
     const double* v1 = P.tri_px + 3*(size_t)m.i1;
     const double v0l[3] = { v0[0], v0[1], v0[2] }, v1l[3] = { v1[0], v1[1], v1[2] };
+    const double* p0 = (m.icam_extrinsics0 >= 0) ? rt0 : NULL;
+    const double* p1 = (m.icam_extrinsics1 >= 0) ? rt1 : NULL;
     if(!WITH_J)
     {
-        const Dual<0> e = tri_pair_error<0>(v0l, v1l, (m.icam_extrinsics0 >= 0) ? rt0 : NULL,
-                                            (m.icam_extrinsics1 >= 0) ? rt1 : NULL, NULL);
-        x[m.i_meas] = e.x;
+        x[m.i_meas] = tri_pair_error<0>(v0l, v1l, p0, p1, NULL).x;
         return;
     }
-    const Dual<12> e = tri_pair_error<12>(v0l, v1l, (m.icam_extrinsics0 >= 0) ? rt0 : NULL,
-                                          (m.icam_extrinsics1 >= 0) ? rt1 : NULL, NULL);
-    x[m.i_meas] = e.x;
-    int c = 0;
-    if(n0)
+    double de[12];
+    if(half == 0)
     {
-        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + i]     = e.d[i]   * SCALE_ROTATION_CAMERA;
-        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + 3 + i] = e.d[3+i] * SCALE_TRANSLATION_CAMERA;
-        c += 6;
+        // (a camera at the reference has no columns and its half carries six zero partials through the error function: one
+        //  piece of code for every lane of the wave, whichever kind of pair it holds)
+        x[m.i_meas] = tri_pair_error_partials<true, false>(de, v0l, v1l, p0, p1, NULL);
+        if(n0)
+        {
+            for(int i=0;i<3;i++) Jv[m.i_nnz0 + i]     = de[i]   * SCALE_ROTATION_CAMERA;
+            for(int i=0;i<3;i++) Jv[m.i_nnz0 + 3 + i] = de[3+i] * SCALE_TRANSLATION_CAMERA;
+        }
     }
-    if(n1)
+    else
     {
-        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + i]     = e.d[6+i] * SCALE_ROTATION_CAMERA;
-        for(int i=0;i<3;i++) Jv[m.i_nnz0 + c + 3 + i] = e.d[9+i] * SCALE_TRANSLATION_CAMERA;
+        (void)tri_pair_error_partials<false, true>(de, v0l, v1l, p0, p1, NULL);
+        if(n1 == 0) return;
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + n0 + i]     = de[6+i] * SCALE_ROTATION_CAMERA;
+        for(int i=0;i<3;i++) Jv[m.i_nnz0 + n0 + 3 + i] = de[9+i] * SCALE_TRANSLATION_CAMERA;
     }
 }
 static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian, hipStream_t stream)
@@ -2292,7 +2305,7 @@ static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bo
     if(P.Npairs_tri <= 0) return;
     const dim3 grid((P.Npairs_tri + 63)/64), block(64);
     if(with_jacobian)
-        hipLaunchKernelGGL((triangulated_kernel<true,false>),  grid, block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+        hipLaunchKernelGGL((triangulated_kernel<true,false>),  dim3(2*grid.x), block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
     else
         hipLaunchKernelGGL((triangulated_kernel<false,false>), grid, block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
 }

@@ -16,6 +16,10 @@
 #include "kernels.hpp"
 #include "problem_object.hpp"
 #include "host_copy.hpp"
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
 
 using namespace mrcal_amd;
 
@@ -754,6 +758,56 @@ bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool w
 } // namespace mrcal_amd
 
 namespace { int& elimination_policy() { static int policy = 0; return policy; } }
+
+// (round 6) The drop-in entry points make a problem, use it once and tear it down: some forty hipFree() calls, each of
+// which waits for the device - 4 ms at the metric's size, a tenth of an mrcal_optimize() call. A problem that nobody can
+// reach any more is torn down by a thread of its own instead, while the caller already has its results; at most two
+// wait at a time (a caller in a loop does not pile up gigabytes: the third waits for the first)
+namespace mrcal_amd {
+class ProblemReaper
+{
+    std::mutex m; std::condition_variable cv, cv_room;
+    std::deque<mrcal_amd_problem*> q;
+    std::thread th;
+    bool quit = false, started = false;
+    int  device = 0;
+    void run()
+    {
+        (void)hipSetDevice(device);
+        for(;;)
+        {
+            mrcal_amd_problem* P = NULL;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return quit || !q.empty(); });
+                if(q.empty()) return;
+                P = q.front();
+            }
+            delete P;
+            { std::lock_guard<std::mutex> lk(m); q.pop_front(); }
+            cv_room.notify_all();
+        }
+    }
+public:
+    static ProblemReaper& get() { static ProblemReaper r; return r; }
+    void later(mrcal_amd_problem* P)
+    {
+        if(P == NULL) return;
+        std::unique_lock<std::mutex> lk(m);
+        if(!started) { (void)hipGetDevice(&device); th = std::thread([this] { run(); }); started = true; }
+        cv_room.wait(lk, [&] { return q.size() < 2; });
+        q.push_back(P);
+        cv.notify_one();
+    }
+    ~ProblemReaper()
+    {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        if(th.joinable()) th.join();
+    }
+};
+void problem_destroy_later(mrcal_amd_problem* P) { ProblemReaper::get().later(P); }
+} // namespace mrcal_amd
 
 extern "C" {
 
@@ -1542,7 +1596,8 @@ bool mrcal_optimizer_callback(double* b_packed, int buffer_size_b_packed,
         if(!mrcal_amd_problem_get_J(P, (int32_t*)Jt->p, (int32_t*)Jt->i, (double*)Jt->x)) goto done;
     ok = true;
  done:
-    mrcal_amd_problem_destroy(P);
+    // (hipStreamSynchronize()d by the copies above: nothing of P is in flight)
+    problem_destroy_later(P);
     return ok;
 }
 

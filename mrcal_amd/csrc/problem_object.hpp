@@ -143,6 +143,8 @@ namespace mrcal_amd {
 bool problem_prepare_solver(mrcal_amd_problem* P);
 // x, J (and the normal equations if with_normal) at op[i].b
 bool problem_evaluate_op(mrcal_amd_problem* P, int i, bool with_jacobian, bool with_normal);
+// tears a problem nobody can reach any more down on a thread of its own (problem.cpp: ProblemReaper)
+void problem_destroy_later(mrcal_amd_problem* P);
 // makes op[icur].Jv the Jacobian at op[icur].b if a solve without the Jacobian stream left it otherwise
 bool problem_ensure_jacobian(mrcal_amd_problem* P);
 // the same, with the operating point possibly resolved on the device

@@ -398,8 +398,9 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
     P->stats.Nfactorizations += c.Nfactorizations;
     // (round 6) how far apart the diagonal entries of the big camera block's factors lay in this pass: the solve ends with
     // d = -Y^T z, Y = L^-1 formed explicitly, whose error grows like n eps max/min of that diagonal. A ratio
-    // below 1e-8 - a camera block of condition 1e16: no factorization of this pass deserved much trust - sends the problem
-    // to the backward sweep for good (mrcal_amd_problem_solve() runs the pass again): slower, backward stable
+    // below 1e-10 - a step that is wrong in its fourth digit; at 5e-9, which ill-determined splined problems of the fuzz
+    // sweeps reach, it is its fifth and the solves end where the reference's end - sends the problem to the backward sweep
+    // for good, from the next pass on (mrcal_amd_problem_solve()): slower, backward stable
     if(P->F.diag_minmax != NULL)
     {
         unsigned long long mm[2];
@@ -408,7 +409,7 @@ bool run_dogleg(mrcal_amd_problem* P, const DoglegParameters& prm)
         if(hi > 0.0 && lo <= hi)
         {
             P->lchol_diag_ratio = lo/hi;
-            const int lg = test_hooks().lchol_fallback_log10 ? test_hooks().lchol_fallback_log10 : -8;
+            const int lg = test_hooks().lchol_fallback_log10 ? test_hooks().lchol_fallback_log10 : -10;
             if(P->lchol_diag_ratio < pow(10.0, (double)lg) && !P->F.use_sweep && P->comm == NULL) P->sweep_fallback_wanted = true;
         }
     }
@@ -728,13 +729,15 @@ double mrcal_amd_problem_solve(mrcal_amd_problem_t* P, int max_iterations,
         if(P->sweep_fallback_wanted)
         {
             P->sweep_fallback_wanted = false;
+            // (the pass that was just done stands - a second run of it would be 300 more iterations in front of the outlier
+            //  marking where the iteration limit ends the passes, another trajectory than the reference's -; what follows it
+            //  goes through the sweep)
             fprintf(stderr, "mrcal_amd: WARNING: the diagonal of the camera block's Cholesky factor spans %.1e: this problem's steps go through "
-                            "the backward sweep from here on instead of the explicit inverse (slower, backward stable). The pass again\n", 1.0/P->lchol_diag_ratio);
+                            "the backward sweep from here on instead of the explicit inverse (slower, backward stable)\n", 1.0/P->lchol_diag_ratio);
             P->F.use_sweep = 1;
             P->F.cperm_cur = NULL; P->plan.spl_compact = 0; P->plan.nd_lim = NULL; P->F.nd_lim.rounds = 0;
             for(int i = 0; i < 3; i++)
                 if(P->step_graph[i]) { hipGraphExecDestroy(P->step_graph[i]); P->step_graph[i] = NULL; }
-            continue;
         }
         if(!P->L.sel.do_apply_outlier_rejection) break;
         bool found;
@@ -1177,7 +1180,7 @@ mrcal_optimize( double* b_packed, int buffer_size_b_packed,
     if(verbose) report_regularization(P, sel);
 
  done:
-    mrcal_amd_problem_destroy(P);
+    problem_destroy_later(P);
     return stats;
 }
 

@@ -127,7 +127,7 @@ struct FactorBuffers
     int     nd_likely_panels;   // the separator's panels at the solve's first point (as lchol_likely_panels)
     int     use_sweep; // the large Cholesky's solve by the backward sweep in groups of panels (backward stable; slower: no explicit
                       // L^-1, no compaction, the end-of-trial logic in launches of its own) instead of d = -Y^T z. Set by the
-                      // automatic fallback (solver.cpp: a factor whose diagonal spans more than 1e8) or by a test hook
+                      // automatic fallback (solver.cpp: a factor whose diagonal spans more than 1e10) or by a test hook
     unsigned long long* diag_minmax; // [2] the smallest / largest diagonal entry of the big camera block's Cholesky factor since the solve's
                       // start (bit patterns of positive doubles; set to +inf, 0 by ctl_reset()): what the fallback to the sweep goes by. NULL: no large Cholesky
     double* Wtile;    // with occ: a second copy of the tiles of Wt that hold something, tile column by tile column -

@@ -5,6 +5,7 @@ kept as small fixtures:
 
     config3   16 cameras x 2000 frames x 10x10, LENSMODEL_OPENCV8, everything optimized, outlier rejection (seed 2)
     config5   SfM: 4 cameras OPENCV4 (intrinsics locked) + 20000 triangulated points + 400 board frames (seed 9)
+    ns_seed0  the metric's 8 cameras x 1000 frames OPENCV8 at bench.py's seed 0: what the 8-rank solve is compared on
 
     python tests/golden/make_reference_solves.py config5 config3       (CPU only; config3 takes ~an hour of one core)
 
@@ -24,6 +25,9 @@ def recorded_inputs(name, api):
     if name == "config3":
         return make_calibration_problem(api, Ncameras=16, Nframes=2000, lensmodel="LENSMODEL_OPENCV8",
                                         object_width_n=10, object_height_n=10, seed=2)[0]
+    if name == "ns_seed0":  # the metric's own problem, bench.py's seed: what the sharded solves are compared on
+        return make_calibration_problem(api, Ncameras=8, Nframes=1000, lensmodel="LENSMODEL_OPENCV8",
+                                        object_width_n=10, object_height_n=10, seed=0)[0]
     if name == "config1":   # (a small one, to try the machinery)
         return make_calibration_problem(api, Ncameras=4, Nframes=400, lensmodel="LENSMODEL_OPENCV8",
                                         object_width_n=10, object_height_n=10, seed=2)[0]

@@ -74,6 +74,26 @@ void hostcheck_project_splined(double* q, double* dq_dp, double* dq_dfxy, int* i
     }
 }
 
+// the same by ROWS (round 6: board_splined_rows_kernel's lanes take one image coordinate each): project_splined_row() of
+// coordinate k into the k-th halves of the same arrays; coef: the x then the y basis values as coordinate 0's call left them,
+// coef_k1[N][8]: coordinate 1's (they must be the same)
+void hostcheck_project_splined_rows(double* q, double* dq_dp, double* dq_dfxy, int* ivar0, double* coef, double* coef_k1,
+                                    const double* p, int N, const double* intr,
+                                    int order, int Nx, int Ny, double fov_x_deg)
+{
+    LensConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    cfg.spline_order = order; cfg.spline_Nx = Nx; cfg.spline_Ny = Ny;
+    cfg.spline_segments_per_u = spline_segments_per_u(order, Nx, fov_x_deg);
+    for(int i=0;i<N;i++)
+        for(int k=0;k<2;k++)
+        {
+            int iv;
+            double* c = k ? &coef_k1[8*i] : &coef[8*i];
+            project_splined_row<true>(k, &q[2*i + k], &dq_dp[6*i + 3*k], &dq_dfxy[2*i + k], &iv, c, c + 4, &p[3*i], intr, cfg);
+            if(k == 0) ivar0[i] = iv; else if(iv != ivar0[i]) ivar0[i] = -1;
+        }
+}
+
 // rotation composition and friends, for the poseutils known-answer tests
 void hostcheck_compose_rt(double* rt_out, double* d_r_r0, double* d_r_r1, double* d_t_r0, double* d_t_t1,
                           const double* rt0, const double* rt1)

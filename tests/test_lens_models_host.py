@@ -204,6 +204,31 @@ def test_splined_against_reference(hostlib, ref_api, lensmodel, order, Nx, Ny, f
     assert relative_error(dense, dq_di_r).max() < REL_TOL
 
 
+@pytest.mark.parametrize("order,Nx,Ny,fov", ((3, 30, 20, 150.), (2, 16, 12, 120.), (3, 11, 8, 100.)))
+def test_splined_projection_by_rows_is_the_projection_by_corners(hostlib, order, Nx, Ny, fov):
+    """Round 6: board_splined_rows_kernel gives every Jacobian ROW a lane, which projects ONE image coordinate
+    (lens_models.hpp project_splined_row: the shared part + one surface). It is project_splined()'s own arithmetic for
+    that coordinate, in its order: the same BITS in q, dq/dp, dq/df, the basis values and the first control point, for
+    either coordinate, inside the grid and in the clamped segments beyond it"""
+    rng = np.random.RandomState(6)
+    intr = np.concatenate(((1500., 1800., 1499.5, 999.5), rng.uniform(-0.05, 0.05, 2*Nx*Ny)))
+    N = 500
+    p = np.column_stack((rng.uniform(-3, 3, N), rng.uniform(-2, 2, N), rng.uniform(0.3, 3.0, N)))
+    p[:8] *= np.array((8., 8., 1.))
+    pc = np.ascontiguousarray(p)
+    def arrays(): return np.zeros((N,2)), np.zeros((N,2,3)), np.zeros((N,2)), np.zeros(N, dtype=np.int32), np.zeros((N,8))
+    q, g, df, iv, coef = arrays()
+    hostlib.hostcheck_project_splined(_ptr(q), _ptr(g), _ptr(df), _ptr(iv), _ptr(coef), _ptr(pc), N, _ptr(intr), order, Nx, Ny, fov)
+    q2, g2, df2, iv2, coef2 = arrays()
+    coef_k1 = np.zeros((N,8))
+    f = hostlib.hostcheck_project_splined_rows
+    f.restype, f.argtypes = None, [C.c_void_p]*7 + [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+    f(_ptr(q2), _ptr(g2), _ptr(df2), _ptr(iv2), _ptr(coef2), _ptr(coef_k1), _ptr(pc), N, _ptr(intr), order, Nx, Ny, fov)
+    assert np.array_equal(iv, iv2)
+    assert np.array_equal(q, q2) and np.array_equal(g, g2) and np.array_equal(df, df2)
+    assert np.array_equal(coef, coef2) and np.array_equal(coef, coef_k1)
+
+
 def test_compose_rt_and_R_from_r(hostlib, ref_api):
     """rotation composition with all its gradients, incl. the tiny-angle and
     near-pi branches, against the reference's poseutils"""

@@ -346,6 +346,57 @@ def test_rccl_worker_measures_at_world1(amd, tmp_path):
     assert rec["world"] == 1 and "allreduce" in rec["ranks"][0], rec["ranks"][0]
 
 
+@pytest.mark.timeout(900)
+def test_sharded_metric_size_outliers_against_the_references_record(amd, tmp_path):
+    """since round 5's arithmetic the 8-rank solve of the metric's problem and the single-GPU
+    solve mark 7843 outliers each but not the same 7843 (one corner at the k-sigma line falls the other way) - and nothing
+    said which of the two the REFERENCE's mask equals. Here both are solved on the inputs the record of the reference's own
+    mrcal_optimize() was made from (tests/golden/reference_solve_ns_seed0.npz: 80 s of one core, in the build container)
+    and both masks are compared with the recorded one: the counts must agree, whatever differs must be a handful of corners
+    AT the line, and the rms must be the reference's to 1e-5 - and no higher - where the marks are identical. Which of the two (or both)
+    reproduces the reference's marks corner by corner is printed and recorded, not imposed: the sums of eight shards and of
+    one GPU are both legitimate roundings of the same numbers"""
+    import torch.multiprocessing as mp
+    from mrcal_amd.resident import Problem
+    from mrcal_amd.synthetic import copy_inputs
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_reference_solves import inputs_hash
+    rec = np.load(os.path.join(ROOT, "tests", "golden", "reference_solve_ns_seed0.npz"))
+    oi = _host_case(amd._api, "metric_size_recorded")
+    assert inputs_hash(oi) == str(rec["inputs_sha256"]), "the synthesized inputs are not the record's"
+    o1 = copy_inputs(oi)
+    s1 = amd.optimize(**o1)
+    mask_1 = (o1["observations_board"][..., 2] < 0).ravel()
+    mask_r = np.unpackbits(rec["outlier_mask_packed"])[:mask_1.size].astype(bool)
+    out = str(tmp_path / "host8.npz")
+    port = 29700 + (os.getpid() % 250)
+    mp.spawn(_host_worker, args=(8, port, out, "metric_size_recorded"), nprocs=8, join=True)
+    r = np.load(out)
+    mask_8 = r["outlier_mask"]
+    d1, d8 = int((mask_1 != mask_r).sum()), int((mask_8 != mask_r).sum())
+    rms_r = float(rec["rms_reproj_error__pixels"])
+    print(f"outliers: reference {int(mask_r.sum())}, single GPU {int(mask_1.sum())} ({d1} marks differ), 8 ranks {int(mask_8.sum())} ({d8} marks differ); "
+          f"rms reference {rms_r!r}, single GPU {s1['rms_reproj_error__pixels']!r}, 8 ranks {float(r['rms'])!r}")
+    import json
+    recd = dict(problem="8 cameras x 1000 frames OPENCV8, seed 0 (bench.py's), inputs made with the reference's library",
+                outliers=dict(reference=int(mask_r.sum()), single_gpu=int(mask_1.sum()), ranks8_host_transport=int(mask_8.sum())),
+                marks_differing_from_the_references=dict(single_gpu=d1, ranks8_host_transport=d8),
+                rms=dict(reference=rms_r, single_gpu=float(s1["rms_reproj_error__pixels"]), ranks8_host_transport=float(r["rms"])))
+    for d in ("gpurun_out", "profiles"):
+        try:
+            with open(os.path.join(ROOT, d, "r06_ns_sharded_outliers_vs_reference.json"), "w") as f: json.dump(recd, f, indent=1)
+        except OSError: pass
+    assert bool(r["replicated"])
+    assert abs(int(mask_1.sum()) - int(mask_r.sum())) <= 2 and abs(int(mask_8.sum()) - int(mask_r.sum())) <= 2
+    assert d1 <= 4 and d8 <= 4, (d1, d8)
+    assert min(d1, d8) == 0, "neither the single-GPU nor the 8-rank solve reproduces the reference's marks corner by corner"
+    # (observed: 0 and 0 marks differ - both solves reproduce the reference's 7843 corner by corner -, and the rms of either is
+    #  1.5e-6 BELOW the recorded one: at this seed the restated libdogleg stops a little earlier in OPENCV8's flat valley)
+    for d, rms in ((d1, float(s1["rms_reproj_error__pixels"])), (d8, float(r["rms"]))):
+        assert abs(rms - rms_r) < (1e-5 if d == 0 else 1e-4)*rms_r
+        assert rms <= rms_r*(1. + 1e-9)
+
+
 # ---- discrete points sharded by point, triangulated points by point set (SURVEY.md 8e) --------------------
 def _sfm_with_everything(api, seed=9):
     """boards AND triangulated points AND discrete points (some fixed, listed out of point order) in one problem,
@@ -475,6 +526,14 @@ def test_world2_points_and_pairs(amd, tmp_path):
 HOST_CASES = ("boards", "boards_splined", "everything", "fewer_frames_than_ranks", "metric_size")
 def _host_case(api, which):
     from mrcal_amd.synthetic import make_calibration_problem
+    if which == "metric_size_recorded":
+        # the same problem with its perfect corners projected by the REFERENCE's library, as the record of the
+        # reference's own solve of it was made (tests/golden/make_reference_solves.py ns_seed0)
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        from make_reference_solves import recorded_inputs
+        from mrcal_amd._cabi import MrcalLib
+        from mrcal_amd._api import Api
+        return recorded_inputs("ns_seed0", Api(MrcalLib(os.path.join(ROOT, "oracle", "_ref", "libmrcal_ref.so"))))
     if which == "metric_size":
         # the benchmark's own problem: 8 cameras x 1000 frames OPENCV8 (bench.py)
         return make_calibration_problem(api, Ncameras=8, Nframes=1000, lensmodel="LENSMODEL_OPENCV8",
@@ -505,7 +564,8 @@ def _host_worker(rank, world, port, out_path, which):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import mrcal_amd
     from mrcal_amd.parallel import ShardedProblem
-    sp = ShardedProblem(_driver="host", **_host_case(mrcal_amd._api, which))
+    oi_case = _host_case(mrcal_amd._api, which)
+    sp = ShardedProblem(_driver="host", **oi_case)
     st = sp.solve()
     b = sp.b_packed()
     t = torch.from_numpy(b.copy())
@@ -517,11 +577,26 @@ def _host_worker(rank, world, port, out_path, which):
     ranges = torch.zeros(world, 6, dtype=torch.int64)
     ranges[rank] = torch.tensor(sp.frame_range + sp.point_range + sp.tripoint_range)
     dist.all_reduce(ranges)
+    # the outlier marks of the whole problem: every rank holds those of its own frames' observations (a contiguous run:
+    # the observations are sorted by frame)
+    mask = None
+    if which == "metric_size_recorded":
+        import ctypes as C
+        iframe = oi_case["indices_frame_camintrinsics_camextrinsics"][:, 0]
+        mine = np.nonzero((iframe >= sp.frame_range[0]) & (iframe < sp.frame_range[1]))[0]
+        H, W = oi_case["observations_board"].shape[1:3]
+        pool = np.zeros((len(mine), H, W, 3))
+        assert sp._lib.mrcal_amd_problem_get_board_pool(sp.problem.handle, pool.ctypes.data_as(C.c_void_p))
+        full = torch.zeros(len(iframe)*H*W, dtype=torch.int64)
+        if len(mine): full[mine[0]*H*W:(mine[-1] + 1)*H*W] = torch.from_numpy((pool[..., 2] < 0).astype(np.int64).ravel())
+        dist.all_reduce(full)
+        mask = full.numpy().astype(bool)
     if rank == 0:
         np.savez(out_path, b=b, rms=st["rms_reproj_error__pixels"], norm2_x=st["norm2_x"],
                  Noutliers=st["Noutliers_board"],
                  replicated=bool(torch.equal(lo, hi) and torch.equal(cl, ch)),
-                 Ncollectives=sp.Ncollectives, Nevaluations=st["Nevaluations"], ranges=ranges.numpy())
+                 Ncollectives=sp.Ncollectives, Nevaluations=st["Nevaluations"], ranges=ranges.numpy(),
+                 **({} if mask is None else {"outlier_mask": mask}))
     sp.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -206,6 +206,26 @@ def test_seed_and_calibrate_real_data(amd, ref_api):
     ndiff = int((mask_r != mask_a).sum())
     assert ndiff <= 10, ndiff          # (6 observed: four corners traded places, two more on the product's side)
     assert abs(s_r["Noutliers_board"] - stats["Noutliers_board"]) <= ndiff
-    assert abs(s_r["rms_reproj_error__pixels"] - stats["rms_reproj_error__pixels"]) < (1e-6 if ndiff == 0 else 1e-2)*s_r["rms_reproj_error__pixels"]
+    # what is NOT a threshold effect stays strict. (1) every corner the two solves mark differently sits AT
+    # the k-sigma line (markOutliers: k0 = 4, /root/reference/mrcal.c:3978-4402): seen from the solve that keeps it, its
+    # residual is 3.5 - 4.6 sigma of that solve's inliers - a corner of 2 or of 10 sigma marked by one and not by the
+    # other would be a defect of the marking, not rounding. (2) on the corners BOTH solves keep, the two solutions fit
+    # the same: rms over the common inliers to 1e-3 (observed 2.8e-4, the product's the LOWER one: a handful of 4-sigma
+    # corners in or out of 18 000 move the optimum, and the restated libdogleg stops a little earlier in OPENCV8's flat
+    # valley; 1e-2 on the whole-problem rms, which this replaces, would have passed a real regression)
+    Ncorn = mask_a.size
+    xa = stats["x"][:2*Ncorn].reshape(-1, 2); xr = s_r["x"][:2*Ncorn].reshape(-1, 2)
+    w  = np.abs(last["observations_board"][..., 2].ravel())             # (|weight|: the residuals are weighted)
+    both = ~mask_a.ravel() & ~mask_r.ravel()
+    rms_a = np.sqrt((xa[both]**2).sum()/(2*both.sum())); rms_r = np.sqrt((xr[both]**2).sum()/(2*both.sum()))
+    print(f"{ndiff} corners marked differently; rms over the {int(both.sum())} common inliers: {rms_a!r} (product) {rms_r!r} (reference)")
+    assert abs(rms_a - rms_r) < 1e-3*rms_r, (rms_a, rms_r)
+    for i in np.nonzero((mask_a != mask_r).ravel())[0]:
+        x_keep, sigma = (xr[i], rms_r) if mask_a.ravel()[i] else (xa[i], rms_a)      # the solve that keeps corner i as an inlier
+        nsig = np.abs(x_keep).max()/sigma
+        print(f"   corner {i}: kept by the {'reference' if mask_a.ravel()[i] else 'product'} at {nsig:.3f} sigma (weight {w[i]:.3f})")
+        assert 3.5 < nsig < 4.6, (i, nsig)
+    if ndiff == 0:
+        assert abs(s_r["rms_reproj_error__pixels"] - stats["rms_reproj_error__pixels"]) < 1e-6*s_r["rms_reproj_error__pixels"]
     assert np.abs(oi["intrinsics"][0, :4] - stored["intrinsics"][0, :4]).max() < 3.0       # pixels, on a 6016x4016 imager
     assert np.abs(oi["calobject_warp"] - stored["calobject_warp"]).max() < 5e-4

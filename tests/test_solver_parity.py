@@ -600,10 +600,10 @@ def test_solve_through_the_explicit_inverse_matches_the_backward_sweep(amd):
                  N d = -g, relative to |N| |d|, is what a backward-stable solve leaves (a few eps) to within 1e3
       sweep      the test hook lchol_sweep: the triangular sweep of rounds 2-3 (which also turns the compaction of the
                  camera block off) from the start: the same outliers, the same optimum, the same kind of residual
-      fallback   round 6's automatic fallback, its threshold raised from 1e-8 to 1e-2 by the test hook
+      fallback   round 6's automatic fallback, its threshold raised from 1e-10 to 1e-2 by the test hook
                  lchol_fallback_log10 so that this problem (whose factors' diagonals span 1e5 - 1e7) trips it: the first pass
-                 runs through the explicit inverse, the solver says so on stderr and switches the problem to the sweep,
-                 the pass runs again - and the solve ends where the others end"""
+                 runs through the explicit inverse, the solver says so on stderr and switches the problem to the sweep
+                 for the passes that follow - and the solve ends where the others end"""
     import os, subprocess, sys, json
     code = r'''
 import sys, os, json, numpy as np
