@@ -465,7 +465,7 @@ def main():
                     achieved = flops/1e12/(kernel_ms*1e-3) if kernel_ms > 0 else 0.0,
                     peak = FP64_MFMA_PEAK_TFLOPS, unit = "TFLOP/s")
         mfma["frac"] = mfma["achieved"]/FP64_MFMA_PEAK_TFLOPS
-        for mname in ("r05_mfma_utilisation.json", "r04_mfma_utilisation.json", "r03_mfma_utilisation.json", "r02_mfma_utilisation.json"):
+        for mname in ("r06_mfma_utilisation.json", "r05_mfma_utilisation.json", "r04_mfma_utilisation.json", "r03_mfma_utilisation.json", "r02_mfma_utilisation.json"):
             mpath = os.path.join(ROOT, "profiles", mname)
             if not os.path.exists(mpath):
                 continue

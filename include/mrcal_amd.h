@@ -498,7 +498,10 @@ int     mrcal_amd_problem_Nmeasurements(const mrcal_amd_problem_t* problem);
 int64_t mrcal_amd_problem_Nnz          (const mrcal_amd_problem_t* problem);
 /* Algorithmic HBM bytes of one launch of the board Jacobian kernel on this
    problem: per observation of P corners with k nonzeros per row,
-   24 P (read qx,qy,weight) + 16 P (write x) + 16 P k (write J values) */
+   24 P (read qx,qy,weight) + 16 P (write x) + 16 P k (write J values); where the
+   triangulated pairs of a structure-from-motion problem ride in that launch (round 6: a
+   problem with boards and pairs whose intrinsics are locked), + per pair 48 (two
+   observation vectors) + its record + 8 (x) + 8 per partial written */
 int64_t mrcal_amd_problem_jacobian_algorithmic_bytes(const mrcal_amd_problem_t* problem);
 /* waits for everything queued on the problem's stream */
 bool    mrcal_amd_problem_synchronize  (mrcal_amd_problem_t* problem);

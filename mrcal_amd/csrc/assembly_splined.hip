@@ -133,7 +133,7 @@ int spl_col_state(const DeviceProblem& P, const NormalDims& nd, int c, int K, in
 }
 // (not inlined: what it needs in registers should not count against the kernel's usual path)
 __device__ __noinline__
-void spl_rows_fallback(const NormalDims& nd, const OpDev& O, int r_first, int r1,
+void spl_rows_fallback(const NormalDims nd /* by value: by reference the kernel's copy lives in scratch, and the usual path reads it from there */, const OpDev& O, int r_first, int r1,
                        const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
 {
     for(int r = r_first; r < r1; r += blockDim.x) rows_generic_row(nd, O, r, r1, Jp, Ji);

@@ -2235,23 +2235,14 @@ static void launch_eval_splined(const DeviceProblem& P, const EvalBuffers& B, bo
 // 0's pose, the odd ones camera 1's (triangulation.hpp: duals that carry the partials they can have). 67 000 pairs are
 // 1045 waves at a lane each: a wave to a SIMD, nothing to hide its own latencies behind, 25.8 us at BASELINE configuration
 // 5, its longest launch; the halves are 2090 waves of half the partials each
-template<bool WITH_J, bool WITH_STRUCTURE>
-__global__ __launch_bounds__(64)
-void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
+// (the body, for the launches that carry it: triangulated_kernel, and board_tri_kernel beside the board observations)
+template<bool WITH_J>
+__device__ __forceinline__ void triangulated_pairs(const DeviceProblem& P, const OpRef& R, const int block)
 {
-    if(opref_skip(R)) return;
-    const int half = WITH_J ? ((int)blockIdx.x & 1) : 0;
-    const int ip = (WITH_J ? ((int)blockIdx.x >> 1) : (int)blockIdx.x)*blockDim.x + threadIdx.x;
+    const int half = WITH_J ? (block & 1) : 0;
+    const int ip = (WITH_J ? (block >> 1) : block)*64 + (int)threadIdx.x;
     if(ip >= P.Npairs_tri) return;
     const TriPairMeta m = P.tri_meta[ip];
-    if(WITH_STRUCTURE)
-    {
-        rowptr[m.i_meas] = (int32_t)m.i_nnz0;
-        int c = 0;
-        if(m.i_state_extrinsics0 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics0 + i; c += 6; }
-        if(m.i_state_extrinsics1 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics1 + i; }
-        return;
-    }
     const double* __restrict__ b  = opref_get(R).b;
     double*       __restrict__ x  = opref_get(R).x;
     double*       __restrict__ Jv = opref_get(R).Jv;
@@ -2300,12 +2291,49 @@ void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr,
         for(int i=0;i<3;i++) Jv[m.i_nnz0 + n0 + 3 + i] = de[9+i] * SCALE_TRANSLATION_CAMERA;
     }
 }
+template<bool WITH_J, bool WITH_STRUCTURE>
+__global__ __launch_bounds__(64)
+void triangulated_kernel(DeviceProblem P, OpRef R, int32_t* __restrict__ rowptr, int32_t* __restrict__ colidx)
+{
+    if(opref_skip(R)) return;
+    if(WITH_STRUCTURE)
+    {
+        const int ip = (int)blockIdx.x*blockDim.x + threadIdx.x;
+        if(ip >= P.Npairs_tri) return;
+        const TriPairMeta m = P.tri_meta[ip];
+        rowptr[m.i_meas] = (int32_t)m.i_nnz0;
+        int c = 0;
+        if(m.i_state_extrinsics0 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics0 + i; c += 6; }
+        if(m.i_state_extrinsics1 >= 0) { for(int i=0;i<6;i++) colidx[m.i_nnz0 + c + i] = m.i_state_extrinsics1 + i; }
+        return;
+    }
+    else
+        triangulated_pairs<WITH_J>(P, R, (int)blockIdx.x);
+}
+// (round 6) The board observations and the triangulated pairs of a structure-from-motion problem in ONE launch: 1600
+// observations are 1600 waves, 67 000 pairs 2090, for 2048 places either way - the two launches one after the other
+// each left the chip half empty for 22 + 24 us (BASELINE configuration 5). Neither reads what the other writes. The
+// pairs' workgroups - the longer waves - come first. For the board kernel's general variant (the intrinsics of such a
+// problem are locked, as a rule); a problem that optimizes everything keeps the two launches
+template<int PROJ, int NDIST, bool STORE_J>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+void board_tri_kernel(DeviceProblem P, OpRef R, const double* __restrict__ joint, double* __restrict__ gram, int ntri_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if((int)blockIdx.x < ntri_blocks)
+    {
+        if(!opref_skip(R)) triangulated_pairs<true>(P, R, (int)blockIdx.x);
+        return;
+    }
+    board_observation<PROJ,NDIST,true,true,false,STORE_J>(P, R, joint, gram, (int)blockIdx.x - ntri_blocks, lds);
+}
+static int triangulated_blocks_with_jacobian(const DeviceProblem& P) { return 2*((P.Npairs_tri + 63)/64); }
 static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian, hipStream_t stream)
 {
     if(P.Npairs_tri <= 0) return;
     const dim3 grid((P.Npairs_tri + 63)/64), block(64);
     if(with_jacobian)
-        hipLaunchKernelGGL((triangulated_kernel<true,false>),  dim3(2*grid.x), block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
+        hipLaunchKernelGGL((triangulated_kernel<true,false>),  dim3(triangulated_blocks_with_jacobian(P)), block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
     else
         hipLaunchKernelGGL((triangulated_kernel<false,false>), grid, block, 0, stream, P, B.R, (int32_t*)NULL, (int32_t*)NULL);
 }
@@ -2313,15 +2341,40 @@ static void launch_triangulated(const DeviceProblem& P, const EvalBuffers& B, bo
 ////////////////////////////////////////////////////////////////////////////////
 // launchers
 ////////////////////////////////////////////////////////////////////////////////
+// the board kernel's variant for problems that optimize everything (the ablation probes keep the general kernel)
+static bool board_allopt(const DeviceProblem& P, int ndist)
+{
+    return ((16 + ndist) & 1) == 0 && P.Ncore_state && (ndist == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
+           P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
+}
+static int lens_ndist(int lens_type)
+{
+    switch(lens_type)
+    {
+    case MRCAL_LENSMODEL_OPENCV4:  return 4;
+    case MRCAL_LENSMODEL_OPENCV5:  return 5;
+    case MRCAL_LENSMODEL_OPENCV8:  return 8;
+    case MRCAL_LENSMODEL_OPENCV12: return 12;
+    case MRCAL_LENSMODEL_CAHVOR:   return 5;
+    case MRCAL_LENSMODEL_CAHVORE:  return 8;
+    default:                       return 0;
+    }
+}
+// the triangulated pairs ride in the board kernel's launch (board_tri_kernel) when both are there and the Jacobian and
+// the Grams are asked for
+bool board_launch_takes_triangulated(const DeviceProblem& P)
+{
+    return P.Nobs_board > 0 && P.Npairs_tri > 0 && P.lens_type != MRCAL_LENSMODEL_SPLINED_STEREOGRAPHIC &&
+           !board_allopt(P, lens_ndist(P.lens_type));
+}
 template<int PROJ, int NDIST>
 static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool with_jacobian,
                           int lds_bytes, hipStream_t stream,
                           hipEvent_t ev_j0, hipEvent_t ev_j1, int parts)
 {
-    // (the ablation probes keep the general kernel)
     constexpr bool kfull_even = ((16 + NDIST) & 1) == 0;
-    const bool allopt = kfull_even && P.Ncore_state && (NDIST == 0 || P.Ndist_state) && P.do_optimize_extrinsics &&
-                        P.do_optimize_frames && P.has_warp_state && P.has_warp_seed && !ABLATE(P, ~0);
+    const bool allopt = board_allopt(P, NDIST);
+    const bool tri_rides = with_jacobian && B.gram != NULL && board_launch_takes_triangulated(P);
     if(P.Nobs_board > 0 && (parts & EVAL_PART_PROLOGUE))
     {
         const int nblocks_obs    = prologue_obs_blocks(P.Nobs_board);
@@ -2345,6 +2398,14 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
                     hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,true,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
                                        P, B.R, B.joint, B.gram);
             }
+        }
+        else if(tri_rides)
+        {
+            const int ntri = triangulated_blocks_with_jacobian(P);
+            if(B.store_jacobian)
+                hipLaunchKernelGGL((board_tri_kernel<PROJ,NDIST,true>),  dim3(ntri + P.Nobs_board), dim3(64), lds_bytes, stream, P, B.R, B.joint, B.gram, ntri);
+            else
+                hipLaunchKernelGGL((board_tri_kernel<PROJ,NDIST,false>), dim3(ntri + P.Nobs_board), dim3(64), lds_bytes, stream, P, B.R, B.joint, B.gram, ntri);
         }
         else if(with_jacobian && B.gram != NULL && !B.store_jacobian)
             hipLaunchKernelGGL((board_kernel<PROJ,NDIST,true,true,false,false>), dim3(P.Nobs_board), dim3(64), lds_bytes, stream,
@@ -2370,7 +2431,7 @@ static void launch_eval_t(const DeviceProblem& P, const EvalBuffers& B, bool wit
             hipLaunchKernelGGL((point_kernel<PROJ,NDIST,false>), dim3((P.Nobs_point + 63)/64), dim3(64), 0, stream,
                                P, B.R);
     }
-    launch_triangulated(P, B, with_jacobian, stream);
+    if(!tri_rides) launch_triangulated(P, B, with_jacobian, stream);
     const int Nreg = P.Nmeas - P.i_meas_regularization;
     // (with board observations the regularization rows were written by the prologue launch)
     if(Nreg > 0 && P.Nobs_board <= 0)

@@ -99,6 +99,8 @@ struct EvalBuffers
 };
 // can the evaluation's prologue launch carry the choice of the trial point (EvalBuffers::choose)?
 bool prologue_takes_choose(const DeviceProblem& P);
+// the triangulated pairs ride in the board kernel's launch (kernels.hip board_tri_kernel) when the Jacobian and the Grams are asked for
+bool board_launch_takes_triangulated(const DeviceProblem& P);
 
 bool lens_supported(int lens_type);
 

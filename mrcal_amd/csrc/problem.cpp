@@ -20,6 +20,8 @@
 #include <mutex>
 #include <condition_variable>
 #include <deque>
+#include <chrono>
+#include <unistd.h>
 
 using namespace mrcal_amd;
 
@@ -762,14 +764,14 @@ namespace { int& elimination_policy() { static int policy = 0; return policy; } 
 // (round 6) The drop-in entry points make a problem, use it once and tear it down: some forty hipFree() calls, each of
 // which waits for the device - 4 ms at the metric's size, a tenth of an mrcal_optimize() call. A problem that nobody can
 // reach any more is torn down by a thread of its own instead, while the caller already has its results; at most two
-// wait at a time (a caller in a loop does not pile up gigabytes: the third waits for the first)
+// are in line at a time (a caller in a loop does not pile up gigabytes: the third it tears down itself, as before)
 namespace mrcal_amd {
 class ProblemReaper
 {
-    std::mutex m; std::condition_variable cv, cv_room;
+    std::mutex m; std::condition_variable cv, cv_idle;
     std::deque<mrcal_amd_problem*> q;
-    std::thread th;
-    bool quit = false, started = false;
+    bool busy = false;
+    pid_t owner = 0;        // the process the thread was started in (a fork()ed child has the object and no thread)
     int  device = 0;
     void run()
     {
@@ -779,31 +781,44 @@ class ProblemReaper
             mrcal_amd_problem* P = NULL;
             {
                 std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return quit || !q.empty(); });
-                if(q.empty()) return;
-                P = q.front();
+                cv.wait(lk, [&] { return !q.empty(); });
+                P = q.front(); q.pop_front(); busy = true;
             }
             delete P;
-            { std::lock_guard<std::mutex> lk(m); q.pop_front(); }
-            cv_room.notify_all();
+            { std::lock_guard<std::mutex> lk(m); busy = false; }
+            cv_idle.notify_all();
         }
     }
 public:
-    static ProblemReaper& get() { static ProblemReaper r; return r; }
+    // (never destroyed: its thread waits on it for as long as the process lives. What IS done when the process ends:
+    //  what is in line is torn down before the runtime's own destructors run - Drain)
+    static ProblemReaper& get()
+    {
+        static ProblemReaper* r = new ProblemReaper;
+        static struct Drain { ProblemReaper* r; ~Drain() { r->drain(); } } d{r};
+        return *r;
+    }
     void later(mrcal_amd_problem* P)
     {
         if(P == NULL) return;
-        std::unique_lock<std::mutex> lk(m);
-        if(!started) { (void)hipGetDevice(&device); th = std::thread([this] { run(); }); started = true; }
-        cv_room.wait(lk, [&] { return q.size() < 2; });
-        q.push_back(P);
-        cv.notify_one();
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if(owner != getpid())
+            {
+                q.clear(); busy = false; owner = getpid();
+                (void)hipGetDevice(&device);
+                std::thread([this] { run(); }).detach();
+            }
+            // (never a wait for the thread here: with two in line already the caller tears this one down itself)
+            if(q.size() + (busy ? 1 : 0) < 2) { q.push_back(P); P = NULL; }
+        }
+        if(P == NULL) cv.notify_one();
+        else          delete P;
     }
-    ~ProblemReaper()
+    void drain()
     {
-        { std::lock_guard<std::mutex> lk(m); quit = true; }
-        cv.notify_all();
-        if(th.joinable()) th.join();
+        std::unique_lock<std::mutex> lk(m);
+        if(owner == getpid()) cv_idle.wait_for(lk, std::chrono::seconds(5), [&] { return q.empty() && !busy; });
     }
 };
 void problem_destroy_later(mrcal_amd_problem* P) { ProblemReaper::get().later(P); }
@@ -1249,6 +1264,12 @@ mrcal_amd_problem_create_sharded(const double*                 intrinsics,
     D.tri_px            = P->d_tri_px;
     D.tri_outlier       = P->d_tri_outlier;
     D.unpacked          = P->d_joint + (size_t)Nboard_local*JOINT_STRIDE;
+    // (round 6) where the triangulated pairs ride in the board kernel's launch (board_tri_kernel) the launch the
+    // benchmark times carries their bytes too: per pair two observation vectors and the record read, x and the
+    // (up to) 12 partials written
+    if(board_launch_takes_triangulated(D))
+        for(const TriPairMeta& m : P->tri_meta_host)
+            P->board_alg_bytes += 2*24 + (int64_t)sizeof(TriPairMeta) + 8 + 8*((m.i_state_extrinsics0 >= 0 ? 6 : 0) + (m.i_state_extrinsics1 >= 0 ? 6 : 0));
 
     // the seed state
     P->b_host.assign(L.Nstate > 0 ? L.Nstate : 1, 0.0);

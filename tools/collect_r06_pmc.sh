@@ -9,7 +9,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for c in $cfgs; do
-    case $c in 2) K="board_splined";; *) K="board_kernel";; esac
+    case $c in 2) K="board_splined";; 5) K="board_tri_kernel";; *) K="board_kernel";; esac
     rm -rf /tmp/pmc_${c}_*
     i=0
     for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
