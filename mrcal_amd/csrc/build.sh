@@ -25,7 +25,7 @@ for a in "$@"; do
 done
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result $DEV"
-SOURCES="kernels.hip project_kernels.hip cholesky_large.hip assembly_splined.hip schur.hip assembly.hip step.hip factorization_solve.hip cholesky_lds.hip uncertainty.hip
+SOURCES="kernels.hip splined_kernels.hip project_kernels.hip cholesky_large.hip assembly_splined.hip schur.hip assembly.hip step.hip factorization_solve.hip cholesky_lds.hip uncertainty.hip
          problem.cpp solver.cpp cabi_layout.cpp factorization.cpp unproject.cpp comm.cpp cameramodel_io.cpp"
 JOBS=${JOBS:-$(nproc)}
 mkdir -p $OBJ

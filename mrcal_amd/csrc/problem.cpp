@@ -17,6 +17,7 @@
 #include "problem_object.hpp"
 #include "host_copy.hpp"
 #include <thread>
+#include <unordered_map>
 #include <mutex>
 #include <condition_variable>
 #include <deque>
@@ -122,20 +123,28 @@ static bool build_gen_plan(mrcal_amd_problem* P)
 
     struct RowInfo { int group, eblk, epos; };
     std::vector<RowInfo> info((size_t)(r1 - r0));
-    std::map<std::vector<int>, int> groups;          // [k | spos.. | scol..] -> group
+    // a row's signature [k | spos.. | scol..] -> its group, the groups numbered as they first appear. (Round 6: the
+    // signature on the stack and a hash in front of the comparison; three vectors and an ordered map of vectors a row
+    // were 10 ms of BASELINE configuration 4's 67 000 rows - as long as its five dog-leg steps and their launches together)
+    std::unordered_map<uint64_t, std::vector<int>> groups;
     std::vector<std::vector<int>> group_sig;
     int kmax = 0;
     for(int r = r0; r < r1; r++)
     {
         const int a = Jp[r - r0] - p0, b = Jp[r - r0 + 1] - p0;
-        std::vector<int> spos, scol;
+        int sig[2*GEN_KMAX + 1], scol[GEN_KMAX];
+        int k = 0;
         int eblk = -1, epos = -1, ecount = 0;
         for(int p = a; p < b; p++)
         {
             const int c = Ji[p];
             if(c < 0 || c >= nd.Nstate) return true;                 // (flagged at run time by the row-by-row path)
             const int se = state_to_SE(nd, c);
-            if(se >= 0) { spos.push_back(p - a); scol.push_back(se); }
+            if(se >= 0)
+            {
+                if(k >= GEN_KMAX) return true;
+                sig[1 + k] = p - a; scol[k] = se; k++;
+            }
             else
             {
                 const int e = -se - 1;
@@ -150,15 +159,17 @@ static bool build_gen_plan(mrcal_amd_problem* P)
             }
         }
         if(eblk >= 0 && ecount != ((eblk < nd.Nfb) ? 6 : 3)) return true;
-        const int k = (int)spos.size();
-        if(k > GEN_KMAX) return true;
         if(k > kmax) kmax = k;
-        std::vector<int> sig; sig.reserve(2*k + 1);
-        sig.push_back(k); sig.insert(sig.end(), spos.begin(), spos.end()); sig.insert(sig.end(), scol.begin(), scol.end());
-        auto it = groups.find(sig);
-        int g;
-        if(it == groups.end()) { g = (int)group_sig.size(); groups.emplace(sig, g); group_sig.push_back(sig); }
-        else g = it->second;
+        sig[0] = k;
+        for(int i = 0; i < k; i++) sig[1 + k + i] = scol[i];
+        const int nsig = 2*k + 1;
+        uint64_t h = 1469598103934665603ull;
+        for(int i = 0; i < nsig; i++) { h ^= (uint64_t)(uint32_t)sig[i]; h *= 1099511628211ull; }
+        std::vector<int>& cand = groups[h];
+        int g = -1;
+        for(int gc : cand)
+            if((int)group_sig[gc].size() == nsig && !memcmp(group_sig[gc].data(), sig, nsig*sizeof(int))) { g = gc; break; }
+        if(g < 0) { g = (int)group_sig.size(); cand.push_back(g); group_sig.emplace_back(sig, sig + nsig); }
         info[r - r0] = RowInfo{ g, eblk, epos };
     }
     const int Ngroups = (int)group_sig.size();
@@ -172,9 +183,14 @@ static bool build_gen_plan(mrcal_amd_problem* P)
     }
 
     // rows by (group, row); chunks
+    // (by counting: the groups are few)
     std::vector<int> rows((size_t)(r1 - r0));
-    for(int i = 0; i < r1 - r0; i++) rows[i] = r0 + i;
-    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return info[a - r0].group < info[b - r0].group; });
+    {
+        std::vector<int> at(Ngroups + 1, 0);
+        for(const RowInfo& ri : info) at[ri.group + 1]++;
+        for(int g = 0; g < Ngroups; g++) at[g + 1] += at[g];
+        for(int i = 0; i < r1 - r0; i++) rows[at[info[i].group]++] = r0 + i;
+    }
     std::vector<int> chunk_begin, chunk_group, group_chunk_begin(Ngroups + 1, 0);
     for(size_t i = 0; i < rows.size();)
     {
@@ -378,7 +394,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     // [S | r | g_S | |x|^2 | status]: comm1 of the sharded step (step2_comm1_doubles())
     ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2 + 64);
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
-    ok = ok && dev_alloc(&P->F.status, 1);
+    ok = ok && dev_alloc(&P->F.status, 2);      // [0] a block that did not factor; [1] the word of step2_chol_backsub_kernel
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
     ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.Nstate + 64);
     ok = ok && dev_alloc(&P->d_counts, 4);

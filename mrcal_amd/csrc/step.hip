@@ -3,118 +3,12 @@
 #include "solver_device.hpp"
 #include "chol_diag16.hpp"
 #include "solver_kernel_decls.hpp"
+#include "step_device.hpp"
 
 namespace mrcal_amd {
 
 
-////////////////////////////////////////////////////////////////////////////////
-// v^T N v = |J v|^2 from the blocks;  dot products
-////////////////////////////////////////////////////////////////////////////////
-// out[0] += v^T N v, and if nout == 3: out[1] += g . v,  out[2] += v . v   with N = [A B; Bt D]
-// of the operating point: v^T N v = v_S^T A v_S + 2 v_E^T (Bt v_S) + v_E^T D v_E.
-// One wave per group of rows of [A ; Bt]; one atomic triple per workgroup
-// (QF_ROWS_PER_WAVE: solver_kernels.hpp. With 8 rows a wave, a 1206-variable camera block had 188 workgroups
-//  walking 46 MB of Bt: 1.4 TB/s)
-// this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
-__device__ __forceinline__
-double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false,
-                     const unsigned* __restrict__ occ = NULL /* eblock_factor_kernel's bit per (block, 16-column tile) of Wt - and of Bt: the same columns */,
-                     int nocc = 0)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int Nrows = nd.Nc + nd.NE;
-    const int row0  = (block*4 + wave)*QF_ROWS_PER_WAVE;
-
-    // the 8 rows of this wave against v_S, all loads in flight together
-    const double* __restrict__ M[QF_ROWS_PER_WAVE];
-#pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
-    {
-        int row = row0 + rr;
-        if(row >= Nrows) row = Nrows - 1;   // duplicate work, discarded below
-        M[rr] = (row < nd.Nc) ? O.A + (size_t)row*nd.Nc : O.Bt + (size_t)(row - nd.Nc)*nd.Nc;
-    }
-    double acc[QF_ROWS_PER_WAVE];
-#pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++) acc[rr] = 0.0;
-    // (of A only the lower triangle: the splined assembly writes no other. An entry below the diagonal counts twice)
-    int rowc[QF_ROWS_PER_WAVE];
-    // (the splined models: a row of Bt holds something under the frame's board only - a sixth of its 76 tiles, 46 MB of
-    //  zeros a step otherwise: a lane whose tile is empty asks for nothing)
-    const unsigned* __restrict__ ob[QF_ROWS_PER_WAVE];
-#pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
-    {
-        rowc[rr] = min(row0 + rr, Nrows - 1);
-        ob[rr] = NULL;
-        if(occ != NULL && rowc[rr] >= nd.Nc)
-        {
-            int blk, a, de, e0;
-            E_to_block(nd, rowc[rr] - nd.Nc, &blk, &a, &de, &e0);
-            ob[rr] = occ + (size_t)blk*nocc;
-        }
-    }
-#pragma unroll 4
-    for(int c = lane; c < nd.Nc; c += 64)
-    {
-        const double vs = v[S_to_state(nd, c)];
-        const int tile = c >> 4;
-#pragma unroll
-        for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
-        {
-            const double wgt = (rowc[rr] >= nd.Nc) ? 1.0 : (c < rowc[rr]) ? 2.0 : (c == rowc[rr]) ? 1.0 : 0.0;
-            // (a branch around the load: the lanes without one reading the row's first entry instead - no branch, the loads
-            //  of four steps in flight - measured slower, 24 us against 20)
-            const bool there = (ob[rr] == NULL) || ((ob[rr][tile >> 5] >> (tile & 31)) & 1u);
-            if(wgt != 0.0 && there) acc[rr] += wgt*(M[rr][c]*vs);
-        }
-    }
-#pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
-        for(int off=32; off>0; off>>=1) acc[rr] += __shfl_down(acc[rr], off);
-    // lane rr finishes row rr
-    double mine = 0.0;
-#pragma unroll
-    for(int rr = 0; rr < QF_ROWS_PER_WAVE; rr++)
-    {
-        const double a0 = __shfl(acc[rr], 0);
-        if(lane == rr) mine = a0;
-    }
-    double t_vNv = 0.0, t_gv = 0.0, t_vv = 0.0;
-    const int row = row0 + lane;
-    if(lane < QF_ROWS_PER_WAVE && row < Nrows)
-    {
-        int    is;      // state index of this row's variable
-        double wgt;
-        if(row < nd.Nc) { is = S_to_state(nd, row); wgt = 1.0; }
-        else            { is = E_to_state(nd, row - nd.Nc);                              wgt = 2.0; }
-        const double vr = v[is];
-        double total = wgt*vr*mine;
-        if(row >= nd.Nc)
-        {
-            int blk, a, de, e0;
-            E_to_block(nd, row - nd.Nc, &blk, &a, &de, &e0);
-            double s = 0.0;
-            for(int c=0;c<de;c++) s += O.D[(size_t)blk*36 + a*6 + c]*v[nd.E_state0 + e0 + c];
-            total += vr*s;
-        }
-        t_vNv = total;
-        t_gv  = O.g[is]*vr;
-        t_vv  = (vv_E_only && row < nd.Nc) ? 0.0 : vr*vr;
-    }
-    for(int off=4; off>0; off>>=1)
-    {
-        t_vNv += __shfl_down(t_vNv, off);
-        t_gv  += __shfl_down(t_gv,  off);
-        t_vv  += __shfl_down(t_vv,  off);
-    }
-    __shared__ double part[4][3];
-    if(lane == 0) { part[wave][0] = t_vNv; part[wave][1] = t_gv; part[wave][2] = t_vv; }
-    __syncthreads();
-    if(threadIdx.x < 3)
-        return (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    return 0.0;
-}
+// (quadform_body, backsub_eblock: step_device.hpp - cholesky_lds.hip runs them beside the factorization)
 __global__ __launch_bounds__(256)
 void quadform_kernel(NormalDims nd, OpRef R, const double* __restrict__ v_in, int v_is_g,
                      double* __restrict__ out_in, int out_in_scalars_at, int nout)
@@ -307,65 +201,7 @@ void step2_backsub_quadform_kernel(NormalDims nd, BlockRanges br, const OpDev* _
             step[S_to_state(nd, i)] = ds[i];
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ibk = 4*b + wave;
-    if(ibk >= br.count()) return;
-    const int blk = br.block(ibk);
-    const int de  = (blk < nd.Nfb) ? 6 : 3;
-    const int e0  = (blk < nd.Nfb) ? 6*blk : 6*nd.Nfb + 3*(blk - nd.Nfb);
-    // all the loads first: L, y, g_e and this lane's columns of Wt_e against d_s
-    // (unconditional, clamped: three loads under conditions were three branches with a wait each)
-    const double Lv = LD[(size_t)blk*36 + min(lane, 35)];
-    const double yv = y[e0 + min(lane, de - 1)];
-    const double gv = O.g[nd.E_state0 + e0 + min(lane, de - 1)];
-    double part[6] = {0,0,0,0,0,0};
-    // (four column groups asked for together: with a 1206-variable camera block the loop is 19 round trips otherwise)
-    // (the tiles of Wt that hold nothing - five in six under the splined models - are not asked for)
-    const unsigned* __restrict__ ob = (occ != NULL) ? occ + (size_t)blk*nocc : (const unsigned*)NULL;
-#pragma unroll 4
-    for(int c = lane; c < nd.Nc; c += 64)
-    {
-        const double d = ds[c];
-        const int tile = c >> 4;
-        if(ob != NULL && !((ob[tile >> 5] >> (tile & 31)) & 1u)) continue;
-#pragma unroll
-        for(int i=0;i<6;i++) if(i < de) part[i] += Wt[(size_t)(e0+i)*nd.Nc + c]*d;
-    }
-#pragma unroll
-    for(int i=0;i<6;i++)
-        for(int off=32; off>0; off>>=1) part[i] += __shfl_down(part[i], off);
-    // lane 0 holds the sums; L, y, g come from the lanes that loaded them (no LDS, no barrier)
-    double v[6], Lr[6][6], ge[6];
-#pragma unroll
-    for(int i=0;i<6;i++)
-    {
-        v[i]  = __shfl(yv, i) + __shfl(part[i], 0);
-        ge[i] = __shfl(gv, i);
-#pragma unroll
-        for(int k=0;k<6;k++) Lr[i][k] = __shfl(Lv, i*6 + k);
-    }
-    if(lane == 0)
-    {
-        double d2 = 0.0, dg = 0.0;
-#pragma unroll
-        for(int i=5;i>=0;i--)
-        {
-            if(i >= de) continue;
-            double sacc = v[i];
-#pragma unroll
-            for(int k=i+1;k<6;k++) if(k < de) sacc -= Lr[k][i]*v[k];
-            v[i] = sacc/Lr[i][i];
-        }
-#pragma unroll
-        for(int i=0;i<6;i++)
-            if(i < de)
-            {
-                const double d = -v[i];
-                step[nd.E_state0 + e0 + i] = d;
-                d2 += d*d; dg += d*ge[i];
-            }
-        dots_part[2*ibk] = d2; dots_part[2*ibk + 1] = dg;
-    }
+    backsub_eblock(nd, br, O, Wt, LD, y, ds, dots_part, 4*b + (int)(threadIdx.x >> 6), occ, nocc, [] { return true; });
 }
 
 // sharded: this rank's summands of comm2, each summed in a fixed order. One workgroup
@@ -647,6 +483,9 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
         const bool finish_done = step2_finish_rides(a);
         if(chol_fits_lds(n))
         {
+            // (round 6) a single GPU: the back-substitution and the quadratic form in the factorization's launch
+            if(finish_done && !test_hooks().separate_backsub)
+                return launch_cholesky_lds_backsub(n, nd, br, F, sd, a.plan->dots_part, a.plan->qf_part, a.snap, stream);
             if(finish_done) launch_cholesky_lds(2, n, (const int*)&fl->skip_chol, 0, F.S, F.r, F.status, sd, stream);
             else            launch_cholesky_lds(1, n, (const int*)NULL, 0, F.S, F.r, F.status, sd, stream);
         }

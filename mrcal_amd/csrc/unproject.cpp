@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <thread>
+#include <vector>
+#include <algorithm>
 #include "layout.hpp"
 #include "kernels.hpp"
 #include "host_state.hpp"
@@ -118,7 +121,11 @@ bool mrcal_unproject(mrcal_point3_t* out, const mrcal_point2_t* q, int N,
         return false;
     }
 
-    for(int ipt=0; ipt<N; ipt++)
+    // (round 6) the points are independent: from 2048 of them on (the 57 000 observations of BASELINE configuration 4 are
+    // 10 ms of one core - as long as that problem's whole solve on the device) a range each for up to 16 threads. The same
+    // code per point: the same bits
+    auto points = [&](int ipt0, int ipt1) {
+    for(int ipt=ipt0; ipt<ipt1; ipt++)
     {
         // seed: the pinhole unprojection, in stereographic pixel coordinates
         double u[2];
@@ -161,6 +168,25 @@ bool mrcal_unproject(mrcal_point3_t* out, const mrcal_point2_t* q, int N,
         {
             out[ipt].x *= -1.0; out[ipt].y *= -1.0; out[ipt].z *= -1.0;
         }
+    }
+    };
+    int nthreads = 1;
+    if(N >= 2048)
+    {
+        nthreads = (int)std::thread::hardware_concurrency();
+        if(nthreads > 16)     nthreads = 16;
+        if(nthreads > N/1024) nthreads = N/1024;
+        if(nthreads < 1)      nthreads = 1;
+    }
+    if(nthreads == 1) points(0, N);
+    else
+    {
+        std::vector<std::thread> th;
+        const int per = (N + nthreads - 1)/nthreads;
+        for(int k = 1; k < nthreads; k++)
+            th.emplace_back(points, std::min(N, k*per), std::min(N, (k + 1)*per));
+        points(0, std::min(N, per));
+        for(std::thread& x : th) x.join();
     }
     return true;
 }
