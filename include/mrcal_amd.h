@@ -667,8 +667,7 @@ int   mrcal_amd_set_elimination(int policy);
    the rest goes through lchol_tail_kernel; "nd_rounds" = k: launches for k rounds of the nested dissection whatever
    the plan needs; "lchol_sweep" = 1: the big Cholesky's solve by the backward sweep (the stable fallback the solver
    switches to by itself when a factor's diagonal spans more than 1e10); "lchol_fallback_log10" = k: that threshold as
-   10^k; "separate_backsub" = 1: the back-substitution and the quadratic form as a launch of their own behind the
-   one-workgroup factorization (the sharded solve's arrangement) instead of workgroups of its launch. 0: not forced. Returns the previous value,
+   10^k. 0: not forced. Returns the previous value,
    -1 for an unknown name. (Round 6: these were environment variables; the library reads six of those now -
    MRCAL_AMD_GRAPH, _ELIMINATE, _RCCL, _LIB, _NO_ND, _NO_SPL_COMPACT - and MRCAL_AMD_DEBUG_SOLVER, which only prints) */
 int   mrcal_amd_set_test_hook(const char* name, int value);

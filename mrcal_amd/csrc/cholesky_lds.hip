@@ -3,7 +3,6 @@
 #include "solver_device.hpp"
 #include "chol_diag16.hpp"
 #include "solver_kernel_decls.hpp"
-#include "step_device.hpp"
 
 namespace mrcal_amd {
 
@@ -31,7 +30,8 @@ namespace mrcal_amd {
 // FINISH: 0 a factorization and solve and nothing else | 1 the end of the trial step in front, the verdict behind (sharded:
 // the end-of-trial logic needs the tail summed over the ranks, which is complete only now) | 2 the verdict behind alone:
 // the end-of-trial logic has run in the reduction's launch (single GPU, round 5: step2_reduce_kernel) and `skip` is its word
-// (the kernel's body: schur_cholesky_solve_kernel, and step2_chol_backsub_kernel's first workgroup)
+// (the kernel's body. Round 6 ran it as the first workgroup of a launch that also held the back-substitution's workgroups,
+//  waiting for a word it left: measured 5 us SLOWER than the two launches - LEDGER R6.16 - and taken out again)
 template<int FINISH>
 __device__ __forceinline__
 void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_factor,
@@ -312,77 +312,6 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     schur_cholesky_solve_body<FINISH>(n, skip, keep_factor, S, r, status, sd);
 }
 
-// (round 6) The factorization, the back-substitution and the quadratic form in ONE launch (a single GPU, camera blocks
-// that fit the LDS: the end of the trial step has run in the reduction's launch). The factorization is one workgroup
-// for 20-46 us and the launch behind it - a wave per eliminated block, d_e = -L^-T (y_e + Wt_e d_s) - needed d_s and
-// nothing else of it: 10.6 us at the metric's size, most of them the launch's own start and its trips to memory for
-// Wt_e, L, y, g. Here its workgroups start WITH the factorization's, ask for everything but d_s, and wait for the
-// word the factorization's workgroup leaves when it is through (device scope: written behind a fence by that
-// workgroup, read with acquire by every waiting wave; the reduction's launch cleared it). The quadratic form of a new
-// current point never needed the factorization: it runs beside it.
-//   workgroup 0                 the factorization (FINISH 2), the snapshot of the control block, the word
-//   [1, 1 + nbs)                back-substitution, 16 eliminated blocks a workgroup (a wave each)
-//   1 + nbs                     d_s into the state-ordered step
-//   the rest                    the quadratic form: four of step2_backsub_quadform_kernel's workgroups each
-// Workgroups are dispatched in order: the first is resident before any that waits for it. Every workgroup reserves the
-// factorization's LDS (the launch's one size): with 101 KB at 140 variables a workgroup a CU - the metric's problem has
-// 257 of them for 256 CUs, the last a quadratic-form one that waits for nobody
-__global__ __launch_bounds__(1024)
-void step2_chol_backsub_kernel(int n, int* __restrict__ status /* [1]: the word */, Step2Dev sd,
-                               NormalDims nd, BlockRanges br,
-                               const double* __restrict__ Wt, const double* __restrict__ LD,
-                               const double* __restrict__ y, double* __restrict__ S, double* __restrict__ r,
-                               double* __restrict__ dots_part, double* __restrict__ qf_part, int nbs,
-                               SolverCtl* __restrict__ snap)
-{
-    const int b = blockIdx.x;
-    int* __restrict__ word = status + 1;
-    if(b == 0)
-    {
-        schur_cholesky_solve_body<2>(n, (const int*)&sd.fl->skip_chol, 0, S, r, status, sd);
-        // (whichever way the body was left: every thread's writes out, then the control block - final for this step -
-        //  to the host's pinned copy, then the word)
-        __threadfence();
-        __syncthreads();
-        if(snap != NULL && threadIdx.x < (int)(sizeof(SolverCtl)/sizeof(int)))
-            ((int*)snap)[threadIdx.x] = ((const int*)sd.ctl)[threadIdx.x];
-        if(threadIdx.x == 0) __hip_atomic_store(word, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const SolverCtl* __restrict__ ctl = sd.ctl;
-    const OpDev& O = sd.ops[ctl->ib];           // (the reduction's launch decided which point is the current one)
-    // (ONE thread of a workgroup asks, twice a microsecond: the first version had a lane of every wave asking every 256
-    //  clocks - a thousand waves on one word of memory: the factorization's own store of it waited in their line, and
-    //  the launch was 20 us longer than the factorization. The waves that have left - past the last block - do not
-    //  count at the barrier)
-    auto wait_for_factorization = [&]
-    {
-        if(threadIdx.x == 0)
-            while(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(16);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    };
-    if(b > nbs + 1)
-    {
-        if(!ctl->derive) return;
-        const int qb = 4*(b - nbs - 2) + (int)(threadIdx.x >> 8);
-        // (a quarter past the last row: its waves clamp their rows and add nothing - but every thread is at the barrier)
-        const double mine = quadform_body(nd, O, O.g, qb, true, (const unsigned*)NULL, 0);
-        if((threadIdx.x & 255) < 3 && qb < (nd.Nc + nd.NE + 4*QF_ROWS_PER_WAVE - 1)/(4*QF_ROWS_PER_WAVE))
-            qf_part[4*qb + (threadIdx.x & 255)] = mine;
-        return;
-    }
-    if(b == nbs + 1)
-    {
-        wait_for_factorization();
-        if(sd.fl->skip_backsub) return;
-        for(int i = threadIdx.x; i < nd.Nc; i += blockDim.x) O.step_gn[S_to_state(nd, i)] = r[i];
-        return;
-    }
-    backsub_eblock(nd, br, O, Wt, LD, y, r, dots_part, 16*(b - 1) + (int)(threadIdx.x >> 6), (const unsigned*)NULL, 0,
-                   [&] { wait_for_factorization(); return sd.fl->skip_backsub == 0; });
-}
-
 // The same in place in global memory, row-major, one workgroup: the plain
 // right-looking blocked algorithm. Only a fallback for callers without the
 // panel workspace; camera blocks that do not fit the LDS normally go through
@@ -468,15 +397,6 @@ hipError_t launch_cholesky_lds(int finish, int n, const int* skip, int keep_fact
     case 2:  hipLaunchKernelGGL(schur_cholesky_solve_kernel<2>, g, b, lds, stream, n, skip, keep_factor, S, r, status, sd); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
-}
-hipError_t launch_cholesky_lds_backsub(int n, const NormalDims& nd, const BlockRanges& br, const FactorBuffers& F, const Step2Dev& sd,
-                                       double* dots_part, double* qf_part, SolverCtl* snap, hipStream_t stream)
-{
-    const int nbs = (br.count() + 15)/16;
-    const int nqf = ((nd.Nc + nd.NE + 4*QF_ROWS_PER_WAVE - 1)/(4*QF_ROWS_PER_WAVE) + 3)/4;
-    hipLaunchKernelGGL(step2_chol_backsub_kernel, dim3(1 + nbs + 1 + nqf), dim3(1024), chol_lds_bytes(n), stream,
-                       n, F.status, sd, nd, br, F.Wt, F.LD, F.y, F.S, F.r, dots_part, qf_part, nbs, snap);
     return hipGetLastError();
 }
 hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, int* status, hipStream_t stream)

@@ -394,7 +394,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     // [S | r | g_S | |x|^2 | status]: comm1 of the sharded step (step2_comm1_doubles())
     ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2 + 64);
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
-    ok = ok && dev_alloc(&P->F.status, 2);      // [0] a block that did not factor; [1] the word of step2_chol_backsub_kernel
+    ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);
     ok = ok && dev_alloc(&P->d_comm,   (size_t)nd.Nstate + 64);
     ok = ok && dev_alloc(&P->d_counts, 4);

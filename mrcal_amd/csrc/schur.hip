@@ -773,8 +773,6 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
                          double* __restrict__ ndMA, double* __restrict__ ndMB, int* __restrict__ ndp_cur, int nfill /* workgroups behind the last */,
                          int ride_finish, Step2Dev sd)
 {
-    // (round 6) the word step2_chol_backsub_kernel's waiting workgroups go by: cleared a launch ahead of it
-    if((int)blockIdx.x == nred && threadIdx.x == 0) ((int*)status)[1] = 0;
     if(fl->skip_elim)
     {
         // (nothing is reduced; the end of the trial step still has to be decided where it rides here)

@@ -673,8 +673,7 @@ int mrcal_amd_set_test_hook(const char* name, int value)
     int* p = !strcmp(name, "lchol_likely_panels") ? &h.lchol_likely_panels :
              !strcmp(name, "nd_rounds")           ? &h.nd_rounds :
              !strcmp(name, "lchol_sweep")         ? &h.lchol_sweep :
-             !strcmp(name, "lchol_fallback_log10") ? &h.lchol_fallback_log10 :
-             !strcmp(name, "separate_backsub")     ? &h.separate_backsub : (int*)NULL;
+             !strcmp(name, "lchol_fallback_log10") ? &h.lchol_fallback_log10 : (int*)NULL;
     if(p == NULL) return -1;
     const int old = *p; *p = value;
     return old;

@@ -114,10 +114,5 @@ hipError_t launch_nd_plans_off(const OpDev* ops, int Nc, hipStream_t stream);
 hipError_t launch_cholesky_lds(int finish, int n, const int* skip, int keep_factor, double* S, double* r, int* status,
                                const Step2Dev& sd, hipStream_t stream);
 hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, int* status, hipStream_t stream);
-// (round 6) the same factorization with the back-substitution and the quadratic form in its launch (cholesky_lds.hip
-// step2_chol_backsub_kernel): a single GPU, the end of the trial decided in the reduction's launch, which also cleared
-// F.status[1], the word the waiting workgroups go by
-hipError_t launch_cholesky_lds_backsub(int n, const NormalDims& nd, const BlockRanges& br, const FactorBuffers& F, const Step2Dev& sd,
-                                       double* dots_part, double* qf_part, SolverCtl* snap, hipStream_t stream);
 
 } // namespace mrcal_amd

@@ -144,8 +144,6 @@ struct TestHooks
     int nd_rounds;             // rounds of the dissection provided for, whatever the plan needs
     int lchol_sweep;           // the large Cholesky's solve by the backward sweep (FactorBuffers::use_sweep) from the start
     int lchol_fallback_log10;  // the automatic fallback's threshold on min / max of the factor's diagonal as a power of ten (default -10)
-    int separate_backsub;      // the back-substitution and the quadratic form as a launch of their own behind the one-workgroup
-                               // factorization (rounds 1-5; the sharded solve's way still) instead of workgroups of its launch
 };
 TestHooks& test_hooks();
 

@@ -483,9 +483,6 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
         const bool finish_done = step2_finish_rides(a);
         if(chol_fits_lds(n))
         {
-            // (round 6) a single GPU: the back-substitution and the quadratic form in the factorization's launch
-            if(finish_done && !test_hooks().separate_backsub)
-                return launch_cholesky_lds_backsub(n, nd, br, F, sd, a.plan->dots_part, a.plan->qf_part, a.snap, stream);
             if(finish_done) launch_cholesky_lds(2, n, (const int*)&fl->skip_chol, 0, F.S, F.r, F.status, sd, stream);
             else            launch_cholesky_lds(1, n, (const int*)NULL, 0, F.S, F.r, F.status, sd, stream);
         }

@@ -1,5 +1,5 @@
-// Device functions of the trial step's last launches that more than one unit runs (step.hip: the kernels of their own;
-// cholesky_lds.hip: step2_chol_backsub_kernel, where they share a launch with the factorization)
+// Device functions of the trial step's last launch (step.hip step2_backsub_quadform_kernel). In a header of their own
+// since round 6, when cholesky_lds.hip ran them as workgroups of the factorization's launch (LEDGER R6.16: slower; gone)
 #pragma once
 #include "solver_device.hpp"
 
@@ -14,8 +14,8 @@ namespace mrcal_amd {
 // (QF_ROWS_PER_WAVE: solver_kernels.hpp. With 8 rows a wave, a 1206-variable camera block had 188 workgroups
 //  walking 46 MB of Bt: 1.4 TB/s)
 // this workgroup's (256 threads) part of (v^T N v, g.v, v.v): returned in threads 0, 1, 2
-// (round 6: or this QUARTER's of a workgroup of 1024, `block` counting the quarters - step2_chol_backsub_kernel -: returned in
-//  the quarter's threads 0, 1, 2. Every thread of the workgroup must call)
+// (or this QUARTER's of a workgroup of 1024, `block` counting the quarters: returned in the quarter's threads 0, 1, 2.
+//  Every thread of the workgroup must call)
 __device__ __forceinline__
 double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restrict__ v, int block, bool vv_E_only = false,
                      const unsigned* __restrict__ occ = NULL /* eblock_factor_kernel's bit per (block, 16-column tile) of Wt - and of Bt: the same columns */,
@@ -119,8 +119,8 @@ double quadform_body(const NormalDims& nd, const OpDev& O, const double* __restr
 }
 
 // The back-substitution of ONE eliminated block by one wave: d_e = -L^-T (y_e + Wt_e d_s); (|d_e|^2, d_e . g_e) into
-// dots_part[ibk]. ready(): called once everything that does not depend on d_s has been asked for (round 6: in
-// step2_chol_backsub_kernel it waits there for the factorization's workgroup); false: there is no d_s, nothing is done
+// dots_part[ibk]. ready(): called once everything that does not depend on d_s has been asked for (a place to wait for
+// d_s's maker, for a caller that shares a launch with it); false: there is no d_s, nothing is done
 template<class Ready>
 __device__ __forceinline__
 void backsub_eblock(const NormalDims& nd, const BlockRanges& br, const OpDev& O,
@@ -143,8 +143,7 @@ void backsub_eblock(const NormalDims& nd, const BlockRanges& br, const OpDev& O,
     // (the tiles of Wt that hold nothing - five in six under the splined models - are not asked for)
     const unsigned* __restrict__ ob = (occ != NULL) ? occ + (size_t)blk*nocc : (const unsigned*)NULL;
     // camera blocks to 256 variables (every one whose factorization is the one-workgroup kernel): this lane's (up to)
-    // four columns of Wt_e in registers BEFORE d_s is needed - beside the factorization they are there when it ends.
-    // The same products in the same order as the loop below
+    // four columns of Wt_e in registers before d_s is asked for. The same products in the same order as the loop below
     constexpr int MAXC = 4;
     const bool pre = (nd.Nc <= 64*MAXC) && ob == NULL;
     double wt[MAXC][6];

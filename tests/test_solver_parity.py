@@ -762,46 +762,3 @@ with Problem(**copy_inputs(oi)) as p:
     assert (a["N"], a["Nout"], a["rms"]) == (b["N"], b["Nout"], b["rms"]) and a["b"] == b["b"]
     assert a["Nout"] == c["Nout"] and abs(a["rms"] - c["rms"]) < 1e-8*c["rms"]
     assert np.abs(np.array(a["b"]) - np.array(c["b"])).max() < 1e-4
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind", ("boards", "boards_graph", "sfm_with_boards", "points_only"))
-def test_backsubstitution_in_the_factorizations_launch_gives_the_same_bits(amd, kind):
-    """Round 6 (cholesky_lds.hip step2_chol_backsub_kernel): on a single GPU the back-substitution's and the quadratic
-    form's workgroups share the one-workgroup factorization's launch - they ask for everything but d_s, wait for the
-    word the factorization's workgroup leaves, and finish. The same device functions in the same order as the launch of
-    their own behind the factorization (the test hook separate_backsub: rounds 1-5's arrangement, the sharded solve's
-    still): the same bits in the state, the residuals' norm and every count - with the step queued launch by launch
-    and replayed as a graph (MRCAL_AMD_GRAPH=1), with boards, with triangulated pairs beside boards, with discrete points only (whose
-    eliminated blocks are the points')"""
-    import os, subprocess, sys, json
-    code = r'''
-import sys, os, json, numpy as np
-sys.path.insert(0, %r)
-import mrcal_amd
-for _kv in os.environ.get("TEST_HOOKS", "").split(","):          # (the test's own variable: hooks of the library's test API)
-    if _kv: mrcal_amd.set_test_hook(_kv.split("=")[0], int(_kv.split("=")[1]))
-from mrcal_amd.synthetic import make_calibration_problem, make_sfm_problem, copy_inputs
-from mrcal_amd.resident import Problem
-kind = %r
-if kind.startswith("boards"):
-    oi, _ = make_calibration_problem(mrcal_amd._api, Ncameras=3, Nframes=60, object_width_n=10, object_height_n=10, lensmodel="LENSMODEL_OPENCV8", seed=11)
-elif kind == "sfm_with_boards":
-    oi = make_sfm_problem("LENSMODEL_OPENCV4", Ncam=4, Npoints=2500, seed=6, noise=0.3, Nboard_frames=50)[0]
-else:
-    sys.path.insert(0, os.path.join(%r, "tests"))
-    from test_callback_parity import points_only_problem
-    oi = points_only_problem(mrcal_amd._api, Np=300)
-with Problem(**copy_inputs(oi)) as p:
-    s = p.solve()
-    print("RESULT " + json.dumps(dict(N=s["Niterations"], Nev=s["Nevaluations"], Nout=s["Noutliers_board"], rms=s["rms_reproj_error__pixels"], b=p.b_packed().tolist())))
-''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), kind, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    res = {}
-    for tag, env in (("one_launch", {}), ("separate", {"TEST_HOOKS": "separate_backsub=1"})):
-        if kind == "boards_graph": env = dict(env, MRCAL_AMD_GRAPH="1")
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
-    a, b = res["one_launch"], res["separate"]
-    assert a["N"] > 3
-    assert (a["N"], a["Nev"], a["Nout"], a["rms"]) == (b["N"], b["Nev"], b["Nout"], b["rms"]) and a["b"] == b["b"]
