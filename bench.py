@@ -201,8 +201,10 @@ def other_configurations(only=None):
                         kms = ktot/nl
                         ach = alg/1e9/(kms*1e-3)
                         entry["roofline"] = dict(bound = "hbm", kernel = "the board Jacobian build of this configuration "
-                                                 "(board_kernel / board_splined_kernel: residuals x, CSR Jacobian values" +
-                                                 ("" if "SPLINED" in workload else ", per-observation Gram") + ")",
+                                                 "(board_kernel / board_splined_rows_kernel: residuals x, CSR Jacobian values" +
+                                                 ("" if "SPLINED" in workload else ", per-observation Gram") + ")" +
+                                                 (" with the triangulated pairs in the same launch (board_tri_kernel: their bytes are in algorithmic_bytes_per_launch)"
+                                                  if key == "5" else ""),
                                                  achieved = ach, peak = HBM_PEAK_GBS, unit = "GB/s", frac = ach/HBM_PEAK_GBS,
                                                  algorithmic_bytes_per_launch = alg, kernel_ms_avg = kms, kernel_ms_min = kmin,
                                                  kernel_ms_max = kmax, launches_timed = nl, timed_every = 1,

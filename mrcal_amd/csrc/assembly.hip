@@ -750,6 +750,17 @@ static size_t gen_lds_bytes(const GenPlan& G, const NormalDims& nd)
     const size_t a = (size_t)GEN_CHUNK*(G.kmax + 1), b = (G.Neblocks > 0) ? (size_t)6*nd.Nc + 42 : 0;
     return (a > b ? a : b)*sizeof(double);
 }
+// the planned rows as workgroups of assemble_factor_kernel's launch: how many, and the launch's LDS with them
+int gen_ride_blocks(const AssemblyPlan& plan)
+{
+    const GenPlan& G = plan.gen;
+    return (G.Nrows > 0 && G.Nchunks + G.Neblocks > 0) ? G.Nchunks + G.Neblocks : 0;
+}
+size_t assemble_lds_bytes_with_gen(const NormalDims& nd, const AssemblyPlan& plan)
+{
+    const size_t a = assemble_lds_bytes(nd), b = gen_ride_blocks(plan) ? gen_lds_bytes(plan.gen, nd) : 0;
+    return a > b ? a : b;
+}
 // workgroups [0, Nchunks): chunks; then the eliminated blocks
 __global__ __launch_bounds__(256)
 void gen_rows_kernel(NormalDims nd, OpRef R, GenPlan G, const int32_t* __restrict__ Jp)
@@ -781,10 +792,10 @@ void rows_single_kernel(NormalDims nd, OpRef R, int row0, int row1, const int32_
     if(threadIdx.x == 0) O.scalars[SC_NORM2_X] += (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-// The Gram assembly (+ elimination of the frame blocks) and the generic rows in
-// ONE launch (all three kinds of work are independent): workgroups
+// The Gram assembly (+ elimination of the frame blocks), the generic rows and the planned rows in
+// ONE launch (all four kinds of work are independent): workgroups
 // [0, nframe_blocks) take a frame each, the next Nchunks*slices 256 positions of a pair chunk each, the
-// rest 256 generic rows each.
+// next 256 generic rows each, the last ngen a chunk of planned rows or an eliminated block of theirs each.
 //   mode (device flag, or mode_host): 0 nothing; 1 the point *sel_eval was just
 //   evaluated; 2 re-eliminate the point *sel_cur from its stored blocks
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5)))
@@ -795,7 +806,7 @@ void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRanges br, cons
                             int do_factor, double lambda_host,
                             AssemblyPlan plan, const double* __restrict__ gram, FactorBuffers F,
                             int nframe_blocks, int row0, int row1,
-                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji)
+                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int ngen)
 {
     // everything the workgroup needs to know before it can ask for data, asked for at once: one trip to memory.
     // (The chunk workgroups last: their loads then fall into the frame workgroups' arithmetic. First: 17.4 us
@@ -820,6 +831,15 @@ void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRanges br, cons
     {
         const int cb = b - nframe_blocks;
         reduce_pair_chunk(P, plan, gram, cb / nslices, cb - (cb / nslices)*nslices);
+    }
+    else if(b >= (int)gridDim.x - ngen)
+    {
+        // (round 6) the planned rows - discrete points, triangulated pairs - as the launch's last workgroups: they were
+        // gen_rows_kernel, a launch of its own behind this one that needed nothing of it (11.5 + 9.5 us at BASELINE
+        // configuration 5). The same functions on the same point (skip_asm is elim_mode != 1)
+        const int gb = b - ((int)gridDim.x - ngen);
+        if(gb < plan.gen.Nchunks) gen_chunk(plan.gen, O, Jp, gb, lds_f);
+        else                      gen_eblock(plan.gen, nd, O, Jp, gb - plan.gen.Nchunks, lds_f);
     }
     else
     {
@@ -910,10 +930,11 @@ hipError_t launch_assemble(const DeviceProblem& P, const NormalDims& nd, const B
     {
         const int nframe_blocks = br.frame_hi - br.frame_lo;        // (the 6x6 eliminated blocks: frames, or cameras)
         FactorBuffers none; memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, plan)), dim3(256),
-                           assemble_lds_bytes(nd), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
-                           (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, assemble_row0(P, plan), P.Nmeas, B.Jp, B.Ji);
-        hipError_t e = launch_gen_rows(nd, plan, B.R, B.Jp, stream);
+        const int ngen = gen_ride_blocks(plan);
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframe_blocks + plan.Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, plan) + ngen), dim3(256),
+                           assemble_lds_bytes_with_gen(nd, plan), stream, P, nd, br, B.R.ops, B.R.sel, B.R.sel, (const SolverCtl*)NULL, B.R.skip,
+                           (const int*)NULL, 1, 0, 0.0, plan, B.gram, none, nframe_blocks, assemble_row0(P, plan), P.Nmeas, B.Jp, B.Ji, ngen);
+        hipError_t e = hipGetLastError();
         if(e != hipSuccess) return e;
         if(plan.Ndest > 0)
             hipLaunchKernelGGL(assemble_finalize_kernel, dim3((plan.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,

@@ -24,7 +24,7 @@ __global__ void assemble_factor_kernel(DeviceProblem P, NormalDims nd, BlockRang
                             int do_factor, double lambda_host,
                             AssemblyPlan plan, const double* __restrict__ gram, FactorBuffers F,
                             int nframe_blocks, int row0, int row1,
-                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji);
+                            const int32_t* __restrict__ Jp, const int32_t* __restrict__ Ji, int ngen /* the launch's last workgroups: the planned rows */);
 __global__ void eblock_factor_kernel(NormalDims nd, BlockRanges br, int first, OpRef R, double lambda_host, const SolverCtl* ctl,
                           double* __restrict__ Wt, double* __restrict__ LD, double* __restrict__ y,
                           int* __restrict__ status, unsigned* __restrict__ occ, int nocc, double* __restrict__ Wtile);
@@ -105,6 +105,9 @@ inline int assemble_row_blocks(const DeviceProblem& P, const AssemblyPlan& plan)
 #endif
 #define SRED_SPLIT 4      // threads sharing one output element of the reduction (adjacent lanes): schur_reduce_body
 hipError_t launch_gen_rows(const NormalDims& nd, const AssemblyPlan& plan, const OpRef& R, const int32_t* Jp, hipStream_t stream);
+// (round 6) the planned rows as the last workgroups of assemble_factor_kernel's launch (assembly.hip)
+int    gen_ride_blocks(const AssemblyPlan& plan);
+size_t assemble_lds_bytes_with_gen(const NormalDims& nd, const AssemblyPlan& plan);
 hipError_t launch_gen_finalize(const NormalDims& nd, const AssemblyPlan& plan, const OpRef& R, hipStream_t stream);
 int launch_syrk(const NormalDims& nd, const BlockRanges& br, const int* skip, const FactorBuffers& F,
                 const FinalizeRide* ride, hipStream_t stream, const unsigned char** live /* out: the slots' flags, or NULL */);

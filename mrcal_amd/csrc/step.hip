@@ -367,14 +367,13 @@ hipError_t launch_step2_assemble(const Step2Args& a, bool initial, hipStream_t s
     {
         const int row0 = 2*P.W*P.H*P.Nobs_board;
         nframes_fused = br.frame_hi - br.frame_lo;
-        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, *a.plan)), dim3(256),
-                           assemble_lds_bytes(nd), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
-                           &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, assemble_row0(P, *a.plan), P.Nmeas, a.Jp, a.Ji);
-        // the planned rows of the evaluated point (their own launch: they ride on nothing; a trial without an
-        // evaluation skips them). Their sums are added after the Grams' (launch_step2_reduce)
+        // (round 6) the planned rows of the evaluated point are the launch's last workgroups (a trial without an evaluation
+        // skips them: elim_mode != 1). Their sums are added after the Grams' (launch_step2_reduce)
+        const int ngen = gen_ride_blocks(*a.plan);
+        hipLaunchKernelGGL(assemble_factor_kernel, dim3(nframes_fused + a.plan->Nchunks*assemble_chunk_slices(P) + assemble_row_blocks(P, *a.plan) + ngen), dim3(256),
+                           assemble_lds_bytes_with_gen(nd, *a.plan), stream, P, nd, br, a.ops, sel_eval, &a.ctl->ib, a.ctl, (const int*)NULL,
+                           &fl->elim_mode, 0, 1, 0.0, *a.plan, a.gram, *a.F, nframes_fused, assemble_row0(P, *a.plan), P.Nmeas, a.Jp, a.Ji, ngen);
         (void)row0;
-        const hipError_t e = launch_gen_rows(nd, *a.plan, OpRef{ a.ops, sel_eval, &fl->skip_asm }, a.Jp, stream);
-        if(e != hipSuccess) return e;
     }
     else
     {
