@@ -208,6 +208,25 @@ void regularization_row(const DeviceProblem& P, const OpRef& R,
     regularization_row_at<WITH_J,WITH_STRUCTURE>(P, b, opref_get(R).x, opref_get(R).Jv, rowptr, colidx, i);
 }
 
+// the workgroups of the prologue launch that clear a point's normal equations: izb of nblocks_zero
+// (round 6: array by array, 16 bytes a store. It was one element a store behind a chain of five compares; at
+//  BASELINE configuration 2 - 58 MB of A and Bt - that was what the prologue launch waited for, not the poses)
+__device__ __forceinline__
+void prologue_clear(const EvalBuffers& B, const OpDev& O, const int izb, const int nblocks_zero)
+{
+    const long long nthreads = (long long)nblocks_zero*PRO_T;
+    const long long t0 = (long long)izb*PRO_T + threadIdx.x;
+    double* const arr[5] = { O.A, O.Bt, O.D, O.g, O.scalars };
+#pragma unroll
+    for(int q = 0; q < 5; q++)
+    {
+        double* __restrict__ p = arr[q];
+        const long long n = B.zero_n[q], npairs = n >> 1;
+        const double2 z = make_double2(0.0, 0.0);
+        for(long long i = t0; i < npairs; i += nthreads) reinterpret_cast<double2*>(p)[i] = z;
+        if((n & 1) && t0 == 0) p[n - 1] = 0.0;
+    }
+}
 // Workgroups (PRO_T threads), in order: [pose records, PRO_LPO lanes per observation: joint_pose_record_lanes] [unpacking of the
 // intrinsics and the warp] [clearing of the normal equations, if asked for]
 // [regularization rows, one per thread: reg_mode 0 = x only, 1 = x and J, -1 = none]
@@ -240,20 +259,7 @@ void board_prologue_body(const DeviceProblem& P, const EvalBuffers& B, const BV&
     // launch of its own)
     if((int)blockIdx.x >= nblocks_obs + nblocks_unpack)
     {
-        // (round 6: array by array, 16 bytes a store. It was one element a store behind a chain of five compares; at
-        //  BASELINE configuration 2 - 58 MB of A and Bt - that was what the prologue launch waited for, not the poses)
-        const long long nthreads = (long long)nblocks_zero*PRO_T;
-        const long long t0 = ((long long)blockIdx.x - nblocks_obs - nblocks_unpack)*PRO_T + threadIdx.x;
-        double* const arr[5] = { O.A, O.Bt, O.D, O.g, O.scalars };
-#pragma unroll
-        for(int q = 0; q < 5; q++)
-        {
-            double* __restrict__ p = arr[q];
-            const long long n = B.zero_n[q], npairs = n >> 1;
-            const double2 z = make_double2(0.0, 0.0);
-            for(long long i = t0; i < npairs; i += nthreads) reinterpret_cast<double2*>(p)[i] = z;
-            if((n & 1) && t0 == 0) p[n - 1] = 0.0;
-        }
+        prologue_clear(B, O, (int)blockIdx.x - nblocks_obs - nblocks_unpack, nblocks_zero);
         return;
     }
     if((int)blockIdx.x >= nblocks_obs)
@@ -317,6 +323,21 @@ void board_prologue_kernel(DeviceProblem P, EvalBuffers B, int nblocks_unpack, i
     const OpRef R = B.R;
     if constexpr(CHOOSE)
     {
+        // (round 6) The workgroups that clear the trial point's normal equations need nothing of the choice but which point
+        // that is - ctl->ia, which the choice does not touch: they do not derive the step's scalars. They were 1024 of the
+        // launch's 1200 workgroups at the metric's size, each reading the 768 + 1000 partial sums of the quadratic form
+        // and the back-substitution after an accepted step: 38 MB out of the L2s, 20.4 us a launch against 14.7 after a
+        // rejected one (tools/exp/prologue_durations.py). A trial that evaluates nothing (a voided step, a step below
+        // the threshold) now has its buffers cleared all the same: nothing reads them
+        {
+            const int z0 = prologue_obs_blocks(P.Nobs_board) + nblocks_unpack;
+            if((int)blockIdx.x >= z0 && (int)blockIdx.x < z0 + nblocks_zero)
+            {
+                if(ca.ctl->done) return;
+                prologue_clear(B, ca.ops[ca.ctl->ia], (int)blockIdx.x - z0, nblocks_zero);
+                return;
+            }
+        }
         __shared__ double scratch[17*7];
         const ChooseOut c = dogleg_choose_scalars(ca, scratch);
         const int first = prologue_obs_blocks(P.Nobs_board) + nblocks_unpack + nblocks_zero + nblocks_reg;
