@@ -863,6 +863,14 @@ void assemble_finalize_kernel(int npos, NormalDims nd, const OpDev* __restrict__
     if(skip != NULL && *skip) return;
     assemble_finalize(npos, nd, ops[sel ? *sel : 0], plan, blockIdx.x*blockDim.x + threadIdx.x);
 }
+// the planned rows' sums: a wave a destination
+__global__ __launch_bounds__(64)
+void assemble_finalize_gen_kernel(int npos, NormalDims nd, const OpDev* __restrict__ ops, const int* __restrict__ sel,
+                                  const int* __restrict__ skip, AssemblyPlan plan)
+{
+    if(skip != NULL && *skip) return;
+    assemble_finalize<FIN_LANES_GEN>(npos, nd, ops[sel ? *sel : 0], plan, blockIdx.x*blockDim.x + threadIdx.x);
+}
 
 // A, Bt, D, g and the scalars of an operating point, zeroed in one launch
 __global__ __launch_bounds__(256)
@@ -909,7 +917,7 @@ hipError_t launch_gen_finalize(const NormalDims& nd, const AssemblyPlan& plan, c
     AssemblyPlan gp = plan;
     gp.Ndest = G.Ndest; gp.dest_id = G.dest_id; gp.dest_begin = G.dest_begin; gp.dest_src = G.dest_src;
     gp.pair_chunk_begin = G.group_chunk_begin; gp.chunk_part = G.part; gp.row_part_n = 0;
-    hipLaunchKernelGGL(assemble_finalize_kernel, dim3((G.Ndest*FIN_LANES + 63)/64), dim3(64), 0, stream,
+    hipLaunchKernelGGL(assemble_finalize_gen_kernel, dim3((G.Ndest*FIN_LANES_GEN + 63)/64), dim3(64), 0, stream,
                        G.stride, nd, R.ops, R.sel, R.skip, gp);
     return hipGetLastError();
 }

@@ -37,12 +37,18 @@ __device__ __forceinline__ void E_to_block(const NormalDims& nd, int e, int* blk
 // points) stays. |x|^2 also takes those rows' per-workgroup partials, in order
 // 16 lanes (one DPP row) per destination: the lanes split the chunks of each source,
 // then add up in a fixed order
+// (round 6: LANES a parameter - the planned rows' destinations are few and their sources' chunks many (configuration 4: 343
+//  destinations, up to three groups of 87 chunks each): with a whole wave a destination their finalize is one trip to
+//  memory a source instead of three, 10.6 -> see LEDGER R6.19. The Grams' plan keeps its 16 - and its bits)
 #define FIN_LANES 16
+#define FIN_LANES_GEN 64
+template<int LANES = FIN_LANES>
 __device__ __forceinline__
 void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const AssemblyPlan& plan,
-                       int gid /* global thread index: destination gid/16, lane gid%16 */)
+                       int gid /* global thread index: destination gid/LANES, lane gid%LANES */)
 {
-    const int k = gid / FIN_LANES, j = gid % FIN_LANES;
+    constexpr int FIN_L = LANES;
+    const int k = gid / FIN_L, j = gid % FIN_L;
     const bool live = k < plan.Ndest;
     const int kc = live ? k : 0;
     const int d  = plan.dest_id[kc];
@@ -56,16 +62,16 @@ void assemble_finalize(int npos, const NormalDims& nd, const OpDev& O, const Ass
         const double* __restrict__ cp = plan.chunk_part + pos;
         double a0 = 0.0, a1 = 0.0;
         int c = c0 + j;
-        for(; c + FIN_LANES < c1; c += 2*FIN_LANES)
+        for(; c + FIN_L < c1; c += 2*FIN_L)
         {
-            const double v0 = cp[(size_t)c*npos], v1 = cp[(size_t)(c + FIN_LANES)*npos];
+            const double v0 = cp[(size_t)c*npos], v1 = cp[(size_t)(c + FIN_L)*npos];
             a0 += v0; a1 += v1;
         }
         if(c < c1) a0 += cp[(size_t)c*npos];
         acc += a0 + a1;
     }
-    // (all 16 lanes of the row take part, whether the destination is live or not)
-    for(int off = FIN_LANES/2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    // (all the lanes of the row take part, whether the destination is live or not)
+    for(int off = FIN_L/2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if(!live || j != 0) return;
     const int nA = nd.Nc*nd.Nc;
     if(d < nA)              O.A[d] += acc;
