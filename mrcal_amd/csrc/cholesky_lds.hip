@@ -3,6 +3,7 @@
 #include "solver_device.hpp"
 #include "chol_diag16.hpp"
 #include "solver_kernel_decls.hpp"
+#include "step_device.hpp"
 
 namespace mrcal_amd {
 
@@ -312,6 +313,31 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
     schur_cholesky_solve_body<FINISH>(n, skip, keep_factor, S, r, status, sd);
 }
 
+// (round 6) The quadratic form of a new current point - g^T N g and |g_E|^2, per-workgroup partials for the next choice -
+// never needed the factorization: its workgroups rode in the launch BEHIND it, beside the back-substitution's, since
+// round 3. On a single GPU (the end of the trial - which point is current, is it new - decided in the reduction's launch)
+// they are workgroups of the factorization's launch instead: independent of its one workgroup, nothing to wait for, done
+// long before it; the launch behind is the back-substitution alone. Four of step2_backsub_quadform_kernel's workgroups
+// of 256 to one of 1024 here (quadform_body counts the quarters): the same partials, the same bits. Every workgroup
+// reserves the factorization's LDS (the launch's one size): a workgroup a CU at 140 variables - 192 of them
+__global__ __launch_bounds__(1024)
+void step2_chol_quadform_kernel(int n, int* __restrict__ status, Step2Dev sd, NormalDims nd,
+                                double* __restrict__ S, double* __restrict__ r, double* __restrict__ qf_part, int nqf)
+{
+    if(blockIdx.x == 0)
+    {
+        schur_cholesky_solve_body<2>(n, (const int*)&sd.fl->skip_chol, 0, S, r, status, sd);
+        return;
+    }
+    const SolverCtl* __restrict__ ctl = sd.ctl;
+    if(!ctl->derive) return;
+    const OpDev& O = sd.ops[ctl->ib];
+    const int qb = 4*((int)blockIdx.x - 1) + (int)(threadIdx.x >> 8);
+    // (a quarter past the last row: its waves clamp their rows and add nothing - but every thread is at the barrier)
+    const double mine = quadform_body(nd, O, O.g, qb, true, (const unsigned*)NULL, 0);
+    if((threadIdx.x & 255) < 3 && qb < nqf) qf_part[4*qb + (threadIdx.x & 255)] = mine;
+}
+
 // The same in place in global memory, row-major, one workgroup: the plain
 // right-looking blocked algorithm. Only a fallback for callers without the
 // panel workspace; camera blocks that do not fit the LDS normally go through
@@ -397,6 +423,13 @@ hipError_t launch_cholesky_lds(int finish, int n, const int* skip, int keep_fact
     case 2:  hipLaunchKernelGGL(schur_cholesky_solve_kernel<2>, g, b, lds, stream, n, skip, keep_factor, S, r, status, sd); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+hipError_t launch_cholesky_lds_quadform(int n, const NormalDims& nd, const FactorBuffers& F, const Step2Dev& sd,
+                                        double* qf_part, int nqf, hipStream_t stream)
+{
+    hipLaunchKernelGGL(step2_chol_quadform_kernel, dim3(1 + (nqf + 3)/4), dim3(1024), chol_lds_bytes(n), stream,
+                       n, F.status, sd, nd, F.S, F.r, qf_part, nqf);
     return hipGetLastError();
 }
 hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, int* status, hipStream_t stream)

@@ -117,5 +117,8 @@ hipError_t launch_nd_plans_off(const OpDev* ops, int Nc, hipStream_t stream);
 hipError_t launch_cholesky_lds(int finish, int n, const int* skip, int keep_factor, double* S, double* r, int* status,
                                const Step2Dev& sd, hipStream_t stream);
 hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, int* status, hipStream_t stream);
+// (round 6) finish = 2 with the quadratic form's workgroups in the launch (cholesky_lds.hip step2_chol_quadform_kernel)
+hipError_t launch_cholesky_lds_quadform(int n, const NormalDims& nd, const FactorBuffers& F, const Step2Dev& sd,
+                                        double* qf_part, int nqf, hipStream_t stream);
 
 } // namespace mrcal_amd

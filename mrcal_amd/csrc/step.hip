@@ -476,13 +476,15 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
     Step2Dev sd;
     sd.nd = nd; sd.ops = a.ops; sd.ctl = a.ctl; sd.fl = fl; sd.initial = initial ? 1 : 0;
     sd.comm1_tail = F.r + nd.Nc;
+    bool qf_rode = false;
     {
         const int n = nd.Nc;
         // (round 5, single GPU: the end-of-trial logic has run in the reduction's launch - step2_finish_rides())
         const bool finish_done = step2_finish_rides(a);
         if(chol_fits_lds(n))
         {
-            if(finish_done) launch_cholesky_lds(2, n, (const int*)&fl->skip_chol, 0, F.S, F.r, F.status, sd, stream);
+            // (round 6, single GPU: the quadratic form's workgroups in the factorization's launch - they never needed it)
+            if(finish_done) { launch_cholesky_lds_quadform(n, nd, F, sd, a.plan->qf_part, quadform_blocks(nd), stream); qf_rode = true; }
             else            launch_cholesky_lds(1, n, (const int*)NULL, 0, F.S, F.r, F.status, sd, stream);
         }
         else
@@ -518,7 +520,7 @@ hipError_t launch_step2_factor(const Step2Args& a, bool initial, hipStream_t str
         }
     }
     const int nbs = (br.count() + 3)/4, nqf = quadform_blocks(nd);
-    hipLaunchKernelGGL(step2_backsub_quadform_kernel, dim3(nbs + 1 + nqf), dim3(256), 0, stream,
+    hipLaunchKernelGGL(step2_backsub_quadform_kernel, dim3(nbs + 1 + (qf_rode ? 0 : nqf)), dim3(256), 0, stream,
                        nd, br, a.ops, a.ctl, fl, F.Wt, F.LD, F.y, F.r, a.plan->dots_part, a.plan->qf_part, nbs, a.snap,
                        (nd.Nc > SYRK_STRIP_FROM) ? F.occ : (const unsigned*)NULL, occ_words(nd));
     if(a.comm2 != NULL)

@@ -445,3 +445,28 @@ def test_boards_and_triangulated_in_one_problem(amd, ref_api, lensmodel, Npoints
     # and the geometry is the truth's up to the noise (the boards fix the scale)
     assert np.abs(oa["rt_cam_ref"][:,:3] - truth["rt_cam_ref"][:,:3]).max() < 5e-3
     assert np.abs(oa["rt_cam_ref"][:,3:] - truth["rt_cam_ref"][:,3:]).max() < (5e-2 if Nboard_frames < 50 else 5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jacobian_stream", (True, False))
+def test_the_solvers_one_launch_writes_the_evaluations_bits(amd, jacobian_stream):
+    """Round 6: inside a solve the board observations and the triangulated pairs of a problem that has both are ONE
+    launch (kernels.hip board_tri_kernel: the pairs' workgroups in front of the observations'), with the Grams; a
+    host-driven evaluation - optimizer_callback()'s - is board_kernel without the Grams and triangulated_kernel behind
+    it. The same device functions, -ffp-contract=on: x and the CSR values the solver's launches left at its current
+    point are, to the last bit, what an evaluation at that state gives - with the solve's Jacobian stream on, and off
+    (the pairs' rows are streamed either way; the boards' are made on demand)"""
+    from mrcal_amd.resident import Problem
+    oi, _ = sfm_problem(lensmodel="LENSMODEL_OPENCV4", Ncam=4, Npoints=2500, seed=9, noise=0.3, Nboard_frames=50)
+    with Problem(**copy_inputs(oi)) as p:
+        p.set_jacobian_stream(jacobian_stream)
+        n, _ = p.run_steps(4)
+        assert n == 4
+        b, x1, J1 = p.b_packed(), p.x(), p.J()
+        p.set_b_packed(b)
+        p.evaluate(with_jacobian=True)
+        x2, J2 = p.x(), p.J()
+    assert np.array_equal(J1.indptr, J2.indptr) and np.array_equal(J1.indices, J2.indices)
+    assert np.array_equal(x1, x2)
+    assert np.array_equal(J1.data, J2.data)
+    assert np.abs(J1.data).max() > 0 and np.isfinite(J1.data).all()
