@@ -261,6 +261,9 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
         }
         else
         {
+            // (the last, partial panel. Its reads asked for together - from rows that exist, the terms past the panel's end
+            //  left out of the same chain of multiply-adds - measured: this panel 4.6k -> 5.1k cycles and the full panels'
+            //  chain behind it 1.6k -> 2.2k each; taken out again)
             double acc = 0.0;
             for(int c = 0; c < jb; c++) acc += rowptr(j0+c)[i]*z[j0+c];
             z[i] -= acc;
@@ -275,14 +278,51 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
     if(wave == 0 && npanels > 0) back_diag(npanels-1);
     __syncthreads();
     CTS();
+    // (round 6) Wave 0's chain through the full panels stays in REGISTERS: d_p, which lanes 0..15 have just made, reaches
+    // the sixteen dot products that update panel p-1's entries by v_readlane instead of through an LDS write and read,
+    // and so do the updated entries on their way into X_{p-1}'s product. The same products and sums in the same order
+    // as back_update() / back_diag() - the same bits -; a panel of the sweep was 2.2k cycles, four LDS round trips of
+    // which two were the wave talking to itself (CHOL_TS: 23.7k cycles for the sweep of 140 variables)
+    auto back_chain = [&](int p, double& dcur) __attribute__((always_inline))
+    {
+        const int j0 = p*CHOL_PB, jm = j0 - CHOL_PB, l16 = (lane < CHOL_PB) ? lane : 0;
+        const int i = jm + l16;
+        const double* __restrict__ X = Xs + (p - 1)*CHOL_PB*CHOL_XLD + l16*CHOL_XLD;
+        double lv[CHOL_PB], xv[CHOL_PB];
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c++) { lv[c] = rowptr(j0+c)[i]; xv[c] = X[c]; }
+        const double zi = z[i];
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for(int c = 0; c < CHOL_PB; c += 2) { acc0 += lv[c]*readlane_f64(dcur, c); acc1 += lv[c+1]*readlane_f64(dcur, c+1); }
+        const double w = zi - (acc0 + acc1);
+        double b0 = 0.0, b1 = 0.0;
+#pragma unroll
+        for(int k = 0; k < CHOL_PB; k += 2)
+        {
+            const double w0 = readlane_f64(w, k), w1 = readlane_f64(w, k+1);
+            b0 += (k   >= lane) ? xv[k]  *w0 : 0.0;
+            b1 += (k+1 >= lane) ? xv[k+1]*w1 : 0.0;
+        }
+        dcur = b0 + b1;
+        if(lane < CHOL_PB) z[jm + lane] = dcur;
+    };
+    double dcur = 0.0;
+    bool have_dcur = false;
     for(int p = npanels-1; p >= 1; p--)
     {
         const int j0 = p*CHOL_PB;
         const int jb = min(CHOL_PB, n - j0);
         if(wave == 0)
         {
-            if(lane < CHOL_PB) back_update(j0 - CHOL_PB + lane, j0, jb);     // panel p-1 is full
-            back_diag(p - 1);
+            if(have_dcur && jb == CHOL_PB) back_chain(p, dcur);
+            else
+            {
+                if(lane < CHOL_PB) back_update(j0 - CHOL_PB + lane, j0, jb);     // panel p-1 is full
+                back_diag(p - 1);
+                dcur = z[j0 - CHOL_PB + ((lane < CHOL_PB) ? lane : 0)];           // (the wave's own writes: in order)
+                have_dcur = true;
+            }
         }
         else
             for(int i = t - 64; i < j0 - CHOL_PB; i += nt - 64) back_update(i, j0, jb);
