@@ -37,7 +37,7 @@ template<int FINISH>
 __device__ __forceinline__
 void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_factor,
                                double* __restrict__ S, double* __restrict__ r,
-                               int* __restrict__ status, const Step2Dev& sd)
+                               int* __restrict__ status, const Step2Dev& sd, const double* __restrict__ Spk = NULL)
 {
     if(skip != NULL && *skip) return;
     if constexpr(FINISH == 1) { if(!step2_finish(sd, status)) return; }
@@ -68,6 +68,23 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
     // lane pass, and asks for ALL of it before it stores anything: S was written
     // by other CUs a launch ago and every load is a trip across the chip (three
     // batches of 12 loads were three such trips: 3.9 us of the kernel's 48)
+    // (round 6: where the reduction left a PACKED copy - this kernel's own layout - the triangle is one run of memory:
+    //  a tenth of a load per entry and thread, all of them asked for at once, instead of 28 loads a thread of which
+    //  half fetch what lies above the diagonal: CHOL_TS, 11.5k cycles of the kernel's 112k)
+    if(Spk != NULL)
+    {
+        const int ntri = (n*(n + 1)) >> 1;
+        constexpr int UP = 16;
+        for(int i0 = t; i0 < ntri; i0 += UP*nt)
+        {
+            double v[UP];
+#pragma unroll
+            for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt; v[u] = Spk[idx < ntri ? idx : 0]; }
+#pragma unroll
+            for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt; if(idx < ntri) Mp[idx] = v[u]; }
+        }
+    }
+    else
     {
         double v[13][4];
 #pragma unroll
@@ -362,11 +379,12 @@ void schur_cholesky_solve_kernel(int n, const int* __restrict__ skip, int keep_f
 // reserves the factorization's LDS (the launch's one size): a workgroup a CU at 140 variables - 192 of them
 __global__ __launch_bounds__(1024)
 void step2_chol_quadform_kernel(int n, int* __restrict__ status, Step2Dev sd, NormalDims nd,
-                                double* __restrict__ S, double* __restrict__ r, double* __restrict__ qf_part, int nqf)
+                                double* __restrict__ S, double* __restrict__ r, double* __restrict__ qf_part, int nqf,
+                                const double* __restrict__ Spk)
 {
     if(blockIdx.x == 0)
     {
-        schur_cholesky_solve_body<2>(n, (const int*)&sd.fl->skip_chol, 0, S, r, status, sd);
+        schur_cholesky_solve_body<2>(n, (const int*)&sd.fl->skip_chol, 0, S, r, status, sd, Spk);
         return;
     }
     const SolverCtl* __restrict__ ctl = sd.ctl;
@@ -469,7 +487,7 @@ hipError_t launch_cholesky_lds_quadform(int n, const NormalDims& nd, const Facto
                                         double* qf_part, int nqf, hipStream_t stream)
 {
     hipLaunchKernelGGL(step2_chol_quadform_kernel, dim3(1 + (nqf + 3)/4), dim3(1024), chol_lds_bytes(n), stream,
-                       n, F.status, sd, nd, F.S, F.r, qf_part, nqf);
+                       n, F.status, sd, nd, F.S, F.r, qf_part, nqf, (const double*)factor_S_packed(F, n));
     return hipGetLastError();
 }
 hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, int* status, hipStream_t stream)

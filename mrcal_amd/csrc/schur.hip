@@ -189,7 +189,9 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
                        double* __restrict__ iso = NULL /* given: S goes out COMPACTED by O.cperm (LcholCompact): the coupled
                                                          variables' n' x n' matrix with its rhs as row n', the isolated pairs' blocks here */,
                        int* __restrict__ err = NULL /* with iso: set to 3 if an entry that the compaction has no place for is not zero */,
-                       double* __restrict__ ndMA = NULL, double* __restrict__ ndMB = NULL /* with iso and an active plan in O.ndp: the two sides' matrices (lchol_nd_*) */)
+                       double* __restrict__ ndMA = NULL, double* __restrict__ ndMB = NULL /* with iso and an active plan in O.ndp: the two sides' matrices (lchol_nd_*) */,
+                       double* __restrict__ Spk = NULL /* without iso: a second, PACKED copy of the lower triangle ([j(j+1)/2 + i], the one-workgroup
+                                                          Cholesky's own layout: what it loads is then 78 KB in a row instead of 140 pieces of rows) */)
 {
     // (the dissection: the coupled variables go to three matrices by their classes - the separator's to S)
     const bool ndact = (iso != NULL && ndMA != NULL && O.ndp != NULL && O.ndp[NDH_ACTIVE] != 0);
@@ -262,7 +264,7 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
         if(i < nd.Nc && j < nd.Nc && j >= i)
         {
             const double v = O.A[(size_t)j*nd.Nc + i] + ((i==j) ? lambda : 0.0) - acc;
-            if(iso == NULL) S[(size_t)j*nd.Nc + i] = v;
+            if(iso == NULL) { S[(size_t)j*nd.Nc + i] = v; if(Spk != NULL) Spk[(((size_t)j*(j + 1)) >> 1) + i] = v; }
             else
             {
                 const int* __restrict__ ip = O.cperm + nd.Nc;
@@ -771,7 +773,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
                          const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso,
                          int* __restrict__ err /* SolverCtl::error */,
                          double* __restrict__ ndMA, double* __restrict__ ndMB, int* __restrict__ ndp_cur, int nfill /* workgroups behind the last */,
-                         int ride_finish, Step2Dev sd)
+                         int ride_finish, Step2Dev sd, double* __restrict__ Spk)
 {
     if(fl->skip_elim)
     {
@@ -820,7 +822,7 @@ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops, const Sol
         // sum over the ranks (step2_finish unpacked it): the leader alone adds it
         const int add_g = (fl->elim_mode == 1) ? 1 : is_leader;
         schur_reduce_body(nd, O, is_leader ? ctl->lambda : 0.0, add_g, nslots, Spart, S, r, blockIdx.x, live,
-                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL, err, ndMA, ndMB);
+                          (cperm_cur != NULL && O.cperm != NULL) ? iso : (double*)NULL, err, ndMA, ndMB, Spk);
         return;
     }
     // (the permutation this reduction went by, for the factorization and the solve behind it: which of the two

@@ -35,7 +35,7 @@ __global__ void step2_reduce_kernel(NormalDims nd, const OpDev* __restrict__ ops
                          const unsigned char* __restrict__ live, int* __restrict__ cperm_cur, double* __restrict__ iso,
                          int* __restrict__ err /* SolverCtl::error */,
                          double* __restrict__ ndMA, double* __restrict__ ndMB, int* __restrict__ ndp_cur, int nfill /* workgroups behind the last */,
-                         int ride_finish, Step2Dev sd);
+                         int ride_finish, Step2Dev sd, double* __restrict__ Spk /* a packed copy of S's lower triangle, or NULL */);
 __global__ void backsub_kernel(NormalDims nd, BlockRanges br, OpRef R, const int* __restrict__ skip_also,
                     const double* __restrict__ Wt, const double* __restrict__ LD,
                     const double* __restrict__ y, const double* __restrict__ ds);
@@ -120,5 +120,8 @@ hipError_t launch_cholesky_global(int n, const int* skip, double* S, double* r, 
 // (round 6) finish = 2 with the quadratic form's workgroups in the launch (cholesky_lds.hip step2_chol_quadform_kernel)
 hipError_t launch_cholesky_lds_quadform(int n, const NormalDims& nd, const FactorBuffers& F, const Step2Dev& sd,
                                         double* qf_part, int nqf, hipStream_t stream);
+// where the reduction leaves the packed copy of S's lower triangle for it (behind [S | r | g_S | 2 | 64] in F.S's allocation)
+inline double* factor_S_packed(const FactorBuffers& F, int Nc) { return F.S + (size_t)Nc*Nc + 2*(size_t)Nc + 2 + 64; }
+// (problem.cpp allocates Nc (Nc + 1)/2 + 2 doubles there)
 
 } // namespace mrcal_amd

@@ -461,7 +461,9 @@ hipError_t launch_step2_reduce(const Step2Args& a, hipStream_t stream, int initi
     hipLaunchKernelGGL(step2_reduce_kernel, dim3(nred + 1 + nfill), dim3(256), 0, stream,
                        nd, a.ops, a.ctl, fl, a.is_leader ? 1 : 0, nred, nslots, F.Spart, F.S, F.r, F.status, live, F.cperm_cur, F.iso, &a.ctl->error,
                        nd_launches ? F.ndMA : (double*)NULL, nd_launches ? F.ndMB : (double*)NULL, nd_on ? F.ndp_cur : (int*)NULL, nfill,
-                       rides ? 1 : 0, sd);
+                       rides ? 1 : 0, sd,
+                       // (a packed copy of S for the one-workgroup Cholesky's launch behind this one - launch_cholesky_lds_quadform())
+                       (rides && chol_fits_lds(nd.Nc)) ? factor_S_packed(F, nd.Nc) : (double*)NULL);
     return hipGetLastError();
 }
 int64_t step2_comm1_doubles(const NormalDims& nd) { return (int64_t)nd.Nc*nd.Nc + 2*nd.Nc + 2; }
