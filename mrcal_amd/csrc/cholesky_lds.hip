@@ -73,7 +73,7 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
     //  half fetch what lies above the diagonal: CHOL_TS, 11.5k cycles of the kernel's 112k)
     if(Spk != NULL)
     {
-        const int ntri = (n*(n + 1)) >> 1;
+        const int ntri = ((n*(n + 1)) >> 1) + n;        // (with the right-hand side, row n)
         constexpr int UP = 16;
         for(int i0 = t; i0 < ntri; i0 += UP*nt)
         {
@@ -107,7 +107,7 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
                     if(i < n && j <= i) rowptr(i)[j] = v[a][b];
                 }
     }
-    for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
+    if(Spk == NULL) for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
     __syncthreads();
 
     // (a) diagonal block of panel p, wave 0: chol_factor_diag16() above. L back into the triangle

@@ -393,7 +393,7 @@ bool problem_prepare_solver(mrcal_amd_problem* P)
     // S and r contiguous: one all-reduce moves both
     // [S | r | g_S | |x|^2 | status]: comm1 of the sharded step (step2_comm1_doubles())
     // (round 6: + a packed copy of the lower triangle behind them, for the one-workgroup Cholesky: factor_S_packed())
-    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2 + 64 + ((((size_t)nd.Nc*(nd.Nc + 1)) >> 1) + 2));
+    ok = ok && dev_alloc(&P->F.S,  (size_t)nd.Nc*nd.Nc + 2*nd.Nc + 2 + 64 + ((((size_t)nd.Nc*(nd.Nc + 1)) >> 1) + nd.Nc + 2));
     P->F.r = ok ? P->F.S + (size_t)nd.Nc*nd.Nc : NULL;
     ok = ok && dev_alloc(&P->F.status, 1);
     ok = ok && dev_alloc(&P->d_step,   (size_t)nd.Nstate);

@@ -304,7 +304,7 @@ void schur_reduce_body(const NormalDims& nd, const OpDev& O, double lambda, int 
         if(i < nd.Nc)
         {
             const double v = (add_g ? O.g[S_to_state(nd, i)] : 0.0) - acc;
-            if(iso == NULL) r[i] = v;
+            if(iso == NULL) { r[i] = v; if(Spk != NULL) Spk[(((size_t)nd.Nc*(nd.Nc + 1)) >> 1) + i] = v; }      // (the rhs: row Nc of the packed copy)
             else
             {
                 const int n1 = O.cperm[2*nd.Nc], pi = O.cperm[nd.Nc + i];

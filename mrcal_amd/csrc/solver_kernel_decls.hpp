@@ -122,6 +122,6 @@ hipError_t launch_cholesky_lds_quadform(int n, const NormalDims& nd, const Facto
                                         double* qf_part, int nqf, hipStream_t stream);
 // where the reduction leaves the packed copy of S's lower triangle for it (behind [S | r | g_S | 2 | 64] in F.S's allocation)
 inline double* factor_S_packed(const FactorBuffers& F, int Nc) { return F.S + (size_t)Nc*Nc + 2*(size_t)Nc + 2 + 64; }
-// (problem.cpp allocates Nc (Nc + 1)/2 + 2 doubles there)
+// (problem.cpp allocates Nc (Nc + 1)/2 + Nc + 2 doubles there: the triangle and, as its row Nc, the right-hand side)
 
 } // namespace mrcal_amd
