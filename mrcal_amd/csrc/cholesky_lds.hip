@@ -74,14 +74,31 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
     if(Spk != NULL)
     {
         const int ntri = ((n*(n + 1)) >> 1) + n;        // (with the right-hand side, row n)
-        constexpr int UP = 16;
-        for(int i0 = t; i0 < ntri; i0 += UP*nt)
+        // Wave 0 takes the first diagonal block's rows (136 entries) and nothing else, and goes on to factor that block
+        // - it reads what it wrote itself - while the other fifteen waves bring the rest in: no barrier before the loop's
+        // own at the end of its first pass (p = -1). The first block's chain started 8k cycles into the kernel, behind
+        // everybody's loads; it needs a fiftieth of them
+        const int n16 = min(n, CHOL_PB), nfirst = (n16*(n16 + 1)) >> 1;
+        if(wave_u == 0)
         {
-            double v[UP];
+            double v[3];
 #pragma unroll
-            for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt; v[u] = Spk[idx < ntri ? idx : 0]; }
+            for(int u = 0; u < 3; u++) { const int idx = lane + 64*u; v[u] = Spk[idx < nfirst ? idx : 0]; }
 #pragma unroll
-            for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt; if(idx < ntri) Mp[idx] = v[u]; }
+            for(int u = 0; u < 3; u++) { const int idx = lane + 64*u; if(idx < nfirst) Mp[idx] = v[u]; }
+        }
+        else
+        {
+            constexpr int UP = 16;
+            const int nt1 = nt - 64;
+            for(int i0 = nfirst + (t - 64); i0 < ntri; i0 += UP*nt1)
+            {
+                double v[UP];
+#pragma unroll
+                for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt1; v[u] = Spk[idx < ntri ? idx : 0]; }
+#pragma unroll
+                for(int u = 0; u < UP; u++) { const int idx = i0 + u*nt1; if(idx < ntri) Mp[idx] = v[u]; }
+            }
         }
     }
     else
@@ -107,8 +124,11 @@ void schur_cholesky_solve_body(int n, const int* __restrict__ skip, int keep_fac
                     if(i < n && j <= i) rowptr(i)[j] = v[a][b];
                 }
     }
-    if(Spk == NULL) for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
-    __syncthreads();
+    if(Spk == NULL)
+    {
+        for(int j = t; j < n; j += nt) rowptr(n)[j] = r[j];
+        __syncthreads();
+    }
 
     // (a) diagonal block of panel p, wave 0: chol_factor_diag16() above. L back into the triangle
     // (entries up to the diagonal; the rest into a per-lane sink), X = L_pp^-T into its block
